@@ -1,0 +1,438 @@
+// extern "C" surface of libgnark_amd.so (include/gnark_amd.h): context, buffers, MSM, NTT, group helpers,
+// profiling.  Groth16 lives in groth16.hip.  Every entry point selects the context's device itself and takes the
+// context mutex (one proof at a time per device, as icicle.go:821-823).
+#include <stdarg.h>
+
+#include "hostops.cuh"
+
+namespace ga {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+const char* get_error() { return g_err; }
+
+int Ctx::scratch_get(const char* key, size_t bytes, void** out) {
+    auto it = scratch.find(key);
+    if (it != scratch.end() && it->second.second >= bytes) {
+        *out = it->second.first;
+        return GA_OK;
+    }
+    if (it != scratch.end()) {
+        hipFree(it->second.first);
+        scratch.erase(it);
+    }
+    void* p = nullptr;
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+        set_error("device scratch '%s': hipMalloc(%zu) failed: %s", key, want, hipGetErrorString(e));
+        return GA_ERR_NOMEM;
+    }
+    scratch[key] = std::make_pair(p, want);
+    *out = p;
+    return GA_OK;
+}
+
+void Ctx::scratch_free_all() {
+    for (auto& kv : scratch) hipFree(kv.second.first);
+    scratch.clear();
+}
+
+struct Lock {
+    std::lock_guard<std::mutex> g;
+    explicit Lock(Ctx* c) : g(c->mu) { hipSetDevice(c->device); }
+};
+
+// Bring inputs to the device when they are host pointers.
+struct Staged {
+    Ctx* ctx;
+    const void* dev = nullptr;
+    void* owned = nullptr;
+    int stage(const void* p, size_t bytes, bool on_device) {
+        if (on_device || bytes == 0) {
+            dev = p;
+            return GA_OK;
+        }
+        hipError_t e = hipMalloc(&owned, bytes);
+        if (e != hipSuccess) {
+            set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+            return GA_ERR_NOMEM;
+        }
+        GA_HIP_CHECK(hipMemcpyAsync(owned, p, bytes, hipMemcpyHostToDevice, ctx->stream));
+        GA_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // host memory must not be referenced after return
+        dev = owned;
+        return GA_OK;
+    }
+    ~Staged() {
+        if (owned) hipFree(owned);
+    }
+};
+
+template <class C, int G>
+static int msm_impl(Ctx* ctx, const void* bases, const void* scalars, size_t n, unsigned flags, int win_lo, int win_hi,
+                    void* out, int* c_out, int* nwin_out, bool want_windows) {
+    typedef typename GroupField<C, G>::F F;
+    int c, nwin;
+    GA_CHECK(msm_plan<C>(G, n, &c, &nwin));
+    if (c_out) *c_out = c;
+    if (nwin_out) *nwin_out = nwin;
+    if (win_hi < 0) win_hi = nwin;
+    if (win_lo < 0 || win_hi > nwin || win_lo >= win_hi) {
+        set_error("msm: window range [%d,%d) outside [0,%d)", win_lo, win_hi, nwin);
+        return GA_ERR_INVALID;
+    }
+    Staged sb{ctx}, ss{ctx};
+    GA_CHECK(sb.stage(bases, n * sizeof(Affine<F>), flags & GA_BASES_ON_DEVICE));
+    GA_CHECK(ss.stage(scalars, n * 32, flags & GA_SCALARS_ON_DEVICE));
+    std::vector<XYZZ<F>> W(win_hi - win_lo);
+    GA_CHECK((msm_windows_device<C, G>(ctx, sb.dev, ss.dev, n, (flags & GA_SCALARS_MONTGOMERY) != 0, c, win_lo, win_hi, W.data())));
+    if (want_windows) {
+        char* o = reinterpret_cast<char*>(out);
+        for (size_t w = 0; w < W.size(); w++) host_store_jac<F>(o + w * sizeof(Jac<F>), W[w]);
+    } else {
+        host_store_jac<F>(out, host_horner(W.data(), (int)W.size(), c));
+    }
+    return GA_OK;
+}
+
+}  // namespace ga
+
+using namespace ga;
+
+#define GA_DISPATCH_GROUP(group, ...)                           \
+    switch (group) {                                            \
+        case GA_G1: {                                           \
+            constexpr int G = GA_G1;                            \
+            __VA_ARGS__;                                        \
+        } break;                                                \
+        case GA_G2: {                                           \
+            constexpr int G = GA_G2;                            \
+            __VA_ARGS__;                                        \
+        } break;                                                \
+        default:                                                \
+            set_error("unknown group id %d", (int)(group));     \
+            return GA_ERR_INVALID;                              \
+    }
+
+extern "C" {
+
+const char* ga_last_error(void) { return get_error(); }
+const char* ga_version(void) { return "gnark_amd 0.1 (gfx950; Groth16/PLONK prover kernels: MSM G1/G2, NTT; BN254, BLS12-381)"; }
+
+int ga_device_count(int* count) {
+    GA_HIP_CHECK(hipGetDeviceCount(count));
+    return GA_OK;
+}
+
+int ga_ctx_create(int device, ga_ctx** out) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        set_error("no HIP device available (%s); libgnark_amd has no CPU fallback", e == hipSuccess ? "count=0" : hipGetErrorString(e));
+        return GA_ERR_HIP;
+    }
+    if (device < 0 || device >= count) {
+        set_error("device %d out of range (have %d)", device, count);
+        return GA_ERR_INVALID;
+    }
+    GA_HIP_CHECK(hipSetDevice(device));
+    Ctx* c = new Ctx();
+    c->device = device;
+    GA_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    *out = reinterpret_cast<ga_ctx*>(c);
+    return GA_OK;
+}
+
+void ga_ctx_destroy(ga_ctx* h) {
+    if (!h) return;
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    c->scratch_free_all();
+    for (auto& s : c->stages) {
+        hipEventDestroy(s.a);
+        hipEventDestroy(s.b);
+    }
+    hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int ga_device_info(ga_ctx* h, char* name, size_t name_len, uint64_t* total_bytes, uint64_t* free_bytes) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    Lock l(c);
+    hipDeviceProp_t p;
+    GA_HIP_CHECK(hipGetDeviceProperties(&p, c->device));
+    if (name && name_len) snprintf(name, name_len, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+    size_t f = 0, t = 0;
+    GA_HIP_CHECK(hipMemGetInfo(&f, &t));
+    if (total_bytes) *total_bytes = t;
+    if (free_bytes) *free_bytes = f;
+    return GA_OK;
+}
+
+int ga_malloc(ga_ctx* h, size_t bytes, void** dptr) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    Lock l(c);
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 16);
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return GA_ERR_NOMEM;
+    }
+    return GA_OK;
+}
+
+int ga_free(ga_ctx* h, void* dptr) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    Lock l(c);
+    GA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    GA_HIP_CHECK(hipFree(dptr));
+    return GA_OK;
+}
+
+int ga_copy_to_device(ga_ctx* h, void* dst, const void* src, size_t bytes) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    Lock l(c);
+    GA_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    GA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return GA_OK;
+}
+
+int ga_copy_to_host(ga_ctx* h, void* dst, const void* src, size_t bytes) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    Lock l(c);
+    GA_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    GA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return GA_OK;
+}
+
+int ga_sync(ga_ctx* h) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    Lock l(c);
+    GA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return GA_OK;
+}
+
+// ---- MSM ------------------------------------------------------------------------------------------------
+int ga_msm(ga_ctx* h, int curve, int group, const void* bases, const void* scalars, size_t n, unsigned flags, void* out_jac) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    if (!c || !out_jac || (n && (!bases || !scalars))) {
+        set_error("ga_msm: null argument");
+        return GA_ERR_INVALID;
+    }
+    Lock l(c);
+    GA_DISPATCH_CURVE(curve, GA_DISPATCH_GROUP(group, return (msm_impl<C, G>(c, bases, scalars, n, flags, 0, -1, out_jac, nullptr, nullptr, false))));
+    return GA_OK;
+}
+
+int ga_msm_windows(ga_ctx* h, int curve, int group, const void* bases, const void* scalars, size_t n, unsigned flags, int win_lo,
+                   int win_hi, void* out_windows, int* window_bits, int* num_windows) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    if (!c || !out_windows || (n && (!bases || !scalars))) {
+        set_error("ga_msm_windows: null argument");
+        return GA_ERR_INVALID;
+    }
+    Lock l(c);
+    GA_DISPATCH_CURVE(curve, GA_DISPATCH_GROUP(group, return (msm_impl<C, G>(c, bases, scalars, n, flags, win_lo, win_hi, out_windows,
+                                                                            window_bits, num_windows, true))));
+    return GA_OK;
+}
+
+int ga_msm_plan(int curve, int group, size_t n, int* window_bits, int* num_windows) {
+    GA_DISPATCH_CURVE(curve, return msm_plan<C>(group, n, window_bits, num_windows));
+    return GA_OK;
+}
+
+int ga_msm_combine_windows(int curve, int group, const void* windows, int num_windows, int window_bits, void* out_jac) {
+    if (!windows || !out_jac || num_windows <= 0 || window_bits <= 0) {
+        set_error("ga_msm_combine_windows: bad argument");
+        return GA_ERR_INVALID;
+    }
+    GA_DISPATCH_CURVE(curve, GA_DISPATCH_GROUP(group, {
+                          typedef typename GroupField<C, G>::F F;
+                          std::vector<XYZZ<F>> W(num_windows);
+                          for (int w = 0; w < num_windows; w++)
+                              W[w] = host_load_jac<F>(reinterpret_cast<const char*>(windows) + (size_t)w * sizeof(Jac<F>));
+                          host_store_jac<F>(out_jac, host_horner(W.data(), num_windows, window_bits));
+                      }));
+    return GA_OK;
+}
+
+// ---- host group helpers ---------------------------------------------------------------------------------
+int ga_jac_add(int curve, int group, const void* a, const void* b, void* out) {
+    GA_DISPATCH_CURVE(curve, GA_DISPATCH_GROUP(group, {
+                          typedef typename GroupField<C, G>::F F;
+                          host_store_jac<F>(out, add(host_load_jac<F>(a), host_load_jac<F>(b)));
+                      }));
+    return GA_OK;
+}
+
+int ga_jac_to_affine(int curve, int group, const void* a, void* out) {
+    GA_DISPATCH_CURVE(curve, GA_DISPATCH_GROUP(group, {
+                          typedef typename GroupField<C, G>::F F;
+                          host_store_affine<F>(out, host_load_jac<F>(a));
+                      }));
+    return GA_OK;
+}
+
+int ga_jac_scalar_mul(int curve, int group, const void* a, const void* k, void* out) {
+    GA_DISPATCH_CURVE(curve, GA_DISPATCH_GROUP(group, {
+                          typedef typename GroupField<C, G>::F F;
+                          uint32_t kw[8];
+                          memcpy(kw, k, 32);
+                          host_store_jac<F>(out, scalar_mul(host_load_jac<F>(a), kw, 8));
+                      }));
+    return GA_OK;
+}
+
+// ---- NTT ------------------------------------------------------------------------------------------------
+int ga_domain_create(ga_ctx* h, int curve, uint64_t cardinality, ga_domain** out) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    if (!c || !out || cardinality == 0) {
+        set_error("ga_domain_create: bad argument");
+        return GA_ERR_INVALID;
+    }
+    Lock l(c);
+    Domain* d = nullptr;
+    GA_DISPATCH_CURVE(curve, GA_CHECK(ntt_domain_new<C>(c, cardinality, &d)));
+    *out = reinterpret_cast<ga_domain*>(d);
+    return GA_OK;
+}
+
+void ga_domain_destroy(ga_domain* dh) {
+    if (!dh) return;
+    Domain* d = reinterpret_cast<Domain*>(dh);
+    Lock l(ntt_domain_ctx(d));
+    hipStreamSynchronize(ntt_domain_ctx(d)->stream);
+    ntt_domain_delete(d);
+}
+
+int ga_fft(ga_domain* dh, void* data, int direction, int decimation, int on_coset, int on_device) {
+    Domain* d = reinterpret_cast<Domain*>(dh);
+    if (!d || !data || (direction != GA_FFT_FORWARD && direction != GA_FFT_INVERSE) || (decimation != GA_DIF && decimation != GA_DIT)) {
+        set_error("ga_fft: bad argument");
+        return GA_ERR_INVALID;
+    }
+    Ctx* c = ntt_domain_ctx(d);
+    Lock l(c);
+    size_t bytes = ntt_domain_size(d) * 32;
+    void* dev = data;
+    if (!on_device) {
+        GA_CHECK(c->scratch_get("fft_io", bytes, &dev));
+        GA_HIP_CHECK(hipMemcpyAsync(dev, data, bytes, hipMemcpyHostToDevice, c->stream));
+    }
+    GA_DISPATCH_CURVE(ntt_domain_curve(d), GA_CHECK(ntt_domain_fft<C>(d, dev, direction, decimation, on_coset)));
+    if (!on_device) GA_HIP_CHECK(hipMemcpyAsync(data, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    GA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return GA_OK;
+}
+
+int ga_compute_h(ga_domain* dh, const void* a, const void* b, const void* cc, uint64_t n_constraints, void* h_out, int on_device) {
+    Domain* d = reinterpret_cast<Domain*>(dh);
+    if (!d || !a || !b || !cc || !h_out || n_constraints > ntt_domain_size(d)) {
+        set_error("ga_compute_h: bad argument (n_constraints must be <= domain cardinality)");
+        return GA_ERR_INVALID;
+    }
+    Ctx* c = ntt_domain_ctx(d);
+    Lock l(c);
+    const uint64_t n = ntt_domain_size(d);
+    const size_t full = n * 32, part = n_constraints * 32;
+    void *da, *db, *dc;
+    GA_CHECK(c->scratch_get("h_a", full, &da));
+    GA_CHECK(c->scratch_get("h_b", full, &db));
+    GA_CHECK(c->scratch_get("h_c", full, &dc));
+    const void* src[3] = {a, b, cc};
+    void* dst[3] = {da, db, dc};
+    for (int k = 0; k < 3; k++) {
+        GA_HIP_CHECK(hipMemcpyAsync(dst[k], src[k], part, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+        if (full > part) GA_HIP_CHECK(hipMemsetAsync(reinterpret_cast<char*>(dst[k]) + part, 0, full - part, c->stream));
+    }
+    GA_DISPATCH_CURVE(ntt_domain_curve(d), GA_CHECK(ntt_domain_compute_h<C>(d, da, db, dc)));
+    GA_HIP_CHECK(hipMemcpyAsync(h_out, da, full, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+    GA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return GA_OK;
+}
+
+// ---- profiling ------------------------------------------------------------------------------------------
+int ga_profile_enable(ga_ctx* h, int on) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    Lock l(c);
+    c->profiling = on != 0;
+    return GA_OK;
+}
+
+int ga_profile_reset(ga_ctx* h) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    Lock l(c);
+    hipStreamSynchronize(c->stream);
+    for (auto& s : c->stages) {
+        hipEventDestroy(s.a);
+        hipEventDestroy(s.b);
+    }
+    c->stages.clear();
+    return GA_OK;
+}
+
+int ga_profile_read(ga_ctx* h, char* buf, size_t cap) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    Lock l(c);
+    GA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    std::string out;
+    for (auto& s : c->stages) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, s.a, s.b) != hipSuccess) ms = -1;
+        char tmp[160];
+        snprintf(tmp, sizeof(tmp), "%s=%.6f;", s.name.c_str(), ms);
+        out += tmp;
+    }
+    if (!buf || cap == 0) return GA_ERR_INVALID;
+    snprintf(buf, cap, "%s", out.c_str());
+    return GA_OK;
+}
+
+// ---- test / bench support -------------------------------------------------------------------------------
+int ga_gen_bases(ga_ctx* h, int curve, int group, uint64_t seed, size_t n, void* bases_dev, void* dlogs_dev) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    Lock l(c);
+    GA_DISPATCH_CURVE(curve, GA_DISPATCH_GROUP(group, GA_CHECK((util_gen_bases<C, G>(c, seed, n, bases_dev, dlogs_dev)))));
+    GA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return GA_OK;
+}
+
+int ga_gen_scalars(ga_ctx* h, int curve, uint64_t seed, size_t n, void* scalars_dev) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    Lock l(c);
+    GA_DISPATCH_CURVE(curve, GA_CHECK(util_gen_scalars<C>(c, seed, n, scalars_dev)));
+    GA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return GA_OK;
+}
+
+int ga_fr_dot(ga_ctx* h, int curve, const void* a_dev, const void* b_dev, size_t n, void* out_host) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    Lock l(c);
+    GA_DISPATCH_CURVE(curve, GA_CHECK(util_fr_dot<C>(c, a_dev, b_dev, n, out_host)));
+    return GA_OK;
+}
+
+int ga_generator_mul(int curve, int group, const void* k, void* out_jac) {
+    GA_DISPATCH_CURVE(curve, GA_DISPATCH_GROUP(group, {
+                          typedef typename GroupField<C, G>::F F;
+                          uint32_t kw[8];
+                          memcpy(kw, k, 32);
+                          host_store_jac<F>(out_jac, scalar_mul(to_xyzz(Generator<C, G>::get()), kw, 8));
+                      }));
+    return GA_OK;
+}
+
+int ga_microbench(ga_ctx* h, char* buf, size_t cap) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    Lock l(c);
+    return util_microbench(c, buf, cap);
+}
+
+}  // extern "C"

@@ -1,0 +1,160 @@
+// Context, error handling, stage profiler and device scratch management shared by every translation unit
+// of libgnark_amd.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/gnark_amd.h"
+#include "ec.cuh"
+
+namespace ga {
+
+// ---- errors --------------------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+const char* get_error();
+
+#define GA_HIP_CHECK(expr)                                                                              \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess) {                                                                         \
+            ::ga::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return GA_ERR_HIP;                                                                          \
+        }                                                                                               \
+    } while (0)
+
+#define GA_CHECK(expr)               \
+    do {                             \
+        int _r = (expr);             \
+        if (_r != GA_OK) return _r;  \
+    } while (0)
+
+#define GA_KERNEL_CHECK() GA_HIP_CHECK(hipGetLastError())
+
+// ---- curve tags ----------------------------------------------------------------------------------
+struct Bn254 {
+    static constexpr int ID = GA_BN254;
+    using FpP = BN254_Fp;
+    using FrP = BN254_Fr;
+};
+struct Bls12381 {
+    static constexpr int ID = GA_BLS12_381;
+    using FpP = BLS12_381_Fp;
+    using FrP = BLS12_381_Fr;
+};
+template <class C, int G> struct GroupField;
+template <class C> struct GroupField<C, GA_G1> { using F = Fe<typename C::FpP>; };
+template <class C> struct GroupField<C, GA_G2> { using F = Fe2<typename C::FpP>; };
+
+GA_HD uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+template <class C, int G> struct Generator;
+template <class C> struct Generator<C, GA_G1> {
+    typedef typename C::FpP P;
+    GA_HD static Affine<Fe<P>> get() { return {fe_const<P>(P::G1X), fe_const<P>(P::G1Y)}; }
+};
+template <class C> struct Generator<C, GA_G2> {
+    typedef typename C::FpP P;
+    GA_HD static Affine<Fe2<P>> get() {
+        return {{fe_const<P>(P::G2X0), fe_const<P>(P::G2X1)}, {fe_const<P>(P::G2Y0), fe_const<P>(P::G2Y1)}};
+    }
+};
+
+// ---- profiler: hipEvent pairs around named stages on the context's stream ----------------------------
+struct StageRec {
+    std::string name;
+    hipEvent_t a, b;
+};
+
+struct Ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    bool profiling = false;
+    std::vector<StageRec> stages;
+    // reusable device scratch, grown on demand (keyed by purpose)
+    std::map<std::string, std::pair<void*, size_t>> scratch;
+
+    int scratch_get(const char* key, size_t bytes, void** out);
+    void scratch_free_all();
+};
+
+struct StageTimer {
+    Ctx* ctx;
+    int idx = -1;
+    StageTimer(Ctx* c, const char* name) : ctx(c) {
+        if (!c->profiling) return;
+        StageRec r;
+        r.name = name;
+        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+        hipEventRecord(r.a, c->stream);
+        c->stages.push_back(r);
+        idx = (int)c->stages.size() - 1;
+    }
+    ~StageTimer() {
+        if (idx >= 0) hipEventRecord(ctx->stages[idx].b, ctx->stream);
+    }
+};
+
+struct DeviceGuard {
+    explicit DeviceGuard(int dev) { hipSetDevice(dev); }
+};
+
+static inline int ilog2_u64(uint64_t x) {
+    int l = 0;
+    while ((1ull << l) < x) l++;
+    return l;
+}
+
+// ---- per-curve entry points; explicitly instantiated in msm_*.hip / ntt_*.hip / util_*.hip -------------
+// MSM: accumulates windows [win_lo, win_hi) of sum scalars[i]*bases[i]; writes (win_hi-win_lo) XYZZ window sums
+// (host memory, XYZZ<F> images).  d_bases / d_scalars are device pointers.
+template <class C, int G>
+int msm_windows_device(Ctx* ctx, const void* d_bases, const void* d_scalars, size_t n, bool scalars_mont, int c,
+                       int win_lo, int win_hi, void* h_window_sums);
+template <class C>
+int msm_plan(int group, size_t n, int* c, int* nwin);
+
+struct Domain;   // ntt.cuh
+template <class C> int ntt_domain_new(Ctx* ctx, uint64_t n, Domain** out);
+template <class C> int ntt_domain_fft(Domain* d, void* d_data, int direction, int decimation, int on_coset);
+template <class C> int ntt_domain_compute_h(Domain* d, void* d_a, void* d_b, void* d_c);
+void ntt_domain_delete(Domain* d);
+int ntt_domain_curve(const Domain* d);
+uint64_t ntt_domain_size(const Domain* d);
+Ctx* ntt_domain_ctx(const Domain* d);
+
+// utility kernels (util_*.hip)
+template <class C, int G> int util_gen_bases(Ctx* ctx, uint64_t seed, size_t n, void* d_bases, void* d_dlogs);
+template <class C> int util_gen_scalars(Ctx* ctx, uint64_t seed, size_t n, void* d_scalars);
+template <class C> int util_fr_dot(Ctx* ctx, const void* d_a, const void* d_b, size_t n, void* h_out);
+template <class C> int util_gather_fr(Ctx* ctx, void* d_dst, const void* d_src, const uint32_t* d_idx, size_t n);
+int util_microbench(Ctx* ctx, char* buf, size_t cap);
+
+#define GA_DISPATCH_CURVE(curve, ...)                                \
+    switch (curve) {                                                 \
+        case GA_BN254: {                                             \
+            using C = ::ga::Bn254;                                   \
+            __VA_ARGS__;                                             \
+        } break;                                                     \
+        case GA_BLS12_381: {                                         \
+            using C = ::ga::Bls12381;                                \
+            __VA_ARGS__;                                             \
+        } break;                                                     \
+        default:                                                     \
+            ::ga::set_error("unknown curve id %d", (int)(curve));    \
+            return GA_ERR_INVALID;                                   \
+    }
+
+}  // namespace ga

@@ -1,0 +1,209 @@
+// Quadratic extension Fp2 = Fp[u]/(u^2+1) and short-Weierstrass (a = 0) group law for G1 (over Fp) and
+// G2 (over Fp2) of BN254 and BLS12-381.
+//
+// Memory images match gnark-crypto: G1Affine{X,Y}, G2Affine{X,Y E2{A0,A1}}, infinity = all-zero coordinates,
+// G1Jac{X,Y,Z}.  Buckets use extended-Jacobian "XYZZ" coordinates (x = X/ZZ, y = Y/ZZZ,
+// ZZ^3 = ZZZ^2): a mixed addition costs 8M+2S and the formulas below are made complete by branching on
+// P == 0 (doubling / inverse), which DummySetup-style keys with identical bases need (setup.go:526-540).
+#pragma once
+#include "field.cuh"
+
+namespace ga {
+
+// ---- Fp2 ---------------------------------------------------------------------------------------
+template <class P>
+struct Fe2 {
+    Fe<P> c0, c1;   // c0 + c1*u   (gnark E2{A0, A1})
+};
+
+template <class P> GA_HD Fe2<P> add(const Fe2<P>& a, const Fe2<P>& b) { return {add(a.c0, b.c0), add(a.c1, b.c1)}; }
+template <class P> GA_HD Fe2<P> sub(const Fe2<P>& a, const Fe2<P>& b) { return {sub(a.c0, b.c0), sub(a.c1, b.c1)}; }
+template <class P> GA_HD Fe2<P> dbl(const Fe2<P>& a) { return {dbl(a.c0), dbl(a.c1)}; }
+template <class P> GA_HD Fe2<P> neg(const Fe2<P>& a) { return {neg(a.c0), neg(a.c1)}; }
+template <class P> GA_HD bool is_zero(const Fe2<P>& a) { return is_zero(a.c0) & is_zero(a.c1); }
+template <class P> GA_HD bool eq(const Fe2<P>& a, const Fe2<P>& b) { return eq(a.c0, b.c0) & eq(a.c1, b.c1); }
+
+template <class P>
+GA_HD Fe2<P> mul(const Fe2<P>& a, const Fe2<P>& b) {
+    Fe<P> v0 = mul(a.c0, b.c0);
+    Fe<P> v1 = mul(a.c1, b.c1);
+    Fe<P> s = mul(add(a.c0, a.c1), add(b.c0, b.c1));
+    return {sub(v0, v1), sub(sub(s, v0), v1)};
+}
+
+template <class P>
+GA_HD Fe2<P> sqr(const Fe2<P>& a) {
+    Fe<P> t = mul(a.c0, a.c1);
+    Fe<P> r0 = mul(add(a.c0, a.c1), sub(a.c0, a.c1));
+    return {r0, dbl(t)};
+}
+
+template <class P>
+GA_HD Fe2<P> inv(const Fe2<P>& a) {
+    Fe<P> d = inv(add(sqr(a.c0), sqr(a.c1)));
+    return {mul(a.c0, d), neg(mul(a.c1, d))};
+}
+
+// zero / one for either field type
+template <class F> struct FieldTraits;
+template <class P> struct FieldTraits<Fe<P>> {
+    GA_HD static Fe<P> zero() { return fe_zero<P>(); }
+    GA_HD static Fe<P> one() { return fe_one<P>(); }
+};
+template <class P> struct FieldTraits<Fe2<P>> {
+    GA_HD static Fe2<P> zero() { return {fe_zero<P>(), fe_zero<P>()}; }
+    GA_HD static Fe2<P> one() { return {fe_one<P>(), fe_zero<P>()}; }
+};
+
+// ---- points ------------------------------------------------------------------------------------
+template <class F> struct Affine { F x, y; };           // (0,0) = infinity
+template <class F> struct Jac { F x, y, z; };            // gnark G1Jac / G2Jac image
+template <class F> struct XYZZ { F x, y, zz, zzz; };     // zz == 0  <=> infinity
+
+template <class F> GA_HD bool is_inf(const Affine<F>& p) { return is_zero(p.x) & is_zero(p.y); }
+template <class F> GA_HD bool is_inf(const XYZZ<F>& p) { return is_zero(p.zz); }
+
+template <class F>
+GA_HD XYZZ<F> xyzz_inf() {
+    F z = FieldTraits<F>::zero();
+    F o = FieldTraits<F>::one();
+    return {o, o, z, z};
+}
+
+template <class F>
+GA_HD XYZZ<F> to_xyzz(const Affine<F>& p) {
+    if (is_inf(p)) return xyzz_inf<F>();
+    F o = FieldTraits<F>::one();
+    return {p.x, p.y, o, o};
+}
+
+template <class F>
+GA_HD Affine<F> neg(const Affine<F>& p) { return {p.x, neg(p.y)}; }
+template <class F>
+GA_HD XYZZ<F> neg(const XYZZ<F>& p) { return {p.x, neg(p.y), p.zz, p.zzz}; }
+
+// 2*(affine) -> XYZZ   (mdbl-2008-s-1, a = 0)
+template <class F>
+GA_HD XYZZ<F> dbl_affine(const Affine<F>& p) {
+    if (is_inf(p) || is_zero(p.y)) return xyzz_inf<F>();
+    F U = dbl(p.y);
+    F V = sqr(U);
+    F W = mul(U, V);
+    F S = mul(p.x, V);
+    F xx = sqr(p.x);
+    F M = add(dbl(xx), xx);
+    F X3 = sub(sqr(M), dbl(S));
+    F Y3 = sub(mul(M, sub(S, X3)), mul(W, p.y));
+    return {X3, Y3, V, W};
+}
+
+// 2*P   (dbl-2008-s-1, a = 0)
+template <class F>
+GA_HD XYZZ<F> dbl(const XYZZ<F>& p) {
+    if (is_inf(p) || is_zero(p.y)) return xyzz_inf<F>();
+    F U = dbl(p.y);
+    F V = sqr(U);
+    F W = mul(U, V);
+    F S = mul(p.x, V);
+    F xx = sqr(p.x);
+    F M = add(dbl(xx), xx);
+    F X3 = sub(sqr(M), dbl(S));
+    F Y3 = sub(mul(M, sub(S, X3)), mul(W, p.y));
+    return {X3, Y3, mul(V, p.zz), mul(W, p.zzz)};
+}
+
+// acc + affine   (madd-2008-s), complete
+template <class F>
+GA_HD XYZZ<F> madd(const XYZZ<F>& a, const Affine<F>& q) {
+    if (is_inf(q)) return a;
+    if (is_inf(a)) return to_xyzz(q);
+    F U2 = mul(q.x, a.zz);
+    F S2 = mul(q.y, a.zzz);
+    F Pp = sub(U2, a.x);
+    F R = sub(S2, a.y);
+    if (is_zero(Pp)) {
+        if (is_zero(R)) return dbl_affine(q);
+        return xyzz_inf<F>();
+    }
+    F PP = sqr(Pp);
+    F PPP = mul(Pp, PP);
+    F Q = mul(a.x, PP);
+    F X3 = sub(sub(sqr(R), PPP), dbl(Q));
+    F Y3 = sub(mul(R, sub(Q, X3)), mul(a.y, PPP));
+    return {X3, Y3, mul(a.zz, PP), mul(a.zzz, PPP)};
+}
+
+// a + b   (add-2008-s), complete
+template <class F>
+GA_HD XYZZ<F> add(const XYZZ<F>& a, const XYZZ<F>& b) {
+    if (is_inf(b)) return a;
+    if (is_inf(a)) return b;
+    F U1 = mul(a.x, b.zz);
+    F U2 = mul(b.x, a.zz);
+    F S1 = mul(a.y, b.zzz);
+    F S2 = mul(b.y, a.zzz);
+    F Pp = sub(U2, U1);
+    F R = sub(S2, S1);
+    if (is_zero(Pp)) {
+        if (is_zero(R)) return dbl(a);
+        return xyzz_inf<F>();
+    }
+    F PP = sqr(Pp);
+    F PPP = mul(Pp, PP);
+    F Q = mul(U1, PP);
+    F X3 = sub(sub(sqr(R), PPP), dbl(Q));
+    F Y3 = sub(mul(R, sub(Q, X3)), mul(S1, PPP));
+    return {X3, Y3, mul(mul(a.zz, b.zz), PP), mul(mul(a.zzz, b.zzz), PPP)};
+}
+
+// XYZZ -> Jacobian without inversion: Z := ZZZ, X := X*ZZ^2, Y := Y*ZZZ^2   (Z^2 = ZZ^3, Z^3 = ZZZ^3)
+template <class F>
+GA_HD Jac<F> to_jac(const XYZZ<F>& p) {
+    if (is_inf(p)) {
+        F o = FieldTraits<F>::one();
+        return {o, o, FieldTraits<F>::zero()};   // gnark's canonical Jacobian infinity (1,1,0)
+    }
+    return {mul(p.x, sqr(p.zz)), mul(p.y, sqr(p.zzz)), p.zzz};
+}
+
+template <class F>
+GA_HD XYZZ<F> from_jac(const Jac<F>& p) {
+    if (is_zero(p.z)) return xyzz_inf<F>();
+    F zz = sqr(p.z);
+    return {p.x, p.y, zz, mul(zz, p.z)};
+}
+
+// XYZZ -> affine (two inversions folded into one)
+template <class F>
+GA_HD Affine<F> to_affine(const XYZZ<F>& p) {
+    if (is_inf(p)) return {FieldTraits<F>::zero(), FieldTraits<F>::zero()};
+    F i = inv(mul(p.zz, p.zzz));          // 1/(zz*zzz)
+    F izz = mul(i, p.zzz);                // 1/zz
+    F izzz = mul(i, p.zz);                // 1/zzz
+    return {mul(p.x, izz), mul(p.y, izzz)};
+}
+
+// [k]P for a little-endian scalar of nwords 32-bit words (canonical integer, NOT Montgomery)
+template <class F>
+GA_HD XYZZ<F> scalar_mul(const XYZZ<F>& p, const uint32_t* k, int nwords) {
+    XYZZ<F> r = xyzz_inf<F>();
+    for (int i = nwords - 1; i >= 0; i--) {
+        for (int b = 31; b >= 0; b--) {
+            r = dbl(r);
+            if ((k[i] >> b) & 1) r = add(r, p);
+        }
+    }
+    return r;
+}
+
+template <class F>
+GA_HD XYZZ<F> scalar_mul_u32(const XYZZ<F>& p, uint32_t k) {
+    XYZZ<F> r = xyzz_inf<F>();
+    for (int b = 31; b >= 0; b--) {
+        r = dbl(r);
+        if ((k >> b) & 1) r = add(r, p);
+    }
+    return r;
+}
+
+}  // namespace ga

@@ -1,0 +1,313 @@
+// Prime-field arithmetic for the MI355X prover kernels.
+//
+// Memory image == gnark-crypto's fp.Element / fr.Element: little-endian 64-bit limbs holding a*R mod p,
+// R = 2^(64*N64)  (SURVEY Appendix A).  On the device the same bytes are viewed as 2*N64 32-bit limbs
+// because CDNA4's widest integer multiplier is v_mad_u64_u32 (32x32+64 -> 64); R is unchanged, so values
+// round-trip bit-for-bit with the Go side.
+//
+// Replaces (as an independent design): gnark-crypto field arithmetic reached from
+// backend/groth16/bn254/prove.go:194-283,362-386 and the ICICLE field kernels reached from
+// backend/accelerated/icicle/groth16/bn254/icicle.go:1425-1480.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include "constants.h"
+
+#define GA_HD __host__ __device__ __forceinline__
+
+namespace ga {
+
+template <class P>
+struct Fe {
+    static constexpr int N = P::N;
+    uint32_t l[N];
+};
+
+// ---- raw multi-word helpers -------------------------------------------------------------------
+
+template <int N>
+GA_HD uint32_t add_words(uint32_t* r, const uint32_t* a, const uint32_t* b) {
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        c += (uint64_t)a[i] + b[i];
+        r[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    return (uint32_t)c;
+}
+
+template <int N>
+GA_HD uint32_t sub_words(uint32_t* r, const uint32_t* a, const uint32_t* b) {
+    int64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        c += (int64_t)a[i] - (int64_t)b[i];
+        r[i] = (uint32_t)c;
+        c >>= 32;   // arithmetic shift: 0 or -1
+    }
+    return (uint32_t)(c & 1);   // borrow
+}
+
+template <class P>
+GA_HD bool geq_mod(const uint32_t* a) {
+#pragma unroll
+    for (int i = P::N - 1; i >= 0; i--) {
+        if (a[i] > P::MOD[i]) return true;
+        if (a[i] < P::MOD[i]) return false;
+    }
+    return true;
+}
+
+// r = a - p if a >= p  (branch-free: compute a-p, keep it when no borrow)
+template <class P>
+GA_HD void reduce_once(uint32_t* a) {
+    uint32_t t[P::N];
+    int64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < P::N; i++) {
+        c += (int64_t)a[i] - (int64_t)P::MOD[i];
+        t[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    bool keep = (c == 0);
+#pragma unroll
+    for (int i = 0; i < P::N; i++) a[i] = keep ? t[i] : a[i];
+}
+
+// ---- field API --------------------------------------------------------------------------------
+
+template <class P>
+GA_HD Fe<P> fe_zero() {
+    Fe<P> r;
+#pragma unroll
+    for (int i = 0; i < P::N; i++) r.l[i] = 0;
+    return r;
+}
+
+template <class P>
+GA_HD Fe<P> fe_one() {
+    Fe<P> r;
+#pragma unroll
+    for (int i = 0; i < P::N; i++) r.l[i] = P::ONE[i];
+    return r;
+}
+
+template <class P>
+GA_HD Fe<P> fe_const(const uint32_t (&c)[P::N]) {
+    Fe<P> r;
+#pragma unroll
+    for (int i = 0; i < P::N; i++) r.l[i] = c[i];
+    return r;
+}
+
+template <class P>
+GA_HD bool is_zero(const Fe<P>& a) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < P::N; i++) o |= a.l[i];
+    return o == 0;
+}
+
+template <class P>
+GA_HD bool eq(const Fe<P>& a, const Fe<P>& b) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < P::N; i++) o |= a.l[i] ^ b.l[i];
+    return o == 0;
+}
+
+template <class P>
+GA_HD Fe<P> add(const Fe<P>& a, const Fe<P>& b) {
+    Fe<P> r;
+    add_words<P::N>(r.l, a.l, b.l);   // both moduli leave >= 1 spare bit: no carry out of the top word
+    reduce_once<P>(r.l);
+    return r;
+}
+
+template <class P>
+GA_HD Fe<P> dbl(const Fe<P>& a) { return add(a, a); }
+
+template <class P>
+GA_HD Fe<P> sub(const Fe<P>& a, const Fe<P>& b) {
+    Fe<P> r;
+    uint32_t borrow = sub_words<P::N>(r.l, a.l, b.l);
+    uint32_t m = 0u - borrow;   // all-ones when we must add p back
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < P::N; i++) {
+        c += (uint64_t)r.l[i] + (P::MOD[i] & m);
+        r.l[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    return r;
+}
+
+template <class P>
+GA_HD Fe<P> neg(const Fe<P>& a) {
+    Fe<P> r;
+    if (is_zero(a)) return a;
+    int64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < P::N; i++) {
+        c += (int64_t)P::MOD[i] - (int64_t)a.l[i];
+        r.l[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    return r;
+}
+
+// Montgomery product a*b*R^-1 mod p.  Interleaved CIOS on 32-bit limbs, "no-carry" form: valid because the
+// top word of every modulus used here is < 2^31 (BN254 p,r: 0x30644e72; BLS12-381 p: 0x1a0111ea, r: 0x73eda753).
+// Each inner step is one v_mad_u64_u32 (+ a 64-bit carry add).
+template <class P>
+GA_HD Fe<P> mul(const Fe<P>& a, const Fe<P>& b) {
+    constexpr int N = P::N;
+    uint32_t t[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const uint32_t bi = b.l[i];
+        uint64_t A = (uint64_t)a.l[0] * bi + t[0];
+        const uint32_t m = (uint32_t)A * P::INV;
+        uint64_t C = (uint64_t)m * P::MOD[0] + (uint32_t)A;
+#pragma unroll
+        for (int j = 1; j < N; j++) {
+            A = (uint64_t)a.l[j] * bi + t[j] + (A >> 32);
+            C = (uint64_t)m * P::MOD[j] + (uint32_t)A + (C >> 32);
+            t[j - 1] = (uint32_t)C;
+        }
+        t[N - 1] = (uint32_t)(C >> 32) + (uint32_t)(A >> 32);
+    }
+    reduce_once<P>(t);
+    Fe<P> r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.l[i] = t[i];
+    return r;
+}
+
+template <class P>
+GA_HD Fe<P> sqr(const Fe<P>& a) { return mul(a, a); }
+
+// a * R^-1 : leave Montgomery form (fr.Element.BigInt / FromMontgomery)
+template <class P>
+GA_HD Fe<P> from_mont(const Fe<P>& a) {
+    Fe<P> one = fe_zero<P>();
+    one.l[0] = 1;
+    return mul(a, one);
+}
+
+template <class P>
+GA_HD Fe<P> to_mont(const Fe<P>& a) { return mul(a, fe_const<P>(P::R2)); }
+
+// a^e, e given as N 32-bit words (little-endian)
+template <class P>
+GA_HD Fe<P> pow_words(const Fe<P>& a, const uint32_t* e, int nwords) {
+    Fe<P> r = fe_one<P>();
+    for (int i = nwords - 1; i >= 0; i--) {
+        for (int b = 31; b >= 0; b--) {
+            r = sqr(r);
+            if ((e[i] >> b) & 1) r = mul(r, a);
+        }
+    }
+    return r;
+}
+
+template <class P>
+GA_HD Fe<P> pow_u64(const Fe<P>& a, uint64_t e) {
+    Fe<P> r = fe_one<P>();
+    Fe<P> x = a;
+    while (e) {
+        if (e & 1) r = mul(r, x);
+        x = sqr(x);
+        e >>= 1;
+    }
+    return r;
+}
+
+// Fermat inverse (0 -> 0)
+template <class P>
+GA_HD Fe<P> inv(const Fe<P>& a) {
+    uint32_t e[P::N];
+#pragma unroll
+    for (int i = 0; i < P::N; i++) e[i] = P::PM2[i];
+    return pow_words(a, e, P::N);
+}
+
+// a * k for a small unsigned k (Montgomery-form-preserving), via double-and-add
+template <class P>
+GA_HD Fe<P> mul_small(const Fe<P>& a, uint32_t k) {
+    Fe<P> r = fe_zero<P>();
+    Fe<P> x = a;
+    while (k) {
+        if (k & 1) r = add(r, x);
+        x = dbl(x);
+        k >>= 1;
+    }
+    return r;
+}
+
+// ---- 16-byte vector access (coalesced 16 B/lane loads) ---------------------------------------
+
+struct alignas(16) u32x4 {
+    uint32_t x, y, z, w;
+};
+
+template <class P>
+GA_HD Fe<P> load_fe(const void* p) {
+    Fe<P> r;
+    const u32x4* q = reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+    for (int i = 0; i < P::N / 4; i++) {
+        u32x4 v = q[i];
+        r.l[4 * i + 0] = v.x;
+        r.l[4 * i + 1] = v.y;
+        r.l[4 * i + 2] = v.z;
+        r.l[4 * i + 3] = v.w;
+    }
+    return r;
+}
+
+template <class P>
+GA_HD void store_fe(void* p, const Fe<P>& a) {
+    u32x4* q = reinterpret_cast<u32x4*>(p);
+#pragma unroll
+    for (int i = 0; i < P::N / 4; i++) {
+        u32x4 v;
+        v.x = a.l[4 * i + 0];
+        v.y = a.l[4 * i + 1];
+        v.z = a.l[4 * i + 2];
+        v.w = a.l[4 * i + 3];
+        q[i] = v;
+    }
+}
+
+// whole-struct 16-byte vector copies (points)
+template <class T>
+GA_HD T load_pod(const void* p) {
+    static_assert(sizeof(T) % 16 == 0, "16-byte multiples only");
+    T r;
+    const u32x4* s = reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+    for (size_t i = 0; i < sizeof(T) / 16; i++) {
+        u32x4 v = s[i];
+        memcpy(reinterpret_cast<char*>(&r) + 16 * i, &v, 16);
+    }
+    return r;
+}
+
+template <class T>
+GA_HD void store_pod(void* p, const T& a) {
+    static_assert(sizeof(T) % 16 == 0, "16-byte multiples only");
+    u32x4* d = reinterpret_cast<u32x4*>(p);
+#pragma unroll
+    for (size_t i = 0; i < sizeof(T) / 16; i++) {
+        u32x4 v;
+        memcpy(&v, reinterpret_cast<const char*>(&a) + 16 * i, 16);
+        d[i] = v;
+    }
+}
+
+}  // namespace ga

@@ -1,0 +1,320 @@
+// Groth16 prover core: device-resident proving key + one-call proof from the solver's output.
+//
+// Mirrors backend/groth16/bn254/prove.go:130-315 (CPU) and backend/accelerated/icicle/groth16/bn254/icicle.go:784-1360
+// (GPU) without BSB22 commitments:  computeH -> filter wire values -> 4 G1 MSMs + 1 G2 MSM -> host epilogue with the
+// caller-supplied randomness (r, s).  The host side is C++ because the reference's host side is compiled Go and no Go
+// toolchain exists in the build image (INTEGRATION.md shows the cgo binding that calls this file's two entry points).
+#include <algorithm>
+
+#include "hostops.cuh"
+
+namespace ga {
+
+struct G16Pk {
+    Ctx* ctx = nullptr;
+    int curve = 0;
+    uint64_t n = 0;            // domain cardinality
+    uint64_t nb_wires = 0;
+    Domain* dom = nullptr;
+    void *d_a = nullptr, *d_b = nullptr, *d_z = nullptr, *d_k = nullptr, *d_b2 = nullptr;
+    uint64_t len_a = 0, len_b = 0, len_z = 0, len_k = 0, len_b2 = 0;
+    uint32_t *d_idx_a = nullptr, *d_idx_b = nullptr;   // wire indices kept for the A / B MSMs (prove.go:147-168)
+    std::vector<uint8_t> alpha1, beta1, delta1, beta2, delta2;   // affine images (host)
+};
+
+static int upload(Ctx* ctx, const void* src, size_t bytes, void** dst) {
+    *dst = nullptr;
+    hipError_t e = hipMalloc(dst, bytes ? bytes : 16);
+    if (e != hipSuccess) {
+        set_error("proving key upload: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return GA_ERR_NOMEM;
+    }
+    if (bytes) GA_HIP_CHECK(hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return GA_OK;
+}
+
+static void pk_free(G16Pk* pk) {
+    if (!pk) return;
+    hipFree(pk->d_a);
+    hipFree(pk->d_b);
+    hipFree(pk->d_z);
+    hipFree(pk->d_k);
+    hipFree(pk->d_b2);
+    hipFree(pk->d_idx_a);
+    hipFree(pk->d_idx_b);
+    if (pk->dom) ntt_domain_delete(pk->dom);
+    delete pk;
+}
+
+template <class C>
+static int pk_create(Ctx* ctx, const ga_g16_key* key, G16Pk** out) {
+    typedef Fe<typename C::FpP> F1;
+    typedef Fe2<typename C::FpP> F2;
+    const size_t s1 = sizeof(Affine<F1>), s2 = sizeof(Affine<F2>);
+    if (key->len_z + 1 != key->domain_cardinality) {
+        set_error("proving key: len(G1.Z)=%llu but domain cardinality is %llu (expected n-1, setup.go:248-249)",
+                  (unsigned long long)key->len_z, (unsigned long long)key->domain_cardinality);
+        return GA_ERR_INVALID;
+    }
+    if (key->len_a + key->nb_infinity_a != key->nb_wires || key->len_b + key->nb_infinity_b != key->nb_wires ||
+        key->len_b2 != key->len_b) {
+        set_error("proving key: len(A)+NbInfinityA, len(B)+NbInfinityB must equal nbWires and len(G2.B)==len(G1.B)");
+        return GA_ERR_INVALID;
+    }
+    G16Pk* pk = new G16Pk();
+    pk->ctx = ctx;
+    pk->curve = C::ID;
+    pk->n = key->domain_cardinality;
+    pk->nb_wires = key->nb_wires;
+    pk->len_a = key->len_a;
+    pk->len_b = key->len_b;
+    pk->len_z = key->len_z;
+    pk->len_k = key->len_k;
+    pk->len_b2 = key->len_b2;
+    int rc = ntt_domain_new<C>(ctx, pk->n, &pk->dom);
+    if (rc == GA_OK) rc = upload(ctx, key->g1_a, key->len_a * s1, &pk->d_a);
+    if (rc == GA_OK) rc = upload(ctx, key->g1_b, key->len_b * s1, &pk->d_b);
+    if (rc == GA_OK) rc = upload(ctx, key->g1_z, key->len_z * s1, &pk->d_z);
+    if (rc == GA_OK) rc = upload(ctx, key->g1_k, key->len_k * s1, &pk->d_k);
+    if (rc == GA_OK) rc = upload(ctx, key->g2_b, key->len_b2 * s2, &pk->d_b2);
+    std::vector<uint32_t> ia, ib;
+    if (rc == GA_OK) {
+        ia.reserve(key->len_a);
+        ib.reserve(key->len_b);
+        for (uint64_t i = 0; i < key->nb_wires; i++) {
+            if (!key->infinity_a[i]) ia.push_back((uint32_t)i);
+            if (!key->infinity_b[i]) ib.push_back((uint32_t)i);
+        }
+        if (ia.size() != key->len_a || ib.size() != key->len_b) {
+            set_error("proving key: InfinityA/B masks disagree with len(A)/len(B)");
+            rc = GA_ERR_INVALID;
+        }
+    }
+    if (rc == GA_OK) rc = upload(ctx, ia.data(), ia.size() * 4, (void**)&pk->d_idx_a);
+    if (rc == GA_OK) rc = upload(ctx, ib.data(), ib.size() * 4, (void**)&pk->d_idx_b);
+    if (rc == GA_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) {   // no host pointer survives this call
+        set_error("proving key upload: stream synchronize failed");
+        rc = GA_ERR_HIP;
+    }
+    if (rc != GA_OK) {
+        pk_free(pk);
+        return rc;
+    }
+    auto cp = [](std::vector<uint8_t>& v, const void* p, size_t n) { v.assign((const uint8_t*)p, (const uint8_t*)p + n); };
+    cp(pk->alpha1, key->g1_alpha, s1);
+    cp(pk->beta1, key->g1_beta, s1);
+    cp(pk->delta1, key->g1_delta, s1);
+    cp(pk->beta2, key->g2_beta, s2);
+    cp(pk->delta2, key->g2_delta, s2);
+    *out = pk;
+    return GA_OK;
+}
+
+template <class C>
+static int prove(G16Pk* pk, const void* w, const void* a, const void* b, const void* c, uint64_t n_constraints,
+                 uint64_t nb_public, const void* r_mont, const void* s_mont, void* proof_out) {
+    typedef typename C::FrP FrP;
+    typedef Fe<typename C::FpP> F1;
+    typedef Fe2<typename C::FpP> F2;
+    Ctx* ctx = pk->ctx;
+    const uint64_t n = pk->n;
+    if (n_constraints > n || nb_public > pk->nb_wires || pk->nb_wires - nb_public != pk->len_k) {
+        set_error("prove: inconsistent sizes (constraints %llu > n %llu, or nbWires-nbPublic != len(K))",
+                  (unsigned long long)n_constraints, (unsigned long long)n);
+        return GA_ERR_INVALID;
+    }
+    hipStream_t st = ctx->stream;
+    // ---- upload the solution ----------------------------------------------------------------------
+    void *d_w, *d_ha, *d_hb, *d_hc, *d_wa, *d_wb;
+    GA_CHECK(ctx->scratch_get("g16_w", pk->nb_wires * 32, &d_w));
+    GA_CHECK(ctx->scratch_get("h_a", n * 32, &d_ha));
+    GA_CHECK(ctx->scratch_get("h_b", n * 32, &d_hb));
+    GA_CHECK(ctx->scratch_get("h_c", n * 32, &d_hc));
+    GA_CHECK(ctx->scratch_get("g16_wa", pk->len_a * 32 + 32, &d_wa));
+    GA_CHECK(ctx->scratch_get("g16_wb", pk->len_b * 32 + 32, &d_wb));
+    {
+        StageTimer tm(ctx, "g16_h2d");
+        GA_HIP_CHECK(hipMemcpyAsync(d_w, w, pk->nb_wires * 32, hipMemcpyHostToDevice, st));
+        const void* src[3] = {a, b, c};
+        void* dst[3] = {d_ha, d_hb, d_hc};
+        for (int k = 0; k < 3; k++) {
+            GA_HIP_CHECK(hipMemcpyAsync(dst[k], src[k], n_constraints * 32, hipMemcpyHostToDevice, st));
+            if (n > n_constraints)   // computeH pads to the domain size (prove.go:356-359)
+                GA_HIP_CHECK(hipMemsetAsync((char*)dst[k] + n_constraints * 32, 0, (n - n_constraints) * 32, st));
+        }
+    }
+    // ---- H ------------------------------------------------------------------------------------------
+    GA_CHECK(ntt_domain_compute_h<C>(pk->dom, d_ha, d_hb, d_hc));   // h in d_ha, bit-reversed like pk.G1.Z
+    // ---- wire filtering (prove.go:147-168) ------------------------------------------------------------
+    GA_CHECK(util_gather_fr<C>(ctx, d_wa, d_w, pk->d_idx_a, pk->len_a));
+    GA_CHECK(util_gather_fr<C>(ctx, d_wb, d_w, pk->d_idx_b, pk->len_b));
+    // ---- the five MSMs (prove.go:194,207,227,237,283) -------------------------------------------------
+    XYZZ<F1> ar, bs1, krs, krs2;
+    XYZZ<F2> bs2;
+    GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_a, d_wa, pk->len_a, true, &ar)));
+    GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_b, d_wb, pk->len_b, true, &bs1)));
+    GA_CHECK((host_msm<C, GA_G2>(ctx, pk->d_b2, d_wb, pk->len_b2, true, &bs2)));
+    GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_k, (const char*)d_w + nb_public * 32, pk->len_k, true, &krs)));
+    GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_z, d_ha, pk->len_z, true, &krs2)));   // h[:n-1], prove.go:225-227
+    // ---- epilogue on the host (prove.go:171-185,199-200,212-214,241-269,287-292) ----------------------------
+    StageTimer tm(ctx, "g16_epilogue_host");
+    Fe<FrP> r, s;
+    memcpy(r.l, r_mont, 32);
+    memcpy(s.l, s_mont, 32);
+    Fe<FrP> kr = neg(mul(r, s));
+    Fe<FrP> rc = from_mont(r), sc = from_mont(s), krc = from_mont(kr);
+    XYZZ<F1> delta1 = host_load_affine<F1>(pk->delta1.data());
+    XYZZ<F1> d_r = scalar_mul(delta1, rc.l, 8), d_s = scalar_mul(delta1, sc.l, 8), d_kr = scalar_mul(delta1, krc.l, 8);
+    bs1 = add(add(bs1, host_load_affine<F1>(pk->beta1.data())), d_s);
+    ar = add(add(ar, host_load_affine<F1>(pk->alpha1.data())), d_r);
+    krs = add(krs, d_kr);
+    krs = add(krs, krs2);
+    krs = add(krs, scalar_mul(ar, sc.l, 8));
+    krs = add(krs, scalar_mul(bs1, rc.l, 8));
+    XYZZ<F2> delta2 = host_load_affine<F2>(pk->delta2.data());
+    bs2 = add(add(bs2, scalar_mul(delta2, sc.l, 8)), host_load_affine<F2>(pk->beta2.data()));
+    char* o = reinterpret_cast<char*>(proof_out);
+    host_store_affine<F1>(o, ar);
+    host_store_affine<F2>(o + sizeof(Affine<F1>), bs2);
+    host_store_affine<F1>(o + sizeof(Affine<F1>) + sizeof(Affine<F2>), krs);
+    return GA_OK;
+}
+
+// ---- compressed point encoding (marshal.go:33-58 via gnark-crypto's encoder [EXT]) ---------
+template <class P>
+static bool lex_largest(const Fe<P>& y_mont) {
+    // y > (p-1)/2 on the canonical value
+    Fe<P> y = from_mont(y_mont);
+    uint32_t half[P::N];
+    for (int i = 0; i < P::N; i++) half[i] = (P::MOD[i] >> 1) | (i + 1 < P::N ? (P::MOD[i + 1] << 31) : 0);
+    for (int i = P::N - 1; i >= 0; i--) {
+        if (y.l[i] > half[i]) return true;
+        if (y.l[i] < half[i]) return false;
+    }
+    return false;
+}
+template <class P>
+static void be_bytes(const Fe<P>& x_mont, uint8_t* out) {
+    Fe<P> x = from_mont(x_mont);
+    for (int i = 0; i < P::N; i++) {
+        uint32_t v = x.l[P::N - 1 - i];
+        out[4 * i] = v >> 24;
+        out[4 * i + 1] = v >> 16;
+        out[4 * i + 2] = v >> 8;
+        out[4 * i + 3] = v;
+    }
+}
+template <class C>
+static void flag_bytes(uint8_t* out, bool inf, bool largest) {
+    if (C::ID == GA_BN254) out[0] |= inf ? 0x40 : (largest ? 0xC0 : 0x80);
+    else out[0] |= inf ? 0xC0 : (0x80 | (largest ? 0x20 : 0));
+}
+template <class C>
+static size_t compress_g1(const void* aff, uint8_t* out) {
+    typedef typename C::FpP P;
+    Affine<Fe<P>> a;
+    memcpy(&a, aff, sizeof(a));
+    const size_t nb = P::N * 4;
+    memset(out, 0, nb);
+    if (is_inf(a)) {
+        flag_bytes<C>(out, true, false);
+        return nb;
+    }
+    be_bytes<P>(a.x, out);
+    flag_bytes<C>(out, false, lex_largest<P>(a.y));
+    return nb;
+}
+template <class C>
+static size_t compress_g2(const void* aff, uint8_t* out) {
+    typedef typename C::FpP P;
+    Affine<Fe2<P>> a;
+    memcpy(&a, aff, sizeof(a));
+    const size_t nb = P::N * 4;
+    memset(out, 0, 2 * nb);
+    if (is_inf(a)) {
+        flag_bytes<C>(out, true, false);
+        return 2 * nb;
+    }
+    be_bytes<P>(a.x.c1, out);        // A1 || A0
+    be_bytes<P>(a.x.c0, out + nb);
+    bool largest = is_zero(a.y.c1) ? lex_largest<P>(a.y.c0) : lex_largest<P>(a.y.c1);
+    flag_bytes<C>(out, false, largest);
+    return 2 * nb;
+}
+
+template <class C>
+static int marshal(const void* proof, uint8_t* out, size_t cap, size_t* len) {
+    typedef Fe<typename C::FpP> F1;
+    typedef Fe2<typename C::FpP> F2;
+    const size_t nb = C::FpP::N * 4;
+    const size_t need = nb + 2 * nb + nb + 4 + nb;
+    if (cap < need) {
+        set_error("proof marshal: buffer too small (%zu < %zu)", cap, need);
+        return GA_ERR_INVALID;
+    }
+    const char* p = reinterpret_cast<const char*>(proof);
+    size_t o = 0;
+    o += compress_g1<C>(p, out + o);
+    o += compress_g2<C>(p + sizeof(Affine<F1>), out + o);
+    o += compress_g1<C>(p + sizeof(Affine<F1>) + sizeof(Affine<F2>), out + o);
+    memset(out + o, 0, 4);   // uint32 number of commitments = 0
+    o += 4;
+    Affine<F1> inf;
+    memset(&inf, 0, sizeof(inf));
+    o += compress_g1<C>(&inf, out + o);   // CommitmentPok = infinity
+    *len = o;
+    return GA_OK;
+}
+
+}  // namespace ga
+
+using namespace ga;
+
+extern "C" {
+
+int ga_g16_pk_create(ga_ctx* h, const ga_g16_key* key, ga_g16_pk** out) {
+    Ctx* ctx = reinterpret_cast<Ctx*>(h);
+    if (!ctx || !key || !out) {
+        set_error("ga_g16_pk_create: null argument");
+        return GA_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> g(ctx->mu);
+    hipSetDevice(ctx->device);
+    G16Pk* pk = nullptr;
+    GA_DISPATCH_CURVE(key->curve, GA_CHECK(pk_create<C>(ctx, key, &pk)));
+    *out = reinterpret_cast<ga_g16_pk*>(pk);
+    return GA_OK;
+}
+
+void ga_g16_pk_destroy(ga_g16_pk* p) {
+    G16Pk* pk = reinterpret_cast<G16Pk*>(p);
+    if (!pk) return;
+    std::lock_guard<std::mutex> g(pk->ctx->mu);
+    hipSetDevice(pk->ctx->device);
+    hipStreamSynchronize(pk->ctx->stream);
+    pk_free(pk);
+}
+
+int ga_g16_prove(ga_g16_pk* p, const void* w, const void* a, const void* b, const void* c, uint64_t n_constraints,
+                 uint64_t nb_public, const void* r, const void* s, void* proof_out) {
+    G16Pk* pk = reinterpret_cast<G16Pk*>(p);
+    if (!pk || !w || !a || !b || !c || !r || !s || !proof_out) {
+        set_error("ga_g16_prove: null argument");
+        return GA_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> g(pk->ctx->mu);
+    hipSetDevice(pk->ctx->device);
+    GA_DISPATCH_CURVE(pk->curve, return prove<C>(pk, w, a, b, c, n_constraints, nb_public, r, s, proof_out));
+    return GA_OK;
+}
+
+int ga_g16_proof_marshal(int curve, const void* proof, uint8_t* out, size_t cap, size_t* len) {
+    if (!proof || !out || !len) {
+        set_error("ga_g16_proof_marshal: null argument");
+        return GA_ERR_INVALID;
+    }
+    GA_DISPATCH_CURVE(curve, return marshal<C>(proof, out, cap, len));
+    return GA_OK;
+}
+
+}  // extern "C"

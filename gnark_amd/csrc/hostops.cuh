@@ -1,0 +1,66 @@
+// Host-side group helpers used by the proof epilogue (prove.go:185,199-200,212-214,241-269,287-292) and by the
+// multi-GPU combine.  Same templates as the device code, compiled for the host: a handful of scalar
+// multiplications and additions per proof, which the reference also keeps on the CPU
+// (icicle.go:1096-1097,1144-1146,1249-1259,1309-1314).
+#pragma once
+#include "common.cuh"
+
+namespace ga {
+
+template <class F>
+inline XYZZ<F> host_load_jac(const void* p) {
+    Jac<F> j;
+    memcpy(&j, p, sizeof(j));
+    return from_jac(j);
+}
+template <class F>
+inline void host_store_jac(void* p, const XYZZ<F>& a) {
+    Jac<F> j = to_jac(a);
+    memcpy(p, &j, sizeof(j));
+}
+template <class F>
+inline XYZZ<F> host_load_affine(const void* p) {
+    Affine<F> a;
+    memcpy(&a, p, sizeof(a));
+    return to_xyzz(a);
+}
+template <class F>
+inline void host_store_affine(void* p, const XYZZ<F>& a) {
+    Affine<F> r = to_affine(a);
+    memcpy(p, &r, sizeof(r));
+}
+
+// scalar: fr element in Montgomery form -> canonical 8 words
+template <class FrP>
+inline void host_fr_canonical(const void* fr_mont, uint32_t* out8) {
+    Fe<FrP> s;
+    memcpy(s.l, fr_mont, 32);
+    s = from_mont(s);
+    memcpy(out8, s.l, 32);
+}
+
+// result = sum_j 2^(c*j) W_j  (host; Horner from the top window)
+template <class F>
+XYZZ<F> host_horner(const XYZZ<F>* W, int nwin, int c) {
+    XYZZ<F> acc = xyzz_inf<F>();
+    for (int w = nwin - 1; w >= 0; w--) {
+        for (int k = 0; k < c; k++) acc = dbl(acc);
+        acc = add(acc, W[w]);
+    }
+    return acc;
+}
+
+// full MSM on device + Horner on host -> XYZZ
+template <class C, int G>
+int host_msm(Ctx* ctx, const void* d_bases, const void* d_scalars, size_t n, bool mont,
+             XYZZ<typename GroupField<C, G>::F>* out) {
+    typedef typename GroupField<C, G>::F F;
+    int c, nwin;
+    GA_CHECK(msm_plan<C>(G, n, &c, &nwin));
+    std::vector<XYZZ<F>> W(nwin);
+    GA_CHECK((msm_windows_device<C, G>(ctx, d_bases, d_scalars, n, mont, c, 0, nwin, W.data())));
+    *out = host_horner(W.data(), nwin, c);
+    return GA_OK;
+}
+
+}  // namespace ga

@@ -1,0 +1,108 @@
+// Issue-rate microbenchmarks for the integer / FP64 instructions a big-integer multiplier can be built from on
+// gfx950 ("microbenchmark v_mad_u64_u32 issue rate and report achieved MAD/s fraction"), plus the
+// achieved throughput of this library's own Montgomery multiplication.
+#include "common.cuh"
+
+namespace ga {
+
+constexpr int MB_ITERS = 2048;
+
+#define MB_KERNEL(name, decl, body)                                                      \
+    __global__ void __launch_bounds__(256) name(uint32_t* out, uint32_t seed) {          \
+        decl;                                                                            \
+        for (int it = 0; it < MB_ITERS; it++) {                                          \
+            body                                                                         \
+        }                                                                                \
+        uint32_t r = (uint32_t)(a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7);                  \
+        if (r == 0x12345u) out[threadIdx.x] = r;                                         \
+    }
+
+#define MB_U64_DECL                                                                                            \
+    uint64_t a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7; \
+    uint32_t x = seed | 1u, y = (seed >> 3) | 1u
+#define MB_U32_DECL                                                                                            \
+    uint32_t a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7; \
+    uint32_t x = seed | 1u, y = (seed >> 3) | 1u
+#define MB_F64_DECL                                                                                            \
+    double a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7; \
+    double x = 1.0000001, y = 0.9999999
+#define MB_F32_DECL                                                                                            \
+    float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7; \
+    float x = 1.0000001f, y = 0.9999999f
+
+#define REP8(OP) OP(a0) OP(a1) OP(a2) OP(a3) OP(a4) OP(a5) OP(a6) OP(a7)
+
+#define OP_MAD64(a) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(a) : "v"(x), "v"(y) : "vcc");
+MB_KERNEL(mb_mad_u64_u32, MB_U64_DECL, REP8(OP_MAD64) REP8(OP_MAD64))
+#define OP_MULLO(a) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a) : "v"(x));
+MB_KERNEL(mb_mul_lo_u32, MB_U32_DECL, REP8(OP_MULLO) REP8(OP_MULLO))
+#define OP_MULHI(a) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(a) : "v"(x));
+MB_KERNEL(mb_mul_hi_u32, MB_U32_DECL, REP8(OP_MULHI) REP8(OP_MULHI))
+#define OP_MAD24(a) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(a) : "v"(x), "v"(y));
+MB_KERNEL(mb_mad_u32_u24, MB_U32_DECL, REP8(OP_MAD24) REP8(OP_MAD24))
+#define OP_ADD64(a) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(a) : "v"(a7));
+MB_KERNEL(mb_lshl_add_u64, MB_U64_DECL, REP8(OP_ADD64) REP8(OP_ADD64))
+#define OP_ADDC(a) asm volatile("v_add_co_u32 %0, vcc, %0, %1\n\tv_addc_co_u32 %0, vcc, %0, %2, vcc" : "+v"(a) : "v"(x), "v"(y) : "vcc");
+MB_KERNEL(mb_add_co_addc, MB_U32_DECL, REP8(OP_ADDC))
+#define OP_MOV(a) asm volatile("v_mov_b32 %0, %1" : "+v"(a) : "v"(x));
+MB_KERNEL(mb_mov_b32, MB_U32_DECL, REP8(OP_MOV) REP8(OP_MOV))
+#define OP_FMA64(a) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(a) : "v"(x), "v"(y));
+MB_KERNEL(mb_fma_f64, MB_F64_DECL, REP8(OP_FMA64) REP8(OP_FMA64))
+#define OP_FMA32(a) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a) : "v"(x), "v"(y));
+MB_KERNEL(mb_fma_f32, MB_F32_DECL, REP8(OP_FMA32) REP8(OP_FMA32))
+
+template <class P>
+__global__ void __launch_bounds__(256) mb_field_mul(uint32_t* out, uint32_t seed) {
+    Fe<P> a = fe_const<P>(P::R2), b = fe_one<P>();
+    a.l[0] ^= seed + threadIdx.x;
+    b.l[1] ^= seed;
+    for (int it = 0; it < MB_ITERS / 8; it++) {
+        a = mul(a, b);
+        b = mul(b, a);
+    }
+    if (a.l[0] == 0x12345u && b.l[0] == 7) out[threadIdx.x] = a.l[1];
+}
+
+template <class K>
+static int run_one(Ctx* ctx, const char* name, K kernel, double ops_per_thread, std::string& out, uint32_t* d_out) {
+    const unsigned blocks = 256 * 8, threads = 256;
+    hipEvent_t a, b;
+    GA_HIP_CHECK(hipEventCreate(&a));
+    GA_HIP_CHECK(hipEventCreate(&b));
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), 0, ctx->stream, d_out, 12345u);   // warm-up
+    GA_HIP_CHECK(hipEventRecord(a, ctx->stream));
+    for (int r = 0; r < 3; r++) hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), 0, ctx->stream, d_out, 12345u + r);
+    GA_HIP_CHECK(hipEventRecord(b, ctx->stream));
+    GA_HIP_CHECK(hipEventSynchronize(b));
+    float ms = 0;
+    GA_HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+    double gops = 3.0 * ops_per_thread * blocks * threads / (ms * 1e-3) / 1e9;
+    char tmp[128];
+    snprintf(tmp, sizeof(tmp), "%s=%.1f;", name, gops);
+    out += tmp;
+    hipEventDestroy(a);
+    hipEventDestroy(b);
+    return GA_OK;
+}
+
+int util_microbench(Ctx* ctx, char* buf, size_t cap) {
+    uint32_t* d_out;
+    GA_CHECK(ctx->scratch_get("microbench", 4096, (void**)&d_out));
+    std::string out;
+    const double n16 = 16.0 * MB_ITERS, n8 = 8.0 * MB_ITERS;
+    GA_CHECK(run_one(ctx, "v_mad_u64_u32_Gops", mb_mad_u64_u32, n16, out, d_out));
+    GA_CHECK(run_one(ctx, "v_mul_lo_u32_Gops", mb_mul_lo_u32, n16, out, d_out));
+    GA_CHECK(run_one(ctx, "v_mul_hi_u32_Gops", mb_mul_hi_u32, n16, out, d_out));
+    GA_CHECK(run_one(ctx, "v_mad_u32_u24_Gops", mb_mad_u32_u24, n16, out, d_out));
+    GA_CHECK(run_one(ctx, "v_lshl_add_u64_Gops", mb_lshl_add_u64, n16, out, d_out));
+    GA_CHECK(run_one(ctx, "v_add_co_addc_pair_Gops", mb_add_co_addc, n8, out, d_out));
+    GA_CHECK(run_one(ctx, "v_mov_b32_Gops", mb_mov_b32, n16, out, d_out));
+    GA_CHECK(run_one(ctx, "v_fma_f64_Gops", mb_fma_f64, n16, out, d_out));
+    GA_CHECK(run_one(ctx, "v_fma_f32_Gops", mb_fma_f32, n16, out, d_out));
+    GA_CHECK(run_one(ctx, "fieldmul_bn254_fr_Gmul", mb_field_mul<BN254_Fr>, 2.0 * (MB_ITERS / 8), out, d_out));
+    GA_CHECK(run_one(ctx, "fieldmul_bls12381_fp_Gmul", mb_field_mul<BLS12_381_Fp>, 2.0 * (MB_ITERS / 8), out, d_out));
+    snprintf(buf, cap, "%s", out.c_str());
+    return GA_OK;
+}
+
+}  // namespace ga

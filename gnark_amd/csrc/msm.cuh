@@ -1,0 +1,316 @@
+// Pippenger multi-scalar multiplication for G1/G2 of BN254 and BLS12-381 on gfx950.
+//
+// Replaces G1Jac.MultiExp / G2Jac.MultiExp (backend/groth16/bn254/prove.go:194,207,227,237,283) and the ICICLE
+// msm.Msm / g2.G2Msm calls (backend/accelerated/icicle/groth16/bn254/icicle.go:362-467).
+//
+// Pipeline (all on the context's stream, no host synchronisation until the window sums are copied back):
+//   1. msm_digits_kernel   scalar -> signed c-bit digits (Montgomery reduction fused in); one (key, value) pair per
+//                          (point, window): key = window*2^(c-1) + |digit|-1, value = point index | sign<<31.
+//                          Zero digits get key = SKIP (sorts last), so zero scalars and the constant-0 wires of a
+//                          witness cost nothing downstream.
+//   2. radix sort          of the pairs by key (hipcub DeviceRadixSort on the significant bits only) -- the utility
+//                          step; after it every bucket is a contiguous run of point indices.
+//   3. msm_offsets_kernel  bucket boundaries by binary search; msm_tasks_kernel splits buckets into tasks of at most
+//                          SEG points so that a hot bucket (witness values 0/1 make bucket 1 of window 0 huge) is spread
+//                          over many lanes; exclusive scan gives the task table.
+//   4. msm_accumulate_kernel  one lane per task: gathers its affine bases (16 B/lane vector loads), XYZZ mixed adds.
+//   5. msm_merge_kernel / msm_hot_kernel  partial sums -> one XYZZ sum per bucket (wave-level LDS tree for hot buckets).
+//   6. msm_reduce_groups_kernel + msm_window_sum_kernel  sum_k k*B_k per window via per-group running sums and a
+//                          wave tree; window sums go back to the host, which does the c doublings per window (Horner)
+//                          -- ~256 sequential doublings are latency-bound on a GPU lane and free on a host core, and the
+//                          multi-GPU window-sharded mode needs the window sums on the host anyway.
+#pragma once
+#include <hipcub/hipcub.hpp>
+
+#include "common.cuh"
+
+namespace ga {
+
+constexpr uint32_t MSM_SIGN = 0x80000000u;
+constexpr int MSM_HOT_TASKS = 8;      // buckets with more partials than this go to the wave-parallel merge
+constexpr int MSM_GROUP = 32;         // buckets per running-sum group in the window reduction
+
+// ---- 1. digits ------------------------------------------------------------------------------------
+template <class FrP>
+__global__ void msm_digits_kernel(const uint32_t* __restrict__ scalars, uint64_t n, int mont, int c, int nwin, int win_lo,
+                                  int win_hi, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fe<FrP> s = load_fe<FrP>(scalars + i * 8);
+    if (mont) s = from_mont(s);
+    const uint32_t half = 1u << (c - 1);
+    const uint32_t mask = (1u << c) - 1;
+    const uint32_t skip = (uint32_t)(win_hi - win_lo) * half;
+    uint32_t carry = 0;
+    for (int w = 0; w < nwin; w++) {
+        uint32_t d = (s.l[0] & mask) + carry;
+        // s >>= c  (c < 32)
+#pragma unroll
+        for (int k = 0; k < 7; k++) s.l[k] = (s.l[k] >> c) | (s.l[k + 1] << (32 - c));
+        s.l[7] >>= c;
+        uint32_t neg = 0;
+        if (d > half) {
+            d = (1u << c) - d;
+            neg = MSM_SIGN;
+            carry = 1;
+        } else {
+            carry = 0;
+        }
+        if (w >= win_lo && w < win_hi) {
+            uint64_t idx = (uint64_t)(w - win_lo) * n + i;
+            keys[idx] = d == 0 ? skip : (uint32_t)(w - win_lo) * half + (d - 1);
+            vals[idx] = (uint32_t)i | neg;
+        }
+    }
+}
+
+// ---- 3. bucket boundaries and tasks ---------------------------------------------------------------
+static __global__ void msm_offsets_kernel(const uint32_t* __restrict__ keys, uint64_t m, uint32_t nb, uint32_t* __restrict__ off) {
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > nb) return;
+    uint64_t lo = 0, hi = m;   // first index with keys[idx] >= b
+    while (lo < hi) {
+        uint64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < b) lo = mid + 1;
+        else hi = mid;
+    }
+    off[b] = (uint32_t)lo;
+}
+
+static __global__ void msm_tasks_kernel(const uint32_t* __restrict__ off, uint32_t nb, uint32_t seg, uint32_t* __restrict__ ntask) {
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > nb) return;
+    uint32_t sz = b < nb ? off[b + 1] - off[b] : 0;
+    ntask[b] = (sz + seg - 1) / seg;
+}
+
+// ---- 4. accumulate --------------------------------------------------------------------------------
+template <class F>
+__global__ void __launch_bounds__(256)
+msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ vals,
+                      const uint32_t* __restrict__ off, const uint32_t* __restrict__ task_off, uint32_t nb, uint32_t seg,
+                      XYZZ<F>* __restrict__ partial) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t total = task_off[nb];
+    if (t >= total) return;
+    // bucket b with task_off[b] <= t < task_off[b+1]
+    uint32_t lo = 0, hi = nb;   // invariant: task_off[lo] <= t, task_off[hi] > t
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (task_off[mid] <= t) lo = mid;
+        else hi = mid;
+    }
+    uint32_t b = lo;
+    uint32_t k = t - task_off[b];
+    uint32_t start = off[b] + k * seg;
+    uint32_t end = off[b + 1];
+    if (end - start > seg) end = start + seg;
+    XYZZ<F> acc = xyzz_inf<F>();
+    for (uint32_t p = start; p < end; p++) {
+        uint32_t v = vals[p];
+        Affine<F> q = load_pod<Affine<F>>(&bases[v & ~MSM_SIGN]);
+        if (v & MSM_SIGN) q.y = neg(q.y);
+        acc = madd(acc, q);
+    }
+    store_pod(&partial[t], acc);
+}
+
+// ---- 5. merge partials ----------------------------------------------------------------------------
+template <class F>
+__global__ void msm_merge_kernel(const XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__ task_off, uint32_t nb,
+                                 XYZZ<F>* __restrict__ bsum, uint32_t* __restrict__ hot_list, uint32_t* __restrict__ hot_count) {
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    uint32_t t0 = task_off[b], t1 = task_off[b + 1];
+    uint32_t nt = t1 - t0;
+    if (nt > MSM_HOT_TASKS) {
+        hot_list[atomicAdd(hot_count, 1u)] = b;
+        return;
+    }
+    XYZZ<F> acc = xyzz_inf<F>();
+    if (nt > 0) acc = load_pod<XYZZ<F>>(&partial[t0]);
+    for (uint32_t t = t0 + 1; t < t1; t++) acc = add(acc, load_pod<XYZZ<F>>(&partial[t]));
+    store_pod(&bsum[b], acc);
+}
+
+// 64-lane tree reduction through LDS; result valid in lane 0
+template <class F>
+__device__ __forceinline__ XYZZ<F> wave_tree_sum(XYZZ<F> acc, XYZZ<F>* sh) {
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t stride = 32; stride >= 1; stride >>= 1) {
+        sh[lane] = acc;
+        __syncthreads();
+        if (lane < stride) acc = add(acc, sh[lane + stride]);
+        __syncthreads();
+    }
+    return acc;
+}
+
+template <class F>
+__global__ void __launch_bounds__(64)
+msm_hot_kernel(const XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__ task_off,
+               const uint32_t* __restrict__ hot_list, const uint32_t* __restrict__ hot_count, XYZZ<F>* __restrict__ bsum) {
+    __shared__ XYZZ<F> sh[64];
+    const uint32_t nh = *hot_count;
+    for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
+        uint32_t b = hot_list[h];
+        uint32_t t0 = task_off[b], t1 = task_off[b + 1];
+        XYZZ<F> acc = xyzz_inf<F>();
+        for (uint32_t t = t0 + threadIdx.x; t < t1; t += 64) acc = add(acc, load_pod<XYZZ<F>>(&partial[t]));
+        acc = wave_tree_sum(acc, sh);
+        if (threadIdx.x == 0) store_pod(&bsum[b], acc);
+    }
+}
+
+// ---- 6. window reduction ----------------------------------------------------------------------------
+// group g of window w covers digits k in [g*m+1, (g+1)*m]; out = sum_k k*B_k over the group
+template <class F>
+__global__ void __launch_bounds__(64)
+msm_reduce_groups_kernel(const XYZZ<F>* __restrict__ bsum, uint32_t half, uint32_t m, uint32_t groups_per_win,
+                         uint32_t total_groups, XYZZ<F>* __restrict__ gsum) {
+    uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total_groups) return;
+    uint32_t w = gid / groups_per_win, g = gid % groups_per_win;
+    const XYZZ<F>* B = bsum + (uint64_t)w * half + (uint64_t)g * m;   // B[j] = bucket of digit g*m + j + 1
+    XYZZ<F> running = xyzz_inf<F>(), local = xyzz_inf<F>();
+    for (int j = (int)m - 1; j >= 0; j--) {
+        running = add(running, load_pod<XYZZ<F>>(&B[j]));
+        local = add(local, running);
+    }
+    uint32_t base = g * m;
+    if (base != 0) {
+        // local += base * running
+        XYZZ<F> r = xyzz_inf<F>();
+        int top = 31 - __clz(base);
+        for (int bit = top; bit >= 0; bit--) {
+            r = dbl(r);
+            if ((base >> bit) & 1) r = add(r, running);
+        }
+        local = add(local, r);
+    }
+    store_pod(&gsum[gid], local);
+}
+
+template <class F>
+__global__ void __launch_bounds__(64)
+msm_window_sum_kernel(const XYZZ<F>* __restrict__ gsum, uint32_t groups_per_win, XYZZ<F>* __restrict__ wsum) {
+    __shared__ XYZZ<F> sh[64];
+    uint32_t w = blockIdx.x;
+    XYZZ<F> acc = xyzz_inf<F>();
+    for (uint32_t g = threadIdx.x; g < groups_per_win; g += 64)
+        acc = add(acc, load_pod<XYZZ<F>>(&gsum[(uint64_t)w * groups_per_win + g]));
+    acc = wave_tree_sum(acc, sh);
+    if (threadIdx.x == 0) store_pod(&wsum[w], acc);
+}
+
+// ---- host driver ------------------------------------------------------------------------------------
+
+template <class C, int G>
+int msm_windows_device(Ctx* ctx, const void* d_bases, const void* d_scalars, size_t n, bool scalars_mont, int c,
+                       int win_lo, int win_hi, void* h_window_sums) {
+    typedef typename GroupField<C, G>::F F;
+    typedef typename C::FrP FrP;
+    const int nwin = FrP::BITS / c + 1;
+    if (win_hi < 0) win_hi = nwin;
+    if (win_lo < 0 || win_hi > nwin || win_lo >= win_hi || c < 2 || c > 24) {
+        set_error("msm: bad window range [%d,%d) of %d (c=%d)", win_lo, win_hi, nwin, c);
+        return GA_ERR_INVALID;
+    }
+    const int nwl = win_hi - win_lo;
+    XYZZ<F>* out = reinterpret_cast<XYZZ<F>*>(h_window_sums);
+    if (n == 0) {
+        for (int w = 0; w < nwl; w++) out[w] = xyzz_inf<F>();
+        return GA_OK;
+    }
+    if (n >= (1ull << 31)) {
+        set_error("msm: n=%zu exceeds 2^31-1 points per call", n);
+        return GA_ERR_INVALID;
+    }
+    const uint32_t half = 1u << (c - 1);
+    const uint64_t m = (uint64_t)nwl * n;
+    const uint64_t nb64 = (uint64_t)nwl * half;
+    if (m >= (1ull << 32) || nb64 >= (1ull << 31)) {
+        set_error("msm: %d windows x %zu points exceeds the 2^32 pair index space; shard the call", nwl, n);
+        return GA_ERR_INVALID;
+    }
+    const uint32_t nb = (uint32_t)nb64;
+    // SEG: buckets up to 4x the mean size stay one task
+    uint64_t mean = m / nb + 1;
+    uint32_t seg = (uint32_t)(mean * 4 < 256 ? 256 : mean * 4);
+    const uint64_t max_tasks = nb + m / seg + 1;
+    const uint32_t m_groups = half < (uint32_t)MSM_GROUP ? half : (uint32_t)MSM_GROUP;
+    const uint32_t groups_per_win = half / m_groups;
+    const uint32_t total_groups = groups_per_win * nwl;
+
+    uint32_t *keys, *vals, *keys2, *vals2, *off, *ntask, *task_off, *hot_list, *hot_count;
+    XYZZ<F>*partial, *bsum, *gsum, *wsum;
+    void* sort_tmp;
+    GA_CHECK(ctx->scratch_get("msm_keys", m * 4, (void**)&keys));
+    GA_CHECK(ctx->scratch_get("msm_vals", m * 4, (void**)&vals));
+    GA_CHECK(ctx->scratch_get("msm_keys2", m * 4, (void**)&keys2));
+    GA_CHECK(ctx->scratch_get("msm_vals2", m * 4, (void**)&vals2));
+    GA_CHECK(ctx->scratch_get("msm_off", ((uint64_t)nb + 2) * 4, (void**)&off));
+    GA_CHECK(ctx->scratch_get("msm_ntask", ((uint64_t)nb + 2) * 4, (void**)&ntask));
+    GA_CHECK(ctx->scratch_get("msm_task_off", ((uint64_t)nb + 2) * 4, (void**)&task_off));
+    GA_CHECK(ctx->scratch_get("msm_hot", ((uint64_t)nb + 2) * 4, (void**)&hot_list));
+    GA_CHECK(ctx->scratch_get("msm_hot_count", 256, (void**)&hot_count));
+    GA_CHECK(ctx->scratch_get("msm_partial", max_tasks * sizeof(XYZZ<F>), (void**)&partial));
+    GA_CHECK(ctx->scratch_get("msm_bsum", (uint64_t)nb * sizeof(XYZZ<F>), (void**)&bsum));
+    GA_CHECK(ctx->scratch_get("msm_gsum", (uint64_t)total_groups * sizeof(XYZZ<F>), (void**)&gsum));
+    GA_CHECK(ctx->scratch_get("msm_wsum", (uint64_t)nwl * sizeof(XYZZ<F>), (void**)&wsum));
+
+    hipStream_t st = ctx->stream;
+    {
+        StageTimer tm(ctx, "msm_digits");
+        hipLaunchKernelGGL((msm_digits_kernel<FrP>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                           (const uint32_t*)d_scalars, (uint64_t)n, scalars_mont ? 1 : 0, c, nwin, win_lo, win_hi, keys, vals);
+        GA_KERNEL_CHECK();
+    }
+    {
+        StageTimer tm(ctx, "msm_sort");
+        int end_bit = 1;
+        while ((1ull << end_bit) <= nb64) end_bit++;   // keys take values 0..nb (nb = SKIP)
+        size_t tmp_bytes = 0;
+        GA_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, (unsigned)m, 0, end_bit, st));
+        GA_CHECK(ctx->scratch_get("msm_sort_tmp", tmp_bytes + 256, &sort_tmp));
+        GA_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(sort_tmp, tmp_bytes, keys, keys2, vals, vals2, (unsigned)m, 0, end_bit, st));
+    }
+    {
+        StageTimer tm(ctx, "msm_tasks");
+        hipLaunchKernelGGL(msm_offsets_kernel, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, (const uint32_t*)keys2, m, nb, off);
+        hipLaunchKernelGGL(msm_tasks_kernel, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, (const uint32_t*)off, nb, seg, ntask);
+        GA_KERNEL_CHECK();
+        size_t tmp_bytes = 0;
+        GA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, ntask, task_off, (int)(nb + 1), st));
+        GA_CHECK(ctx->scratch_get("msm_scan_tmp", tmp_bytes + 256, &sort_tmp));
+        GA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(sort_tmp, tmp_bytes, ntask, task_off, (int)(nb + 1), st));
+        GA_HIP_CHECK(hipMemsetAsync(hot_count, 0, 4, st));
+    }
+    {
+        StageTimer tm(ctx, "msm_accumulate");
+        hipLaunchKernelGGL((msm_accumulate_kernel<F>), dim3((unsigned)((max_tasks + 255) / 256)), dim3(256), 0, st,
+                           (const Affine<F>*)d_bases, (const uint32_t*)vals2, (const uint32_t*)off, (const uint32_t*)task_off, nb,
+                           seg, partial);
+        GA_KERNEL_CHECK();
+    }
+    {
+        StageTimer tm(ctx, "msm_merge");
+        hipLaunchKernelGGL((msm_merge_kernel<F>), dim3((nb + 255) / 256), dim3(256), 0, st, (const XYZZ<F>*)partial,
+                           (const uint32_t*)task_off, nb, bsum, hot_list, hot_count);
+        hipLaunchKernelGGL((msm_hot_kernel<F>), dim3(512), dim3(64), 0, st, (const XYZZ<F>*)partial, (const uint32_t*)task_off,
+                           (const uint32_t*)hot_list, (const uint32_t*)hot_count, bsum);
+        GA_KERNEL_CHECK();
+    }
+    {
+        StageTimer tm(ctx, "msm_reduce");
+        hipLaunchKernelGGL((msm_reduce_groups_kernel<F>), dim3((total_groups + 63) / 64), dim3(64), 0, st, (const XYZZ<F>*)bsum,
+                           half, m_groups, groups_per_win, total_groups, gsum);
+        hipLaunchKernelGGL((msm_window_sum_kernel<F>), dim3(nwl), dim3(64), 0, st, (const XYZZ<F>*)gsum, groups_per_win, wsum);
+        GA_KERNEL_CHECK();
+    }
+    GA_HIP_CHECK(hipMemcpyAsync(out, wsum, (size_t)nwl * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
+    GA_HIP_CHECK(hipStreamSynchronize(st));
+    return GA_OK;
+}
+
+}  // namespace ga

@@ -1,0 +1,414 @@
+// Radix-2 NTT / iNTT over the scalar field Fr for gfx950, with gnark-crypto's ordering conventions.
+//
+// Replaces fft.Domain.FFT / FFTInverse as used by computeH (backend/groth16/bn254/prove.go:346-389) and the
+// ICICLE ntt.Ntt calls (backend/accelerated/icicle/groth16/bn254/icicle.go:1425,1428,1474):
+//   DIF: natural in -> bit-reversed out;  DIT: bit-reversed in -> natural out;
+//   inverse includes 1/n;  OnCoset: forward pre-scales coefficient i by g^i, inverse post-scales by g^-i.
+//
+// Design (HBM-bound shape: 64 B algorithmic traffic per element per transform):
+//   * log2(n) butterfly stages are split into passes; one pass = one kernel = one HBM round trip.  A pass owns
+//     K consecutive stages [s_lo, s_lo+K); a workgroup stages a tile of 2^K strided rows x 2^lc contiguous
+//     columns (x 2^g independent groups) in LDS, runs the K stages out of LDS and writes the tile back.
+//   * global traffic is 16 B per lane, lanes walking consecutive 16-byte halves of consecutive elements
+//     (2^lc * 32 B contiguous per row), so every pass streams at full width even for the strided top stages.
+//   * LDS layout is two planes of uint4 (low / high 16 bytes of each element): a butterfly's ds_read_b128 /
+//     ds_write_b128 are conflict-free for unit-stride lanes.
+//   * coset scaling and the 1/n factor are fused into the first / last pass (two small power tables:
+//     g^k for k < 2^12 and g^(k*2^12)), so OnCoset transforms cost no extra HBM pass.
+#pragma once
+#include "common.cuh"
+
+namespace ga {
+
+constexpr int NTT_LG_TILE = 10;               // 1024 elements = 32 KiB of LDS per workgroup
+constexpr int NTT_THREADS = 256;
+constexpr int NTT_POW_LO_BITS = 12;
+
+struct NttScale {
+    int mode;                 // 0 none, 1 constant only, 2 power tables (lo*hi), constant folded into lo
+    int bitrev;               // index the power by bitrev(i) instead of i
+    const uint32_t* lo;       // [2^lo_bits] g^k (* const)
+    const uint32_t* hi;       // [n >> lo_bits] g^(k << lo_bits)
+    int lo_bits;
+    uint32_t cst[8];          // mode 1: constant factor (Montgomery)
+};
+
+struct NttPass {
+    int s_lo, K, lc;
+};
+
+// global element index of local slot l of tile `tile`
+__device__ __forceinline__ uint64_t ntt_gidx(uint32_t l, uint64_t tile, int lg_tile, int s_lo, int K, int lc) {
+    uint32_t col = l & ((1u << lc) - 1);
+    uint32_t mid = (l >> lc) & ((1u << K) - 1);
+    uint32_t grp = l >> (lc + K);
+    uint64_t u = (tile << (lg_tile - lc - K)) | grp;
+    uint64_t lo_chunk = u & ((1ull << (s_lo - lc)) - 1);
+    uint64_t hi = u >> (s_lo - lc);
+    return (hi << (s_lo + K)) | ((uint64_t)mid << s_lo) | (lo_chunk << lc) | col;
+}
+
+__device__ __forceinline__ uint64_t bitrev64(uint64_t i, int logn) {
+    uint32_t lo = __brev((uint32_t)i), hi = __brev((uint32_t)(i >> 32));
+    uint64_t r = ((uint64_t)lo << 32) | hi;
+    return r >> (64 - logn);
+}
+
+template <class FrP>
+__device__ __forceinline__ Fe<FrP> ntt_scale_factor(const NttScale& sc, uint64_t i, int logn) {
+    if (sc.mode == 1) {
+        Fe<FrP> f;
+#pragma unroll
+        for (int k = 0; k < 8; k++) f.l[k] = sc.cst[k];
+        return f;
+    }
+    uint64_t idx = sc.bitrev ? bitrev64(i, logn) : i;
+    Fe<FrP> a = load_fe<FrP>(sc.lo + (idx & ((1ull << sc.lo_bits) - 1)) * 8);
+    uint64_t h = idx >> sc.lo_bits;
+    if (h == 0 && logn <= sc.lo_bits) return a;
+    Fe<FrP> b = load_fe<FrP>(sc.hi + h * 8);
+    return mul(a, b);
+}
+
+template <class FrP>
+struct LdsTile {
+    u32x4* p0;
+    u32x4* p1;
+    __device__ __forceinline__ Fe<FrP> get(uint32_t l) const {
+        Fe<FrP> r;
+        u32x4 a = p0[l], b = p1[l];
+        r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+        r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+        return r;
+    }
+    __device__ __forceinline__ void put(uint32_t l, const Fe<FrP>& v) const {
+        u32x4 a, b;
+        a.x = v.l[0]; a.y = v.l[1]; a.z = v.l[2]; a.w = v.l[3];
+        b.x = v.l[4]; b.y = v.l[5]; b.z = v.l[6]; b.w = v.l[7];
+        p0[l] = a;
+        p1[l] = b;
+    }
+};
+
+// One pass over stages [s_lo, s_lo+K).  DIT_ = false: DIF butterflies, stages descending; true: DIT, ascending.
+template <class FrP, bool DIT_>
+__global__ void __launch_bounds__(NTT_THREADS)
+ntt_pass_kernel(uint32_t* __restrict__ data, const uint32_t* __restrict__ tw, int logn, int lg_tile, int s_lo, int K,
+                int lc, NttScale pre, NttScale post) {
+    static_assert(FrP::N == 8, "Fr is 4x64-bit limbs on both curves");
+    __shared__ u32x4 lds[2 << NTT_LG_TILE];
+    LdsTile<FrP> T{lds, lds + (1 << NTT_LG_TILE)};
+    const uint32_t tile_elems = 1u << lg_tile;
+    const uint64_t tile = blockIdx.x;
+    const uint32_t tid = threadIdx.x;
+    u32x4* g = reinterpret_cast<u32x4*>(data);
+
+    // ---- load: chunk = 16 bytes; consecutive lanes -> consecutive chunks
+    for (uint32_t ch = tid; ch < 2 * tile_elems; ch += NTT_THREADS) {
+        uint32_t l = ch >> 1, half = ch & 1;
+        uint64_t i = ntt_gidx(l, tile, lg_tile, s_lo, K, lc);
+        u32x4 v = g[i * 2 + half];
+        (half ? T.p1 : T.p0)[l] = v;
+    }
+    __syncthreads();
+
+    if (pre.mode != 0) {
+        for (uint32_t l = tid; l < tile_elems; l += NTT_THREADS) {
+            uint64_t i = ntt_gidx(l, tile, lg_tile, s_lo, K, lc);
+            T.put(l, mul(T.get(l), ntt_scale_factor<FrP>(pre, i, logn)));
+        }
+        __syncthreads();
+    }
+
+    for (int k = 0; k < K; k++) {
+        const int t = DIT_ ? k : (K - 1 - k);
+        const int lb = lc + t;
+        const int s = s_lo + t;
+        for (uint32_t q = tid; q < tile_elems / 2; q += NTT_THREADS) {
+            uint32_t l0 = ((q >> lb) << (lb + 1)) | (q & ((1u << lb) - 1));
+            uint32_t l1 = l0 | (1u << lb);
+            uint64_t i0 = ntt_gidx(l0, tile, lg_tile, s_lo, K, lc);
+            uint64_t e = (i0 & ((1ull << s) - 1)) << (logn - 1 - s);
+            Fe<FrP> x = T.get(l0), y = T.get(l1);
+            if (DIT_) {
+                if (e != 0) y = mul(y, load_fe<FrP>(tw + e * 8));
+                T.put(l0, add(x, y));
+                T.put(l1, sub(x, y));
+            } else {
+                Fe<FrP> d = sub(x, y);
+                if (e != 0) d = mul(d, load_fe<FrP>(tw + e * 8));
+                T.put(l0, add(x, y));
+                T.put(l1, d);
+            }
+        }
+        __syncthreads();
+    }
+
+    if (post.mode != 0) {
+        for (uint32_t l = tid; l < tile_elems; l += NTT_THREADS) {
+            uint64_t i = ntt_gidx(l, tile, lg_tile, s_lo, K, lc);
+            T.put(l, mul(T.get(l), ntt_scale_factor<FrP>(post, i, logn)));
+        }
+        __syncthreads();
+    }
+
+    for (uint32_t ch = tid; ch < 2 * tile_elems; ch += NTT_THREADS) {
+        uint32_t l = ch >> 1, half = ch & 1;
+        uint64_t i = ntt_gidx(l, tile, lg_tile, s_lo, K, lc);
+        g[i * 2 + half] = (half ? T.p1 : T.p0)[l];
+    }
+}
+
+// tw[e] = w^e for e < count, from the table of w^(2^k)
+template <class FrP>
+__global__ void ntt_twiddle_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ pow2, uint64_t count,
+                                   int nbits) {
+    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= count) return;
+    Fe<FrP> r = fe_one<FrP>();
+    for (int k = 0; k < nbits; k++)
+        if ((e >> k) & 1) r = mul(r, load_fe<FrP>(pow2 + k * 8));
+    store_fe(out + e * 8, r);
+}
+
+// a[i] = (a[i]*b[i] - c[i]) * den      (prove.go:377-383)
+template <class FrP>
+__global__ void ntt_pointwise_h_kernel(uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
+                                       const uint32_t* __restrict__ c, uint64_t n, NttScale den) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fe<FrP> d;
+#pragma unroll
+    for (int k = 0; k < 8; k++) d.l[k] = den.cst[k];
+    Fe<FrP> x = load_fe<FrP>(a + i * 8), y = load_fe<FrP>(b + i * 8), z = load_fe<FrP>(c + i * 8);
+    store_fe(a + i * 8, mul(sub(mul(x, y), z), d));
+}
+
+// ---- host side -----------------------------------------------------------------------------------
+
+struct Domain {
+    Ctx* ctx = nullptr;
+    int curve = 0;
+    uint64_t n = 0;
+    int logn = 0;
+    uint32_t* d_tw = nullptr;       // w^e,  e < n/2
+    uint32_t* d_tw_inv = nullptr;   // w^-e
+    // coset power tables
+    uint32_t* d_g_lo = nullptr;     // g^k
+    uint32_t* d_g_hi = nullptr;
+    uint32_t* d_gi_lo = nullptr;    // g^-k / n
+    uint32_t* d_gi_hi = nullptr;
+    uint32_t* d_gn_lo = nullptr;    // g^k / n   (computeH: coset FFT fused with the 1/n of the preceding iFFT)
+    uint32_t ninv[8];               // 1/n (Montgomery)
+    uint32_t den[8];                // (g^n - 1)^-1 (Montgomery), prove.go:370-373
+    std::vector<NttPass> passes;    // ascending stage order
+};
+
+inline std::vector<NttPass> ntt_plan(int logn) {
+    std::vector<NttPass> v;
+    if (logn == 0) return v;
+    int k0 = logn < NTT_LG_TILE ? logn : NTT_LG_TILE;
+    v.push_back({0, k0, 0});
+    int rem = logn - k0;
+    if (rem == 0) return v;
+    const int LC = 3;                       // 8 contiguous elements = 256 B per strided row
+    const int KUP = NTT_LG_TILE - LC;
+    int np = (rem + KUP - 1) / KUP;
+    int s = k0;
+    for (int p = 0; p < np; p++) {
+        int K = rem / np + (p < rem % np ? 1 : 0);
+        v.push_back({s, K, LC});
+        s += K;
+    }
+    return v;
+}
+
+template <class FrP>
+int ntt_run(Domain* d, uint32_t* d_data, bool inverse, bool dit, const NttScale& pre_first, const NttScale& post_last) {
+    Ctx* ctx = d->ctx;
+    const uint32_t* tw = inverse ? d->d_tw_inv : d->d_tw;
+    NttScale none;
+    memset(&none, 0, sizeof(none));
+    int np = (int)d->passes.size();
+    for (int p = 0; p < np; p++) {
+        const NttPass& ps = dit ? d->passes[p] : d->passes[np - 1 - p];
+        int lg_tile = d->logn < NTT_LG_TILE ? d->logn : NTT_LG_TILE;
+        uint64_t tiles = d->n >> lg_tile;
+        const NttScale& pre = (p == 0) ? pre_first : none;
+        const NttScale& post = (p == np - 1) ? post_last : none;
+        StageTimer st(ctx, dit ? "ntt_pass_dit" : "ntt_pass_dif");
+        if (dit)
+            hipLaunchKernelGGL((ntt_pass_kernel<FrP, true>), dim3((unsigned)tiles), dim3(NTT_THREADS), 0, ctx->stream,
+                               d_data, tw, d->logn, lg_tile, ps.s_lo, ps.K, ps.lc, pre, post);
+        else
+            hipLaunchKernelGGL((ntt_pass_kernel<FrP, false>), dim3((unsigned)tiles), dim3(NTT_THREADS), 0, ctx->stream,
+                               d_data, tw, d->logn, lg_tile, ps.s_lo, ps.K, ps.lc, pre, post);
+        GA_KERNEL_CHECK();
+    }
+    return GA_OK;
+}
+
+inline NttScale scale_none() {
+    NttScale s;
+    memset(&s, 0, sizeof(s));
+    return s;
+}
+inline NttScale scale_const(const uint32_t* c) {
+    NttScale s = scale_none();
+    s.mode = 1;
+    memcpy(s.cst, c, 32);
+    return s;
+}
+inline NttScale scale_pow(const uint32_t* lo, const uint32_t* hi, bool bitrev) {
+    NttScale s = scale_none();
+    s.mode = 2;
+    s.bitrev = bitrev ? 1 : 0;
+    s.lo = lo;
+    s.hi = hi;
+    s.lo_bits = NTT_POW_LO_BITS;
+    return s;
+}
+
+// gnark semantics wrapper: see header comment
+template <class FrP>
+int ntt_fft(Domain* d, uint32_t* d_data, int direction, int decimation, int on_coset) {
+    if (d->logn == 0) return GA_OK;
+    bool inverse = direction == GA_FFT_INVERSE;
+    bool dit = decimation == GA_DIT;
+    NttScale pre = scale_none(), post = scale_none();
+    if (!inverse) {
+        if (on_coset) pre = scale_pow(d->d_g_lo, d->d_g_hi, /*bitrev=*/dit);
+    } else {
+        if (on_coset) post = scale_pow(d->d_gi_lo, d->d_gi_hi, /*bitrev=*/!dit);
+        else post = scale_const(d->ninv);
+    }
+    return ntt_run<FrP>(d, d_data, inverse, dit, pre, post);
+}
+
+// computeH on device buffers of exactly n elements each (already zero-padded); result in d_a (bit-reversed)
+template <class FrP>
+int ntt_compute_h(Domain* d, uint32_t* d_a, uint32_t* d_b, uint32_t* d_c) {
+    Ctx* ctx = d->ctx;
+    uint32_t* v[3] = {d_a, d_b, d_c};
+    if (d->logn == 0) {
+        // n = 1: iFFT and coset FFT are identities
+        NttScale den = scale_const(d->den);
+        hipLaunchKernelGGL((ntt_pointwise_h_kernel<FrP>), dim3(1), dim3(64), 0, ctx->stream, d_a, d_b, d_c, d->n, den);
+        GA_KERNEL_CHECK();
+        return GA_OK;
+    }
+    for (int k = 0; k < 3; k++) {
+        // iFFT (DIF) without its 1/n ...
+        GA_CHECK(ntt_run<FrP>(d, v[k], /*inverse=*/true, /*dit=*/false, scale_none(), scale_none()));
+        // ... which is folded into the coset pre-scale of the forward DIT: factor g^bitrev(i) / n
+        GA_CHECK(ntt_run<FrP>(d, v[k], /*inverse=*/false, /*dit=*/true, scale_pow(d->d_gn_lo, d->d_g_hi, true),
+                              scale_none()));
+    }
+    {
+        StageTimer st(ctx, "h_pointwise");
+        NttScale den = scale_const(d->den);
+        unsigned blocks = (unsigned)((d->n + 255) / 256);
+        hipLaunchKernelGGL((ntt_pointwise_h_kernel<FrP>), dim3(blocks), dim3(256), 0, ctx->stream, d_a, d_b, d_c, d->n, den);
+        GA_KERNEL_CHECK();
+    }
+    return ntt_fft<FrP>(d, d_a, GA_FFT_INVERSE, GA_DIF, 1);
+}
+
+template <class FrP>
+int domain_init(Ctx* ctx, Domain* d, int curve, uint64_t n) {
+    typedef Fe<FrP> F;
+    d->ctx = ctx;
+    d->curve = curve;
+    d->n = n;
+    d->logn = ilog2_u64(n);
+    if ((1ull << d->logn) != n || d->logn > FrP::ADICITY) {
+        set_error("domain cardinality %llu is not a power of two <= 2^%d", (unsigned long long)n, FrP::ADICITY);
+        return GA_ERR_INVALID;
+    }
+    d->passes = ntt_plan(d->logn);
+    // host: w = ROOT^(2^(adicity-logn)), inverse likewise; tables of w^(2^k)
+    F w = fe_const<FrP>(FrP::ROOT), wi = fe_const<FrP>(FrP::ROOT_INV);
+    for (int k = 0; k < FrP::ADICITY - d->logn; k++) {
+        w = sqr(w);
+        wi = sqr(wi);
+    }
+    F g = fe_const<FrP>(FrP::GEN), gi = fe_const<FrP>(FrP::GEN_INV);
+    // 1/n = (1/2)^logn
+    F two = add(fe_one<FrP>(), fe_one<FrP>());
+    F half = inv(two);
+    F ninv = fe_one<FrP>();
+    for (int k = 0; k < d->logn; k++) ninv = mul(ninv, half);
+    memcpy(d->ninv, ninv.l, 32);
+    // den = (g^n - 1)^-1
+    F gn = g;
+    for (int k = 0; k < d->logn; k++) gn = sqr(gn);
+    F den = inv(sub(gn, fe_one<FrP>()));
+    memcpy(d->den, den.l, 32);
+
+    const int nb = d->logn > 0 ? d->logn - 1 : 0;   // exponent bits of the twiddle tables (e < n/2)
+    uint64_t half_n = n / 2;
+    if (half_n > 0) {
+        std::vector<uint32_t> p2(2 * 32 * 8, 0);
+        F a = w, b = wi;
+        for (int k = 0; k < 32; k++) {
+            memcpy(&p2[k * 8], a.l, 32);
+            memcpy(&p2[(32 + k) * 8], b.l, 32);
+            a = sqr(a);
+            b = sqr(b);
+        }
+        void* d_p2 = nullptr;
+        GA_HIP_CHECK(hipMalloc(&d_p2, p2.size() * 4));
+        GA_HIP_CHECK(hipMemcpy(d_p2, p2.data(), p2.size() * 4, hipMemcpyHostToDevice));
+        GA_HIP_CHECK(hipMalloc((void**)&d->d_tw, half_n * 32));
+        GA_HIP_CHECK(hipMalloc((void**)&d->d_tw_inv, half_n * 32));
+        unsigned blocks = (unsigned)((half_n + 255) / 256);
+        hipLaunchKernelGGL((ntt_twiddle_kernel<FrP>), dim3(blocks), dim3(256), 0, ctx->stream, d->d_tw,
+                           (const uint32_t*)d_p2, half_n, nb);
+        hipLaunchKernelGGL((ntt_twiddle_kernel<FrP>), dim3(blocks), dim3(256), 0, ctx->stream, d->d_tw_inv,
+                           (const uint32_t*)d_p2 + 32 * 8, half_n, nb);
+        GA_KERNEL_CHECK();
+        GA_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        GA_HIP_CHECK(hipFree(d_p2));
+    }
+    // coset power tables (host-computed: <= 2^12 + n/2^12 entries each)
+    uint64_t nlo = 1ull << NTT_POW_LO_BITS;
+    uint64_t nhi = (n >> NTT_POW_LO_BITS) ? (n >> NTT_POW_LO_BITS) : 1;
+    auto build = [&](const F& base, const F& c0, uint32_t** dlo, uint32_t** dhi) -> int {
+        std::vector<uint32_t> lo(nlo * 8), hi(nhi * 8);
+        F acc = c0;
+        for (uint64_t k = 0; k < nlo; k++) {
+            memcpy(&lo[k * 8], acc.l, 32);
+            acc = mul(acc, base);
+        }
+        F step = base;
+        for (int k = 0; k < NTT_POW_LO_BITS; k++) step = sqr(step);
+        acc = fe_one<FrP>();
+        for (uint64_t k = 0; k < nhi; k++) {
+            memcpy(&hi[k * 8], acc.l, 32);
+            acc = mul(acc, step);
+        }
+        GA_HIP_CHECK(hipMalloc((void**)dlo, nlo * 32));
+        GA_HIP_CHECK(hipMemcpy(*dlo, lo.data(), nlo * 32, hipMemcpyHostToDevice));
+        if (dhi) {
+            GA_HIP_CHECK(hipMalloc((void**)dhi, nhi * 32));
+            GA_HIP_CHECK(hipMemcpy(*dhi, hi.data(), nhi * 32, hipMemcpyHostToDevice));
+        }
+        return GA_OK;
+    };
+    GA_CHECK(build(g, fe_one<FrP>(), &d->d_g_lo, &d->d_g_hi));
+    GA_CHECK(build(gi, ninv, &d->d_gi_lo, &d->d_gi_hi));
+    GA_CHECK(build(g, ninv, &d->d_gn_lo, nullptr));
+    return GA_OK;
+}
+
+inline void domain_free(Domain* d) {
+    hipFree(d->d_tw);
+    hipFree(d->d_tw_inv);
+    hipFree(d->d_g_lo);
+    hipFree(d->d_g_hi);
+    hipFree(d->d_gi_lo);
+    hipFree(d->d_gi_hi);
+    hipFree(d->d_gn_lo);
+}
+
+}  // namespace ga

@@ -1,0 +1,12 @@
+// Non-templated accessors of the fft.Domain analogue (see ntt.cuh).
+#include "ntt.cuh"
+namespace ga {
+void ntt_domain_delete(Domain* d) {
+    if (!d) return;
+    domain_free(d);
+    delete d;
+}
+int ntt_domain_curve(const Domain* d) { return d->curve; }
+uint64_t ntt_domain_size(const Domain* d) { return d->n; }
+Ctx* ntt_domain_ctx(const Domain* d) { return d->ctx; }
+}  // namespace ga

@@ -1,0 +1,10 @@
+// Explicit instantiation: synthetic-input / checking kernels, bn254 (see util.cuh).
+#include "util.cuh"
+namespace ga {
+template int util_gen_bases<Bn254, GA_G1>(Ctx*, uint64_t, size_t, void*, void*);
+template int util_gen_bases<Bn254, GA_G2>(Ctx*, uint64_t, size_t, void*, void*);
+template int util_gen_scalars<Bn254>(Ctx*, uint64_t, size_t, void*);
+template int util_fr_dot<Bn254>(Ctx*, const void*, const void*, size_t, void*);
+template int util_gather_fr<Bn254>(Ctx*, void*, const void*, const uint32_t*, size_t);
+template int msm_plan<Bn254>(int, size_t, int*, int*);
+}  // namespace ga

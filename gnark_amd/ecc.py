@@ -1,0 +1,117 @@
+"""Multi-scalar multiplication -- mirror of gnark-crypto's `G1Jac.MultiExp` / `G2Jac.MultiExp` as the reference
+calls them (backend/groth16/bn254/prove.go:194,207,227,237,283), on gnark's own memory images."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .device import Context, DeviceBuffer, _ptr, affine_words, as_u64, curve_id, jac_words
+
+G1, G2 = _lib.G1, _lib.G2
+
+
+def _arg(x, flag):
+    if isinstance(x, DeviceBuffer):
+        return C.c_void_p(x.ptr), flag
+    if isinstance(x, int):
+        return C.c_void_p(x), flag
+    return _ptr(x), 0
+
+
+def MultiExp(ctx: Context, curve, group: int, points, scalars, n: int | None = None, montgomery: bool = True) -> np.ndarray:
+    """sum_i scalars[i] * points[i]  ->  one Jacobian point {X,Y,Z} (uint64 limbs, Montgomery).
+
+    points : (n, 2*fp) [G1] or (n, 4*fp) [G2] uint64 array (G1Affine/G2Affine images) or a DeviceBuffer
+    scalars: (n, 4) uint64 array (fr.Element images) or a DeviceBuffer
+    Errors mirror MultiExp's "len(points) != len(scalars)" check.
+    """
+    cid = curve_id(curve)
+    if not isinstance(points, (DeviceBuffer, int)):
+        points = as_u64(points, affine_words(cid, group))
+        n_p = points.shape[0]
+    else:
+        n_p = n
+    if not isinstance(scalars, (DeviceBuffer, int)):
+        scalars = as_u64(scalars, 4)
+        n_s = scalars.shape[0]
+    else:
+        n_s = n
+    if n_p is None or n_s is None:
+        raise ValueError("n is required when both operands are device buffers")
+    if n_p != n_s:
+        raise ValueError("len(points) != len(scalars)")
+    bp, f1 = _arg(points, _lib.BASES_ON_DEVICE)
+    sp, f2 = _arg(scalars, _lib.SCALARS_ON_DEVICE)
+    flags = f1 | f2 | (_lib.SCALARS_MONTGOMERY if montgomery else 0)
+    out = np.zeros(jac_words(cid, group), dtype=np.uint64)
+    ctx.lib.check(ctx.lib.ga_msm(ctx.handle, cid, group, bp, sp, n_p, flags, _ptr(out)))
+    return out
+
+
+def MultiExpWindows(ctx: Context, curve, group: int, points, scalars, n: int, win_lo: int, win_hi: int, montgomery=True):
+    """Window-sharded MSM (multi-GPU partitioning A): Jacobian window sums for windows [win_lo, win_hi)."""
+    cid = curve_id(curve)
+    c, nw = plan(curve, group, n, lib=ctx.lib)
+    hi = nw if win_hi < 0 else win_hi
+    bp, f1 = _arg(points, _lib.BASES_ON_DEVICE)
+    sp, f2 = _arg(scalars, _lib.SCALARS_ON_DEVICE)
+    flags = f1 | f2 | (_lib.SCALARS_MONTGOMERY if montgomery else 0)
+    out = np.zeros((hi - win_lo, jac_words(cid, group)), dtype=np.uint64)
+    cc, nn = C.c_int(), C.c_int()
+    ctx.lib.check(ctx.lib.ga_msm_windows(ctx.handle, cid, group, bp, sp, n, flags, win_lo, win_hi, _ptr(out), C.byref(cc), C.byref(nn)))
+    return out, cc.value, nn.value
+
+
+def plan(curve, group: int, n: int, lib=None):
+    lib = lib or _lib.load()
+    c, nw = C.c_int(), C.c_int()
+    lib.check(lib.ga_msm_plan(curve_id(curve), group, n, C.byref(c), C.byref(nw)))
+    return c.value, nw.value
+
+
+def combine_windows(curve, group: int, windows: np.ndarray, window_bits: int, lib=None) -> np.ndarray:
+    lib = lib or _lib.load()
+    cid = curve_id(curve)
+    windows = as_u64(windows, jac_words(cid, group))
+    out = np.zeros(jac_words(cid, group), dtype=np.uint64)
+    lib.check(lib.ga_msm_combine_windows(cid, group, _ptr(windows), windows.shape[0], window_bits, _ptr(out)))
+    return out
+
+
+def jac_add(curve, group, a, b, lib=None):
+    lib = lib or _lib.load()
+    cid = curve_id(curve)
+    a, b = np.ascontiguousarray(a, dtype=np.uint64), np.ascontiguousarray(b, dtype=np.uint64)
+    out = np.zeros(jac_words(cid, group), dtype=np.uint64)
+    lib.check(lib.ga_jac_add(cid, group, _ptr(a), _ptr(b), _ptr(out)))
+    return out
+
+
+def jac_to_affine(curve, group, a, lib=None):
+    lib = lib or _lib.load()
+    cid = curve_id(curve)
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    out = np.zeros(affine_words(cid, group), dtype=np.uint64)
+    lib.check(lib.ga_jac_to_affine(cid, group, _ptr(a), _ptr(out)))
+    return out
+
+
+def jac_scalar_mul(curve, group, a, k_canonical: int, lib=None):
+    lib = lib or _lib.load()
+    cid = curve_id(curve)
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    k = np.array([(k_canonical >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+    out = np.zeros(jac_words(cid, group), dtype=np.uint64)
+    lib.check(lib.ga_jac_scalar_mul(cid, group, _ptr(a), _ptr(k), _ptr(out)))
+    return out
+
+
+def generator_mul(curve, group, k_canonical: int, lib=None):
+    lib = lib or _lib.load()
+    cid = curve_id(curve)
+    k = np.array([(k_canonical >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+    out = np.zeros(jac_words(cid, group), dtype=np.uint64)
+    lib.check(lib.ga_generator_mul(cid, group, _ptr(k), _ptr(out)))
+    return out

@@ -1,0 +1,102 @@
+"""Mirror of `backend/accelerated/icicle/groth16` (groth16_icicle.go:79-194, provingkey.go:37-42): a ProvingKey
+whose G1/G2 vectors live on the GPU, `Prove(pk, solution, ...) -> Proof`, and `Proof.WriteTo` bytes.
+
+The solver is out of scope: `Prove` takes what `r1cs.Solve` returns -- W, A, B, C as fr.Element images."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from .device import FP_LIMBS, Context, _ptr, as_u64, curve_id
+
+
+@dataclass
+class Solution:
+    """constraint/bn254/system.go:162-165 R1CSSolution: W (nbWires), A, B, C (nbConstraints)."""
+    W: np.ndarray
+    A: np.ndarray
+    B: np.ndarray
+    C: np.ndarray
+
+
+@dataclass
+class Proof:
+    """backend/groth16/bn254/prove.go:34-39 (no commitments): affine images, Montgomery limbs."""
+    curve: int
+    Ar: np.ndarray
+    Bs: np.ndarray
+    Krs: np.ndarray
+    _lib: object = None
+
+    def raw(self) -> np.ndarray:
+        return np.concatenate([self.Ar, self.Bs, self.Krs]).astype(np.uint64)
+
+    def WriteTo(self) -> bytes:
+        """Proof.WriteTo (marshal.go:33-58): compressed Ar | Bs | Krs | u32 0 | CommitmentPok."""
+        lib = self._lib or _lib.load()
+        raw = self.raw()
+        out = np.zeros(512, dtype=np.uint8)
+        n = C.c_size_t()
+        lib.check(lib.ga_g16_proof_marshal(self.curve, _ptr(raw), _ptr(out), out.nbytes, C.byref(n)))
+        return out[: n.value].tobytes()
+
+
+class ProvingKey:
+    """setup.go:25-48 fields, uploaded once ("PinToGPU"); free with FreeGPUResources() (icicle.go:1493)."""
+
+    def __init__(self, ctx: Context, curve, *, domain_cardinality, alpha1, beta1, delta1, A, B, Z, K, beta2, delta2, B2,
+                 infinityA, infinityB):
+        cid = curve_id(curve)
+        fp = FP_LIMBS[cid]
+        self.ctx, self.curve = ctx, cid
+        g1 = lambda v: as_u64(np.asarray(v).reshape(-1, 2 * fp), 2 * fp)
+        g2 = lambda v: as_u64(np.asarray(v).reshape(-1, 4 * fp), 4 * fp)
+        A, B, Z, K, B2 = g1(A), g1(B), g1(Z), g1(K), g2(B2)
+        alpha1, beta1, delta1, beta2, delta2 = g1(alpha1), g1(beta1), g1(delta1), g2(beta2), g2(delta2)
+        ia = np.ascontiguousarray(infinityA, dtype=np.uint8)
+        ib = np.ascontiguousarray(infinityB, dtype=np.uint8)
+        if ia.shape != ib.shape:
+            raise ValueError("InfinityA and InfinityB must have nbWires entries each")
+        key = _lib.G16Key()
+        key.curve, key.domain_cardinality = cid, int(domain_cardinality)
+        key.g1_alpha, key.g1_beta, key.g1_delta = alpha1.ctypes.data, beta1.ctypes.data, delta1.ctypes.data
+        key.g1_a, key.len_a = A.ctypes.data, A.shape[0]
+        key.g1_b, key.len_b = B.ctypes.data, B.shape[0]
+        key.g1_z, key.len_z = Z.ctypes.data, Z.shape[0]
+        key.g1_k, key.len_k = K.ctypes.data, K.shape[0]
+        key.g2_beta, key.g2_delta = beta2.ctypes.data, delta2.ctypes.data
+        key.g2_b, key.len_b2 = B2.ctypes.data, B2.shape[0]
+        key.infinity_a, key.infinity_b = ia.ctypes.data, ib.ctypes.data
+        key.nb_wires = ia.shape[0]
+        key.nb_infinity_a, key.nb_infinity_b = int(ia.sum()), int(ib.sum())
+        h = C.c_void_p()
+        ctx.lib.check(ctx.lib.ga_g16_pk_create(ctx.handle, C.byref(key), C.byref(h)))
+        self.handle = h
+        self.nb_wires = int(key.nb_wires)
+        self.domain_cardinality = int(domain_cardinality)
+
+    def FreeGPUResources(self):
+        if self.handle:
+            self.ctx.lib.ga_g16_pk_destroy(self.handle)
+            self.handle = None
+
+
+def Prove(pk: ProvingKey, solution: Solution, nb_public: int, r: np.ndarray, s: np.ndarray) -> Proof:
+    """groth16.Prove from the solver's output (prove.go:130-315).  r, s: fr.Element images (Montgomery) of the
+    prover's randomness -- gnark samples them with crypto/rand (prove.go:171-177); the caller supplies them here."""
+    if pk.handle is None:
+        raise _lib.GnarkAmdError("proving key has been freed")
+    W, A, B, Cc = (as_u64(x, 4) for x in (solution.W, solution.A, solution.B, solution.C))
+    if W.shape[0] != pk.nb_wires:
+        raise ValueError(f"len(W)={W.shape[0]} != nbWires={pk.nb_wires}")
+    if not (A.shape == B.shape == Cc.shape):
+        raise ValueError("A, B, C must have the same length")
+    r, s = as_u64(np.asarray(r).reshape(1, 4), 4), as_u64(np.asarray(s).reshape(1, 4), 4)
+    fp = FP_LIMBS[pk.curve]
+    out = np.zeros(8 * fp, dtype=np.uint64)
+    lib = pk.ctx.lib
+    lib.check(lib.ga_g16_prove(pk.handle, _ptr(W), _ptr(A), _ptr(B), _ptr(Cc), A.shape[0], nb_public, _ptr(r), _ptr(s), _ptr(out)))
+    return Proof(pk.curve, out[: 2 * fp].copy(), out[2 * fp: 6 * fp].copy(), out[6 * fp:].copy(), lib)

@@ -1,0 +1,192 @@
+/* gnark_amd.h -- C ABI of libgnark_amd.so, the MI355X (gfx950) prover backend for gnark.
+ *
+ * This is the drop-in boundary: the surface a Go package `backend/accelerated/mi355x/groth16` binds through
+ * cgo in place of the ~20 ICICLE entry points that backend/accelerated/icicle/groth16/bn254/icicle.go uses
+ * (reference line numbers below are into /root/reference).  INTEGRATION.md shows the cgo stub.
+ *
+ * Conventions
+ *  - All field elements / points are gnark-crypto memory images: little-endian 64-bit limbs in Montgomery
+ *    form (fr.Element = [4]uint64; fp.Element = [4]uint64 BN254 / [6]uint64 BLS12-381); G1Affine = {X,Y};
+ *    G2Affine = {X{A0,A1}, Y{A0,A1}}; point at infinity = all-zero coordinates; G1Jac/G2Jac = {X,Y,Z}.
+ *    A Go slice `[]fr.Element` / `[]curve.G1Affine` can be passed as `unsafe.Pointer(&s[0])` unchanged.
+ *  - No pointer passed in is retained after the call returns (cgo pointer rules): inputs are copied to
+ *    device memory (or are already device pointers, see GA_*_ON_DEVICE) before the function returns.
+ *  - Every entry point selects its device itself (hipSetDevice), so callers need not pin OS threads
+ *    (icicle.go relies on RunOnDevice + LockOSThread instead).
+ *  - Every function returns GA_OK (0) or a negative error code; ga_last_error() gives the message for the
+ *    calling thread.  There is NO CPU fallback: without a usable HIP device ga_ctx_create fails.
+ *  - One proof at a time per context: calls on one ga_ctx are serialised by an internal mutex
+ *    (icicle.go:77-86,821-823 keeps a per-device prove mutex for the same reason).
+ */
+#ifndef GNARK_AMD_H
+#define GNARK_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GA_OK 0
+#define GA_ERR_INVALID (-1)   /* bad argument */
+#define GA_ERR_HIP (-2)       /* HIP runtime error (message in ga_last_error) */
+#define GA_ERR_NOMEM (-3)     /* device allocation failed */
+#define GA_ERR_STATE (-4)     /* object used in the wrong state */
+
+/* curve ids (ecc.ID analogue; only the two curves of BASELINE.json are built) */
+#define GA_BN254 0
+#define GA_BLS12_381 1
+
+/* group ids */
+#define GA_G1 0
+#define GA_G2 1
+
+/* flags for ga_msm */
+#define GA_BASES_ON_DEVICE 0x1u        /* `bases` is a device pointer */
+#define GA_SCALARS_ON_DEVICE 0x2u      /* `scalars` is a device pointer */
+#define GA_SCALARS_MONTGOMERY 0x4u     /* scalars are fr.Element images (Montgomery); else canonical LE integers
+                                          (ICICLE's AreScalarsMontgomeryForm, icicle.go:861-863,1232) */
+#define GA_RESULT_WINDOW_SUMS 0x8u     /* multi-GPU window sharding: see ga_msm_windows */
+
+/* NTT direction / ordering, mirroring gnark-crypto fft.Domain.FFT / FFTInverse (prove.go:362-386) */
+#define GA_FFT_FORWARD 0
+#define GA_FFT_INVERSE 1
+#define GA_DIF 0   /* natural in  -> bit-reversed out */
+#define GA_DIT 1   /* bit-reversed in -> natural out  */
+
+typedef struct ga_ctx ga_ctx;         /* one per (process, device) */
+typedef struct ga_domain ga_domain;   /* fft.Domain analogue: twiddles for one (curve, cardinality) */
+typedef struct ga_g16_pk ga_g16_pk;   /* device-resident Groth16 proving key ("PinToGPU", provingkey.go:37-42) */
+
+/* ---- context ------------------------------------------------------------------------------------------
+ * replaces: icicle runtime LoadBackend / CreateDevice / WarmUpDevice (groth16_icicle.go:38-72). */
+int ga_device_count(int* count);
+int ga_ctx_create(int device, ga_ctx** out);
+void ga_ctx_destroy(ga_ctx* ctx);
+const char* ga_last_error(void);
+const char* ga_version(void);
+/* device name / gcn arch / total and free bytes (runtime.GetAvailableMemory, icicle.go:475) */
+int ga_device_info(ga_ctx* ctx, char* name, size_t name_len, uint64_t* total_bytes, uint64_t* free_bytes);
+
+/* ---- raw device buffers (DeviceSlice analogue: icicle.go:120,321,...) ---------------------------------*/
+int ga_malloc(ga_ctx* ctx, size_t bytes, void** dptr);
+int ga_free(ga_ctx* ctx, void* dptr);
+int ga_copy_to_device(ga_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int ga_copy_to_host(ga_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int ga_sync(ga_ctx* ctx);
+
+/* ---- multi-scalar multiplication -----------------------------------------------------------------------
+ * replaces: G1Jac.MultiExp / G2Jac.MultiExp (prove.go:194,207,227,237,283) and icicle msm.Msm / g2.G2Msm
+ * (icicle.go:397,451).  Computes sum_i scalars[i] * bases[i].
+ *   bases   : n affine points (Montgomery), host or device pointer per flags
+ *   scalars : n fr elements, Montgomery if GA_SCALARS_MONTGOMERY
+ *   out_jac : HOST buffer for one Jacobian point {X,Y,Z} (Montgomery) -- castable to curve.G1Jac / G2Jac.
+ * (0,0) bases are treated as infinity and zero scalars are skipped, as gnark-crypto does. */
+int ga_msm(ga_ctx* ctx, int curve, int group, const void* bases, const void* scalars, size_t n, unsigned flags,
+           void* out_jac);
+
+/* Window-sharded variant for multi-GPU partitioning A: only windows [win_lo, win_hi) of the
+ * Pippenger decomposition are accumulated; out_windows receives (win_hi - win_lo) Jacobian window sums W_j,
+ * and *window_bits / *num_windows describe the decomposition so that the caller can all-gather the sums and
+ * Horner-combine them with ga_msm_combine_windows.  win_lo = 0, win_hi = -1 means "all windows". */
+int ga_msm_windows(ga_ctx* ctx, int curve, int group, const void* bases, const void* scalars, size_t n,
+                   unsigned flags, int win_lo, int win_hi, void* out_windows, int* window_bits, int* num_windows);
+/* number of windows / window width ga_msm* will use for an n-point MSM (deterministic in (curve, group, n)) */
+int ga_msm_plan(int curve, int group, size_t n, int* window_bits, int* num_windows);
+/* result = sum_j 2^(window_bits*j) * windows[j]   (host arithmetic; windows are Jacobian, Montgomery) */
+int ga_msm_combine_windows(int curve, int group, const void* windows, int num_windows, int window_bits,
+                           void* out_jac);
+
+/* ---- small host-side group helpers used by the Go epilogue / multi-GPU combine -------------------------
+ * (curve.G1Jac.AddAssign / ScalarMultiplication / FromJacobian, prove.go:199-292).  Host arithmetic. */
+int ga_jac_add(int curve, int group, const void* a_jac, const void* b_jac, void* out_jac);
+int ga_jac_to_affine(int curve, int group, const void* a_jac, void* out_affine);
+int ga_jac_scalar_mul(int curve, int group, const void* a_jac, const void* scalar_canonical_le32,
+                      void* out_jac);
+
+/* ---- NTT -----------------------------------------------------------------------------------------------
+ * replaces: fft.NewDomain (setup.go:101), fft.Domain.FFT / FFTInverse (prove.go:362-368,386) and icicle
+ * ntt.InitDomain / ntt.Ntt (icicle.go:163,1425,1428,1474). */
+int ga_domain_create(ga_ctx* ctx, int curve, uint64_t cardinality, ga_domain** out);
+void ga_domain_destroy(ga_domain* d);
+/* In-place transform of `cardinality` fr elements (Montgomery).  direction: GA_FFT_FORWARD / GA_FFT_INVERSE
+ * (inverse includes the 1/n factor); decimation: GA_DIF / GA_DIT; on_coset: fft.OnCoset() with the domain's
+ * FrMultiplicativeGen (5 for BN254, 7 for BLS12-381).  data is a host pointer unless on_device != 0. */
+int ga_fft(ga_domain* d, void* data, int direction, int decimation, int on_coset, int on_device);
+
+/* computeH (prove.go:346-389 / icicle.go:1391-1488): h = coefficients of (A*B - C)/(X^n - 1) in bit-reversed
+ * order.  a,b,c hold n_constraints fr elements (Montgomery), zero-padded internally to the domain size;
+ * h_out receives cardinality elements.  Pointers are host unless on_device != 0 (then a is clobbered). */
+int ga_compute_h(ga_domain* d, const void* a, const void* b, const void* c, uint64_t n_constraints,
+                 void* h_out, int on_device);
+
+/* ---- Groth16 -------------------------------------------------------------------------------------------
+ * replaces: (*ProvingKey).setupDevicePointers (icicle.go:88-264) and Prove (icicle.go:784-1360).
+ * ga_g16_key describes gnark's groth16 ProvingKey (setup.go:25-48) by pointer+length; everything is copied to
+ * the device synchronously by ga_g16_pk_create. */
+typedef struct ga_g16_key {
+    int curve;
+    uint64_t domain_cardinality;     /* pk.Domain.Cardinality */
+    const void* g1_alpha;            /* G1Affine */
+    const void* g1_beta;
+    const void* g1_delta;
+    const void* g1_a; uint64_t len_a;   /* pk.G1.A (infinity entries removed, setup.go:195-219) */
+    const void* g1_b; uint64_t len_b;   /* pk.G1.B */
+    const void* g1_z; uint64_t len_z;   /* pk.G1.Z, bit-reversed, len n-1 (setup.go:247-249) */
+    const void* g1_k; uint64_t len_k;   /* pk.G1.K */
+    const void* g2_beta;             /* G2Affine */
+    const void* g2_delta;
+    const void* g2_b; uint64_t len_b2;  /* pk.G2.B */
+    const uint8_t* infinity_a;       /* pk.InfinityA as bytes (Go []bool image), len nb_wires */
+    const uint8_t* infinity_b;
+    uint64_t nb_wires;
+    uint64_t nb_infinity_a;
+    uint64_t nb_infinity_b;
+} ga_g16_key;
+
+int ga_g16_pk_create(ga_ctx* ctx, const ga_g16_key* key, ga_g16_pk** out);
+void ga_g16_pk_destroy(ga_g16_pk* pk);   /* FreeGPUResources, icicle.go:1493-1549 */
+
+/* One proof, from the solver's output to the three proof points (prove.go:130-315 minus commitments):
+ *   w        : solution.W, nb_wires fr elements (Montgomery)
+ *   a,b,c    : solution.A/B/C, n_constraints elements each
+ *   nb_public: r1cs.GetNbPublicVariables() (includes the constant-one wire; K scalars start there, prove.go:235)
+ *   r,s      : the prover's randomness as fr elements in Montgomery form (prove.go:171-177 samples them; the Go
+ *              shim samples and passes them so that tests can inject fixed values)
+ *   proof_out: Ar (G1Affine) | Bs (G2Affine) | Krs (G1Affine), Montgomery -- castable to the Proof fields.
+ * All pointers are host pointers. */
+int ga_g16_prove(ga_g16_pk* pk, const void* w, const void* a, const void* b, const void* c,
+                 uint64_t n_constraints, uint64_t nb_public, const void* r, const void* s, void* proof_out);
+
+/* Proof.WriteTo wire format (marshal.go:33-58, no commitments): compressed Ar | Bs | Krs | u32 0 | PoK(inf).
+ * Returns the number of bytes written in *len (164 for BN254, 244 for BLS12-381). */
+int ga_g16_proof_marshal(int curve, const void* proof, uint8_t* out, size_t cap, size_t* len);
+
+/* ---- profiling hooks (ICICLE_STEP_PROFILE analogue, icicle.go:72-75) ------------------------------------
+ * When enabled, every kernel stage is bracketed by hipEvents on the stream it is launched on; ga_profile_read
+ * returns "name=ms;name=ms;..." for the stages recorded since the last ga_profile_reset. */
+int ga_profile_enable(ga_ctx* ctx, int on);
+int ga_profile_reset(ga_ctx* ctx);
+int ga_profile_read(ga_ctx* ctx, char* buf, size_t cap);
+
+/* ---- test / bench support: on-device synthetic key material with known discrete logs --------------------
+ * out[i] = [k_i]G (affine, Montgomery) where k_i = xoshiro-derived 64-bit values expanded from `seed`;
+ * the same k_i are written (as canonical fr elements, 4 limbs) to dlogs_out (device) so that a test can check
+ * MSM(s, P) == [sum s_i k_i] G with a field dot product (SURVEY 8c "known discrete log").  */
+int ga_gen_bases(ga_ctx* ctx, int curve, int group, uint64_t seed, size_t n, void* bases_dev, void* dlogs_dev);
+/* out[i] = uniform fr element (Montgomery) from a counter-based generator keyed by seed (device) */
+int ga_gen_scalars(ga_ctx* ctx, int curve, uint64_t seed, size_t n, void* scalars_dev);
+/* dot = sum a_i * b_i over fr; a Montgomery, b canonical (the dlogs above); result canonical LE (32 bytes, host) */
+int ga_fr_dot(ga_ctx* ctx, int curve, const void* a_dev, const void* b_dev, size_t n, void* out_host);
+/* [k]G for the group generator, k canonical LE 32 bytes (host arithmetic) -> Jacobian */
+int ga_generator_mul(int curve, int group, const void* k_canonical_le32, void* out_jac);
+
+/* integer-multiplier / FMA issue-rate microbenchmarks (SURVEY 8d asks for the v_mad_u64_u32 rate);
+ * writes "name=Gops;..." */
+int ga_microbench(ga_ctx* ctx, char* buf, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNARK_AMD_H */

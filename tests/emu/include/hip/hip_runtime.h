@@ -1,0 +1,326 @@
+// TEST INFRASTRUCTURE ONLY -- a tiny functional emulation of the subset of the HIP runtime and device
+// language that gnark_amd/csrc uses, so that kernel *logic* (indexing, barriers, wave shuffles) can be
+// exercised by `pytest -m "not gpu"` in a container without a GPU.
+//
+// It is never part of the product: gnark_amd/_lib.py only ever loads the hipcc-built libgnark_amd.so and
+// raises if it is missing; tests/emu builds a separate libgnark_amd_emu.so (tests/emu/build_emu.sh) by
+// compiling the unmodified product sources with this directory first on the include path.
+//
+// Model: blocks of a launch run one after another; the threads of a block are real OS threads that meet at
+// pthread barriers for __syncthreads(); a wave is 64 consecutive threads with its own barrier for
+// __shfl*/__ballot.  `__shared__` maps to `static` (blocks are sequential, so one copy is enough).
+#pragma once
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+#include <thread>
+#include <tuple>
+#include <utility>
+#include <vector>
+
+#define GA_HIP_EMULATION 1
+
+#define __host__
+#define __device__
+#define __global__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __launch_bounds__(...)
+#define __restrict__ __restrict
+#define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(::hipemu::dyn_smem());
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+struct uint4 {
+    unsigned x, y, z, w;
+} __attribute__((aligned(16)));
+struct uint2 {
+    unsigned x, y;
+} __attribute__((aligned(8)));
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
+
+namespace hipemu {
+struct Wave {
+    pthread_barrier_t bar;
+    uint64_t scratch[64];
+    uint64_t ballot;
+};
+struct Block {
+    pthread_barrier_t bar;
+    std::vector<Wave> waves;
+    std::vector<char> smem;
+};
+inline Block*& cur_block() {
+    static Block* b = nullptr;
+    return b;
+}
+inline void* dyn_smem() { return cur_block()->smem.data(); }
+struct Idx {
+    unsigned x, y, z;
+};
+}  // namespace hipemu
+
+extern thread_local hipemu::Idx threadIdx;
+extern thread_local hipemu::Idx blockIdx;
+extern thread_local dim3 blockDim;
+extern thread_local dim3 gridDim;
+#ifdef GA_HIP_EMULATION_IMPL
+thread_local hipemu::Idx threadIdx;
+thread_local hipemu::Idx blockIdx;
+thread_local dim3 blockDim;
+thread_local dim3 gridDim;
+#endif
+
+static const int warpSize = 64;
+
+inline void __syncthreads() { pthread_barrier_wait(&hipemu::cur_block()->bar); }
+
+namespace hipemu {
+inline Wave& my_wave() { return cur_block()->waves[threadIdx.x / 64]; }
+inline unsigned lane() { return threadIdx.x % 64; }
+template <class T>
+inline T wave_exchange(T v, unsigned src) {
+    static_assert(sizeof(T) <= 8, "shuffle of <= 8 bytes only");
+    Wave& w = my_wave();
+    uint64_t raw = 0;
+    memcpy(&raw, &v, sizeof(T));
+    w.scratch[lane()] = raw;
+    pthread_barrier_wait(&w.bar);
+    uint64_t got = w.scratch[src % 64];
+    pthread_barrier_wait(&w.bar);
+    T out;
+    memcpy(&out, &got, sizeof(T));
+    return out;
+}
+}  // namespace hipemu
+
+template <class T>
+inline T __shfl(T v, int src, int width = 64) {
+    unsigned l = hipemu::lane();
+    unsigned base = l - (l % width);
+    return hipemu::wave_exchange(v, base + ((unsigned)src % width));
+}
+template <class T>
+inline T __shfl_xor(T v, int mask, int width = 64) {
+    unsigned l = hipemu::lane();
+    unsigned t = l ^ (unsigned)mask;
+    if ((t / width) != (l / width)) t = l;
+    return hipemu::wave_exchange(v, t);
+}
+template <class T>
+inline T __shfl_down(T v, unsigned d, int width = 64) {
+    unsigned l = hipemu::lane();
+    unsigned t = l + d;
+    if ((t / width) != (l / width)) t = l;
+    return hipemu::wave_exchange(v, t);
+}
+template <class T>
+inline T __shfl_up(T v, unsigned d, int width = 64) {
+    unsigned l = hipemu::lane();
+    unsigned t = (l % width) >= d ? l - d : l;
+    return hipemu::wave_exchange(v, t);
+}
+inline unsigned long long __ballot(int pred) {
+    hipemu::Wave& w = hipemu::my_wave();
+    w.scratch[hipemu::lane()] = pred ? 1 : 0;
+    pthread_barrier_wait(&w.bar);
+    unsigned long long m = 0;
+    for (int i = 0; i < 64; i++) m |= (unsigned long long)(w.scratch[i] & 1) << i;
+    pthread_barrier_wait(&w.bar);
+    return m;
+}
+inline int __any(int p) { return __ballot(p) != 0; }
+inline int __all(int p) { return __ballot(p) == ~0ull; }
+inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+inline int __popc(unsigned x) { return __builtin_popcount(x); }
+inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
+inline int __clz(unsigned x) { return x ? __builtin_clz(x) : 32; }
+inline int __clzll(unsigned long long x) { return x ? __builtin_clzll(x) : 64; }
+inline unsigned __brev(unsigned x) {
+    unsigned r = 0;
+    for (int i = 0; i < 32; i++) r |= ((x >> i) & 1u) << (31 - i);
+    return r;
+}
+inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((uint64_t)a * b) >> 32); }
+
+template <class T>
+inline T atomicAdd(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+template <class T>
+inline T atomicMax(T* p, T v) {
+    T old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (old < v && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+    }
+    return old;
+}
+template <class T>
+inline T atomicOr(T* p, T v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+template <class T>
+inline T atomicExch(T* p, T v) { return __atomic_exchange_n(p, v, __ATOMIC_RELAXED); }
+template <class T>
+inline T atomicCAS(T* p, T cmp, T v) {
+    __atomic_compare_exchange_n(p, &cmp, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED);
+    return cmp;
+}
+inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+
+// ---- runtime API ---------------------------------------------------------------------------------
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotReady = 600 };
+typedef struct hipemuStream* hipStream_t;
+struct hipemuEvent {
+    std::chrono::steady_clock::time_point t;
+};
+typedef hipemuEvent* hipEvent_t;
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+enum { hipHostMallocDefault = 0, hipStreamNonBlocking = 1, hipEventDefault = 0 };
+
+struct hipDeviceProp_t {
+    char name[256];
+    char gcnArchName[256];
+    size_t totalGlobalMem;
+    int multiProcessorCount;
+};
+
+inline const char* hipGetErrorString(hipError_t e) { return e == 0 ? "hipSuccess" : "hipemu error"; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipGetDevice(int* d) {
+    *d = 0;
+    return hipSuccess;
+}
+inline hipError_t hipGetDeviceCount(int* n) {
+    *n = 1;
+    return hipSuccess;
+}
+inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
+    memset(p, 0, sizeof(*p));
+    strcpy(p->name, "hipemu (CPU functional emulation)");
+    strcpy(p->gcnArchName, "emu");
+    p->totalGlobalMem = 8ull << 30;
+    p->multiProcessorCount = 1;
+    return hipSuccess;
+}
+inline hipError_t hipMemGetInfo(size_t* f, size_t* t) {
+    *f = 4ull << 30;
+    *t = 8ull << 30;
+    return hipSuccess;
+}
+inline hipError_t hipMalloc(void** p, size_t n) {
+    *p = aligned_alloc(256, (n + 255) / 256 * 256 + 256);
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+template <class T>
+inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
+inline hipError_t hipFree(void* p) {
+    free(p);
+    return hipSuccess;
+}
+inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
+template <class T>
+inline hipError_t hipHostMalloc(T** p, size_t n, unsigned f = 0) { return hipMalloc((void**)p, n); }
+inline hipError_t hipHostFree(void* p) { return hipFree(p); }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) {
+    memmove(d, s, n);
+    return hipSuccess;
+}
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t = nullptr) { return hipMemcpy(d, s, n, k); }
+inline hipError_t hipMemset(void* d, int v, size_t n) {
+    memset(d, v, n);
+    return hipSuccess;
+}
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr) { return hipMemset(d, v, n); }
+inline hipError_t hipStreamCreate(hipStream_t* s) {
+    *s = nullptr;
+    return hipSuccess;
+}
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) {
+    *s = nullptr;
+    return hipSuccess;
+}
+inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned = 0) { return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t* e) {
+    *e = new hipemuEvent();
+    return hipSuccess;
+}
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
+inline hipError_t hipEventDestroy(hipEvent_t e) {
+    delete e;
+    return hipSuccess;
+}
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) {
+    e->t = std::chrono::steady_clock::now();
+    return hipSuccess;
+}
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
+    *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
+    return hipSuccess;
+}
+
+// ---- kernel launch --------------------------------------------------------------------------------
+namespace hipemu {
+template <class F, class Tuple>
+struct LaunchCtx {
+    F f;
+    Tuple args;
+    dim3 grid, block;
+    Block* blk;
+    pthread_barrier_t* blockbar;
+};
+
+template <class F, class Tuple>
+void worker(LaunchCtx<F, Tuple>* c, unsigned tid) {
+    blockDim = c->block;
+    gridDim = c->grid;
+    threadIdx.x = tid % c->block.x;
+    threadIdx.y = (tid / c->block.x) % c->block.y;
+    threadIdx.z = tid / (c->block.x * c->block.y);
+    for (unsigned bz = 0; bz < c->grid.z; bz++)
+        for (unsigned by = 0; by < c->grid.y; by++)
+            for (unsigned bx = 0; bx < c->grid.x; bx++) {
+                blockIdx.x = bx;
+                blockIdx.y = by;
+                blockIdx.z = bz;
+                std::apply(c->f, c->args);
+                pthread_barrier_wait(c->blockbar);   // next block reuses the `static` LDS
+            }
+}
+}  // namespace hipemu
+
+template <class F, class... Args>
+inline void hipLaunchKernelGGL(F kernel, dim3 grid, dim3 block, size_t shmem, hipStream_t, Args... args) {
+    using namespace hipemu;
+    unsigned nthreads = block.x * block.y * block.z;
+    Block blk;
+    pthread_barrier_init(&blk.bar, nullptr, nthreads);
+    blk.waves.resize((nthreads + 63) / 64);
+    for (size_t w = 0; w < blk.waves.size(); w++) {
+        unsigned cnt = std::min<unsigned>(64, nthreads - w * 64);
+        pthread_barrier_init(&blk.waves[w].bar, nullptr, cnt);
+    }
+    blk.smem.resize(shmem + 64);
+    pthread_barrier_t blockbar;
+    pthread_barrier_init(&blockbar, nullptr, nthreads);
+    cur_block() = &blk;
+    auto tup = std::make_tuple(args...);
+    LaunchCtx<F, decltype(tup)> ctx{kernel, tup, grid, block, &blk, &blockbar};
+    if (nthreads == 1) {
+        worker(&ctx, 0);
+    } else {
+        std::vector<std::thread> th;
+        th.reserve(nthreads);
+        for (unsigned t = 0; t < nthreads; t++) th.emplace_back(worker<F, decltype(tup)>, &ctx, t);
+        for (auto& t : th) t.join();
+    }
+    cur_block() = nullptr;
+}

@@ -1,0 +1,156 @@
+"""Kernel-logic checks of the product sources under the functional HIP emulation (tests/emu), against the
+big-integer oracle.  These run on CPU (`-m "not gpu"`); the same cases run on the real GPU in test_gpu_*.py."""
+import numpy as np
+import pytest
+
+import pyref
+from gnark_amd import ecc, fft, groth16
+from helpers import BLS12_381, BN254, arr_to_fr, arr_to_g1_affine, arr_to_g2_affine, fr_to_arr, gen_of, group_of, jac_to_affine_py, pts_to_arr
+
+CURVES = [BN254, BLS12_381]
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("logn", [0, 1, 3, 5])
+def test_emu_fft_all_modes(emu_ctx, c, logn):
+    n = 1 << logn
+    rng = pyref.Xoshiro(100 + logn)
+    a = [rng.field(c.r) for _ in range(n)]
+    d = fft.Domain(emu_ctx, c.name, n)
+    try:
+        for dec in (pyref.DIF, pyref.DIT):
+            for coset in (False, True):
+                for inv in (False, True):
+                    want = pyref.fft(c, a, dec, on_coset=coset, inverse=inv)
+                    run = d.FFTInverse if inv else d.FFT
+                    got = arr_to_fr(c, run(fr_to_arr(c, a), dec, coset))
+                    assert got == want, (dec, coset, inv)
+    finally:
+        d.close()
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_emu_fft_multi_pass(emu_ctx, c):
+    # 2^12 > one LDS tile (2^10): exercises the strided upper pass and the fused scaling of both passes
+    n = 1 << 12
+    rng = pyref.Xoshiro(7)
+    a = [rng.field(c.r) for _ in range(n)]
+    d = fft.Domain(emu_ctx, c.name, n)
+    try:
+        got = arr_to_fr(c, d.FFT(fr_to_arr(c, a), pyref.DIF, True))
+        assert got == pyref.fft(c, a, pyref.DIF, on_coset=True)
+        got = arr_to_fr(c, d.FFTInverse(fr_to_arr(c, a), pyref.DIF, True))
+        assert got == pyref.fft(c, a, pyref.DIF, on_coset=True, inverse=True)
+        got = arr_to_fr(c, d.FFT(fr_to_arr(c, a), pyref.DIT, True))
+        assert got == pyref.fft(c, a, pyref.DIT, on_coset=True)
+    finally:
+        d.close()
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_emu_compute_h(emu_ctx, c):
+    rng = pyref.Xoshiro(11)
+    m, n = 13, 16
+    A = [rng.field(c.r) for _ in range(m)]
+    B = [rng.field(c.r) for _ in range(m)]
+    Cc = [x * y % c.r for x, y in zip(A, B)]
+    d = fft.Domain(emu_ctx, c.name, m)
+    try:
+        assert d.Cardinality == n
+        got = arr_to_fr(c, d.compute_h(fr_to_arr(c, A), fr_to_arr(c, B), fr_to_arr(c, Cc)))
+        assert got == pyref.compute_h(c, A, B, Cc, n)
+    finally:
+        d.close()
+
+
+def _random_points(c, group, n, rng):
+    G, g = group_of(c, group), gen_of(c, group)
+    ks = [rng.next() & 0xFFFFFF for _ in range(n)]
+    return [G.mul(g, k) for k in ks], ks
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("group", [0, 1], ids=["G1", "G2"])
+def test_emu_msm_matches_naive(emu_ctx, c, group):
+    rng = pyref.Xoshiro(1000 + group)
+    n = 40
+    pts, ks = _random_points(c, group, n, rng)
+    scalars = [rng.field(c.r) for _ in range(n)]
+    # edge cases the reference handles: zero / one / r-1 scalars, infinity bases, repeated bases (DummySetup-like)
+    scalars[0], scalars[1], scalars[2] = 0, 1, c.r - 1
+    pts[3] = None
+    pts[5] = pts[4]
+    pts[7] = group_of(c, group).neg(pts[6])
+    scalars[7] = scalars[6]
+    got = ecc.MultiExp(emu_ctx, c.name, group, pts_to_arr(c, group, pts), fr_to_arr(c, scalars))
+    want = group_of(c, group).msm(pts, scalars)
+    assert jac_to_affine_py(c, group, got) == want
+    # canonical (non-Montgomery) scalars give the same point
+    got2 = ecc.MultiExp(emu_ctx, c.name, group, pts_to_arr(c, group, pts), fr_to_arr(c, scalars, mont=False), montgomery=False)
+    assert jac_to_affine_py(c, group, got2) == want
+
+
+def test_emu_msm_hot_bucket_and_windows(emu_ctx):
+    # witness-like scalars: many equal small values -> one bucket holds most points (task splitting + hot merge)
+    c, group = BN254, 0
+    rng = pyref.Xoshiro(5)
+    n = 3000
+    G = group_of(c, group)
+    base_pts, _ = _random_points(c, group, 8, rng)
+    pts = [base_pts[i % 8] for i in range(n)]
+    scalars = [1 if i % 10 else (rng.next() & 0xFFFF) for i in range(n)]
+    P, S = pts_to_arr(c, group, pts), fr_to_arr(c, scalars)
+    got = ecc.MultiExp(emu_ctx, c.name, group, P, S)
+    # expected via grouping by base
+    want = None
+    for j in range(8):
+        k = sum(s for i, s in enumerate(scalars) if i % 8 == j) % c.r
+        want = G.add(want, G.mul(base_pts[j], k))
+    assert jac_to_affine_py(c, group, got) == want
+    # window-sharded evaluation (multi-GPU partitioning A) recombines to the same point
+    cbits, nwin = ecc.plan(c.name, group, n, lib=emu_ctx.lib)
+    halves = []
+    mid = nwin // 2
+    for lo, hi in ((0, mid), (mid, nwin)):
+        w, cb, nw = ecc.MultiExpWindows(emu_ctx, c.name, group, P, S, n, lo, hi)
+        assert (cb, nw) == (cbits, nwin)
+        halves.append(w)
+    comb = ecc.combine_windows(c.name, group, np.concatenate(halves), cbits, lib=emu_ctx.lib)
+    assert jac_to_affine_py(c, group, comb) == want
+
+
+def test_emu_msm_empty_and_single(emu_ctx):
+    c = BN254
+    z = ecc.MultiExp(emu_ctx, c.name, 0, np.zeros((0, 8), np.uint64), np.zeros((0, 4), np.uint64))
+    assert jac_to_affine_py(c, 0, z) is None
+    got = ecc.MultiExp(emu_ctx, c.name, 0, pts_to_arr(c, 0, [c.g1]), fr_to_arr(c, [12345]))
+    assert jac_to_affine_py(c, 0, got) == group_of(c, 0).mul(c.g1, 12345)
+    with pytest.raises(ValueError):
+        ecc.MultiExp(emu_ctx, c.name, 0, pts_to_arr(c, 0, [c.g1]), fr_to_arr(c, [1, 2]))
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_emu_groth16_cubic(emu_ctx, c):
+    """config 1: examples/cubic through the whole prover core, proof bytes identical to the oracle's."""
+    rng = pyref.Xoshiro(2024)
+    cs, w = pyref.cubic_r1cs(), pyref.cubic_witness(3)
+    toxic = [rng.field(c.r) for _ in range(5)]
+    pk, vk, _ = pyref.groth16_setup(c, cs, toxic)
+    r, s = rng.field(c.r), rng.field(c.r)
+    ar, bs, krs = pyref.groth16_prove(pk, cs, w, r, s)
+    A, B, Cc = pyref.r1cs_solve(c, cs, w)
+    dpk = groth16.ProvingKey(
+        emu_ctx, c.name, domain_cardinality=pk.n,
+        alpha1=pts_to_arr(c, 0, [pk.alpha1]), beta1=pts_to_arr(c, 0, [pk.beta1]), delta1=pts_to_arr(c, 0, [pk.delta1]),
+        A=pts_to_arr(c, 0, pk.A), B=pts_to_arr(c, 0, pk.B), Z=pts_to_arr(c, 0, pk.Z), K=pts_to_arr(c, 0, pk.K),
+        beta2=pts_to_arr(c, 1, [pk.beta2]), delta2=pts_to_arr(c, 1, [pk.delta2]), B2=pts_to_arr(c, 1, pk.B2),
+        infinityA=pk.infinityA, infinityB=pk.infinityB)
+    try:
+        sol = groth16.Solution(W=fr_to_arr(c, w), A=fr_to_arr(c, A), B=fr_to_arr(c, B), C=fr_to_arr(c, Cc))
+        proof = groth16.Prove(dpk, sol, cs.nb_public, fr_to_arr(c, [r]), fr_to_arr(c, [s]))
+    finally:
+        dpk.FreeGPUResources()
+    assert arr_to_g1_affine(c, proof.Ar) == ar
+    assert arr_to_g2_affine(c, proof.Bs) == bs
+    assert arr_to_g1_affine(c, proof.Krs) == krs
+    assert proof.WriteTo() == pyref.proof_bytes(c, ar, bs, krs)
