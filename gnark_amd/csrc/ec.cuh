@@ -24,7 +24,7 @@ template <class P> GA_HD bool is_zero(const Fe2<P>& a) { return is_zero(a.c0) & 
 template <class P> GA_HD bool eq(const Fe2<P>& a, const Fe2<P>& b) { return eq(a.c0, b.c0) & eq(a.c1, b.c1); }
 
 template <class P>
-GA_HD Fe2<P> mul(const Fe2<P>& a, const Fe2<P>& b) {
+GA_HD_CALL Fe2<P> mul(const Fe2<P>& a, const Fe2<P>& b) {
     Fe<P> v0 = mul(a.c0, b.c0);
     Fe<P> v1 = mul(a.c1, b.c1);
     Fe<P> s = mul(add(a.c0, a.c1), add(b.c0, b.c1));
@@ -32,14 +32,14 @@ GA_HD Fe2<P> mul(const Fe2<P>& a, const Fe2<P>& b) {
 }
 
 template <class P>
-GA_HD Fe2<P> sqr(const Fe2<P>& a) {
+GA_HD_CALL Fe2<P> sqr(const Fe2<P>& a) {
     Fe<P> t = mul(a.c0, a.c1);
     Fe<P> r0 = mul(add(a.c0, a.c1), sub(a.c0, a.c1));
     return {r0, dbl(t)};
 }
 
 template <class P>
-GA_HD Fe2<P> inv(const Fe2<P>& a) {
+GA_HD_CALL Fe2<P> inv(const Fe2<P>& a) {
     Fe<P> d = inv(add(sqr(a.c0), sqr(a.c1)));
     return {mul(a.c0, d), neg(mul(a.c1, d))};
 }
@@ -84,7 +84,7 @@ GA_HD XYZZ<F> neg(const XYZZ<F>& p) { return {p.x, neg(p.y), p.zz, p.zzz}; }
 
 // 2*(affine) -> XYZZ   (mdbl-2008-s-1, a = 0)
 template <class F>
-GA_HD XYZZ<F> dbl_affine(const Affine<F>& p) {
+GA_HD_CALL XYZZ<F> dbl_affine(const Affine<F>& p) {
     if (is_inf(p) || is_zero(p.y)) return xyzz_inf<F>();
     F U = dbl(p.y);
     F V = sqr(U);
@@ -99,7 +99,7 @@ GA_HD XYZZ<F> dbl_affine(const Affine<F>& p) {
 
 // 2*P   (dbl-2008-s-1, a = 0)
 template <class F>
-GA_HD XYZZ<F> dbl(const XYZZ<F>& p) {
+GA_HD_CALL XYZZ<F> dbl(const XYZZ<F>& p) {
     if (is_inf(p) || is_zero(p.y)) return xyzz_inf<F>();
     F U = dbl(p.y);
     F V = sqr(U);
@@ -114,7 +114,7 @@ GA_HD XYZZ<F> dbl(const XYZZ<F>& p) {
 
 // acc + affine   (madd-2008-s), complete
 template <class F>
-GA_HD XYZZ<F> madd(const XYZZ<F>& a, const Affine<F>& q) {
+GA_HD_BIG XYZZ<F> madd(const XYZZ<F>& a, const Affine<F>& q) {
     if (is_inf(q)) return a;
     if (is_inf(a)) return to_xyzz(q);
     F U2 = mul(q.x, a.zz);
@@ -135,7 +135,7 @@ GA_HD XYZZ<F> madd(const XYZZ<F>& a, const Affine<F>& q) {
 
 // a + b   (add-2008-s), complete
 template <class F>
-GA_HD XYZZ<F> add(const XYZZ<F>& a, const XYZZ<F>& b) {
+GA_HD_CALL XYZZ<F> add(const XYZZ<F>& a, const XYZZ<F>& b) {
     if (is_inf(b)) return a;
     if (is_inf(a)) return b;
     F U1 = mul(a.x, b.zz);
@@ -175,7 +175,7 @@ GA_HD XYZZ<F> from_jac(const Jac<F>& p) {
 
 // XYZZ -> affine (two inversions folded into one)
 template <class F>
-GA_HD Affine<F> to_affine(const XYZZ<F>& p) {
+GA_HD_CALL Affine<F> to_affine(const XYZZ<F>& p) {
     if (is_inf(p)) return {FieldTraits<F>::zero(), FieldTraits<F>::zero()};
     F i = inv(mul(p.zz, p.zzz));          // 1/(zz*zzz)
     F izz = mul(i, p.zzz);                // 1/zz
@@ -185,7 +185,7 @@ GA_HD Affine<F> to_affine(const XYZZ<F>& p) {
 
 // [k]P for a little-endian scalar of nwords 32-bit words (canonical integer, NOT Montgomery)
 template <class F>
-GA_HD XYZZ<F> scalar_mul(const XYZZ<F>& p, const uint32_t* k, int nwords) {
+GA_HD_CALL XYZZ<F> scalar_mul(const XYZZ<F>& p, const uint32_t* k, int nwords) {
     XYZZ<F> r = xyzz_inf<F>();
     for (int i = nwords - 1; i >= 0; i--) {
         for (int b = 31; b >= 0; b--) {
@@ -197,7 +197,7 @@ GA_HD XYZZ<F> scalar_mul(const XYZZ<F>& p, const uint32_t* k, int nwords) {
 }
 
 template <class F>
-GA_HD XYZZ<F> scalar_mul_u32(const XYZZ<F>& p, uint32_t k) {
+GA_HD_CALL XYZZ<F> scalar_mul_u32(const XYZZ<F>& p, uint32_t k) {
     XYZZ<F> r = xyzz_inf<F>();
     for (int b = 31; b >= 0; b--) {
         r = dbl(r);

@@ -15,6 +15,15 @@
 #include "constants.h"
 
 #define GA_HD __host__ __device__ __forceinline__
+// Large bodies: inlined into kernels on the device, real functions in host code (keeps host objects small).
+// GA_HD_CALL bodies are real functions on the device as well: out-of-line Fp2 / point arithmetic keeps the hot
+// loops inside the instruction cache and the build time sane (a G2 point addition is ~40 Montgomery products).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GA_HD_BIG __host__ __device__ __forceinline__
+#else
+#define GA_HD_BIG __host__ __device__ inline __attribute__((noinline))
+#endif
+#define GA_HD_CALL __host__ __device__ inline __attribute__((noinline))
 
 namespace ga {
 
@@ -162,7 +171,7 @@ GA_HD Fe<P> neg(const Fe<P>& a) {
 // top word of every modulus used here is < 2^31 (BN254 p,r: 0x30644e72; BLS12-381 p: 0x1a0111ea, r: 0x73eda753).
 // Each inner step is one v_mad_u64_u32 (+ a 64-bit carry add).
 template <class P>
-GA_HD Fe<P> mul(const Fe<P>& a, const Fe<P>& b) {
+GA_HD_BIG Fe<P> mul_body(const Fe<P>& a, const Fe<P>& b) {
     constexpr int N = P::N;
     uint32_t t[N];
 #pragma unroll
@@ -189,6 +198,16 @@ GA_HD Fe<P> mul(const Fe<P>& a, const Fe<P>& b) {
 }
 
 template <class P>
+GA_HD_CALL Fe<P> mul_call(const Fe<P>& a, const Fe<P>& b) { return mul_body(a, b); }
+
+// 8-limb fields (BN254 Fp/Fr, BLS12-381 Fr): inlined.  12-limb BLS12-381 Fp: one shared out-of-line copy.
+template <class P>
+GA_HD Fe<P> mul(const Fe<P>& a, const Fe<P>& b) {
+    if constexpr (P::N > 8) return mul_call(a, b);
+    else return mul_body(a, b);
+}
+
+template <class P>
 GA_HD Fe<P> sqr(const Fe<P>& a) { return mul(a, a); }
 
 // a * R^-1 : leave Montgomery form (fr.Element.BigInt / FromMontgomery)
@@ -204,7 +223,7 @@ GA_HD Fe<P> to_mont(const Fe<P>& a) { return mul(a, fe_const<P>(P::R2)); }
 
 // a^e, e given as N 32-bit words (little-endian)
 template <class P>
-GA_HD Fe<P> pow_words(const Fe<P>& a, const uint32_t* e, int nwords) {
+GA_HD_CALL Fe<P> pow_words(const Fe<P>& a, const uint32_t* e, int nwords) {
     Fe<P> r = fe_one<P>();
     for (int i = nwords - 1; i >= 0; i--) {
         for (int b = 31; b >= 0; b--) {
@@ -216,7 +235,7 @@ GA_HD Fe<P> pow_words(const Fe<P>& a, const uint32_t* e, int nwords) {
 }
 
 template <class P>
-GA_HD Fe<P> pow_u64(const Fe<P>& a, uint64_t e) {
+GA_HD_CALL Fe<P> pow_u64(const Fe<P>& a, uint64_t e) {
     Fe<P> r = fe_one<P>();
     Fe<P> x = a;
     while (e) {

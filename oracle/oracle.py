@@ -1,0 +1,151 @@
+"""ctypes wrapper of oracle/liboracle.so (oracle.c).  TEST INFRASTRUCTURE ONLY: imported by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg -- never by gnark_amd/."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liboracle.so")
+_P = C.c_void_p
+FP_LIMBS = {0: 4, 1: 6}
+
+
+class OraclePk(C.Structure):
+    _fields_ = [("curve", C.c_int), ("n", C.c_uint64),
+                ("alpha1", _P), ("beta1", _P), ("delta1", _P),
+                ("A", _P), ("len_a", C.c_uint64), ("B", _P), ("len_b", C.c_uint64),
+                ("Z", _P), ("len_z", C.c_uint64), ("K", _P), ("len_k", C.c_uint64),
+                ("beta2", _P), ("delta2", _P), ("B2", _P), ("len_b2", C.c_uint64),
+                ("inf_a", _P), ("inf_b", _P), ("nb_wires", C.c_uint64)]
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call([os.path.join(_HERE, "build.sh")], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_dll = None
+
+
+def dll():
+    global _dll
+    if _dll is None:
+        _dll = C.CDLL(build())
+    return _dll
+
+
+def _p(a):
+    return a.ctypes.data_as(_P)
+
+
+def _u64(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def jac_words(curve, group):
+    return FP_LIMBS[curve] * (3 if group == 0 else 6)
+
+
+def aff_words(curve, group):
+    return FP_LIMBS[curve] * (2 if group == 0 else 4)
+
+
+def msm(curve, group, points, scalars, mont=True, nthreads=1, naive=False):
+    points, scalars = _u64(points), _u64(scalars)
+    n = scalars.reshape(-1, 4).shape[0]
+    out = np.zeros(jac_words(curve, group), dtype=np.uint64)
+    if naive:
+        dll().oracle_msm_naive(curve, group, _p(points), _p(scalars), C.c_size_t(n), int(mont), _p(out))
+    else:
+        dll().oracle_msm(curve, group, _p(points), _p(scalars), C.c_size_t(n), int(mont), _p(out), nthreads)
+    return out
+
+
+def jac_to_affine(curve, group, jac):
+    jac = _u64(jac)
+    out = np.zeros(aff_words(curve, group), dtype=np.uint64)
+    dll().oracle_jac_to_affine(curve, group, _p(jac), _p(out))
+    return out
+
+
+def jac_add(curve, group, a, b):
+    a, b = _u64(a), _u64(b)
+    out = np.zeros(jac_words(curve, group), dtype=np.uint64)
+    dll().oracle_jac_add(curve, group, _p(a), _p(b), _p(out))
+    return out
+
+
+def generator_mul(curve, group, k: int):
+    kk = np.array([(k >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+    out = np.zeros(jac_words(curve, group), dtype=np.uint64)
+    dll().oracle_generator_mul(curve, group, _p(kk), _p(out))
+    return out
+
+
+def gen_bases(curve, group, ks):
+    ks = _u64(ks)
+    out = np.zeros((ks.shape[0], aff_words(curve, group)), dtype=np.uint64)
+    dll().oracle_gen_bases(curve, group, _p(ks), C.c_size_t(ks.shape[0]), _p(out))
+    return out
+
+
+def fr_dot(curve, a_mont, b_canon) -> int:
+    a, b = _u64(a_mont), _u64(b_canon)
+    out = np.zeros(4, dtype=np.uint64)
+    dll().oracle_fr_dot(curve, _p(a), _p(b), C.c_size_t(a.reshape(-1, 4).shape[0]), _p(out))
+    return sum(int(v) << (64 * i) for i, v in enumerate(out))
+
+
+def fr_from_mont(curve, a):
+    a = _u64(a).reshape(-1, 4)
+    out = np.zeros_like(a)
+    dll().oracle_fr_from_mont(curve, _p(a), C.c_size_t(a.shape[0]), _p(out))
+    return out
+
+
+def fr_mul(curve, a, b):
+    a, b = _u64(a).reshape(-1, 4), _u64(b).reshape(-1, 4)
+    out = np.zeros_like(a)
+    dll().oracle_fr_mul(curve, _p(a), _p(b), C.c_size_t(a.shape[0]), _p(out))
+    return out
+
+
+def fft(curve, a, direction, decimation, on_coset):
+    out = _u64(a).reshape(-1, 4).copy()
+    rc = dll().oracle_fft(curve, _p(out), C.c_uint64(out.shape[0]), direction, decimation, int(on_coset))
+    assert rc == 0
+    return out
+
+
+def compute_h(curve, a, b, c, n):
+    a, b, c = (_u64(x).reshape(-1, 4) for x in (a, b, c))
+    out = np.zeros((n, 4), dtype=np.uint64)
+    dll().oracle_compute_h(curve, _p(a), _p(b), _p(c), C.c_uint64(a.shape[0]), C.c_uint64(n), _p(out))
+    return out
+
+
+def groth16_prove(curve, key: dict, W, A, B, Cc, nb_public, r_mont, s_mont, nthreads=1):
+    """key: dict of uint64 arrays (alpha1,beta1,delta1,A,B,Z,K,beta2,delta2,B2) + infinityA/B (uint8) + n."""
+    k = {name: _u64(key[name]) for name in ("alpha1", "beta1", "delta1", "A", "B", "Z", "K", "beta2", "delta2", "B2")}
+    ia = np.ascontiguousarray(key["infinityA"], dtype=np.uint8)
+    ib = np.ascontiguousarray(key["infinityB"], dtype=np.uint8)
+    fp = FP_LIMBS[curve]
+    pk = OraclePk()
+    pk.curve, pk.n = curve, int(key["n"])
+    pk.alpha1, pk.beta1, pk.delta1 = (k[x].ctypes.data for x in ("alpha1", "beta1", "delta1"))
+    pk.A, pk.len_a = k["A"].ctypes.data, k["A"].size // (2 * fp)
+    pk.B, pk.len_b = k["B"].ctypes.data, k["B"].size // (2 * fp)
+    pk.Z, pk.len_z = k["Z"].ctypes.data, k["Z"].size // (2 * fp)
+    pk.K, pk.len_k = k["K"].ctypes.data, k["K"].size // (2 * fp)
+    pk.beta2, pk.delta2 = k["beta2"].ctypes.data, k["delta2"].ctypes.data
+    pk.B2, pk.len_b2 = k["B2"].ctypes.data, k["B2"].size // (4 * fp)
+    pk.inf_a, pk.inf_b, pk.nb_wires = ia.ctypes.data, ib.ctypes.data, ia.shape[0]
+    W, A, B, Cc, r, s = (_u64(x) for x in (W, A, B, Cc, r_mont, s_mont))
+    out = np.zeros(8 * fp, dtype=np.uint64)
+    dll().oracle_groth16_prove(C.byref(pk), _p(W), _p(A), _p(B), _p(Cc), C.c_uint64(A.reshape(-1, 4).shape[0]),
+                               C.c_uint64(nb_public), _p(r), _p(s), _p(out), nthreads)
+    return out[:2 * fp], out[2 * fp:6 * fp], out[6 * fp:]

@@ -1,0 +1,61 @@
+"""CPU-side checks of the drop-in boundary: every function declared in include/gnark_amd.h is exported by the
+hipcc-built shared library and bound by the Python mirror; no compute calls (no GPU here)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "gnark_amd.h")
+SO = os.path.join(ROOT, "gnark_amd", "libgnark_amd.so")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ga_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def built_so():
+    if not os.path.exists(SO):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "gnark_amd", "csrc"), "-j", str(os.cpu_count() or 4)],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return SO
+
+
+def test_header_functions_all_bound_in_python():
+    from gnark_amd import _lib
+    assert set(declared_functions()) == set(_lib.EXPORTED_SYMBOLS)
+
+
+def test_shared_library_exports_every_declared_symbol(built_so):
+    dll = ctypes.CDLL(built_so)
+    missing = [f for f in declared_functions() if not hasattr(dll, f)]
+    assert not missing, missing
+    from gnark_amd import _lib
+    lib = _lib.Library(built_so)            # binds every prototype
+    assert b"gfx950" in lib.ga_version()
+    c, nw = ctypes.c_int(), ctypes.c_int()
+    assert lib.ga_msm_plan(0, 0, 1 << 20, ctypes.byref(c), ctypes.byref(nw)) == 0   # host-only planner
+    assert c.value >= 10 and nw.value == 254 // c.value + 1
+    assert lib.ga_msm_plan(7, 0, 16, ctypes.byref(c), ctypes.byref(nw)) != 0        # unknown curve id -> error, message set
+    assert b"curve" in lib.ga_last_error()
+
+
+def test_no_cpu_fallback_in_package():
+    """The product package must not import the oracle or the emulation build."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "gnark_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cuh", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "liboracle" not in txt and "import oracle" not in txt and "pyref" not in txt, f
+                assert "libgnark_amd_emu" not in txt, f
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from gnark_amd import _lib
+    with pytest.raises(_lib.GnarkAmdError, match="no CPU fallback"):
+        _lib.Library(str(tmp_path / "nope.so"))

@@ -1,0 +1,124 @@
+"""The C oracle (oracle/oracle.c) against the independent big-integer restatement (oracle/pyref.py)."""
+import numpy as np
+import pytest
+
+import oracle
+import pyref
+from helpers import BLS12_381, BN254, arr_to_fr, arr_to_g1_affine, arr_to_g2_affine, fr_to_arr, gen_of, group_of, jac_to_affine_py, pts_to_arr
+
+CURVES = [BN254, BLS12_381]
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_field_and_generator(c):
+    rng = pyref.Xoshiro(1)
+    a = [rng.field(c.r) for _ in range(32)]
+    b = [rng.field(c.r) for _ in range(32)]
+    got = arr_to_fr(c, oracle.fr_mul(c.cid, fr_to_arr(c, a), fr_to_arr(c, b)))
+    assert got == [x * y % c.r for x, y in zip(a, b)]
+    assert oracle.fr_dot(c.cid, fr_to_arr(c, a), fr_to_arr(c, b, mont=False)) == sum(x * y for x, y in zip(a, b)) % c.r
+    for group in (0, 1):
+        k = rng.field(c.r)
+        got = jac_to_affine_py(c, group, oracle.generator_mul(c.cid, group, k))
+        assert got == group_of(c, group).mul(gen_of(c, group), k)
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("group", [0, 1], ids=["G1", "G2"])
+def test_msm_pippenger_vs_naive_vs_python(c, group):
+    rng = pyref.Xoshiro(77 + group)
+    n = 24
+    G, g = group_of(c, group), gen_of(c, group)
+    pts = [G.mul(g, rng.next() & 0xFFFFF) for _ in range(n)]
+    sc = [rng.field(c.r) for _ in range(n)]
+    sc[0], sc[1], sc[2] = 0, 1, c.r - 1
+    pts[3] = None
+    pts[5] = pts[4]
+    P, S = pts_to_arr(c, group, pts), fr_to_arr(c, sc)
+    want = G.msm(pts, sc)
+    assert jac_to_affine_py(c, group, oracle.msm(c.cid, group, P, S)) == want
+    assert jac_to_affine_py(c, group, oracle.msm(c.cid, group, P, S, nthreads=4)) == want
+    assert jac_to_affine_py(c, group, oracle.msm(c.cid, group, P, S, naive=True)) == want
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_fft_conventions(c):
+    rng = pyref.Xoshiro(3)
+    for logn in (0, 1, 4, 7):
+        n = 1 << logn
+        a = [rng.field(c.r) for _ in range(n)]
+        for dec in (pyref.DIF, pyref.DIT):
+            for coset in (False, True):
+                for inv in (False, True):
+                    got = arr_to_fr(c, oracle.fft(c.cid, fr_to_arr(c, a), int(inv), dec, coset))
+                    assert got == pyref.fft(c, a, dec, on_coset=coset, inverse=inv), (logn, dec, coset, inv)
+    # O(n^2) DFT definition
+    a = [rng.field(c.r) for _ in range(64)]
+    w = c.fr_root_of_unity(64)
+    nat = pyref.dft_naive(a, w, c.r)
+    assert arr_to_fr(c, oracle.fft(c.cid, fr_to_arr(c, a), 0, pyref.DIF, False)) == pyref.bitrev_permute(nat)
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_compute_h_identity(c):
+    """A(x)B(x) - C(x) = H(x)(x^n - 1) at a random point, H from the C oracle (bit-reversed coefficients)."""
+    rng = pyref.Xoshiro(9)
+    m, n = 50, 64
+    A = [rng.field(c.r) for _ in range(m)]
+    B = [rng.field(c.r) for _ in range(m)]
+    Cc = [x * y % c.r for x, y in zip(A, B)]
+    h = arr_to_fr(c, oracle.compute_h(c.cid, fr_to_arr(c, A), fr_to_arr(c, B), fr_to_arr(c, Cc), n))
+    assert h == pyref.compute_h(c, A, B, Cc, n)
+    hc = pyref.bitrev_permute(h)   # natural coefficient order
+    assert hc[n - 1] == 0          # deg H <= n-2 (setup.go:247-249)
+    pad = lambda v: v + [0] * (n - m)
+    coef = lambda ev: pyref.fft(c, pyref.fft(c, pad(ev), pyref.DIF, inverse=True), pyref.DIT, inverse=False) and \
+        pyref.bitrev_permute(pyref.fft(c, pad(ev), pyref.DIF, inverse=True))
+    x = rng.field(c.r)
+    ev = lambda co: sum(v * pow(x, i, c.r) for i, v in enumerate(co)) % c.r
+    lhs = (ev(coef(A)) * ev(coef(B)) - ev(coef(Cc))) % c.r
+    assert lhs == ev(hc) * (pow(x, n, c.r) - 1) % c.r
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_groth16_cubic_matches_python_and_dlog(c):
+    rng = pyref.Xoshiro(2024)
+    cs, w = pyref.cubic_r1cs(), pyref.cubic_witness(3)
+    toxic = [rng.field(c.r) for _ in range(5)]
+    pk, vk, dl = pyref.groth16_setup(c, cs, toxic)
+    r, s = rng.field(c.r), rng.field(c.r)
+    ar, bs, krs = pyref.groth16_prove(pk, cs, w, r, s)
+    A, B, Cc = pyref.r1cs_solve(c, cs, w)
+    key = dict(n=pk.n, alpha1=pts_to_arr(c, 0, [pk.alpha1]), beta1=pts_to_arr(c, 0, [pk.beta1]), delta1=pts_to_arr(c, 0, [pk.delta1]),
+               A=pts_to_arr(c, 0, pk.A), B=pts_to_arr(c, 0, pk.B), Z=pts_to_arr(c, 0, pk.Z), K=pts_to_arr(c, 0, pk.K),
+               beta2=pts_to_arr(c, 1, [pk.beta2]), delta2=pts_to_arr(c, 1, [pk.delta2]), B2=pts_to_arr(c, 1, pk.B2),
+               infinityA=pk.infinityA, infinityB=pk.infinityB)
+    gar, gbs, gkrs = oracle.groth16_prove(c.cid, key, fr_to_arr(c, w), fr_to_arr(c, A), fr_to_arr(c, B), fr_to_arr(c, Cc),
+                                          cs.nb_public, fr_to_arr(c, [r]), fr_to_arr(c, [s]))
+    assert arr_to_g1_affine(c, gar) == ar
+    assert arr_to_g2_affine(c, gbs) == bs
+    assert arr_to_g1_affine(c, gkrs) == krs
+    # closed form in the exponent (Groth16 equation): with a = alpha + A(tau) + r*delta etc. the proof verifies iff
+    #   a*b = alpha*beta + (sum_pub w_i K_i) + krs*delta     (all as discrete logs)
+    alpha, beta, gamma, delta, tau = toxic
+    mod = c.r
+    G1, G2 = group_of(c, 0), group_of(c, 1)
+    a_dl = (alpha + sum(wv * k for wv, k in zip([w[i] for i in range(len(w)) if not pk.infinityA[i]], dl["A"])) + r * delta) % mod
+    b_dl = (beta + sum(wv * k for wv, k in zip([w[i] for i in range(len(w)) if not pk.infinityB[i]], dl["B"])) + s * delta) % mod
+    assert G1.mul(c.g1, a_dl) == ar and G2.mul(c.g2, b_dl) == bs
+    h = pyref.compute_h(c, A, B, Cc, pk.n)
+    krs_dl = (sum(wv * k for wv, k in zip(w[cs.nb_public:], dl["K"])) + sum(hv * z for hv, z in zip(h, dl["Z"]))
+              + s * a_dl + r * b_dl - r * s * delta) % mod
+    assert G1.mul(c.g1, krs_dl) == krs
+    # pairing equation in the exponent: e(A,B) = e(alpha,beta) * e(sum_pub w_i vkK_i, gamma) * e(Krs, delta)
+    n = pk.n
+    wroot = c.fr_root_of_unity(n)
+    tn1 = (pow(tau, n, mod) - 1) % mod
+    lag = [tn1 * pow(wroot, i, mod) * pow(n, -1, mod) * pow((tau - pow(wroot, i, mod)) % mod, -1, mod) % mod for i in range(n)]
+    Av, Bv, Cv = [0] * cs.nb_wires, [0] * cs.nb_wires, [0] * cs.nb_wires
+    for i in range(len(cs.L)):
+        for wi, k in cs.L[i].items(): Av[wi] = (Av[wi] + k * lag[i]) % mod
+        for wi, k in cs.R[i].items(): Bv[wi] = (Bv[wi] + k * lag[i]) % mod
+        for wi, k in cs.O[i].items(): Cv[wi] = (Cv[wi] + k * lag[i]) % mod
+    pub = sum(w[i] * (beta * Av[i] + alpha * Bv[i] + Cv[i]) for i in range(cs.nb_public)) % mod
+    assert a_dl * b_dl % mod == (alpha * beta + pub + krs_dl * delta) % mod
