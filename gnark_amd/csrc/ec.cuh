@@ -23,19 +23,39 @@ template <class P> GA_HD Fe2<P> neg(const Fe2<P>& a) { return {neg(a.c0), neg(a.
 template <class P> GA_HD bool is_zero(const Fe2<P>& a) { return is_zero(a.c0) & is_zero(a.c1); }
 template <class P> GA_HD bool eq(const Fe2<P>& a, const Fe2<P>& b) { return eq(a.c0, b.c0) & eq(a.c1, b.c1); }
 
+// Karatsuba product / complex squaring with every base-field product inlined (hot loops) ...
 template <class P>
-GA_HD_CALL Fe2<P> mul(const Fe2<P>& a, const Fe2<P>& b) {
-    Fe<P> v0 = mul(a.c0, b.c0);
-    Fe<P> v1 = mul(a.c1, b.c1);
-    Fe<P> s = mul(add(a.c0, a.c1), add(b.c0, b.c1));
+GA_HD_BIG Fe2<P> mul_body(const Fe2<P>& a, const Fe2<P>& b) {
+    Fe<P> v0 = mul_body(a.c0, b.c0);
+    Fe<P> v1 = mul_body(a.c1, b.c1);
+    Fe<P> s = mul_body(add(a.c0, a.c1), add(b.c0, b.c1));
     return {sub(v0, v1), sub(sub(s, v0), v1)};
 }
-
 template <class P>
-GA_HD_CALL Fe2<P> sqr(const Fe2<P>& a) {
-    Fe<P> t = mul(a.c0, a.c1);
-    Fe<P> r0 = mul(add(a.c0, a.c1), sub(a.c0, a.c1));
+GA_HD_BIG Fe2<P> sqr_body(const Fe2<P>& a) {
+    Fe<P> t = mul_body(a.c0, a.c1);
+    Fe<P> r0 = mul_body(add(a.c0, a.c1), sub(a.c0, a.c1));
     return {r0, dbl(t)};
+}
+template <class P>
+GA_HD_BIG Fe<P> sqr_body(const Fe<P>& a) { return mul_body(a, a); }
+
+// ... and as shared out-of-line functions (cold kernels, host code)
+template <class P>
+GA_HD_CALL Fe2<P> mul(const Fe2<P>& a, const Fe2<P>& b) { return mul_body(a, b); }
+template <class P>
+GA_HD_CALL Fe2<P> sqr(const Fe2<P>& a) { return sqr_body(a); }
+
+// INL = true: fully inlined product (accumulator stays in registers, no call ABI traffic); false: shared functions
+template <bool INL, class F>
+GA_HD F fmul(const F& a, const F& b) {
+    if constexpr (INL) return mul_body(a, b);
+    else return mul(a, b);
+}
+template <bool INL, class F>
+GA_HD F fsqr(const F& a) {
+    if constexpr (INL) return sqr_body(a);
+    else return sqr(a);
 }
 
 template <class P>
@@ -83,19 +103,21 @@ template <class F>
 GA_HD XYZZ<F> neg(const XYZZ<F>& p) { return {p.x, neg(p.y), p.zz, p.zzz}; }
 
 // 2*(affine) -> XYZZ   (mdbl-2008-s-1, a = 0)
-template <class F>
-GA_HD_CALL XYZZ<F> dbl_affine(const Affine<F>& p) {
+template <bool INL, class F>
+GA_HD XYZZ<F> dbl_affine_t(const Affine<F>& p) {
     if (is_inf(p) || is_zero(p.y)) return xyzz_inf<F>();
     F U = dbl(p.y);
-    F V = sqr(U);
-    F W = mul(U, V);
-    F S = mul(p.x, V);
-    F xx = sqr(p.x);
+    F V = fsqr<INL>(U);
+    F W = fmul<INL>(U, V);
+    F S = fmul<INL>(p.x, V);
+    F xx = fsqr<INL>(p.x);
     F M = add(dbl(xx), xx);
-    F X3 = sub(sqr(M), dbl(S));
-    F Y3 = sub(mul(M, sub(S, X3)), mul(W, p.y));
+    F X3 = sub(fsqr<INL>(M), dbl(S));
+    F Y3 = sub(fmul<INL>(M, sub(S, X3)), fmul<INL>(W, p.y));
     return {X3, Y3, V, W};
 }
+template <class F>
+GA_HD_CALL XYZZ<F> dbl_affine(const Affine<F>& p) { return dbl_affine_t<false>(p); }
 
 // 2*P   (dbl-2008-s-1, a = 0)
 template <class F>
@@ -112,26 +134,30 @@ GA_HD_CALL XYZZ<F> dbl(const XYZZ<F>& p) {
     return {X3, Y3, mul(V, p.zz), mul(W, p.zzz)};
 }
 
-// acc + affine   (madd-2008-s), complete
-template <class F>
-GA_HD_BIG XYZZ<F> madd(const XYZZ<F>& a, const Affine<F>& q) {
+// acc + affine   (madd-2008-s), complete.  INL = true is the bucket-accumulation hot loop: everything inlined so
+// that the accumulator never has its address taken (a call returning a point through memory forces the whole
+// accumulator into scratch -- measured as 13.7 GB of WRITE_SIZE per 2^22 MSM before this split).
+template <bool INL, class F>
+GA_HD XYZZ<F> madd_t(const XYZZ<F>& a, const Affine<F>& q) {
     if (is_inf(q)) return a;
     if (is_inf(a)) return to_xyzz(q);
-    F U2 = mul(q.x, a.zz);
-    F S2 = mul(q.y, a.zzz);
+    F U2 = fmul<INL>(q.x, a.zz);
+    F S2 = fmul<INL>(q.y, a.zzz);
     F Pp = sub(U2, a.x);
     F R = sub(S2, a.y);
     if (is_zero(Pp)) {
-        if (is_zero(R)) return dbl_affine(q);
+        if (is_zero(R)) return dbl_affine_t<INL>(q);
         return xyzz_inf<F>();
     }
-    F PP = sqr(Pp);
-    F PPP = mul(Pp, PP);
-    F Q = mul(a.x, PP);
-    F X3 = sub(sub(sqr(R), PPP), dbl(Q));
-    F Y3 = sub(mul(R, sub(Q, X3)), mul(a.y, PPP));
-    return {X3, Y3, mul(a.zz, PP), mul(a.zzz, PPP)};
+    F PP = fsqr<INL>(Pp);
+    F PPP = fmul<INL>(Pp, PP);
+    F Q = fmul<INL>(a.x, PP);
+    F X3 = sub(sub(fsqr<INL>(R), PPP), dbl(Q));
+    F Y3 = sub(fmul<INL>(R, sub(Q, X3)), fmul<INL>(a.y, PPP));
+    return {X3, Y3, fmul<INL>(a.zz, PP), fmul<INL>(a.zzz, PPP)};
 }
+template <class F>
+GA_HD_BIG XYZZ<F> madd(const XYZZ<F>& a, const Affine<F>& q) { return madd_t<false>(a, q); }
 
 // a + b   (add-2008-s), complete
 template <class F>

@@ -110,7 +110,7 @@ msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __res
         uint32_t v = vals[p];
         Affine<F> q = load_pod<Affine<F>>(&bases[v & ~MSM_SIGN]);
         if (v & MSM_SIGN) q.y = neg(q.y);
-        acc = madd(acc, q);
+        acc = madd_t<true>(acc, q);
     }
     store_pod(&partial[t], acc);
 }
@@ -191,16 +191,16 @@ msm_reduce_groups_kernel(const XYZZ<F>* __restrict__ bsum, uint32_t half, uint32
     store_pod(&gsum[gid], local);
 }
 
+// out[b] = sum of in[b*seg_len .. (b+1)*seg_len): one wave per segment, strided partial sums + LDS tree
 template <class F>
 __global__ void __launch_bounds__(64)
-msm_window_sum_kernel(const XYZZ<F>* __restrict__ gsum, uint32_t groups_per_win, XYZZ<F>* __restrict__ wsum) {
+msm_segment_sum_kernel(const XYZZ<F>* __restrict__ in, uint32_t seg_len, XYZZ<F>* __restrict__ out) {
     __shared__ XYZZ<F> sh[64];
-    uint32_t w = blockIdx.x;
+    const uint64_t base = (uint64_t)blockIdx.x * seg_len;
     XYZZ<F> acc = xyzz_inf<F>();
-    for (uint32_t g = threadIdx.x; g < groups_per_win; g += 64)
-        acc = add(acc, load_pod<XYZZ<F>>(&gsum[(uint64_t)w * groups_per_win + g]));
+    for (uint32_t g = threadIdx.x; g < seg_len; g += 64) acc = add(acc, load_pod<XYZZ<F>>(&in[base + g]));
     acc = wave_tree_sum(acc, sh);
-    if (threadIdx.x == 0) store_pod(&wsum[w], acc);
+    if (threadIdx.x == 0) store_pod(&out[blockIdx.x], acc);
 }
 
 // ---- host driver ------------------------------------------------------------------------------------
@@ -243,7 +243,7 @@ int msm_windows_device(Ctx* ctx, const void* d_bases, const void* d_scalars, siz
     const uint32_t total_groups = groups_per_win * nwl;
 
     uint32_t *keys, *vals, *keys2, *vals2, *off, *ntask, *task_off, *hot_list, *hot_count;
-    XYZZ<F>*partial, *bsum, *gsum, *wsum;
+    XYZZ<F>*partial, *bsum, *gsum, *gsum2, *wsum;
     void* sort_tmp;
     GA_CHECK(ctx->scratch_get("msm_keys", m * 4, (void**)&keys));
     GA_CHECK(ctx->scratch_get("msm_vals", m * 4, (void**)&vals));
@@ -257,6 +257,7 @@ int msm_windows_device(Ctx* ctx, const void* d_bases, const void* d_scalars, siz
     GA_CHECK(ctx->scratch_get("msm_partial", max_tasks * sizeof(XYZZ<F>), (void**)&partial));
     GA_CHECK(ctx->scratch_get("msm_bsum", (uint64_t)nb * sizeof(XYZZ<F>), (void**)&bsum));
     GA_CHECK(ctx->scratch_get("msm_gsum", (uint64_t)total_groups * sizeof(XYZZ<F>), (void**)&gsum));
+    GA_CHECK(ctx->scratch_get("msm_gsum2", ((uint64_t)total_groups / 1024 + 64) * sizeof(XYZZ<F>), (void**)&gsum2));
     GA_CHECK(ctx->scratch_get("msm_wsum", (uint64_t)nwl * sizeof(XYZZ<F>), (void**)&wsum));
 
     hipStream_t st = ctx->stream;
@@ -305,7 +306,16 @@ int msm_windows_device(Ctx* ctx, const void* d_bases, const void* d_scalars, siz
         StageTimer tm(ctx, "msm_reduce");
         hipLaunchKernelGGL((msm_reduce_groups_kernel<F>), dim3((total_groups + 63) / 64), dim3(64), 0, st, (const XYZZ<F>*)bsum,
                            half, m_groups, groups_per_win, total_groups, gsum);
-        hipLaunchKernelGGL((msm_window_sum_kernel<F>), dim3(nwl), dim3(64), 0, st, (const XYZZ<F>*)gsum, groups_per_win, wsum);
+        // window sum = sum of its group results; two levels when a window has many groups so that the first level
+        // spreads over >= 16 waves per window instead of one
+        const uint32_t seg = 1024;
+        if (groups_per_win > 2 * seg) {
+            const uint32_t nseg = groups_per_win / seg;   // powers of two: exact
+            hipLaunchKernelGGL((msm_segment_sum_kernel<F>), dim3(nseg * nwl), dim3(64), 0, st, (const XYZZ<F>*)gsum, seg, gsum2);
+            hipLaunchKernelGGL((msm_segment_sum_kernel<F>), dim3(nwl), dim3(64), 0, st, (const XYZZ<F>*)gsum2, nseg, wsum);
+        } else {
+            hipLaunchKernelGGL((msm_segment_sum_kernel<F>), dim3(nwl), dim3(64), 0, st, (const XYZZ<F>*)gsum, groups_per_win, wsum);
+        }
         GA_KERNEL_CHECK();
     }
     GA_HIP_CHECK(hipMemcpyAsync(out, wsum, (size_t)nwl * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));

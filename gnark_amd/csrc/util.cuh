@@ -129,12 +129,13 @@ int util_gather_fr(Ctx* ctx, void* d_dst, const void* d_src, const uint32_t* d_i
 template <class C>
 int msm_plan(int group, size_t n, int* c_out, int* nwin_out) {
     const int bits = C::FrP::BITS;
-    // cost ~ windows * (n mixed adds + ~3 general adds per bucket); G2 adds are ~3x as expensive either way
+    // cost ~ windows * (n mixed adds + the per-bucket reduction work, ~6 mixed-add equivalents per bucket as measured on
+    // MI355X: profiles/r01_*); G2 scales both terms alike
     double best = 1e300;
     int bc = 4;
     for (int c = 4; c <= 22; c++) {
         int nwin = bits / c + 1;
-        double cost = (double)nwin * ((double)n + 3.0 * (double)(1u << (c - 1)));
+        double cost = (double)nwin * ((double)n + 6.0 * (double)(1u << (c - 1)));
         if (cost < best) {
             best = cost;
             bc = c;
