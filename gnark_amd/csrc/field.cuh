@@ -167,28 +167,90 @@ GA_HD Fe<P> neg(const Fe<P>& a) {
     return r;
 }
 
-// Montgomery product a*b*R^-1 mod p.  Interleaved CIOS on 32-bit limbs, "no-carry" form: valid because the
-// top word of every modulus used here is < 2^31 (BN254 p,r: 0x30644e72; BLS12-381 p: 0x1a0111ea, r: 0x73eda753).
-// Each inner step is one v_mad_u64_u32 (+ a 64-bit carry add).
+// Montgomery product a*b*R^-1 mod p, R = 2^(32N) (gnark's R), computed carry-free in a smaller radix.
+//
+// gfx950 has no multiply with carry-in: v_mad_u64_u32 is 32x32+64 -> 64 at ~half rate, and a 64-bit add or an add-with-
+// carry costs the same issue slot as the multiply (profiles/r01_microbench.txt: all ~30-35 Gop/s/lane-group), so a
+// 32-bit-limb CIOS spends more time on carry plumbing (v_lshl_add_u64, v_mov to build {x,0} pairs) than on products.
+// Instead the operands are unpacked to L-bit limbs (L = 29 for the 254/255-bit fields, 28 for the 381-bit one) so that
+// a whole column  sum_i a_i*b_j + sum_i m_i*p_j  (2*NL products < 2^(2L)) fits a 64-bit accumulator: every product is ONE
+// v_mad_u64_u32 accumulating in place, and carries are resolved once per column with a shift.
+//   a' = a << S  (S = NL*L - 32N), so that  a'*b / 2^(NL*L) = a*b / 2^(32N)  -- the memory format keeps gnark's R.
+//   result < 1.25 p  ->  one conditional subtraction.
+template <class P>
+struct Radix {
+    static constexpr int L = (P::N == 8) ? 29 : 28;
+    static constexpr int NL = (32 * P::N + L - 1) / L + ((32 * P::N) % L == 0 ? 1 : 0);
+    static constexpr int S = NL * L - 32 * P::N;
+    static constexpr uint32_t MASK = (1u << L) - 1;
+    static_assert(S > 0 && S < L, "pre-shift must fit one limb");
+    static_assert(2 * L + 6 <= 64, "column sums must fit 64 bits");
+};
+
+// bits [lo, lo+L) of the little-endian word array w[0..N), zero outside
+template <int N, int L>
+GA_HD uint32_t take_bits(const uint32_t* w, int lo) {
+    if (lo + L <= 0 || lo >= 32 * N) return 0;
+    uint64_t v;
+    if (lo < 0) {
+        v = (uint64_t)w[0] << (-lo);
+    } else {
+        const int i = lo >> 5, off = lo & 31;
+        v = (uint64_t)w[i] >> off;
+        if (i + 1 < N) v |= (uint64_t)w[i + 1] << (32 - off);
+    }
+    return (uint32_t)v & ((1u << L) - 1);
+}
+
+// p as L-bit limbs and -p^-1 mod 2^L, folded to immediates by the compiler
+template <class P>
+GA_HD uint32_t mod_limb(int j) { return take_bits<P::N, Radix<P>::L>(P::MOD, j * Radix<P>::L); }
+
 template <class P>
 GA_HD_BIG Fe<P> mul_body(const Fe<P>& a, const Fe<P>& b) {
-    constexpr int N = P::N;
+    typedef Radix<P> R;
+    constexpr int N = P::N, L = R::L, NL = R::NL;
+    uint32_t al[NL], bl[NL], pl[NL];
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        al[i] = take_bits<N, L>(a.l, i * L - R::S);   // a << S
+        bl[i] = take_bits<N, L>(b.l, i * L);
+        pl[i] = mod_limb<P>(i);
+    }
+    // column accumulators of the schoolbook product
+    uint64_t col[2 * NL];
+#pragma unroll
+    for (int k = 0; k < 2 * NL; k++) col[k] = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++)
+#pragma unroll
+        for (int j = 0; j < NL; j++) col[i + j] += (uint64_t)al[i] * bl[j];
+    // Montgomery reduction, one L-bit digit per row; -p^-1 mod 2^L == low L bits of (-p^-1 mod 2^32)
+    const uint32_t inv = P::INV & R::MASK;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        const uint32_t m = ((uint32_t)col[i] * inv) & R::MASK;
+#pragma unroll
+        for (int j = 0; j < NL; j++) col[i + j] += (uint64_t)m * pl[j];
+        col[i + 1] += col[i] >> L;   // low L bits of col[i] are now zero
+    }
+    // carry-normalise the high half and repack to 32-bit words
+    uint32_t rl[NL];
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+        rl[k] = (uint32_t)col[NL + k] & R::MASK;
+        if (k + 1 < NL) col[NL + k + 1] += col[NL + k] >> L;
+        else rl[k] = (uint32_t)col[NL + k];   // top limb keeps everything (value < 2p < 2^(32N))
+    }
     uint32_t t[N];
 #pragma unroll
-    for (int i = 0; i < N; i++) t[i] = 0;
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        const uint32_t bi = b.l[i];
-        uint64_t A = (uint64_t)a.l[0] * bi + t[0];
-        const uint32_t m = (uint32_t)A * P::INV;
-        uint64_t C = (uint64_t)m * P::MOD[0] + (uint32_t)A;
-#pragma unroll
-        for (int j = 1; j < N; j++) {
-            A = (uint64_t)a.l[j] * bi + t[j] + (A >> 32);
-            C = (uint64_t)m * P::MOD[j] + (uint32_t)A + (C >> 32);
-            t[j - 1] = (uint32_t)C;
-        }
-        t[N - 1] = (uint32_t)(C >> 32) + (uint32_t)(A >> 32);
+    for (int w = 0; w < N; w++) {
+        // word w = bits [32w, 32w+32) of sum rl[k] << (k*L)
+        const int k0 = (32 * w) / L, off = (32 * w) % L;
+        uint64_t v = (uint64_t)rl[k0] >> off;
+        if (k0 + 1 < NL) v |= (uint64_t)rl[k0 + 1] << (L - off);
+        if (2 * L - off < 32 && k0 + 2 < NL) v |= (uint64_t)rl[k0 + 2] << (2 * L - off);
+        t[w] = (uint32_t)v;
     }
     reduce_once<P>(t);
     Fe<P> r;

@@ -26,6 +26,15 @@
 
 namespace ga {
 
+#ifndef GA_ACC_MINW_SMALL
+#define GA_ACC_MINW_SMALL 3   // BN254 G1 (XYZZ = 128 B)
+#endif
+#ifndef GA_ACC_MINW_MID
+#define GA_ACC_MINW_MID 2     // BN254 G2 (256 B), BLS12-381 G1 (192 B)
+#endif
+#ifndef GA_ACC_MINW_BIG
+#define GA_ACC_MINW_BIG 1     // BLS12-381 G2 (384 B)
+#endif
 constexpr uint32_t MSM_SIGN = 0x80000000u;
 constexpr int MSM_HOT_TASKS = 8;      // buckets with more partials than this go to the wave-parallel merge
 constexpr int MSM_GROUP = 32;         // buckets per running-sum group in the window reduction
@@ -85,8 +94,14 @@ static __global__ void msm_tasks_kernel(const uint32_t* __restrict__ off, uint32
 }
 
 // ---- 4. accumulate --------------------------------------------------------------------------------
+// minimum waves per SIMD requested from the register allocator, by point size (tuned on MI355X):
+// the bucket loop is a long dependent chain of v_mad_u64_u32, so it needs >= 2 resident waves per SIMD to stay busy.
+template <class F> struct AccumulateTuning {
+    static constexpr int MIN_WAVES = sizeof(XYZZ<F>) <= 128 ? GA_ACC_MINW_SMALL : (sizeof(XYZZ<F>) <= 256 ? GA_ACC_MINW_MID : GA_ACC_MINW_BIG);
+};
+
 template <class F>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, AccumulateTuning<F>::MIN_WAVES)
 msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ vals,
                       const uint32_t* __restrict__ off, const uint32_t* __restrict__ task_off, uint32_t nb, uint32_t seg,
                       XYZZ<F>* __restrict__ partial) {
