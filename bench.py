@@ -128,17 +128,13 @@ def main():
     lib.check(lib.ga_gen_scalars(ctx.handle, cid, 0x5EED0001 + 977 * rank, n, scalars.ptr))
     cbits, nwin = ecc.plan(cid, _lib.G1, n)
 
+    from gnark_amd import multigpu
+    dev = torch.device("cuda", local_rank)
+
     def step():
-        part = ecc.MultiExp(ctx, cid, _lib.G1, bases, scalars, n=n)
-        if world > 1:
-            t = torch.from_numpy(part.view(np.int64)).cuda()
-            out = [torch.empty_like(t) for _ in range(world)]
-            dist.all_gather(out, t)
-            acc = out[0].cpu().numpy().view(np.uint64)
-            for o in out[1:]:
-                acc = ecc.jac_add(cid, _lib.G1, acc, o.cpu().numpy().view(np.uint64))
-            return acc
-        return part
+        # N = 1: plain MSM.  N > 1: partition B (base-point range) -- every rank reduces its own 2^log_n pairs to one
+        # Jacobian partial, RCCL all_gather of the partials, local add (gnark_amd/multigpu.py)
+        return multigpu.msm_base_sharded(ctx, cid, _lib.G1, bases, scalars, n, dist, dev)
 
     def fence():
         torch.cuda.synchronize()

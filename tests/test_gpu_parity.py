@@ -233,3 +233,28 @@ def test_loaded_library_is_the_hip_build(gpu_ctx):
     assert "gfx950" in info["name"], info
     mb = gpu_ctx.microbench()
     assert mb.get("v_mad_u64_u32_Gops", 0) > 0
+
+
+def test_kzg_ceremony_relations_on_device(gpu_ctx):
+    """The reference's EIP-4844 fixture (tests/golden/kzg4096_bls12381.npz, from std/evmprecompiles/kzg_trusted_setup.json)
+    through the HIP path: sum L_i = G, sum w^i L_i = [tau]G, and MSM(p, monomial) == MSM(NTT(p), lagrange)."""
+    import os
+    c = BLS12_381
+    kzg = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kzg4096_bls12381.npz"))
+    n = 4096
+    L, M = kzg["g1_lagrange"], kzg["g1_monomial"]
+    aff = lambda jac: oracle.jac_to_affine(c.cid, 0, jac)
+    one = fr_to_arr(c, [1] * n)
+    assert np.array_equal(aff(ecc.MultiExp(gpu_ctx, c.name, 0, L, one)), M[0])
+    w = c.fr_root_of_unity(n)
+    pw = fr_to_arr(c, [pow(w, i, c.r) for i in range(n)])
+    assert np.array_equal(aff(ecc.MultiExp(gpu_ctx, c.name, 0, L, pw)), M[1])
+    rng = pyref.Xoshiro(4844)
+    p = fr_to_arr(c, [rng.field(c.r) for _ in range(n)])
+    d = fft.Domain(gpu_ctx, c.name, n)
+    ev_bitrev = d.FFT(p, fft.DIF)
+    d.close()
+    idx = np.array([pyref.bitrev(i, 12) for i in range(n)])
+    lhs = aff(ecc.MultiExp(gpu_ctx, c.name, 0, M, p))
+    rhs = aff(ecc.MultiExp(gpu_ctx, c.name, 0, L, ev_bitrev[idx]))
+    assert np.array_equal(lhs, rhs) and lhs.any()

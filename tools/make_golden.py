@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/ from the fixtures the reference ships (run in the build container, where /root/reference
+exists; the GPU box only sees the committed outputs).
+
+  kzg4096_bls12381.npz   std/evmprecompiles/kzg_trusted_setup.json (EIP-4844 ceremony): g1_monomial, g1_lagrange
+                         (4096 each) and g2_monomial[0..3], decompressed with oracle/pyref.py to gnark memory images
+                         (Montgomery limbs) + the compressed bytes of the first 8 entries (decompression KATs)
+  vk_*.bin               backend/solidity/testdata/blank_groth16_{bn254,bls12381}_nocommit.vk (serialized VKs, raw)
+  bellman_bls12381.json  the first (vk, proof) tuple of backend/groth16/bellman_test.go:26-40 (base64 as in the file)
+"""
+import base64
+import json
+import os
+import re
+import shutil
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import pyref  # noqa: E402
+from helpers import g1_to_arr, g2_to_arr  # noqa: E402
+
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    c = pyref.BLS12_381
+    ts = json.load(open(os.path.join(REF, "std/evmprecompiles/kzg_trusted_setup.json")))
+    hexb = lambda s: bytes.fromhex(s[2:])
+    mono = [pyref.g1_decompress(c, hexb(s)) for s in ts["g1_monomial"]]
+    lag = [pyref.g1_decompress(c, hexb(s)) for s in ts["g1_lagrange"]]
+    g2m = [pyref.g2_decompress(c, hexb(s)) for s in ts["g2_monomial"][:4]]
+    np.savez_compressed(
+        os.path.join(OUT, "kzg4096_bls12381.npz"),
+        g1_monomial=g1_to_arr(c, mono), g1_lagrange=g1_to_arr(c, lag), g2_monomial=g2_to_arr(c, g2m),
+        g1_monomial_compressed=np.frombuffer(b"".join(hexb(s) for s in ts["g1_monomial"][:8]), dtype=np.uint8),
+        g1_lagrange_compressed=np.frombuffer(b"".join(hexb(s) for s in ts["g1_lagrange"][:8]), dtype=np.uint8),
+        g2_monomial_compressed=np.frombuffer(b"".join(hexb(s) for s in ts["g2_monomial"][:4]), dtype=np.uint8))
+    for name in ("blank_groth16_bn254_nocommit.vk", "blank_groth16_bls12381_nocommit.vk"):
+        shutil.copyfile(os.path.join(REF, "backend/solidity/testdata", name), os.path.join(OUT, "vk_" + name.replace(".vk", ".bin")))
+    src = open(os.path.join(REF, "backend/groth16/bellman_test.go")).read()
+    strs = re.findall(r'"([A-Za-z0-9+/=]{40,})"', src)
+    json.dump({"vk": strs[0], "proof": strs[1], "inputs": strs[2] if len(strs) > 2 else ""}, open(os.path.join(OUT, "bellman_bls12381.json"), "w"))
+    print("wrote", sorted(os.listdir(OUT)))
+
+
+if __name__ == "__main__":
+    main()
