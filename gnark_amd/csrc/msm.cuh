@@ -93,6 +93,28 @@ static __global__ void msm_tasks_kernel(const uint32_t* __restrict__ off, uint32
     ntask[b] = (sz + seg - 1) / seg;
 }
 
+// task t of bucket b covers sorted pairs [start, start+len); key = SEG - len so that an ascending radix sort puts the
+// longest tasks first and lanes of one wave get tasks of (nearly) equal length (bucket sizes are Poisson-distributed:
+// without this a wave waits for its longest bucket, ~25 % of the lanes' time at 2^24)
+static __global__ void msm_iota_kernel(uint32_t* __restrict__ out, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = i;
+}
+
+static __global__ void msm_task_list_kernel(const uint32_t* __restrict__ off, const uint32_t* __restrict__ task_off, uint32_t nb,
+                                            uint32_t seg, uint32_t* __restrict__ task_start, uint32_t* __restrict__ task_key) {
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    uint32_t t0 = task_off[b], t1 = task_off[b + 1];
+    uint32_t start = off[b], end = off[b + 1];
+    for (uint32_t t = t0; t < t1; t++) {
+        uint32_t len = end - start < seg ? end - start : seg;
+        task_start[t] = start;
+        task_key[t] = seg - len;
+        start += len;
+    }
+}
+
 // ---- 4. accumulate --------------------------------------------------------------------------------
 // minimum waves per SIMD requested from the register allocator, by point size (tuned on MI355X):
 // the bucket loop is a long dependent chain of v_mad_u64_u32, so it needs >= 2 resident waves per SIMD to stay busy.
@@ -103,23 +125,15 @@ template <class F> struct AccumulateTuning {
 template <class F>
 __global__ void __launch_bounds__(256, AccumulateTuning<F>::MIN_WAVES)
 msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ vals,
-                      const uint32_t* __restrict__ off, const uint32_t* __restrict__ task_off, uint32_t nb, uint32_t seg,
-                      XYZZ<F>* __restrict__ partial) {
+                      const uint32_t* __restrict__ task_start, const uint32_t* __restrict__ task_key_sorted,
+                      const uint32_t* __restrict__ task_perm, uint32_t max_tasks, uint32_t seg, XYZZ<F>* __restrict__ partial) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t total = task_off[nb];
-    if (t >= total) return;
-    // bucket b with task_off[b] <= t < task_off[b+1]
-    uint32_t lo = 0, hi = nb;   // invariant: task_off[lo] <= t, task_off[hi] > t
-    while (hi - lo > 1) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (task_off[mid] <= t) lo = mid;
-        else hi = mid;
-    }
-    uint32_t b = lo;
-    uint32_t k = t - task_off[b];
-    uint32_t start = off[b] + k * seg;
-    uint32_t end = off[b + 1];
-    if (end - start > seg) end = start + seg;
+    if (t >= max_tasks) return;
+    const uint32_t key = task_key_sorted[t];
+    if (key >= seg) return;              // padding slots (length 0) sort last
+    const uint32_t tid = task_perm[t];
+    const uint32_t start = task_start[tid];
+    const uint32_t end = start + (seg - key);
     XYZZ<F> acc = xyzz_inf<F>();
     for (uint32_t p = start; p < end; p++) {
         uint32_t v = vals[p];
@@ -127,7 +141,7 @@ msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __res
         if (v & MSM_SIGN) q.y = neg(q.y);
         acc = madd_t<true>(acc, q);
     }
-    store_pod(&partial[t], acc);
+    store_pod(&partial[tid], acc);
 }
 
 // ---- 5. merge partials ----------------------------------------------------------------------------
@@ -257,7 +271,7 @@ int msm_windows_device(Ctx* ctx, const void* d_bases, const void* d_scalars, siz
     const uint32_t groups_per_win = half / m_groups;
     const uint32_t total_groups = groups_per_win * nwl;
 
-    uint32_t *keys, *vals, *keys2, *vals2, *off, *ntask, *task_off, *hot_list, *hot_count;
+    uint32_t *keys, *vals, *keys2, *vals2, *off, *ntask, *task_off, *hot_list, *hot_count, *task_start, *task_key, *task_key2, *task_id, *task_perm;
     XYZZ<F>*partial, *bsum, *gsum, *gsum2, *wsum;
     void* sort_tmp;
     GA_CHECK(ctx->scratch_get("msm_keys", m * 4, (void**)&keys));
@@ -269,6 +283,11 @@ int msm_windows_device(Ctx* ctx, const void* d_bases, const void* d_scalars, siz
     GA_CHECK(ctx->scratch_get("msm_task_off", ((uint64_t)nb + 2) * 4, (void**)&task_off));
     GA_CHECK(ctx->scratch_get("msm_hot", ((uint64_t)nb + 2) * 4, (void**)&hot_list));
     GA_CHECK(ctx->scratch_get("msm_hot_count", 256, (void**)&hot_count));
+    GA_CHECK(ctx->scratch_get("msm_task_start", max_tasks * 4, (void**)&task_start));
+    GA_CHECK(ctx->scratch_get("msm_task_key", max_tasks * 4, (void**)&task_key));
+    GA_CHECK(ctx->scratch_get("msm_task_key2", max_tasks * 4, (void**)&task_key2));
+    GA_CHECK(ctx->scratch_get("msm_task_id", max_tasks * 4, (void**)&task_id));
+    GA_CHECK(ctx->scratch_get("msm_task_perm", max_tasks * 4, (void**)&task_perm));
     GA_CHECK(ctx->scratch_get("msm_partial", max_tasks * sizeof(XYZZ<F>), (void**)&partial));
     GA_CHECK(ctx->scratch_get("msm_bsum", (uint64_t)nb * sizeof(XYZZ<F>), (void**)&bsum));
     GA_CHECK(ctx->scratch_get("msm_gsum", (uint64_t)total_groups * sizeof(XYZZ<F>), (void**)&gsum));
@@ -301,12 +320,25 @@ int msm_windows_device(Ctx* ctx, const void* d_bases, const void* d_scalars, siz
         GA_CHECK(ctx->scratch_get("msm_scan_tmp", tmp_bytes + 256, &sort_tmp));
         GA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(sort_tmp, tmp_bytes, ntask, task_off, (int)(nb + 1), st));
         GA_HIP_CHECK(hipMemsetAsync(hot_count, 0, 4, st));
+        // explicit task list, ordered by decreasing length (padding slots keep key = 0xFFFFFFFF >= seg)
+        GA_HIP_CHECK(hipMemsetAsync(task_key, 0xFF, max_tasks * 4, st));
+        hipLaunchKernelGGL(msm_task_list_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, (const uint32_t*)off, (const uint32_t*)task_off,
+                           nb, seg, task_start, task_key);
+        hipLaunchKernelGGL(msm_iota_kernel, dim3((unsigned)((max_tasks + 255) / 256)), dim3(256), 0, st, task_id, (uint32_t)max_tasks);
+        GA_KERNEL_CHECK();
+        int kbits = 1;
+        while ((1u << kbits) <= seg) kbits++;
+        // padding keys are all-ones: sort on kbits+1 bits so that they stay behind every real key (real keys < seg)
+        size_t tb = 0;
+        GA_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, task_key, task_key2, task_id, task_perm, (unsigned)max_tasks, 0, kbits + 1, st));
+        GA_CHECK(ctx->scratch_get("msm_tasksort_tmp", tb + 256, &sort_tmp));
+        GA_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(sort_tmp, tb, task_key, task_key2, task_id, task_perm, (unsigned)max_tasks, 0, kbits + 1, st));
     }
     {
         StageTimer tm(ctx, "msm_accumulate");
         hipLaunchKernelGGL((msm_accumulate_kernel<F>), dim3((unsigned)((max_tasks + 255) / 256)), dim3(256), 0, st,
-                           (const Affine<F>*)d_bases, (const uint32_t*)vals2, (const uint32_t*)off, (const uint32_t*)task_off, nb,
-                           seg, partial);
+                           (const Affine<F>*)d_bases, (const uint32_t*)vals2, (const uint32_t*)task_start, (const uint32_t*)task_key2,
+                           (const uint32_t*)task_perm, (uint32_t)max_tasks, seg, partial);
         GA_KERNEL_CHECK();
     }
     {
