@@ -35,6 +35,9 @@ namespace ga {
 #ifndef GA_ACC_MINW_BIG
 #define GA_ACC_MINW_BIG 1     // BLS12-381 G2 (384 B)
 #endif
+#ifndef GA_ACC_LDS_BYTES
+#define GA_ACC_LDS_BYTES 256  // accumulators of at least this many bytes live in LDS (G2)
+#endif
 constexpr uint32_t MSM_SIGN = 0x80000000u;
 constexpr int MSM_HOT_TASKS = 8;      // buckets with more partials than this go to the wave-parallel merge
 constexpr int MSM_GROUP = 32;         // buckets per running-sum group in the window reduction
@@ -122,6 +125,63 @@ template <class F> struct AccumulateTuning {
     static constexpr int MIN_WAVES = sizeof(XYZZ<F>) <= 128 ? GA_ACC_MINW_SMALL : (sizeof(XYZZ<F>) <= 256 ? GA_ACC_MINW_MID : GA_ACC_MINW_BIG);
 };
 
+// Accumulator kept in LDS, word-major ([word][lane]: conflict-free) -- used for the Fp2 points, whose XYZZ accumulator
+// (256 / 384 B per lane) would otherwise be spilled to scratch by the register allocator at 2 waves per SIMD.
+template <class F>
+struct LdsAcc {
+    uint32_t* base;   // &lds[threadIdx.x], stride 256 words
+    static constexpr int FW = sizeof(F) / 4;
+    __device__ __forceinline__ F get(int field) const {
+        F r;
+        uint32_t* w = reinterpret_cast<uint32_t*>(&r);
+#pragma unroll
+        for (int i = 0; i < FW; i++) w[i] = base[(field * FW + i) * 256];
+        return r;
+    }
+    __device__ __forceinline__ void put(int field, const F& v) const {
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(&v);
+#pragma unroll
+        for (int i = 0; i < FW; i++) base[(field * FW + i) * 256] = w[i];
+    }
+};
+
+// acc (in LDS) += q   -- same formulas as madd_t<true>, loading accumulator coordinates only where they are consumed
+template <class F>
+__device__ __forceinline__ void madd_lds(const LdsAcc<F>& A, const Affine<F>& q) {
+    if (is_inf(q)) return;
+    F zz = A.get(2);
+    if (is_zero(zz)) {   // accumulator is infinity
+        A.put(0, q.x);
+        A.put(1, q.y);
+        A.put(2, FieldTraits<F>::one());
+        A.put(3, FieldTraits<F>::one());
+        return;
+    }
+    F U2 = mul_body(q.x, zz);
+    F ax = A.get(0);
+    F Pp = sub(U2, ax);
+    F zzz = A.get(3);
+    F S2 = mul_body(q.y, zzz);
+    F ay = A.get(1);
+    F R = sub(S2, ay);
+    if (is_zero(Pp)) {
+        XYZZ<F> d = is_zero(R) ? dbl_affine_t<true>(q) : xyzz_inf<F>();
+        A.put(0, d.x);
+        A.put(1, d.y);
+        A.put(2, d.zz);
+        A.put(3, d.zzz);
+        return;
+    }
+    F PP = sqr_body(Pp);
+    A.put(2, mul_body(zz, PP));
+    F PPP = mul_body(Pp, PP);
+    A.put(3, mul_body(zzz, PPP));
+    F Q = mul_body(ax, PP);
+    F X3 = sub(sub(sqr_body(R), PPP), dbl(Q));
+    A.put(0, X3);
+    A.put(1, sub(mul_body(R, sub(Q, X3)), mul_body(ay, PPP)));
+}
+
 template <class F>
 __global__ void __launch_bounds__(256, AccumulateTuning<F>::MIN_WAVES)
 msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ vals,
@@ -134,14 +194,35 @@ msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __res
     const uint32_t tid = task_perm[t];
     const uint32_t start = task_start[tid];
     const uint32_t end = start + (seg - key);
-    XYZZ<F> acc = xyzz_inf<F>();
-    for (uint32_t p = start; p < end; p++) {
-        uint32_t v = vals[p];
-        Affine<F> q = load_pod<Affine<F>>(&bases[v & ~MSM_SIGN]);
-        if (v & MSM_SIGN) q.y = neg(q.y);
-        acc = madd_t<true>(acc, q);
+    if constexpr (sizeof(XYZZ<F>) >= GA_ACC_LDS_BYTES) {
+        __shared__ uint32_t lds[sizeof(XYZZ<F>) / 4 * 256];
+        LdsAcc<F> A{lds + threadIdx.x};
+        A.put(2, FieldTraits<F>::zero());
+        for (uint32_t p = start; p < end; p++) {
+            uint32_t v = vals[p];
+            Affine<F> q = load_pod<Affine<F>>(&bases[v & ~MSM_SIGN]);
+            if (v & MSM_SIGN) q.y = neg(q.y);
+            madd_lds(A, q);
+        }
+        XYZZ<F> acc;
+        acc.zz = A.get(2);
+        if (is_zero(acc.zz)) acc = xyzz_inf<F>();
+        else {
+            acc.x = A.get(0);
+            acc.y = A.get(1);
+            acc.zzz = A.get(3);
+        }
+        store_pod(&partial[tid], acc);
+    } else {
+        XYZZ<F> acc = xyzz_inf<F>();
+        for (uint32_t p = start; p < end; p++) {
+            uint32_t v = vals[p];
+            Affine<F> q = load_pod<Affine<F>>(&bases[v & ~MSM_SIGN]);
+            if (v & MSM_SIGN) q.y = neg(q.y);
+            acc = madd_t<true>(acc, q);
+        }
+        store_pod(&partial[tid], acc);
     }
-    store_pod(&partial[tid], acc);
 }
 
 // ---- 5. merge partials ----------------------------------------------------------------------------
