@@ -145,6 +145,7 @@ int ga_ctx_create(int device, ga_ctx** out) {
     Ctx* c = new Ctx();
     c->device = device;
     GA_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    GA_HIP_CHECK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     *out = reinterpret_cast<ga_ctx*>(c);
     return GA_OK;
 }
@@ -160,6 +161,7 @@ void ga_ctx_destroy(ga_ctx* h) {
         hipEventDestroy(s.b);
     }
     hipStreamDestroy(c->stream);
+    hipStreamDestroy(c->copy_stream);
     delete c;
 }
 

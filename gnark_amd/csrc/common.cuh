@@ -80,6 +80,7 @@ struct StageRec {
 struct Ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;   // uploads that overlap kernels (groth16.hip)
     std::mutex mu;
     bool profiling = false;
     std::vector<StageRec> stages;

@@ -5,6 +5,8 @@
 // caller-supplied randomness (r, s).  The host side is C++ because the reference's host side is compiled Go and no Go
 // toolchain exists in the build image (INTEGRATION.md shows the cgo binding that calls this file's two entry points).
 #include <algorithm>
+#include <string>
+#include <thread>
 
 #include "hostops.cuh"
 
@@ -132,30 +134,64 @@ static int prove(G16Pk* pk, const void* w, const void* a, const void* b, const v
     GA_CHECK(ctx->scratch_get("h_c", n * 32, &d_hc));
     GA_CHECK(ctx->scratch_get("g16_wa", pk->len_a * 32 + 32, &d_wa));
     GA_CHECK(ctx->scratch_get("g16_wb", pk->len_b * 32 + 32, &d_wb));
+    // W first (the four witness MSMs only need W); A, B, C are uploaded by a helper thread on a second stream while
+    // those MSMs run -- pageable H2D copies block the calling thread, hence the thread.  Everything is joined before
+    // this function returns, so no host pointer outlives the call.
     {
-        StageTimer tm(ctx, "g16_h2d");
+        StageTimer tm(ctx, "g16_h2d_w");
         GA_HIP_CHECK(hipMemcpyAsync(d_w, w, pk->nb_wires * 32, hipMemcpyHostToDevice, st));
+    }
+    hipEvent_t ev_abc;
+    GA_HIP_CHECK(hipEventCreateWithFlags(&ev_abc, hipEventDisableTiming));
+    int up_rc = GA_OK;
+    std::string up_err;
+    std::thread uploader([&]() {
+        if (hipSetDevice(ctx->device) != hipSuccess) {
+            up_rc = GA_ERR_HIP;
+            return;
+        }
         const void* src[3] = {a, b, c};
         void* dst[3] = {d_ha, d_hb, d_hc};
-        for (int k = 0; k < 3; k++) {
-            GA_HIP_CHECK(hipMemcpyAsync(dst[k], src[k], n_constraints * 32, hipMemcpyHostToDevice, st));
-            if (n > n_constraints)   // computeH pads to the domain size (prove.go:356-359)
-                GA_HIP_CHECK(hipMemsetAsync((char*)dst[k] + n_constraints * 32, 0, (n - n_constraints) * 32, st));
+        hipError_t e = hipSuccess;
+        for (int k = 0; k < 3 && e == hipSuccess; k++) {
+            e = hipMemcpyAsync(dst[k], src[k], n_constraints * 32, hipMemcpyHostToDevice, ctx->copy_stream);
+            if (e == hipSuccess && n > n_constraints)   // computeH pads to the domain size (prove.go:356-359)
+                e = hipMemsetAsync((char*)dst[k] + n_constraints * 32, 0, (n - n_constraints) * 32, ctx->copy_stream);
         }
-    }
-    // ---- H ------------------------------------------------------------------------------------------
-    GA_CHECK(ntt_domain_compute_h<C>(pk->dom, d_ha, d_hb, d_hc));   // h in d_ha, bit-reversed like pk.G1.Z
+        if (e == hipSuccess) e = hipEventRecord(ev_abc, ctx->copy_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->copy_stream);
+        if (e != hipSuccess) {
+            up_rc = GA_ERR_HIP;
+            up_err = hipGetErrorString(e);
+        }
+    });
+    struct Joiner {
+        std::thread& t;
+        ~Joiner() {
+            if (t.joinable()) t.join();
+        }
+    } joiner{uploader};
     // ---- wire filtering (prove.go:147-168) ------------------------------------------------------------
     GA_CHECK(util_gather_fr<C>(ctx, d_wa, d_w, pk->d_idx_a, pk->len_a));
     GA_CHECK(util_gather_fr<C>(ctx, d_wb, d_w, pk->d_idx_b, pk->len_b));
-    // ---- the five MSMs (prove.go:194,207,227,237,283) -------------------------------------------------
+    // ---- the four witness MSMs (prove.go:194,207,237,283) ----------------------------------------------
     XYZZ<F1> ar, bs1, krs, krs2;
     XYZZ<F2> bs2;
     GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_a, d_wa, pk->len_a, true, &ar)));
     GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_b, d_wb, pk->len_b, true, &bs1)));
     GA_CHECK((host_msm<C, GA_G2>(ctx, pk->d_b2, d_wb, pk->len_b2, true, &bs2)));
     GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_k, (const char*)d_w + nb_public * 32, pk->len_k, true, &krs)));
-    GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_z, d_ha, pk->len_z, true, &krs2)));   // h[:n-1], prove.go:225-227
+    // ---- H (prove.go:134,346-389), then the MSM over pk.G1.Z (prove.go:225-227) ----------------------------
+    uploader.join();
+    if (up_rc != GA_OK) {
+        set_error("prove: uploading A,B,C failed: %s", up_err.c_str());
+        hipEventDestroy(ev_abc);
+        return up_rc;
+    }
+    GA_HIP_CHECK(hipStreamWaitEvent(st, ev_abc, 0));
+    GA_CHECK(ntt_domain_compute_h<C>(pk->dom, d_ha, d_hb, d_hc));   // h in d_ha, bit-reversed like pk.G1.Z
+    GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_z, d_ha, pk->len_z, true, &krs2)));   // h[:n-1]
+    hipEventDestroy(ev_abc);
     // ---- epilogue on the host (prove.go:171-185,199-200,212-214,241-269,287-292) ----------------------------
     StageTimer tm(ctx, "g16_epilogue_host");
     Fe<FrP> r, s;

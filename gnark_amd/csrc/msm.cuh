@@ -27,7 +27,7 @@
 namespace ga {
 
 #ifndef GA_ACC_MINW_SMALL
-#define GA_ACC_MINW_SMALL 3   // BN254 G1 (XYZZ = 128 B)
+#define GA_ACC_MINW_SMALL 4   // BN254 G1 (XYZZ = 128 B)
 #endif
 #ifndef GA_ACC_MINW_MID
 #define GA_ACC_MINW_MID 2     // BN254 G2 (256 B), BLS12-381 G1 (192 B)
@@ -36,7 +36,7 @@ namespace ga {
 #define GA_ACC_MINW_BIG 1     // BLS12-381 G2 (384 B)
 #endif
 #ifndef GA_ACC_LDS_BYTES
-#define GA_ACC_LDS_BYTES 256  // accumulators of at least this many bytes live in LDS (G2)
+#define GA_ACC_LDS_BYTES 128  // accumulators of at least this many bytes live in LDS (all groups; measured best)
 #endif
 constexpr uint32_t MSM_SIGN = 0x80000000u;
 constexpr int MSM_HOT_TASKS = 8;      // buckets with more partials than this go to the wave-parallel merge

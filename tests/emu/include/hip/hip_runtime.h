@@ -179,7 +179,7 @@ struct hipemuEvent {
 };
 typedef hipemuEvent* hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
-enum { hipHostMallocDefault = 0, hipStreamNonBlocking = 1, hipEventDefault = 0 };
+enum { hipHostMallocDefault = 0, hipStreamNonBlocking = 1, hipEventDefault = 0, hipEventDisableTiming = 2 };
 
 struct hipDeviceProp_t {
     char name[256];
