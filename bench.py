@@ -168,16 +168,24 @@ def main():
         acc = stages.get("msm_accumulate", {"avg_ms": float("nan")})
         alg_bytes = 96.0 * n if cid == 0 else 128.0 * n
         achieved = alg_bytes / (acc["avg_ms"] * 1e-3) / 1e9
+        traffic = None   # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_latest.json), same shape only
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))["kernels"]["msm_accumulate_kernel"]
+            ent = pmc.get(args.curve, {}).get(str(args.log_n))
+            if ent and world == 1:
+                traffic = ent["fetch_bytes"] + ent["write_bytes"]
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
-            "metric": "G1 MSM throughput, BN254, 2^%d scalar-muls per GPU (Groth16 proofs/s at 2^%d constraints in 'groth16')" % (args.log_n, args.log_n),
+            "metric": "G1 MSM throughput, %s, 2^%d scalar-muls per GPU (Groth16 proofs/s at 2^%d constraints in 'groth16')" % (args.curve.upper(), args.log_n, args.log_n),
             "value": round(value, 3), "unit": "Mscalar-mul/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32 limbs (v_mad_u64_u32) over 4x64-bit Montgomery elements", "data": "synthetic",
-            "config": {"workload": "BN254 G1 Pippenger MSM, 2^%d uniform scalars x distinct known-dlog affine bases per GPU, inputs resident in HBM" % args.log_n,
+            "dtype": "u64 Montgomery limbs in memory; 29/28-bit limbs, v_mad_u64_u32 (32x32+64) in registers", "data": "synthetic",
+            "config": {"workload": "%s G1 Pippenger MSM, 2^%d uniform scalars x distinct known-dlog affine bases per GPU, inputs resident in HBM" % (args.curve.upper(), args.log_n),
                        "curve": args.curve, "window_bits": cbits, "windows": nwin,
                        "parallelism": "1 GPU" if world == 1 else "base-range sharding x%d, RCCL all_gather of Jacobian partials" % world},
             "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(achieved / 8000.0, 6), "traffic": None,
+                         "frac": round(achieved / 8000.0, 6), "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": acc["avg_ms"],
                          "note": "MSM is integer-multiplier bound (SURVEY 8d): ~2.4e4 32-bit MADs per scalar-mul vs 96 B"},
             "stages_ms": stages,
@@ -204,10 +212,11 @@ def main():
         ctx.profile(False)
         pk.FreeGPUResources()
         ntt_ms = sum(v["total_ms"] for k, v in gst.items() if k.startswith("ntt_") or k == "h_pointwise") / args.groth16_proofs
+        bytes_per_constraint = 992 if cid == 0 else 1184   # 4 G1 + 1 G2 MSM + 7 NTTs
         out["groth16"] = {"proofs_per_s": round(args.groth16_proofs / el, 4), "ms_per_proof": round(el * 1e3 / args.groth16_proofs, 2),
                           "proofs": args.groth16_proofs, "constraints": n, "key_setup_s": round(setup_s, 1),
                           "definition": "W,A,B,C in host memory -> Ar,Bs,Krs affine on host; key pinned; solver excluded",
-                          "algorithmic_bytes": 992 * n, "hbm_frac_whole_proof": round(992.0 * n / (el / args.groth16_proofs) / 8e12, 6),
+                          "algorithmic_bytes": bytes_per_constraint * n, "hbm_frac_whole_proof": round(bytes_per_constraint * n / (el / args.groth16_proofs) / 8e12, 6),
                           "computeH_ms": round(ntt_ms, 3),
                           "computeH_hbm_frac": round(448.0 * n / (ntt_ms * 1e-3) / 8e12, 5) if ntt_ms > 0 else None,
                           "proof_sha": __import__("hashlib").sha256(proof.WriteTo()).hexdigest()[:16],
@@ -232,8 +241,8 @@ def main():
         cpu_s = time.perf_counter() - t0
         gpu = ecc.MultiExp(ctx, cid, _lib.G1, sb, ss, n=sn)
         same = bool(np.array_equal(oracle.jac_to_affine(cid, 0, ref), ecc.jac_to_affine(cid, _lib.G1, gpu)))
-        out["cpu_baseline"] = {"value": round(sn / cpu_s / 1e6, 4), "unit": "Mscalar-mul/s", "cores": min(cores, 17), "kind": "port",
-                               "sample": "BN254 G1 MSM of 2^%d points, oracle/oracle.c Pippenger (one thread per window), %.1f s" % (sample_log, cpu_s),
+        out["cpu_baseline"] = {"value": round(sn / cpu_s / 1e6, 4), "unit": "Mscalar-mul/s", "cores": min(cores, oracle.msm_windows(cid, sn)), "kind": "port",
+                               "sample": "%s G1 MSM of 2^%d points, oracle/oracle.c Pippenger (one thread per window), %.1f s" % (args.curve.upper(), sample_log, cpu_s),
                                "gpu_result_matches_oracle": same}
     if rank == 0:
         print(json.dumps(out))

@@ -33,7 +33,7 @@ namespace ga {
 #define GA_ACC_MINW_MID 2     // BN254 G2 (256 B), BLS12-381 G1 (192 B)
 #endif
 #ifndef GA_ACC_MINW_BIG
-#define GA_ACC_MINW_BIG 1     // BLS12-381 G2 (384 B)
+#define GA_ACC_MINW_BIG 2     // BLS12-381 G2 (384 B), 128-thread workgroups
 #endif
 #ifndef GA_ACC_LDS_BYTES
 #define GA_ACC_LDS_BYTES 128  // accumulators of at least this many bytes live in LDS (all groups; measured best)
@@ -123,25 +123,28 @@ static __global__ void msm_task_list_kernel(const uint32_t* __restrict__ off, co
 // the bucket loop is a long dependent chain of v_mad_u64_u32, so it needs >= 2 resident waves per SIMD to stay busy.
 template <class F> struct AccumulateTuning {
     static constexpr int MIN_WAVES = sizeof(XYZZ<F>) <= 128 ? GA_ACC_MINW_SMALL : (sizeof(XYZZ<F>) <= 256 ? GA_ACC_MINW_MID : GA_ACC_MINW_BIG);
+    // workgroup size: the LDS-resident accumulators of one workgroup must leave room for >= 2 workgroups per CU
+    static constexpr int THREADS = sizeof(XYZZ<F>) <= 256 ? 256 : 128;
 };
 
 // Accumulator kept in LDS, word-major ([word][lane]: conflict-free) -- used for the Fp2 points, whose XYZZ accumulator
 // (256 / 384 B per lane) would otherwise be spilled to scratch by the register allocator at 2 waves per SIMD.
 template <class F>
 struct LdsAcc {
-    uint32_t* base;   // &lds[threadIdx.x], stride 256 words
+    uint32_t* base;   // &lds[threadIdx.x], stride THREADS words
     static constexpr int FW = sizeof(F) / 4;
+    static constexpr int STRIDE = AccumulateTuning<F>::THREADS;
     __device__ __forceinline__ F get(int field) const {
         F r;
         uint32_t* w = reinterpret_cast<uint32_t*>(&r);
 #pragma unroll
-        for (int i = 0; i < FW; i++) w[i] = base[(field * FW + i) * 256];
+        for (int i = 0; i < FW; i++) w[i] = base[(field * FW + i) * STRIDE];
         return r;
     }
     __device__ __forceinline__ void put(int field, const F& v) const {
         const uint32_t* w = reinterpret_cast<const uint32_t*>(&v);
 #pragma unroll
-        for (int i = 0; i < FW; i++) base[(field * FW + i) * 256] = w[i];
+        for (int i = 0; i < FW; i++) base[(field * FW + i) * STRIDE] = w[i];
     }
 };
 
@@ -183,7 +186,7 @@ __device__ __forceinline__ void madd_lds(const LdsAcc<F>& A, const Affine<F>& q)
 }
 
 template <class F>
-__global__ void __launch_bounds__(256, AccumulateTuning<F>::MIN_WAVES)
+__global__ void __launch_bounds__(AccumulateTuning<F>::THREADS, AccumulateTuning<F>::MIN_WAVES)
 msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ vals,
                       const uint32_t* __restrict__ task_start, const uint32_t* __restrict__ task_key_sorted,
                       const uint32_t* __restrict__ task_perm, uint32_t max_tasks, uint32_t seg, XYZZ<F>* __restrict__ partial) {
@@ -195,7 +198,7 @@ msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __res
     const uint32_t start = task_start[tid];
     const uint32_t end = start + (seg - key);
     if constexpr (sizeof(XYZZ<F>) >= GA_ACC_LDS_BYTES) {
-        __shared__ uint32_t lds[sizeof(XYZZ<F>) / 4 * 256];
+        __shared__ uint32_t lds[sizeof(XYZZ<F>) / 4 * AccumulateTuning<F>::THREADS];
         LdsAcc<F> A{lds + threadIdx.x};
         A.put(2, FieldTraits<F>::zero());
         for (uint32_t p = start; p < end; p++) {
@@ -417,7 +420,8 @@ int msm_windows_device(Ctx* ctx, const void* d_bases, const void* d_scalars, siz
     }
     {
         StageTimer tm(ctx, "msm_accumulate");
-        hipLaunchKernelGGL((msm_accumulate_kernel<F>), dim3((unsigned)((max_tasks + 255) / 256)), dim3(256), 0, st,
+        constexpr unsigned AT = AccumulateTuning<F>::THREADS;
+        hipLaunchKernelGGL((msm_accumulate_kernel<F>), dim3((unsigned)((max_tasks + AT - 1) / AT)), dim3(AT), 0, st,
                            (const Affine<F>*)d_bases, (const uint32_t*)vals2, (const uint32_t*)task_start, (const uint32_t*)task_key2,
                            (const uint32_t*)task_perm, (uint32_t)max_tasks, seg, partial);
         GA_KERNEL_CHECK();

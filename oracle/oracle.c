@@ -455,6 +455,12 @@ static int msm_best_c(int bits, size_t n) {
     return bc;
 }
 
+/* number of windows (= max useful threads) oracle_msm uses for n points */
+int oracle_msm_windows(int curve, size_t n) {
+    const int bits = CURVES[curve].fr.bits;
+    return bits / msm_best_c(bits, n ? n : 1) + 1;
+}
+
 /* sum scalars[i]*points[i] -> Jacobian image.  scalars: fr images (Montgomery if mont). */
 int oracle_msm(int curve, int group, const u64* points, const u64* scalars, size_t n, int mont, u64* out_jac,
                int nthreads) {

@@ -65,6 +65,10 @@ def msm(curve, group, points, scalars, mont=True, nthreads=1, naive=False):
     return out
 
 
+def msm_windows(curve, n) -> int:
+    return dll().oracle_msm_windows(curve, C.c_size_t(n))
+
+
 def jac_to_affine(curve, group, jac):
     jac = _u64(jac)
     out = np.zeros(aff_words(curve, group), dtype=np.uint64)

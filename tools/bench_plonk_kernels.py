@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""BASELINE config 5: the kernel work of one PLONK BN254 proof at 2^22 gates:
+10 G1 MSMs over an SRS of 2^22 points + 108 NTTs of size 2^22 (4 cosets x 12 polynomials x {iFFT, coset FFT} + 12) +
+one iNTT of size 2^24, everything resident in HBM.  The PLONK round logic itself stays in Go."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import gnark_amd  # noqa: E402
+from gnark_amd import _lib, ecc, fft  # noqa: E402
+
+
+def main():
+    logn = int(os.environ.get("GA_PLONK_LOGN", "22"))
+    n = 1 << logn
+    ctx = gnark_amd.Context(0)
+    lib = ctx.lib
+    srs = ctx.malloc(n * 64)
+    lib.check(lib.ga_gen_bases(ctx.handle, 0, 0, 0x5EED0007, n, srs.ptr, None))
+    polys = [ctx.malloc(n * 32) for _ in range(12)]
+    for i, p in enumerate(polys):
+        lib.check(lib.ga_gen_scalars(ctx.handle, 0, 100 + i, n, p.ptr))
+    big = ctx.malloc(4 * n * 32)
+    lib.check(lib.ga_gen_scalars(ctx.handle, 0, 999, 4 * n, big.ptr))
+    d = fft.Domain(ctx, "bn254", n)
+    d4 = fft.Domain(ctx, "bn254", 4 * n)
+
+    def proof_kernels():
+        for k in range(10):                       # commitToLRO x3, Z, quotient x3, opening x2, linearised
+            ecc.MultiExp(ctx, "bn254", ecc.G1, srs, polys[k % 12], n=n)
+        for _ in range(4):                        # computeNumerator: per coset, every polynomial iFFT -> coset FFT
+            for p in polys:
+                d.FFTInverse(p, fft.DIF)
+                d.FFT(p, fft.DIT, on_coset=True)
+        for p in polys:                           # restore canonical form (prove.go:1101-1107, 1420)
+            d.FFTInverse(p, fft.DIF)
+        d4.FFTInverse(big, fft.DIF, on_coset=True)   # divideByZH: one size-4n inverse transform
+
+    proof_kernels()
+    ctx.profile(True)
+    ctx.profile_reset()
+    ctx.sync()
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        proof_kernels()
+    ctx.sync()
+    el = (time.perf_counter() - t0) / reps
+    st = {}
+    for name, ms in ctx.profile_read():
+        st[name] = st.get(name, 0.0) + ms / reps
+    alg = 10 * 96 * n + 108 * 64 * n + 64 * 4 * n
+    msm_ms = sum(v for k, v in st.items() if k.startswith("msm_"))
+    ntt_ms = sum(v for k, v in st.items() if k.startswith("ntt_"))
+    print(json.dumps({"workload": "PLONK BN254 2^%d kernels: 10 G1 MSM + 108 NTT(2^%d) + 1 iNTT(2^%d)" % (logn, logn, logn + 2),
+                      "ms_per_proof_kernels": round(el * 1e3, 2), "msm_ms": round(msm_ms, 2), "ntt_ms": round(ntt_ms, 2),
+                      "algorithmic_bytes": alg, "hbm_frac": round(alg / el / 8e12, 5),
+                      "ntt_hbm_frac": round((108 * 64 * n + 64 * 4 * n) / (ntt_ms * 1e-3) / 8e12, 5),
+                      "stages_ms": {k: round(v, 3) for k, v in st.items()}}))
+
+
+if __name__ == "__main__":
+    main()
