@@ -105,18 +105,22 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
+    ndev = max(1, torch.cuda.device_count())
+    device_index = local_rank % ndev       # one rank per GPU on the driver's runs; wraps only in single-GPU smoke runs
+    torch.cuda.set_device(device_index)
+    backend = os.environ.get("GA_BENCH_BACKEND", "nccl")   # "gloo" lets a 1-GPU box exercise the N>1 code path
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend=backend)
 
     import gnark_amd
     from gnark_amd import _lib, ecc
     from gnark_amd.device import curve_id, jac_words
     cid = curve_id(args.curve)
-    ctx = gnark_amd.Context(local_rank)
+    ctx = gnark_amd.Context(device_index)
     lib = ctx.lib
     n = 1 << args.log_n
     words_aff = gnark_amd.device.affine_words(cid, _lib.G1)
@@ -129,7 +133,7 @@ def main():
     cbits, nwin = ecc.plan(cid, _lib.G1, n)
 
     from gnark_amd import multigpu
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", device_index) if backend == "nccl" else None
 
     def step():
         # N = 1: plain MSM.  N > 1: partition B (base-point range) -- every rank reduces its own 2^log_n pairs to one
@@ -156,7 +160,7 @@ def main():
     stages = stage_stats(ctx.profile_read())
     ctx.profile(False)
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
