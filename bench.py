@@ -130,7 +130,14 @@ def main():
     scalars = ctx.malloc(n * 32)
     lib.check(lib.ga_gen_bases(ctx.handle, cid, _lib.G1, 0x5EED0002 + 977 * rank, n, bases.ptr, None))
     lib.check(lib.ga_gen_scalars(ctx.handle, cid, 0x5EED0001 + 977 * rank, n, scalars.ptr))
-    cbits, nwin = ecc.plan(cid, _lib.G1, n)
+    # the bases are a pinned key: keep them with their window multiples (ga_msm_table_*, built outside the timed region)
+    use_table = os.environ.get("GA_BENCH_TABLE", "1") != "0"
+    table = ecc.PrecomputedBases(ctx, cid, _lib.G1, bases, n=n) if use_table else None
+    if use_table:
+        ti = table.info()
+        cbits, nwin = ti["window_bits"], ti["windows"]
+    else:
+        cbits, nwin = ecc.plan(cid, _lib.G1, n)
 
     from gnark_amd import multigpu
     dev = torch.device("cuda", device_index) if backend == "nccl" else None
@@ -138,7 +145,7 @@ def main():
     def step():
         # N = 1: plain MSM.  N > 1: partition B (base-point range) -- every rank reduces its own 2^log_n pairs to one
         # Jacobian partial, RCCL all_gather of the partials, local add (gnark_amd/multigpu.py)
-        return multigpu.msm_base_sharded(ctx, cid, _lib.G1, bases, scalars, n, dist, dev)
+        return multigpu.msm_base_sharded(ctx, cid, _lib.G1, table if use_table else bases, scalars, n, dist, dev)
 
     def fence():
         torch.cuda.synchronize()
@@ -187,6 +194,7 @@ def main():
             "dtype": "u64 Montgomery limbs in memory; 29/28-bit limbs, v_mad_u64_u32 (32x32+64) in registers", "data": "synthetic",
             "config": {"workload": "%s G1 Pippenger MSM, 2^%d uniform scalars x distinct known-dlog affine bases per GPU, inputs resident in HBM" % (args.curve.upper(), args.log_n),
                        "curve": args.curve, "window_bits": cbits, "windows": nwin,
+                       "precompute": ("[2^(c*w)]P tables for all %d windows, %.1f GiB, one shared bucket set" % (nwin, ti["table_bytes"] / 2**30)) if use_table else "none",
                        "parallelism": "1 GPU" if world == 1 else "base-range sharding x%d, RCCL all_gather of Jacobian partials" % world},
             "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 6), "traffic": traffic,
@@ -196,6 +204,16 @@ def main():
         }
 
     # ---- Groth16 leg (rank 0 only; N=1 semantics) ---------------------------------------------------------------
+    if rank == 0 and world == 1 and use_table:
+        # the same MSM without precomputed tables (ga_msm on the raw bases), for reference
+        ecc.MultiExp(ctx, cid, _lib.G1, bases, scalars, n=n)
+        t0 = time.perf_counter()
+        for _ in range(2):
+            ecc.MultiExp(ctx, cid, _lib.G1, bases, scalars, n=n)
+        out["plain_msm_no_tables"] = {"ms_per_msm": round((time.perf_counter() - t0) * 500, 3),
+                                      "Mscalar_mul_per_s": round(n / ((time.perf_counter() - t0) / 2) / 1e6, 2)}
+    if table is not None:
+        table.free()
     if rank == 0 and args.groth16_proofs > 0:
         bases.free()
         scalars.free()

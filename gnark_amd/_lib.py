@@ -37,6 +37,7 @@ class G16Key(C.Structure):
         ("g2_b", C.c_void_p), ("len_b2", C.c_uint64),
         ("infinity_a", C.c_void_p), ("infinity_b", C.c_void_p),
         ("nb_wires", C.c_uint64), ("nb_infinity_a", C.c_uint64), ("nb_infinity_b", C.c_uint64),
+        ("precompute", C.c_int32),
     ]
 
 
@@ -58,6 +59,10 @@ _PROTOS = {
                                  C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ga_msm_plan": (C.c_int, [C.c_int, C.c_int, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ga_msm_combine_windows": (C.c_int, [C.c_int, C.c_int, _P, C.c_int, C.c_int, _P]),
+    "ga_msm_table_create": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_size_t, C.c_uint, C.POINTER(_P)]),
+    "ga_msm_table_destroy": (None, [_P]),
+    "ga_msm_table_run": (C.c_int, [_P, _P, C.c_uint, _P]),
+    "ga_msm_table_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
     "ga_jac_add": (C.c_int, [C.c_int, C.c_int, _P, _P, _P]),
     "ga_jac_to_affine": (C.c_int, [C.c_int, C.c_int, _P, _P]),
     "ga_jac_scalar_mul": (C.c_int, [C.c_int, C.c_int, _P, _P, _P]),

@@ -265,6 +265,86 @@ int ga_msm_combine_windows(int curve, int group, const void* windows, int num_wi
     return GA_OK;
 }
 
+// ---- precomputed tables ------------------------------------------------------------------------------------
+struct MsmTable {
+    Ctx* ctx;
+    int curve, group, c, nwin;
+    size_t n;
+    void* d_table;
+    uint64_t bytes;
+};
+
+int ga_msm_table_create(ga_ctx* h, int curve, int group, const void* bases, size_t n, unsigned flags, ga_msm_table** out) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    if (!c || !out || !bases || n == 0) {
+        set_error("ga_msm_table_create: bad argument");
+        return GA_ERR_INVALID;
+    }
+    Lock l(c);
+    MsmTable* t = new MsmTable{c, curve, group, 0, 0, n, nullptr, 0};
+    int rc = GA_OK;
+    GA_DISPATCH_CURVE(curve, GA_DISPATCH_GROUP(group, {
+                          typedef typename GroupField<C, G>::F F;
+                          rc = msm_plan_table<C>(n, &t->c, &t->nwin);
+                          t->bytes = (uint64_t)t->nwin * n * sizeof(Affine<F>);
+                          Staged sb{c};
+                          if (rc == GA_OK) rc = sb.stage(bases, n * sizeof(Affine<F>), flags & GA_BASES_ON_DEVICE);
+                          if (rc == GA_OK && hipMalloc(&t->d_table, t->bytes) != hipSuccess) {
+                              set_error("ga_msm_table_create: hipMalloc(%llu) failed", (unsigned long long)t->bytes);
+                              rc = GA_ERR_NOMEM;
+                          }
+                          if (rc == GA_OK) rc = msm_table_build<C, G>(c, sb.dev, n, t->c, t->d_table);
+                          if (rc == GA_OK && hipStreamSynchronize(c->stream) != hipSuccess) {
+                              set_error("ga_msm_table_create: table kernel failed");
+                              rc = GA_ERR_HIP;
+                          }
+                      }));
+    if (rc != GA_OK) {
+        hipFree(t->d_table);
+        delete t;
+        return rc;
+    }
+    *out = reinterpret_cast<ga_msm_table*>(t);
+    return GA_OK;
+}
+
+void ga_msm_table_destroy(ga_msm_table* th) {
+    MsmTable* t = reinterpret_cast<MsmTable*>(th);
+    if (!t) return;
+    Lock l(t->ctx);
+    hipStreamSynchronize(t->ctx->stream);
+    hipFree(t->d_table);
+    delete t;
+}
+
+int ga_msm_table_info(ga_msm_table* th, int* window_bits, int* num_windows, uint64_t* table_bytes) {
+    MsmTable* t = reinterpret_cast<MsmTable*>(th);
+    if (!t) return GA_ERR_INVALID;
+    if (window_bits) *window_bits = t->c;
+    if (num_windows) *num_windows = t->nwin;
+    if (table_bytes) *table_bytes = t->bytes;
+    return GA_OK;
+}
+
+int ga_msm_table_run(ga_msm_table* th, const void* scalars, unsigned flags, void* out_jac) {
+    MsmTable* t = reinterpret_cast<MsmTable*>(th);
+    if (!t || !scalars || !out_jac) {
+        set_error("ga_msm_table_run: null argument");
+        return GA_ERR_INVALID;
+    }
+    Ctx* c = t->ctx;
+    Lock l(c);
+    GA_DISPATCH_CURVE(t->curve, GA_DISPATCH_GROUP(t->group, {
+                          typedef typename GroupField<C, G>::F F;
+                          Staged ss{c};
+                          GA_CHECK(ss.stage(scalars, t->n * 32, flags & GA_SCALARS_ON_DEVICE));
+                          XYZZ<F> sum;
+                          GA_CHECK((msm_table_device<C, G>(c, t->d_table, ss.dev, t->n, (flags & GA_SCALARS_MONTGOMERY) != 0, t->c, &sum)));
+                          host_store_jac<F>(out_jac, sum);
+                      }));
+    return GA_OK;
+}
+
 // ---- host group helpers ---------------------------------------------------------------------------------
 int ga_jac_add(int curve, int group, const void* a, const void* b, void* out) {
     GA_DISPATCH_CURVE(curve, GA_DISPATCH_GROUP(group, {

@@ -126,6 +126,31 @@ int msm_windows_device(Ctx* ctx, const void* d_bases, const void* d_scalars, siz
                        int win_lo, int win_hi, void* h_window_sums);
 template <class C>
 int msm_plan(int group, size_t n, int* c, int* nwin);
+// window width for the precomputed-table mode (one shared bucket set; table = nwin x n affine points)
+template <class C>
+int msm_plan_table(size_t n, int* c, int* nwin);
+
+// Output of the group-independent half of an MSM (digits -> sort -> bucket offsets -> length-ordered task list).
+// The arrays live in the context's scratch; they stay valid until the next msm_prepare on the same context, so one
+// prepared scalar vector can feed several base vectors (G1.B and G2.B share wireValuesB, prove.go:194,283).
+struct MsmPrepared {
+    size_t n = 0;
+    int c = 0, nwin = 0, win_lo = 0, win_hi = 0;
+    int nsets = 0;          // bucket sets = window sums produced: (win_hi - win_lo), or 1 in table mode
+    bool table = false;
+    uint32_t half = 0, nb = 0, seg = 0;
+    uint64_t m = 0, max_tasks = 0;
+    uint32_t *vals = nullptr, *task_off = nullptr, *task_start = nullptr, *task_key = nullptr, *task_perm = nullptr;
+};
+
+template <class C, int G>
+int msm_table_build(Ctx* ctx, const void* d_bases, size_t n, int c, void* d_table);
+template <class C, int G>
+int msm_table_device(Ctx* ctx, const void* d_table, const void* d_scalars, size_t n, bool scalars_mont, int c, void* h_sum);
+template <class C>
+int msm_prepare_table_scalars(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, int c, MsmPrepared* P);
+template <class C, int G>
+int msm_table_device_reuse(Ctx* ctx, const void* d_table, const MsmPrepared& P, void* h_sum);
 
 struct Domain;   // ntt.cuh
 template <class C> int ntt_domain_new(Ctx* ctx, uint64_t n, Domain** out);

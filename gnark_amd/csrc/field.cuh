@@ -24,6 +24,12 @@
 #define GA_HD_BIG __host__ __device__ inline __attribute__((noinline))
 #endif
 #define GA_HD_CALL __host__ __device__ inline __attribute__((noinline))
+// keep a loaded value (and therefore its load) alive up to this point without using it
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GA_KEEP_LIVE(x) asm volatile("" ::"v"(x))
+#else
+#define GA_KEEP_LIVE(x) asm volatile("" ::"r"(x))
+#endif
 
 namespace ga {
 
@@ -336,13 +342,26 @@ struct alignas(16) u32x4 {
     uint32_t x, y, z, w;
 };
 
+// One 16-byte vector load that the compiler may neither split nor narrow.  Without the `volatile`, LLVM fuses a point
+// load with the 29-bit limb extraction that follows and emits dozens of 2-byte global_load_ushort at odd offsets
+// (52 per G2 point) instead of eight global_load_dwordx4.
+typedef uint32_t ga_v4u __attribute__((vector_size(16)));
+GA_HD u32x4 load16(const void* p) {
+    ga_v4u v = *reinterpret_cast<const volatile ga_v4u*>(p);
+    u32x4 r;
+    r.x = v[0];
+    r.y = v[1];
+    r.z = v[2];
+    r.w = v[3];
+    return r;
+}
+
 template <class P>
 GA_HD Fe<P> load_fe(const void* p) {
     Fe<P> r;
-    const u32x4* q = reinterpret_cast<const u32x4*>(p);
 #pragma unroll
     for (int i = 0; i < P::N / 4; i++) {
-        u32x4 v = q[i];
+        u32x4 v = load16(reinterpret_cast<const char*>(p) + 16 * i);
         r.l[4 * i + 0] = v.x;
         r.l[4 * i + 1] = v.y;
         r.l[4 * i + 2] = v.z;
@@ -370,10 +389,9 @@ template <class T>
 GA_HD T load_pod(const void* p) {
     static_assert(sizeof(T) % 16 == 0, "16-byte multiples only");
     T r;
-    const u32x4* s = reinterpret_cast<const u32x4*>(p);
 #pragma unroll
     for (size_t i = 0; i < sizeof(T) / 16; i++) {
-        u32x4 v = s[i];
+        u32x4 v = load16(reinterpret_cast<const char*>(p) + 16 * i);
         memcpy(reinterpret_cast<char*>(&r) + 16 * i, &v, 16);
     }
     return r;

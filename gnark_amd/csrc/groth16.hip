@@ -21,6 +21,9 @@ struct G16Pk {
     void *d_a = nullptr, *d_b = nullptr, *d_z = nullptr, *d_k = nullptr, *d_b2 = nullptr;
     uint64_t len_a = 0, len_b = 0, len_z = 0, len_k = 0, len_b2 = 0;
     uint32_t *d_idx_a = nullptr, *d_idx_b = nullptr;   // wire indices kept for the A / B MSMs (prove.go:147-168)
+    // precomputed window-multiple tables (msm.cuh): d_a.. then point to windows x len points and c_* is the window width
+    bool tables = false;
+    int c_a = 0, c_b = 0, c_z = 0, c_k = 0;
     std::vector<uint8_t> alpha1, beta1, delta1, beta2, delta2;   // affine images (host)
 };
 
@@ -97,6 +100,46 @@ static int pk_create(Ctx* ctx, const ga_g16_key* key, G16Pk** out) {
     if (rc == GA_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) {   // no host pointer survives this call
         set_error("proving key upload: stream synchronize failed");
         rc = GA_ERR_HIP;
+    }
+    // ---- optional precomputation: [2^(c*w)]P for every window (one shared bucket set per MSM afterwards) ----------
+    if (rc == GA_OK && key->precompute >= 0) {
+        int nw;
+        msm_plan_table<C>(pk->len_a, &pk->c_a, &nw);
+        uint64_t need = (uint64_t)nw * pk->len_a * s1;
+        msm_plan_table<C>(pk->len_b, &pk->c_b, &nw);
+        need += (uint64_t)nw * pk->len_b * (s1 + s2);
+        msm_plan_table<C>(pk->len_z, &pk->c_z, &nw);
+        need += (uint64_t)nw * pk->len_z * s1;
+        msm_plan_table<C>(pk->len_k, &pk->c_k, &nw);
+        need += (uint64_t)nw * pk->len_k * s1;
+        size_t free_b = 0, total_b = 0;
+        hipMemGetInfo(&free_b, &total_b);
+        // leave room for the per-proof scratch (~1.5 KB per constraint) and for other tenants: use at most half of what is free
+        const bool fits = need + (uint64_t)pk->n * 2048 < free_b / 2;
+        if (key->precompute > 0 || fits) {
+            auto make = [&](void** slot, uint64_t len, int c, size_t psz, auto build) -> int {
+                if (len == 0) return GA_OK;
+                const int nwin = C::FrP::BITS / c + 1;
+                void* t = nullptr;
+                if (hipMalloc(&t, (uint64_t)nwin * len * psz) != hipSuccess) {
+                    set_error("proving key: hipMalloc of a %llu-byte window table failed", (unsigned long long)((uint64_t)nwin * len * psz));
+                    return GA_ERR_NOMEM;
+                }
+                int r = build(*slot, len, c, t);
+                if (r == GA_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) r = GA_ERR_HIP;
+                hipFree(*slot);
+                *slot = t;
+                return r;
+            };
+            auto b1 = [&](const void* src, uint64_t len, int c, void* t) { return msm_table_build<C, GA_G1>(ctx, src, len, c, t); };
+            auto b2 = [&](const void* src, uint64_t len, int c, void* t) { return msm_table_build<C, GA_G2>(ctx, src, len, c, t); };
+            rc = make(&pk->d_a, pk->len_a, pk->c_a, s1, b1);
+            if (rc == GA_OK) rc = make(&pk->d_b, pk->len_b, pk->c_b, s1, b1);
+            if (rc == GA_OK) rc = make(&pk->d_z, pk->len_z, pk->c_z, s1, b1);
+            if (rc == GA_OK) rc = make(&pk->d_k, pk->len_k, pk->c_k, s1, b1);
+            if (rc == GA_OK) rc = make(&pk->d_b2, pk->len_b2, pk->c_b, s2, b2);
+            pk->tables = rc == GA_OK;
+        }
     }
     if (rc != GA_OK) {
         pk_free(pk);
@@ -177,10 +220,27 @@ static int prove(G16Pk* pk, const void* w, const void* a, const void* b, const v
     // ---- the four witness MSMs (prove.go:194,207,237,283) ----------------------------------------------
     XYZZ<F1> ar, bs1, krs, krs2;
     XYZZ<F2> bs2;
-    GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_a, d_wa, pk->len_a, true, &ar)));
-    GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_b, d_wb, pk->len_b, true, &bs1)));
-    GA_CHECK((host_msm<C, GA_G2>(ctx, pk->d_b2, d_wb, pk->len_b2, true, &bs2)));
-    GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_k, (const char*)d_w + nb_public * 32, pk->len_k, true, &krs)));
+    MsmPrepared prep;
+    auto table_msm_g1 = [&](const void* table, const void* scal, uint64_t len, int c, XYZZ<F1>* out) -> int {
+        if (len == 0) {
+            *out = xyzz_inf<F1>();
+            return GA_OK;
+        }
+        GA_CHECK(msm_prepare_table_scalars<C>(ctx, scal, len, true, c, &prep));
+        return msm_table_device_reuse<C, GA_G1>(ctx, table, prep, out);
+    };
+    if (pk->tables) {
+        GA_CHECK(table_msm_g1(pk->d_a, d_wa, pk->len_a, pk->c_a, &ar));
+        GA_CHECK(table_msm_g1(pk->d_b, d_wb, pk->len_b, pk->c_b, &bs1));
+        if (pk->len_b2) GA_CHECK((msm_table_device_reuse<C, GA_G2>(ctx, pk->d_b2, prep, &bs2)));   // same scalars wB: digits/sort shared
+        else bs2 = xyzz_inf<F2>();
+        GA_CHECK(table_msm_g1(pk->d_k, (const char*)d_w + nb_public * 32, pk->len_k, pk->c_k, &krs));
+    } else {
+        GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_a, d_wa, pk->len_a, true, &ar)));
+        GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_b, d_wb, pk->len_b, true, &bs1)));
+        GA_CHECK((host_msm<C, GA_G2>(ctx, pk->d_b2, d_wb, pk->len_b2, true, &bs2)));
+        GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_k, (const char*)d_w + nb_public * 32, pk->len_k, true, &krs)));
+    }
     // ---- H (prove.go:134,346-389), then the MSM over pk.G1.Z (prove.go:225-227) ----------------------------
     uploader.join();
     if (up_rc != GA_OK) {
@@ -190,7 +250,8 @@ static int prove(G16Pk* pk, const void* w, const void* a, const void* b, const v
     }
     GA_HIP_CHECK(hipStreamWaitEvent(st, ev_abc, 0));
     GA_CHECK(ntt_domain_compute_h<C>(pk->dom, d_ha, d_hb, d_hc));   // h in d_ha, bit-reversed like pk.G1.Z
-    GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_z, d_ha, pk->len_z, true, &krs2)));   // h[:n-1]
+    if (pk->tables) GA_CHECK(table_msm_g1(pk->d_z, d_ha, pk->len_z, pk->c_z, &krs2));   // h[:n-1]
+    else GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_z, d_ha, pk->len_z, true, &krs2)));
     hipEventDestroy(ev_abc);
     // ---- epilogue on the host (prove.go:171-185,199-200,212-214,241-269,287-292) ----------------------------
     StageTimer tm(ctx, "g16_epilogue_host");

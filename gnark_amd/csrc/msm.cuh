@@ -39,20 +39,21 @@ namespace ga {
 #define GA_ACC_LDS_BYTES 128  // accumulators of at least this many bytes live in LDS (all groups; measured best)
 #endif
 constexpr uint32_t MSM_SIGN = 0x80000000u;
-constexpr int MSM_HOT_TASKS = 8;      // buckets with more partials than this go to the wave-parallel merge
+constexpr int MSM_HOT_TASKS = 16;     // buckets with more partials than this go to the wave-parallel merge
 constexpr int MSM_GROUP = 32;         // buckets per running-sum group in the window reduction
 
 // ---- 1. digits ------------------------------------------------------------------------------------
 template <class FrP>
 __global__ void msm_digits_kernel(const uint32_t* __restrict__ scalars, uint64_t n, int mont, int c, int nwin, int win_lo,
-                                  int win_hi, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+                                  int win_hi, int table, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Fe<FrP> s = load_fe<FrP>(scalars + i * 8);
     if (mont) s = from_mont(s);
     const uint32_t half = 1u << (c - 1);
     const uint32_t mask = (1u << c) - 1;
-    const uint32_t skip = (uint32_t)(win_hi - win_lo) * half;
+    // table mode: every window shares ONE bucket set and the value indexes the precomputed table [window][point]
+    const uint32_t skip = table ? half : (uint32_t)(win_hi - win_lo) * half;
     uint32_t carry = 0;
     for (int w = 0; w < nwin; w++) {
         uint32_t d = (s.l[0] & mask) + carry;
@@ -70,8 +71,8 @@ __global__ void msm_digits_kernel(const uint32_t* __restrict__ scalars, uint64_t
         }
         if (w >= win_lo && w < win_hi) {
             uint64_t idx = (uint64_t)(w - win_lo) * n + i;
-            keys[idx] = d == 0 ? skip : (uint32_t)(w - win_lo) * half + (d - 1);
-            vals[idx] = (uint32_t)i | neg;
+            keys[idx] = d == 0 ? skip : (table ? 0u : (uint32_t)(w - win_lo) * half) + (d - 1);
+            vals[idx] = (table ? (uint32_t)((uint64_t)w * n + i) : (uint32_t)i) | neg;
         }
     }
 }
@@ -201,11 +202,18 @@ msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __res
         __shared__ uint32_t lds[sizeof(XYZZ<F>) / 4 * AccumulateTuning<F>::THREADS];
         LdsAcc<F> A{lds + threadIdx.x};
         A.put(2, FieldTraits<F>::zero());
+        uint32_t v = vals[start];
         for (uint32_t p = start; p < end; p++) {
-            uint32_t v = vals[p];
+            // touch the NEXT base now (one dword: pulls its cache line towards the CU while this addition runs);
+            // the gather over a multi-GiB table is otherwise a dependent HBM miss per addition
+            const uint32_t vn = p + 1 < end ? vals[p + 1] : v;
             Affine<F> q = load_pod<Affine<F>>(&bases[v & ~MSM_SIGN]);
+            // issued AFTER the current point's loads: vector loads retire in order, so the waitcnt for q leaves this one in flight
+            const uint32_t touch = *reinterpret_cast<const volatile uint32_t*>(&bases[vn & ~MSM_SIGN]);
             if (v & MSM_SIGN) q.y = neg(q.y);
             madd_lds(A, q);
+            GA_KEEP_LIVE(touch);
+            v = vn;
         }
         XYZZ<F> acc;
         acc.zz = A.get(2);
@@ -218,11 +226,15 @@ msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __res
         store_pod(&partial[tid], acc);
     } else {
         XYZZ<F> acc = xyzz_inf<F>();
+        uint32_t v = vals[start];
         for (uint32_t p = start; p < end; p++) {
-            uint32_t v = vals[p];
+            const uint32_t vn = p + 1 < end ? vals[p + 1] : v;
             Affine<F> q = load_pod<Affine<F>>(&bases[v & ~MSM_SIGN]);
+            const uint32_t touch = *reinterpret_cast<const volatile uint32_t*>(&bases[vn & ~MSM_SIGN]);
             if (v & MSM_SIGN) q.y = neg(q.y);
             acc = madd_t<true>(acc, q);
+            GA_KEEP_LIVE(touch);
+            v = vn;
         }
         store_pod(&partial[tid], acc);
     }
@@ -316,48 +328,64 @@ msm_segment_sum_kernel(const XYZZ<F>* __restrict__ in, uint32_t seg_len, XYZZ<F>
     if (threadIdx.x == 0) store_pod(&out[blockIdx.x], acc);
 }
 
+// ---- precomputed tables (pinned keys): table[w*n + i] = [2^(c*w)] P_i, affine ----------------------------------
+// With 288 GB of HBM a pinned key can afford windows x its size: all windows then share one bucket set (one
+// reduction instead of `windows`, no Horner) and c can grow to 23 => 12 instead of 14 window passes over the scalars.
+// (ICICLE exposes the same idea as MSMConfig.PrecomputeFactor, icicle.go:507-525.)
+template <class F>
+__global__ void __launch_bounds__(64)
+msm_table_kernel(const Affine<F>* __restrict__ bases, uint64_t n, int c, int nwin, Affine<F>* __restrict__ table) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine<F> a = load_pod<Affine<F>>(&bases[i]);
+    store_pod(&table[i], a);
+    XYZZ<F> p = to_xyzz(a);
+    for (int w = 1; w < nwin; w++) {
+        for (int k = 0; k < c; k++) p = dbl(p);
+        a = to_affine(p);
+        store_pod(&table[(uint64_t)w * n + i], a);
+        p = to_xyzz(a);   // restart from the affine point: keeps zz = zzz = 1 and the next to_affine cheap to verify
+    }
+}
+
 // ---- host driver ------------------------------------------------------------------------------------
 
-template <class C, int G>
-int msm_windows_device(Ctx* ctx, const void* d_bases, const void* d_scalars, size_t n, bool scalars_mont, int c,
-                       int win_lo, int win_hi, void* h_window_sums) {
-    typedef typename GroupField<C, G>::F F;
-    typedef typename C::FrP FrP;
+template <class FrP>
+int msm_prepare(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, int c, int win_lo, int win_hi, bool table,
+                MsmPrepared* P) {
     const int nwin = FrP::BITS / c + 1;
     if (win_hi < 0) win_hi = nwin;
-    if (win_lo < 0 || win_hi > nwin || win_lo >= win_hi || c < 2 || c > 24) {
-        set_error("msm: bad window range [%d,%d) of %d (c=%d)", win_lo, win_hi, nwin, c);
+    if (win_lo < 0 || win_hi > nwin || win_lo >= win_hi || c < 2 || c > 24 || (table && (win_lo != 0 || win_hi != nwin))) {
+        set_error("msm: bad window range [%d,%d) of %d (c=%d, table=%d)", win_lo, win_hi, nwin, c, (int)table);
         return GA_ERR_INVALID;
     }
     const int nwl = win_hi - win_lo;
-    XYZZ<F>* out = reinterpret_cast<XYZZ<F>*>(h_window_sums);
-    if (n == 0) {
-        for (int w = 0; w < nwl; w++) out[w] = xyzz_inf<F>();
-        return GA_OK;
-    }
-    if (n >= (1ull << 31)) {
-        set_error("msm: n=%zu exceeds 2^31-1 points per call", n);
+    if (n == 0 || n >= (1ull << 31)) {
+        set_error("msm: n=%zu outside [1, 2^31)", n);
         return GA_ERR_INVALID;
     }
     const uint32_t half = 1u << (c - 1);
     const uint64_t m = (uint64_t)nwl * n;
-    const uint64_t nb64 = (uint64_t)nwl * half;
-    if (m >= (1ull << 32) || nb64 >= (1ull << 31)) {
-        set_error("msm: %d windows x %zu points exceeds the 2^32 pair index space; shard the call", nwl, n);
+    const uint64_t nb64 = table ? half : (uint64_t)nwl * half;
+    if (m >= (1ull << 31) || nb64 >= (1ull << 31) || (table && (uint64_t)nwin * n >= (1ull << 31))) {
+        set_error("msm: %d windows x %zu points exceeds the 2^31 pair index space; shard the call", nwl, n);
         return GA_ERR_INVALID;
     }
     const uint32_t nb = (uint32_t)nb64;
-    // SEG: buckets up to 4x the mean size stay one task
+    // task length: buckets up to 4x the mean size stay one task, unless that would leave fewer than ~2^20 tasks for the
+    // 256 CUs x 16 waves x 64 lanes (few-bucket cases: small n, or table mode where all windows share 2^(c-1) buckets)
     uint64_t mean = m / nb + 1;
-    uint32_t seg = (uint32_t)(mean * 4 < 256 ? 256 : mean * 4);
+    uint64_t seg64 = mean * 4 < 256 ? 256 : mean * 4;
+    if (nb < (1u << 19)) {
+        uint64_t want = (m >> 19) + 1, lo = mean / 6 > 32 ? mean / 6 : 32;   // keep a bucket's partials <= ~MSM_HOT_TASKS
+        if (want < lo) want = lo;
+        if (want < seg64) seg64 = want;
+    }
+    const uint32_t seg = (uint32_t)seg64;
     const uint64_t max_tasks = nb + m / seg + 1;
-    const uint32_t m_groups = half < (uint32_t)MSM_GROUP ? half : (uint32_t)MSM_GROUP;
-    const uint32_t groups_per_win = half / m_groups;
-    const uint32_t total_groups = groups_per_win * nwl;
 
-    uint32_t *keys, *vals, *keys2, *vals2, *off, *ntask, *task_off, *hot_list, *hot_count, *task_start, *task_key, *task_key2, *task_id, *task_perm;
-    XYZZ<F>*partial, *bsum, *gsum, *gsum2, *wsum;
-    void* sort_tmp;
+    uint32_t *keys, *vals, *keys2, *vals2, *off, *ntask, *task_off, *task_start, *task_key, *task_key2, *task_id, *task_perm;
+    void* tmp;
     GA_CHECK(ctx->scratch_get("msm_keys", m * 4, (void**)&keys));
     GA_CHECK(ctx->scratch_get("msm_vals", m * 4, (void**)&vals));
     GA_CHECK(ctx->scratch_get("msm_keys2", m * 4, (void**)&keys2));
@@ -365,24 +393,17 @@ int msm_windows_device(Ctx* ctx, const void* d_bases, const void* d_scalars, siz
     GA_CHECK(ctx->scratch_get("msm_off", ((uint64_t)nb + 2) * 4, (void**)&off));
     GA_CHECK(ctx->scratch_get("msm_ntask", ((uint64_t)nb + 2) * 4, (void**)&ntask));
     GA_CHECK(ctx->scratch_get("msm_task_off", ((uint64_t)nb + 2) * 4, (void**)&task_off));
-    GA_CHECK(ctx->scratch_get("msm_hot", ((uint64_t)nb + 2) * 4, (void**)&hot_list));
-    GA_CHECK(ctx->scratch_get("msm_hot_count", 256, (void**)&hot_count));
     GA_CHECK(ctx->scratch_get("msm_task_start", max_tasks * 4, (void**)&task_start));
     GA_CHECK(ctx->scratch_get("msm_task_key", max_tasks * 4, (void**)&task_key));
     GA_CHECK(ctx->scratch_get("msm_task_key2", max_tasks * 4, (void**)&task_key2));
     GA_CHECK(ctx->scratch_get("msm_task_id", max_tasks * 4, (void**)&task_id));
     GA_CHECK(ctx->scratch_get("msm_task_perm", max_tasks * 4, (void**)&task_perm));
-    GA_CHECK(ctx->scratch_get("msm_partial", max_tasks * sizeof(XYZZ<F>), (void**)&partial));
-    GA_CHECK(ctx->scratch_get("msm_bsum", (uint64_t)nb * sizeof(XYZZ<F>), (void**)&bsum));
-    GA_CHECK(ctx->scratch_get("msm_gsum", (uint64_t)total_groups * sizeof(XYZZ<F>), (void**)&gsum));
-    GA_CHECK(ctx->scratch_get("msm_gsum2", ((uint64_t)total_groups / 1024 + 64) * sizeof(XYZZ<F>), (void**)&gsum2));
-    GA_CHECK(ctx->scratch_get("msm_wsum", (uint64_t)nwl * sizeof(XYZZ<F>), (void**)&wsum));
 
     hipStream_t st = ctx->stream;
     {
         StageTimer tm(ctx, "msm_digits");
-        hipLaunchKernelGGL((msm_digits_kernel<FrP>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
-                           (const uint32_t*)d_scalars, (uint64_t)n, scalars_mont ? 1 : 0, c, nwin, win_lo, win_hi, keys, vals);
+        hipLaunchKernelGGL((msm_digits_kernel<FrP>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint32_t*)d_scalars,
+                           (uint64_t)n, scalars_mont ? 1 : 0, c, nwin, win_lo, win_hi, table ? 1 : 0, keys, vals);
         GA_KERNEL_CHECK();
     }
     {
@@ -391,8 +412,8 @@ int msm_windows_device(Ctx* ctx, const void* d_bases, const void* d_scalars, siz
         while ((1ull << end_bit) <= nb64) end_bit++;   // keys take values 0..nb (nb = SKIP)
         size_t tmp_bytes = 0;
         GA_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, (unsigned)m, 0, end_bit, st));
-        GA_CHECK(ctx->scratch_get("msm_sort_tmp", tmp_bytes + 256, &sort_tmp));
-        GA_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(sort_tmp, tmp_bytes, keys, keys2, vals, vals2, (unsigned)m, 0, end_bit, st));
+        GA_CHECK(ctx->scratch_get("msm_sort_tmp", tmp_bytes + 256, &tmp));
+        GA_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys2, vals, vals2, (unsigned)m, 0, end_bit, st));
     }
     {
         StageTimer tm(ctx, "msm_tasks");
@@ -401,9 +422,8 @@ int msm_windows_device(Ctx* ctx, const void* d_bases, const void* d_scalars, siz
         GA_KERNEL_CHECK();
         size_t tmp_bytes = 0;
         GA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, ntask, task_off, (int)(nb + 1), st));
-        GA_CHECK(ctx->scratch_get("msm_scan_tmp", tmp_bytes + 256, &sort_tmp));
-        GA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(sort_tmp, tmp_bytes, ntask, task_off, (int)(nb + 1), st));
-        GA_HIP_CHECK(hipMemsetAsync(hot_count, 0, 4, st));
+        GA_CHECK(ctx->scratch_get("msm_scan_tmp", tmp_bytes + 256, &tmp));
+        GA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, ntask, task_off, (int)(nb + 1), st));
         // explicit task list, ordered by decreasing length (padding slots keep key = 0xFFFFFFFF >= seg)
         GA_HIP_CHECK(hipMemsetAsync(task_key, 0xFF, max_tasks * 4, st));
         hipLaunchKernelGGL(msm_task_list_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, (const uint32_t*)off, (const uint32_t*)task_off,
@@ -415,22 +435,62 @@ int msm_windows_device(Ctx* ctx, const void* d_bases, const void* d_scalars, siz
         // padding keys are all-ones: sort on kbits+1 bits so that they stay behind every real key (real keys < seg)
         size_t tb = 0;
         GA_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, task_key, task_key2, task_id, task_perm, (unsigned)max_tasks, 0, kbits + 1, st));
-        GA_CHECK(ctx->scratch_get("msm_tasksort_tmp", tb + 256, &sort_tmp));
-        GA_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(sort_tmp, tb, task_key, task_key2, task_id, task_perm, (unsigned)max_tasks, 0, kbits + 1, st));
+        GA_CHECK(ctx->scratch_get("msm_tasksort_tmp", tb + 256, &tmp));
+        GA_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp, tb, task_key, task_key2, task_id, task_perm, (unsigned)max_tasks, 0, kbits + 1, st));
     }
+    P->n = n;
+    P->c = c;
+    P->nwin = nwin;
+    P->win_lo = win_lo;
+    P->win_hi = win_hi;
+    P->nsets = table ? 1 : nwl;
+    P->table = table;
+    P->half = half;
+    P->nb = nb;
+    P->seg = seg;
+    P->m = m;
+    P->max_tasks = max_tasks;
+    P->vals = vals2;
+    P->task_off = task_off;
+    P->task_start = task_start;
+    P->task_key = task_key2;
+    P->task_perm = task_perm;
+    return GA_OK;
+}
+
+// Group-dependent half: bucket accumulation over `d_bases` (the affine bases, or the precomputed table in table mode),
+// merge, per-set reduction.  Writes P.nsets XYZZ sums to host memory.
+template <class F>
+int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, XYZZ<F>* out) {
+    const uint32_t nb = P.nb, half = P.half, seg = P.seg;
+    const int nsets = P.nsets;
+    const uint32_t m_groups = half < (uint32_t)MSM_GROUP ? half : (uint32_t)MSM_GROUP;
+    const uint32_t groups_per_win = half / m_groups;
+    const uint32_t total_groups = groups_per_win * nsets;
+    uint32_t *hot_list, *hot_count;
+    XYZZ<F>*partial, *bsum, *gsum, *gsum2, *wsum;
+    GA_CHECK(ctx->scratch_get("msm_hot", ((uint64_t)nb + 2) * 4, (void**)&hot_list));
+    GA_CHECK(ctx->scratch_get("msm_hot_count", 256, (void**)&hot_count));
+    GA_CHECK(ctx->scratch_get("msm_partial", P.max_tasks * sizeof(XYZZ<F>), (void**)&partial));
+    GA_CHECK(ctx->scratch_get("msm_bsum", (uint64_t)nb * sizeof(XYZZ<F>), (void**)&bsum));
+    GA_CHECK(ctx->scratch_get("msm_gsum", (uint64_t)total_groups * sizeof(XYZZ<F>), (void**)&gsum));
+    GA_CHECK(ctx->scratch_get("msm_gsum2", ((uint64_t)total_groups / 1024 + 64) * sizeof(XYZZ<F>), (void**)&gsum2));
+    GA_CHECK(ctx->scratch_get("msm_wsum", (uint64_t)nsets * sizeof(XYZZ<F>), (void**)&wsum));
+    hipStream_t st = ctx->stream;
+    GA_HIP_CHECK(hipMemsetAsync(hot_count, 0, 4, st));
     {
         StageTimer tm(ctx, "msm_accumulate");
         constexpr unsigned AT = AccumulateTuning<F>::THREADS;
-        hipLaunchKernelGGL((msm_accumulate_kernel<F>), dim3((unsigned)((max_tasks + AT - 1) / AT)), dim3(AT), 0, st,
-                           (const Affine<F>*)d_bases, (const uint32_t*)vals2, (const uint32_t*)task_start, (const uint32_t*)task_key2,
-                           (const uint32_t*)task_perm, (uint32_t)max_tasks, seg, partial);
+        hipLaunchKernelGGL((msm_accumulate_kernel<F>), dim3((unsigned)((P.max_tasks + AT - 1) / AT)), dim3(AT), 0, st,
+                           (const Affine<F>*)d_bases, (const uint32_t*)P.vals, (const uint32_t*)P.task_start, (const uint32_t*)P.task_key,
+                           (const uint32_t*)P.task_perm, (uint32_t)P.max_tasks, seg, partial);
         GA_KERNEL_CHECK();
     }
     {
         StageTimer tm(ctx, "msm_merge");
         hipLaunchKernelGGL((msm_merge_kernel<F>), dim3((nb + 255) / 256), dim3(256), 0, st, (const XYZZ<F>*)partial,
-                           (const uint32_t*)task_off, nb, bsum, hot_list, hot_count);
-        hipLaunchKernelGGL((msm_hot_kernel<F>), dim3(512), dim3(64), 0, st, (const XYZZ<F>*)partial, (const uint32_t*)task_off,
+                           (const uint32_t*)P.task_off, nb, bsum, hot_list, hot_count);
+        hipLaunchKernelGGL((msm_hot_kernel<F>), dim3(512), dim3(64), 0, st, (const XYZZ<F>*)partial, (const uint32_t*)P.task_off,
                            (const uint32_t*)hot_list, (const uint32_t*)hot_count, bsum);
         GA_KERNEL_CHECK();
     }
@@ -438,20 +498,75 @@ int msm_windows_device(Ctx* ctx, const void* d_bases, const void* d_scalars, siz
         StageTimer tm(ctx, "msm_reduce");
         hipLaunchKernelGGL((msm_reduce_groups_kernel<F>), dim3((total_groups + 63) / 64), dim3(64), 0, st, (const XYZZ<F>*)bsum,
                            half, m_groups, groups_per_win, total_groups, gsum);
-        // window sum = sum of its group results; two levels when a window has many groups so that the first level
-        // spreads over >= 16 waves per window instead of one
-        const uint32_t seg = 1024;
-        if (groups_per_win > 2 * seg) {
-            const uint32_t nseg = groups_per_win / seg;   // powers of two: exact
-            hipLaunchKernelGGL((msm_segment_sum_kernel<F>), dim3(nseg * nwl), dim3(64), 0, st, (const XYZZ<F>*)gsum, seg, gsum2);
-            hipLaunchKernelGGL((msm_segment_sum_kernel<F>), dim3(nwl), dim3(64), 0, st, (const XYZZ<F>*)gsum2, nseg, wsum);
+        // set sum = sum of its group results; two levels when a set has many groups so that the first level spreads
+        // over >= 16 waves per set instead of one
+        const uint32_t sg = 1024;
+        if (groups_per_win > 2 * sg) {
+            const uint32_t nseg = groups_per_win / sg;   // powers of two: exact
+            hipLaunchKernelGGL((msm_segment_sum_kernel<F>), dim3(nseg * nsets), dim3(64), 0, st, (const XYZZ<F>*)gsum, sg, gsum2);
+            hipLaunchKernelGGL((msm_segment_sum_kernel<F>), dim3(nsets), dim3(64), 0, st, (const XYZZ<F>*)gsum2, nseg, wsum);
         } else {
-            hipLaunchKernelGGL((msm_segment_sum_kernel<F>), dim3(nwl), dim3(64), 0, st, (const XYZZ<F>*)gsum, groups_per_win, wsum);
+            hipLaunchKernelGGL((msm_segment_sum_kernel<F>), dim3(nsets), dim3(64), 0, st, (const XYZZ<F>*)gsum, groups_per_win, wsum);
         }
         GA_KERNEL_CHECK();
     }
-    GA_HIP_CHECK(hipMemcpyAsync(out, wsum, (size_t)nwl * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
+    GA_HIP_CHECK(hipMemcpyAsync(out, wsum, (size_t)nsets * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
     GA_HIP_CHECK(hipStreamSynchronize(st));
+    return GA_OK;
+}
+
+template <class C, int G>
+int msm_windows_device(Ctx* ctx, const void* d_bases, const void* d_scalars, size_t n, bool scalars_mont, int c,
+                       int win_lo, int win_hi, void* h_window_sums) {
+    typedef typename GroupField<C, G>::F F;
+    XYZZ<F>* out = reinterpret_cast<XYZZ<F>*>(h_window_sums);
+    const int nwin = C::FrP::BITS / c + 1;
+    if (win_hi < 0) win_hi = nwin;
+    if (n == 0) {
+        for (int w = 0; w < win_hi - win_lo; w++) out[w] = xyzz_inf<F>();
+        return GA_OK;
+    }
+    MsmPrepared P;
+    GA_CHECK(msm_prepare<typename C::FrP>(ctx, d_scalars, n, scalars_mont, c, win_lo, win_hi, false, &P));
+    return msm_accumulate_reduce<F>(ctx, d_bases, P, out);
+}
+
+// MSM over a precomputed table: one XYZZ result (no Horner)
+template <class C, int G>
+int msm_table_device(Ctx* ctx, const void* d_table, const void* d_scalars, size_t n, bool scalars_mont, int c, void* h_sum) {
+    typedef typename GroupField<C, G>::F F;
+    XYZZ<F>* out = reinterpret_cast<XYZZ<F>*>(h_sum);
+    if (n == 0) {
+        *out = xyzz_inf<F>();
+        return GA_OK;
+    }
+    MsmPrepared P;
+    GA_CHECK(msm_prepare<typename C::FrP>(ctx, d_scalars, n, scalars_mont, c, 0, -1, true, &P));
+    return msm_accumulate_reduce<F>(ctx, d_table, P, out);
+}
+
+// prepared scalars (table mode) reused for another base table of the same length (G1.B / G2.B)
+template <class C, int G>
+int msm_table_device_reuse(Ctx* ctx, const void* d_table, const MsmPrepared& P, void* h_sum) {
+    typedef typename GroupField<C, G>::F F;
+    return msm_accumulate_reduce<F>(ctx, d_table, P, reinterpret_cast<XYZZ<F>*>(h_sum));
+}
+
+// group-independent preparation callable from translation units that do not include this header (groth16.hip)
+template <class C>
+int msm_prepare_table_scalars(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, int c, MsmPrepared* P) {
+    return msm_prepare<typename C::FrP>(ctx, d_scalars, n, scalars_mont, c, 0, -1, true, P);
+}
+
+template <class C, int G>
+int msm_table_build(Ctx* ctx, const void* d_bases, size_t n, int c, void* d_table) {
+    typedef typename GroupField<C, G>::F F;
+    if (n == 0) return GA_OK;
+    const int nwin = C::FrP::BITS / c + 1;
+    StageTimer tm(ctx, "msm_table_build");
+    hipLaunchKernelGGL((msm_table_kernel<F>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, (const Affine<F>*)d_bases,
+                       (uint64_t)n, c, nwin, (Affine<F>*)d_table);
+    GA_KERNEL_CHECK();
     return GA_OK;
 }
 

@@ -147,4 +147,23 @@ int msm_plan(int group, size_t n, int* c_out, int* nwin_out) {
     return GA_OK;
 }
 
+template <class C>
+int msm_plan_table(size_t n, int* c_out, int* nwin_out) {
+    const int bits = C::FrP::BITS;
+    double best = 1e300;
+    int bc = 4;
+    for (int c = 4; c <= 23; c++) {
+        int nwin = bits / c + 1;
+        if ((double)nwin * (double)n >= 2147483648.0) continue;   // table index must fit 31 bits
+        double cost = (double)nwin * (double)n + 6.0 * (double)(1u << (c - 1));
+        if (cost < best) {
+            best = cost;
+            bc = c;
+        }
+    }
+    *c_out = bc;
+    *nwin_out = bits / bc + 1;
+    return GA_OK;
+}
+
 }  // namespace ga

@@ -50,6 +50,43 @@ def MultiExp(ctx: Context, curve, group: int, points, scalars, n: int | None = N
     return out
 
 
+class PrecomputedBases:
+    """Bases pinned on the device together with [2^(c*w)]P for every Pippenger window w (ga_msm_table_*): the GPU analogue of
+    keeping `pk.G1.A` etc. resident ("PinToGPU", provingkey.go:37-42) with ICICLE's PrecomputeFactor."""
+
+    def __init__(self, ctx: Context, curve, group: int, points, n: int | None = None):
+        cid = curve_id(curve)
+        if not isinstance(points, (DeviceBuffer, int)):
+            points = as_u64(points, affine_words(cid, group))
+            n = points.shape[0]
+        if n is None:
+            raise ValueError("n is required for device-resident points")
+        bp, f1 = _arg(points, _lib.BASES_ON_DEVICE)
+        h = C.c_void_p()
+        ctx.lib.check(ctx.lib.ga_msm_table_create(ctx.handle, cid, group, bp, n, f1, C.byref(h)))
+        self.ctx, self.curve, self.group, self.n, self.handle = ctx, cid, group, n, h
+
+    def info(self):
+        c, nw, nb = C.c_int(), C.c_int(), C.c_uint64()
+        self.ctx.lib.check(self.ctx.lib.ga_msm_table_info(self.handle, C.byref(c), C.byref(nw), C.byref(nb)))
+        return {"window_bits": c.value, "windows": nw.value, "table_bytes": nb.value}
+
+    def MultiExp(self, scalars, montgomery: bool = True) -> np.ndarray:
+        if not isinstance(scalars, (DeviceBuffer, int)):
+            scalars = as_u64(scalars, 4)
+            if scalars.shape[0] != self.n:
+                raise ValueError("len(points) != len(scalars)")
+        sp, f2 = _arg(scalars, _lib.SCALARS_ON_DEVICE)
+        out = np.zeros(jac_words(self.curve, self.group), dtype=np.uint64)
+        self.ctx.lib.check(self.ctx.lib.ga_msm_table_run(self.handle, sp, f2 | (_lib.SCALARS_MONTGOMERY if montgomery else 0), _ptr(out)))
+        return out
+
+    def free(self):
+        if self.handle:
+            self.ctx.lib.ga_msm_table_destroy(self.handle)
+            self.handle = None
+
+
 def MultiExpWindows(ctx: Context, curve, group: int, points, scalars, n: int, win_lo: int, win_hi: int, montgomery=True):
     """Window-sharded MSM (multi-GPU partitioning A): Jacobian window sums for windows [win_lo, win_hi)."""
     cid = curve_id(curve)

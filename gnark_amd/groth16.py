@@ -48,7 +48,7 @@ class ProvingKey:
     """setup.go:25-48 fields, uploaded once ("PinToGPU"); free with FreeGPUResources() (icicle.go:1493)."""
 
     def __init__(self, ctx: Context, curve, *, domain_cardinality, alpha1, beta1, delta1, A, B, Z, K, beta2, delta2, B2,
-                 infinityA, infinityB):
+                 infinityA, infinityB, precompute: int = 0):
         cid = curve_id(curve)
         fp = FP_LIMBS[cid]
         self.ctx, self.curve = ctx, cid
@@ -72,6 +72,7 @@ class ProvingKey:
         key.infinity_a, key.infinity_b = ia.ctypes.data, ib.ctypes.data
         key.nb_wires = ia.shape[0]
         key.nb_infinity_a, key.nb_infinity_b = int(ia.sum()), int(ib.sum())
+        key.precompute = int(precompute)   # 0 auto, 1 always, -1 never (window-multiple tables, ga_g16_key.precompute)
         h = C.c_void_p()
         ctx.lib.check(ctx.lib.ga_g16_pk_create(ctx.handle, C.byref(key), C.byref(h)))
         self.handle = h

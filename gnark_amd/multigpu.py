@@ -41,8 +41,12 @@ def combine_partials(curve, group: int, partials, lib=None) -> np.ndarray:
 
 
 def msm_base_sharded(ctx, curve, group: int, points_shard, scalars_shard, n_shard: int, dist, device=None) -> np.ndarray:
-    """partition B: every rank passes ITS slice; every rank returns the full MSM (Jacobian)."""
-    part = ecc.MultiExp(ctx, curve, group, points_shard, scalars_shard, n=n_shard)
+    """partition B: every rank passes ITS slice; every rank returns the full MSM (Jacobian).
+    points_shard may be an ecc.PrecomputedBases built from the rank's slice (pinned key with window tables)."""
+    if isinstance(points_shard, ecc.PrecomputedBases):
+        part = points_shard.MultiExp(scalars_shard)
+    else:
+        part = ecc.MultiExp(ctx, curve, group, points_shard, scalars_shard, n=n_shard)
     if dist is None or dist.get_world_size() == 1:
         return part
     return combine_partials(curve, group, _all_gather_u64(part, dist, device), lib=ctx.lib)

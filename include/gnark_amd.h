@@ -98,6 +98,18 @@ int ga_msm_plan(int curve, int group, size_t n, int* window_bits, int* num_windo
 int ga_msm_combine_windows(int curve, int group, const void* windows, int num_windows, int window_bits,
                            void* out_jac);
 
+/* ---- MSM over pinned bases with precomputed window multiples ---------------------------------------------
+ * (ICICLE's MSMConfig.PrecomputeFactor / precompute-bases, icicle.go:507-525.)  ga_msm_table_create uploads (or takes
+ * from the device) n affine bases and stores [2^(c*w)]P_i for every window w: windows x n points, sized for the
+ * 288 GB of an MI355X (2^24 BN254 G1 points: 12 GiB).  All windows then share one bucket set, so ga_msm_table_run does
+ * windows x n bucket additions, ONE bucket reduction and no Horner step.  Results are identical to ga_msm. */
+typedef struct ga_msm_table ga_msm_table;
+int ga_msm_table_create(ga_ctx* ctx, int curve, int group, const void* bases, size_t n, unsigned flags, ga_msm_table** out);
+void ga_msm_table_destroy(ga_msm_table* t);
+/* scalars: exactly n fr elements (the table's n); flags: GA_SCALARS_ON_DEVICE, GA_SCALARS_MONTGOMERY */
+int ga_msm_table_run(ga_msm_table* t, const void* scalars, unsigned flags, void* out_jac);
+int ga_msm_table_info(ga_msm_table* t, int* window_bits, int* num_windows, uint64_t* table_bytes);
+
 /* ---- small host-side group helpers used by the Go epilogue / multi-GPU combine -------------------------
  * (curve.G1Jac.AddAssign / ScalarMultiplication / FromJacobian, prove.go:199-292).  Host arithmetic. */
 int ga_jac_add(int curve, int group, const void* a_jac, const void* b_jac, void* out_jac);
@@ -143,6 +155,8 @@ typedef struct ga_g16_key {
     uint64_t nb_wires;
     uint64_t nb_infinity_a;
     uint64_t nb_infinity_b;
+    int32_t precompute;              /* 0: precompute window tables for A,B,K,Z,G2.B when they fit comfortably in free HBM
+                                        (default), 1: always, -1: never */
 } ga_g16_key;
 
 int ga_g16_pk_create(ga_ctx* ctx, const ga_g16_key* key, ga_g16_pk** out);

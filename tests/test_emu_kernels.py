@@ -119,6 +119,29 @@ def test_emu_msm_hot_bucket_and_windows(emu_ctx):
     assert jac_to_affine_py(c, group, comb) == want
 
 
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("group", [0, 1], ids=["G1", "G2"])
+def test_emu_msm_precomputed_table(emu_ctx, c, group):
+    """ga_msm_table_*: windows share one bucket set over [2^(c*w)]P tables; same point as the plain MSM."""
+    rng = pyref.Xoshiro(31 + group)
+    n = 33
+    pts, _ = _random_points(c, group, n, rng)
+    scalars = [rng.field(c.r) for _ in range(n)]
+    scalars[0], scalars[1], scalars[2] = 0, 1, c.r - 1
+    pts[3] = None
+    pts[5] = pts[4]
+    t = ecc.PrecomputedBases(emu_ctx, c.name, group, pts_to_arr(c, group, pts))
+    try:
+        info = t.info()
+        assert info["windows"] == c.r.bit_length() // info["window_bits"] + 1
+        got = t.MultiExp(fr_to_arr(c, scalars))
+        assert jac_to_affine_py(c, group, got) == group_of(c, group).msm(pts, scalars)
+        got = t.MultiExp(fr_to_arr(c, [0] * n))
+        assert jac_to_affine_py(c, group, got) is None
+    finally:
+        t.free()
+
+
 def test_emu_msm_empty_and_single(emu_ctx):
     c = BN254
     z = ecc.MultiExp(emu_ctx, c.name, 0, np.zeros((0, 8), np.uint64), np.zeros((0, 4), np.uint64))
@@ -129,8 +152,9 @@ def test_emu_msm_empty_and_single(emu_ctx):
         ecc.MultiExp(emu_ctx, c.name, 0, pts_to_arr(c, 0, [c.g1]), fr_to_arr(c, [1, 2]))
 
 
+@pytest.mark.parametrize("precompute", [1, -1], ids=["tables", "no-tables"])
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
-def test_emu_groth16_cubic(emu_ctx, c):
+def test_emu_groth16_cubic(emu_ctx, c, precompute):
     """config 1: examples/cubic through the whole prover core, proof bytes identical to the oracle's."""
     rng = pyref.Xoshiro(2024)
     cs, w = pyref.cubic_r1cs(), pyref.cubic_witness(3)
@@ -144,7 +168,7 @@ def test_emu_groth16_cubic(emu_ctx, c):
         alpha1=pts_to_arr(c, 0, [pk.alpha1]), beta1=pts_to_arr(c, 0, [pk.beta1]), delta1=pts_to_arr(c, 0, [pk.delta1]),
         A=pts_to_arr(c, 0, pk.A), B=pts_to_arr(c, 0, pk.B), Z=pts_to_arr(c, 0, pk.Z), K=pts_to_arr(c, 0, pk.K),
         beta2=pts_to_arr(c, 1, [pk.beta2]), delta2=pts_to_arr(c, 1, [pk.delta2]), B2=pts_to_arr(c, 1, pk.B2),
-        infinityA=pk.infinityA, infinityB=pk.infinityB)
+        infinityA=pk.infinityA, infinityB=pk.infinityB, precompute=precompute)
     try:
         sol = groth16.Solution(W=fr_to_arr(c, w), A=fr_to_arr(c, A), B=fr_to_arr(c, B), C=fr_to_arr(c, Cc))
         proof = groth16.Prove(dpk, sol, cs.nb_public, fr_to_arr(c, [r]), fr_to_arr(c, [s]))

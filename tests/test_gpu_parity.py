@@ -46,9 +46,33 @@ def test_msm_empty_and_single(gpu_ctx):
     cases.test_emu_msm_empty_and_single(gpu_ctx)
 
 
+@pytest.mark.parametrize("precompute", [1, -1], ids=["tables", "no-tables"])
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
-def test_groth16_cubic_bytes(gpu_ctx, c):
-    cases.test_emu_groth16_cubic(gpu_ctx, c)
+def test_groth16_cubic_bytes(gpu_ctx, c, precompute):
+    cases.test_emu_groth16_cubic(gpu_ctx, c, precompute)
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("group", [0, 1], ids=["G1", "G2"])
+def test_msm_precomputed_table_small(gpu_ctx, c, group):
+    cases.test_emu_msm_precomputed_table(gpu_ctx, c, group)
+
+
+@pytest.mark.parametrize("c,group,logn", [(BN254, 0, 20), (BN254, 1, 16), (BLS12_381, 0, 16), (BLS12_381, 1, 14)],
+                         ids=["bn254-G1-2^20", "bn254-G2-2^16", "bls-G1-2^16", "bls-G2-2^14"])
+def test_msm_precomputed_table_vs_plain_and_dlog(gpu_ctx, c, group, logn):
+    n = 1 << logn
+    bases, dlogs, scal = _device_inputs(gpu_ctx, c, group, n, 0x7AB1E + group)
+    t = ecc.PrecomputedBases(gpu_ctx, c.name, group, bases, n=n)
+    try:
+        got = oracle.jac_to_affine(c.cid, group, t.MultiExp(scal))
+        plain = oracle.jac_to_affine(c.cid, group, ecc.MultiExp(gpu_ctx, c.name, group, bases, scal, n=n))
+        assert np.array_equal(got, plain)
+        assert np.array_equal(got, _expect_from_dlogs(c, group, scal.to_host((n, 4)), dlogs.to_host((n, 4))))
+    finally:
+        t.free()
+        for b in (bases, dlogs, scal):
+            b.free()
 
 
 # ---- larger sizes -------------------------------------------------------------------------------------------
@@ -218,12 +242,13 @@ def test_groth16_synthetic_2_10_vs_oracle(gpu_ctx, c):
     Cc = oracle.fr_mul(c.cid, A, B)
     rs = scal(2, 13)
     want = oracle.groth16_prove(c.cid, key, W, A, B, Cc, nb_public, rs[0], rs[1], nthreads=8)
-    pk = groth16.ProvingKey(ctx, c.name, domain_cardinality=n, **{k: v for k, v in key.items() if k != "n"})
-    try:
-        proof = groth16.Prove(pk, groth16.Solution(W, A, B, Cc), nb_public, rs[0], rs[1])
-    finally:
-        pk.FreeGPUResources()
-    assert np.array_equal(proof.Ar, want[0]) and np.array_equal(proof.Bs, want[1]) and np.array_equal(proof.Krs, want[2])
+    for precompute in (1, -1):
+        pk = groth16.ProvingKey(ctx, c.name, domain_cardinality=n, precompute=precompute, **{k: v for k, v in key.items() if k != "n"})
+        try:
+            proof = groth16.Prove(pk, groth16.Solution(W, A, B, Cc), nb_public, rs[0], rs[1])
+        finally:
+            pk.FreeGPUResources()
+        assert np.array_equal(proof.Ar, want[0]) and np.array_equal(proof.Bs, want[1]) and np.array_equal(proof.Krs, want[2]), precompute
     assert len(proof.WriteTo()) == (164 if c.cid == 0 else 244)
 
 
