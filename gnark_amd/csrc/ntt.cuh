@@ -63,10 +63,10 @@ __device__ __forceinline__ Fe<FrP> ntt_scale_factor(const NttScale& sc, uint64_t
         return f;
     }
     uint64_t idx = sc.bitrev ? bitrev64(i, logn) : i;
-    Fe<FrP> a = load_fe<FrP>(sc.lo + (idx & ((1ull << sc.lo_bits) - 1)) * 8);
+    Fe<FrP> a = load_fe_plain<FrP>(sc.lo + (idx & ((1ull << sc.lo_bits) - 1)) * 8);
     uint64_t h = idx >> sc.lo_bits;
     if (h == 0 && logn <= sc.lo_bits) return a;
-    Fe<FrP> b = load_fe<FrP>(sc.hi + h * 8);
+    Fe<FrP> b = load_fe_plain<FrP>(sc.hi + h * 8);
     return mul(a, b);
 }
 
@@ -131,12 +131,12 @@ ntt_pass_kernel(uint32_t* __restrict__ data, const uint32_t* __restrict__ tw, in
             uint64_t e = (i0 & ((1ull << s) - 1)) << (logn - 1 - s);
             Fe<FrP> x = T.get(l0), y = T.get(l1);
             if (DIT_) {
-                if (e != 0) y = mul(y, load_fe<FrP>(tw + e * 8));
+                if (e != 0) y = mul(y, load_fe_plain<FrP>(tw + e * 8));
                 T.put(l0, add(x, y));
                 T.put(l1, sub(x, y));
             } else {
                 Fe<FrP> d = sub(x, y);
-                if (e != 0) d = mul(d, load_fe<FrP>(tw + e * 8));
+                if (e != 0) d = mul(d, load_fe_plain<FrP>(tw + e * 8));
                 T.put(l0, add(x, y));
                 T.put(l1, d);
             }

@@ -20,6 +20,7 @@ def main():
     lib = ctx.lib
     srs = ctx.malloc(n * 64)
     lib.check(lib.ga_gen_bases(ctx.handle, 0, 0, 0x5EED0007, n, srs.ptr, None))
+    srs_table = ecc.PrecomputedBases(ctx, "bn254", ecc.G1, srs, n=n)   # the KZG SRS is a pinned key
     polys = [ctx.malloc(n * 32) for _ in range(12)]
     for i, p in enumerate(polys):
         lib.check(lib.ga_gen_scalars(ctx.handle, 0, 100 + i, n, p.ptr))
@@ -30,7 +31,7 @@ def main():
 
     def proof_kernels():
         for k in range(10):                       # commitToLRO x3, Z, quotient x3, opening x2, linearised
-            ecc.MultiExp(ctx, "bn254", ecc.G1, srs, polys[k % 12], n=n)
+            srs_table.MultiExp(polys[k % 12])
         for _ in range(4):                        # computeNumerator: per coset, every polynomial iFFT -> coset FFT
             for p in polys:
                 d.FFTInverse(p, fft.DIF)
