@@ -26,19 +26,19 @@ template <class P> GA_HD bool eq(const Fe2<P>& a, const Fe2<P>& b) { return eq(a
 // Karatsuba product / complex squaring with every base-field product inlined (hot loops) ...
 template <class P>
 GA_HD_BIG Fe2<P> mul_body(const Fe2<P>& a, const Fe2<P>& b) {
-    Fe<P> v0 = mul_body(a.c0, b.c0);
-    Fe<P> v1 = mul_body(a.c1, b.c1);
-    Fe<P> s = mul_body(add(a.c0, a.c1), add(b.c0, b.c1));
+    Fe<P> v0 = mul_hot(a.c0, b.c0);
+    Fe<P> v1 = mul_hot(a.c1, b.c1);
+    Fe<P> s = mul_hot(add(a.c0, a.c1), add(b.c0, b.c1));
     return {sub(v0, v1), sub(sub(s, v0), v1)};
 }
 template <class P>
 GA_HD_BIG Fe2<P> sqr_body(const Fe2<P>& a) {
-    Fe<P> t = mul_body(a.c0, a.c1);
-    Fe<P> r0 = mul_body(add(a.c0, a.c1), sub(a.c0, a.c1));
+    Fe<P> t = mul_hot(a.c0, a.c1);
+    Fe<P> r0 = mul_hot(add(a.c0, a.c1), sub(a.c0, a.c1));
     return {r0, dbl(t)};
 }
 template <class P>
-GA_HD_BIG Fe<P> sqr_body(const Fe<P>& a) { return mul_body(a, a); }
+GA_HD_BIG Fe<P> sqr_body(const Fe<P>& a) { return mul_hot(a, a); }
 
 // ... and as shared out-of-line functions (cold kernels, host code)
 template <class P>
@@ -47,9 +47,13 @@ template <class P>
 GA_HD_CALL Fe2<P> sqr(const Fe2<P>& a) { return sqr_body(a); }
 
 // INL = true: fully inlined product (accumulator stays in registers, no call ABI traffic); false: shared functions
+template <class P>
+GA_HD Fe<P> mul_inl(const Fe<P>& a, const Fe<P>& b) { return mul_hot(a, b); }
+template <class P>
+GA_HD Fe2<P> mul_inl(const Fe2<P>& a, const Fe2<P>& b) { return mul_body(a, b); }
 template <bool INL, class F>
 GA_HD F fmul(const F& a, const F& b) {
-    if constexpr (INL) return mul_body(a, b);
+    if constexpr (INL) return mul_inl(a, b);
     else return mul(a, b);
 }
 template <bool INL, class F>

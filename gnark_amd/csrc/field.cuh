@@ -268,6 +268,20 @@ GA_HD_BIG Fe<P> mul_body(const Fe<P>& a, const Fe<P>& b) {
 template <class P>
 GA_HD_CALL Fe<P> mul_call(const Fe<P>& a, const Fe<P>& b) { return mul_body(a, b); }
 
+// by-value variant: operands and result travel in VGPRs (AMDGPU calling convention), no memory traffic.  Used by the
+// 12-limb field inside hot loops when enabled: a fully inlined BLS12-381 point addition is ~200 KB of code, beyond
+// the 64 KB instruction cache.
+#ifndef GA_BIGFIELD_CALLS
+#define GA_BIGFIELD_CALLS 0   // measured on MI355X: calls cost 20-25 % (BLS12-381 G1 accumulate 42 -> 51 ms); kept for experiments
+#endif
+template <class P>
+GA_HD_CALL Fe<P> mul_val(Fe<P> a, Fe<P> b) { return mul_body(a, b); }
+template <class P>
+GA_HD Fe<P> mul_hot(const Fe<P>& a, const Fe<P>& b) {
+    if constexpr (P::N > 8 && GA_BIGFIELD_CALLS) return mul_val(a, b);
+    else return mul_body(a, b);
+}
+
 // 8-limb fields (BN254 Fp/Fr, BLS12-381 Fr): inlined.  12-limb BLS12-381 Fp: one shared out-of-line copy.
 template <class P>
 GA_HD Fe<P> mul(const Fe<P>& a, const Fe<P>& b) {

@@ -161,11 +161,11 @@ __device__ __forceinline__ void madd_lds(const LdsAcc<F>& A, const Affine<F>& q)
         A.put(3, FieldTraits<F>::one());
         return;
     }
-    F U2 = mul_body(q.x, zz);
+    F U2 = mul_inl(q.x, zz);
     F ax = A.get(0);
     F Pp = sub(U2, ax);
     F zzz = A.get(3);
-    F S2 = mul_body(q.y, zzz);
+    F S2 = mul_inl(q.y, zzz);
     F ay = A.get(1);
     F R = sub(S2, ay);
     if (is_zero(Pp)) {
@@ -177,13 +177,13 @@ __device__ __forceinline__ void madd_lds(const LdsAcc<F>& A, const Affine<F>& q)
         return;
     }
     F PP = sqr_body(Pp);
-    A.put(2, mul_body(zz, PP));
-    F PPP = mul_body(Pp, PP);
-    A.put(3, mul_body(zzz, PPP));
-    F Q = mul_body(ax, PP);
+    A.put(2, mul_inl(zz, PP));
+    F PPP = mul_inl(Pp, PP);
+    A.put(3, mul_inl(zzz, PPP));
+    F Q = mul_inl(ax, PP);
     F X3 = sub(sub(sqr_body(R), PPP), dbl(Q));
     A.put(0, X3);
-    A.put(1, sub(mul_body(R, sub(Q, X3)), mul_body(ay, PPP)));
+    A.put(1, sub(mul_inl(R, sub(Q, X3)), mul_inl(ay, PPP)));
 }
 
 template <class F>
