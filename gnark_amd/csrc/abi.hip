@@ -2,6 +2,7 @@
 // profiling.  Groth16 lives in groth16.hip.  Every entry point selects the context's device itself and takes the
 // context mutex (one proof at a time per device, as icicle.go:821-823).
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "hostops.cuh"
 
@@ -87,11 +88,27 @@ static int msm_impl(Ctx* ctx, const void* bases, const void* scalars, size_t n, 
         set_error("msm: window range [%d,%d) outside [0,%d)", win_lo, win_hi, nwin);
         return GA_ERR_INVALID;
     }
-    Staged sb{ctx}, ss{ctx};
-    GA_CHECK(sb.stage(bases, n * sizeof(Affine<F>), flags & GA_BASES_ON_DEVICE));
-    GA_CHECK(ss.stage(scalars, n * 32, flags & GA_SCALARS_ON_DEVICE));
-    std::vector<XYZZ<F>> W(win_hi - win_lo);
-    GA_CHECK((msm_windows_device<C, G>(ctx, sb.dev, ss.dev, n, (flags & GA_SCALARS_MONTGOMERY) != 0, c, win_lo, win_hi, W.data())));
+    // Split along the point axis when one call would overflow the 2^31 (point, window) pair space -- the analogue of
+    // msmChunkedG1/G2 (icicle.go:362-467); partial results are added on the host.  Never needed up to 2^26 points.
+    size_t max_chunk = ((size_t)1 << 31) / (size_t)(win_hi - win_lo) - 1;
+    if (const char* cap = getenv("GA_MSM_MAX_CHUNK")) {   // test hook, like ICICLE's chunk-cap override (icicle.go:577-584)
+        size_t v = strtoull(cap, nullptr, 10);
+        if (v > 0 && v < max_chunk) max_chunk = v;
+    }
+    std::vector<XYZZ<F>> W(win_hi - win_lo, xyzz_inf<F>());
+    for (size_t done = 0; done < n || n == 0; ) {
+        const size_t cn = n - done < max_chunk ? n - done : max_chunk;
+        Staged sb{ctx}, ss{ctx};
+        const char* bp = reinterpret_cast<const char*>(bases) + done * sizeof(Affine<F>);
+        const char* sp = reinterpret_cast<const char*>(scalars) + done * 32;
+        GA_CHECK(sb.stage(bp, cn * sizeof(Affine<F>), flags & GA_BASES_ON_DEVICE));
+        GA_CHECK(ss.stage(sp, cn * 32, flags & GA_SCALARS_ON_DEVICE));
+        std::vector<XYZZ<F>> part(win_hi - win_lo);
+        GA_CHECK((msm_windows_device<C, G>(ctx, sb.dev, ss.dev, cn, (flags & GA_SCALARS_MONTGOMERY) != 0, c, win_lo, win_hi, part.data())));
+        for (size_t w = 0; w < W.size(); w++) W[w] = add(W[w], part[w]);
+        done += cn;
+        if (n == 0) break;
+    }
     if (want_windows) {
         char* o = reinterpret_cast<char*>(out);
         for (size_t w = 0; w < W.size(); w++) host_store_jac<F>(o + w * sizeof(Jac<F>), W[w]);

@@ -142,6 +142,49 @@ def test_emu_msm_precomputed_table(emu_ctx, c, group):
         t.free()
 
 
+def test_emu_msm_chunked_and_ragged_sizes(emu_ctx, monkeypatch, sizes=(2, 7, 65)):
+    """point-axis chunking (the msmChunkedG1 analogue) and sizes that are not multiples of anything"""
+    c, group = BN254, 0
+    rng = pyref.Xoshiro(99)
+    G = group_of(c, group)
+    pts, _ = _random_points(c, group, 9, rng)
+    for n in sizes:
+        P = [pts[i % 9] for i in range(n)]
+        S = [rng.field(c.r) for _ in range(n)]
+        want = None
+        for j in range(9):
+            want = G.add(want, G.mul(pts[j], sum(s for i, s in enumerate(S) if i % 9 == j) % c.r))
+        for cap in (None, "5"):
+            if cap:
+                monkeypatch.setenv("GA_MSM_MAX_CHUNK", cap)
+            else:
+                monkeypatch.delenv("GA_MSM_MAX_CHUNK", raising=False)
+            got = ecc.MultiExp(emu_ctx, c.name, group, pts_to_arr(c, group, P), fr_to_arr(c, S))
+            assert jac_to_affine_py(c, group, got) == want, (n, cap)
+    monkeypatch.delenv("GA_MSM_MAX_CHUNK", raising=False)
+    # all bases at infinity, all scalars zero
+    z = ecc.MultiExp(emu_ctx, c.name, group, pts_to_arr(c, group, [None] * 5), fr_to_arr(c, [3] * 5))
+    assert jac_to_affine_py(c, group, z) is None
+
+
+def test_emu_error_behaviour(emu_ctx):
+    """errors mirror the reference's: bad sizes are rejected with a message, nothing is computed"""
+    from gnark_amd import GnarkAmdError
+    c = BN254
+    with pytest.raises(ValueError):
+        fft.Domain(emu_ctx, c.name, 8).FFT(fr_to_arr(c, [1, 2, 3]), fft.DIF)          # len != cardinality
+    with pytest.raises(ValueError):
+        ecc.MultiExp(emu_ctx, "bw6-761", 0, np.zeros((1, 8), np.uint64), np.zeros((1, 4), np.uint64))   # curve not built
+    with pytest.raises(GnarkAmdError, match="power of two|cardinality"):
+        import ctypes as C
+        h = C.c_void_p()
+        emu_ctx.lib.check(emu_ctx.lib.ga_domain_create(emu_ctx.handle, 0, 12, C.byref(h)))
+    with pytest.raises(GnarkAmdError, match="len\\(G1.Z\\)|n-1"):
+        groth16.ProvingKey(emu_ctx, c.name, domain_cardinality=8, alpha1=np.zeros((1, 8)), beta1=np.zeros((1, 8)), delta1=np.zeros((1, 8)),
+                           A=np.zeros((2, 8)), B=np.zeros((2, 8)), Z=np.zeros((3, 8)), K=np.zeros((1, 8)), beta2=np.zeros((1, 16)),
+                           delta2=np.zeros((1, 16)), B2=np.zeros((2, 16)), infinityA=[0, 0], infinityB=[0, 0])
+
+
 def test_emu_msm_empty_and_single(emu_ctx):
     c = BN254
     z = ecc.MultiExp(emu_ctx, c.name, 0, np.zeros((0, 8), np.uint64), np.zeros((0, 4), np.uint64))

@@ -42,6 +42,14 @@ def test_msm_hot_bucket_and_windows(gpu_ctx):
     cases.test_emu_msm_hot_bucket_and_windows(gpu_ctx)
 
 
+def test_msm_chunked_and_ragged_sizes(gpu_ctx, monkeypatch):
+    cases.test_emu_msm_chunked_and_ragged_sizes(gpu_ctx, monkeypatch, sizes=(2, 3, 7, 65, 257, 1000))
+
+
+def test_error_behaviour(gpu_ctx):
+    cases.test_emu_error_behaviour(gpu_ctx)
+
+
 def test_msm_empty_and_single(gpu_ctx):
     cases.test_emu_msm_empty_and_single(gpu_ctx)
 
