@@ -141,10 +141,14 @@ struct MsmPrepared {
     uint32_t half = 0, nb = 0, seg = 0;
     uint64_t m = 0, max_tasks = 0;
     uint32_t *vals = nullptr, *task_off = nullptr, *task_start = nullptr, *task_key = nullptr, *task_perm = nullptr;
+    uint32_t* task_key_by_id = nullptr;   // unsorted: seg - len of task id
 };
 
 template <class C, int G>
 int msm_table_build(Ctx* ctx, const void* d_bases, size_t n, int c, void* d_table);
+// bytes per table entry: G1 tables are stored unpacked (field29.cuh: 2*NL limbs padded to 16 B), G2 tables as affine points
+template <class C, int G>
+size_t msm_table_point_bytes();
 template <class C, int G>
 int msm_table_device(Ctx* ctx, const void* d_table, const void* d_scalars, size_t n, bool scalars_mont, int c, void* h_sum);
 template <class C>

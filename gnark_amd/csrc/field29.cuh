@@ -1,0 +1,161 @@
+// Unpacked field representation for hot loops: NL limbs of L bits (9 x 29 for the 254/255-bit fields, 14 x 28 for the
+// 381-bit one), one limb per 32-bit register, values kept in the Montgomery domain of R' = 2^(NL*L):
+//
+//     hat(x) = x * 2^(NL*L) mod p        (memory format is x * 2^(32N); hat = memory value * 2^S, S = NL*L - 32N)
+//
+// Why: on gfx950 every carry costs an issue slot as expensive as the multiply (profiles/r01_b_microbench.json).  In this
+// representation a Montgomery product is 2*NL^2 v_mad_u64_u32 + one shift/mask per column -- no operand unpacking, no
+// repacking, no final conditional subtraction -- and additions/subtractions are limb-wise with one carry sweep and NO
+// modular correction: values are only kept below 2^(NL*L - 2), far above p (7 spare bits for BN254, 11 for BLS12-381),
+// by adding fixed multiples of p on subtraction.  Exact reduction happens once, when a result leaves the hot loop.
+#pragma once
+#include "ec.cuh"
+
+namespace ga {
+
+template <class P>
+struct F29 {
+    static constexpr int NL = Radix<P>::NL;
+    uint32_t l[NL];
+};
+
+// k*p as limbs prepared for borrow-free subtraction:  a - b + k*p  computed limb-wise never goes negative as long as
+// b's limbs are normalized (< 2^L) and b < k*p: every limb but the top lends 2^L to its lower neighbour.
+template <class P, int K>
+GA_HD uint32_t kp_limb(int i) {
+    typedef Radix<P> R;
+    // k*p in plain limbs (host/compile-time folded): multiply the modulus limbs by K with carry
+    uint64_t carry = 0;
+    uint32_t v = 0;
+    for (int j = 0; j <= i; j++) {
+        uint64_t t = (uint64_t)mod_limb<P>(j) * (uint32_t)K + carry;
+        v = (uint32_t)(t & R::MASK);
+        carry = t >> R::L;
+        if (j == R::NL - 1) v = (uint32_t)t;   // top limb keeps the overflow
+    }
+    // lend: limb i gains 2^L (if not the top) and loses 1 (if not the bottom)
+    uint32_t r = v;
+    if (i < R::NL - 1) r += (1u << R::L);
+    if (i > 0) r -= 1;
+    return r;
+}
+
+template <class P>
+GA_HD F29<P> f29_zero() {
+    F29<P> r;
+#pragma unroll
+    for (int i = 0; i < F29<P>::NL; i++) r.l[i] = 0;
+    return r;
+}
+
+template <class P>
+GA_HD bool f29_is_zero_limbs(const F29<P>& a) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < F29<P>::NL; i++) o |= a.l[i];
+    return o == 0;
+}
+
+// carry sweep: limbs back below 2^L (the top limb keeps the excess)
+template <class P>
+GA_HD void f29_normalize(F29<P>& a) {
+    typedef Radix<P> R;
+#pragma unroll
+    for (int i = 0; i < R::NL - 1; i++) {
+        a.l[i + 1] += a.l[i] >> R::L;
+        a.l[i] &= R::MASK;
+    }
+}
+
+template <class P>
+GA_HD F29<P> f29_add(const F29<P>& a, const F29<P>& b) {
+    F29<P> r;
+#pragma unroll
+    for (int i = 0; i < F29<P>::NL; i++) r.l[i] = a.l[i] + b.l[i];
+    f29_normalize(r);
+    return r;
+}
+
+// a - b + K*p   (requires b < K*p, b normalized)
+template <int K, class P>
+GA_HD F29<P> f29_sub(const F29<P>& a, const F29<P>& b) {
+    F29<P> r;
+#pragma unroll
+    for (int i = 0; i < F29<P>::NL; i++) r.l[i] = a.l[i] + kp_limb<P, K>(i) - b.l[i];
+    f29_normalize(r);
+    return r;
+}
+
+// a*b / 2^(NL*L) (+ a multiple of p): normalized limbs in, normalized limbs out; result < a*b/2^(NL*L) + p
+template <class P>
+GA_HD_BIG F29<P> f29_mul(const F29<P>& a, const F29<P>& b) {
+    typedef Radix<P> R;
+    constexpr int NL = R::NL, L = R::L;
+    uint64_t col[2 * NL];
+#pragma unroll
+    for (int k = 0; k < 2 * NL; k++) col[k] = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++)
+#pragma unroll
+        for (int j = 0; j < NL; j++) col[i + j] += (uint64_t)a.l[i] * b.l[j];
+    const uint32_t inv = P::INV & R::MASK;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        const uint32_t m = ((uint32_t)col[i] * inv) & R::MASK;
+#pragma unroll
+        for (int j = 0; j < NL; j++) col[i + j] += (uint64_t)m * mod_limb<P>(j);
+        col[i + 1] += col[i] >> L;
+    }
+    F29<P> r;
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+        if (k + 1 < NL) {
+            r.l[k] = (uint32_t)col[NL + k] & R::MASK;
+            col[NL + k + 1] += col[NL + k] >> L;
+        } else {
+            r.l[k] = (uint32_t)col[NL + k];
+        }
+    }
+    return r;
+}
+
+// memory image (x * 2^(32N), canonical) -> hat(x), canonical limbs
+template <class P>
+GA_HD F29<P> f29_from_mem(const Fe<P>& x) {
+    typedef Radix<P> R;
+    Fe<P> t = x;
+#pragma unroll
+    for (int k = 0; k < R::S; k++) t = dbl(t);   // * 2^S mod p
+    F29<P> r;
+#pragma unroll
+    for (int i = 0; i < R::NL; i++) r.l[i] = take_bits<P::N, R::L>(t.l, i * R::L);
+    return r;
+}
+
+// hat(x) with any value < 2^(32N) -> canonical memory image x * 2^(32N) mod p
+template <class P>
+GA_HD_BIG Fe<P> f29_to_mem(const F29<P>& a) {
+    typedef Radix<P> R;
+    // mont'(a, 2^(32N) mod p) = a * 2^(32N) / 2^(NL*L) = a * 2^-S : hat -> memory scaling; P::ONE is 2^(32N) mod p
+    F29<P> one;
+#pragma unroll
+    for (int i = 0; i < R::NL; i++) one.l[i] = take_bits<P::N, R::L>(P::ONE, i * R::L);
+    F29<P> v = f29_mul(a, one);   // < a*p/2^(NL*L) + p < 2p
+    uint32_t t[P::N];
+#pragma unroll
+    for (int w = 0; w < P::N; w++) {
+        const int k0 = (32 * w) / R::L, off = (32 * w) % R::L;
+        uint64_t u = (uint64_t)v.l[k0] >> off;
+        if (k0 + 1 < R::NL) u |= (uint64_t)v.l[k0 + 1] << (R::L - off);
+        if (2 * R::L - off < 32 && k0 + 2 < R::NL) u |= (uint64_t)v.l[k0 + 2] << (2 * R::L - off);
+        t[w] = (uint32_t)u;
+    }
+    reduce_once<P>(t);
+    reduce_once<P>(t);
+    Fe<P> r;
+#pragma unroll
+    for (int i = 0; i < P::N; i++) r.l[i] = t[i];
+    return r;
+}
+
+}  // namespace ga

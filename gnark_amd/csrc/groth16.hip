@@ -104,14 +104,15 @@ static int pk_create(Ctx* ctx, const ga_g16_key* key, G16Pk** out) {
     // ---- optional precomputation: [2^(c*w)]P for every window (one shared bucket set per MSM afterwards) ----------
     if (rc == GA_OK && key->precompute >= 0) {
         int nw;
+        const size_t t1 = msm_table_point_bytes<C, GA_G1>(), t2 = msm_table_point_bytes<C, GA_G2>();
         msm_plan_table<C>(pk->len_a, &pk->c_a, &nw);
-        uint64_t need = (uint64_t)nw * pk->len_a * s1;
+        uint64_t need = (uint64_t)nw * pk->len_a * t1;
         msm_plan_table<C>(pk->len_b, &pk->c_b, &nw);
-        need += (uint64_t)nw * pk->len_b * (s1 + s2);
+        need += (uint64_t)nw * pk->len_b * (t1 + t2);
         msm_plan_table<C>(pk->len_z, &pk->c_z, &nw);
-        need += (uint64_t)nw * pk->len_z * s1;
+        need += (uint64_t)nw * pk->len_z * t1;
         msm_plan_table<C>(pk->len_k, &pk->c_k, &nw);
-        need += (uint64_t)nw * pk->len_k * s1;
+        need += (uint64_t)nw * pk->len_k * t1;
         size_t free_b = 0, total_b = 0;
         hipMemGetInfo(&free_b, &total_b);
         // leave room for the per-proof scratch (~0.6 KB per constraint measured) and some slack
@@ -133,11 +134,11 @@ static int pk_create(Ctx* ctx, const ga_g16_key* key, G16Pk** out) {
             };
             auto b1 = [&](const void* src, uint64_t len, int c, void* t) { return msm_table_build<C, GA_G1>(ctx, src, len, c, t); };
             auto b2 = [&](const void* src, uint64_t len, int c, void* t) { return msm_table_build<C, GA_G2>(ctx, src, len, c, t); };
-            rc = make(&pk->d_a, pk->len_a, pk->c_a, s1, b1);
-            if (rc == GA_OK) rc = make(&pk->d_b, pk->len_b, pk->c_b, s1, b1);
-            if (rc == GA_OK) rc = make(&pk->d_z, pk->len_z, pk->c_z, s1, b1);
-            if (rc == GA_OK) rc = make(&pk->d_k, pk->len_k, pk->c_k, s1, b1);
-            if (rc == GA_OK) rc = make(&pk->d_b2, pk->len_b2, pk->c_b, s2, b2);
+            rc = make(&pk->d_a, pk->len_a, pk->c_a, t1, b1);
+            if (rc == GA_OK) rc = make(&pk->d_b, pk->len_b, pk->c_b, t1, b1);
+            if (rc == GA_OK) rc = make(&pk->d_z, pk->len_z, pk->c_z, t1, b1);
+            if (rc == GA_OK) rc = make(&pk->d_k, pk->len_k, pk->c_k, t1, b1);
+            if (rc == GA_OK) rc = make(&pk->d_b2, pk->len_b2, pk->c_b, t2, b2);
             pk->tables = rc == GA_OK;
         }
     }

@@ -2,6 +2,7 @@
 // gfx950 ("microbenchmark v_mad_u64_u32 issue rate and report achieved MAD/s fraction"), plus the
 // achieved throughput of this library's own Montgomery multiplication.
 #include "common.cuh"
+#include "field29.cuh"
 
 namespace ga {
 
@@ -63,6 +64,40 @@ __global__ void __launch_bounds__(256) mb_field_mul(uint32_t* out, uint32_t seed
     if (a.l[0] == 0x12345u && b.l[0] == 7) out[threadIdx.x] = a.l[1];
 }
 
+template <class P>
+__global__ void __launch_bounds__(256) mb_f29_mul(uint32_t* out, uint32_t seed) {
+    F29<P> a = f29_from_mem(fe_const<P>(P::R2)), b = f29_from_mem(fe_one<P>());
+    a.l[0] ^= (seed + threadIdx.x) & 0xFFFF;
+    b.l[1] ^= seed & 0xFFFF;
+    for (int it = 0; it < MB_ITERS / 8; it++) {
+        a = f29_mul(a, b);
+        b = f29_mul(b, a);
+    }
+    if (a.l[0] == 0x12345u && b.l[0] == 7) out[threadIdx.x] = a.l[1];
+}
+
+template <class P>
+__global__ void __launch_bounds__(256) mb_f29_addsub(uint32_t* out, uint32_t seed) {
+    F29<P> a = f29_from_mem(fe_const<P>(P::R2)), b = f29_from_mem(fe_one<P>());
+    a.l[0] ^= (seed + threadIdx.x) & 0xFFFF;
+    for (int it = 0; it < MB_ITERS / 8; it++) {
+        a = f29_sub<4>(f29_add(a, b), b);
+        b = f29_sub<4>(f29_add(b, a), a);
+    }
+    if (a.l[0] == 0x12345u && b.l[0] == 7) out[threadIdx.x] = a.l[1];
+}
+
+template <class P>
+__global__ void __launch_bounds__(256) mb_fe_addsub(uint32_t* out, uint32_t seed) {
+    Fe<P> a = fe_const<P>(P::R2), b = fe_one<P>();
+    a.l[0] ^= seed + threadIdx.x;
+    for (int it = 0; it < MB_ITERS / 8; it++) {
+        a = sub(add(a, b), b);
+        b = sub(add(b, a), a);
+    }
+    if (a.l[0] == 0x12345u && b.l[0] == 7) out[threadIdx.x] = a.l[1];
+}
+
 template <class K>
 static int run_one(Ctx* ctx, const char* name, K kernel, double ops_per_thread, std::string& out, uint32_t* d_out) {
     const unsigned blocks = 256 * 8, threads = 256;
@@ -101,6 +136,10 @@ int util_microbench(Ctx* ctx, char* buf, size_t cap) {
     GA_CHECK(run_one(ctx, "v_fma_f32_Gops", mb_fma_f32, n16, out, d_out));
     GA_CHECK(run_one(ctx, "fieldmul_bn254_fr_Gmul", mb_field_mul<BN254_Fr>, 2.0 * (MB_ITERS / 8), out, d_out));
     GA_CHECK(run_one(ctx, "fieldmul_bls12381_fp_Gmul", mb_field_mul<BLS12_381_Fp>, 2.0 * (MB_ITERS / 8), out, d_out));
+    GA_CHECK(run_one(ctx, "f29mul_bn254_Gmul", mb_f29_mul<BN254_Fp>, 2.0 * (MB_ITERS / 8), out, d_out));
+    GA_CHECK(run_one(ctx, "f29mul_bls12381_fp_Gmul", mb_f29_mul<BLS12_381_Fp>, 2.0 * (MB_ITERS / 8), out, d_out));
+    GA_CHECK(run_one(ctx, "f29addsub_bn254_Gop", mb_f29_addsub<BN254_Fp>, 4.0 * (MB_ITERS / 8), out, d_out));
+    GA_CHECK(run_one(ctx, "fe_addsub_bn254_Gop", mb_fe_addsub<BN254_Fp>, 4.0 * (MB_ITERS / 8), out, d_out));
     snprintf(buf, cap, "%s", out.c_str());
     return GA_OK;
 }

@@ -23,6 +23,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include "common.cuh"
+#include "field29.cuh"
 
 namespace ga {
 
@@ -34,6 +35,9 @@ namespace ga {
 #endif
 #ifndef GA_ACC_MINW_BIG
 #define GA_ACC_MINW_BIG 2     // BLS12-381 G2 (384 B), 128-thread workgroups
+#endif
+#ifndef GA_ACC29_MINW
+#define GA_ACC29_MINW 3       // lazy-representation table kernel (G1)
 #endif
 #ifndef GA_ACC_LDS_BYTES
 #define GA_ACC_LDS_BYTES 128  // accumulators of at least this many bytes live in LDS (all groups; measured best)
@@ -237,6 +241,196 @@ msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __res
             v = vn;
         }
         store_pod(&partial[tid], acc);
+    }
+}
+
+// ---- 4b. accumulate over a precomputed table in the unpacked ("29-bit limb") format, G1 ---------------------------
+// Table entry = hat(x) | hat(y) as NL limbs each (field29.cuh), padded to a multiple of 16 bytes; (0,0) = infinity.
+// The bucket loop runs entirely in the lazy representation: per mixed addition 10 products of 2*NL^2 MADs + one
+// shift/mask per column, limb-wise add/sub with a carry sweep, no unpacking, no conditional subtractions.  The
+// exceptional cases of the addition law (doubling, P + (-P), accumulator at infinity) are not branched on: they all
+// make ZZ == 0 (mod p) and 0 is absorbing, so ONE exact test when the task ends detects them; such tasks are queued for
+// msm_accumulate29_redo_kernel, which repeats them with the complete formulas.
+template <class P>
+struct Table29 {
+    static constexpr int NL = Radix<P>::NL;
+    static constexpr int WORDS = (2 * NL + 3) / 4 * 4;   // 20 words (80 B) for BN254, 28 (112 B) for BLS12-381
+};
+
+template <class P>
+struct LdsAcc29 {
+    uint32_t* base;
+    static constexpr int NL = Radix<P>::NL;
+    __device__ __forceinline__ F29<P> get(int field) const {
+        F29<P> r;
+#pragma unroll
+        for (int i = 0; i < NL; i++) r.l[i] = base[(field * NL + i) * 256];
+        return r;
+    }
+    __device__ __forceinline__ void put(int field, const F29<P>& v) const {
+#pragma unroll
+        for (int i = 0; i < NL; i++) base[(field * NL + i) * 256] = v.l[i];
+    }
+};
+
+template <class P>
+__device__ __forceinline__ void load_point29(const uint32_t* __restrict__ table, uint32_t idx, F29<P>& x, F29<P>& y) {
+    constexpr int NL = Radix<P>::NL, W = Table29<P>::WORDS;
+    uint32_t w[W];
+    const uint32_t* src = table + (uint64_t)idx * W;
+#pragma unroll
+    for (int q = 0; q < W / 4; q++) {
+        u32x4 v = load16(src + 4 * q);
+        w[4 * q] = v.x;
+        w[4 * q + 1] = v.y;
+        w[4 * q + 2] = v.z;
+        w[4 * q + 3] = v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        x.l[i] = w[i];
+        y.l[i] = w[NL + i];
+    }
+}
+
+// acc += q in the lazy representation (madd-2008-s); bounds: DESIGN.md "lazy bounds" (all values < 2^257 for BN254,
+// < 2^385 for BLS12-381, limits 2^261 / 2^392)
+template <class P>
+__device__ __forceinline__ void madd29(const LdsAcc29<P>& A, const F29<P>& qx, const F29<P>& qy) {
+    F29<P> zz = A.get(2);
+    F29<P> U2 = f29_mul(qx, zz);
+    F29<P> ax = A.get(0);
+    F29<P> Pp = f29_sub<8>(U2, ax);
+    F29<P> zzz = A.get(3);
+    F29<P> S2 = f29_mul(qy, zzz);
+    F29<P> ay = A.get(1);
+    F29<P> R = f29_sub<8>(S2, ay);
+    F29<P> PP = f29_mul(Pp, Pp);
+    A.put(2, f29_mul(zz, PP));
+    F29<P> PPP = f29_mul(Pp, PP);
+    A.put(3, f29_mul(zzz, PPP));
+    F29<P> Q = f29_mul(ax, PP);
+    F29<P> X3 = f29_sub<4>(f29_mul(R, R), f29_add(PPP, f29_add(Q, Q)));
+    A.put(0, X3);
+    A.put(1, f29_sub<2>(f29_mul(R, f29_sub<8>(Q, X3)), f29_mul(ay, PPP)));
+}
+
+template <class P>
+__global__ void __launch_bounds__(256, GA_ACC29_MINW)
+msm_accumulate29_kernel(const uint32_t* __restrict__ table, const uint32_t* __restrict__ vals,
+                        const uint32_t* __restrict__ task_start, const uint32_t* __restrict__ task_key_sorted,
+                        const uint32_t* __restrict__ task_perm, uint32_t max_tasks, uint32_t seg,
+                        XYZZ<Fe<P>>* __restrict__ partial, uint32_t* __restrict__ redo_list, uint32_t* __restrict__ redo_count) {
+    typedef Fe<P> F;
+    constexpr int NL = Radix<P>::NL;
+    __shared__ uint32_t lds[4 * NL * 256];
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= max_tasks) return;
+    const uint32_t key = task_key_sorted[t];
+    if (key >= seg) return;
+    const uint32_t tid = task_perm[t];
+    const uint32_t start = task_start[tid];
+    const uint32_t end = start + (seg - key);
+    LdsAcc29<P> A{lds + threadIdx.x};
+    const F29<P> one = f29_from_mem(fe_one<P>());
+    bool have = false;
+    uint32_t v = vals[start];
+    for (uint32_t p = start; p < end; p++) {
+        const uint32_t vn = p + 1 < end ? vals[p + 1] : v;
+        F29<P> qx, qy;
+        load_point29<P>(table, v & ~MSM_SIGN, qx, qy);
+        const uint32_t touch = *reinterpret_cast<const volatile uint32_t*>(table + (uint64_t)(vn & ~MSM_SIGN) * Table29<P>::WORDS);
+        if (!(f29_is_zero_limbs(qx) & f29_is_zero_limbs(qy))) {   // (0,0) = infinity: skip
+            if (v & MSM_SIGN) qy = f29_sub<2>(f29_zero<P>(), qy);
+            if (!have) {
+                A.put(0, qx);
+                A.put(1, qy);
+                A.put(2, one);
+                A.put(3, one);
+                have = true;
+            } else {
+                madd29(A, qx, qy);
+            }
+        }
+        GA_KEEP_LIVE(touch);
+        v = vn;
+    }
+    XYZZ<F> acc = xyzz_inf<F>();
+    if (have) {
+        F zz = f29_to_mem(A.get(2));
+        if (is_zero(zz)) {   // an exceptional addition happened somewhere in this task: redo it exactly
+            redo_list[atomicAdd(redo_count, 1u)] = tid;
+            return;
+        }
+        acc.x = f29_to_mem(A.get(0));
+        acc.y = f29_to_mem(A.get(1));
+        acc.zz = zz;
+        acc.zzz = f29_to_mem(A.get(3));
+    }
+    store_pod(&partial[tid], acc);
+}
+
+// exact re-run of the tasks the lazy kernel flagged (complete formulas; table points converted back to gnark's form)
+template <class P>
+__global__ void __launch_bounds__(64)
+msm_accumulate29_redo_kernel(const uint32_t* __restrict__ table, const uint32_t* __restrict__ vals,
+                             const uint32_t* __restrict__ task_start, const uint32_t* __restrict__ task_key_by_tid,
+                             uint32_t seg, const uint32_t* __restrict__ redo_list, const uint32_t* __restrict__ redo_count,
+                             XYZZ<Fe<P>>* __restrict__ partial) {
+    typedef Fe<P> F;
+    const uint32_t nredo = *redo_count;
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nredo; r += gridDim.x * blockDim.x) {
+        const uint32_t tid = redo_list[r];
+        const uint32_t start = task_start[tid];
+        const uint32_t end = start + (seg - task_key_by_tid[tid]);
+        XYZZ<F> acc = xyzz_inf<F>();
+        for (uint32_t p = start; p < end; p++) {
+            const uint32_t v = vals[p];
+            F29<P> qx, qy;
+            load_point29<P>(table, v & ~MSM_SIGN, qx, qy);
+            Affine<F> q{f29_to_mem(qx), f29_to_mem(qy)};
+            if (v & MSM_SIGN) q.y = neg(q.y);
+            acc = madd(acc, q);
+        }
+        store_pod(&partial[tid], acc);
+    }
+}
+
+// table29[w*n + i] = [2^(c*w)] P_i in the unpacked format
+template <class P>
+__global__ void __launch_bounds__(64)
+msm_table29_kernel(const Affine<Fe<P>>* __restrict__ bases, uint64_t n, int c, int nwin, uint32_t* __restrict__ table) {
+    typedef Fe<P> F;
+    constexpr int NL = Radix<P>::NL, W = Table29<P>::WORDS;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine<F> a = load_pod<Affine<F>>(&bases[i]);
+    XYZZ<F> p = to_xyzz(a);
+    for (int w = 0; w < nwin; w++) {
+        if (w > 0) {
+            for (int k = 0; k < c; k++) p = dbl(p);
+            a = to_affine(p);
+            p = to_xyzz(a);
+        }
+        F29<P> x = f29_from_mem(a.x), y = f29_from_mem(a.y);
+        uint32_t out[W];
+#pragma unroll
+        for (int k = 0; k < W; k++) out[k] = 0;
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            out[k] = x.l[k];
+            out[NL + k] = y.l[k];
+        }
+        u32x4* dst = reinterpret_cast<u32x4*>(table + ((uint64_t)w * n + i) * W);
+#pragma unroll
+        for (int q = 0; q < W / 4; q++) {
+            u32x4 v;
+            v.x = out[4 * q];
+            v.y = out[4 * q + 1];
+            v.z = out[4 * q + 2];
+            v.w = out[4 * q + 3];
+            dst[q] = v;
+        }
     }
 }
 
@@ -454,12 +648,17 @@ int msm_prepare(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, in
     P->task_off = task_off;
     P->task_start = task_start;
     P->task_key = task_key2;
+    P->task_key_by_id = task_key;
     P->task_perm = task_perm;
     return GA_OK;
 }
 
 // Group-dependent half: bucket accumulation over `d_bases` (the affine bases, or the precomputed table in table mode),
 // merge, per-set reduction.  Writes P.nsets XYZZ sums to host memory.
+template <class F> struct BaseFieldOf;
+template <class Pp> struct BaseFieldOf<Fe<Pp>> { typedef Pp P; static constexpr bool IS_FP = true; };
+template <class Pp> struct BaseFieldOf<Fe2<Pp>> { typedef Pp P; static constexpr bool IS_FP = false; };
+
 template <class F>
 int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, XYZZ<F>* out) {
     const uint32_t nb = P.nb, half = P.half, seg = P.seg;
@@ -478,7 +677,23 @@ int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, X
     GA_CHECK(ctx->scratch_get("msm_wsum", (uint64_t)nsets * sizeof(XYZZ<F>), (void**)&wsum));
     hipStream_t st = ctx->stream;
     GA_HIP_CHECK(hipMemsetAsync(hot_count, 0, 4, st));
-    {
+    if (P.table && BaseFieldOf<F>::IS_FP) {
+        if constexpr (BaseFieldOf<F>::IS_FP) {
+            typedef typename BaseFieldOf<F>::P FpP;
+            uint32_t *redo_list, *redo_count;
+            GA_CHECK(ctx->scratch_get("msm_redo", (P.max_tasks + 2) * 4, (void**)&redo_list));
+            GA_CHECK(ctx->scratch_get("msm_redo_count", 256, (void**)&redo_count));
+            GA_HIP_CHECK(hipMemsetAsync(redo_count, 0, 4, st));
+            StageTimer tm(ctx, "msm_accumulate");
+            hipLaunchKernelGGL((msm_accumulate29_kernel<FpP>), dim3((unsigned)((P.max_tasks + 255) / 256)), dim3(256), 0, st,
+                               (const uint32_t*)d_bases, (const uint32_t*)P.vals, (const uint32_t*)P.task_start, (const uint32_t*)P.task_key,
+                               (const uint32_t*)P.task_perm, (uint32_t)P.max_tasks, seg, partial, redo_list, redo_count);
+            hipLaunchKernelGGL((msm_accumulate29_redo_kernel<FpP>), dim3(1024), dim3(64), 0, st, (const uint32_t*)d_bases,
+                               (const uint32_t*)P.vals, (const uint32_t*)P.task_start, (const uint32_t*)P.task_key_by_id, seg,
+                               (const uint32_t*)redo_list, (const uint32_t*)redo_count, partial);
+            GA_KERNEL_CHECK();
+        }
+    } else {
         StageTimer tm(ctx, "msm_accumulate");
         constexpr unsigned AT = AccumulateTuning<F>::THREADS;
         hipLaunchKernelGGL((msm_accumulate_kernel<F>), dim3((unsigned)((P.max_tasks + AT - 1) / AT)), dim3(AT), 0, st,
@@ -559,13 +774,24 @@ int msm_prepare_table_scalars(Ctx* ctx, const void* d_scalars, size_t n, bool sc
 }
 
 template <class C, int G>
+size_t msm_table_point_bytes() {
+    typedef typename GroupField<C, G>::F F;
+    if constexpr (G == GA_G1) return Table29<typename C::FpP>::WORDS * 4;
+    else return sizeof(Affine<F>);
+}
+
+template <class C, int G>
 int msm_table_build(Ctx* ctx, const void* d_bases, size_t n, int c, void* d_table) {
     typedef typename GroupField<C, G>::F F;
     if (n == 0) return GA_OK;
     const int nwin = C::FrP::BITS / c + 1;
     StageTimer tm(ctx, "msm_table_build");
-    hipLaunchKernelGGL((msm_table_kernel<F>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, (const Affine<F>*)d_bases,
-                       (uint64_t)n, c, nwin, (Affine<F>*)d_table);
+    if constexpr (G == GA_G1)
+        hipLaunchKernelGGL((msm_table29_kernel<typename C::FpP>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream,
+                           (const Affine<F>*)d_bases, (uint64_t)n, c, nwin, (uint32_t*)d_table);
+    else
+        hipLaunchKernelGGL((msm_table_kernel<F>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, (const Affine<F>*)d_bases,
+                           (uint64_t)n, c, nwin, (Affine<F>*)d_table);
     GA_KERNEL_CHECK();
     return GA_OK;
 }

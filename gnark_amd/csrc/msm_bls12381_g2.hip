@@ -5,4 +5,5 @@ template int msm_windows_device<Bls12381, GA_G2>(Ctx*, const void*, const void*,
 template int msm_table_device<Bls12381, GA_G2>(Ctx*, const void*, const void*, size_t, bool, int, void*);
 template int msm_table_device_reuse<Bls12381, GA_G2>(Ctx*, const void*, const MsmPrepared&, void*);
 template int msm_table_build<Bls12381, GA_G2>(Ctx*, const void*, size_t, int, void*);
+template size_t msm_table_point_bytes<Bls12381, GA_G2>();
 }  // namespace ga

@@ -5,4 +5,5 @@ template int msm_windows_device<Bn254, GA_G2>(Ctx*, const void*, const void*, si
 template int msm_table_device<Bn254, GA_G2>(Ctx*, const void*, const void*, size_t, bool, int, void*);
 template int msm_table_device_reuse<Bn254, GA_G2>(Ctx*, const void*, const MsmPrepared&, void*);
 template int msm_table_build<Bn254, GA_G2>(Ctx*, const void*, size_t, int, void*);
+template size_t msm_table_point_bytes<Bn254, GA_G2>();
 }  // namespace ga
