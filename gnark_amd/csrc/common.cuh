@@ -146,7 +146,7 @@ struct MsmPrepared {
 
 template <class C, int G>
 int msm_table_build(Ctx* ctx, const void* d_bases, size_t n, int c, void* d_table);
-// bytes per table entry: G1 tables are stored unpacked (field29.cuh: 2*NL limbs padded to 16 B), G2 tables as affine points
+// bytes per table entry: tables are stored unpacked (field29.cuh: 29/28-bit limbs, one per word, padded to 16 B)
 template <class C, int G>
 size_t msm_table_point_bytes();
 template <class C, int G>

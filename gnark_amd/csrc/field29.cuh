@@ -158,4 +158,86 @@ GA_HD_BIG Fe<P> f29_to_mem(const F29<P>& a) {
     return r;
 }
 
+// one step towards [0, p): v - floor(v / 2^BITS) * p   (>= 0; result < 2^BITS + q*(2^BITS - p), i.e. < 4p for v < 2^(BITS+3))
+template <class P>
+GA_HD F29<P> f29_partial_reduce(const F29<P>& a) {
+    typedef Radix<P> R;
+    constexpr int TOP = P::BITS / R::L, OFF = P::BITS % R::L;
+    static_assert(TOP == R::NL - 1, "the modulus' top bit lives in the top limb");
+    const uint32_t q = a.l[TOP] >> OFF;
+    F29<P> r;
+    uint64_t c = 0;
+    int32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < R::NL; i++) {
+        uint64_t u = (uint64_t)q * mod_limb<P>(i) + c;   // limb i of q*p
+        c = u >> R::L;
+        int32_t d = (int32_t)a.l[i] - (int32_t)((uint32_t)u & R::MASK) + borrow;
+        if (i < R::NL - 1) {
+            r.l[i] = (uint32_t)d & R::MASK;
+            borrow = d >> R::L;   // arithmetic shift: 0 or -1
+        } else {
+            r.l[i] = (uint32_t)d;
+        }
+    }
+    return r;
+}
+
+// ---- Fp2 = Fp[u]/(u^2+1) in the lazy representation ------------------------------------------------------------------
+template <class P>
+struct F29x2 {
+    F29<P> c0, c1;
+};
+
+template <class P> GA_HD F29x2<P> f29_add(const F29x2<P>& a, const F29x2<P>& b) { return {f29_add(a.c0, b.c0), f29_add(a.c1, b.c1)}; }
+template <int K, class P> GA_HD F29x2<P> f29_sub(const F29x2<P>& a, const F29x2<P>& b) {
+    return {f29_sub<K>(a.c0, b.c0), f29_sub<K>(a.c1, b.c1)};
+}
+template <class P> GA_HD F29x2<P> f29_partial_reduce(const F29x2<P>& a) { return {f29_partial_reduce(a.c0), f29_partial_reduce(a.c1)}; }
+template <class P> GA_HD bool f29_is_zero_limbs(const F29x2<P>& a) { return f29_is_zero_limbs(a.c0) & f29_is_zero_limbs(a.c1); }
+
+// Karatsuba; requires component sums < 2^(NL*L) (bounds: DESIGN.md "lazy bounds")
+template <class P>
+GA_HD_BIG F29x2<P> f29_mul(const F29x2<P>& a, const F29x2<P>& b) {
+    F29<P> v0 = f29_mul(a.c0, b.c0);
+    F29<P> v1 = f29_mul(a.c1, b.c1);
+    F29<P> s = f29_mul(f29_add(a.c0, a.c1), f29_add(b.c0, b.c1));
+    return {f29_sub<2>(v0, v1), f29_sub<4>(s, f29_add(v0, v1))};
+}
+// complex squaring: (a0+a1)(a0-a1) + 2 a0 a1 u
+template <class P>
+GA_HD_BIG F29x2<P> f29_sqr(const F29x2<P>& a) {
+    F29<P> t = f29_mul(a.c0, a.c1);
+    F29<P> r0 = f29_mul(f29_add(a.c0, a.c1), f29_sub<8>(a.c0, a.c1));
+    return {r0, f29_add(t, t)};
+}
+template <class P>
+GA_HD_BIG F29<P> f29_sqr(const F29<P>& a) { return f29_mul(a, a); }
+
+// ---- uniform view used by the table kernels: Lazy<Fe<P>> / Lazy<Fe2<P>> ------------------------------------------------
+template <class F> struct Lazy;
+template <class P> struct Lazy<Fe<P>> {
+    typedef P Params;
+    typedef F29<P> T;
+    static constexpr int NW = Radix<P>::NL;          // 32-bit words per coordinate
+    static constexpr bool FP2 = false;
+    GA_HD static T from_mem(const Fe<P>& x) { return f29_from_mem(x); }
+    GA_HD static Fe<P> to_mem(const T& x) { return f29_to_mem(x); }
+    GA_HD static uint32_t word(const T& x, int i) { return x.l[i]; }
+    GA_HD static void set_word(T& x, int i, uint32_t v) { x.l[i] = v; }
+};
+template <class P> struct Lazy<Fe2<P>> {
+    typedef P Params;
+    typedef F29x2<P> T;
+    static constexpr int NW = 2 * Radix<P>::NL;
+    static constexpr bool FP2 = true;
+    GA_HD static T from_mem(const Fe2<P>& x) { return {f29_from_mem(x.c0), f29_from_mem(x.c1)}; }
+    GA_HD static Fe2<P> to_mem(const T& x) { return {f29_to_mem(x.c0), f29_to_mem(x.c1)}; }
+    GA_HD static uint32_t word(const T& x, int i) { return i < Radix<P>::NL ? x.c0.l[i] : x.c1.l[i - Radix<P>::NL]; }
+    GA_HD static void set_word(T& x, int i, uint32_t v) {
+        if (i < Radix<P>::NL) x.c0.l[i] = v;
+        else x.c1.l[i - Radix<P>::NL] = v;
+    }
+};
+
 }  // namespace ga

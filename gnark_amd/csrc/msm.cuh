@@ -251,31 +251,36 @@ msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __res
 // exceptional cases of the addition law (doubling, P + (-P), accumulator at infinity) are not branched on: they all
 // make ZZ == 0 (mod p) and 0 is absorbing, so ONE exact test when the task ends detects them; such tasks are queued for
 // msm_accumulate29_redo_kernel, which repeats them with the complete formulas.
-template <class P>
+template <class F>
 struct Table29 {
-    static constexpr int NL = Radix<P>::NL;
-    static constexpr int WORDS = (2 * NL + 3) / 4 * 4;   // 20 words (80 B) for BN254, 28 (112 B) for BLS12-381
+    static constexpr int NW = Lazy<F>::NW;                 // words per coordinate
+    static constexpr int WORDS = (2 * NW + 3) / 4 * 4;     // G1: 20 / 28 words (80 / 112 B); G2: 36 / 56 words (144 / 224 B)
+    // workgroup size: the LDS-resident accumulators (4*NW words per lane) must leave room for 2 workgroups per CU
+    static constexpr int THREADS = (4 * NW * 4 * 256 <= 72 * 1024) ? 256 : 128;
+    static constexpr int MIN_WAVES = Lazy<F>::FP2 ? 2 : GA_ACC29_MINW;
 };
 
-template <class P>
+template <class F>
 struct LdsAcc29 {
+    typedef typename Lazy<F>::T T;
     uint32_t* base;
-    static constexpr int NL = Radix<P>::NL;
-    __device__ __forceinline__ F29<P> get(int field) const {
-        F29<P> r;
+    static constexpr int NW = Lazy<F>::NW, STRIDE = Table29<F>::THREADS;
+    __device__ __forceinline__ T get(int field) const {
+        T r;
 #pragma unroll
-        for (int i = 0; i < NL; i++) r.l[i] = base[(field * NL + i) * 256];
+        for (int i = 0; i < NW; i++) Lazy<F>::set_word(r, i, base[(field * NW + i) * STRIDE]);
         return r;
     }
-    __device__ __forceinline__ void put(int field, const F29<P>& v) const {
+    __device__ __forceinline__ void put(int field, const T& v) const {
 #pragma unroll
-        for (int i = 0; i < NL; i++) base[(field * NL + i) * 256] = v.l[i];
+        for (int i = 0; i < NW; i++) base[(field * NW + i) * STRIDE] = Lazy<F>::word(v, i);
     }
 };
 
-template <class P>
-__device__ __forceinline__ void load_point29(const uint32_t* __restrict__ table, uint32_t idx, F29<P>& x, F29<P>& y) {
-    constexpr int NL = Radix<P>::NL, W = Table29<P>::WORDS;
+template <class F>
+__device__ __forceinline__ void load_point29(const uint32_t* __restrict__ table, uint32_t idx, typename Lazy<F>::T& x,
+                                             typename Lazy<F>::T& y) {
+    constexpr int NW = Lazy<F>::NW, W = Table29<F>::WORDS;
     uint32_t w[W];
     const uint32_t* src = table + (uint64_t)idx * W;
 #pragma unroll
@@ -287,16 +292,17 @@ __device__ __forceinline__ void load_point29(const uint32_t* __restrict__ table,
         w[4 * q + 3] = v.w;
     }
 #pragma unroll
-    for (int i = 0; i < NL; i++) {
-        x.l[i] = w[i];
-        y.l[i] = w[NL + i];
+    for (int i = 0; i < NW; i++) {
+        Lazy<F>::set_word(x, i, w[i]);
+        Lazy<F>::set_word(y, i, w[NW + i]);
     }
 }
 
-// acc += q in the lazy representation (madd-2008-s); bounds: DESIGN.md "lazy bounds" (all values < 2^257 for BN254,
-// < 2^385 for BLS12-381, limits 2^261 / 2^392)
+// acc += q in the lazy representation (madd-2008-s).  Subtraction constants and partial reductions come from the bound
+// analysis in DESIGN.md ("lazy bounds"): G1 keeps every value < 2^257 (BN254) / 2^385 (BLS12-381) with no reduction at
+// all; G2 (Karatsuba doubles the operand bounds) additionally applies f29_partial_reduce to P, R, PPP and X3.
 template <class P>
-__device__ __forceinline__ void madd29(const LdsAcc29<P>& A, const F29<P>& qx, const F29<P>& qy) {
+__device__ __forceinline__ void madd29(const LdsAcc29<Fe<P>>& A, const F29<P>& qx, const F29<P>& qy) {
     F29<P> zz = A.get(2);
     F29<P> U2 = f29_mul(qx, zz);
     F29<P> ax = A.get(0);
@@ -316,14 +322,36 @@ __device__ __forceinline__ void madd29(const LdsAcc29<P>& A, const F29<P>& qx, c
 }
 
 template <class P>
-__global__ void __launch_bounds__(256, GA_ACC29_MINW)
+__device__ __forceinline__ void madd29(const LdsAcc29<Fe2<P>>& A, const F29x2<P>& qx, const F29x2<P>& qy) {
+    typedef F29x2<P> T;
+    T zz = A.get(2);
+    T U2 = f29_mul(qx, zz);
+    T ax = A.get(0);
+    T Pp = f29_partial_reduce(f29_sub<16>(U2, ax));
+    T zzz = A.get(3);
+    T S2 = f29_mul(qy, zzz);
+    T ay = A.get(1);
+    T R = f29_partial_reduce(f29_sub<16>(S2, ay));
+    T PP = f29_sqr(Pp);
+    A.put(2, f29_mul(zz, PP));
+    T PPP = f29_partial_reduce(f29_mul(Pp, PP));
+    A.put(3, f29_mul(zzz, PPP));
+    T Q = f29_mul(ax, PP);
+    T X3 = f29_partial_reduce(f29_sub<16>(f29_sqr(R), f29_add(PPP, f29_add(Q, Q))));
+    A.put(0, X3);
+    A.put(1, f29_sub<8>(f29_mul(R, f29_sub<8>(Q, X3)), f29_mul(ay, PPP)));
+}
+
+template <class F>
+__global__ void __launch_bounds__(Table29<F>::THREADS, Table29<F>::MIN_WAVES)
 msm_accumulate29_kernel(const uint32_t* __restrict__ table, const uint32_t* __restrict__ vals,
                         const uint32_t* __restrict__ task_start, const uint32_t* __restrict__ task_key_sorted,
                         const uint32_t* __restrict__ task_perm, uint32_t max_tasks, uint32_t seg,
-                        XYZZ<Fe<P>>* __restrict__ partial, uint32_t* __restrict__ redo_list, uint32_t* __restrict__ redo_count) {
-    typedef Fe<P> F;
-    constexpr int NL = Radix<P>::NL;
-    __shared__ uint32_t lds[4 * NL * 256];
+                        XYZZ<F>* __restrict__ partial, uint32_t* __restrict__ redo_list, uint32_t* __restrict__ redo_count) {
+    typedef typename Lazy<F>::T T;
+    typedef typename Lazy<F>::Params P;
+    constexpr int NW = Lazy<F>::NW;
+    __shared__ uint32_t lds[4 * NW * Table29<F>::THREADS];
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= max_tasks) return;
     const uint32_t key = task_key_sorted[t];
@@ -331,17 +359,17 @@ msm_accumulate29_kernel(const uint32_t* __restrict__ table, const uint32_t* __re
     const uint32_t tid = task_perm[t];
     const uint32_t start = task_start[tid];
     const uint32_t end = start + (seg - key);
-    LdsAcc29<P> A{lds + threadIdx.x};
-    const F29<P> one = f29_from_mem(fe_one<P>());
+    LdsAcc29<F> A{lds + threadIdx.x};
+    const T one = Lazy<F>::from_mem(FieldTraits<F>::one());
     bool have = false;
     uint32_t v = vals[start];
     for (uint32_t p = start; p < end; p++) {
         const uint32_t vn = p + 1 < end ? vals[p + 1] : v;
-        F29<P> qx, qy;
-        load_point29<P>(table, v & ~MSM_SIGN, qx, qy);
-        const uint32_t touch = *reinterpret_cast<const volatile uint32_t*>(table + (uint64_t)(vn & ~MSM_SIGN) * Table29<P>::WORDS);
+        T qx, qy;
+        load_point29<F>(table, v & ~MSM_SIGN, qx, qy);
+        const uint32_t touch = *reinterpret_cast<const volatile uint32_t*>(table + (uint64_t)(vn & ~MSM_SIGN) * Table29<F>::WORDS);
         if (!(f29_is_zero_limbs(qx) & f29_is_zero_limbs(qy))) {   // (0,0) = infinity: skip
-            if (v & MSM_SIGN) qy = f29_sub<2>(f29_zero<P>(), qy);
+            if (v & MSM_SIGN) qy = f29_sub<2>(Lazy<F>::from_mem(FieldTraits<F>::zero()), qy);   // 2p - y
             if (!have) {
                 A.put(0, qx);
                 A.put(1, qy);
@@ -349,7 +377,7 @@ msm_accumulate29_kernel(const uint32_t* __restrict__ table, const uint32_t* __re
                 A.put(3, one);
                 have = true;
             } else {
-                madd29(A, qx, qy);
+                madd29<P>(A, qx, qy);
             }
         }
         GA_KEEP_LIVE(touch);
@@ -357,27 +385,27 @@ msm_accumulate29_kernel(const uint32_t* __restrict__ table, const uint32_t* __re
     }
     XYZZ<F> acc = xyzz_inf<F>();
     if (have) {
-        F zz = f29_to_mem(A.get(2));
+        F zz = Lazy<F>::to_mem(A.get(2));
         if (is_zero(zz)) {   // an exceptional addition happened somewhere in this task: redo it exactly
             redo_list[atomicAdd(redo_count, 1u)] = tid;
             return;
         }
-        acc.x = f29_to_mem(A.get(0));
-        acc.y = f29_to_mem(A.get(1));
+        acc.x = Lazy<F>::to_mem(A.get(0));
+        acc.y = Lazy<F>::to_mem(A.get(1));
         acc.zz = zz;
-        acc.zzz = f29_to_mem(A.get(3));
+        acc.zzz = Lazy<F>::to_mem(A.get(3));
     }
     store_pod(&partial[tid], acc);
 }
 
 // exact re-run of the tasks the lazy kernel flagged (complete formulas; table points converted back to gnark's form)
-template <class P>
+template <class F>
 __global__ void __launch_bounds__(64)
 msm_accumulate29_redo_kernel(const uint32_t* __restrict__ table, const uint32_t* __restrict__ vals,
                              const uint32_t* __restrict__ task_start, const uint32_t* __restrict__ task_key_by_tid,
                              uint32_t seg, const uint32_t* __restrict__ redo_list, const uint32_t* __restrict__ redo_count,
-                             XYZZ<Fe<P>>* __restrict__ partial) {
-    typedef Fe<P> F;
+                             XYZZ<F>* __restrict__ partial) {
+    typedef typename Lazy<F>::T T;
     const uint32_t nredo = *redo_count;
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nredo; r += gridDim.x * blockDim.x) {
         const uint32_t tid = redo_list[r];
@@ -386,9 +414,9 @@ msm_accumulate29_redo_kernel(const uint32_t* __restrict__ table, const uint32_t*
         XYZZ<F> acc = xyzz_inf<F>();
         for (uint32_t p = start; p < end; p++) {
             const uint32_t v = vals[p];
-            F29<P> qx, qy;
-            load_point29<P>(table, v & ~MSM_SIGN, qx, qy);
-            Affine<F> q{f29_to_mem(qx), f29_to_mem(qy)};
+            T qx, qy;
+            load_point29<F>(table, v & ~MSM_SIGN, qx, qy);
+            Affine<F> q{Lazy<F>::to_mem(qx), Lazy<F>::to_mem(qy)};
             if (v & MSM_SIGN) q.y = neg(q.y);
             acc = madd(acc, q);
         }
@@ -397,11 +425,11 @@ msm_accumulate29_redo_kernel(const uint32_t* __restrict__ table, const uint32_t*
 }
 
 // table29[w*n + i] = [2^(c*w)] P_i in the unpacked format
-template <class P>
+template <class F>
 __global__ void __launch_bounds__(64)
-msm_table29_kernel(const Affine<Fe<P>>* __restrict__ bases, uint64_t n, int c, int nwin, uint32_t* __restrict__ table) {
-    typedef Fe<P> F;
-    constexpr int NL = Radix<P>::NL, W = Table29<P>::WORDS;
+msm_table29_kernel(const Affine<F>* __restrict__ bases, uint64_t n, int c, int nwin, uint32_t* __restrict__ table) {
+    typedef typename Lazy<F>::T T;
+    constexpr int NW = Lazy<F>::NW, W = Table29<F>::WORDS;
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Affine<F> a = load_pod<Affine<F>>(&bases[i]);
@@ -412,24 +440,14 @@ msm_table29_kernel(const Affine<Fe<P>>* __restrict__ bases, uint64_t n, int c, i
             a = to_affine(p);
             p = to_xyzz(a);
         }
-        F29<P> x = f29_from_mem(a.x), y = f29_from_mem(a.y);
-        uint32_t out[W];
+        T x = Lazy<F>::from_mem(a.x), y = Lazy<F>::from_mem(a.y);
+        uint32_t* dst = table + ((uint64_t)w * n + i) * W;
 #pragma unroll
-        for (int k = 0; k < W; k++) out[k] = 0;
-#pragma unroll
-        for (int k = 0; k < NL; k++) {
-            out[k] = x.l[k];
-            out[NL + k] = y.l[k];
-        }
-        u32x4* dst = reinterpret_cast<u32x4*>(table + ((uint64_t)w * n + i) * W);
-#pragma unroll
-        for (int q = 0; q < W / 4; q++) {
-            u32x4 v;
-            v.x = out[4 * q];
-            v.y = out[4 * q + 1];
-            v.z = out[4 * q + 2];
-            v.w = out[4 * q + 3];
-            dst[q] = v;
+        for (int k = 0; k < W; k++) {
+            uint32_t v = 0;
+            if (k < NW) v = Lazy<F>::word(x, k);
+            else if (k < 2 * NW) v = Lazy<F>::word(y, k - NW);
+            dst[k] = v;
         }
     }
 }
@@ -526,22 +544,6 @@ msm_segment_sum_kernel(const XYZZ<F>* __restrict__ in, uint32_t seg_len, XYZZ<F>
 // With 288 GB of HBM a pinned key can afford windows x its size: all windows then share one bucket set (one
 // reduction instead of `windows`, no Horner) and c can grow to 23 => 12 instead of 14 window passes over the scalars.
 // (ICICLE exposes the same idea as MSMConfig.PrecomputeFactor, icicle.go:507-525.)
-template <class F>
-__global__ void __launch_bounds__(64)
-msm_table_kernel(const Affine<F>* __restrict__ bases, uint64_t n, int c, int nwin, Affine<F>* __restrict__ table) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Affine<F> a = load_pod<Affine<F>>(&bases[i]);
-    store_pod(&table[i], a);
-    XYZZ<F> p = to_xyzz(a);
-    for (int w = 1; w < nwin; w++) {
-        for (int k = 0; k < c; k++) p = dbl(p);
-        a = to_affine(p);
-        store_pod(&table[(uint64_t)w * n + i], a);
-        p = to_xyzz(a);   // restart from the affine point: keeps zz = zzz = 1 and the next to_affine cheap to verify
-    }
-}
-
 // ---- host driver ------------------------------------------------------------------------------------
 
 template <class FrP>
@@ -677,22 +679,20 @@ int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, X
     GA_CHECK(ctx->scratch_get("msm_wsum", (uint64_t)nsets * sizeof(XYZZ<F>), (void**)&wsum));
     hipStream_t st = ctx->stream;
     GA_HIP_CHECK(hipMemsetAsync(hot_count, 0, 4, st));
-    if (P.table && BaseFieldOf<F>::IS_FP) {
-        if constexpr (BaseFieldOf<F>::IS_FP) {
-            typedef typename BaseFieldOf<F>::P FpP;
-            uint32_t *redo_list, *redo_count;
-            GA_CHECK(ctx->scratch_get("msm_redo", (P.max_tasks + 2) * 4, (void**)&redo_list));
-            GA_CHECK(ctx->scratch_get("msm_redo_count", 256, (void**)&redo_count));
-            GA_HIP_CHECK(hipMemsetAsync(redo_count, 0, 4, st));
-            StageTimer tm(ctx, "msm_accumulate");
-            hipLaunchKernelGGL((msm_accumulate29_kernel<FpP>), dim3((unsigned)((P.max_tasks + 255) / 256)), dim3(256), 0, st,
-                               (const uint32_t*)d_bases, (const uint32_t*)P.vals, (const uint32_t*)P.task_start, (const uint32_t*)P.task_key,
-                               (const uint32_t*)P.task_perm, (uint32_t)P.max_tasks, seg, partial, redo_list, redo_count);
-            hipLaunchKernelGGL((msm_accumulate29_redo_kernel<FpP>), dim3(1024), dim3(64), 0, st, (const uint32_t*)d_bases,
-                               (const uint32_t*)P.vals, (const uint32_t*)P.task_start, (const uint32_t*)P.task_key_by_id, seg,
-                               (const uint32_t*)redo_list, (const uint32_t*)redo_count, partial);
-            GA_KERNEL_CHECK();
-        }
+    if (P.table) {
+        uint32_t *redo_list, *redo_count;
+        GA_CHECK(ctx->scratch_get("msm_redo", (P.max_tasks + 2) * 4, (void**)&redo_list));
+        GA_CHECK(ctx->scratch_get("msm_redo_count", 256, (void**)&redo_count));
+        GA_HIP_CHECK(hipMemsetAsync(redo_count, 0, 4, st));
+        StageTimer tm(ctx, "msm_accumulate");
+        constexpr unsigned AT = Table29<F>::THREADS;
+        hipLaunchKernelGGL((msm_accumulate29_kernel<F>), dim3((unsigned)((P.max_tasks + AT - 1) / AT)), dim3(AT), 0, st,
+                           (const uint32_t*)d_bases, (const uint32_t*)P.vals, (const uint32_t*)P.task_start, (const uint32_t*)P.task_key,
+                           (const uint32_t*)P.task_perm, (uint32_t)P.max_tasks, seg, partial, redo_list, redo_count);
+        hipLaunchKernelGGL((msm_accumulate29_redo_kernel<F>), dim3(1024), dim3(64), 0, st, (const uint32_t*)d_bases,
+                           (const uint32_t*)P.vals, (const uint32_t*)P.task_start, (const uint32_t*)P.task_key_by_id, seg,
+                           (const uint32_t*)redo_list, (const uint32_t*)redo_count, partial);
+        GA_KERNEL_CHECK();
     } else {
         StageTimer tm(ctx, "msm_accumulate");
         constexpr unsigned AT = AccumulateTuning<F>::THREADS;
@@ -776,8 +776,7 @@ int msm_prepare_table_scalars(Ctx* ctx, const void* d_scalars, size_t n, bool sc
 template <class C, int G>
 size_t msm_table_point_bytes() {
     typedef typename GroupField<C, G>::F F;
-    if constexpr (G == GA_G1) return Table29<typename C::FpP>::WORDS * 4;
-    else return sizeof(Affine<F>);
+    return Table29<F>::WORDS * 4;
 }
 
 template <class C, int G>
@@ -786,12 +785,8 @@ int msm_table_build(Ctx* ctx, const void* d_bases, size_t n, int c, void* d_tabl
     if (n == 0) return GA_OK;
     const int nwin = C::FrP::BITS / c + 1;
     StageTimer tm(ctx, "msm_table_build");
-    if constexpr (G == GA_G1)
-        hipLaunchKernelGGL((msm_table29_kernel<typename C::FpP>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream,
-                           (const Affine<F>*)d_bases, (uint64_t)n, c, nwin, (uint32_t*)d_table);
-    else
-        hipLaunchKernelGGL((msm_table_kernel<F>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, (const Affine<F>*)d_bases,
-                           (uint64_t)n, c, nwin, (Affine<F>*)d_table);
+    hipLaunchKernelGGL((msm_table29_kernel<F>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream,
+                       (const Affine<F>*)d_bases, (uint64_t)n, c, nwin, (uint32_t*)d_table);
     GA_KERNEL_CHECK();
     return GA_OK;
 }
