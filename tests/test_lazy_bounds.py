@@ -1,0 +1,35 @@
+"""The bucket loops run in an unreduced representation (field29.cuh); tools/lazy_bounds.py is the interval analysis that
+justifies the constants.  It must hold for every (curve, group) the kernels are instantiated for, with headroom."""
+import os
+import re
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import lazy_bounds  # noqa: E402
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12-381"])
+@pytest.mark.parametrize("fp2", [False, True], ids=["G1", "G2"])
+def test_bounds_hold_with_headroom(curve, fp2):
+    out = lazy_bounds.check(curve, fp2)
+    assert max(out["X"], out["Y"], out["P"], out["R"]) < out["limit"] - 2.5   # >= 2.5 bits below R'
+
+
+def test_constants_match_the_kernels():
+    src = open(os.path.join(ROOT, "gnark_amd", "csrc", "msm.cuh")).read()
+    g1 = src[src.index("__device__ __forceinline__ void madd29(const LdsAcc29<Fe<P>>"):src.index("__device__ __forceinline__ void madd29(const LdsAcc29<Fe2<P>>")]
+    g2 = src[src.index("__device__ __forceinline__ void madd29(const LdsAcc29<Fe2<P>>"):src.index("msm_accumulate29_kernel(")]
+    subs = lambda s: [int(x) for x in re.findall(r"f29_sub<(\d+)>", s)]
+    k = lazy_bounds.G1
+    assert subs(g1) == [k["Kx"], k["Ky"], k["K3"], k["Ky3"], k["Kq"]]
+    k = lazy_bounds.G2
+    assert subs(g2) == [k["Kx"], k["Ky"], k["K3"], k["Ky3"], k["Kq"]]
+    assert g2.count("f29_partial_reduce(") == len(k["partial_reduce"])
+    f29 = open(os.path.join(ROOT, "gnark_amd", "csrc", "field29.cuh")).read()
+    kar = f29[f29.index("GA_HD_BIG F29x2<P> f29_mul("):f29.index("GA_HD_BIG F29x2<P> f29_sqr(")]
+    assert subs(kar) == [k["KV"], k["KS"]]
+    sq = f29[f29.index("GA_HD_BIG F29x2<P> f29_sqr("):f29.index("GA_HD_BIG F29<P> f29_sqr(")]
+    assert subs(sq) == [k["KQ"]]

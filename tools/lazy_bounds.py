@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Interval analysis behind the lazy (unreduced) arithmetic of gnark_amd/csrc/field29.cuh + msm.cuh::madd29.
+
+Every value is tracked by an upper bound.  The representation needs (NL limbs of L bits, R' = 2^(NL*L)):
+  * values < R' (the top limb must stay below 2^L so that column sums of 2*NL products fit 64 bits);
+  * for every  a - b + K*p :  b < K*p  (with a margin of one top-limb unit, 2^(L*(NL-1)));
+  * Karatsuba operand sums (Fp2) < R'.
+`check(...)` iterates the mixed-addition formulas to a fixed point of the accumulator bounds and asserts all of the
+above with exactly the constants the kernels use.  tests/test_lazy_bounds.py runs it for both curves."""
+from math import log2
+
+BN254_P = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
+BLS12_381_P = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+CURVES = {"bn254": (BN254_P, 29, 9, 254), "bls12-381": (BLS12_381_P, 28, 14, 381)}
+
+# constants used by msm.cuh::madd29 (G1) and its Fp2 overload (G2), and by field29.cuh's Fp2 product / square
+G1 = dict(Kx=8, Ky=8, K3=4, Kq=8, Ky3=2)
+G2 = dict(Kx=16, Ky=16, K3=16, Kq=8, Ky3=8, KV=2, KS=4, KQ=8, partial_reduce=("P", "R", "PPP", "X"))
+
+
+def check(curve: str, fp2: bool, verbose=False):
+    p, L, NL, bits = CURVES[curve]
+    R = 1 << (L * NL)
+    unit = 1 << (L * (NL - 1))
+    k = G2 if fp2 else G1
+
+    def lim(v):
+        assert v < R, ("value exceeds R'", log2(v))
+        return v
+
+    def need(K, b, what):
+        assert K * p - b > unit, (what, K, log2(b), log2(K * p))
+
+    def mul1(a, b):
+        lim(a), lim(b)
+        return a * b // R + p
+
+    def pr(v):   # f29_partial_reduce
+        q = v >> bits
+        return (1 << bits) + q * ((1 << bits) - p)
+
+    if fp2:
+        def mul(a, b):
+            lim(2 * a), lim(2 * b)
+            v, s = mul1(a, b), mul1(2 * a, 2 * b)
+            need(k["KV"], v, "KV")
+            need(k["KS"], 2 * v, "KS")
+            return max(v + k["KV"] * p, s + k["KS"] * p)
+
+        def sqr(a):
+            need(k["KQ"], a, "KQ")
+            return max(mul1(lim(2 * a), a + k["KQ"] * p), 2 * mul1(a, a))
+        red = set(k["partial_reduce"])
+    else:
+        mul, red = mul1, set()
+
+        def sqr(a):
+            return mul1(a, a)
+
+    bx = by = bzz = bzzz = p                 # accumulator starts as an affine point (canonical limbs)
+    for _ in range(1000):
+        qx, qy = p, 2 * p                    # table points are canonical; a negated y is 2p - y
+        U2, S2 = mul(qx, bzz), mul(qy, bzzz)
+        need(k["Kx"], bx, "Kx")
+        need(k["Ky"], by, "Ky")
+        Pp, Rr = U2 + k["Kx"] * p, S2 + k["Ky"] * p
+        if "P" in red:
+            Pp = pr(Pp)
+        if "R" in red:
+            Rr = pr(Rr)
+        PP = sqr(Pp)
+        PPP, Q = mul(Pp, PP), mul(bx, PP)
+        if "PPP" in red:
+            PPP = pr(PPP)
+        need(k["K3"], PPP + 2 * Q, "K3")
+        X3 = sqr(Rr) + k["K3"] * p
+        if "X" in red:
+            X3 = pr(X3)
+        need(k["Kq"], X3, "Kq")
+        t = Q + k["Kq"] * p
+        need(k["Ky3"], mul(by, PPP), "Ky3")
+        Y3 = mul(Rr, t) + k["Ky3"] * p
+        ZZ3, ZZZ3 = mul(bzz, PP), mul(bzzz, PPP)
+        for v in (Pp, Rr, PP, PPP, Q, X3, t, Y3, ZZ3, ZZZ3):
+            lim(v)
+        nb = (max(bx, X3), max(by, Y3), max(bzz, ZZ3), max(bzzz, ZZZ3))
+        if nb == (bx, by, bzz, bzzz):
+            break
+        bx, by, bzz, bzzz = nb
+    else:
+        raise AssertionError("accumulator bounds do not converge")
+    out = {"X": log2(bx), "Y": log2(by), "ZZ": log2(bzz), "ZZZ": log2(bzzz), "P": log2(Pp), "R": log2(Rr), "limit": L * NL}
+    if verbose:
+        print(curve, "G2" if fp2 else "G1", {a: round(b, 2) for a, b in out.items()})
+    return out
+
+
+if __name__ == "__main__":
+    for c in CURVES:
+        for fp2 in (False, True):
+            check(c, fp2, verbose=True)
