@@ -119,18 +119,26 @@ GA_HD_BIG F29<P> f29_mul(const F29<P>& a, const F29<P>& b) {
     return r;
 }
 
-// memory image (x * 2^(32N), canonical) -> hat(x), canonical limbs
+// memory image (x * 2^(32N), canonical) -> hat(x) as an ordinary canonical 32N-bit integer (table storage format)
 template <class P>
-GA_HD F29<P> f29_from_mem(const Fe<P>& x) {
-    typedef Radix<P> R;
+GA_HD Fe<P> f29_hat_packed(const Fe<P>& x) {
     Fe<P> t = x;
 #pragma unroll
-    for (int k = 0; k < R::S; k++) t = dbl(t);   // * 2^S mod p
+    for (int k = 0; k < Radix<P>::S; k++) t = dbl(t);   // * 2^S mod p
+    return t;
+}
+// packed integer -> limbs (no arithmetic: bit-field extraction only)
+template <class P>
+GA_HD F29<P> f29_unpack(const Fe<P>& t) {
+    typedef Radix<P> R;
     F29<P> r;
 #pragma unroll
     for (int i = 0; i < R::NL; i++) r.l[i] = take_bits<P::N, R::L>(t.l, i * R::L);
     return r;
 }
+// memory image -> hat(x), canonical limbs
+template <class P>
+GA_HD F29<P> f29_from_mem(const Fe<P>& x) { return f29_unpack(f29_hat_packed(x)); }
 
 // hat(x) with any value < 2^(32N) -> canonical memory image x * 2^(32N) mod p
 template <class P>
@@ -222,6 +230,8 @@ template <class P> struct Lazy<Fe<P>> {
     static constexpr int NW = Radix<P>::NL;          // 32-bit words per coordinate
     static constexpr bool FP2 = false;
     GA_HD static T from_mem(const Fe<P>& x) { return f29_from_mem(x); }
+    GA_HD static Fe<P> hat_packed(const Fe<P>& x) { return f29_hat_packed(x); }
+    GA_HD static T unpack(const Fe<P>& x) { return f29_unpack(x); }
     GA_HD static Fe<P> to_mem(const T& x) { return f29_to_mem(x); }
     GA_HD static uint32_t word(const T& x, int i) { return x.l[i]; }
     GA_HD static void set_word(T& x, int i, uint32_t v) { x.l[i] = v; }
@@ -232,6 +242,8 @@ template <class P> struct Lazy<Fe2<P>> {
     static constexpr int NW = 2 * Radix<P>::NL;
     static constexpr bool FP2 = true;
     GA_HD static T from_mem(const Fe2<P>& x) { return {f29_from_mem(x.c0), f29_from_mem(x.c1)}; }
+    GA_HD static Fe2<P> hat_packed(const Fe2<P>& x) { return {f29_hat_packed(x.c0), f29_hat_packed(x.c1)}; }
+    GA_HD static T unpack(const Fe2<P>& x) { return {f29_unpack(x.c0), f29_unpack(x.c1)}; }
     GA_HD static Fe2<P> to_mem(const T& x) { return {f29_to_mem(x.c0), f29_to_mem(x.c1)}; }
     GA_HD static uint32_t word(const T& x, int i) { return i < Radix<P>::NL ? x.c0.l[i] : x.c1.l[i - Radix<P>::NL]; }
     GA_HD static void set_word(T& x, int i, uint32_t v) {

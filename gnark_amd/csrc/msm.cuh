@@ -253,8 +253,11 @@ msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __res
 // msm_accumulate29_redo_kernel, which repeats them with the complete formulas.
 template <class F>
 struct Table29 {
-    static constexpr int NW = Lazy<F>::NW;                 // words per coordinate
-    static constexpr int WORDS = (2 * NW + 3) / 4 * 4;     // G1: 20 / 28 words (80 / 112 B); G2: 36 / 56 words (144 / 224 B)
+    static constexpr int NW = Lazy<F>::NW;                 // 32-bit registers per coordinate once unpacked
+    // In HBM a table entry is the hat-domain point with each coordinate packed as an ordinary 32N-bit integer: 64 B
+    // (BN254 G1, half a cache line, never straddling), 128 B (BN254 G2, one line), 96 / 192 B for BLS12-381.  Storing the
+    // limbs unpacked (80 B for BN254 G1) made every third gather touch two lines: FETCH_SIZE 41 GB per 2^24 MSM.
+    static constexpr int WORDS = sizeof(Affine<F>) / 4;
     // workgroup size: the LDS-resident accumulators (4*NW words per lane) must leave room for 2 workgroups per CU
     static constexpr int THREADS = (4 * NW * 4 * 256 <= 72 * 1024) ? 256 : 128;
     static constexpr int MIN_WAVES = Lazy<F>::FP2 ? 2 : GA_ACC29_MINW;
@@ -280,22 +283,9 @@ struct LdsAcc29 {
 template <class F>
 __device__ __forceinline__ void load_point29(const uint32_t* __restrict__ table, uint32_t idx, typename Lazy<F>::T& x,
                                              typename Lazy<F>::T& y) {
-    constexpr int NW = Lazy<F>::NW, W = Table29<F>::WORDS;
-    uint32_t w[W];
-    const uint32_t* src = table + (uint64_t)idx * W;
-#pragma unroll
-    for (int q = 0; q < W / 4; q++) {
-        u32x4 v = load16(src + 4 * q);
-        w[4 * q] = v.x;
-        w[4 * q + 1] = v.y;
-        w[4 * q + 2] = v.z;
-        w[4 * q + 3] = v.w;
-    }
-#pragma unroll
-    for (int i = 0; i < NW; i++) {
-        Lazy<F>::set_word(x, i, w[i]);
-        Lazy<F>::set_word(y, i, w[NW + i]);
-    }
+    Affine<F> a = load_pod<Affine<F>>(table + (uint64_t)idx * Table29<F>::WORDS);
+    x = Lazy<F>::unpack(a.x);
+    y = Lazy<F>::unpack(a.y);
 }
 
 // acc += q in the lazy representation (madd-2008-s).  Subtraction constants and partial reductions come from the bound
@@ -428,8 +418,6 @@ msm_accumulate29_redo_kernel(const uint32_t* __restrict__ table, const uint32_t*
 template <class F>
 __global__ void __launch_bounds__(64)
 msm_table29_kernel(const Affine<F>* __restrict__ bases, uint64_t n, int c, int nwin, uint32_t* __restrict__ table) {
-    typedef typename Lazy<F>::T T;
-    constexpr int NW = Lazy<F>::NW, W = Table29<F>::WORDS;
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Affine<F> a = load_pod<Affine<F>>(&bases[i]);
@@ -440,15 +428,8 @@ msm_table29_kernel(const Affine<F>* __restrict__ bases, uint64_t n, int c, int n
             a = to_affine(p);
             p = to_xyzz(a);
         }
-        T x = Lazy<F>::from_mem(a.x), y = Lazy<F>::from_mem(a.y);
-        uint32_t* dst = table + ((uint64_t)w * n + i) * W;
-#pragma unroll
-        for (int k = 0; k < W; k++) {
-            uint32_t v = 0;
-            if (k < NW) v = Lazy<F>::word(x, k);
-            else if (k < 2 * NW) v = Lazy<F>::word(y, k - NW);
-            dst[k] = v;
-        }
+        Affine<F> h{Lazy<F>::hat_packed(a.x), Lazy<F>::hat_packed(a.y)};
+        store_pod(table + ((uint64_t)w * n + i) * Table29<F>::WORDS, h);
     }
 }
 
