@@ -646,7 +646,11 @@ template <class F>
 int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, XYZZ<F>* out) {
     const uint32_t nb = P.nb, half = P.half, seg = P.seg;
     const int nsets = P.nsets;
-    const uint32_t m_groups = half < (uint32_t)MSM_GROUP ? half : (uint32_t)MSM_GROUP;
+    // buckets per running-sum group: MSM_GROUP when there are plenty of buckets, smaller (down to 2) when a set has few so
+    // that the reduction still spreads over >= 2^15 lanes (small n, or table mode's single bucket set)
+    uint32_t m_groups = (uint32_t)MSM_GROUP;
+    while (m_groups > 2 && (uint64_t)half * nsets / m_groups < 32768) m_groups >>= 1;
+    if (m_groups > half) m_groups = half;
     const uint32_t groups_per_win = half / m_groups;
     const uint32_t total_groups = groups_per_win * nsets;
     uint32_t *hot_list, *hot_count;
