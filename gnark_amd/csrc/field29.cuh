@@ -191,6 +191,53 @@ GA_HD F29<P> f29_partial_reduce(const F29<P>& a) {
     return r;
 }
 
+// Barrett step: v - q*p with q = ((v >> (BITS-4)) * MU12) >> 12, q <= floor(v/p) <= q+2  =>  result in [0, 3p)
+// (valid for any normalized v < 2^(NL*L)); used where sums keep doubling (NTT butterflies)
+template <class P>
+GA_HD F29<P> f29_reduce_3p(const F29<P>& a) {
+    typedef Radix<P> R;
+    constexpr int SH = P::BITS - 4, TOP = R::NL - 1;
+    static_assert(SH >= R::L * TOP, "quotient estimate comes from the top limb");
+    const uint32_t q = ((a.l[TOP] >> (SH - R::L * TOP)) * P::MU12) >> 12;
+    F29<P> r;
+    uint64_t c = 0;
+    int32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < R::NL; i++) {
+        uint64_t u = (uint64_t)q * mod_limb<P>(i) + c;
+        c = u >> R::L;
+        int32_t d = (int32_t)a.l[i] - (int32_t)((uint32_t)u & R::MASK) + borrow;
+        if (i < R::NL - 1) {
+            r.l[i] = (uint32_t)d & R::MASK;
+            borrow = d >> R::L;
+        } else {
+            r.l[i] = (uint32_t)d;
+        }
+    }
+    return r;
+}
+
+// limbs (value < 3p) -> canonical packed words
+template <class P>
+GA_HD Fe<P> f29_pack_canonical(const F29<P>& v) {
+    typedef Radix<P> R;
+    uint32_t t[P::N];
+#pragma unroll
+    for (int w = 0; w < P::N; w++) {
+        const int k0 = (32 * w) / R::L, off = (32 * w) % R::L;
+        uint64_t u = (uint64_t)v.l[k0] >> off;
+        if (k0 + 1 < R::NL) u |= (uint64_t)v.l[k0 + 1] << (R::L - off);
+        if (2 * R::L - off < 32 && k0 + 2 < R::NL) u |= (uint64_t)v.l[k0 + 2] << (2 * R::L - off);
+        t[w] = (uint32_t)u;
+    }
+    reduce_once<P>(t);
+    reduce_once<P>(t);
+    Fe<P> r;
+#pragma unroll
+    for (int i = 0; i < P::N; i++) r.l[i] = t[i];
+    return r;
+}
+
 // ---- Fp2 = Fp[u]/(u^2+1) in the lazy representation ------------------------------------------------------------------
 template <class P>
 struct F29x2 {

@@ -17,6 +17,8 @@
 //     g^k for k < 2^12 and g^(k*2^12)), so OnCoset transforms cost no extra HBM pass.
 #pragma once
 #include "common.cuh"
+#include "field29.cuh"
+#include <stdlib.h>
 
 namespace ga {
 
@@ -159,15 +161,108 @@ ntt_pass_kernel(uint32_t* __restrict__ data, const uint32_t* __restrict__ tw, in
     }
 }
 
+// ---- the same pass in the lazy unpacked representation (field29.cuh) ------------------------------------------------
+// Elements stay in gnark's Montgomery form x*2^256 but as 9 limbs of 29 bits, unreduced; twiddles and scale factors are
+// tables of hat(w) = w*2^261, so  f29_mul(v, hat(w)) = v*w  is again in gnark's form -- no domain change at load/store.
+// Butterfly sums double per DIF stage and are Barrett-reduced to < 3p every third stage (subtractions add 32p); DIT adds a
+// fresh (< 3p) product per stage and needs no reduction inside a pass.  Results are made canonical once, at the store.
+template <class FrP>
+struct LdsTile29 {
+    uint32_t* base;   // [NL][tile] words: lane-consecutive elements hit consecutive banks
+    static constexpr int NL = Radix<FrP>::NL, STRIDE = 1 << NTT_LG_TILE;
+    __device__ __forceinline__ F29<FrP> get(uint32_t l) const {
+        F29<FrP> r;
+#pragma unroll
+        for (int i = 0; i < NL; i++) r.l[i] = base[i * STRIDE + l];
+        return r;
+    }
+    __device__ __forceinline__ void put(uint32_t l, const F29<FrP>& v) const {
+#pragma unroll
+        for (int i = 0; i < NL; i++) base[i * STRIDE + l] = v.l[i];
+    }
+};
+
+template <class FrP>
+__device__ __forceinline__ F29<FrP> ntt_scale_factor29(const NttScale& sc, uint64_t i, int logn) {
+    if (sc.mode == 1) {
+        Fe<FrP> f;
+#pragma unroll
+        for (int k = 0; k < 8; k++) f.l[k] = sc.cst[k];
+        return f29_unpack(f);
+    }
+    uint64_t idx = sc.bitrev ? bitrev64(i, logn) : i;
+    F29<FrP> a = f29_unpack(load_fe_plain<FrP>(sc.lo + (idx & ((1ull << sc.lo_bits) - 1)) * 8));
+    uint64_t h = idx >> sc.lo_bits;
+    if (h == 0 && logn <= sc.lo_bits) return a;
+    return f29_mul(a, f29_unpack(load_fe_plain<FrP>(sc.hi + h * 8)));   // hat(a)*hat(b)/R' = hat(a*b)
+}
+
+template <class FrP, bool DIT_>
+__global__ void __launch_bounds__(NTT_THREADS)
+ntt_pass29_kernel(uint32_t* __restrict__ data, const uint32_t* __restrict__ tw, int logn, int lg_tile, int s_lo, int K, int lc,
+                  NttScale pre, NttScale post) {
+    static_assert(FrP::N == 8, "Fr is 4x64-bit limbs on both curves");
+    __shared__ uint32_t lds[Radix<FrP>::NL << NTT_LG_TILE];
+    LdsTile29<FrP> T{lds};
+    const uint32_t tile_elems = 1u << lg_tile;
+    const uint64_t tile = blockIdx.x;
+    const uint32_t tid = threadIdx.x;
+
+    for (uint32_t l = tid; l < tile_elems; l += NTT_THREADS) {
+        uint64_t i = ntt_gidx(l, tile, lg_tile, s_lo, K, lc);
+        F29<FrP> v = f29_unpack(load_fe<FrP>(data + i * 8));
+        if (pre.mode != 0) v = f29_mul(v, ntt_scale_factor29<FrP>(pre, i, logn));
+        T.put(l, v);
+    }
+    __syncthreads();
+
+    for (int k = 0; k < K; k++) {
+        const int t = DIT_ ? k : (K - 1 - k);
+        const int lb = lc + t;
+        const int s = s_lo + t;
+        const bool reduce_sum = (k % 3) == 2;
+        for (uint32_t q = tid; q < tile_elems / 2; q += NTT_THREADS) {
+            uint32_t l0 = ((q >> lb) << (lb + 1)) | (q & ((1u << lb) - 1));
+            uint32_t l1 = l0 | (1u << lb);
+            uint64_t i0 = ntt_gidx(l0, tile, lg_tile, s_lo, K, lc);
+            uint64_t e = (i0 & ((1ull << s) - 1)) << (logn - 1 - s);
+            F29<FrP> x = T.get(l0), y = T.get(l1);
+            if (DIT_) {
+                // y*w (or y itself when w = 1) brought below 3p; x grows by < 3p per stage: < 33p after 10 stages
+                F29<FrP> m = e != 0 ? f29_mul(y, f29_unpack(load_fe_plain<FrP>(tw + e * 8))) : f29_reduce_3p(y);
+                T.put(l0, f29_add(x, m));
+                T.put(l1, f29_sub<4>(x, m));
+            } else {
+                // inputs < 24p (sums double per stage, reduced every third stage): x - y + 32p < 56p
+                F29<FrP> d = f29_sub<32>(x, y);
+                d = e != 0 ? f29_mul(d, f29_unpack(load_fe_plain<FrP>(tw + e * 8))) : f29_reduce_3p(d);
+                F29<FrP> sum = f29_add(x, y);
+                if (reduce_sum) sum = f29_reduce_3p(sum);
+                T.put(l0, sum);
+                T.put(l1, d);
+            }
+        }
+        __syncthreads();
+    }
+
+    for (uint32_t l = tid; l < tile_elems; l += NTT_THREADS) {
+        uint64_t i = ntt_gidx(l, tile, lg_tile, s_lo, K, lc);
+        F29<FrP> v = T.get(l);
+        if (post.mode != 0) v = f29_mul(v, ntt_scale_factor29<FrP>(post, i, logn));
+        store_fe(data + i * 8, f29_pack_canonical(f29_reduce_3p(v)));
+    }
+}
+
 // tw[e] = w^e for e < count, from the table of w^(2^k)
 template <class FrP>
 __global__ void ntt_twiddle_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ pow2, uint64_t count,
-                                   int nbits) {
+                                   int nbits, int hat) {
     uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= count) return;
     Fe<FrP> r = fe_one<FrP>();
     for (int k = 0; k < nbits; k++)
         if ((e >> k) & 1) r = mul(r, load_fe<FrP>(pow2 + k * 8));
+    if (hat) r = f29_hat_packed(r);   // tables for the lazy kernels hold w * 2^261
     store_fe(out + e * 8, r);
 }
 
@@ -199,7 +294,8 @@ struct Domain {
     uint32_t* d_gi_lo = nullptr;    // g^-k / n
     uint32_t* d_gi_hi = nullptr;
     uint32_t* d_gn_lo = nullptr;    // g^k / n   (computeH: coset FFT fused with the 1/n of the preceding iFFT)
-    uint32_t ninv[8];               // 1/n (Montgomery)
+    bool lazy = true;               // tables in the hat domain, ntt_pass29_kernel (GA_NTT_LAZY=0 selects the packed kernel)
+    uint32_t ninv[8];               // 1/n (Montgomery; hat-packed when lazy)
     uint32_t den[8];                // (g^n - 1)^-1 (Montgomery), prove.go:370-373
     std::vector<NttPass> passes;    // ascending stage order
 };
@@ -237,7 +333,14 @@ int ntt_run(Domain* d, uint32_t* d_data, bool inverse, bool dit, const NttScale&
         const NttScale& pre = (p == 0) ? pre_first : none;
         const NttScale& post = (p == np - 1) ? post_last : none;
         StageTimer st(ctx, dit ? "ntt_pass_dit" : "ntt_pass_dif");
-        if (dit)
+        if (d->lazy) {
+            if (dit)
+                hipLaunchKernelGGL((ntt_pass29_kernel<FrP, true>), dim3((unsigned)tiles), dim3(NTT_THREADS), 0, ctx->stream,
+                                   d_data, tw, d->logn, lg_tile, ps.s_lo, ps.K, ps.lc, pre, post);
+            else
+                hipLaunchKernelGGL((ntt_pass29_kernel<FrP, false>), dim3((unsigned)tiles), dim3(NTT_THREADS), 0, ctx->stream,
+                                   d_data, tw, d->logn, lg_tile, ps.s_lo, ps.K, ps.lc, pre, post);
+        } else if (dit)
             hipLaunchKernelGGL((ntt_pass_kernel<FrP, true>), dim3((unsigned)tiles), dim3(NTT_THREADS), 0, ctx->stream,
                                d_data, tw, d->logn, lg_tile, ps.s_lo, ps.K, ps.lc, pre, post);
         else
@@ -326,6 +429,10 @@ int domain_init(Ctx* ctx, Domain* d, int curve, uint64_t n) {
         return GA_ERR_INVALID;
     }
     d->passes = ntt_plan(d->logn);
+    {
+        const char* env = getenv("GA_NTT_LAZY");
+        d->lazy = !(env && env[0] == '0');
+    }
     // host: w = ROOT^(2^(adicity-logn)), inverse likewise; tables of w^(2^k)
     F w = fe_const<FrP>(FrP::ROOT), wi = fe_const<FrP>(FrP::ROOT_INV);
     for (int k = 0; k < FrP::ADICITY - d->logn; k++) {
@@ -338,7 +445,10 @@ int domain_init(Ctx* ctx, Domain* d, int curve, uint64_t n) {
     F half = inv(two);
     F ninv = fe_one<FrP>();
     for (int k = 0; k < d->logn; k++) ninv = mul(ninv, half);
-    memcpy(d->ninv, ninv.l, 32);
+    {
+        F nv = d->lazy ? f29_hat_packed(ninv) : ninv;   // used as a scale factor by the pass kernels
+        memcpy(d->ninv, nv.l, 32);
+    }
     // den = (g^n - 1)^-1
     F gn = g;
     for (int k = 0; k < d->logn; k++) gn = sqr(gn);
@@ -363,9 +473,9 @@ int domain_init(Ctx* ctx, Domain* d, int curve, uint64_t n) {
         GA_HIP_CHECK(hipMalloc((void**)&d->d_tw_inv, half_n * 32));
         unsigned blocks = (unsigned)((half_n + 255) / 256);
         hipLaunchKernelGGL((ntt_twiddle_kernel<FrP>), dim3(blocks), dim3(256), 0, ctx->stream, d->d_tw,
-                           (const uint32_t*)d_p2, half_n, nb);
+                           (const uint32_t*)d_p2, half_n, nb, d->lazy ? 1 : 0);
         hipLaunchKernelGGL((ntt_twiddle_kernel<FrP>), dim3(blocks), dim3(256), 0, ctx->stream, d->d_tw_inv,
-                           (const uint32_t*)d_p2 + 32 * 8, half_n, nb);
+                           (const uint32_t*)d_p2 + 32 * 8, half_n, nb, d->lazy ? 1 : 0);
         GA_KERNEL_CHECK();
         GA_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         GA_HIP_CHECK(hipFree(d_p2));
@@ -377,14 +487,16 @@ int domain_init(Ctx* ctx, Domain* d, int curve, uint64_t n) {
         std::vector<uint32_t> lo(nlo * 8), hi(nhi * 8);
         F acc = c0;
         for (uint64_t k = 0; k < nlo; k++) {
-            memcpy(&lo[k * 8], acc.l, 32);
+            F st = d->lazy ? f29_hat_packed(acc) : acc;
+            memcpy(&lo[k * 8], st.l, 32);
             acc = mul(acc, base);
         }
         F step = base;
         for (int k = 0; k < NTT_POW_LO_BITS; k++) step = sqr(step);
         acc = fe_one<FrP>();
         for (uint64_t k = 0; k < nhi; k++) {
-            memcpy(&hi[k * 8], acc.l, 32);
+            F st = d->lazy ? f29_hat_packed(acc) : acc;
+            memcpy(&hi[k * 8], st.l, 32);
             acc = mul(acc, step);
         }
         GA_HIP_CHECK(hipMalloc((void**)dlo, nlo * 32));
