@@ -163,6 +163,7 @@ int ga_ctx_create(int device, ga_ctx** out) {
     c->device = device;
     GA_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     GA_HIP_CHECK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    GA_HIP_CHECK(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
     *out = reinterpret_cast<ga_ctx*>(c);
     return GA_OK;
 }
@@ -179,6 +180,7 @@ void ga_ctx_destroy(ga_ctx* h) {
     }
     hipStreamDestroy(c->stream);
     hipStreamDestroy(c->copy_stream);
+    hipStreamDestroy(c->aux_stream);
     delete c;
 }
 

@@ -81,6 +81,7 @@ struct Ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;   // uploads that overlap kernels (groth16.hip)
+    hipStream_t aux_stream = nullptr;    // digit/sort preparation of the NEXT MSM while the current one accumulates
     std::mutex mu;
     bool profiling = false;
     std::vector<StageRec> stages;
@@ -94,17 +95,18 @@ struct Ctx {
 struct StageTimer {
     Ctx* ctx;
     int idx = -1;
-    StageTimer(Ctx* c, const char* name) : ctx(c) {
+    hipStream_t st;
+    StageTimer(Ctx* c, const char* name, hipStream_t stream = nullptr) : ctx(c), st(stream ? stream : c->stream) {
         if (!c->profiling) return;
         StageRec r;
         r.name = name;
         if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
-        hipEventRecord(r.a, c->stream);
+        hipEventRecord(r.a, st);
         c->stages.push_back(r);
         idx = (int)c->stages.size() - 1;
     }
     ~StageTimer() {
-        if (idx >= 0) hipEventRecord(ctx->stages[idx].b, ctx->stream);
+        if (idx >= 0) hipEventRecord(ctx->stages[idx].b, st);
     }
 };
 
@@ -151,8 +153,11 @@ template <class C, int G>
 size_t msm_table_point_bytes();
 template <class C, int G>
 int msm_table_device(Ctx* ctx, const void* d_table, const void* d_scalars, size_t n, bool scalars_mont, int c, void* h_sum);
+// slot 0/1 selects one of two scratch sets; on_aux runs the preparation on ctx->aux_stream (the caller orders it against
+// the main stream with events) so that it overlaps the previous MSM's (ALU-bound) bucket accumulation
 template <class C>
-int msm_prepare_table_scalars(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, int c, MsmPrepared* P);
+int msm_prepare_table_scalars(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, int c, MsmPrepared* P, int slot = 0,
+                              bool on_aux = false);
 template <class C, int G>
 int msm_table_device_reuse(Ctx* ctx, const void* d_table, const MsmPrepared& P, void* h_sum);
 

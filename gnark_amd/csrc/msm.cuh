@@ -22,6 +22,8 @@
 #pragma once
 #include <hipcub/hipcub.hpp>
 
+#include <string>
+
 #include "common.cuh"
 #include "field29.cuh"
 
@@ -529,7 +531,10 @@ msm_segment_sum_kernel(const XYZZ<F>* __restrict__ in, uint32_t seg_len, XYZZ<F>
 
 template <class FrP>
 int msm_prepare(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, int c, int win_lo, int win_hi, bool table,
-                MsmPrepared* P) {
+                MsmPrepared* P, int slot = 0, hipStream_t st = nullptr) {
+    if (!st) st = ctx->stream;
+    const std::string sfx = slot ? "#1" : "";
+    auto key = [&](const char* k) { return std::string(k) + sfx; };
     const int nwin = FrP::BITS / c + 1;
     if (win_hi < 0) win_hi = nwin;
     if (win_lo < 0 || win_hi > nwin || win_lo >= win_hi || c < 2 || c > 24 || (table && (win_lo != 0 || win_hi != nwin))) {
@@ -563,43 +568,42 @@ int msm_prepare(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, in
 
     uint32_t *keys, *vals, *keys2, *vals2, *off, *ntask, *task_off, *task_start, *task_key, *task_key2, *task_id, *task_perm;
     void* tmp;
-    GA_CHECK(ctx->scratch_get("msm_keys", m * 4, (void**)&keys));
-    GA_CHECK(ctx->scratch_get("msm_vals", m * 4, (void**)&vals));
-    GA_CHECK(ctx->scratch_get("msm_keys2", m * 4, (void**)&keys2));
-    GA_CHECK(ctx->scratch_get("msm_vals2", m * 4, (void**)&vals2));
-    GA_CHECK(ctx->scratch_get("msm_off", ((uint64_t)nb + 2) * 4, (void**)&off));
-    GA_CHECK(ctx->scratch_get("msm_ntask", ((uint64_t)nb + 2) * 4, (void**)&ntask));
-    GA_CHECK(ctx->scratch_get("msm_task_off", ((uint64_t)nb + 2) * 4, (void**)&task_off));
-    GA_CHECK(ctx->scratch_get("msm_task_start", max_tasks * 4, (void**)&task_start));
-    GA_CHECK(ctx->scratch_get("msm_task_key", max_tasks * 4, (void**)&task_key));
-    GA_CHECK(ctx->scratch_get("msm_task_key2", max_tasks * 4, (void**)&task_key2));
-    GA_CHECK(ctx->scratch_get("msm_task_id", max_tasks * 4, (void**)&task_id));
-    GA_CHECK(ctx->scratch_get("msm_task_perm", max_tasks * 4, (void**)&task_perm));
+    GA_CHECK(ctx->scratch_get(key("msm_keys").c_str(), m * 4, (void**)&keys));
+    GA_CHECK(ctx->scratch_get(key("msm_vals").c_str(), m * 4, (void**)&vals));
+    GA_CHECK(ctx->scratch_get(key("msm_keys2").c_str(), m * 4, (void**)&keys2));
+    GA_CHECK(ctx->scratch_get(key("msm_vals2").c_str(), m * 4, (void**)&vals2));
+    GA_CHECK(ctx->scratch_get(key("msm_off").c_str(), ((uint64_t)nb + 2) * 4, (void**)&off));
+    GA_CHECK(ctx->scratch_get(key("msm_ntask").c_str(), ((uint64_t)nb + 2) * 4, (void**)&ntask));
+    GA_CHECK(ctx->scratch_get(key("msm_task_off").c_str(), ((uint64_t)nb + 2) * 4, (void**)&task_off));
+    GA_CHECK(ctx->scratch_get(key("msm_task_start").c_str(), max_tasks * 4, (void**)&task_start));
+    GA_CHECK(ctx->scratch_get(key("msm_task_key").c_str(), max_tasks * 4, (void**)&task_key));
+    GA_CHECK(ctx->scratch_get(key("msm_task_key2").c_str(), max_tasks * 4, (void**)&task_key2));
+    GA_CHECK(ctx->scratch_get(key("msm_task_id").c_str(), max_tasks * 4, (void**)&task_id));
+    GA_CHECK(ctx->scratch_get(key("msm_task_perm").c_str(), max_tasks * 4, (void**)&task_perm));
 
-    hipStream_t st = ctx->stream;
     {
-        StageTimer tm(ctx, "msm_digits");
+        StageTimer tm(ctx, "msm_digits", st);
         hipLaunchKernelGGL((msm_digits_kernel<FrP>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint32_t*)d_scalars,
                            (uint64_t)n, scalars_mont ? 1 : 0, c, nwin, win_lo, win_hi, table ? 1 : 0, keys, vals);
         GA_KERNEL_CHECK();
     }
     {
-        StageTimer tm(ctx, "msm_sort");
+        StageTimer tm(ctx, "msm_sort", st);
         int end_bit = 1;
         while ((1ull << end_bit) <= nb64) end_bit++;   // keys take values 0..nb (nb = SKIP)
         size_t tmp_bytes = 0;
         GA_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, (unsigned)m, 0, end_bit, st));
-        GA_CHECK(ctx->scratch_get("msm_sort_tmp", tmp_bytes + 256, &tmp));
+        GA_CHECK(ctx->scratch_get(key("msm_sort_tmp").c_str(), tmp_bytes + 256, &tmp));
         GA_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys2, vals, vals2, (unsigned)m, 0, end_bit, st));
     }
     {
-        StageTimer tm(ctx, "msm_tasks");
+        StageTimer tm(ctx, "msm_tasks", st);
         hipLaunchKernelGGL(msm_offsets_kernel, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, (const uint32_t*)keys2, m, nb, off);
         hipLaunchKernelGGL(msm_tasks_kernel, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, (const uint32_t*)off, nb, seg, ntask);
         GA_KERNEL_CHECK();
         size_t tmp_bytes = 0;
         GA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, ntask, task_off, (int)(nb + 1), st));
-        GA_CHECK(ctx->scratch_get("msm_scan_tmp", tmp_bytes + 256, &tmp));
+        GA_CHECK(ctx->scratch_get(key("msm_scan_tmp").c_str(), tmp_bytes + 256, &tmp));
         GA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, ntask, task_off, (int)(nb + 1), st));
         // explicit task list, ordered by decreasing length (padding slots keep key = 0xFFFFFFFF >= seg)
         GA_HIP_CHECK(hipMemsetAsync(task_key, 0xFF, max_tasks * 4, st));
@@ -612,7 +616,7 @@ int msm_prepare(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, in
         // padding keys are all-ones: sort on kbits+1 bits so that they stay behind every real key (real keys < seg)
         size_t tb = 0;
         GA_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, task_key, task_key2, task_id, task_perm, (unsigned)max_tasks, 0, kbits + 1, st));
-        GA_CHECK(ctx->scratch_get("msm_tasksort_tmp", tb + 256, &tmp));
+        GA_CHECK(ctx->scratch_get(key("msm_tasksort_tmp").c_str(), tb + 256, &tmp));
         GA_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp, tb, task_key, task_key2, task_id, task_perm, (unsigned)max_tasks, 0, kbits + 1, st));
     }
     P->n = n;
@@ -754,8 +758,9 @@ int msm_table_device_reuse(Ctx* ctx, const void* d_table, const MsmPrepared& P, 
 
 // group-independent preparation callable from translation units that do not include this header (groth16.hip)
 template <class C>
-int msm_prepare_table_scalars(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, int c, MsmPrepared* P) {
-    return msm_prepare<typename C::FrP>(ctx, d_scalars, n, scalars_mont, c, 0, -1, true, P);
+int msm_prepare_table_scalars(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, int c, MsmPrepared* P, int slot,
+                              bool on_aux) {
+    return msm_prepare<typename C::FrP>(ctx, d_scalars, n, scalars_mont, c, 0, -1, true, P, slot, on_aux ? ctx->aux_stream : ctx->stream);
 }
 
 template <class C, int G>
