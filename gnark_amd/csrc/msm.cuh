@@ -359,7 +359,11 @@ msm_accumulate29_kernel(const uint32_t* __restrict__ table, const uint32_t* __re
         const uint32_t vn = p + 1 < end ? vals[p + 1] : v;
         T qx, qy;
         load_point29<F>(table, v & ~MSM_SIGN, qx, qy);
+#ifndef GA_NO_TOUCH
         const uint32_t touch = *reinterpret_cast<const volatile uint32_t*>(table + (uint64_t)(vn & ~MSM_SIGN) * Table29<F>::WORDS);
+#else
+        const uint32_t touch = 0;
+#endif
         if (!(f29_is_zero_limbs(qx) & f29_is_zero_limbs(qy))) {   // (0,0) = infinity: skip
             if (v & MSM_SIGN) qy = f29_sub<2>(Lazy<F>::from_mem(FieldTraits<F>::zero()), qy);   // 2p - y
             if (!have) {
