@@ -196,7 +196,7 @@ def main():
                        "curve": args.curve, "window_bits": cbits, "windows": nwin,
                        "precompute": ("[2^(c*w)]P tables for all %d windows, %.1f GiB, one shared bucket set" % (nwin, ti["table_bytes"] / 2**30)) if use_table else "none",
                        "parallelism": "1 GPU" if world == 1 else "base-range sharding x%d, RCCL all_gather of Jacobian partials" % world},
-            "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "msm_accumulate29_kernel" if use_table else "msm_accumulate_kernel", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 6), "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": acc["avg_ms"],
                          "note": "MSM is integer-multiplier bound (SURVEY 8d): ~2.4e4 32-bit MADs per scalar-mul vs 96 B"},

@@ -291,3 +291,39 @@ def test_kzg_ceremony_relations_on_device(gpu_ctx):
     lhs = aff(ecc.MultiExp(gpu_ctx, c.name, 0, M, p))
     rhs = aff(ecc.MultiExp(gpu_ctx, c.name, 0, L, ev_bitrev[idx]))
     assert np.array_equal(lhs, rhs) and lhs.any()
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_kzg_commit_shape_plonk(gpu_ctx, c):
+    """PLONK's kzg.Commit (backend/plonk/bn254/prove.go:438-476,532,1267-1277) is MultiExp(pk.G1[:len(p)], p) over the
+    monomial SRS [tau^i]G (test/unsafekzg/kzgsrs.go:186-200): with a known tau the commitment must equal [p(tau)]G.
+    Also exercises ToLagrange/ToCanonical round trips through the pinned-SRS table path."""
+    n = 1 << 12
+    rng = pyref.Xoshiro(0x5125)
+    tau = rng.field(c.r)
+    # SRS on the host via the oracle (known discrete logs tau^i); committed polynomial p
+    pw = [pow(tau, i, c.r) for i in range(n)]
+    srs = np.stack([oracle.jac_to_affine(c.cid, 0, oracle.generator_mul(c.cid, 0, k)) for k in pw])
+    p = [rng.field(c.r) for _ in range(n)]
+    P = fr_to_arr(c, p)
+    want = oracle.jac_to_affine(c.cid, 0, oracle.generator_mul(c.cid, 0, sum(a * b for a, b in zip(p, pw)) % c.r))
+    table = ecc.PrecomputedBases(gpu_ctx, c.name, 0, srs)
+    try:
+        assert np.array_equal(oracle.jac_to_affine(c.cid, 0, table.MultiExp(P)), want)
+        assert np.array_equal(oracle.jac_to_affine(c.cid, 0, ecc.MultiExp(gpu_ctx, c.name, 0, srs, P)), want)
+        # Lagrange-basis commitment: Commit_lagrange(NTT(p)) == Commit(p) with the Lagrange SRS [L_i(tau)]G
+        w = c.fr_root_of_unity(n)
+        ninv = pow(n, -1, c.r)
+        tn1 = (pow(tau, n, c.r) - 1) % c.r
+        lag = [tn1 * pow(w, i, c.r) % c.r * ninv % c.r * pow((tau - pow(w, i, c.r)) % c.r, -1, c.r) % c.r for i in range(n)]
+        srs_l = np.stack([oracle.jac_to_affine(c.cid, 0, oracle.generator_mul(c.cid, 0, k)) for k in lag])
+        d = fft.Domain(gpu_ctx, c.name, n)
+        ev = d.FFT(P, fft.DIF)                                            # bit-reversed evaluations
+        idx = np.array([pyref.bitrev(i, 12) for i in range(n)])
+        got = oracle.jac_to_affine(c.cid, 0, ecc.MultiExp(gpu_ctx, c.name, 0, srs_l, ev[idx]))
+        assert np.array_equal(got, want)
+        back = d.FFTInverse(ev, fft.DIT)                                  # ToCanonical
+        assert np.array_equal(back, P)
+        d.close()
+    finally:
+        table.free()
