@@ -249,7 +249,7 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle
         cores = os.cpu_count() or 1
-        sample_log = min(args.log_n, 23)
+        sample_log = min(args.log_n, 24)
         sn = 1 << sample_log
         ks = (np.arange(sn, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(12345)) | np.uint64(1)
         sb = ctx.malloc(sn * words_aff * 8)

@@ -327,3 +327,17 @@ def test_kzg_commit_shape_plonk(gpu_ctx, c):
         d.close()
     finally:
         table.free()
+
+
+def test_plain_c_client_of_the_abi(tmp_path):
+    """include/gnark_amd.h is a genuine C ABI: a C99 program (what cgo compiles) links libgnark_amd.so and runs an MSM
+    (raw bases and precomputed table) + NTT round trip without Python, torch or C++ in the client."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "abi_client")
+    lib = os.path.join(root, "gnark_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c_abi", "abi_client.c"),
+                           "-L", lib, "-lgnark_amd", "-Wl,-rpath," + lib, "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ABI_CLIENT_OK" in r.stdout, r.stdout + r.stderr
