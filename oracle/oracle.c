@@ -622,6 +622,18 @@ int oracle_fr_mul(int curve, const u64* a, const u64* b, size_t n, u64* out) {
     return 0;
 }
 
+/* p(x) by Horner; coefficients and x in Montgomery form, result Montgomery */
+int oracle_fr_horner(int curve, const u64* coeffs, size_t n, const u64* x, u64* out) {
+    const field_t* f = &CURVES[curve].fr;
+    u64 acc[4] = {0};
+    for (size_t i = n; i-- > 0;) {
+        fe_mul(f, acc, acc, x);
+        fe_add(f, acc, acc, coeffs + 4 * i);
+    }
+    memcpy(out, acc, 32);
+    return 0;
+}
+
 /* ---------------- NTT (fft.Domain conventions) ------------------------------------------------------------- */
 static int ilog2(u64 n) {
     int l = 0;

@@ -118,6 +118,13 @@ def fr_mul(curve, a, b):
     return out
 
 
+def fr_horner(curve, coeffs_mont, x_mont):
+    c, x = _u64(coeffs_mont).reshape(-1, 4), _u64(x_mont).reshape(4)
+    out = np.zeros(4, dtype=np.uint64)
+    dll().oracle_fr_horner(curve, _p(c), C.c_size_t(c.shape[0]), _p(x), _p(out))
+    return out
+
+
 def fft(curve, a, direction, decimation, on_coset):
     out = _u64(a).reshape(-1, 4).copy()
     rc = dll().oracle_fft(curve, _p(out), C.c_uint64(out.shape[0]), direction, decimation, int(on_coset))

@@ -341,3 +341,34 @@ def test_plain_c_client_of_the_abi(tmp_path):
                            "-L", lib, "-lgnark_amd", "-Wl,-rpath," + lib, "-o", exe])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ABI_CLIENT_OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_compute_h_2_20_polynomial_identity(gpu_ctx):
+    """size-independent property of computeH at 2^20: A(x)B(x) - C(x) == H(x)(x^n - 1) at a random point, with A, B, C
+    interpolated by the CPU oracle and H (bit-reversed coefficients, deg <= n-2) from the device."""
+    c = BN254
+    n = 1 << 20
+    m = n - 12345
+    buf = gpu_ctx.malloc(3 * n * 32)
+    gpu_ctx.lib.check(gpu_ctx.lib.ga_gen_scalars(gpu_ctx.handle, c.cid, 4242, 3 * n, buf.ptr))
+    v = buf.to_host((3 * n, 4))
+    buf.free()
+    A, B = v[:m], v[n:n + m]
+    Cc = oracle.fr_mul(c.cid, A, B)
+    d = fft.Domain(gpu_ctx, c.name, m)
+    assert d.Cardinality == n
+    h_bitrev = d.compute_h(A, B, Cc)
+    d.close()
+    idx = np.arange(n, dtype=np.uint64)
+    rev = np.zeros(n, dtype=np.int64)
+    for b in range(20):
+        rev |= (((idx >> np.uint64(b)) & np.uint64(1)).astype(np.int64)) << (19 - b)
+    h = h_bitrev[rev]                                   # natural coefficient order
+    assert not h[n - 1].any()                           # deg H <= n-2 (setup.go:247-249)
+    pad = lambda x: np.concatenate([x, np.zeros((n - x.shape[0], 4), np.uint64)])
+    coef = lambda ev: oracle.fft(c.cid, pad(ev), 1, 0, False)[rev]     # iFFT (DIF -> bit-reversed) -> natural order
+    xv = 0x1234567890ABCDEF1234567890ABCDEF % c.r
+    x = fr_to_arr(c, [xv])[0]
+    ev = lambda co: pyref.from_mont_limbs(oracle.fr_horner(c.cid, co, x), c.r)
+    lhs = (ev(coef(A)) * ev(coef(B)) - ev(coef(Cc))) % c.r
+    assert lhs == ev(h) * (pow(xv, n, c.r) - 1) % c.r
