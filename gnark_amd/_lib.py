@@ -38,6 +38,7 @@ class G16Key(C.Structure):
         ("infinity_a", C.c_void_p), ("infinity_b", C.c_void_p),
         ("nb_wires", C.c_uint64), ("nb_infinity_a", C.c_uint64), ("nb_infinity_b", C.c_uint64),
         ("precompute", C.c_int32),
+        ("shard_index", C.c_uint32), ("shard_count", C.c_uint32),
     ]
 
 
@@ -73,6 +74,8 @@ _PROTOS = {
     "ga_g16_pk_create": (C.c_int, [_P, C.POINTER(G16Key), C.POINTER(_P)]),
     "ga_g16_pk_destroy": (None, [_P]),
     "ga_g16_prove": (C.c_int, [_P, _P, _P, _P, _P, C.c_uint64, C.c_uint64, _P, _P, _P]),
+    "ga_g16_prove_partial": (C.c_int, [_P, _P, _P, _P, _P, C.c_uint64, C.c_uint64, _P]),
+    "ga_g16_finish": (C.c_int, [_P, _P, _P, _P, _P]),
     "ga_g16_proof_marshal": (C.c_int, [C.c_int, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "ga_profile_enable": (C.c_int, [_P, C.c_int]),
     "ga_profile_reset": (C.c_int, [_P]),

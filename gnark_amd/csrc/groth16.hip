@@ -24,6 +24,9 @@ struct G16Pk {
     // precomputed window-multiple tables (msm.cuh): d_a.. then point to windows x len points and c_* is the window width
     bool tables = false;
     int c_a = 0, c_b = 0, c_z = 0, c_k = 0;
+    // multi-GPU partition B: this key holds slice [off, off+len) of every base vector (ga_g16_key.shard_index/count)
+    uint32_t shard_index = 0, shard_count = 1;
+    uint64_t off_k = 0, off_z = 0, full_len_k = 0;
     std::vector<uint8_t> alpha1, beta1, delta1, beta2, delta2;   // affine images (host)
 };
 
@@ -71,17 +74,33 @@ static int pk_create(Ctx* ctx, const ga_g16_key* key, G16Pk** out) {
     pk->curve = C::ID;
     pk->n = key->domain_cardinality;
     pk->nb_wires = key->nb_wires;
-    pk->len_a = key->len_a;
-    pk->len_b = key->len_b;
-    pk->len_z = key->len_z;
-    pk->len_k = key->len_k;
-    pk->len_b2 = key->len_b2;
+    pk->shard_count = key->shard_count ? key->shard_count : 1;
+    pk->shard_index = key->shard_index;
+    if (pk->shard_index >= pk->shard_count) {
+        set_error("proving key: shard_index %u >= shard_count %u", pk->shard_index, pk->shard_count);
+        delete pk;
+        return GA_ERR_INVALID;
+    }
+    auto slice = [&](uint64_t len, uint64_t* lo, uint64_t* cnt) {   // same split as gnark_amd/multigpu.py shard_range
+        uint64_t base = len / pk->shard_count, rem = len % pk->shard_count, k = pk->shard_index;
+        *lo = k * base + (k < rem ? k : rem);
+        *cnt = base + (k < rem ? 1 : 0);
+    };
+    uint64_t lo_a, lo_b, lo_z, lo_k;
+    slice(key->len_a, &lo_a, &pk->len_a);
+    slice(key->len_b, &lo_b, &pk->len_b);
+    slice(key->len_z, &lo_z, &pk->len_z);
+    slice(key->len_k, &lo_k, &pk->len_k);
+    pk->len_b2 = pk->len_b;
+    pk->off_k = lo_k;
+    pk->off_z = lo_z;
+    pk->full_len_k = key->len_k;
     int rc = ntt_domain_new<C>(ctx, pk->n, &pk->dom);
-    if (rc == GA_OK) rc = upload(ctx, key->g1_a, key->len_a * s1, &pk->d_a);
-    if (rc == GA_OK) rc = upload(ctx, key->g1_b, key->len_b * s1, &pk->d_b);
-    if (rc == GA_OK) rc = upload(ctx, key->g1_z, key->len_z * s1, &pk->d_z);
-    if (rc == GA_OK) rc = upload(ctx, key->g1_k, key->len_k * s1, &pk->d_k);
-    if (rc == GA_OK) rc = upload(ctx, key->g2_b, key->len_b2 * s2, &pk->d_b2);
+    if (rc == GA_OK) rc = upload(ctx, (const char*)key->g1_a + lo_a * s1, pk->len_a * s1, &pk->d_a);
+    if (rc == GA_OK) rc = upload(ctx, (const char*)key->g1_b + lo_b * s1, pk->len_b * s1, &pk->d_b);
+    if (rc == GA_OK) rc = upload(ctx, (const char*)key->g1_z + lo_z * s1, pk->len_z * s1, &pk->d_z);
+    if (rc == GA_OK) rc = upload(ctx, (const char*)key->g1_k + lo_k * s1, pk->len_k * s1, &pk->d_k);
+    if (rc == GA_OK) rc = upload(ctx, (const char*)key->g2_b + lo_b * s2, pk->len_b2 * s2, &pk->d_b2);
     std::vector<uint32_t> ia, ib;
     if (rc == GA_OK) {
         ia.reserve(key->len_a);
@@ -95,8 +114,8 @@ static int pk_create(Ctx* ctx, const ga_g16_key* key, G16Pk** out) {
             rc = GA_ERR_INVALID;
         }
     }
-    if (rc == GA_OK) rc = upload(ctx, ia.data(), ia.size() * 4, (void**)&pk->d_idx_a);
-    if (rc == GA_OK) rc = upload(ctx, ib.data(), ib.size() * 4, (void**)&pk->d_idx_b);
+    if (rc == GA_OK) rc = upload(ctx, ia.data() + lo_a, pk->len_a * 4, (void**)&pk->d_idx_a);
+    if (rc == GA_OK) rc = upload(ctx, ib.data() + lo_b, pk->len_b * 4, (void**)&pk->d_idx_b);
     if (rc == GA_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) {   // no host pointer survives this call
         set_error("proving key upload: stream synchronize failed");
         rc = GA_ERR_HIP;
@@ -156,15 +175,17 @@ static int pk_create(Ctx* ctx, const ga_g16_key* key, G16Pk** out) {
     return GA_OK;
 }
 
+// The device part of a proof on this key's shard: computeH + the five MSMs over the pinned slices.
+// Outputs (before randomisation): A-sum, B1-sum, K-sum + Z-sum (G1), B2-sum (G2) -- to be added across shards.
 template <class C>
-static int prove(G16Pk* pk, const void* w, const void* a, const void* b, const void* c, uint64_t n_constraints,
-                 uint64_t nb_public, const void* r_mont, const void* s_mont, void* proof_out) {
-    typedef typename C::FrP FrP;
+static int prove_partial(G16Pk* pk, const void* w, const void* a, const void* b, const void* c, uint64_t n_constraints,
+                         uint64_t nb_public, XYZZ<Fe<typename C::FpP>>* o_ar, XYZZ<Fe<typename C::FpP>>* o_bs1,
+                         XYZZ<Fe<typename C::FpP>>* o_krs, XYZZ<Fe2<typename C::FpP>>* o_bs2) {
     typedef Fe<typename C::FpP> F1;
     typedef Fe2<typename C::FpP> F2;
     Ctx* ctx = pk->ctx;
     const uint64_t n = pk->n;
-    if (n_constraints > n || nb_public > pk->nb_wires || pk->nb_wires - nb_public != pk->len_k) {
+    if (n_constraints > n || nb_public > pk->nb_wires || pk->nb_wires - nb_public != pk->full_len_k) {
         set_error("prove: inconsistent sizes (constraints %llu > n %llu, or nbWires-nbPublic != len(K))",
                   (unsigned long long)n_constraints, (unsigned long long)n);
         return GA_ERR_INVALID;
@@ -235,12 +256,12 @@ static int prove(G16Pk* pk, const void* w, const void* a, const void* b, const v
         GA_CHECK(table_msm_g1(pk->d_b, d_wb, pk->len_b, pk->c_b, &bs1));
         if (pk->len_b2) GA_CHECK((msm_table_device_reuse<C, GA_G2>(ctx, pk->d_b2, prep, &bs2)));   // same scalars wB: digits/sort shared
         else bs2 = xyzz_inf<F2>();
-        GA_CHECK(table_msm_g1(pk->d_k, (const char*)d_w + nb_public * 32, pk->len_k, pk->c_k, &krs));
+        GA_CHECK(table_msm_g1(pk->d_k, (const char*)d_w + (nb_public + pk->off_k) * 32, pk->len_k, pk->c_k, &krs));
     } else {
         GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_a, d_wa, pk->len_a, true, &ar)));
         GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_b, d_wb, pk->len_b, true, &bs1)));
         GA_CHECK((host_msm<C, GA_G2>(ctx, pk->d_b2, d_wb, pk->len_b2, true, &bs2)));
-        GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_k, (const char*)d_w + nb_public * 32, pk->len_k, true, &krs)));
+        GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_k, (const char*)d_w + (nb_public + pk->off_k) * 32, pk->len_k, true, &krs)));
     }
     // ---- H (prove.go:134,346-389), then the MSM over pk.G1.Z (prove.go:225-227) ----------------------------
     uploader.join();
@@ -251,11 +272,25 @@ static int prove(G16Pk* pk, const void* w, const void* a, const void* b, const v
     }
     GA_HIP_CHECK(hipStreamWaitEvent(st, ev_abc, 0));
     GA_CHECK(ntt_domain_compute_h<C>(pk->dom, d_ha, d_hb, d_hc));   // h in d_ha, bit-reversed like pk.G1.Z
-    if (pk->tables) GA_CHECK(table_msm_g1(pk->d_z, d_ha, pk->len_z, pk->c_z, &krs2));   // h[:n-1]
-    else GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_z, d_ha, pk->len_z, true, &krs2)));
+    const void* d_hz = (const char*)d_ha + pk->off_z * 32;   // this shard's slice of h[:n-1]
+    if (pk->tables) GA_CHECK(table_msm_g1(pk->d_z, d_hz, pk->len_z, pk->c_z, &krs2));
+    else GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_z, d_hz, pk->len_z, true, &krs2)));
     hipEventDestroy(ev_abc);
-    // ---- epilogue on the host (prove.go:171-185,199-200,212-214,241-269,287-292) ----------------------------
-    StageTimer tm(ctx, "g16_epilogue_host");
+    *o_ar = ar;
+    *o_bs1 = bs1;
+    *o_krs = add(krs, krs2);
+    *o_bs2 = bs2;
+    return GA_OK;
+}
+
+// Host epilogue with the prover's randomness (prove.go:171-185,199-200,212-214,241-269,287-292) on the SUMMED partials.
+template <class C>
+static int finish(G16Pk* pk, XYZZ<Fe<typename C::FpP>> ar, XYZZ<Fe<typename C::FpP>> bs1, XYZZ<Fe<typename C::FpP>> krs,
+                  XYZZ<Fe2<typename C::FpP>> bs2, const void* r_mont, const void* s_mont, void* proof_out) {
+    typedef typename C::FrP FrP;
+    typedef Fe<typename C::FpP> F1;
+    typedef Fe2<typename C::FpP> F2;
+    StageTimer tm(pk->ctx, "g16_epilogue_host");
     Fe<FrP> r, s;
     memcpy(r.l, r_mont, 32);
     memcpy(s.l, s_mont, 32);
@@ -266,7 +301,6 @@ static int prove(G16Pk* pk, const void* w, const void* a, const void* b, const v
     bs1 = add(add(bs1, host_load_affine<F1>(pk->beta1.data())), d_s);
     ar = add(add(ar, host_load_affine<F1>(pk->alpha1.data())), d_r);
     krs = add(krs, d_kr);
-    krs = add(krs, krs2);
     krs = add(krs, scalar_mul(ar, sc.l, 8));
     krs = add(krs, scalar_mul(bs1, rc.l, 8));
     XYZZ<F2> delta2 = host_load_affine<F2>(pk->delta2.data());
@@ -402,7 +436,56 @@ int ga_g16_prove(ga_g16_pk* p, const void* w, const void* a, const void* b, cons
     }
     std::lock_guard<std::mutex> g(pk->ctx->mu);
     hipSetDevice(pk->ctx->device);
-    GA_DISPATCH_CURVE(pk->curve, return prove<C>(pk, w, a, b, c, n_constraints, nb_public, r, s, proof_out));
+    if (pk->shard_count != 1) {
+        set_error("ga_g16_prove: this key holds shard %u of %u; use ga_g16_prove_partial + ga_g16_finish", pk->shard_index, pk->shard_count);
+        return GA_ERR_STATE;
+    }
+    GA_DISPATCH_CURVE(pk->curve, {
+        XYZZ<Fe<typename C::FpP>> ar, bs1, krs;
+        XYZZ<Fe2<typename C::FpP>> bs2;
+        GA_CHECK(prove_partial<C>(pk, w, a, b, c, n_constraints, nb_public, &ar, &bs1, &krs, &bs2));
+        return finish<C>(pk, ar, bs1, krs, bs2, r, s, proof_out);
+    });
+    return GA_OK;
+}
+
+int ga_g16_prove_partial(ga_g16_pk* p, const void* w, const void* a, const void* b, const void* c, uint64_t n_constraints,
+                         uint64_t nb_public, void* partials_out) {
+    G16Pk* pk = reinterpret_cast<G16Pk*>(p);
+    if (!pk || !w || !a || !b || !c || !partials_out) {
+        set_error("ga_g16_prove_partial: null argument");
+        return GA_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> g(pk->ctx->mu);
+    hipSetDevice(pk->ctx->device);
+    GA_DISPATCH_CURVE(pk->curve, {
+        typedef Fe<typename C::FpP> F1;
+        typedef Fe2<typename C::FpP> F2;
+        XYZZ<F1> ar, bs1, krs;
+        XYZZ<F2> bs2;
+        GA_CHECK(prove_partial<C>(pk, w, a, b, c, n_constraints, nb_public, &ar, &bs1, &krs, &bs2));
+        char* o = reinterpret_cast<char*>(partials_out);
+        host_store_jac<F1>(o, ar);
+        host_store_jac<F1>(o + sizeof(Jac<F1>), bs1);
+        host_store_jac<F1>(o + 2 * sizeof(Jac<F1>), krs);
+        host_store_jac<F2>(o + 3 * sizeof(Jac<F1>), bs2);
+    });
+    return GA_OK;
+}
+
+int ga_g16_finish(ga_g16_pk* p, const void* partials_sum, const void* r, const void* s, void* proof_out) {
+    G16Pk* pk = reinterpret_cast<G16Pk*>(p);
+    if (!pk || !partials_sum || !r || !s || !proof_out) {
+        set_error("ga_g16_finish: null argument");
+        return GA_ERR_INVALID;
+    }
+    GA_DISPATCH_CURVE(pk->curve, {
+        typedef Fe<typename C::FpP> F1;
+        typedef Fe2<typename C::FpP> F2;
+        const char* i = reinterpret_cast<const char*>(partials_sum);
+        return finish<C>(pk, host_load_jac<F1>(i), host_load_jac<F1>(i + sizeof(Jac<F1>)), host_load_jac<F1>(i + 2 * sizeof(Jac<F1>)),
+                         host_load_jac<F2>(i + 3 * sizeof(Jac<F1>)), r, s, proof_out);
+    });
     return GA_OK;
 }
 

@@ -48,7 +48,7 @@ class ProvingKey:
     """setup.go:25-48 fields, uploaded once ("PinToGPU"); free with FreeGPUResources() (icicle.go:1493)."""
 
     def __init__(self, ctx: Context, curve, *, domain_cardinality, alpha1, beta1, delta1, A, B, Z, K, beta2, delta2, B2,
-                 infinityA, infinityB, precompute: int = 0):
+                 infinityA, infinityB, precompute: int = 0, shard=(0, 1)):
         cid = curve_id(curve)
         fp = FP_LIMBS[cid]
         self.ctx, self.curve = ctx, cid
@@ -73,6 +73,8 @@ class ProvingKey:
         key.nb_wires = ia.shape[0]
         key.nb_infinity_a, key.nb_infinity_b = int(ia.sum()), int(ib.sum())
         key.precompute = int(precompute)   # 0 auto, 1 always, -1 never (window-multiple tables, ga_g16_key.precompute)
+        key.shard_index, key.shard_count = int(shard[0]), int(shard[1])   # multi-GPU: pin slice k of N of every base vector
+        self.shard = (int(shard[0]), int(shard[1]))
         h = C.c_void_p()
         ctx.lib.check(ctx.lib.ga_g16_pk_create(ctx.handle, C.byref(key), C.byref(h)))
         self.handle = h
@@ -100,4 +102,43 @@ def Prove(pk: ProvingKey, solution: Solution, nb_public: int, r: np.ndarray, s: 
     out = np.zeros(8 * fp, dtype=np.uint64)
     lib = pk.ctx.lib
     lib.check(lib.ga_g16_prove(pk.handle, _ptr(W), _ptr(A), _ptr(B), _ptr(Cc), A.shape[0], nb_public, _ptr(r), _ptr(s), _ptr(out)))
+    return Proof(pk.curve, out[: 2 * fp].copy(), out[2 * fp: 6 * fp].copy(), out[6 * fp:].copy(), lib)
+
+
+def ProvePartial(pk: ProvingKey, solution: Solution, nb_public: int) -> np.ndarray:
+    """Device part of a proof on this key's shard (ga_g16_prove_partial): Jacobian sums A | B1 | K+Z | B2 before
+    randomisation, as one uint64 vector (3 G1Jac + 1 G2Jac) ready for an all_gather."""
+    if pk.handle is None:
+        raise _lib.GnarkAmdError("proving key has been freed")
+    W, A, B, Cc = (as_u64(x, 4) for x in (solution.W, solution.A, solution.B, solution.C))
+    if W.shape[0] != pk.nb_wires:
+        raise ValueError(f"len(W)={W.shape[0]} != nbWires={pk.nb_wires}")
+    fp = FP_LIMBS[pk.curve]
+    out = np.zeros(3 * 3 * fp + 6 * fp, dtype=np.uint64)
+    lib = pk.ctx.lib
+    lib.check(lib.ga_g16_prove_partial(pk.handle, _ptr(W), _ptr(A), _ptr(B), _ptr(Cc), A.shape[0], nb_public, _ptr(out)))
+    return out
+
+
+def SumPartials(curve, parts, lib=None) -> np.ndarray:
+    """component-wise group addition of several ProvePartial outputs (host arithmetic, ga_jac_add)"""
+    from . import ecc
+    cid = curve_id(curve)
+    fp = FP_LIMBS[cid]
+    cuts = [(0, 3 * fp, 0), (3 * fp, 6 * fp, 0), (6 * fp, 9 * fp, 0), (9 * fp, 15 * fp, 1)]
+    acc = np.ascontiguousarray(parts[0], dtype=np.uint64).copy()
+    for p in parts[1:]:
+        for lo, hi, grp in cuts:
+            acc[lo:hi] = ecc.jac_add(cid, grp, acc[lo:hi], np.ascontiguousarray(p[lo:hi]), lib=lib)
+    return acc
+
+
+def Finish(pk: ProvingKey, partials_sum: np.ndarray, r: np.ndarray, s: np.ndarray) -> Proof:
+    """host epilogue with the prover's randomness on the summed partials (ga_g16_finish)"""
+    fp = FP_LIMBS[pk.curve]
+    ps = np.ascontiguousarray(partials_sum, dtype=np.uint64)
+    r, s = as_u64(np.asarray(r).reshape(1, 4), 4), as_u64(np.asarray(s).reshape(1, 4), 4)
+    out = np.zeros(8 * fp, dtype=np.uint64)
+    lib = pk.ctx.lib
+    lib.check(lib.ga_g16_finish(pk.handle, _ptr(ps), _ptr(r), _ptr(s), _ptr(out)))
     return Proof(pk.curve, out[: 2 * fp].copy(), out[2 * fp: 6 * fp].copy(), out[6 * fp:].copy(), lib)

@@ -157,6 +157,8 @@ typedef struct ga_g16_key {
     uint64_t nb_infinity_b;
     int32_t precompute;              /* 0: precompute window tables for A,B,K,Z,G2.B when they fit comfortably in free HBM
                                         (default), 1: always, -1: never */
+    uint32_t shard_index;            /* multi-GPU partition B: pin only slice shard_index of shard_count of every */
+    uint32_t shard_count;            /* base vector (contiguous ranges); 0 or 1 = the whole key */
 } ga_g16_key;
 
 int ga_g16_pk_create(ga_ctx* ctx, const ga_g16_key* key, ga_g16_pk** out);
@@ -172,6 +174,14 @@ void ga_g16_pk_destroy(ga_g16_pk* pk);   /* FreeGPUResources, icicle.go:1493-154
  * All pointers are host pointers. */
 int ga_g16_prove(ga_g16_pk* pk, const void* w, const void* a, const void* b, const void* c,
                  uint64_t n_constraints, uint64_t nb_public, const void* r, const void* s, void* proof_out);
+
+/* Multi-GPU proving with a key sharded by base-point range (one context + one shard per GPU, every rank gets the whole
+ * solution): ga_g16_prove_partial runs computeH and the five MSMs over this shard and returns the sums BEFORE
+ * randomisation as Jacobian points  A | B1 | K+Z (G1Jac each) | B2 (G2Jac);  the caller all-gathers them (RCCL), adds them
+ * with ga_jac_add and calls ga_g16_finish on the totals with (r, s).  ga_g16_prove == partial + finish on an unsharded key. */
+int ga_g16_prove_partial(ga_g16_pk* pk, const void* w, const void* a, const void* b, const void* c,
+                         uint64_t n_constraints, uint64_t nb_public, void* partials_out);
+int ga_g16_finish(ga_g16_pk* pk, const void* partials_sum, const void* r, const void* s, void* proof_out);
 
 /* Proof.WriteTo wire format (marshal.go:33-58, no commitments): compressed Ar | Bs | Krs | u32 0 | PoK(inf).
  * Returns the number of bytes written in *len (164 for BN254, 244 for BLS12-381). */

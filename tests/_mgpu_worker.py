@@ -32,6 +32,24 @@ def main():
     got_a = multigpu.msm_window_sharded(ctx, c.name, group, P, S, n, dist)
     assert jac_to_affine_py(c, group, got_b) == want, "base-range sharding mismatch"
     assert jac_to_affine_py(c, group, got_a) == want, "window sharding mismatch"
+    # ---- Groth16 with the key sharded by base-point range: same proof bytes as the oracle -----------------
+    from gnark_amd import groth16
+    from helpers import pts_to_arr
+    cs, wv = pyref.cubic_r1cs(), pyref.cubic_witness(3)
+    rng2 = pyref.Xoshiro(2024)
+    pk, _, _ = pyref.groth16_setup(c, cs, [rng2.field(c.r) for _ in range(5)])
+    r, s = rng2.field(c.r), rng2.field(c.r)
+    A, B, Cc = pyref.r1cs_solve(c, cs, wv)
+    for precompute in (1, -1):
+        dpk = groth16.ProvingKey(
+            ctx, c.name, domain_cardinality=pk.n, alpha1=pts_to_arr(c, 0, [pk.alpha1]), beta1=pts_to_arr(c, 0, [pk.beta1]),
+            delta1=pts_to_arr(c, 0, [pk.delta1]), A=pts_to_arr(c, 0, pk.A), B=pts_to_arr(c, 0, pk.B), Z=pts_to_arr(c, 0, pk.Z),
+            K=pts_to_arr(c, 0, pk.K), beta2=pts_to_arr(c, 1, [pk.beta2]), delta2=pts_to_arr(c, 1, [pk.delta2]),
+            B2=pts_to_arr(c, 1, pk.B2), infinityA=pk.infinityA, infinityB=pk.infinityB, precompute=precompute, shard=(rank, world))
+        sol = groth16.Solution(fr_to_arr(c, wv), fr_to_arr(c, A), fr_to_arr(c, B), fr_to_arr(c, Cc))
+        proof = multigpu.groth16_prove_sharded(dpk, sol, cs.nb_public, fr_to_arr(c, [r]), fr_to_arr(c, [s]), dist)
+        dpk.FreeGPUResources()
+        assert proof.WriteTo() == pyref.proof_bytes(c, *pyref.groth16_prove(pk, cs, wv, r, s)), "sharded Groth16 proof differs"
     dist.barrier()
     if rank == 0:
         print("MGPU_OK world=%d" % world)

@@ -167,6 +167,37 @@ def test_emu_msm_chunked_and_ragged_sizes(emu_ctx, monkeypatch, sizes=(2, 7, 65)
     assert jac_to_affine_py(c, group, z) is None
 
 
+@pytest.mark.parametrize("world", [1, 3])
+def test_emu_groth16_sharded_key_single_process(emu_ctx, world):
+    """key sharded by base-point range (multi-GPU partition B), all shards driven from one process: partials add up to the
+    same proof bytes as the unsharded prover / the oracle"""
+    c = BN254
+    rng = pyref.Xoshiro(777)
+    cs, w = pyref.cubic_r1cs(), pyref.cubic_witness(3)
+    pk, _, _ = pyref.groth16_setup(c, cs, [rng.field(c.r) for _ in range(5)])
+    r, s = rng.field(c.r), rng.field(c.r)
+    A, B, Cc = pyref.r1cs_solve(c, cs, w)
+    sol = groth16.Solution(W=fr_to_arr(c, w), A=fr_to_arr(c, A), B=fr_to_arr(c, B), C=fr_to_arr(c, Cc))
+    kw = dict(domain_cardinality=pk.n, alpha1=pts_to_arr(c, 0, [pk.alpha1]), beta1=pts_to_arr(c, 0, [pk.beta1]),
+              delta1=pts_to_arr(c, 0, [pk.delta1]), A=pts_to_arr(c, 0, pk.A), B=pts_to_arr(c, 0, pk.B), Z=pts_to_arr(c, 0, pk.Z),
+              K=pts_to_arr(c, 0, pk.K), beta2=pts_to_arr(c, 1, [pk.beta2]), delta2=pts_to_arr(c, 1, [pk.delta2]),
+              B2=pts_to_arr(c, 1, pk.B2), infinityA=pk.infinityA, infinityB=pk.infinityB)
+    parts, keys = [], []
+    for k in range(world):
+        dpk = groth16.ProvingKey(emu_ctx, c.name, shard=(k, world), **kw)
+        keys.append(dpk)
+        parts.append(groth16.ProvePartial(dpk, sol, cs.nb_public))
+    total = groth16.SumPartials(c.name, parts, lib=emu_ctx.lib)
+    proof = groth16.Finish(keys[0], total, fr_to_arr(c, [r]), fr_to_arr(c, [s]))
+    if world > 1:
+        from gnark_amd import GnarkAmdError
+        with pytest.raises(GnarkAmdError, match="shard"):
+            groth16.Prove(keys[0], sol, cs.nb_public, fr_to_arr(c, [r]), fr_to_arr(c, [s]))
+    for dpk in keys:
+        dpk.FreeGPUResources()
+    assert proof.WriteTo() == pyref.proof_bytes(c, *pyref.groth16_prove(pk, cs, w, r, s))
+
+
 def test_emu_error_behaviour(emu_ctx):
     """errors mirror the reference's: bad sizes are rejected with a message, nothing is computed"""
     from gnark_amd import GnarkAmdError

@@ -372,3 +372,7 @@ def test_compute_h_2_20_polynomial_identity(gpu_ctx):
     ev = lambda co: pyref.from_mont_limbs(oracle.fr_horner(c.cid, co, x), c.r)
     lhs = (ev(coef(A)) * ev(coef(B)) - ev(coef(Cc))) % c.r
     assert lhs == ev(h) * (pow(xv, n, c.r) - 1) % c.r
+
+
+def test_groth16_sharded_key_on_device(gpu_ctx):
+    cases.test_emu_groth16_sharded_key_single_process(gpu_ctx, 3)
