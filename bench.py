@@ -46,7 +46,7 @@ def stage_stats(records):
     return {k: {"launches": v[0], "total_ms": round(v[1], 4), "avg_ms": round(v[1] / v[0], 4)} for k, v in agg.items()}
 
 
-def synth_groth16(ctx, cid, logn, seed):
+def synth_groth16(ctx, cid, logn, seed, shard=(0, 1)):
     """Synthetic 2^logn-constraint instance: known-dlog key generated on device, pulled to the
     host once so that it can go through the same ga_g16_pk_create upload path a Go caller uses."""
     import ctypes as C
@@ -79,7 +79,7 @@ def synth_groth16(ctx, cid, logn, seed):
     misc1 = gen(0, 3, seed + 6)
     misc2 = gen(1, 2, seed + 7)
     pk = groth16.ProvingKey(ctx, cid, domain_cardinality=n, alpha1=misc1[0:1], beta1=misc1[1:2], delta1=misc1[2:3], A=A, B=B, Z=Z,
-                            K=K, beta2=misc2[0:1], delta2=misc2[1:2], B2=B2, infinityA=infA, infinityB=infB)
+                            K=K, beta2=misc2[0:1], delta2=misc2[1:2], B2=B2, infinityA=infA, infinityB=infB, shard=shard)
     del A, B, Z, K, B2
 
     def scal(count, sd):
@@ -214,6 +214,9 @@ def main():
                                       "Mscalar_mul_per_s": round(n / ((time.perf_counter() - t0) / 2) / 1e6, 2)}
     if table is not None:
         table.free()
+        if world > 1:
+            bases.free()
+            scalars.free()
     if rank == 0 and world == 1 and args.groth16_proofs > 0:   # N = 1 semantics; multi-rank runs time the sharded MSM only
         bases.free()
         scalars.free()
@@ -243,6 +246,35 @@ def main():
                           "computeH_hbm_frac": round(448.0 * n / (ntt_ms * 1e-3) / 8e12, 5) if ntt_ms > 0 else None,
                           "proof_sha": __import__("hashlib").sha256(proof.WriteTo()).hexdigest()[:16],
                           "stages_ms": gst}
+
+    # ---- Groth16 across ranks (N > 1): key sharded by base-point range, partial MSM sums all-gathered (multigpu.py) -------
+    if world > 1 and args.groth16_proofs > 0 and os.environ.get("GA_BENCH_SHARDED_G16", "1") != "0":
+        g16 = None
+        try:
+            import psutil
+            need = (8 << 30) * (1 << args.log_n) // (1 << 24) + (2 << 30)   # full synthetic key + solution staged on the host per rank
+            if psutil.virtual_memory().available < need * world // max(1, world // 8 or 1):
+                raise RuntimeError("not enough host memory to stage %d synthetic keys" % world)
+            from gnark_amd import groth16
+            if table is None:
+                bases.free()
+                scalars.free()
+            pk, sol, nb_public, r, s = synth_groth16(ctx, cid, args.log_n, 0x5EED0005, shard=(rank, world))   # same seeds on every rank
+            multigpu.groth16_prove_sharded(pk, sol, nb_public, r, s, dist, dev)   # warm-up
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(args.groth16_proofs):
+                proof = multigpu.groth16_prove_sharded(pk, sol, nb_public, r, s, dist, dev)
+            fence()
+            el = time.perf_counter() - t0
+            pk.FreeGPUResources()
+            g16 = {"proofs_per_s": round(args.groth16_proofs / el, 4), "ms_per_proof": round(el * 1e3 / args.groth16_proofs, 2),
+                   "constraints": n, "mode": "one proof over %d GPUs: key sharded by base-point range, H replicated, all_gather of 4 partial points" % world,
+                   "proof_sha": __import__("hashlib").sha256(proof.WriteTo()).hexdigest()[:16]}
+        except Exception as e:   # never lose the headline line because of the optional leg
+            g16 = {"error": repr(e)[:300]}
+        if rank == 0:
+            out["groth16"] = g16
 
     # ---- CPU baseline: the oracle's Pippenger on a bounded sample (rank 0, N=1) ----------------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
