@@ -39,6 +39,9 @@ class G16Key(C.Structure):
         ("nb_wires", C.c_uint64), ("nb_infinity_a", C.c_uint64), ("nb_infinity_b", C.c_uint64),
         ("precompute", C.c_int32),
         ("shard_index", C.c_uint32), ("shard_count", C.c_uint32),
+        ("nb_commitments", C.c_uint32),
+        ("ck_basis", C.POINTER(C.c_void_p)), ("ck_basis_exp_sigma", C.POINTER(C.c_void_p)), ("ck_len", C.POINTER(C.c_uint64)),
+        ("k_remove", C.POINTER(C.c_uint64)), ("len_k_remove", C.c_uint64),
     ]
 
 
@@ -77,6 +80,12 @@ _PROTOS = {
     "ga_g16_prove_partial": (C.c_int, [_P, _P, _P, _P, _P, C.c_uint64, C.c_uint64, _P]),
     "ga_g16_finish": (C.c_int, [_P, _P, _P, _P, _P]),
     "ga_g16_proof_marshal": (C.c_int, [C.c_int, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "ga_g16_commit": (C.c_int, [_P, C.c_uint32, _P, C.c_uint64, _P, _P]),
+    "ga_g16_fold_pok": (C.c_int, [C.c_int, _P, C.c_uint64, _P, _P]),
+    "ga_hash_to_field": (C.c_int, [C.c_int, _P, C.c_size_t, _P, C.c_size_t, C.c_uint32, _P]),
+    "ga_expand_message_xmd": (C.c_int, [_P, C.c_size_t, _P, C.c_size_t, C.c_size_t, _P]),
+    "ga_g16_proof_marshal_bsb22": (C.c_int, [C.c_int, _P, _P, C.c_uint32, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "ga_g1_marshal_uncompressed": (C.c_int, [C.c_int, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "ga_profile_enable": (C.c_int, [_P, C.c_int]),
     "ga_profile_reset": (C.c_int, [_P]),
     "ga_profile_read": (C.c_int, [_P, C.c_char_p, C.c_size_t]),

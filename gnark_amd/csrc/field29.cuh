@@ -306,7 +306,48 @@ GA_HD_BIG F29x2<P> f29_sqr(const F29x2<P>& a) {
     return {r0, f29_add(t, t)};
 }
 template <class P>
-GA_HD_BIG F29<P> f29_sqr(const F29<P>& a) { return f29_mul(a, a); }
+GA_HD_BIG F29<P> f29_sqr(const F29<P>& a) {
+#if GA_F29_CHAINED
+    return f29_mul(a, a);
+#else
+    // a_i*a_j (i<j) computed once against the doubled limb: NL(NL+1)/2 products instead of NL^2 (45 vs 81 for 9 limbs).
+    // Doubled limbs stay below 2^(L+1), a column holds at most NL/2 doubled products + one square + the NL reduction
+    // products: < 2^(2L+1) * NL < 2^63 for both limb layouts.
+    typedef Radix<P> R;
+    constexpr int NL = R::NL, L = R::L;
+    const uint32_t inv = P::INV & R::MASK;
+    F29<P> r;
+    uint32_t d[NL];
+#pragma unroll
+    for (int i = 0; i < NL; i++) d[i] = a.l[i] << 1;
+    uint64_t col[2 * NL];
+#pragma unroll
+    for (int k = 0; k < 2 * NL; k++) col[k] = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        col[2 * i] += (uint64_t)a.l[i] * a.l[i];
+#pragma unroll
+        for (int j = i + 1; j < NL; j++) col[i + j] += (uint64_t)a.l[i] * d[j];
+    }
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        const uint32_t m = ((uint32_t)col[i] * inv) & R::MASK;
+#pragma unroll
+        for (int j = 0; j < NL; j++) col[i + j] += (uint64_t)m * mod_limb<P>(j);
+        col[i + 1] += col[i] >> L;
+    }
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+        if (k + 1 < NL) {
+            r.l[k] = (uint32_t)col[NL + k] & R::MASK;
+            col[NL + k + 1] += col[NL + k] >> L;
+        } else {
+            r.l[k] = (uint32_t)col[NL + k];
+        }
+    }
+    return r;
+#endif
+}
 
 // ---- uniform view used by the table kernels: Lazy<Fe<P>> / Lazy<Fe2<P>> ------------------------------------------------
 template <class F> struct Lazy;

@@ -1,8 +1,8 @@
 // Groth16 prover core: device-resident proving key + one-call proof from the solver's output.
 //
 // Mirrors backend/groth16/bn254/prove.go:130-315 (CPU) and backend/accelerated/icicle/groth16/bn254/icicle.go:784-1360
-// (GPU) without BSB22 commitments:  computeH -> filter wire values -> 4 G1 MSMs + 1 G2 MSM -> host epilogue with the
-// caller-supplied randomness (r, s).  The host side is C++ because the reference's host side is compiled Go and no Go
+// (GPU):  computeH -> filter wire values -> 4 G1 MSMs + 1 G2 MSM -> host epilogue with the caller-supplied randomness
+// (r, s); BSB22 commitments are the two extra MSMs per commitment of ga_g16_commit (prove.go:84,114) plus the K filter.  The host side is C++ because the reference's host side is compiled Go and no Go
 // toolchain exists in the build image (INTEGRATION.md shows the cgo binding that calls this file's two entry points).
 #include <algorithm>
 #include <string>
@@ -21,6 +21,10 @@ struct G16Pk {
     void *d_a = nullptr, *d_b = nullptr, *d_z = nullptr, *d_k = nullptr, *d_b2 = nullptr;
     uint64_t len_a = 0, len_b = 0, len_z = 0, len_k = 0, len_b2 = 0;
     uint32_t *d_idx_a = nullptr, *d_idx_b = nullptr;   // wire indices kept for the A / B MSMs (prove.go:147-168)
+    uint32_t* d_idx_k = nullptr;   // wire indices feeding the K MSM when committed wires are left out (prove.go:231-235); null = W[nbPublic:]
+    uint64_t len_k_remove = 0;
+    std::vector<void*> d_ck_basis, d_ck_sigma;   // pinned pedersen keys (setup.go:260-287, icicle.go:231-261)
+    std::vector<uint64_t> ck_len;
     // precomputed window-multiple tables (msm.cuh): d_a.. then point to windows x len points and c_* is the window width
     bool tables = false;
     int c_a = 0, c_b = 0, c_z = 0, c_k = 0;
@@ -50,6 +54,9 @@ static void pk_free(G16Pk* pk) {
     hipFree(pk->d_b2);
     hipFree(pk->d_idx_a);
     hipFree(pk->d_idx_b);
+    hipFree(pk->d_idx_k);
+    for (void* p : pk->d_ck_basis) hipFree(p);
+    for (void* p : pk->d_ck_sigma) hipFree(p);
     if (pk->dom) ntt_domain_delete(pk->dom);
     delete pk;
 }
@@ -116,6 +123,44 @@ static int pk_create(Ctx* ctx, const ga_g16_key* key, G16Pk** out) {
     }
     if (rc == GA_OK) rc = upload(ctx, ia.data() + lo_a, pk->len_a * 4, (void**)&pk->d_idx_a);
     if (rc == GA_OK) rc = upload(ctx, ib.data() + lo_b, pk->len_b * 4, (void**)&pk->d_idx_b);
+    // K filter with commitments: wireValues[nbPublic:] minus the private committed and commitment wires (prove.go:231-235)
+    std::vector<uint32_t> ik;
+    pk->len_k_remove = key->len_k_remove;
+    if (rc == GA_OK && key->len_k_remove) {
+        if (!key->k_remove || key->len_k + key->len_k_remove > key->nb_wires) {
+            set_error("proving key: k_remove missing or len(K)+len(k_remove) > nbWires");
+            rc = GA_ERR_INVALID;
+        } else {
+            const uint64_t nb_public = key->nb_wires - key->len_k - key->len_k_remove;
+            ik.reserve(key->len_k);
+            uint64_t j = 0;
+            bool ok = true;
+            for (uint64_t i = 0; i < key->len_k_remove; i++)
+                ok = ok && key->k_remove[i] >= nb_public && key->k_remove[i] < key->nb_wires && (i == 0 || key->k_remove[i] > key->k_remove[i - 1]);
+            for (uint64_t i = nb_public; ok && i < key->nb_wires; i++) {
+                if (j < key->len_k_remove && key->k_remove[j] == i) j++;
+                else ik.push_back((uint32_t)i);
+            }
+            if (!ok || ik.size() != key->len_k) {
+                set_error("proving key: k_remove must be strictly increasing wire ids in [nbPublic, nbWires)");
+                rc = GA_ERR_INVALID;
+            }
+        }
+        if (rc == GA_OK) rc = upload(ctx, ik.data() + lo_k, pk->len_k * 4, (void**)&pk->d_idx_k);
+    }
+    for (uint32_t i = 0; rc == GA_OK && i < key->nb_commitments; i++) {
+        if (!key->ck_basis || !key->ck_basis_exp_sigma || !key->ck_len) {
+            set_error("proving key: nb_commitments > 0 but the commitment key arrays are null");
+            rc = GA_ERR_INVALID;
+            break;
+        }
+        void *db = nullptr, *ds = nullptr;
+        rc = upload(ctx, key->ck_basis[i], key->ck_len[i] * s1, &db);
+        if (rc == GA_OK) rc = upload(ctx, key->ck_basis_exp_sigma[i], key->ck_len[i] * s1, &ds);
+        pk->d_ck_basis.push_back(db);
+        pk->d_ck_sigma.push_back(ds);
+        pk->ck_len.push_back(key->ck_len[i]);
+    }
     if (rc == GA_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) {   // no host pointer survives this call
         set_error("proving key upload: stream synchronize failed");
         rc = GA_ERR_HIP;
@@ -185,8 +230,8 @@ static int prove_partial(G16Pk* pk, const void* w, const void* a, const void* b,
     typedef Fe2<typename C::FpP> F2;
     Ctx* ctx = pk->ctx;
     const uint64_t n = pk->n;
-    if (n_constraints > n || nb_public > pk->nb_wires || pk->nb_wires - nb_public != pk->full_len_k) {
-        set_error("prove: inconsistent sizes (constraints %llu > n %llu, or nbWires-nbPublic != len(K))",
+    if (n_constraints > n || nb_public > pk->nb_wires || pk->nb_wires - nb_public != pk->full_len_k + pk->len_k_remove) {
+        set_error("prove: inconsistent sizes (constraints %llu > n %llu, or nbWires-nbPublic != len(K)+len(k_remove))",
                   (unsigned long long)n_constraints, (unsigned long long)n);
         return GA_ERR_INVALID;
     }
@@ -239,6 +284,13 @@ static int prove_partial(G16Pk* pk, const void* w, const void* a, const void* b,
     // ---- wire filtering (prove.go:147-168) ------------------------------------------------------------
     GA_CHECK(util_gather_fr<C>(ctx, d_wa, d_w, pk->d_idx_a, pk->len_a));
     GA_CHECK(util_gather_fr<C>(ctx, d_wb, d_w, pk->d_idx_b, pk->len_b));
+    const void* d_wk = (const char*)d_w + (nb_public + pk->off_k) * 32;
+    if (pk->d_idx_k) {
+        void* g;
+        GA_CHECK(ctx->scratch_get("g16_wk", pk->len_k * 32 + 32, &g));
+        GA_CHECK(util_gather_fr<C>(ctx, g, d_w, pk->d_idx_k, pk->len_k));
+        d_wk = g;
+    }
     // ---- the four witness MSMs (prove.go:194,207,237,283) ----------------------------------------------
     XYZZ<F1> ar, bs1, krs, krs2;
     XYZZ<F2> bs2;
@@ -256,12 +308,12 @@ static int prove_partial(G16Pk* pk, const void* w, const void* a, const void* b,
         GA_CHECK(table_msm_g1(pk->d_b, d_wb, pk->len_b, pk->c_b, &bs1));
         if (pk->len_b2) GA_CHECK((msm_table_device_reuse<C, GA_G2>(ctx, pk->d_b2, prep, &bs2)));   // same scalars wB: digits/sort shared
         else bs2 = xyzz_inf<F2>();
-        GA_CHECK(table_msm_g1(pk->d_k, (const char*)d_w + (nb_public + pk->off_k) * 32, pk->len_k, pk->c_k, &krs));
+        GA_CHECK(table_msm_g1(pk->d_k, d_wk, pk->len_k, pk->c_k, &krs));
     } else {
         GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_a, d_wa, pk->len_a, true, &ar)));
         GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_b, d_wb, pk->len_b, true, &bs1)));
         GA_CHECK((host_msm<C, GA_G2>(ctx, pk->d_b2, d_wb, pk->len_b2, true, &bs2)));
-        GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_k, (const char*)d_w + (nb_public + pk->off_k) * 32, pk->len_k, true, &krs)));
+        GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_k, d_wk, pk->len_k, true, &krs)));
     }
     // ---- H (prove.go:134,346-389), then the MSM over pk.G1.Z (prove.go:225-227) ----------------------------
     uploader.join();
@@ -309,6 +361,45 @@ static int finish(G16Pk* pk, XYZZ<Fe<typename C::FpP>> ar, XYZZ<Fe<typename C::F
     host_store_affine<F1>(o, ar);
     host_store_affine<F2>(o + sizeof(Affine<F1>), bs2);
     host_store_affine<F1>(o + sizeof(Affine<F1>) + sizeof(Affine<F2>), krs);
+    return GA_OK;
+}
+
+// BSB22: commitment_i = <values, Basis_i> (pedersen Commit, prove.go:84) and its proof of knowledge <values, BasisExpSigma_i>
+// (ProveKnowledge, prove.go:114) -- the ICICLE prover's two commitment MSM blocks (icicle.go:834-873,904-944) in one call.
+template <class C>
+static int commit(G16Pk* pk, uint32_t index, const void* values, uint64_t n_values, void* commitment_out, void* pok_out) {
+    typedef Fe<typename C::FpP> F1;
+    Ctx* ctx = pk->ctx;
+    if (index >= pk->ck_len.size() || n_values != pk->ck_len[index]) {
+        set_error("commit: commitment %u of %zu, %llu values for a basis of %llu points", index, pk->ck_len.size(),
+                  (unsigned long long)n_values, (unsigned long long)(index < pk->ck_len.size() ? pk->ck_len[index] : 0));
+        return GA_ERR_INVALID;
+    }
+    XYZZ<F1> com = xyzz_inf<F1>(), pok = xyzz_inf<F1>();
+    if (n_values) {
+        void* d_v;
+        GA_CHECK(ctx->scratch_get("g16_commit_values", n_values * 32, &d_v));
+        GA_HIP_CHECK(hipMemcpyAsync(d_v, values, n_values * 32, hipMemcpyHostToDevice, ctx->stream));
+        GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_ck_basis[index], d_v, n_values, true, &com)));
+        GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_ck_sigma[index], d_v, n_values, true, &pok)));
+    }
+    host_store_affine<F1>(commitment_out, com);
+    host_store_affine<F1>(pok_out, pok);
+    return GA_OK;
+}
+
+// sum_i challenge^i * poks[i]  (Horner from the last point)
+template <class C>
+static int fold_pok(const void* poks, uint64_t n, const void* challenge_mont, void* out) {
+    typedef Fe<typename C::FpP> F1;
+    uint32_t ch[8];
+    host_fr_canonical<typename C::FrP>(challenge_mont, ch);
+    XYZZ<F1> acc = xyzz_inf<F1>();
+    for (uint64_t i = n; i-- > 0;) {
+        acc = scalar_mul(acc, ch, 8);
+        acc = add(acc, host_load_affine<F1>((const char*)poks + i * sizeof(Affine<F1>)));
+    }
+    host_store_affine<F1>(out, acc);
     return GA_OK;
 }
 
@@ -375,11 +466,11 @@ static size_t compress_g2(const void* aff, uint8_t* out) {
 }
 
 template <class C>
-static int marshal(const void* proof, uint8_t* out, size_t cap, size_t* len) {
+static int marshal(const void* proof, const void* commitments, uint32_t ncom, const void* pok, uint8_t* out, size_t cap, size_t* len) {
     typedef Fe<typename C::FpP> F1;
     typedef Fe2<typename C::FpP> F2;
     const size_t nb = C::FpP::N * 4;
-    const size_t need = nb + 2 * nb + nb + 4 + nb;
+    const size_t need = nb + 2 * nb + nb + 4 + (size_t)ncom * nb + nb;
     if (cap < need) {
         set_error("proof marshal: buffer too small (%zu < %zu)", cap, need);
         return GA_ERR_INVALID;
@@ -389,11 +480,15 @@ static int marshal(const void* proof, uint8_t* out, size_t cap, size_t* len) {
     o += compress_g1<C>(p, out + o);
     o += compress_g2<C>(p + sizeof(Affine<F1>), out + o);
     o += compress_g1<C>(p + sizeof(Affine<F1>) + sizeof(Affine<F2>), out + o);
-    memset(out + o, 0, 4);   // uint32 number of commitments = 0
+    out[o] = ncom >> 24;   // uint32 big-endian number of commitments (the slice encoder's length prefix)
+    out[o + 1] = ncom >> 16;
+    out[o + 2] = ncom >> 8;
+    out[o + 3] = ncom;
     o += 4;
+    for (uint32_t i = 0; i < ncom; i++) o += compress_g1<C>((const char*)commitments + i * sizeof(Affine<F1>), out + o);
     Affine<F1> inf;
     memset(&inf, 0, sizeof(inf));
-    o += compress_g1<C>(&inf, out + o);   // CommitmentPok = infinity
+    o += compress_g1<C>(pok ? pok : &inf, out + o);   // CommitmentPok (infinity without commitments)
     *len = o;
     return GA_OK;
 }
@@ -494,7 +589,64 @@ int ga_g16_proof_marshal(int curve, const void* proof, uint8_t* out, size_t cap,
         set_error("ga_g16_proof_marshal: null argument");
         return GA_ERR_INVALID;
     }
-    GA_DISPATCH_CURVE(curve, return marshal<C>(proof, out, cap, len));
+    GA_DISPATCH_CURVE(curve, return marshal<C>(proof, nullptr, 0, nullptr, out, cap, len));
+    return GA_OK;
+}
+
+int ga_g16_proof_marshal_bsb22(int curve, const void* proof, const void* commitments, uint32_t n, const void* pok, uint8_t* out,
+                               size_t cap, size_t* len) {
+    if (!proof || !out || !len || (n && !commitments)) {
+        set_error("ga_g16_proof_marshal_bsb22: null argument");
+        return GA_ERR_INVALID;
+    }
+    GA_DISPATCH_CURVE(curve, return marshal<C>(proof, commitments, n, pok, out, cap, len));
+    return GA_OK;
+}
+
+int ga_g1_marshal_uncompressed(int curve, const void* affine, uint8_t* out, size_t cap, size_t* len) {
+    if (!affine || !out || !len) {
+        set_error("ga_g1_marshal_uncompressed: null argument");
+        return GA_ERR_INVALID;
+    }
+    GA_DISPATCH_CURVE(curve, {
+        typedef typename C::FpP P;
+        const size_t nb = P::N * 4;
+        if (cap < 2 * nb) {
+            set_error("ga_g1_marshal_uncompressed: buffer too small");
+            return GA_ERR_INVALID;
+        }
+        Affine<Fe<P>> a;
+        memcpy(&a, affine, sizeof(a));
+        memset(out, 0, 2 * nb);
+        if (is_inf(a)) {
+            out[0] = C::ID == GA_BN254 ? 0x40 : 0x40;   // mUncompressedInfinity: 0b01<<6 (BN254), 0b010<<5 (BLS12-381)
+        } else {
+            be_bytes<P>(a.x, out);
+            be_bytes<P>(a.y, out + nb);
+        }
+        *len = 2 * nb;
+    });
+    return GA_OK;
+}
+
+int ga_g16_commit(ga_g16_pk* p, uint32_t index, const void* values, uint64_t n_values, void* commitment_out, void* pok_out) {
+    G16Pk* pk = reinterpret_cast<G16Pk*>(p);
+    if (!pk || (!values && n_values) || !commitment_out || !pok_out) {
+        set_error("ga_g16_commit: null argument");
+        return GA_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> g(pk->ctx->mu);
+    hipSetDevice(pk->ctx->device);
+    GA_DISPATCH_CURVE(pk->curve, return commit<C>(pk, index, values, n_values, commitment_out, pok_out));
+    return GA_OK;
+}
+
+int ga_g16_fold_pok(int curve, const void* poks, uint64_t n, const void* challenge, void* out) {
+    if ((!poks && n) || !challenge || !out) {
+        set_error("ga_g16_fold_pok: null argument");
+        return GA_ERR_INVALID;
+    }
+    GA_DISPATCH_CURVE(curve, return fold_pok<C>(poks, n, challenge, out));
     return GA_OK;
 }
 

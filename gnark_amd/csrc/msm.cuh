@@ -303,12 +303,12 @@ __device__ __forceinline__ void madd29(const LdsAcc29<Fe<P>>& A, const F29<P>& q
     F29<P> S2 = f29_mul(qy, zzz);
     F29<P> ay = A.get(1);
     F29<P> R = f29_sub<8>(S2, ay);
-    F29<P> PP = f29_mul(Pp, Pp);
+    F29<P> PP = f29_sqr(Pp);
     A.put(2, f29_mul(zz, PP));
     F29<P> PPP = f29_mul(Pp, PP);
     A.put(3, f29_mul(zzz, PPP));
     F29<P> Q = f29_mul(ax, PP);
-    F29<P> X3 = f29_sub<4>(f29_mul(R, R), f29_add(PPP, f29_add(Q, Q)));
+    F29<P> X3 = f29_sub<4>(f29_sqr(R), f29_add(PPP, f29_add(Q, Q)));
     A.put(0, X3);
     A.put(1, f29_sub<2>(f29_mul(R, f29_sub<8>(Q, X3)), f29_mul(ay, PPP)));
 }

@@ -24,23 +24,34 @@ class Solution:
 
 @dataclass
 class Proof:
-    """backend/groth16/bn254/prove.go:34-39 (no commitments): affine images, Montgomery limbs."""
+    """backend/groth16/bn254/prove.go:34-39: affine images, Montgomery limbs.  Commitments / CommitmentPok are filled by the
+    caller from ProvingKey.Commit + FoldPok when the circuit uses api.Commit (BSB22)."""
     curve: int
     Ar: np.ndarray
     Bs: np.ndarray
     Krs: np.ndarray
     _lib: object = None
+    Commitments: np.ndarray = None     # (n, 2*fp) G1Affine
+    CommitmentPok: np.ndarray = None   # (2*fp,) G1Affine
 
     def raw(self) -> np.ndarray:
         return np.concatenate([self.Ar, self.Bs, self.Krs]).astype(np.uint64)
 
     def WriteTo(self) -> bytes:
-        """Proof.WriteTo (marshal.go:33-58): compressed Ar | Bs | Krs | u32 0 | CommitmentPok."""
+        """Proof.WriteTo (marshal.go:33-58): compressed Ar | Bs | Krs | u32 n | commitments | CommitmentPok."""
         lib = self._lib or _lib.load()
         raw = self.raw()
-        out = np.zeros(512, dtype=np.uint8)
+        fp = FP_LIMBS[self.curve]
         n = C.c_size_t()
-        lib.check(lib.ga_g16_proof_marshal(self.curve, _ptr(raw), _ptr(out), out.nbytes, C.byref(n)))
+        if self.Commitments is None or len(self.Commitments) == 0:
+            out = np.zeros(512, dtype=np.uint8)
+            lib.check(lib.ga_g16_proof_marshal(self.curve, _ptr(raw), _ptr(out), out.nbytes, C.byref(n)))
+        else:
+            com = as_u64(np.asarray(self.Commitments).reshape(-1, 2 * fp), 2 * fp)
+            pok = as_u64(np.asarray(self.CommitmentPok).reshape(1, 2 * fp), 2 * fp)
+            out = np.zeros(512 + 64 * com.shape[0], dtype=np.uint8)
+            lib.check(lib.ga_g16_proof_marshal_bsb22(self.curve, _ptr(raw), _ptr(com), com.shape[0], _ptr(pok), _ptr(out),
+                                                     out.nbytes, C.byref(n)))
         return out[: n.value].tobytes()
 
 
@@ -48,7 +59,9 @@ class ProvingKey:
     """setup.go:25-48 fields, uploaded once ("PinToGPU"); free with FreeGPUResources() (icicle.go:1493)."""
 
     def __init__(self, ctx: Context, curve, *, domain_cardinality, alpha1, beta1, delta1, A, B, Z, K, beta2, delta2, B2,
-                 infinityA, infinityB, precompute: int = 0, shard=(0, 1)):
+                 infinityA, infinityB, precompute: int = 0, shard=(0, 1), commitment_keys=(), k_remove=()):
+        """commitment_keys: [(Basis, BasisExpSigma)] per pk.CommitmentKeys[i] (setup.go:276-287); k_remove: sorted wire ids of the
+        private committed wires and the commitment wires, left out of the K MSM (prove.go:231-235)."""
         cid = curve_id(curve)
         fp = FP_LIMBS[cid]
         self.ctx, self.curve = ctx, cid
@@ -75,11 +88,37 @@ class ProvingKey:
         key.precompute = int(precompute)   # 0 auto, 1 always, -1 never (window-multiple tables, ga_g16_key.precompute)
         key.shard_index, key.shard_count = int(shard[0]), int(shard[1])   # multi-GPU: pin slice k of N of every base vector
         self.shard = (int(shard[0]), int(shard[1]))
+        cks = [(g1(b), g1(e)) for b, e in commitment_keys]
+        if cks:
+            nck = len(cks)
+            bas = (C.c_void_p * nck)(*[b.ctypes.data for b, _ in cks])
+            sig = (C.c_void_p * nck)(*[e.ctypes.data for _, e in cks])
+            lens = (C.c_uint64 * nck)(*[b.shape[0] for b, _ in cks])
+            for b, e in cks:
+                if b.shape != e.shape:
+                    raise ValueError("Basis and BasisExpSigma must have the same length")
+            key.nb_commitments, key.ck_basis, key.ck_basis_exp_sigma, key.ck_len = nck, bas, sig, lens
+        rem = np.ascontiguousarray(k_remove, dtype=np.uint64)
+        if rem.size:
+            key.k_remove, key.len_k_remove = rem.ctypes.data_as(C.POINTER(C.c_uint64)), rem.size
+        self.nb_commitments = len(cks)
         h = C.c_void_p()
         ctx.lib.check(ctx.lib.ga_g16_pk_create(ctx.handle, C.byref(key), C.byref(h)))
         self.handle = h
         self.nb_wires = int(key.nb_wires)
         self.domain_cardinality = int(domain_cardinality)
+
+    def Commit(self, index: int, values):
+        """pk.CommitmentKeys[index].Commit(values) and .ProveKnowledge(values) (prove.go:84,114) on the pinned bases:
+        returns (commitment, pok) as G1Affine images."""
+        if self.handle is None:
+            raise _lib.GnarkAmdError("proving key has been freed")
+        fp = FP_LIMBS[self.curve]
+        v = as_u64(np.asarray(values, dtype=np.uint64).reshape(-1, 4), 4)
+        com, pok = np.zeros(2 * fp, dtype=np.uint64), np.zeros(2 * fp, dtype=np.uint64)
+        lib = self.ctx.lib
+        lib.check(lib.ga_g16_commit(self.handle, int(index), _ptr(v) if v.shape[0] else None, v.shape[0], _ptr(com), _ptr(pok)))
+        return com, pok
 
     def FreeGPUResources(self):
         if self.handle:
@@ -142,3 +181,41 @@ def Finish(pk: ProvingKey, partials_sum: np.ndarray, r: np.ndarray, s: np.ndarra
     lib = pk.ctx.lib
     lib.check(lib.ga_g16_finish(pk.handle, _ptr(ps), _ptr(r), _ptr(s), _ptr(out)))
     return Proof(pk.curve, out[: 2 * fp].copy(), out[2 * fp: 6 * fp].copy(), out[6 * fp:].copy(), lib)
+
+
+# ---- BSB22 host helpers (what the Go shim gets from gnark-crypto; here through the library's host code) -------------------
+COMMITMENT_DST = b"bsb22-commitment"   # constraint/commitment.go:7
+FOLD_DST = b"G16-BSB22"                # prove.go:123
+
+
+def HashToField(curve, msg: bytes, dst: bytes, count: int = 1, lib=None) -> np.ndarray:
+    """fr.Hash(msg, dst, count) -> (count, 4) fr.Element images (Montgomery)."""
+    lib = lib or _lib.load()
+    m = np.frombuffer(bytes(msg), dtype=np.uint8) if len(msg) else np.zeros(1, dtype=np.uint8)
+    d = np.frombuffer(bytes(dst), dtype=np.uint8)
+    out = np.zeros((count, 4), dtype=np.uint64)
+    lib.check(lib.ga_hash_to_field(curve_id(curve), _ptr(m), len(msg), _ptr(d), len(dst), count, _ptr(out)))
+    return out
+
+
+def MarshalG1(curve, affine, lib=None) -> bytes:
+    """G1Affine.Marshal(): uncompressed big-endian x | y (what SerializeCommitment hashes, constraint/commitment.go:76-89)."""
+    lib = lib or _lib.load()
+    cid = curve_id(curve)
+    a = as_u64(np.asarray(affine).reshape(1, 2 * FP_LIMBS[cid]), 2 * FP_LIMBS[cid])
+    out = np.zeros(96, dtype=np.uint8)
+    n = C.c_size_t()
+    lib.check(lib.ga_g1_marshal_uncompressed(cid, _ptr(a), _ptr(out), out.nbytes, C.byref(n)))
+    return out[: n.value].tobytes()
+
+
+def FoldPok(curve, poks, challenge, lib=None) -> np.ndarray:
+    """proof.CommitmentPok.Fold(poks, challenge) (prove.go:127): sum_i challenge^i poks[i]."""
+    lib = lib or _lib.load()
+    cid = curve_id(curve)
+    fp = FP_LIMBS[cid]
+    p = as_u64(np.asarray(poks).reshape(-1, 2 * fp), 2 * fp)
+    ch = as_u64(np.asarray(challenge).reshape(1, 4), 4)
+    out = np.zeros(2 * fp, dtype=np.uint64)
+    lib.check(lib.ga_g16_fold_pok(cid, _ptr(p), p.shape[0], _ptr(ch), _ptr(out)))
+    return out

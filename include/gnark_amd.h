@@ -159,6 +159,13 @@ typedef struct ga_g16_key {
                                         (default), 1: always, -1: never */
     uint32_t shard_index;            /* multi-GPU partition B: pin only slice shard_index of shard_count of every */
     uint32_t shard_count;            /* base vector (contiguous ranges); 0 or 1 = the whole key */
+    /* BSB22 commitments (setup.go:260-287, prove.go:60-135,231-235); all zero / NULL for a circuit without api.Commit */
+    uint32_t nb_commitments;             /* len(pk.CommitmentKeys) */
+    const void* const* ck_basis;         /* [nb_commitments] -> pk.CommitmentKeys[i].Basis (G1Affine) */
+    const void* const* ck_basis_exp_sigma; /* [nb_commitments] -> pk.CommitmentKeys[i].BasisExpSigma */
+    const uint64_t* ck_len;              /* [nb_commitments] number of points in each basis */
+    const uint64_t* k_remove;            /* sorted wire ids left out of the K MSM: every PrivateCommitted wire and every */
+    uint64_t len_k_remove;               /* commitment wire (the toRemove list of prove.go:233-235); len_k = nbWires - nbPublic - len_k_remove */
 } ga_g16_key;
 
 int ga_g16_pk_create(ga_ctx* ctx, const ga_g16_key* key, ga_g16_pk** out);
@@ -186,6 +193,31 @@ int ga_g16_finish(ga_g16_pk* pk, const void* partials_sum, const void* r, const 
 /* Proof.WriteTo wire format (marshal.go:33-58, no commitments): compressed Ar | Bs | Krs | u32 0 | PoK(inf).
  * Returns the number of bytes written in *len (164 for BN254, 244 for BLS12-381). */
 int ga_g16_proof_marshal(int curve, const void* proof, uint8_t* out, size_t cap, size_t* len);
+
+/* ---- BSB22 commitments ------------------------------------------------------------------
+ * replaces: the two commitment MSM blocks of the ICICLE prover -- pk.CommitmentKeys[i].Commit inside the solver hint
+ * (prove.go:84, icicle.go:834-873) and ProveKnowledge after the solve (prove.go:112-117, icicle.go:904-944).
+ * values = privateCommittedValues[i] (host, fr Montgomery, ck_len[i] elements).  Both MSMs run on the pinned bases with one
+ * upload of the scalars; outputs are G1Affine (Montgomery): the commitment the hint hashes, and this commitment's proof of
+ * knowledge (kept by the caller until all commitments are done, then folded). */
+int ga_g16_commit(ga_g16_pk* pk, uint32_t index, const void* values, uint64_t n_values, void* commitment_out, void* pok_out);
+/* proof.CommitmentPok.Fold(poks, challenge) (prove.go:127): sum_i challenge^i * poks[i]; host arithmetic (a handful of points).
+ * poks: n G1Affine; challenge: fr Montgomery; out: G1Affine. */
+int ga_g16_fold_pok(int curve, const void* poks, uint64_t n, const void* challenge, void* out);
+/* fr.Hash(msg, dst, count) of gnark-crypto (field/hash ExpandMsgXmd with SHA-256, L = 16 + fr.Bytes = 48 bytes per element,
+ * big-endian reduction mod r; same code shape as internal/smallfields/tinyfield/element.go:456-481): the commitment hint's
+ * hash_to_field.New("bsb22-commitment") (prove.go:57-58,88-98) and the fold challenge fr.Hash(..., "G16-BSB22", 1) (:123).
+ * out: count fr elements, Montgomery.  Host only. */
+int ga_hash_to_field(int curve, const uint8_t* msg, size_t msg_len, const uint8_t* dst, size_t dst_len, uint32_t count, void* out);
+/* expand_message_xmd (RFC 9380 5.3.1, SHA-256) on its own, so that tests can pin it to std/hash/expand/expand_test.go:52-140 */
+int ga_expand_message_xmd(const uint8_t* msg, size_t msg_len, const uint8_t* dst, size_t dst_len, size_t n, uint8_t* out);
+/* Proof.WriteTo with commitments (marshal.go:33-58): Ar | Bs | Krs | u32be n | n compressed commitments | compressed PoK.
+ * commitments: n G1Affine (may be NULL when n = 0), pok: G1Affine or NULL (= infinity). */
+int ga_g16_proof_marshal_bsb22(int curve, const void* proof, const void* commitments, uint32_t n, const void* pok,
+                               uint8_t* out, size_t cap, size_t* len);
+/* G1Affine.Marshal() (uncompressed big-endian x | y; what SerializeCommitment hashes, constraint/commitment.go:76-89,
+ * prove.go:88).  out: 64 bytes (BN254) / 96 bytes (BLS12-381). */
+int ga_g1_marshal_uncompressed(int curve, const void* affine, uint8_t* out, size_t cap, size_t* len);
 
 /* ---- profiling hooks (ICICLE_STEP_PROFILE analogue, icicle.go:72-75) ------------------------------------
  * When enabled, every kernel stage is bracketed by hipEvents on the stream it is launched on; ga_profile_read

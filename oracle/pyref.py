@@ -21,7 +21,7 @@ against in tests/test_oracle_fixtures.py).
 from __future__ import annotations
 
 import hashlib
-from dataclasses import dataclass
+from dataclasses import dataclass, field
 
 # ----------------------------------------------------------------------------------------------
 # curve parameter sets
@@ -493,6 +493,16 @@ class R1CS:
     L: list
     R: list
     O: list
+    commitments: list = field(default_factory=list)   # constraint.Groth16Commitments (constraint/commitment.go:9-14)
+
+
+@dataclass
+class Commitment:
+    """constraint/commitment.go:9-14 Groth16Commitment"""
+    public_and_commitment_committed: list   # sorted wire ids (public wires first, then earlier commitment wires)
+    private_committed: list                 # sorted wire ids
+    commitment_index: int                   # wire that receives the hash of the commitment
+    nb_public_committed: int
 
 
 def cubic_r1cs() -> R1CS:
@@ -510,6 +520,31 @@ def cubic_r1cs() -> R1CS:
 def cubic_witness(x=3):
     y = x ** 3 + x + 5
     return [1, y, x, x * x, x * x * x]
+
+
+def commit_r1cs() -> R1CS:
+    """A hand-written circuit with two api.Commit calls, shaped like the ones test/commitments_test.go builds: wires
+    {0:1, 1:p (public), 2:x, 3:y (secret), 4:v=x*y, 5:cm0, 6:t=cm0*x, 7:cm1, 8:u=cm1*v}; commitment 0 commits to the private
+    wires {x, y} and the public wire p, commitment 1 to the private wire v and to commitment 0's wire.  Commitment wires are
+    hint outputs, i.e. internal wires for the solver and public inputs for the Groth16 setup (setup.go:94-98)."""
+    L = [{2: 1}, {4: 1}, {5: 1}, {7: 1}]
+    R = [{3: 1}, {0: 1}, {2: 1}, {4: 1}]
+    O = [{4: 1}, {1: 1}, {6: 1}, {8: 1}]
+    cms = [Commitment([1], [2, 3], 5, 1), Commitment([5], [4], 7, 0)]
+    return R1CS(nb_public=2, nb_wires=9, L=L, R=R, O=O, commitments=cms)
+
+
+def commit_solve(c: Curve, cs: R1CS, x: int, y: int, hint) -> list:
+    """Solve commit_r1cs in wire order; hint(i, w) returns the value of commitment i's wire (the bsb22 hint, prove.go:72-100)."""
+    w = [0] * cs.nb_wires
+    w[0], w[2], w[3] = 1, x % c.r, y % c.r
+    w[4] = w[2] * w[3] % c.r
+    w[1] = w[4]
+    w[5] = hint(0, w)
+    w[6] = w[5] * w[2] % c.r
+    w[7] = hint(1, w)
+    w[8] = w[7] * w[4] % c.r
+    return w
 
 
 def r1cs_solve(c: Curve, cs: R1CS, w):
@@ -540,6 +575,7 @@ class ProvingKey:
     B2: list
     infinityA: list
     infinityB: list
+    commitment_keys: list = field(default_factory=list)   # [(Basis, BasisExpSigma)] pedersen.ProvingKey (setup.go:276-287)
 
 
 @dataclass
@@ -549,11 +585,13 @@ class VerifyingKey:
     gamma2: tuple
     delta2: tuple
     K: list
+    commitment_g2: tuple = None                 # pedersen.VerifyingKey.G (shared, setup.go:272-281)
+    commitment_g2_sigma_neg: list = field(default_factory=list)   # [-sigma_i]G per commitment key
 
 
 def groth16_setup(c: Curve, cs: R1CS, toxic):
     """setup.go:75-331 with injected toxic waste (alpha,beta,gamma,delta,tau)."""
-    alpha, beta, gamma, delta, tau = toxic
+    alpha, beta, gamma, delta, tau = toxic[:5]   # then one sigma per commitment, then the dlog of the pedersen G2 point
     mod = c.r
     m = len(cs.L)
     n = 1
@@ -577,10 +615,29 @@ def groth16_setup(c: Curve, cs: R1CS, toxic):
     G1, G2 = g1_group(c), g2_group(c)
     g1, g2 = c.g1, c.g2
     dinv, ginv = pow(delta, -1, mod), pow(gamma, -1, mod)
-    # K scalars (setup.go:142-178): public part / gamma (vk), private part / delta (pk)
+    # K scalars (setup.go:133-178): public wires and commitment wires / gamma -> vk.K; private committed wires / gamma ->
+    # the commitment bases ckK[i]; every other private wire / delta -> pk.K
     kk = [(beta * Av[i] + alpha * Bv[i] + Cv[i]) % mod for i in range(nw)]
-    vkK = [G1.mul(g1, kk[i] * ginv % mod) for i in range(cs.nb_public)]
-    pkK = [G1.mul(g1, kk[i] * dinv % mod) for i in range(cs.nb_public, nw)]
+    com_wires = {cm.commitment_index for cm in cs.commitments}
+    owner = {wi: ci for ci, cm in enumerate(cs.commitments) for wi in cm.private_committed}
+    vk_s, pk_s, ck_s = [], [], [[] for _ in cs.commitments]
+    for i in range(nw):
+        if i < cs.nb_public or i in com_wires:
+            vk_s.append(kk[i] * ginv % mod)
+        elif i in owner:
+            ck_s[owner[i]].append(kk[i] * ginv % mod)
+        else:
+            pk_s.append(kk[i] * dinv % mod)
+    vkK = [G1.mul(g1, k) for k in vk_s]
+    pkK = [G1.mul(g1, k) for k in pk_s]
+    # pedersen.Setup per commitment (setup.go:280-287; gnark-crypto [EXT]): BasisExpSigma = [sigma]Basis, vk.GSigmaNeg = [-sigma]G
+    sigmas = list(toxic[5:5 + len(cs.commitments)]) if len(toxic) > 5 else []
+    assert len(sigmas) == len(cs.commitments), "one sigma per commitment must be injected after (alpha,beta,gamma,delta,tau)"
+    cg2_dlog = toxic[5 + len(cs.commitments)] if len(toxic) > 5 + len(cs.commitments) else 1
+    cks = []
+    for ci in range(len(cs.commitments)):
+        basis = [G1.mul(g1, k) for k in ck_s[ci]]
+        cks.append((basis, [G1.mul(P, sigmas[ci]) for P in basis]))
     # Z scalars tau^i (tau^n - 1)/delta (setup.go:181-192), stored bit-reversed (:247), n-1 kept (:248-249)
     zs = [pow(tau, i, mod) * tn1 % mod * dinv % mod for i in range(n)]
     Zp = bitrev_permute([G1.mul(g1, z) for z in zs])[: n - 1]
@@ -594,16 +651,65 @@ def groth16_setup(c: Curve, cs: R1CS, toxic):
         Z=Zp, K=pkK,
         beta2=G2.mul(g2, beta), delta2=G2.mul(g2, delta),
         B2=[G2.mul(g2, b) for b in Bv if b != 0],
-        infinityA=infA, infinityB=infB)
-    vk = VerifyingKey(alpha1=pk.alpha1, beta2=pk.beta2, gamma2=G2.mul(g2, gamma), delta2=pk.delta2, K=vkK)
+        infinityA=infA, infinityB=infB, commitment_keys=cks)
+    cg2 = G2.mul(g2, cg2_dlog)
+    vk = VerifyingKey(alpha1=pk.alpha1, beta2=pk.beta2, gamma2=G2.mul(g2, gamma), delta2=pk.delta2, K=vkK,
+                      commitment_g2=cg2, commitment_g2_sigma_neg=[G2.mul(cg2, (-sg) % mod) for sg in sigmas])
     dlog = dict(A=[a for a in Av if a], B=[b for b in Bv if b], Z=bitrev_permute(zs)[: n - 1],
-                K=[kk[i] * dinv % mod for i in range(cs.nb_public, nw)],
-                alpha=alpha, beta=beta, delta=delta)
+                K=pk_s, CK=ck_s, kk=kk, alpha=alpha, beta=beta, delta=delta, sigmas=sigmas)
     return pk, vk, dlog
 
 
+# ---- BSB22 commitments: hash-to-field and the solver-side hint (prove.go:60-127) ------------------------------------------
+COMMITMENT_DST = b"bsb22-commitment"   # constraint/commitment.go:7
+FOLD_DST = b"G16-BSB22"                # prove.go:123
+
+
+def expand_message_xmd(msg: bytes, dst: bytes, n: int) -> bytes:
+    """RFC 9380 5.3.1 with SHA-256 (gnark-crypto field/hash.ExpandMsgXmd [EXT]); pinned by the vectors of
+    std/hash/expand/expand_test.go:52-140."""
+    ell = (n + 31) // 32
+    assert ell <= 255 and len(dst) <= 255
+    dst_prime = dst + bytes([len(dst)])
+    b0 = hashlib.sha256(bytes(64) + msg + n.to_bytes(2, "big") + b"\x00" + dst_prime).digest()
+    out, bi = b"", b""
+    for i in range(1, ell + 1):
+        x = b0 if i == 1 else bytes(a ^ b for a, b in zip(b0, bi))
+        bi = hashlib.sha256(x + bytes([i]) + dst_prime).digest()
+        out += bi
+    return out[:n]
+
+
+def fr_hash(c: Curve, msg: bytes, dst: bytes, count: int = 1) -> list:
+    """fr.Hash (same template as internal/smallfields/tinyfield/element.go:456-481): L = 16 + fr.Bytes bytes per element,
+    big-endian, reduced mod r."""
+    L = 16 + (c.r.bit_length() + 7) // 8
+    b = expand_message_xmd(msg, dst, count * L)
+    return [int.from_bytes(b[i * L:(i + 1) * L], "big") % c.r for i in range(count)]
+
+
+def g1_marshal_uncompressed(c: Curve, P) -> bytes:
+    """G1Affine.Marshal() [EXT]: big-endian x | y; infinity = flag byte 0x40 then zeros."""
+    nb = c.fp_bytes
+    if P is None:
+        return bytes([0x40]) + bytes(2 * nb - 1)
+    return P[0].to_bytes(nb, "big") + P[1].to_bytes(nb, "big")
+
+
+def commitment_hint(pk: ProvingKey, cs: R1CS, i: int, w) -> tuple:
+    """The bsb22 hint override of prove.go:72-100 for commitment i on the partially solved wire vector w: returns
+    (commitment point, value of the commitment wire)."""
+    c = pk.curve
+    cm = cs.commitments[i]
+    G1 = g1_group(c)
+    com = G1.msm(pk.commitment_keys[i][0], [w[j] for j in cm.private_committed])
+    fbytes = (c.r.bit_length() - 1) // 8 + 1
+    msg = g1_marshal_uncompressed(c, com) + b"".join(int(w[j]).to_bytes(fbytes, "big") for j in cm.public_and_commitment_committed)
+    return com, fr_hash(c, msg, COMMITMENT_DST, 1)[0]
+
+
 def groth16_prove(pk: ProvingKey, cs: R1CS, w, r, s):
-    """prove.go:52-315 with injected (r, s), no commitments.  Returns affine (Ar, Bs, Krs)."""
+    """prove.go:52-315 with injected (r, s).  Returns affine (Ar, Bs, Krs); with commitments use groth16_prove_bsb22."""
     c = pk.curve
     mod = c.r
     G1, G2 = g1_group(c), g2_group(c)
@@ -616,7 +722,8 @@ def groth16_prove(pk: ProvingKey, cs: R1CS, w, r, s):
     bs1 = G1.add(G1.add(G1.msm(pk.B, wB), pk.beta1), deltas[1])
     ar = G1.add(G1.add(G1.msm(pk.A, wA), pk.alpha1), deltas[0])
     krs2 = G1.msm(pk.Z, h[: pk.n - 1])
-    krs = G1.msm(pk.K, w[cs.nb_public:])
+    removed = {j for cm in cs.commitments for j in cm.private_committed} | {cm.commitment_index for cm in cs.commitments}
+    krs = G1.msm(pk.K, [w[i] for i in range(cs.nb_public, len(w)) if i not in removed])   # filterHeap, prove.go:231-235
     krs = G1.add(krs, deltas[2])
     krs = G1.add(krs, krs2)
     krs = G1.add(krs, G1.mul(ar, s))
@@ -625,10 +732,31 @@ def groth16_prove(pk: ProvingKey, cs: R1CS, w, r, s):
     return ar, bs, krs
 
 
-def proof_bytes(c: Curve, ar, bs, krs) -> bytes:
-    """Proof.WriteTo, marshal.go:33-58: Ar | Bs | Krs | u32 len(commitments)=0 | CommitmentPok (infinity)."""
-    return (g1_compress(c, ar) + g2_compress(c, bs) + g1_compress(c, krs) + (0).to_bytes(4, "big")
-            + g1_compress(c, None))
+def groth16_prove_bsb22(pk: ProvingKey, cs: R1CS, w, r, s):
+    """prove.go:52-315 for a circuit with commitments; w is the full solution (commitment wires already set by
+    commitment_hint).  Returns (Ar, Bs, Krs, commitments, folded PoK)."""
+    c = pk.curve
+    G1 = g1_group(c)
+    coms, poks = [], []
+    for i, cm in enumerate(cs.commitments):
+        vals = [w[j] for j in cm.private_committed]
+        com, hv = commitment_hint(pk, cs, i, w)
+        assert hv == w[cm.commitment_index], "commitment wire does not hold the hash of the commitment"
+        coms.append(com)
+        poks.append(G1.msm(pk.commitment_keys[i][1], vals))                     # ProveKnowledge, prove.go:112-117
+    ser = b"".join(int(w[cm.commitment_index]).to_bytes(32, "big") for cm in cs.commitments)   # prove.go:119-122
+    pok = None
+    if cs.commitments:
+        ch = fr_hash(c, ser, FOLD_DST, 1)[0]
+        pok = G1.msm(poks, [pow(ch, i, c.r) for i in range(len(poks))])      # Fold, prove.go:127
+    ar, bs, krs = groth16_prove(pk, cs, w, r, s)
+    return ar, bs, krs, coms, pok
+
+
+def proof_bytes(c: Curve, ar, bs, krs, commitments=(), pok=None) -> bytes:
+    """Proof.WriteTo, marshal.go:33-58: Ar | Bs | Krs | u32 len(commitments) | commitments | CommitmentPok."""
+    return (g1_compress(c, ar) + g2_compress(c, bs) + g1_compress(c, krs) + len(commitments).to_bytes(4, "big")
+            + b"".join(g1_compress(c, P) for P in commitments) + g1_compress(c, pok))
 
 
 def sha_tag(*parts) -> str:

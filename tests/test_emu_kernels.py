@@ -252,3 +252,87 @@ def test_emu_groth16_cubic(emu_ctx, c, precompute):
     assert arr_to_g2_affine(c, proof.Bs) == bs
     assert arr_to_g1_affine(c, proof.Krs) == krs
     assert proof.WriteTo() == pyref.proof_bytes(c, ar, bs, krs)
+
+
+def _xmd_vectors():
+    import json, os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "expand_msg_xmd.json")) as f:
+        return json.load(f)
+
+
+def test_emu_hash_to_field(emu_ctx):
+    """the library's host hash-to-field: expand_message_xmd against the reference's vectors
+    (std/hash/expand/expand_test.go:52-140), fr.Hash against the oracle for both scalar fields"""
+    import ctypes as C
+    lib = emu_ctx.lib
+    g = _xmd_vectors()
+    dst = np.frombuffer(g["dst"].encode(), dtype=np.uint8)
+    for v in g["vectors"]:
+        msg = np.frombuffer(v["msg"].encode(), dtype=np.uint8) if v["msg"] else np.zeros(1, dtype=np.uint8)
+        out = np.zeros(v["len_in_bytes"], dtype=np.uint8)
+        lib.check(lib.ga_expand_message_xmd(msg.ctypes.data_as(C.c_void_p), len(v["msg"]), dst.ctypes.data_as(C.c_void_p), dst.size,
+                                            out.size, out.ctypes.data_as(C.c_void_p)))
+        assert out.tobytes().hex() == v["uniform_bytes_hex"]
+    rng = pyref.Xoshiro(31)
+    for c in CURVES:
+        for ln in (0, 1, 55, 56, 64, 200):
+            msg = bytes(rng.next() & 0xFF for _ in range(ln))
+            got = groth16.HashToField(c.name, msg, groth16.FOLD_DST, 3, lib=lib)
+            assert arr_to_fr(c, got) == pyref.fr_hash(c, msg, pyref.FOLD_DST, 3)
+
+
+@pytest.mark.parametrize("precompute", [1, -1], ids=["tables", "no-tables"])
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_emu_groth16_bsb22_commitments(emu_ctx, c, precompute):
+    """a circuit with two api.Commit calls.  The solver-side hint calls ProvingKey.Commit (device MSMs over
+    the pinned pedersen bases) and hashes the commitment; Prove leaves the committed wires out of the K MSM; the folded proof
+    of knowledge and the proof bytes equal the oracle's (prove.go:60-127,231-235, marshal.go:33-58)."""
+    lib = emu_ctx.lib
+    rng = pyref.Xoshiro(4242)
+    cs = pyref.commit_r1cs()
+    toxic = [rng.field(c.r) for _ in range(5 + len(cs.commitments) + 1)]
+    pk, vk, _ = pyref.groth16_setup(c, cs, toxic)
+    removed = sorted({j for cm in cs.commitments for j in cm.private_committed} | {cm.commitment_index for cm in cs.commitments})
+    dpk = groth16.ProvingKey(
+        emu_ctx, c.name, domain_cardinality=pk.n,
+        alpha1=pts_to_arr(c, 0, [pk.alpha1]), beta1=pts_to_arr(c, 0, [pk.beta1]), delta1=pts_to_arr(c, 0, [pk.delta1]),
+        A=pts_to_arr(c, 0, pk.A), B=pts_to_arr(c, 0, pk.B), Z=pts_to_arr(c, 0, pk.Z), K=pts_to_arr(c, 0, pk.K),
+        beta2=pts_to_arr(c, 1, [pk.beta2]), delta2=pts_to_arr(c, 1, [pk.delta2]), B2=pts_to_arr(c, 1, pk.B2),
+        infinityA=pk.infinityA, infinityB=pk.infinityB, precompute=precompute,
+        commitment_keys=[(pts_to_arr(c, 0, b), pts_to_arr(c, 0, e)) for b, e in pk.commitment_keys], k_remove=removed)
+    coms, poks = {}, {}
+    fbytes = (c.r.bit_length() - 1) // 8 + 1
+
+    def hint(i, w):   # the bsb22 hint override (prove.go:72-100) with the device doing the MSMs
+        cm = cs.commitments[i]
+        coms[i], poks[i] = dpk.Commit(i, fr_to_arr(c, [w[j] for j in cm.private_committed]))
+        msg = groth16.MarshalG1(c.name, coms[i], lib=lib) + b"".join(int(w[j]).to_bytes(fbytes, "big") for j in cm.public_and_commitment_committed)
+        return arr_to_fr(c, groth16.HashToField(c.name, msg, groth16.COMMITMENT_DST, 1, lib=lib))[0]
+
+    try:
+        w = pyref.commit_solve(c, cs, 3, 11, hint)
+        assert w == pyref.commit_solve(c, cs, 3, 11, lambda i, ww: pyref.commitment_hint(pk, cs, i, ww)[1])
+        r, s = rng.field(c.r), rng.field(c.r)
+        A, B, Cc = pyref.r1cs_solve(c, cs, w)
+        sol = groth16.Solution(W=fr_to_arr(c, w), A=fr_to_arr(c, A), B=fr_to_arr(c, B), C=fr_to_arr(c, Cc))
+        proof = groth16.Prove(dpk, sol, cs.nb_public, fr_to_arr(c, [r]), fr_to_arr(c, [s]))
+        with pytest.raises(Exception, match="values for a basis"):
+            dpk.Commit(0, fr_to_arr(c, [1, 2, 3]))
+        with pytest.raises(Exception, match="commitment 2 of 2"):
+            dpk.Commit(2, fr_to_arr(c, [1]))
+    finally:
+        dpk.FreeGPUResources()
+    ser = b"".join(int(w[cm.commitment_index]).to_bytes(32, "big") for cm in cs.commitments)
+    challenge = groth16.HashToField(c.name, ser, groth16.FOLD_DST, 1, lib=lib)
+    proof.Commitments = np.stack([coms[i] for i in range(len(cs.commitments))])
+    proof.CommitmentPok = groth16.FoldPok(c.name, np.stack([poks[i] for i in range(len(cs.commitments))]), challenge, lib=lib)
+    ar, bs, krs, ocoms, opok = pyref.groth16_prove_bsb22(pk, cs, w, r, s)
+    assert [arr_to_g1_affine(c, x) for x in proof.Commitments] == ocoms
+    assert arr_to_g1_affine(c, proof.CommitmentPok) == opok
+    assert (arr_to_g1_affine(c, proof.Ar), arr_to_g2_affine(c, proof.Bs), arr_to_g1_affine(c, proof.Krs)) == (ar, bs, krs)
+    assert proof.WriteTo() == pyref.proof_bytes(c, ar, bs, krs, ocoms, opok)
+    # pedersen verification in the exponent: pok_i = [sigma_i] commitment_i, folded with the challenge powers
+    G1 = group_of(c, 0)
+    sig = toxic[5:7]
+    ch = pyref.fr_hash(c, ser, pyref.FOLD_DST, 1)[0]
+    assert opok == G1.msm(ocoms, [sg * pow(ch, i, c.r) % c.r for i, sg in enumerate(sig)])

@@ -260,6 +260,74 @@ def test_groth16_synthetic_2_10_vs_oracle(gpu_ctx, c):
     assert len(proof.WriteTo()) == (164 if c.cid == 0 else 244)
 
 
+@pytest.mark.parametrize("precompute", [1, -1], ids=["tables", "no-tables"])
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_groth16_bsb22_commitments_bytes(gpu_ctx, c, precompute):
+    cases.test_emu_groth16_bsb22_commitments(gpu_ctx, c, precompute)
+
+
+def test_hash_to_field_host(gpu_ctx):
+    cases.test_emu_hash_to_field(gpu_ctx)
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_groth16_bsb22_synthetic_2_14_vs_oracle(gpu_ctx, c):
+    """Commitments at a size where the MSM pipeline (not the tiny-input path) runs: 2 commitment keys of 2^12 and 37 points,
+    a K MSM with the committed wires filtered out on device; everything against the C oracle (commitment / PoK = plain MSMs,
+    Krs via a K vector with infinity at the removed wires)."""
+    ctx, lib = gpu_ctx, gpu_ctx.lib
+    n = 1 << 14
+    nw, nb_public = n, 3
+    wa = affine_words(c.cid, 0)
+
+    def gen(group, count, seed):
+        buf = ctx.malloc(count * affine_words(c.cid, group) * 8)
+        lib.check(lib.ga_gen_bases(ctx.handle, c.cid, group, seed, count, buf.ptr, None))
+        h = buf.to_host((count, affine_words(c.cid, group)))
+        buf.free()
+        return h
+
+    def scal(count, seed):
+        buf = ctx.malloc(count * 32)
+        lib.check(lib.ga_gen_scalars(ctx.handle, c.cid, seed, count, buf.ptr))
+        h = buf.to_host((count, 4))
+        buf.free()
+        return h
+    rng = np.random.default_rng(8)
+    committed = [np.sort(rng.choice(np.arange(nb_public, nw - 2), size=sz, replace=False)) for sz in (1 << 12, 37)]
+    committed[1] = np.setdiff1d(committed[1], committed[0])
+    com_wires = np.array([nw - 2, nw - 1])
+    removed = np.sort(np.concatenate(committed + [com_wires]))
+    keep = np.setdiff1d(np.arange(nb_public, nw), removed)
+    infA = np.zeros(nw, np.uint8)
+    infB = np.zeros(nw, np.uint8)
+    infA[[1, 5]] = 1
+    infB[[0, 7, 9]] = 1
+    m1, m2 = gen(0, 3, 1), gen(1, 2, 2)
+    Kc = gen(0, keep.size, 6)
+    Kfull = np.zeros((nw - nb_public, wa), np.uint64)   # oracle view: infinity where the wire is committed
+    Kfull[keep - nb_public] = Kc
+    key = dict(n=n, alpha1=m1[0:1], beta1=m1[1:2], delta1=m1[2:3], A=gen(0, nw - 2, 3), B=gen(0, nw - 3, 4), Z=gen(0, n - 1, 5),
+               K=Kfull, beta2=m2[0:1], delta2=m2[1:2], B2=gen(1, nw - 3, 7), infinityA=infA, infinityB=infB)
+    cks = [(gen(0, len(cw), 20 + i), gen(0, len(cw), 30 + i)) for i, cw in enumerate(committed)]
+    m = n - 5
+    W, A, B = scal(nw, 10), scal(m, 11), scal(m, 12)
+    Cc = oracle.fr_mul(c.cid, A, B)
+    rs = scal(2, 13)
+    want = oracle.groth16_prove(c.cid, key, W, A, B, Cc, nb_public, rs[0], rs[1], nthreads=8)
+    pk = groth16.ProvingKey(ctx, c.name, domain_cardinality=n, precompute=1, commitment_keys=cks, k_remove=removed,
+                            **{k: (Kc if k == "K" else v) for k, v in key.items() if k != "n"})
+    try:
+        for i, cw in enumerate(committed):
+            com, pok = pk.Commit(i, W[cw])
+            assert np.array_equal(com, oracle.jac_to_affine(c.cid, 0, oracle.msm(c.cid, 0, cks[i][0], W[cw], nthreads=8)))
+            assert np.array_equal(pok, oracle.jac_to_affine(c.cid, 0, oracle.msm(c.cid, 0, cks[i][1], W[cw], nthreads=8)))
+        proof = groth16.Prove(pk, groth16.Solution(W, A, B, Cc), nb_public, rs[0], rs[1])
+    finally:
+        pk.FreeGPUResources()
+    assert np.array_equal(proof.Ar, want[0]) and np.array_equal(proof.Bs, want[1]) and np.array_equal(proof.Krs, want[2])
+
+
 def test_loaded_library_is_the_hip_build(gpu_ctx):
     assert gpu_ctx.lib.path.endswith("gnark_amd/libgnark_amd.so")
     info = gpu_ctx.info()

@@ -129,3 +129,52 @@ def test_bellman_tuple_points_decode():
     pyref.g1_decompress(c, vk[:48])
     pyref.g1_decompress(c, vk[48:96])
     pyref.g2_decompress(c, vk[96:192])
+
+
+def test_expand_message_xmd_reference_vectors():
+    """std/hash/expand/expand_test.go:52-140 (16 vectors: 32, 48 and 128 output bytes) pin the oracle's hash-to-field, i.e. the
+    BSB22 commitment hint (prove.go:88-98) and the PoK fold challenge (prove.go:123)."""
+    import json
+    g = json.load(open(os.path.join(GOLD, "expand_msg_xmd.json")))
+    assert len(g["vectors"]) == 16
+    for v in g["vectors"]:
+        assert pyref.expand_message_xmd(v["msg"].encode(), g["dst"].encode(), v["len_in_bytes"]).hex() == v["uniform_bytes_hex"]
+
+
+def test_groth16_bsb22_equation_in_the_exponent():
+    """Groth16 with commitments (setup.go:133-178,260-287, prove.go:60-127,231-235, verify.go:75-125) restated in the oracle:
+    the verifier's equation holds in the exponent, with the commitments standing in for the private committed wires, and the
+    folded proof of knowledge is [sigma_i]-related to the commitments."""
+    for c in (pyref.BN254, pyref.BLS12_381):
+        rng = pyref.Xoshiro(99)
+        cs = pyref.commit_r1cs()
+        toxic = [rng.field(c.r) for _ in range(8)]
+        pk, vk, dl = pyref.groth16_setup(c, cs, toxic)
+        assert len(pk.K) == 2 and [len(b) for b, _ in pk.commitment_keys] == [2, 1] and len(vk.K) == 4
+        w = pyref.commit_solve(c, cs, 5, 7, lambda i, ww: pyref.commitment_hint(pk, cs, i, ww)[1])
+        r, s = rng.field(c.r), rng.field(c.r)
+        ar, bs, krs, coms, pok = pyref.groth16_prove_bsb22(pk, cs, w, r, s)
+        mod = c.r
+        alpha, beta, gamma, delta, tau = toxic[:5]
+        A, B, C = pyref.r1cs_solve(c, cs, w)
+        a_dl = (alpha + sum(x * k for x, k in zip([w[i] for i in range(len(w)) if not pk.infinityA[i]], dl["A"])) + r * delta) % mod
+        b_dl = (beta + sum(x * k for x, k in zip([w[i] for i in range(len(w)) if not pk.infinityB[i]], dl["B"])) + s * delta) % mod
+        removed = {j for cm in cs.commitments for j in cm.private_committed} | {cm.commitment_index for cm in cs.commitments}
+        kw = [w[i] for i in range(cs.nb_public, len(w)) if i not in removed]
+        h = pyref.compute_h(c, A, B, C, pk.n)
+        krs_dl = (sum(x * k for x, k in zip(kw, dl["K"])) + sum(x * k for x, k in zip(h, dl["Z"])) + s * a_dl + r * b_dl - r * s * delta) % mod
+        G1 = pyref.g1_group(c)
+        assert G1.mul(c.g1, krs_dl) == krs
+        # kSum of verify.go:112-121 in the exponent: public wires, commitment wires (hash values) and the commitments themselves
+        ginv = pow(gamma, -1, mod)
+        com_dl = [sum(w[j] * k for j, k in zip(cm.private_committed, dl["CK"][i])) % mod for i, cm in enumerate(cs.commitments)]
+        assert [G1.mul(c.g1, d) for d in com_dl] == coms
+        vk_wires = [i for i in range(len(w)) if i < cs.nb_public or i in {cm.commitment_index for cm in cs.commitments}]
+        ksum = (sum(w[i] * dl["kk"][i] * ginv for i in vk_wires) + sum(com_dl)) % mod
+        assert a_dl * b_dl % mod == (alpha * beta + ksum * gamma + krs_dl * delta) % mod
+        ser = b"".join(int(w[cm.commitment_index]).to_bytes(32, "big") for cm in cs.commitments)
+        ch = pyref.fr_hash(c, ser, pyref.FOLD_DST, 1)[0]
+        assert pok == G1.mul(c.g1, sum(sg * pow(ch, i, mod) * com_dl[i] for i, sg in enumerate(dl["sigmas"])) % mod)
+        # proof wire format with commitments (marshal.go:33-58): 3 points, u32 count, commitments, pok
+        nb = c.fp_bytes
+        assert len(pyref.proof_bytes(c, ar, bs, krs, coms, pok)) == 4 * nb + 4 + 2 * nb + nb

@@ -7,6 +7,7 @@ exists; the GPU box only sees the committed outputs).
                          (Montgomery limbs) + the compressed bytes of the first 8 entries (decompression KATs)
   vk_*.bin               backend/solidity/testdata/blank_groth16_{bn254,bls12381}_nocommit.vk (serialized VKs, raw)
   bellman_bls12381.json  the first (vk, proof) tuple of backend/groth16/bellman_test.go:26-40 (base64 as in the file)
+  expand_msg_xmd.json    the 16 expand_message_xmd (SHA-256) vectors of std/hash/expand/expand_test.go:44-140 (32, 48 and 128 output bytes)
 """
 import base64
 import json
@@ -46,6 +47,14 @@ def main():
     src = open(os.path.join(REF, "backend/groth16/bellman_test.go")).read()
     strs = re.findall(r'"([A-Za-z0-9+/=]{40,})"', src)
     json.dump({"vk": strs[0], "proof": strs[1], "inputs": strs[2] if len(strs) > 2 else ""}, open(os.path.join(OUT, "bellman_bls12381.json"), "w"))
+    # expand_message_xmd known answers (std/hash/expand/expand_test.go:44-140, "adapted from gnark-crypto/field/hash"): they pin
+    # the hash-to-field used by the BSB22 commitment hint and the PoK fold challenge
+    src = open(os.path.join(REF, "std/hash/expand/expand_test.go")).read()
+    dst = re.search(r'dst := "([^"]+)"', src).group(1)
+    vecs = re.findall(r'\{\s*"([^"]*)",\s*(0x[0-9a-fA-F]+),\s*"([0-9a-f]+)",\s*\}', src)
+    assert len(vecs) == 16
+    json.dump({"dst": dst, "vectors": [{"msg": m, "len_in_bytes": int(n, 16), "uniform_bytes_hex": h} for m, n, h in vecs]},
+              open(os.path.join(OUT, "expand_msg_xmd.json"), "w"), indent=1)
     print("wrote", sorted(os.listdir(OUT)))
 
 
