@@ -45,6 +45,17 @@ class G16Key(C.Structure):
     ]
 
 
+class PlonkQuotientIn(C.Structure):
+    """struct ga_plonk_quotient_in"""
+    _fields_ = [("nb_bsb", C.c_uint32)] + [(k, C.c_void_p) for k in ("l", "r", "o", "z", "ql", "qr", "qm", "qo", "qk", "s1", "s2", "s3")] + [
+        ("qcp", C.POINTER(C.c_void_p)), ("pi2", C.POINTER(C.c_void_p)),
+        ("lagrange_mask", C.c_uint64),
+        ("bl", C.c_void_p), ("br", C.c_void_p), ("bo", C.c_void_p), ("bz", C.c_void_p),
+        ("alpha", C.c_void_p), ("beta", C.c_void_p), ("gamma", C.c_void_p),
+        ("flags", C.c_uint32),
+    ]
+
+
 _P = C.c_void_p
 _PROTOS = {
     "ga_device_count": (C.c_int, [C.POINTER(C.c_int)]),
@@ -74,6 +85,9 @@ _PROTOS = {
     "ga_domain_destroy": (None, [_P]),
     "ga_fft": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ga_compute_h": (C.c_int, [_P, _P, _P, _P, C.c_uint64, _P, C.c_int]),
+    "ga_plonk_quotient": (C.c_int, [_P, _P, C.POINTER(PlonkQuotientIn), _P]),
+    "ga_plonk_build_z": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
+    "ga_fr_batch_invert": (C.c_int, [_P, C.c_int, _P, C.c_uint64, C.c_int]),
     "ga_g16_pk_create": (C.c_int, [_P, C.POINTER(G16Key), C.POINTER(_P)]),
     "ga_g16_pk_destroy": (None, [_P]),
     "ga_g16_prove": (C.c_int, [_P, _P, _P, _P, _P, C.c_uint64, C.c_uint64, _P, _P, _P]),

@@ -433,6 +433,73 @@ int ga_fft(ga_domain* dh, void* data, int direction, int decimation, int on_cose
     return GA_OK;
 }
 
+int ga_plonk_quotient(ga_domain* dh0, ga_domain* dh1, const ga_plonk_quotient_in* in, void* h_out) {
+    Domain *d0 = reinterpret_cast<Domain*>(dh0), *d1 = reinterpret_cast<Domain*>(dh1);
+    if (!d0 || !d1 || !in || !h_out || !in->l || !in->r || !in->o || !in->z || !in->ql || !in->qr || !in->qm || !in->qo || !in->qk ||
+        !in->s1 || !in->s2 || !in->s3 || !in->bl || !in->br || !in->bo || !in->bz || !in->alpha || !in->beta || !in->gamma ||
+        (in->nb_bsb && (!in->qcp || !in->pi2))) {
+        set_error("ga_plonk_quotient: null argument");
+        return GA_ERR_INVALID;
+    }
+    if (in->nb_bsb > (uint32_t)PLONK_MAX_BSB || ntt_domain_curve(d0) != ntt_domain_curve(d1) || ntt_domain_ctx(d0) != ntt_domain_ctx(d1)) {
+        set_error("ga_plonk_quotient: more than %d BSB22 gates, or the two domains differ in curve/context", PLONK_MAX_BSB);
+        return GA_ERR_INVALID;
+    }
+    Ctx* c = ntt_domain_ctx(d0);
+    Lock l(c);
+    PlonkQuotientArgs a;
+    memset(&a, 0, sizeof(a));
+    a.nb_bsb = in->nb_bsb;
+    const void* fixed[PLONK_NB_FIXED] = {in->l, in->r, in->o, in->z, in->ql, in->qr, in->qm, in->qo, in->qk, in->s1, in->s2, in->s3};
+    for (int k = 0; k < PLONK_NB_FIXED; k++) a.polys[k] = fixed[k];
+    for (uint32_t k = 0; k < in->nb_bsb; k++) {
+        if (!in->qcp[k] || !in->pi2[k]) {
+            set_error("ga_plonk_quotient: null Qcp / Pi2 polynomial %u", k);
+            return GA_ERR_INVALID;
+        }
+        a.polys[PLONK_NB_FIXED + 2 * k] = in->qcp[k];
+        a.polys[PLONK_NB_FIXED + 2 * k + 1] = in->pi2[k];
+    }
+    a.lagrange_mask = in->lagrange_mask;
+    a.on_device = (in->flags & GA_PLONK_ON_DEVICE) != 0;
+    a.bl = in->bl; a.br = in->br; a.bo = in->bo; a.bz = in->bz;
+    a.alpha = in->alpha; a.beta = in->beta; a.gamma = in->gamma;
+    GA_DISPATCH_CURVE(ntt_domain_curve(d0), GA_CHECK(plonk_domain_quotient<C>(d0, d1, a, h_out)));
+    return GA_OK;
+}
+
+int ga_plonk_build_z(ga_domain* dh0, const void* lv, const void* rv, const void* ov, const int64_t* permutation, const void* beta,
+                     const void* gamma, int on_device, void* z_out) {
+    Domain* d0 = reinterpret_cast<Domain*>(dh0);
+    if (!d0 || !lv || !rv || !ov || !permutation || !beta || !gamma || !z_out) {
+        set_error("ga_plonk_build_z: null argument");
+        return GA_ERR_INVALID;
+    }
+    Ctx* c = ntt_domain_ctx(d0);
+    Lock l(c);
+    if (!on_device) {
+        const uint64_t n3 = 3 * ntt_domain_size(d0);
+        for (uint64_t i = 0; i < n3; i++)
+            if (permutation[i] < 0 || (uint64_t)permutation[i] >= n3) {
+                set_error("ga_plonk_build_z: permutation[%llu] = %lld is outside [0, 3n)", (unsigned long long)i, (long long)permutation[i]);
+                return GA_ERR_INVALID;
+            }
+    }
+    GA_DISPATCH_CURVE(ntt_domain_curve(d0), GA_CHECK(plonk_domain_build_z<C>(d0, lv, rv, ov, permutation, beta, gamma, on_device != 0, z_out)));
+    return GA_OK;
+}
+
+int ga_fr_batch_invert(ga_ctx* h, int curve, void* v, uint64_t n, int on_device) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    if (!c || (!v && n)) {
+        set_error("ga_fr_batch_invert: null argument");
+        return GA_ERR_INVALID;
+    }
+    Lock l(c);
+    GA_DISPATCH_CURVE(curve, GA_CHECK(fr_vec_batch_inverse<C>(c, v, n, on_device != 0)));
+    return GA_OK;
+}
+
 int ga_compute_h(ga_domain* dh, const void* a, const void* b, const void* cc, uint64_t n_constraints, void* h_out, int on_device) {
     Domain* d = reinterpret_cast<Domain*>(dh);
     if (!d || !a || !b || !cc || !h_out || n_constraints > ntt_domain_size(d)) {

@@ -170,6 +170,22 @@ int ntt_domain_curve(const Domain* d);
 uint64_t ntt_domain_size(const Domain* d);
 Ctx* ntt_domain_ctx(const Domain* d);
 
+// PLONK quotient / grand product on device (plonk.cuh)
+constexpr int PLONK_MAX_BSB = 16;
+constexpr int PLONK_NB_FIXED = 12;   // L R O Z Ql Qr Qm Qo Qk S1 S2 S3 (plonk prove.go:44-59; ZS is Z shifted by one)
+struct PlonkQuotientArgs {
+    uint32_t nb_bsb;
+    const void* polys[PLONK_NB_FIXED + 2 * PLONK_MAX_BSB];   // fixed ids, then (Qcp_i, committed polynomial i) pairs
+    uint64_t lagrange_mask;   // bit k: polys[k] holds evaluations on the small domain (Lagrange, regular) instead of canonical coefficients
+    bool on_device;           // polys and h_out are device pointers
+    const void *bl, *br, *bo, *bz;   // blinding polynomials: 2, 2, 2, 3 coefficients
+    const void *alpha, *beta, *gamma;
+};
+template <class C> int plonk_domain_quotient(Domain* d0, Domain* d1, const PlonkQuotientArgs& args, void* h_out);
+template <class C> int plonk_domain_build_z(Domain* d0, const void* L, const void* R, const void* O, const int64_t* perm, const void* beta,
+                                            const void* gamma, bool on_device, void* z_out);
+template <class C> int fr_vec_batch_inverse(Ctx* ctx, void* v, uint64_t n, bool on_device);
+
 // utility kernels (util_*.hip)
 template <class C, int G> int util_gen_bases(Ctx* ctx, uint64_t seed, size_t n, void* d_bases, void* d_dlogs);
 template <class C> int util_gen_scalars(Ctx* ctx, uint64_t seed, size_t n, void* d_scalars);

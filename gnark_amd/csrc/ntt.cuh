@@ -95,7 +95,7 @@ struct LdsTile {
 // One pass over stages [s_lo, s_lo+K).  DIT_ = false: DIF butterflies, stages descending; true: DIT, ascending.
 template <class FrP, bool DIT_>
 __global__ void __launch_bounds__(NTT_THREADS)
-ntt_pass_kernel(uint32_t* __restrict__ data, const uint32_t* __restrict__ tw, int logn, int lg_tile, int s_lo, int K,
+ntt_pass_kernel(uint32_t* data, const uint32_t* src, const uint32_t* __restrict__ tw, int logn, int lg_tile, int s_lo, int K,
                 int lc, NttScale pre, NttScale post) {
     static_assert(FrP::N == 8, "Fr is 4x64-bit limbs on both curves");
     __shared__ u32x4 lds[2 << NTT_LG_TILE];
@@ -104,12 +104,13 @@ ntt_pass_kernel(uint32_t* __restrict__ data, const uint32_t* __restrict__ tw, in
     const uint64_t tile = blockIdx.x;
     const uint32_t tid = threadIdx.x;
     u32x4* g = reinterpret_cast<u32x4*>(data);
+    const u32x4* gs = reinterpret_cast<const u32x4*>(src);   // == data for an in-place pass
 
     // ---- load: chunk = 16 bytes; consecutive lanes -> consecutive chunks
     for (uint32_t ch = tid; ch < 2 * tile_elems; ch += NTT_THREADS) {
         uint32_t l = ch >> 1, half = ch & 1;
         uint64_t i = ntt_gidx(l, tile, lg_tile, s_lo, K, lc);
-        u32x4 v = g[i * 2 + half];
+        u32x4 v = gs[i * 2 + half];
         (half ? T.p1 : T.p0)[l] = v;
     }
     __syncthreads();
@@ -199,8 +200,8 @@ __device__ __forceinline__ F29<FrP> ntt_scale_factor29(const NttScale& sc, uint6
 
 template <class FrP, bool DIT_>
 __global__ void __launch_bounds__(NTT_THREADS)
-ntt_pass29_kernel(uint32_t* __restrict__ data, const uint32_t* __restrict__ tw, int logn, int lg_tile, int s_lo, int K, int lc,
-                  NttScale pre, NttScale post) {
+ntt_pass29_kernel(uint32_t* data, const uint32_t* src, const uint32_t* __restrict__ tw, int logn, int lg_tile, int s_lo, int K,
+                  int lc, NttScale pre, NttScale post) {
     static_assert(FrP::N == 8, "Fr is 4x64-bit limbs on both curves");
     __shared__ uint32_t lds[Radix<FrP>::NL << NTT_LG_TILE];
     LdsTile29<FrP> T{lds};
@@ -210,7 +211,7 @@ ntt_pass29_kernel(uint32_t* __restrict__ data, const uint32_t* __restrict__ tw, 
 
     for (uint32_t l = tid; l < tile_elems; l += NTT_THREADS) {
         uint64_t i = ntt_gidx(l, tile, lg_tile, s_lo, K, lc);
-        F29<FrP> v = f29_unpack(load_fe<FrP>(data + i * 8));
+        F29<FrP> v = f29_unpack(load_fe<FrP>(src + i * 8));   // src == data for an in-place pass
         if (pre.mode != 0) v = f29_mul(v, ntt_scale_factor29<FrP>(pre, i, logn));
         T.put(l, v);
     }
@@ -320,7 +321,9 @@ inline std::vector<NttPass> ntt_plan(int logn) {
 }
 
 template <class FrP>
-int ntt_run(Domain* d, uint32_t* d_data, bool inverse, bool dit, const NttScale& pre_first, const NttScale& post_last) {
+int ntt_run(Domain* d, uint32_t* d_data, bool inverse, bool dit, const NttScale& pre_first, const NttScale& post_last,
+            const uint32_t* d_src = nullptr) {
+    // d_src != nullptr: out-of-place transform (the first pass reads d_src, every pass writes d_data; d_src is left untouched)
     Ctx* ctx = d->ctx;
     const uint32_t* tw = inverse ? d->d_tw_inv : d->d_tw;
     NttScale none;
@@ -332,20 +335,21 @@ int ntt_run(Domain* d, uint32_t* d_data, bool inverse, bool dit, const NttScale&
         uint64_t tiles = d->n >> lg_tile;
         const NttScale& pre = (p == 0) ? pre_first : none;
         const NttScale& post = (p == np - 1) ? post_last : none;
+        const uint32_t* src = (p == 0 && d_src) ? d_src : d_data;
         StageTimer st(ctx, dit ? "ntt_pass_dit" : "ntt_pass_dif");
         if (d->lazy) {
             if (dit)
                 hipLaunchKernelGGL((ntt_pass29_kernel<FrP, true>), dim3((unsigned)tiles), dim3(NTT_THREADS), 0, ctx->stream,
-                                   d_data, tw, d->logn, lg_tile, ps.s_lo, ps.K, ps.lc, pre, post);
+                                   d_data, src, tw, d->logn, lg_tile, ps.s_lo, ps.K, ps.lc, pre, post);
             else
                 hipLaunchKernelGGL((ntt_pass29_kernel<FrP, false>), dim3((unsigned)tiles), dim3(NTT_THREADS), 0, ctx->stream,
-                                   d_data, tw, d->logn, lg_tile, ps.s_lo, ps.K, ps.lc, pre, post);
+                                   d_data, src, tw, d->logn, lg_tile, ps.s_lo, ps.K, ps.lc, pre, post);
         } else if (dit)
             hipLaunchKernelGGL((ntt_pass_kernel<FrP, true>), dim3((unsigned)tiles), dim3(NTT_THREADS), 0, ctx->stream,
-                               d_data, tw, d->logn, lg_tile, ps.s_lo, ps.K, ps.lc, pre, post);
+                               d_data, src, tw, d->logn, lg_tile, ps.s_lo, ps.K, ps.lc, pre, post);
         else
             hipLaunchKernelGGL((ntt_pass_kernel<FrP, false>), dim3((unsigned)tiles), dim3(NTT_THREADS), 0, ctx->stream,
-                               d_data, tw, d->logn, lg_tile, ps.s_lo, ps.K, ps.lc, pre, post);
+                               d_data, src, tw, d->logn, lg_tile, ps.s_lo, ps.K, ps.lc, pre, post);
         GA_KERNEL_CHECK();
     }
     return GA_OK;

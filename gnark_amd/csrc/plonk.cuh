@@ -1,0 +1,464 @@
+// PLONK quotient on the device: computeNumerator + divideByZH of backend/plonk/bn254/prove.go:841-1123,1287-1350
+// (SURVEY 8f row 4), and the grand-product polynomial of iop.BuildRatioCopyConstraint (call site prove.go:645-655).
+//
+// The reference keeps 13+2k polynomials of size n on the CPU and, for each of the rho = |domain1|/n cosets
+// coset_i = g*w1^i, converts every polynomial back to canonical form, rescales it and runs a forward FFT (two FFTs per
+// polynomial and coset, prove.go:1033-1058: "we do **a lot** of FFT here").  Here the canonical coefficients stay resident
+// in HBM in bit-reversed order (one inverse DIF per polynomial, once), each coset costs ONE out-of-place coset DIT per
+// polynomial with the coset scaling fused into its first pass, the pointwise constraint (gate + alpha*ordering +
+// alpha^2*(Z-1)*L1, blinding included) is one kernel that also applies divideByZH's 1/(X^n-1) factor and writes the result
+// at its bit-reversed slot, and the final inverse coset transform of size rho*n produces h in canonical order.
+// 1/(x-1) for L1 comes from a batched Montgomery-trick inversion kernel (the reference's batchInvert, prove.go:1134-1147).
+// Field elements are mathematically unique, so the coefficients equal the reference's bit for bit.
+#pragma once
+#include "ntt.cuh"
+
+namespace ga {
+
+// PLONK_MAX_BSB, PLONK_NB_FIXED and PlonkQuotientArgs live in common.cuh (shared with the ABI translation unit)
+enum { PX_L = 0, PX_R, PX_O, PX_Z, PX_QL, PX_QR, PX_QM, PX_QO, PX_QK, PX_S1, PX_S2, PX_S3 };
+
+struct PlonkPtrs {
+    const uint32_t* p[PLONK_NB_FIXED + 2 * PLONK_MAX_BSB];   // [12 + 2*i] = Qcp_i, [13 + 2*i] = committed polynomial i
+    int nb_bsb;
+};
+
+struct PlonkConsts {
+    uint32_t alpha[8], beta[8], gamma[8], cs[8], css[8];
+    uint32_t bl[2][8], br[2][8], bo[2][8], bz[3][8];   // blinding coefficients already multiplied by (coset^n - 1)
+    uint32_t lone[8];      // (coset^n - 1) / n
+    uint32_t omega[8];     // generator of the small domain
+    uint32_t zh_inv[8];    // 1 / (coset^n - 1): divideByZH's factor for this coset (prove.go:1327-1350)
+};
+
+template <class FrP>
+__device__ __forceinline__ Fe<FrP> plonk_c(const uint32_t* w) {
+    Fe<FrP> r;
+#pragma unroll
+    for (int k = 0; k < 8; k++) r.l[k] = w[k];
+    return r;
+}
+
+// x_j = coset * w^j from the two power tables (lo: coset*w^k, k < 2^lo_bits; hi: w^(k << lo_bits)), plain Montgomery form
+template <class FrP>
+__device__ __forceinline__ Fe<FrP> plonk_point(const uint32_t* lo, const uint32_t* hi, int lo_bits, uint64_t j) {
+    Fe<FrP> a = load_fe<FrP>(lo + (j & ((1ull << lo_bits) - 1)) * 8);
+    uint64_t h = j >> lo_bits;
+    return h ? mul(a, load_fe<FrP>(hi + h * 8)) : a;
+}
+
+template <class FrP>
+__global__ void plonk_x_minus_one_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ lo, const uint32_t* __restrict__ hi,
+                                         int lo_bits, uint64_t n) {
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    store_fe(out + j * 8, sub(plonk_point<FrP>(lo, hi, lo_bits, j), fe_one<FrP>()));
+}
+
+// In-place batched inversion (Montgomery's trick; zeros stay zero like fr.BatchInvert).  Thread t owns elements
+// t, t+T, t+2T, ... (T = total threads): every access is coalesced across the wave; tmp holds the running products.
+template <class FrP>
+__global__ void fr_batch_inverse_kernel(uint32_t* __restrict__ v, uint32_t* __restrict__ tmp, uint64_t n) {
+    const uint64_t T = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    Fe<FrP> acc = fe_one<FrP>();
+    for (uint64_t i = t; i < n; i += T) {
+        store_fe(tmp + i * 8, acc);   // product of the (non-zero) elements before i
+        Fe<FrP> x = load_fe<FrP>(v + i * 8);
+        if (!is_zero(x)) acc = mul(acc, x);
+    }
+    acc = inv(acc);
+    uint64_t last = t + ((n - 1 - t) / T) * T;
+    for (uint64_t i = last;; i -= T) {
+        Fe<FrP> x = load_fe<FrP>(v + i * 8);
+        if (!is_zero(x)) {
+            store_fe(v + i * 8, mul(acc, load_fe<FrP>(tmp + i * 8)));
+            acc = mul(acc, x);
+        }
+        if (i == t) break;
+    }
+}
+
+// allConstraints of prove.go:950-981 at point j of the current coset, times 1/(X^n-1) on this coset (divideByZH,
+// prove.go:1311-1316), stored where the big inverse DIT expects evaluation rho*j + i: block*n + bitrev_n(j) (prove.go:1073).
+template <class FrP>
+__global__ void __launch_bounds__(128)
+plonk_constraints_kernel(PlonkPtrs P, PlonkConsts K, const uint32_t* __restrict__ x_lo, const uint32_t* __restrict__ x_hi, int lo_bits,
+                         const uint32_t* __restrict__ inv_xm1, uint32_t* __restrict__ out_block, uint64_t n, int logn) {
+    typedef Fe<FrP> F;
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    // ~45 products per point against 14 x 32 B of loads: one shared out-of-line multiply keeps the kernel small
+    auto mul = [](const F& u, const F& v) { return mul_val(u, v); };
+    auto at = [&](int id, uint64_t idx) { return load_fe<FrP>(P.p[id] + idx * 8); };
+    const F x = plonk_point<FrP>(x_lo, x_hi, lo_bits, j);
+    const F xw = mul(x, plonk_c<FrP>(K.omega));   // next point of the coset: ZS is Z shifted by one (prove.go:602,972)
+    const F beta = plonk_c<FrP>(K.beta), gamma = plonk_c<FrP>(K.gamma), alpha = plonk_c<FrP>(K.alpha);
+    // blinded wires (prove.go:957-973): p + b(x)*(x^n - 1), the factor (coset^n - 1) is folded into the coefficients
+    F l = add(at(PX_L, j), add(plonk_c<FrP>(K.bl[0]), mul(plonk_c<FrP>(K.bl[1]), x)));
+    F r = add(at(PX_R, j), add(plonk_c<FrP>(K.br[0]), mul(plonk_c<FrP>(K.br[1]), x)));
+    F o = add(at(PX_O, j), add(plonk_c<FrP>(K.bo[0]), mul(plonk_c<FrP>(K.bo[1]), x)));
+    auto bz = [&](const F& pt) {
+        return add(plonk_c<FrP>(K.bz[0]), mul(pt, add(plonk_c<FrP>(K.bz[1]), mul(pt, plonk_c<FrP>(K.bz[2])))));
+    };
+    F z = add(at(PX_Z, j), bz(x));
+    F zs = add(at(PX_Z, j + 1 == n ? 0 : j + 1), bz(xw));
+    // gate (prove.go:868-885)
+    F gate = add(mul(at(PX_QL, j), l), mul(at(PX_QR, j), r));
+    gate = add(gate, mul(mul(at(PX_QM, j), l), r));
+    gate = add(gate, mul(at(PX_QO, j), o));
+    gate = add(gate, at(PX_QK, j));
+    for (int t = 0; t < P.nb_bsb; t++) gate = add(gate, mul(at(PLONK_NB_FIXED + 2 * t, j), at(PLONK_NB_FIXED + 2 * t + 1, j)));
+    // ordering (prove.go:898-923)
+    F id = mul(x, beta);
+    F a = add(add(gamma, l), id);
+    F b = add(add(mul(id, plonk_c<FrP>(K.cs)), r), gamma);
+    F c = add(add(mul(id, plonk_c<FrP>(K.css)), o), gamma);
+    F rr = mul(mul(mul(a, b), c), z);
+    a = add(add(mul(at(PX_S1, j), beta), l), gamma);
+    b = add(add(mul(at(PX_S2, j), beta), r), gamma);
+    c = add(add(mul(at(PX_S3, j), beta), o), gamma);
+    F ll = mul(mul(mul(a, b), c), zs);
+    F ord = sub(ll, rr);
+    // local (prove.go:926-934, 380-385)
+    F lone = mul(plonk_c<FrP>(K.lone), load_fe<FrP>(inv_xm1 + j * 8));
+    F loc = mul(sub(z, fe_one<FrP>()), lone);
+    F res = add(mul(add(mul(loc, alpha), ord), alpha), gate);
+    res = mul(res, plonk_c<FrP>(K.zh_inv));
+    store_fe(out_block + bitrev64(j, logn) * 8, res);
+}
+
+// out[bitrev(i)] = in[i]
+template <class FrP>
+__global__ void fr_bitrev_copy_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ in, uint64_t n, int logn) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    store_fe(out + bitrev64(i, logn) * 8, load_fe<FrP>(in + i * 8));
+}
+
+// ---- grand product (iop.BuildRatioCopyConstraint) --------------------------------------------------------------------
+// ratio[i] = prod_k (e_k[i] + beta*id_k(i) + gamma) and its denominator prod_k (e_k[i] + beta*id(perm[k*n+i]) + gamma)
+template <class FrP>
+__global__ void plonk_ratio_terms_kernel(const uint32_t* __restrict__ L, const uint32_t* __restrict__ R, const uint32_t* __restrict__ O,
+                                         const int64_t* __restrict__ perm, const uint32_t* __restrict__ w_lo,
+                                         const uint32_t* __restrict__ w_hi, int lo_bits, PlonkConsts K, uint32_t* __restrict__ num,
+                                         uint32_t* __restrict__ den, uint64_t n) {
+    typedef Fe<FrP> F;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const F beta = plonk_c<FrP>(K.beta), gamma = plonk_c<FrP>(K.gamma);
+    const F shift[3] = {fe_one<FrP>(), plonk_c<FrP>(K.cs), plonk_c<FrP>(K.css)};
+    const uint32_t* e[3] = {L, R, O};
+    auto idv = [&](uint64_t pos) {   // evaluation of the identity permutation at flat position pos: u^(pos / n) * w^(pos % n)
+        uint64_t k = pos / n, j = pos % n;
+        F w = plonk_point<FrP>(w_lo, w_hi, lo_bits, j);
+        return k == 0 ? w : mul(w, shift[k]);
+    };
+    F a = fe_one<FrP>(), b = fe_one<FrP>();
+    for (int k = 0; k < 3; k++) {
+        F v = add(load_fe<FrP>(e[k] + i * 8), gamma);
+        a = mul(a, add(v, mul(beta, idv((uint64_t)k * n + i))));
+        b = mul(b, add(v, mul(beta, idv((uint64_t)perm[(uint64_t)k * n + i]))));
+    }
+    store_fe(num + i * 8, a);
+    store_fe(den + i * 8, b);
+}
+
+// exclusive prefix product over n elements, three phases: per-chunk products, scan of the chunk products (one block),
+// per-chunk rescan with the carried-in prefix.  z[0] = 1, z[i] = prod_{t<i} r[t].
+constexpr int PROD_CHUNK = 256;
+template <class FrP>
+__global__ void fr_chunk_product_kernel(const uint32_t* __restrict__ num, const uint32_t* __restrict__ den_inv,
+                                        uint32_t* __restrict__ chunk_prod, uint64_t n) {
+    uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t lo = c * PROD_CHUNK;
+    if (lo >= n) return;
+    uint64_t hi = lo + PROD_CHUNK < n ? lo + PROD_CHUNK : n;
+    Fe<FrP> acc = fe_one<FrP>();
+    for (uint64_t i = lo; i < hi; i++) acc = mul(acc, mul(load_fe<FrP>(num + i * 8), load_fe<FrP>(den_inv + i * 8)));
+    store_fe(chunk_prod + c * 8, acc);
+}
+template <class FrP>
+__global__ void __launch_bounds__(256) fr_chunk_scan_kernel(uint32_t* __restrict__ chunk_prod, uint64_t nchunks) {
+    // one block: each thread multiplies a contiguous segment of chunk products, the 256 segment products are scanned in LDS
+    // (Hillis-Steele, 8 steps), then every thread rewrites its segment as exclusive prefixes
+    __shared__ uint32_t sh[256 * 8];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t seg = (nchunks + 255) / 256;
+    const uint64_t lo = (uint64_t)tid * seg < nchunks ? (uint64_t)tid * seg : nchunks;
+    const uint64_t hi = lo + seg < nchunks ? lo + seg : nchunks;
+    Fe<FrP> acc = fe_one<FrP>();
+    for (uint64_t c = lo; c < hi; c++) acc = mul_val(acc, load_fe<FrP>(chunk_prod + c * 8));
+    store_fe(sh + tid * 8, acc);
+    __syncthreads();
+    for (uint32_t off = 1; off < 256; off <<= 1) {
+        Fe<FrP> v = load_fe<FrP>(sh + tid * 8);
+        if (tid >= off) v = mul_val(v, load_fe<FrP>(sh + (tid - off) * 8));
+        __syncthreads();
+        store_fe(sh + tid * 8, v);
+        __syncthreads();
+    }
+    acc = tid ? load_fe<FrP>(sh + (tid - 1) * 8) : fe_one<FrP>();
+    for (uint64_t c = lo; c < hi; c++) {
+        Fe<FrP> p = load_fe<FrP>(chunk_prod + c * 8);
+        store_fe(chunk_prod + c * 8, acc);
+        acc = mul_val(acc, p);
+    }
+}
+template <class FrP>
+__global__ void fr_chunk_apply_kernel(const uint32_t* __restrict__ num, const uint32_t* __restrict__ den_inv,
+                                      const uint32_t* __restrict__ chunk_prefix, uint32_t* __restrict__ z, uint64_t n) {
+    uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t lo = c * PROD_CHUNK;
+    if (lo >= n) return;
+    uint64_t hi = lo + PROD_CHUNK < n ? lo + PROD_CHUNK : n;
+    Fe<FrP> acc = load_fe<FrP>(chunk_prefix + c * 8);
+    for (uint64_t i = lo; i < hi; i++) {
+        store_fe(z + i * 8, acc);
+        acc = mul(acc, mul(load_fe<FrP>(num + i * 8), load_fe<FrP>(den_inv + i * 8)));
+    }
+}
+
+// ---- host side -----------------------------------------------------------------------------------------------------
+
+// two-level power table of `base` with first factor c0 (plain Montgomery form): lo[k] = c0*base^k, hi[k] = base^(k << LO)
+template <class FrP>
+int plonk_pow_tables(Ctx* ctx, const char* key, const Fe<FrP>& base, const Fe<FrP>& c0, uint64_t n, bool hat, uint32_t** d_lo,
+                     uint32_t** d_hi) {
+    typedef Fe<FrP> F;
+    const uint64_t nlo = 1ull << NTT_POW_LO_BITS;
+    const uint64_t nhi = (n >> NTT_POW_LO_BITS) ? (n >> NTT_POW_LO_BITS) : 1;
+    std::vector<uint32_t> buf((nlo + nhi) * 8);
+    F acc = c0;
+    for (uint64_t k = 0; k < nlo; k++) {
+        F st = hat ? f29_hat_packed(acc) : acc;
+        memcpy(&buf[k * 8], st.l, 32);
+        acc = mul(acc, base);
+    }
+    F step = base;
+    for (int k = 0; k < NTT_POW_LO_BITS; k++) step = sqr(step);
+    acc = fe_one<FrP>();
+    for (uint64_t k = 0; k < nhi; k++) {
+        F st = hat ? f29_hat_packed(acc) : acc;
+        memcpy(&buf[(nlo + k) * 8], st.l, 32);
+        acc = mul(acc, step);
+    }
+    void* d;
+    GA_CHECK(ctx->scratch_get(key, buf.size() * 4, &d));
+    // the staging vector dies at return: synchronous copy (pageable memory)
+    GA_HIP_CHECK(hipMemcpyAsync(d, buf.data(), buf.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    GA_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    *d_lo = (uint32_t*)d;
+    *d_hi = (uint32_t*)d + nlo * 8;
+    return GA_OK;
+}
+
+template <class FrP>
+Fe<FrP> plonk_host_pow(Fe<FrP> a, uint64_t e) {
+    Fe<FrP> r = fe_one<FrP>();
+    while (e) {
+        if (e & 1) r = mul(r, a);
+        a = sqr(a);
+        e >>= 1;
+    }
+    return r;
+}
+
+template <class FrP>
+Fe<FrP> plonk_root_of_unity(int logn) {
+    Fe<FrP> w = fe_const<FrP>(FrP::ROOT);
+    for (int k = 0; k < FrP::ADICITY - logn; k++) w = sqr(w);
+    return w;
+}
+
+template <class FrP>
+int plonk_quotient(Domain* d0, Domain* d1, const PlonkQuotientArgs& A, void* h_out) {
+    typedef Fe<FrP> F;
+    Ctx* ctx = d0->ctx;
+    const uint64_t n = d0->n, N = d1->n;
+    const int logn = d0->logn;
+    if (n < 2 || N < n || N % n != 0 || A.nb_bsb > (uint32_t)PLONK_MAX_BSB || d1->ctx != ctx) {
+        set_error("plonk quotient: need n >= 2, |domain1| a multiple of |domain0|, at most %d BSB22 gates", PLONK_MAX_BSB);
+        return GA_ERR_INVALID;
+    }
+    const uint64_t rho = N / n;
+    const int logrho = ilog2_u64(rho);
+    const int np = PLONK_NB_FIXED + 2 * (int)A.nb_bsb;
+    hipStream_t st = ctx->stream;
+    uint32_t *canon, *work, *invb, *tmpb, *cres;
+    GA_CHECK(ctx->scratch_get("plonk_canon", (size_t)np * n * 32, (void**)&canon));
+    GA_CHECK(ctx->scratch_get("plonk_work", (size_t)np * n * 32, (void**)&work));
+    GA_CHECK(ctx->scratch_get("plonk_inv", n * 32, (void**)&invb));
+    GA_CHECK(ctx->scratch_get("plonk_tmp", n * 32, (void**)&tmpb));
+    GA_CHECK(ctx->scratch_get("plonk_cres", N * 32, (void**)&cres));
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    // ---- canonical coefficients in bit-reversed order, once ---------------------------------------------------------
+    for (int p = 0; p < np; p++) {
+        uint32_t* dst = canon + (size_t)p * n * 8;
+        uint32_t* stage = work + (size_t)p * n * 8;
+        const bool lag = (A.lagrange_mask >> p) & 1;
+        {
+            StageTimer tm(ctx, "plonk_h2d");
+            GA_HIP_CHECK(hipMemcpyAsync(lag ? dst : stage, A.polys[p], n * 32, A.on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+        }
+        if (lag) {
+            // Lagrange regular -> canonical bit-reversed: inverse DIF with the 1/n (p.ToCanonical, prove.go:1036)
+            GA_CHECK(ntt_run<FrP>(d0, dst, /*inverse=*/true, /*dit=*/false, scale_none(), scale_const(d0->ninv)));
+        } else {
+            StageTimer tm(ctx, "plonk_bitrev");
+            hipLaunchKernelGGL((fr_bitrev_copy_kernel<FrP>), dim3(blocks), dim3(256), 0, st, dst, stage, n, logn);
+            GA_KERNEL_CHECK();
+        }
+    }
+    // ---- constants ------------------------------------------------------------------------------------------------------
+    auto ld = [](const void* p, int k = 0) {
+        F f;
+        memcpy(f.l, (const char*)p + 32 * k, 32);
+        return f;
+    };
+    const F g = fe_const<FrP>(FrP::GEN);
+    const F w0 = plonk_root_of_unity<FrP>(logn), w1 = plonk_root_of_unity<FrP>(d1->logn);
+    F ninv = fe_one<FrP>();
+    {
+        F half = inv(add(fe_one<FrP>(), fe_one<FrP>()));
+        for (int k = 0; k < logn; k++) ninv = mul(ninv, half);
+    }
+    PlonkConsts K;
+    auto put = [](uint32_t* dst, const F& v) { memcpy(dst, v.l, 32); };
+    put(K.alpha, ld(A.alpha));
+    put(K.beta, ld(A.beta));
+    put(K.gamma, ld(A.gamma));
+    put(K.cs, g);              // prove.go:891-893
+    put(K.css, sqr(g));
+    put(K.omega, w0);
+    PlonkPtrs P;
+    memset(&P, 0, sizeof(P));
+    P.nb_bsb = (int)A.nb_bsb;
+    for (int p = 0; p < np; p++) P.p[p] = work + (size_t)p * n * 8;
+    F coset = fe_one<FrP>();
+    for (uint64_t i = 0; i < rho; i++) {
+        coset = mul(coset, i == 0 ? g : w1);                       // shifters, prove.go:936-941,998
+        const F cexp = sub(plonk_host_pow<FrP>(coset, n), fe_one<FrP>());   // (coset^n - 1), prove.go:999-1000
+        for (int k = 0; k < 2; k++) {
+            put(K.bl[k], mul(ld(A.bl, k), cexp));
+            put(K.br[k], mul(ld(A.br, k), cexp));
+            put(K.bo[k], mul(ld(A.bo, k), cexp));
+        }
+        for (int k = 0; k < 3; k++) put(K.bz[k], mul(ld(A.bz, k), cexp));
+        put(K.lone, mul(cexp, ninv));
+        put(K.zh_inv, inv(cexp));
+        // evaluations on coset*H: forward DIT with the coset powers fused into the first pass (prove.go:1033-1058)
+        uint32_t *s_lo, *s_hi, *x_lo, *x_hi;
+        GA_CHECK(plonk_pow_tables<FrP>(ctx, "plonk_scale_tab", coset, fe_one<FrP>(), n, d0->lazy, &s_lo, &s_hi));
+        GA_CHECK(plonk_pow_tables<FrP>(ctx, "plonk_x_tab", w0, coset, n, false, &x_lo, &x_hi));
+        for (int p = 0; p < np; p++)
+            GA_CHECK(ntt_run<FrP>(d0, work + (size_t)p * n * 8, /*inverse=*/false, /*dit=*/true, scale_pow(s_lo, s_hi, /*bitrev=*/true),
+                                  scale_none(), canon + (size_t)p * n * 8));
+        {
+            StageTimer tm(ctx, "plonk_batch_inverse");
+            hipLaunchKernelGGL((plonk_x_minus_one_kernel<FrP>), dim3(blocks), dim3(256), 0, st, invb, x_lo, x_hi, NTT_POW_LO_BITS, n);
+            const uint64_t threads = n < 65536 ? (n + 63) / 64 : n / 64;   // >= 64 elements per thread amortise the inversion
+            const unsigned ib = (unsigned)((threads + 63) / 64);
+            hipLaunchKernelGGL((fr_batch_inverse_kernel<FrP>), dim3(ib), dim3(64), 0, st, invb, tmpb, n);
+            GA_KERNEL_CHECK();
+        }
+        {
+            StageTimer tm(ctx, "plonk_constraints");
+            uint64_t block = 0;   // bitrev_N(rho*j + i) = bitrev_rho(i)*n + bitrev_n(j)
+            for (int b = 0; b < logrho; b++) block |= ((i >> b) & 1) << (logrho - 1 - b);
+            hipLaunchKernelGGL((plonk_constraints_kernel<FrP>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, P, K, x_lo, x_hi,
+                               NTT_POW_LO_BITS, invb, cres + block * n * 8, n, logn);
+            GA_KERNEL_CHECK();
+        }
+    }
+    // ---- a.ToCanonical(bigDomain).ToRegular() from LagrangeCoset/BitReverse (prove.go:1319): inverse DIT on the coset ----
+    GA_CHECK(ntt_fft<FrP>(d1, cres, GA_FFT_INVERSE, GA_DIT, 1));
+    {
+        StageTimer tm(ctx, "plonk_d2h");
+        GA_HIP_CHECK(hipMemcpyAsync(h_out, cres, N * 32, A.on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
+    }
+    GA_HIP_CHECK(hipStreamSynchronize(st));
+    return GA_OK;
+}
+
+// fr.BatchInvert on a vector (host or device memory), in place
+template <class FrP>
+int fr_batch_inverse(Ctx* ctx, void* v, uint64_t n, bool on_device) {
+    if (n == 0) return GA_OK;
+    uint32_t *buf, *tmp;
+    GA_CHECK(ctx->scratch_get("plonk_inv", n * 32, (void**)&buf));
+    GA_CHECK(ctx->scratch_get("plonk_tmp", n * 32, (void**)&tmp));
+    hipStream_t st = ctx->stream;
+    uint32_t* d = on_device ? (uint32_t*)v : buf;
+    if (!on_device) GA_HIP_CHECK(hipMemcpyAsync(buf, v, n * 32, hipMemcpyHostToDevice, st));
+    {
+        StageTimer tm(ctx, "plonk_batch_inverse");
+        const uint64_t threads = n < 65536 ? (n + 63) / 64 : n / 64;
+        hipLaunchKernelGGL((fr_batch_inverse_kernel<FrP>), dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, st, d, tmp, n);
+        GA_KERNEL_CHECK();
+    }
+    if (!on_device) GA_HIP_CHECK(hipMemcpyAsync(v, buf, n * 32, hipMemcpyDeviceToHost, st));
+    GA_HIP_CHECK(hipStreamSynchronize(st));
+    return GA_OK;
+}
+
+// iop.BuildRatioCopyConstraint: Z in Lagrange form (regular layout) from L, R, O (Lagrange regular) and the permutation.
+template <class FrP>
+int plonk_build_z(Domain* d0, const void* L, const void* R, const void* O, const int64_t* perm, const void* beta, const void* gamma,
+                  bool on_device, void* z_out) {
+    typedef Fe<FrP> F;
+    Ctx* ctx = d0->ctx;
+    const uint64_t n = d0->n;
+    hipStream_t st = ctx->stream;
+    uint32_t *lro, *num, *den, *tmp, *z, *cp;
+    int64_t* dperm;
+    const uint64_t nchunks = (n + PROD_CHUNK - 1) / PROD_CHUNK;
+    GA_CHECK(ctx->scratch_get("plonk_z_lro", 3 * n * 32, (void**)&lro));
+    GA_CHECK(ctx->scratch_get("plonk_z_num", n * 32, (void**)&num));
+    GA_CHECK(ctx->scratch_get("plonk_z_den", n * 32, (void**)&den));
+    GA_CHECK(ctx->scratch_get("plonk_tmp", n * 32, (void**)&tmp));
+    GA_CHECK(ctx->scratch_get("plonk_z_out", n * 32, (void**)&z));
+    GA_CHECK(ctx->scratch_get("plonk_z_chunks", nchunks * 32, (void**)&cp));
+    GA_CHECK(ctx->scratch_get("plonk_z_perm", 3 * n * 8, (void**)&dperm));
+    const hipMemcpyKind kin = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    const void* src[3] = {L, R, O};
+    for (int k = 0; k < 3; k++) GA_HIP_CHECK(hipMemcpyAsync(lro + (size_t)k * n * 8, src[k], n * 32, kin, st));
+    GA_HIP_CHECK(hipMemcpyAsync(dperm, perm, 3 * n * 8, kin, st));
+    PlonkConsts K;
+    memset(&K, 0, sizeof(K));
+    memcpy(K.beta, beta, 32);
+    memcpy(K.gamma, gamma, 32);
+    const F g = fe_const<FrP>(FrP::GEN);
+    memcpy(K.cs, g.l, 32);
+    F gg = sqr(g);
+    memcpy(K.css, gg.l, 32);
+    uint32_t *w_lo, *w_hi;
+    GA_CHECK(plonk_pow_tables<FrP>(ctx, "plonk_x_tab", plonk_root_of_unity<FrP>(d0->logn), fe_one<FrP>(), n, false, &w_lo, &w_hi));
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    {
+        StageTimer tm(ctx, "plonk_z_terms");
+        hipLaunchKernelGGL((plonk_ratio_terms_kernel<FrP>), dim3(blocks), dim3(256), 0, st, lro, lro + n * 8, lro + 2 * n * 8, dperm, w_lo,
+                           w_hi, NTT_POW_LO_BITS, K, num, den, n);
+        GA_KERNEL_CHECK();
+    }
+    {
+        StageTimer tm(ctx, "plonk_batch_inverse");
+        const uint64_t threads = n < 65536 ? (n + 63) / 64 : n / 64;
+        hipLaunchKernelGGL((fr_batch_inverse_kernel<FrP>), dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, st, den, tmp, n);
+        GA_KERNEL_CHECK();
+    }
+    {
+        StageTimer tm(ctx, "plonk_z_prefix_product");
+        const unsigned cb = (unsigned)((nchunks + 63) / 64);
+        hipLaunchKernelGGL((fr_chunk_product_kernel<FrP>), dim3(cb), dim3(64), 0, st, num, den, cp, n);
+        hipLaunchKernelGGL((fr_chunk_scan_kernel<FrP>), dim3(1), dim3(256), 0, st, cp, nchunks);
+        hipLaunchKernelGGL((fr_chunk_apply_kernel<FrP>), dim3(cb), dim3(64), 0, st, num, den, cp, z, n);
+        GA_KERNEL_CHECK();
+    }
+    GA_HIP_CHECK(hipMemcpyAsync(z_out, z, n * 32, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
+    GA_HIP_CHECK(hipStreamSynchronize(st));
+    return GA_OK;
+}
+
+}  // namespace ga

@@ -1,0 +1,17 @@
+// Explicit instantiation: PLONK quotient / grand product / batch inversion, bls12381 (see plonk.cuh).
+#include "plonk.cuh"
+namespace ga {
+template <>
+int plonk_domain_quotient<Bls12381>(Domain* d0, Domain* d1, const PlonkQuotientArgs& args, void* h_out) {
+    return plonk_quotient<Bls12381::FrP>(d0, d1, args, h_out);
+}
+template <>
+int plonk_domain_build_z<Bls12381>(Domain* d0, const void* L, const void* R, const void* O, const int64_t* perm, const void* beta,
+                                const void* gamma, bool on_device, void* z_out) {
+    return plonk_build_z<Bls12381::FrP>(d0, L, R, O, perm, beta, gamma, on_device, z_out);
+}
+template <>
+int fr_vec_batch_inverse<Bls12381>(Ctx* ctx, void* v, uint64_t n, bool on_device) {
+    return fr_batch_inverse<Bls12381::FrP>(ctx, v, n, on_device);
+}
+}  // namespace ga

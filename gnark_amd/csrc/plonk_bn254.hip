@@ -1,0 +1,17 @@
+// Explicit instantiation: PLONK quotient / grand product / batch inversion, bn254 (see plonk.cuh).
+#include "plonk.cuh"
+namespace ga {
+template <>
+int plonk_domain_quotient<Bn254>(Domain* d0, Domain* d1, const PlonkQuotientArgs& args, void* h_out) {
+    return plonk_quotient<Bn254::FrP>(d0, d1, args, h_out);
+}
+template <>
+int plonk_domain_build_z<Bn254>(Domain* d0, const void* L, const void* R, const void* O, const int64_t* perm, const void* beta,
+                                const void* gamma, bool on_device, void* z_out) {
+    return plonk_build_z<Bn254::FrP>(d0, L, R, O, perm, beta, gamma, on_device, z_out);
+}
+template <>
+int fr_vec_batch_inverse<Bn254>(Ctx* ctx, void* v, uint64_t n, bool on_device) {
+    return fr_batch_inverse<Bn254::FrP>(ctx, v, n, on_device);
+}
+}  // namespace ga

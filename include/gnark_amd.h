@@ -133,6 +133,35 @@ int ga_fft(ga_domain* d, void* data, int direction, int decimation, int on_coset
 int ga_compute_h(ga_domain* d, const void* a, const void* b, const void* c, uint64_t n_constraints,
                  void* h_out, int on_device);
 
+/* ---- PLONK: quotient and grand product on the device ---------------------------------------
+ * replaces: (*instance).computeNumerator + divideByZH (backend/plonk/bn254/prove.go:841-1123,1287-1350; the "we do **a lot** of
+ * FFT here" loop, ~108 FFTs of size n on the CPU) and iop.BuildRatioCopyConstraint (gnark-crypto, call site prove.go:645-655).
+ * domain0 / domain1 are ga_domain handles of cardinality n and rho*n (rho = 4, or 8 below 6 constraints, prove.go:247-251).
+ * Every polynomial is n fr elements (Montgomery), either canonical coefficients in regular order or -- when its bit of
+ * lagrange_mask is set -- evaluations on domain0 in regular order (what s.x[...] holds before computeNumerator).  Bit order:
+ * L R O Z Ql Qr Qm Qo Qk S1 S2 S3, then Qcp_0, Pi2_0, Qcp_1, Pi2_1, ...  (prove.go:44-59 without ZS, which is Z shifted).
+ * bl, br, bo: the blinding polynomials of L, R, O (order 1: 2 coefficients), bz: of Z (order 2: 3 coefficients), prove.go:72-75.
+ * h_out: rho*n fr elements, canonical, regular order -- s.h after divideByZH; h1/h2/h3 are its slices (prove.go:691-728). */
+#define GA_PLONK_ON_DEVICE 0x1u   /* polynomials and the output are device pointers */
+typedef struct ga_plonk_quotient_in {
+    uint32_t nb_bsb;                     /* len(proof.Bsb22Commitments), at most 16 */
+    const void *l, *r, *o, *z, *ql, *qr, *qm, *qo, *qk, *s1, *s2, *s3;
+    const void* const* qcp;              /* [nb_bsb] s.trace.Qcp[i] */
+    const void* const* pi2;              /* [nb_bsb] s.cCommitments[i] */
+    uint64_t lagrange_mask;
+    const void *bl, *br, *bo, *bz;
+    const void *alpha, *beta, *gamma;    /* fr, Montgomery */
+    uint32_t flags;
+} ga_plonk_quotient_in;
+int ga_plonk_quotient(ga_domain* domain0, ga_domain* domain1, const ga_plonk_quotient_in* in, void* h_out);
+/* Z in Lagrange form, regular order (n elements): Z[0] = 1, Z[i+1] = Z[i] * prod_k (e_k[i] + beta*id_k(i) + gamma) /
+ * prod_k (e_k[i] + beta*id(perm[k*n+i]) + gamma), id over {1, g, g^2} * w^i.  l, r, o: evaluations on domain0; permutation:
+ * 3n int64 (s.trace.S). */
+int ga_plonk_build_z(ga_domain* domain0, const void* l, const void* r, const void* o, const int64_t* permutation,
+                     const void* beta, const void* gamma, int on_device, void* z_out);
+/* fr.BatchInvert in place (zeros stay zero): the batchInvert of prove.go:1134-1147 */
+int ga_fr_batch_invert(ga_ctx* ctx, int curve, void* v, uint64_t n, int on_device);
+
 /* ---- Groth16 -------------------------------------------------------------------------------------------
  * replaces: (*ProvingKey).setupDevicePointers (icicle.go:88-264) and Prove (icicle.go:784-1360).
  * ga_g16_key describes gnark's groth16 ProvingKey (setup.go:25-48) by pointer+length; everything is copied to

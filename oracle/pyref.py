@@ -299,6 +299,160 @@ def compute_h(c: Curve, a, b, cc, n):
 
 
 # ----------------------------------------------------------------------------------------------
+# PLONK quotient: computeNumerator + divideByZH (backend/plonk/bn254/prove.go:841-1123,1287-1350)
+# ----------------------------------------------------------------------------------------------
+PLONK_IDS = ("L", "R", "O", "Z", "Ql", "Qr", "Qm", "Qo", "Qk", "S1", "S2", "S3")   # prove.go:44-59 without ZS (= Z shifted)
+
+
+def _poly_eval(coeffs, x, mod):
+    acc = 0
+    for cf in reversed(coeffs):
+        acc = (acc * x + cf) % mod
+    return acc
+
+
+def plonk_rho(n: int) -> int:
+    """domain1 = 8n below 6 constraints, else 4n (prove.go:247-251)"""
+    return 8 if n < 6 else 4
+
+
+def plonk_quotient(c: Curve, n: int, x: dict, qcp, pi2, bp: dict, alpha, beta, gamma):
+    """x: canonical coefficients (n each) of PLONK_IDS; qcp/pi2: lists of canonical polynomials (Qcp_i, the committed
+    polynomial of BSB22 gate i); bp: blinding polynomials {"Bl","Br","Bo" (2 coeffs), "Bz" (3 coeffs)}.  Returns the canonical
+    coefficients (rho*n of them) of h, exactly what computeNumerator followed by divideByZH leaves in s.h.
+
+    Follows prove.go:841-1123: for each of the rho cosets coset_i = g*w1^i of the small domain inside the big one, evaluate
+    every polynomial on coset_i*H (the reference does it with ToCanonical / scale / ToLagrange, :1033-1058), apply
+    allConstraints (:950-981) pointwise, store at the bit-reversed position (:1073); then divideByZH (:1287-1324)."""
+    mod = c.r
+    rho = plonk_rho(n)
+    N = rho * n
+    logN = N.bit_length() - 1
+    w0 = c.fr_root_of_unity(n)
+    w1 = c.fr_root_of_unity(N)
+    g = c.fr_gen
+    cs, css = g, g * g % mod                               # :891-893
+    ninv = pow(n, -1, mod)
+    tw = [pow(w0, j, mod) for j in range(n)]               # twiddles0, :845-858
+    cres = [0] * N
+    coset = 1
+    nb_bsb = len(qcp)
+    polys = dict(x)
+    for i in range(nb_bsb):
+        polys["Qc%d" % i], polys["Pi%d" % i] = qcp[i], pi2[i]
+    for i in range(rho):
+        coset = coset * (g if i == 0 else w1) % mod        # shifters, :936-941,998
+        cexp = (pow(coset, n, mod) - 1) % mod              # cosetExponentiatedToNMinusOne, :999-1000
+        den = [pow((coset * tw[j] - 1) % mod, -1, mod) for j in range(n)]   # precomputedDenominators, :1002-1007
+        ev = {}
+        for k, cf in polys.items():                        # batchApply, :1033-1058: evaluations on coset*H, natural order
+            sc = [cf[j] * pow(coset, j, mod) % mod for j in range(n)]
+            ev[k] = _ntt_natural(sc, w0, mod)
+        # blinding polynomials scaled by (coset^n - 1) and by the coset powers (:1009-1017): Evaluate(w^j) = b(coset*w^j)*cexp
+        bev = lambda name, j: _poly_eval(bp[name], coset * tw[j % n] % mod, mod) * cexp % mod
+        for j in range(n):
+            l = (ev["L"][j] + bev("Bl", j)) % mod          # :958-970
+            r = (ev["R"][j] + bev("Br", j)) % mod
+            o = (ev["O"][j] + bev("Bo", j)) % mod
+            z = (ev["Z"][j] + bev("Bz", j)) % mod
+            zs = (ev["Z"][(j + 1) % n] + bev("Bz", j + 1)) % mod   # ZS = Z shifted by one (:602,:972-973)
+            s1, s2, s3 = ev["S1"][j] * beta % mod, ev["S2"][j] * beta % mod, ev["S3"][j] * beta % mod   # :953-955
+            gate = (ev["Ql"][j] * l + ev["Qr"][j] * r + ev["Qm"][j] * l % mod * r + ev["Qo"][j] * o + ev["Qk"][j]) % mod   # :868-885
+            for t in range(nb_bsb):
+                gate = (gate + ev["Qc%d" % t][j] * ev["Pi%d" % t][j]) % mod
+            idv = tw[j] * coset % mod * beta % mod          # :908
+            rr = (gamma + l + idv) * ((idv * cs + r + gamma) % mod) % mod * ((idv * css + o + gamma) % mod) % mod * z % mod
+            ll = (s1 + l + gamma) * ((s2 + r + gamma) % mod) % mod * ((s3 + o + gamma) % mod) % mod * zs % mod
+            ordering = (ll - rr) % mod                      # :921
+            lone = cexp * ninv % mod * den[j] % mod         # computeLagrangeOneOnCoset, :380-385
+            local = (z - 1) * lone % mod                    # :926-934
+            val = ((local * alpha + ordering) % mod * alpha + gate) % mod   # :978-980
+            cres[bitrev(rho * j + i, logN)] = val           # :1073
+    # divideByZH (:1287-1324): r[i] *= 1/((g*w1^k)^n - 1) with k = bitrev(i) % rho, then ToCanonical on the big coset
+    xinv = [pow((pow(g * pow(w1, k, mod) % mod, n, mod) - 1) % mod, -1, mod) for k in range(rho)]   # :1327-1350
+    nat = [0] * N
+    for idx in range(N):
+        m = bitrev(idx, logN)
+        nat[m] = cres[idx] * xinv[m % rho] % mod
+    co = _ntt_natural(nat, pow(w1, -1, mod), mod)
+    Ninv, ginv = pow(N, -1, mod), pow(g, -1, mod)
+    return [co[k] * Ninv % mod * pow(ginv, k, mod) % mod for k in range(N)]
+
+
+def plonk_numerator_at(c: Curve, n: int, x: dict, qcp, pi2, bp: dict, alpha, beta, gamma, zeta):
+    """The blinded constraint polynomial evaluated at one point from the canonical coefficients (independent of any FFT):
+    gate + alpha*ordering + alpha^2*(Z-1)*L1.  For a satisfying instance it equals h(zeta)*(zeta^n - 1)."""
+    mod = c.r
+    w0 = c.fr_root_of_unity(n)
+    zn1 = (pow(zeta, n, mod) - 1) % mod
+    e = lambda k: _poly_eval(x[k], zeta, mod)
+    b = lambda k, pt: _poly_eval(bp[k], pt, mod) * ((pow(pt, n, mod) - 1) % mod) % mod
+    l, r, o = (e("L") + b("Bl", zeta)) % mod, (e("R") + b("Br", zeta)) % mod, (e("O") + b("Bo", zeta)) % mod
+    z = (e("Z") + b("Bz", zeta)) % mod
+    zw = zeta * w0 % mod
+    zs = (_poly_eval(x["Z"], zw, mod) + b("Bz", zw)) % mod
+    gate = (e("Ql") * l + e("Qr") * r + e("Qm") * l % mod * r + e("Qo") * o + e("Qk")) % mod
+    for qc, pi in zip(qcp, pi2):
+        gate = (gate + _poly_eval(qc, zeta, mod) * _poly_eval(pi, zeta, mod)) % mod
+    g = c.fr_gen
+    idv = zeta * beta % mod
+    rr = (gamma + l + idv) * ((idv * g + r + gamma) % mod) % mod * ((idv * g * g + o + gamma) % mod) % mod * z % mod
+    ll = (e("S1") * beta + l + gamma) * ((e("S2") * beta + r + gamma) % mod) % mod * ((e("S3") * beta + o + gamma) % mod) % mod * zs % mod
+    lone = zn1 * pow(n, -1, mod) % mod * pow((zeta - 1) % mod, -1, mod) % mod
+    return (((z - 1) * lone % mod * alpha + (ll - rr)) % mod * alpha + gate) % mod
+
+
+def plonk_build_z(c: Curve, n: int, L, R, O, perm, beta, gamma):
+    """iop.BuildRatioCopyConstraint (gnark-crypto [EXT], call site backend/plonk/bn254/prove.go:645-655): the grand-product
+    polynomial in Lagrange form.  L,R,O: evaluations on the domain; perm: permutation of [0,3n) (s.trace.S).
+    Z[0] = 1, Z[i+1] = Z[i] * prod_k (e_k[i] + beta*id_k(i) + gamma) / prod_k (e_k[i] + beta*id(perm[k*n+i]) + gamma)
+    with id over the three cosets {1, g, g^2} * w^i."""
+    mod = c.r
+    w0, g = c.fr_root_of_unity(n), c.fr_gen
+    ids = [pow(g, k, mod) * pow(w0, i, mod) % mod for k in range(3) for i in range(n)]
+    ev = [L, R, O]
+    Z = [1] * n
+    for i in range(n - 1):
+        num = den = 1
+        for k in range(3):
+            num = num * ((ev[k][i] + beta * ids[k * n + i] + gamma) % mod) % mod
+            den = den * ((ev[k][i] + beta * ids[perm[k * n + i]] + gamma) % mod) % mod
+        Z[i + 1] = Z[i] * num % mod * pow(den, -1, mod) % mod
+    return Z
+
+
+def plonk_synthetic_instance(c: Curve, n: int, seed: int, nb_bsb: int = 1):
+    """A satisfying PLONK trace of size n built directly in Lagrange form (no circuit): random wire values with copy
+    constraints (cycles over equal values), random selectors with Qk chosen so that every gate holds, S1..S3 from the
+    permutation, Z from plonk_build_z.  Returns (lagrange dict, qcp, pi2, perm) -- all evaluation vectors."""
+    mod = c.r
+    rng = Xoshiro(seed)
+    pool = [rng.field(mod) for _ in range(max(2, n // 2))]
+    assign = [rng.next() % len(pool) for _ in range(3 * n)]
+    wires = [pool[a] for a in assign]
+    perm = list(range(3 * n))
+    by_val = {}
+    for pos, a in enumerate(assign):
+        by_val.setdefault(a, []).append(pos)
+    for cyc in by_val.values():
+        for k, pos in enumerate(cyc):
+            perm[pos] = cyc[(k + 1) % len(cyc)]
+    L, R, O = wires[:n], wires[n:2 * n], wires[2 * n:]
+    lag = dict(L=L, R=R, O=O)
+    for k in ("Ql", "Qr", "Qm", "Qo"):
+        lag[k] = [rng.field(mod) for _ in range(n)]
+    qcp = [[rng.field(mod) if rng.next() % 4 == 0 else 0 for _ in range(n)] for _ in range(nb_bsb)]
+    pi2 = [[rng.field(mod) for _ in range(n)] for _ in range(nb_bsb)]
+    lag["Qk"] = [(-(lag["Ql"][i] * L[i] + lag["Qr"][i] * R[i] + lag["Qm"][i] * L[i] * R[i] + lag["Qo"][i] * O[i]
+                    + sum(q[i] * p[i] for q, p in zip(qcp, pi2)))) % mod for i in range(n)]
+    w0, g = c.fr_root_of_unity(n), c.fr_gen
+    ids = [pow(g, k, mod) * pow(w0, i, mod) % mod for k in range(3) for i in range(n)]
+    for k, name in enumerate(("S1", "S2", "S3")):
+        lag[name] = [ids[perm[k * n + i]] for i in range(n)]
+    return lag, qcp, pi2, perm, rng
+
+
+# ----------------------------------------------------------------------------------------------
 # point (de)compression [EXT gnark-crypto encoders; probed on the reference's fixtures, SURVEY 8c]
 # ----------------------------------------------------------------------------------------------
 

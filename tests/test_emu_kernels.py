@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import pyref
-from gnark_amd import ecc, fft, groth16
+from gnark_amd import ecc, fft, groth16, plonk
 from helpers import BLS12_381, BN254, arr_to_fr, arr_to_g1_affine, arr_to_g2_affine, fr_to_arr, gen_of, group_of, jac_to_affine_py, pts_to_arr
 
 CURVES = [BN254, BLS12_381]
@@ -336,3 +336,76 @@ def test_emu_groth16_bsb22_commitments(emu_ctx, c, precompute):
     sig = toxic[5:7]
     ch = pyref.fr_hash(c, ser, pyref.FOLD_DST, 1)[0]
     assert opok == G1.msm(ocoms, [sg * pow(ch, i, c.r) % c.r for i, sg in enumerate(sig)])
+
+
+def _plonk_case(c, n, seed, nb_bsb):
+    """a satisfying synthetic PLONK trace (oracle) with its challenges and blinding polynomials, canonical + Lagrange forms"""
+    mod = c.r
+    lag, qcp, pi2, perm, rng = pyref.plonk_synthetic_instance(c, n, seed, nb_bsb)
+    beta, gamma, alpha = rng.field(mod), rng.field(mod), rng.field(mod)
+    lag["Z"] = pyref.plonk_build_z(c, n, lag["L"], lag["R"], lag["O"], perm, beta, gamma)
+    w0 = c.fr_root_of_unity(n)
+    ninv = pow(n, -1, mod)
+    tocan = lambda v: [x * ninv % mod for x in pyref._ntt_natural(v, pow(w0, -1, mod), mod)]
+    can = {k: tocan(v) for k, v in lag.items()}
+    qc_can, pi_can = [tocan(v) for v in qcp], [tocan(v) for v in pi2]
+    bp = {"Bl": [rng.field(mod) for _ in range(2)], "Br": [rng.field(mod) for _ in range(2)],
+          "Bo": [rng.field(mod) for _ in range(2)], "Bz": [rng.field(mod) for _ in range(3)]}
+    return dict(lag=lag, can=can, qcp=qcp, pi2=pi2, qc_can=qc_can, pi_can=pi_can, perm=perm, bp=bp, alpha=alpha, beta=beta,
+                gamma=gamma, rng=rng)
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("n,nb_bsb", [(4, 0), (8, 1), (64, 2)])
+def test_emu_plonk_quotient(emu_ctx, c, n, nb_bsb, seed=11):
+    """computeNumerator + divideByZH on the device == the oracle's restatement of prove.go:841-1123,1287-1350,
+    coefficient for coefficient, from canonical inputs, from Lagrange inputs and from a mix; and h(x)(x^n-1) equals the blinded
+    constraint polynomial at a random point (the instance satisfies its gates and copy constraints)."""
+    mod = c.r
+    T = _plonk_case(c, n, seed, nb_bsb)
+    want = pyref.plonk_quotient(c, n, T["can"], T["qc_can"], T["pi_can"], T["bp"], T["alpha"], T["beta"], T["gamma"])
+    zeta = T["rng"].field(mod)
+    assert pyref._poly_eval(want, zeta, mod) * (pow(zeta, n, mod) - 1) % mod == pyref.plonk_numerator_at(
+        c, n, T["can"], T["qc_can"], T["pi_can"], T["bp"], T["alpha"], T["beta"], T["gamma"], zeta)
+    d0 = fft.Domain(emu_ctx, c.name, n)
+    d1 = fft.Domain(emu_ctx, c.name, plonk.Rho(n) * n)
+    try:
+        kw = dict(bp={k: fr_to_arr(c, v) for k, v in T["bp"].items()}, alpha=fr_to_arr(c, [T["alpha"]]), beta=fr_to_arr(c, [T["beta"]]),
+                  gamma=fr_to_arr(c, [T["gamma"]]))
+        names = list(plonk.IDS) + [x for i in range(nb_bsb) for x in (f"Qcp{i}", f"Pi2{i}")]
+        for lagr in ((), tuple(names), tuple(names[::2])):
+            pick = lambda nm, canv, lagv: fr_to_arr(c, lagv if nm in lagr else canv)
+            polys = {k: pick(k, T["can"][k], T["lag"][k]) for k in plonk.IDS}
+            qc = [pick(f"Qcp{i}", T["qc_can"][i], T["qcp"][i]) for i in range(nb_bsb)]
+            pi = [pick(f"Pi2{i}", T["pi_can"][i], T["pi2"][i]) for i in range(nb_bsb)]
+            got = plonk.ComputeQuotient(d0, d1, polys, qc, pi, lagrange=lagr, **kw)
+            assert arr_to_fr(c, got) == want, lagr
+    finally:
+        d0.close()
+        d1.close()
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("n", [2, 8, 512, 1000])
+def test_emu_plonk_build_z_and_batch_invert(emu_ctx, c, n):
+    """iop.BuildRatioCopyConstraint (prove.go:645-655) and batchInvert (prove.go:1134-1147) against the oracle; the grand
+    product closes (Z[n-1] * ratio[n-1] == 1) because the permutation only links equal values"""
+    mod = c.r
+    vals = [0, 1, mod - 1] + [pyref.Xoshiro(n).field(mod) for _ in range(max(0, n - 3))]
+    got = plonk.BatchInvert(emu_ctx, c.name, fr_to_arr(c, vals[:n]))
+    assert arr_to_fr(c, got) == [pow(v, -1, mod) if v else 0 for v in vals[:n]]
+    if n & (n - 1):
+        return
+    lag, _, _, perm, rng = pyref.plonk_synthetic_instance(c, n, 3 + n, 0)
+    beta, gamma = rng.field(mod), rng.field(mod)
+    want = pyref.plonk_build_z(c, n, lag["L"], lag["R"], lag["O"], perm, beta, gamma)
+    d0 = fft.Domain(emu_ctx, c.name, n)
+    try:
+        got = plonk.BuildRatioCopyConstraint(d0, fr_to_arr(c, lag["L"]), fr_to_arr(c, lag["R"]), fr_to_arr(c, lag["O"]), perm,
+                                             fr_to_arr(c, [beta]), fr_to_arr(c, [gamma]))
+        with pytest.raises(Exception, match="outside"):
+            plonk.BuildRatioCopyConstraint(d0, fr_to_arr(c, lag["L"]), fr_to_arr(c, lag["R"]), fr_to_arr(c, lag["O"]),
+                                           [3 * n] + list(perm[1:]), fr_to_arr(c, [beta]), fr_to_arr(c, [gamma]))
+    finally:
+        d0.close()
+    assert arr_to_fr(c, got) == want

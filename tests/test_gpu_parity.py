@@ -9,7 +9,7 @@ import pyref
 import test_emu_kernels as cases
 from gnark_amd import _lib, ecc, fft, groth16
 from gnark_amd.device import affine_words
-from helpers import BLS12_381, BN254, fr_to_arr, pts_to_arr
+from helpers import BLS12_381, BN254, arr_to_fr, fr_to_arr, pts_to_arr
 
 pytestmark = pytest.mark.gpu
 CURVES = [BN254, BLS12_381]
@@ -326,6 +326,81 @@ def test_groth16_bsb22_synthetic_2_14_vs_oracle(gpu_ctx, c):
     finally:
         pk.FreeGPUResources()
     assert np.array_equal(proof.Ar, want[0]) and np.array_equal(proof.Bs, want[1]) and np.array_equal(proof.Krs, want[2])
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("n,nb_bsb", [(4, 0), (8, 1), (64, 2), (1024, 1)])
+def test_plonk_quotient_vs_oracle(gpu_ctx, c, n, nb_bsb):
+    cases.test_emu_plonk_quotient(gpu_ctx, c, n, nb_bsb, seed=77 + n)
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("n", [2, 8, 512, 1000, 4096])
+def test_plonk_build_z_and_batch_invert(gpu_ctx, c, n):
+    cases.test_emu_plonk_build_z_and_batch_invert(gpu_ctx, c, n)
+
+
+def test_plonk_quotient_2_16_identity(gpu_ctx):
+    """n = 2^16 (4n = 2^18: multi-pass transforms): a satisfying synthetic trace built with the C oracle's FFT, Z from the device
+    grand product (checked against a Python prefix product at sampled positions and to close), then
+    h(zeta) * (zeta^n - 1) == gate + alpha*ordering + alpha^2*(Z-1)*L1 at a random zeta, every polynomial evaluated by the C
+    oracle's Horner -- independent of the device transforms."""
+    from gnark_amd import plonk
+    c, n = BN254, 1 << 16
+    mod = c.r
+    lag, qcp, pi2, perm, rng = pyref.plonk_synthetic_instance(c, n, 2024, 1)
+    beta, gamma, alpha, zeta = (rng.field(mod) for _ in range(4))
+    d0, d1 = fft.Domain(gpu_ctx, c.name, n), fft.Domain(gpu_ctx, c.name, 4 * n)
+    try:
+        arr = {k: fr_to_arr(c, v) for k, v in lag.items()}
+        Z = plonk.BuildRatioCopyConstraint(d0, arr["L"], arr["R"], arr["O"], perm, fr_to_arr(c, [beta]), fr_to_arr(c, [gamma]))
+        arr["Z"] = Z
+        zi = arr_to_fr(c, Z)
+        w0, g = c.fr_root_of_unity(n), c.fr_gen
+        ids = lambda pos: pow(g, pos // n, mod) * pow(w0, pos % n, mod) % mod
+        ev = [lag["L"], lag["R"], lag["O"]]
+
+        def ratio(i):
+            num = den = 1
+            for k in range(3):
+                num = num * ((ev[k][i] + beta * ids(k * n + i) + gamma) % mod) % mod
+                den = den * ((ev[k][i] + beta * ids(perm[k * n + i]) + gamma) % mod) % mod
+            return num * pow(den, -1, mod) % mod
+        assert zi[0] == 1 and zi[n - 1] * ratio(n - 1) % mod == 1
+        for i in (0, 1, 255, 256, 4097, n - 2):
+            assert zi[i + 1] == zi[i] * ratio(i) % mod
+        bp = {"Bl": [rng.field(mod) for _ in range(2)], "Br": [rng.field(mod) for _ in range(2)],
+              "Bo": [rng.field(mod) for _ in range(2)], "Bz": [rng.field(mod) for _ in range(3)]}
+        names = list(plonk.IDS) + ["Qcp0", "Pi20"]
+        h = plonk.ComputeQuotient(d0, d1, {k: arr[k] for k in plonk.IDS}, [fr_to_arr(c, qcp[0])], [fr_to_arr(c, pi2[0])],
+                                  bp={k: fr_to_arr(c, v) for k, v in bp.items()}, alpha=fr_to_arr(c, [alpha]), beta=fr_to_arr(c, [beta]),
+                                  gamma=fr_to_arr(c, [gamma]), lagrange=tuple(names))
+    finally:
+        d0.close()
+        d1.close()
+    horner = lambda coeffs, x: arr_to_fr(c, oracle.fr_horner(c.cid, coeffs, fr_to_arr(c, [x])[0]).reshape(1, 4))[0]
+
+    def lag_eval(evals_arr, x):
+        """evaluate the interpolant of evals on the domain at x: C oracle inverse FFT (DIF: bit-reversed output), then Horner"""
+        nat = oracle.fft(c.cid, evals_arr, 1, 0, False)
+        idx = np.array([pyref.bitrev(i, 16) for i in range(n)])
+        return horner(nat[idx], x)
+    e = {k: lag_eval(arr[k], zeta) for k in plonk.IDS}
+    zw = zeta * w0 % mod
+    z_w = lag_eval(arr["Z"], zw)
+    qc_z, pi_z = lag_eval(fr_to_arr(c, qcp[0]), zeta), lag_eval(fr_to_arr(c, pi2[0]), zeta)
+    zn1 = (pow(zeta, n, mod) - 1) % mod
+    b = lambda k, pt: pyref._poly_eval(bp[k], pt, mod) * ((pow(pt, n, mod) - 1) % mod) % mod
+    l, r, o = (e["L"] + b("Bl", zeta)) % mod, (e["R"] + b("Br", zeta)) % mod, (e["O"] + b("Bo", zeta)) % mod
+    z, zs = (e["Z"] + b("Bz", zeta)) % mod, (z_w + b("Bz", zw)) % mod
+    gate = (e["Ql"] * l + e["Qr"] * r + e["Qm"] * l % mod * r + e["Qo"] * o + e["Qk"] + qc_z * pi_z) % mod
+    idv = zeta * beta % mod
+    rr = (gamma + l + idv) * ((idv * g + r + gamma) % mod) % mod * ((idv * g * g + o + gamma) % mod) % mod * z % mod
+    ll = (e["S1"] * beta + l + gamma) * ((e["S2"] * beta + r + gamma) % mod) % mod * ((e["S3"] * beta + o + gamma) % mod) % mod * zs % mod
+    lone = zn1 * pow(n, -1, mod) % mod * pow((zeta - 1) % mod, -1, mod) % mod
+    want = (((z - 1) * lone % mod * alpha + (ll - rr)) % mod * alpha + gate) % mod
+    assert horner(h, zeta) * zn1 % mod == want
+    assert not h[3 * n + 6:].any()          # deg h = 3n + 5
 
 
 def test_loaded_library_is_the_hip_build(gpu_ctx):

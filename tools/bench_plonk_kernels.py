@@ -40,6 +40,53 @@ def main():
             d.FFTInverse(p, fft.DIF)
         d4.FFTInverse(big, fft.DIF, on_coset=True)   # divideByZH: one size-4n inverse transform
 
+    # ---- the same proof with the quotient computed by the fused device pipeline (ga_plonk_quotient):
+    # 12 inverse transforms once + 12 coset transforms per coset + one size-4n inverse, instead of 108 + 1
+    import ctypes as C
+    qin = _lib.PlonkQuotientIn()
+    for k, pbuf in zip(("l", "r", "o", "z", "ql", "qr", "qm", "qo", "qk", "s1", "s2", "s3"), polys):
+        setattr(qin, k, pbuf.ptr)
+    small = ctx.malloc(16 * 32)
+    lib.check(lib.ga_gen_scalars(ctx.handle, 0, 4242, 16, small.ptr))
+    host_small = small.to_host((16, 4))
+    qin.bl, qin.br, qin.bo, qin.bz = (host_small[i:].ctypes.data for i in (0, 2, 4, 6))
+    qin.alpha, qin.beta, qin.gamma = (host_small[i:].ctypes.data for i in (9, 10, 11))
+    qin.lagrange_mask = (1 << 12) - 1          # s.x[...] are in Lagrange form when computeNumerator starts
+    qin.flags = 1                              # GA_PLONK_ON_DEVICE
+    perm = ctx.malloc(3 * n * 8)
+    import numpy as np
+    host_perm = np.random.default_rng(1).permutation(3 * n).astype(np.int64)
+    ctx.lib.check(ctx.lib.ga_copy_to_device(ctx.handle, perm.ptr, host_perm.ctypes.data, 3 * n * 8))
+    zbuf = ctx.malloc(n * 32)
+
+    def proof_fused():
+        for k in range(10):
+            srs_table.MultiExp(polys[k % 12])
+        lib.check(lib.ga_plonk_build_z(d.handle, polys[0].ptr, polys[1].ptr, polys[2].ptr, perm.ptr, host_small[10:].ctypes.data,
+                                       host_small[11:].ctypes.data, 1, zbuf.ptr))
+        lib.check(lib.ga_plonk_quotient(d.handle, d4.handle, C.byref(qin), big.ptr))
+
+    if os.environ.get("GA_PLONK_FUSED", "1") == "1":
+        proof_fused()
+        ctx.profile(True)
+        ctx.profile_reset()
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            proof_fused()
+        ctx.sync()
+        el = (time.perf_counter() - t0) / 3
+        st = {}
+        for name, ms in ctx.profile_read():
+            st[name] = st.get(name, 0.0) + ms / 3
+        print(json.dumps({"workload": "PLONK BN254 2^%d, fused quotient: 10 G1 MSM + BuildRatioCopyConstraint + computeNumerator/divideByZH on device" % logn,
+                          "ms_per_proof_kernels": round(el * 1e3, 2),
+                          "msm_ms": round(sum(v for k, v in st.items() if k.startswith("msm_")), 2),
+                          "ntt_ms": round(sum(v for k, v in st.items() if k.startswith("ntt_")), 2),
+                          "plonk_pointwise_ms": round(sum(v for k, v in st.items() if k.startswith("plonk_")), 2),
+                          "stages_ms": {k: round(v, 3) for k, v in st.items()}}))
+        ctx.profile(False)
+
     proof_kernels()
     ctx.profile(True)
     ctx.profile_reset()
