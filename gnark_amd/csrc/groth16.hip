@@ -12,6 +12,15 @@
 
 namespace ga {
 
+// dst[idx[i]] = src[i] for elements of `chunks` 16-byte pieces (building the wire-indexed base arrays at pin time)
+static __global__ void g16_scatter_points_kernel(u32x4* __restrict__ dst, const u32x4* __restrict__ src, const uint32_t* __restrict__ idx,
+                                                 uint64_t n, uint32_t chunks) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t i = t / chunks, k = t % chunks;
+    if (i >= n) return;
+    dst[(uint64_t)idx[i] * chunks + k] = src[i * chunks + k];
+}
+
 struct G16Pk {
     Ctx* ctx = nullptr;
     int curve = 0;
@@ -28,6 +37,11 @@ struct G16Pk {
     // precomputed window-multiple tables (msm.cuh): d_a.. then point to windows x len points and c_* is the window width
     bool tables = false;
     int c_a = 0, c_b = 0, c_z = 0, c_k = 0;
+    // Wire-indexed tables: when a base vector covers (almost) every wire, its table is laid out by WIRE id with (0,0) at the
+    // wires it lacks (infinity entries are skipped by the bucket kernel), so that the digit extraction + radix sort of the whole
+    // witness is done ONCE and shared by the A, B (G1 and G2) and K MSMs instead of once per filtered copy of the witness.
+    bool share_a = false, share_b = false, share_k = false;
+    int c_w = 0;
     // multi-GPU partition B: this key holds slice [off, off+len) of every base vector (ga_g16_key.shard_index/count)
     uint32_t shard_index = 0, shard_count = 1;
     uint64_t off_k = 0, off_z = 0, full_len_k = 0;
@@ -169,14 +183,26 @@ static int pk_create(Ctx* ctx, const ga_g16_key* key, G16Pk** out) {
     if (rc == GA_OK && key->precompute >= 0) {
         int nw;
         const size_t t1 = msm_table_point_bytes<C, GA_G1>(), t2 = msm_table_point_bytes<C, GA_G2>();
+        // share the witness sort between the vectors that cover at least GA_G16_SHARE_MIN_PCT % of the wires (default 90: a
+        // sparse vector would make the lanes of the bucket kernel idle on its missing wires, and waste table memory)
+        int share_pct = 90;
+        if (const char* e = getenv("GA_G16_SHARE_MIN_PCT")) share_pct = atoi(e);
+        auto dense = [&](uint64_t len) {
+            return pk->shard_count == 1 && pk->nb_wires < (1ull << 27) && len > 0 && (double)len * 100.0 >= (double)pk->nb_wires * share_pct;
+        };
+        pk->share_a = dense(pk->len_a);
+        pk->share_b = dense(pk->len_b);
+        pk->share_k = dense(pk->len_k);
+        msm_plan_table<C>(pk->nb_wires, &pk->c_w, &nw);
+        const uint64_t wide = (uint64_t)nw * pk->nb_wires;
         msm_plan_table<C>(pk->len_a, &pk->c_a, &nw);
-        uint64_t need = (uint64_t)nw * pk->len_a * t1;
+        uint64_t need = pk->share_a ? wide * t1 : (uint64_t)nw * pk->len_a * t1;
         msm_plan_table<C>(pk->len_b, &pk->c_b, &nw);
-        need += (uint64_t)nw * pk->len_b * (t1 + t2);
+        need += pk->share_b ? wide * (t1 + t2) : (uint64_t)nw * pk->len_b * (t1 + t2);
         msm_plan_table<C>(pk->len_z, &pk->c_z, &nw);
         need += (uint64_t)nw * pk->len_z * t1;
         msm_plan_table<C>(pk->len_k, &pk->c_k, &nw);
-        need += (uint64_t)nw * pk->len_k * t1;
+        need += pk->share_k ? wide * t1 : (uint64_t)nw * pk->len_k * t1;
         size_t free_b = 0, total_b = 0;
         hipMemGetInfo(&free_b, &total_b);
         // leave room for the per-proof scratch (~0.6 KB per constraint measured) and some slack
@@ -198,14 +224,48 @@ static int pk_create(Ctx* ctx, const ga_g16_key* key, G16Pk** out) {
             };
             auto b1 = [&](const void* src, uint64_t len, int c, void* t) { return msm_table_build<C, GA_G1>(ctx, src, len, c, t); };
             auto b2 = [&](const void* src, uint64_t len, int c, void* t) { return msm_table_build<C, GA_G2>(ctx, src, len, c, t); };
-            rc = make(&pk->d_a, pk->len_a, pk->c_a, t1, b1);
-            if (rc == GA_OK) rc = make(&pk->d_b, pk->len_b, pk->c_b, t1, b1);
+            // compact base array -> wire-indexed array with (0,0) at the missing wires
+            auto widen = [&](void** slot, uint64_t len, const uint32_t* d_idx, size_t psz) -> int {
+                void* wide_arr = nullptr;
+                if (hipMalloc(&wide_arr, pk->nb_wires * psz) != hipSuccess) {
+                    set_error("proving key: hipMalloc of a wire-indexed base array failed");
+                    return GA_ERR_NOMEM;
+                }
+                GA_HIP_CHECK(hipMemsetAsync(wide_arr, 0, pk->nb_wires * psz, ctx->stream));
+                const uint32_t chunks = (uint32_t)(psz / 16);
+                const uint64_t threads = len * chunks;
+                hipLaunchKernelGGL(g16_scatter_points_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream,
+                                   (u32x4*)wide_arr, (const u32x4*)*slot, d_idx, len, chunks);
+                GA_KERNEL_CHECK();
+                GA_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+                hipFree(*slot);
+                *slot = wide_arr;
+                return GA_OK;
+            };
+            uint32_t* d_ik = pk->d_idx_k;   // wire ids of K's entries: the remove-list gather, or nbPublic + i
+            if (pk->share_k && !d_ik) {
+                const uint64_t nbp = pk->nb_wires - pk->len_k;
+                std::vector<uint32_t> ikk(pk->len_k);
+                for (uint64_t i = 0; i < pk->len_k; i++) ikk[i] = (uint32_t)(nbp + i);
+                rc = upload(ctx, ikk.data(), pk->len_k * 4, (void**)&d_ik);
+                if (rc == GA_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = GA_ERR_HIP;
+            }
+            if (rc == GA_OK && pk->share_a) rc = widen(&pk->d_a, pk->len_a, pk->d_idx_a, s1);
+            if (rc == GA_OK && pk->share_b) rc = widen(&pk->d_b, pk->len_b, pk->d_idx_b, s1);
+            if (rc == GA_OK && pk->share_b) rc = widen(&pk->d_b2, pk->len_b2, pk->d_idx_b, s2);
+            if (rc == GA_OK && pk->share_k) rc = widen(&pk->d_k, pk->len_k, d_ik, s1);
+            if (d_ik && d_ik != pk->d_idx_k) hipFree(d_ik);
+            const uint64_t nwr = pk->nb_wires;
+            if (rc == GA_OK) rc = pk->share_a ? make(&pk->d_a, nwr, pk->c_w, t1, b1) : make(&pk->d_a, pk->len_a, pk->c_a, t1, b1);
+            if (rc == GA_OK) rc = pk->share_b ? make(&pk->d_b, nwr, pk->c_w, t1, b1) : make(&pk->d_b, pk->len_b, pk->c_b, t1, b1);
             if (rc == GA_OK) rc = make(&pk->d_z, pk->len_z, pk->c_z, t1, b1);
-            if (rc == GA_OK) rc = make(&pk->d_k, pk->len_k, pk->c_k, t1, b1);
-            if (rc == GA_OK) rc = make(&pk->d_b2, pk->len_b2, pk->c_b, t2, b2);
+            if (rc == GA_OK) rc = pk->share_k ? make(&pk->d_k, nwr, pk->c_w, t1, b1) : make(&pk->d_k, pk->len_k, pk->c_k, t1, b1);
+            if (rc == GA_OK) rc = pk->share_b ? make(&pk->d_b2, nwr, pk->c_w, t2, b2) : make(&pk->d_b2, pk->len_b2, pk->c_b, t2, b2);
             pk->tables = rc == GA_OK;
+            if (!pk->tables) pk->share_a = pk->share_b = pk->share_k = false;
         }
     }
+    if (!pk->tables) pk->share_a = pk->share_b = pk->share_k = false;
     if (rc != GA_OK) {
         pk_free(pk);
         return rc;
@@ -282,10 +342,10 @@ static int prove_partial(G16Pk* pk, const void* w, const void* a, const void* b,
         }
     } joiner{uploader};
     // ---- wire filtering (prove.go:147-168) ------------------------------------------------------------
-    GA_CHECK(util_gather_fr<C>(ctx, d_wa, d_w, pk->d_idx_a, pk->len_a));
-    GA_CHECK(util_gather_fr<C>(ctx, d_wb, d_w, pk->d_idx_b, pk->len_b));
+    if (!pk->share_a) GA_CHECK(util_gather_fr<C>(ctx, d_wa, d_w, pk->d_idx_a, pk->len_a));
+    if (!pk->share_b) GA_CHECK(util_gather_fr<C>(ctx, d_wb, d_w, pk->d_idx_b, pk->len_b));
     const void* d_wk = (const char*)d_w + (nb_public + pk->off_k) * 32;
-    if (pk->d_idx_k) {
+    if (pk->d_idx_k && !pk->share_k) {
         void* g;
         GA_CHECK(ctx->scratch_get("g16_wk", pk->len_k * 32 + 32, &g));
         GA_CHECK(util_gather_fr<C>(ctx, g, d_w, pk->d_idx_k, pk->len_k));
@@ -304,11 +364,21 @@ static int prove_partial(G16Pk* pk, const void* w, const void* a, const void* b,
         return msm_table_device_reuse<C, GA_G1>(ctx, table, prep, out);
     };
     if (pk->tables) {
-        GA_CHECK(table_msm_g1(pk->d_a, d_wa, pk->len_a, pk->c_a, &ar));
-        GA_CHECK(table_msm_g1(pk->d_b, d_wb, pk->len_b, pk->c_b, &bs1));
-        if (pk->len_b2) GA_CHECK((msm_table_device_reuse<C, GA_G2>(ctx, pk->d_b2, prep, &bs2)));   // same scalars wB: digits/sort shared
-        else bs2 = xyzz_inf<F2>();
-        GA_CHECK(table_msm_g1(pk->d_k, d_wk, pk->len_k, pk->c_k, &krs));
+        // digits + sort of the WHOLE witness once (scratch slot 1), reused by every wire-indexed table
+        MsmPrepared prep_w;
+        if (pk->share_a || pk->share_b || pk->share_k) GA_CHECK(msm_prepare_table_scalars<C>(ctx, d_w, pk->nb_wires, true, pk->c_w, &prep_w, 1));
+        if (pk->share_a) GA_CHECK((msm_table_device_reuse<C, GA_G1>(ctx, pk->d_a, prep_w, &ar)));
+        else GA_CHECK(table_msm_g1(pk->d_a, d_wa, pk->len_a, pk->c_a, &ar));
+        if (pk->share_b) {
+            GA_CHECK((msm_table_device_reuse<C, GA_G1>(ctx, pk->d_b, prep_w, &bs1)));
+            GA_CHECK((msm_table_device_reuse<C, GA_G2>(ctx, pk->d_b2, prep_w, &bs2)));
+        } else {
+            GA_CHECK(table_msm_g1(pk->d_b, d_wb, pk->len_b, pk->c_b, &bs1));
+            if (pk->len_b2) GA_CHECK((msm_table_device_reuse<C, GA_G2>(ctx, pk->d_b2, prep, &bs2)));   // same scalars wB: digits/sort shared
+            else bs2 = xyzz_inf<F2>();
+        }
+        if (pk->share_k) GA_CHECK((msm_table_device_reuse<C, GA_G1>(ctx, pk->d_k, prep_w, &krs)));
+        else GA_CHECK(table_msm_g1(pk->d_k, d_wk, pk->len_k, pk->c_k, &krs));
     } else {
         GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_a, d_wa, pk->len_a, true, &ar)));
         GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_b, d_wb, pk->len_b, true, &bs1)));

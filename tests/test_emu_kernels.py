@@ -226,10 +226,32 @@ def test_emu_msm_empty_and_single(emu_ctx):
         ecc.MultiExp(emu_ctx, c.name, 0, pts_to_arr(c, 0, [c.g1]), fr_to_arr(c, [1, 2]))
 
 
-@pytest.mark.parametrize("precompute", [1, -1], ids=["tables", "no-tables"])
+class _share_pct:
+    """GA_G16_SHARE_MIN_PCT for the duration of a key pin: 0 forces the wire-indexed tables + single witness sort for every
+    base vector (even sparse ones), 101 forbids it"""
+    def __init__(self, pct):
+        self.pct = pct
+
+    def __enter__(self):
+        import os
+        self.old = os.environ.get("GA_G16_SHARE_MIN_PCT")
+        if self.pct is not None:
+            os.environ["GA_G16_SHARE_MIN_PCT"] = str(self.pct)
+
+    def __exit__(self, *a):
+        import os
+        if self.old is None:
+            os.environ.pop("GA_G16_SHARE_MIN_PCT", None)
+        else:
+            os.environ["GA_G16_SHARE_MIN_PCT"] = self.old
+
+
+@pytest.mark.parametrize("precompute", [1, -1, "shared-sort"], ids=["tables", "no-tables", "tables-shared-sort"])
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
 def test_emu_groth16_cubic(emu_ctx, c, precompute):
     """config 1: examples/cubic through the whole prover core, proof bytes identical to the oracle's."""
+    share = 0 if precompute == "shared-sort" else None
+    precompute = 1 if precompute == "shared-sort" else precompute
     rng = pyref.Xoshiro(2024)
     cs, w = pyref.cubic_r1cs(), pyref.cubic_witness(3)
     toxic = [rng.field(c.r) for _ in range(5)]
@@ -237,12 +259,13 @@ def test_emu_groth16_cubic(emu_ctx, c, precompute):
     r, s = rng.field(c.r), rng.field(c.r)
     ar, bs, krs = pyref.groth16_prove(pk, cs, w, r, s)
     A, B, Cc = pyref.r1cs_solve(c, cs, w)
-    dpk = groth16.ProvingKey(
-        emu_ctx, c.name, domain_cardinality=pk.n,
-        alpha1=pts_to_arr(c, 0, [pk.alpha1]), beta1=pts_to_arr(c, 0, [pk.beta1]), delta1=pts_to_arr(c, 0, [pk.delta1]),
-        A=pts_to_arr(c, 0, pk.A), B=pts_to_arr(c, 0, pk.B), Z=pts_to_arr(c, 0, pk.Z), K=pts_to_arr(c, 0, pk.K),
-        beta2=pts_to_arr(c, 1, [pk.beta2]), delta2=pts_to_arr(c, 1, [pk.delta2]), B2=pts_to_arr(c, 1, pk.B2),
-        infinityA=pk.infinityA, infinityB=pk.infinityB, precompute=precompute)
+    with _share_pct(share):
+        dpk = groth16.ProvingKey(
+            emu_ctx, c.name, domain_cardinality=pk.n,
+            alpha1=pts_to_arr(c, 0, [pk.alpha1]), beta1=pts_to_arr(c, 0, [pk.beta1]), delta1=pts_to_arr(c, 0, [pk.delta1]),
+            A=pts_to_arr(c, 0, pk.A), B=pts_to_arr(c, 0, pk.B), Z=pts_to_arr(c, 0, pk.Z), K=pts_to_arr(c, 0, pk.K),
+            beta2=pts_to_arr(c, 1, [pk.beta2]), delta2=pts_to_arr(c, 1, [pk.delta2]), B2=pts_to_arr(c, 1, pk.B2),
+            infinityA=pk.infinityA, infinityB=pk.infinityB, precompute=precompute)
     try:
         sol = groth16.Solution(W=fr_to_arr(c, w), A=fr_to_arr(c, A), B=fr_to_arr(c, B), C=fr_to_arr(c, Cc))
         proof = groth16.Prove(dpk, sol, cs.nb_public, fr_to_arr(c, [r]), fr_to_arr(c, [s]))
@@ -281,25 +304,28 @@ def test_emu_hash_to_field(emu_ctx):
             assert arr_to_fr(c, got) == pyref.fr_hash(c, msg, pyref.FOLD_DST, 3)
 
 
-@pytest.mark.parametrize("precompute", [1, -1], ids=["tables", "no-tables"])
+@pytest.mark.parametrize("precompute", [1, -1, "shared-sort"], ids=["tables", "no-tables", "tables-shared-sort"])
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
 def test_emu_groth16_bsb22_commitments(emu_ctx, c, precompute):
     """a circuit with two api.Commit calls.  The solver-side hint calls ProvingKey.Commit (device MSMs over
     the pinned pedersen bases) and hashes the commitment; Prove leaves the committed wires out of the K MSM; the folded proof
     of knowledge and the proof bytes equal the oracle's (prove.go:60-127,231-235, marshal.go:33-58)."""
     lib = emu_ctx.lib
+    share = 0 if precompute == "shared-sort" else None
+    precompute = 1 if precompute == "shared-sort" else precompute
     rng = pyref.Xoshiro(4242)
     cs = pyref.commit_r1cs()
     toxic = [rng.field(c.r) for _ in range(5 + len(cs.commitments) + 1)]
     pk, vk, _ = pyref.groth16_setup(c, cs, toxic)
     removed = sorted({j for cm in cs.commitments for j in cm.private_committed} | {cm.commitment_index for cm in cs.commitments})
-    dpk = groth16.ProvingKey(
-        emu_ctx, c.name, domain_cardinality=pk.n,
-        alpha1=pts_to_arr(c, 0, [pk.alpha1]), beta1=pts_to_arr(c, 0, [pk.beta1]), delta1=pts_to_arr(c, 0, [pk.delta1]),
-        A=pts_to_arr(c, 0, pk.A), B=pts_to_arr(c, 0, pk.B), Z=pts_to_arr(c, 0, pk.Z), K=pts_to_arr(c, 0, pk.K),
-        beta2=pts_to_arr(c, 1, [pk.beta2]), delta2=pts_to_arr(c, 1, [pk.delta2]), B2=pts_to_arr(c, 1, pk.B2),
-        infinityA=pk.infinityA, infinityB=pk.infinityB, precompute=precompute,
-        commitment_keys=[(pts_to_arr(c, 0, b), pts_to_arr(c, 0, e)) for b, e in pk.commitment_keys], k_remove=removed)
+    with _share_pct(share):
+        dpk = groth16.ProvingKey(
+            emu_ctx, c.name, domain_cardinality=pk.n,
+            alpha1=pts_to_arr(c, 0, [pk.alpha1]), beta1=pts_to_arr(c, 0, [pk.beta1]), delta1=pts_to_arr(c, 0, [pk.delta1]),
+            A=pts_to_arr(c, 0, pk.A), B=pts_to_arr(c, 0, pk.B), Z=pts_to_arr(c, 0, pk.Z), K=pts_to_arr(c, 0, pk.K),
+            beta2=pts_to_arr(c, 1, [pk.beta2]), delta2=pts_to_arr(c, 1, [pk.delta2]), B2=pts_to_arr(c, 1, pk.B2),
+            infinityA=pk.infinityA, infinityB=pk.infinityB, precompute=precompute,
+            commitment_keys=[(pts_to_arr(c, 0, b), pts_to_arr(c, 0, e)) for b, e in pk.commitment_keys], k_remove=removed)
     coms, poks = {}, {}
     fbytes = (c.r.bit_length() - 1) // 8 + 1
 

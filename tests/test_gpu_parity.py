@@ -54,7 +54,7 @@ def test_msm_empty_and_single(gpu_ctx):
     cases.test_emu_msm_empty_and_single(gpu_ctx)
 
 
-@pytest.mark.parametrize("precompute", [1, -1], ids=["tables", "no-tables"])
+@pytest.mark.parametrize("precompute", [1, -1, "shared-sort"], ids=["tables", "no-tables", "tables-shared-sort"])
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
 def test_groth16_cubic_bytes(gpu_ctx, c, precompute):
     cases.test_emu_groth16_cubic(gpu_ctx, c, precompute)
@@ -260,7 +260,7 @@ def test_groth16_synthetic_2_10_vs_oracle(gpu_ctx, c):
     assert len(proof.WriteTo()) == (164 if c.cid == 0 else 244)
 
 
-@pytest.mark.parametrize("precompute", [1, -1], ids=["tables", "no-tables"])
+@pytest.mark.parametrize("precompute", [1, -1, "shared-sort"], ids=["tables", "no-tables", "tables-shared-sort"])
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
 def test_groth16_bsb22_commitments_bytes(gpu_ctx, c, precompute):
     cases.test_emu_groth16_bsb22_commitments(gpu_ctx, c, precompute)
