@@ -291,12 +291,113 @@ template <class P> GA_HD F29x2<P> f29_partial_reduce(const F29x2<P>& a) { return
 template <class P> GA_HD bool f29_is_zero_limbs(const F29x2<P>& a) { return f29_is_zero_limbs(a.c0) & f29_is_zero_limbs(a.c1); }
 
 // Karatsuba; requires component sums < 2^(NL*L) (bounds: DESIGN.md "lazy bounds")
+// Montgomery reduction of 2*NL product columns (column sums below 2^63): the second half of f29_mul on its own
+template <class P>
+GA_HD F29<P> f29_reduce_cols(uint64_t (&col)[2 * Radix<P>::NL]) {
+    typedef Radix<P> R;
+    constexpr int NL = R::NL, L = R::L;
+    const uint32_t inv = P::INV & R::MASK;
+    F29<P> r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        const uint32_t m = ((uint32_t)col[i] * inv) & R::MASK;
+#pragma unroll
+        for (int j = 0; j < NL; j++) col[i + j] += (uint64_t)m * mod_limb<P>(j);
+        col[i + 1] += col[i] >> L;
+    }
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+        if (k + 1 < NL) {
+            r.l[k] = (uint32_t)col[NL + k] & R::MASK;
+            col[NL + k + 1] += col[NL + k] >> L;
+        } else {
+            r.l[k] = (uint32_t)col[NL + k];
+        }
+    }
+    return r;
+}
+
+// Fp2 product.  GA_FP2_LAZY (9-limb fields): Karatsuba on the UNREDUCED product columns -- three limb products, the
+// combinations  a0*b0 - a1*b1 + Z  and  (a0+a1)(b0+b1) - a0*b0 - a1*b1  formed column by column in 64-bit arithmetic, then
+// TWO Montgomery reductions instead of three (405 instead of 486 v_mad_u64_u32, and none of the five limb-wise add/sub
+// sweeps of the reduced-operand version).  The imaginary part's columns are sums of non-negative terms a0_i*b1_j + a1_i*b0_j;
+// the real part needs the offset Z = P::FP2Z, a multiple of p written with redundant digits so that every column dominates the
+// matching column of a1*b1 for operands below FP2Z_K*p (tools/gen_constants.py; bounds in tools/lazy_bounds.py).
+// Operand-sum limbs are < 2^(L+1): NL * 2^(2L+2) < 2^64.
+#ifndef GA_FP2_LAZY
+#define GA_FP2_LAZY 2
+#endif
+#ifndef GA_FP2_LAZY_MAX_NL
+#define GA_FP2_LAZY_MAX_NL 14
+#endif
 template <class P>
 GA_HD_BIG F29x2<P> f29_mul(const F29x2<P>& a, const F29x2<P>& b) {
-    F29<P> v0 = f29_mul(a.c0, b.c0);
-    F29<P> v1 = f29_mul(a.c1, b.c1);
-    F29<P> s = f29_mul(f29_add(a.c0, a.c1), f29_add(b.c0, b.c1));
-    return {f29_sub<2>(v0, v1), f29_sub<4>(s, f29_add(v0, v1))};
+    typedef Radix<P> R;
+    constexpr int NL = R::NL;
+    if constexpr (GA_FP2_LAZY == 2 && NL <= GA_FP2_LAZY_MAX_NL) {
+        // schoolbook on unreduced columns: real part a0*b0 + (K*p - a1)*b1, imaginary part a0*b1 + a1*b0 -- every term is
+        // non-negative, so there is no 64-bit subtraction (a v_sub_co/v_subb pair costs more than a multiply on gfx950) and
+        // only two column sets are live; 324 limb products + 2 reductions
+        constexpr int K = P::FP2Z_K;
+        F29<P> n1;
+#pragma unroll
+        for (int i = 0; i < NL; i++) n1.l[i] = kp_limb<P, K>(i) - a.c1.l[i];
+        f29_normalize(n1);
+        F29x2<P> r;
+        {   // one column set live at a time
+            uint64_t c0[2 * NL];
+#pragma unroll
+            for (int k = 0; k < 2 * NL; k++) c0[k] = 0;
+#pragma unroll
+            for (int i = 0; i < NL; i++)
+#pragma unroll
+                for (int j = 0; j < NL; j++) {
+                    c0[i + j] += (uint64_t)a.c0.l[i] * b.c0.l[j];
+                    c0[i + j] += (uint64_t)n1.l[i] * b.c1.l[j];
+                }
+            r.c0 = f29_reduce_cols<P>(c0);
+        }
+        {
+            uint64_t c1[2 * NL];
+#pragma unroll
+            for (int k = 0; k < 2 * NL; k++) c1[k] = 0;
+#pragma unroll
+            for (int i = 0; i < NL; i++)
+#pragma unroll
+                for (int j = 0; j < NL; j++) {
+                    c1[i + j] += (uint64_t)a.c0.l[i] * b.c1.l[j];
+                    c1[i + j] += (uint64_t)a.c1.l[i] * b.c0.l[j];
+                }
+            r.c1 = f29_reduce_cols<P>(c1);
+        }
+        return r;
+    } else if constexpr (GA_FP2_LAZY == 1 && NL <= 9) {
+        uint64_t c0[2 * NL], c1[2 * NL], cs[2 * NL];
+#pragma unroll
+        for (int k = 0; k < 2 * NL; k++) c0[k] = c1[k] = cs[k] = 0;
+#pragma unroll
+        for (int i = 0; i < NL; i++)
+#pragma unroll
+            for (int j = 0; j < NL; j++) {
+                c0[i + j] += (uint64_t)a.c0.l[i] * b.c0.l[j];
+                c1[i + j] += (uint64_t)a.c1.l[i] * b.c1.l[j];
+                cs[i + j] += (uint64_t)(a.c0.l[i] + a.c1.l[i]) * (b.c0.l[j] + b.c1.l[j]);
+            }
+#pragma unroll
+        for (int k = 0; k < 2 * NL - 1; k++) {
+            cs[k] = cs[k] - c0[k] - c1[k];
+            c0[k] = c0[k] + P::FP2Z[k] - c1[k];
+        }
+        F29x2<P> r;
+        r.c0 = f29_reduce_cols<P>(c0);
+        r.c1 = f29_reduce_cols<P>(cs);
+        return r;
+    } else {
+        F29<P> v0 = f29_mul(a.c0, b.c0);
+        F29<P> v1 = f29_mul(a.c1, b.c1);
+        F29<P> s = f29_mul(f29_add(a.c0, a.c1), f29_add(b.c0, b.c1));
+        return {f29_sub<2>(v0, v1), f29_sub<4>(s, f29_add(v0, v1))};
+    }
 }
 // complex squaring: (a0+a1)(a0-a1) + 2 a0 a1 u
 template <class P>

@@ -25,6 +25,35 @@ def arr(x, n, w):
     return "{" + ", ".join(f"0x{v:0{w // 4}x}{sfx}" for v in limbs(x, n, w)) + "}"
 
 
+FP2_LAZY_K = 16   # operands of the lazy Fp2 product are below 16p (asserted by tools/lazy_bounds.py)
+
+
+def fp2_lazy_offset(mod, n64, K=FP2_LAZY_K):
+    """Column constants Z[0..2NL-2] for field29.cuh's Fp2 product: a multiple of p in a redundant base-2^L representation whose
+    every column dominates the corresponding column of a1*b1 (operands < K*p, normalized limbs), so that
+    a0*b0 - a1*b1 + Z can be formed column by column in unsigned 64-bit arithmetic before ONE Montgomery reduction."""
+    n32 = 2 * n64
+    L = 29 if n32 == 8 else 28
+    NL = (32 * n32 + L - 1) // L + (1 if (32 * n32) % L == 0 else 0)
+    top = (K * mod >> (L * (NL - 1))) + 1
+    A = [2 ** L - 1] * (NL - 1) + [top]
+    ncol = 2 * NL - 1
+    colb = [sum(A[i] * A[j - i] for i in range(NL) if 0 <= j - i < NL) for j in range(ncol)]
+    t = [0] * ncol            # t[j]: units of 2^L column j borrows from column j+1
+    prev = 0
+    for j in range(ncol - 1):
+        t[j] = (colb[j] + prev + (1 << L) - 1) >> L
+        prev = t[j]
+    need_top = colb[ncol - 1] + prev
+    zint = -(-(need_top << (L * (ncol - 1))) // mod) * mod
+    z = [(zint >> (L * j)) & ((1 << L) - 1) for j in range(ncol - 1)] + [zint >> (L * (ncol - 1))]
+    Z = [z[j] + (t[j] << L) - (t[j - 1] if j else 0) for j in range(ncol)]
+    assert sum(Z[j] << (L * j) for j in range(ncol)) == zint and zint % mod == 0
+    assert all(Z[j] >= colb[j] for j in range(ncol)) and max(Z) + max(colb) + NL * (1 << (2 * L)) < 1 << 63
+    R = 1 << (L * NL)
+    return Z, zint, -(-zint // R)     # the offset adds less than this to a reduced value
+
+
 def field_block(name, mod, n64, w, extra=None):
     n = n64 * (64 // w)
     R = 1 << (64 * n64)
@@ -40,6 +69,12 @@ def field_block(name, mod, n64, w, extra=None):
     out.append(f"    static constexpr {ty} R2[{n}] = {arr(R * R % mod, n, w)};    // R^2 mod p")
     out.append(f"    static constexpr {ty} PM2[{n}] = {arr(mod - 2, n, w)};   // p-2 (Fermat inverse exponent)")
     out.append(f"    static constexpr uint32_t MU12 = {(1 << (mod.bit_length() + 8)) // mod}u;   // floor(2^(BITS+8) / p): Barrett quotient estimate (field29.cuh)")
+    if w == 32 and name.endswith("_Fp"):
+        Z, zint, add = fp2_lazy_offset(mod, n64)
+        out.append(f"    // lazy Fp2 product (field29.cuh): redundant-digit columns of a multiple of p dominating a1*b1 for operands < {FP2_LAZY_K}p;")
+        out.append(f"    // it adds < {add / mod:.3f} p to the reduced real part")
+        out.append(f"    static constexpr int FP2Z_K = {FP2_LAZY_K};")
+        out.append(f"    static constexpr uint64_t FP2Z[{len(Z)}] = {{" + ", ".join(f"0x{v:x}ull" for v in Z) + "};")
     for k, v in (extra or {}).items():
         if isinstance(v, int) and k.isupper() and k.startswith("I_"):
             out.append(f"    static constexpr int {k[2:]} = {v};")

@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 cp gnark_amd/libgnark_amd.so /tmp/lib_default.so
 for v in gnark_amd/variants/lib_*.so; do
   cp $v gnark_amd/libgnark_amd.so
-  timeout 600 python bench.py --no-cpu-baseline > gpurun_out/var.log 2>&1
+  timeout 600 python bench.py --no-cpu-baseline $VAR_ARGS > gpurun_out/var.log 2>&1
   python - "$v" <<'PY'
 import json,sys
 for line in open('gpurun_out/var.log'):

@@ -39,7 +39,25 @@ def check(curve: str, fp2: bool, verbose=False):
         q = v >> bits
         return (1 << bits) + q * ((1 << bits) - p)
 
-    if fp2:
+    if fp2 and NL <= int(__import__("os").environ.get("GA_FP2_LAZY_MAX_NL", "14")):
+        # lazy Fp2 product (field29.cuh, GA_FP2_LAZY): Karatsuba on unreduced columns, offset Z (gen_constants.fp2_lazy_offset)
+        import os
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from gen_constants import FP2_LAZY_K, fp2_lazy_offset
+        _, zint, _ = fp2_lazy_offset(p, (bits + 63) // 64)
+        assert NL * (1 << (2 * L + 2)) < 1 << 64, "operand-sum columns overflow 64 bits"
+
+        variant = int(os.environ.get("GA_FP2_LAZY", "2"))   # 1: Karatsuba on columns with the offset Z; 2: schoolbook with K*p - a1
+
+        def mul(a, b):
+            assert a < FP2_LAZY_K * p and b < FP2_LAZY_K * p, ("Fp2 operand above FP2Z_K*p", log2(a), log2(b))
+            lim(a), lim(b)
+            if variant == 2:
+                assert 2 * NL * (1 << (2 * L)) + NL * (1 << (2 * L)) < 1 << 64
+                return max((a * b + (FP2_LAZY_K * p + unit) * b) // R + p, 2 * a * b // R + p)
+            return max((a * b + zint) // R + p, 2 * a * b // R + p)
+    elif fp2:
         def mul(a, b):
             lim(2 * a), lim(2 * b)
             v, s = mul1(a, b), mul1(2 * a, 2 * b)
@@ -47,6 +65,7 @@ def check(curve: str, fp2: bool, verbose=False):
             need(k["KS"], 2 * v, "KS")
             return max(v + k["KV"] * p, s + k["KS"] * p)
 
+    if fp2:
         def sqr(a):
             need(k["KQ"], a, "KQ")
             return max(mul1(lim(2 * a), a + k["KQ"] * p), 2 * mul1(a, a))
