@@ -158,6 +158,56 @@ GA_HD_BIG F29<P> f29_mul(const F29<P>& a, const F29<P>& b) {
     return r;
 }
 
+// Montgomery reduction of 2*NL product columns (column sums below 2^63): the second half of f29_mul on its own
+template <class P>
+GA_HD F29<P> f29_reduce_cols(uint64_t (&col)[2 * Radix<P>::NL]) {
+    typedef Radix<P> R;
+    constexpr int NL = R::NL, L = R::L;
+    const uint32_t inv = P::INV & R::MASK;
+    F29<P> r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        const uint32_t m = ((uint32_t)col[i] * inv) & R::MASK;
+#pragma unroll
+        for (int j = 0; j < NL; j++) col[i + j] += (uint64_t)m * mod_limb<P>(j);
+        col[i + 1] += col[i] >> L;
+    }
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+        if (k + 1 < NL) {
+            r.l[k] = (uint32_t)col[NL + k] & R::MASK;
+            col[NL + k + 1] += col[NL + k] >> L;
+        } else {
+            r.l[k] = (uint32_t)col[NL + k];
+        }
+    }
+    return r;
+}
+
+// a*b - c*d (+ a multiple of p) with ONE reduction: the columns of a*b and of (K*p - c)*d are accumulated together.
+// Requires c < K*p; result < (a*b + K*p*d) / 2^(NL*L) + p.  Saves a Montgomery reduction and a limb-wise subtraction per
+// difference of products (Y3 of the mixed addition).
+template <int K, class P>
+GA_HD_BIG F29<P> f29_mul_sub(const F29<P>& a, const F29<P>& b, const F29<P>& c, const F29<P>& d) {
+    typedef Radix<P> R;
+    constexpr int NL = R::NL;
+    F29<P> nc;
+#pragma unroll
+    for (int i = 0; i < NL; i++) nc.l[i] = kp_limb<P, K>(i) - c.l[i];
+    f29_normalize(nc);
+    uint64_t col[2 * NL];
+#pragma unroll
+    for (int k = 0; k < 2 * NL; k++) col[k] = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++)
+#pragma unroll
+        for (int j = 0; j < NL; j++) {
+            col[i + j] += (uint64_t)a.l[i] * b.l[j];
+            col[i + j] += (uint64_t)nc.l[i] * d.l[j];
+        }
+    return f29_reduce_cols<P>(col);
+}
+
 // memory image (x * 2^(32N), canonical) -> hat(x) as an ordinary canonical 32N-bit integer (table storage format)
 template <class P>
 GA_HD Fe<P> f29_hat_packed(const Fe<P>& x) {
@@ -291,32 +341,6 @@ template <class P> GA_HD F29x2<P> f29_partial_reduce(const F29x2<P>& a) { return
 template <class P> GA_HD bool f29_is_zero_limbs(const F29x2<P>& a) { return f29_is_zero_limbs(a.c0) & f29_is_zero_limbs(a.c1); }
 
 // Karatsuba; requires component sums < 2^(NL*L) (bounds: DESIGN.md "lazy bounds")
-// Montgomery reduction of 2*NL product columns (column sums below 2^63): the second half of f29_mul on its own
-template <class P>
-GA_HD F29<P> f29_reduce_cols(uint64_t (&col)[2 * Radix<P>::NL]) {
-    typedef Radix<P> R;
-    constexpr int NL = R::NL, L = R::L;
-    const uint32_t inv = P::INV & R::MASK;
-    F29<P> r;
-#pragma unroll
-    for (int i = 0; i < NL; i++) {
-        const uint32_t m = ((uint32_t)col[i] * inv) & R::MASK;
-#pragma unroll
-        for (int j = 0; j < NL; j++) col[i + j] += (uint64_t)m * mod_limb<P>(j);
-        col[i + 1] += col[i] >> L;
-    }
-#pragma unroll
-    for (int k = 0; k < NL; k++) {
-        if (k + 1 < NL) {
-            r.l[k] = (uint32_t)col[NL + k] & R::MASK;
-            col[NL + k + 1] += col[NL + k] >> L;
-        } else {
-            r.l[k] = (uint32_t)col[NL + k];
-        }
-    }
-    return r;
-}
-
 // Fp2 product.  GA_FP2_LAZY (9-limb fields): Karatsuba on the UNREDUCED product columns -- three limb products, the
 // combinations  a0*b0 - a1*b1 + Z  and  (a0+a1)(b0+b1) - a0*b0 - a1*b1  formed column by column in 64-bit arithmetic, then
 // TWO Montgomery reductions instead of three (405 instead of 486 v_mad_u64_u32, and none of the five limb-wise add/sub
@@ -406,6 +430,57 @@ GA_HD_BIG F29x2<P> f29_sqr(const F29x2<P>& a) {
     F29<P> r0 = f29_mul(f29_add(a.c0, a.c1), f29_sub<8>(a.c0, a.c1));
     return {r0, f29_add(t, t)};
 }
+// a*b - c*d in Fp2 with two reductions (instead of four): real = a0*b0 + (Kp-a1)*b1 + (Kp-c0)*d0 + c1*d1,
+// imaginary = a0*b1 + a1*b0 + (Kp-c0)*d1 + (Kp-c1)*d0.  Four products per column: 4*NL*2^(2L) + NL*2^(2L) < 2^64.
+template <int K, class P>
+GA_HD_BIG F29x2<P> f29_mul_sub(const F29x2<P>& a, const F29x2<P>& b, const F29x2<P>& c, const F29x2<P>& d) {
+    typedef Radix<P> R;
+    constexpr int NL = R::NL;
+    static_assert(5.0 * NL * (double)(1ull << (2 * R::L)) < 18446744073709551616.0, "column sums must fit 64 bits");
+    F29<P> na1, nc0, nc1;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        na1.l[i] = kp_limb<P, K>(i) - a.c1.l[i];
+        nc0.l[i] = kp_limb<P, K>(i) - c.c0.l[i];
+        nc1.l[i] = kp_limb<P, K>(i) - c.c1.l[i];
+    }
+    f29_normalize(na1);
+    f29_normalize(nc0);
+    f29_normalize(nc1);
+    F29x2<P> r;
+    {
+        uint64_t col[2 * NL];
+#pragma unroll
+        for (int k = 0; k < 2 * NL; k++) col[k] = 0;
+#pragma unroll
+        for (int i = 0; i < NL; i++)
+#pragma unroll
+            for (int j = 0; j < NL; j++) {
+                col[i + j] += (uint64_t)a.c0.l[i] * b.c0.l[j];
+                col[i + j] += (uint64_t)na1.l[i] * b.c1.l[j];
+                col[i + j] += (uint64_t)nc0.l[i] * d.c0.l[j];
+                col[i + j] += (uint64_t)c.c1.l[i] * d.c1.l[j];
+            }
+        r.c0 = f29_reduce_cols<P>(col);
+    }
+    {
+        uint64_t col[2 * NL];
+#pragma unroll
+        for (int k = 0; k < 2 * NL; k++) col[k] = 0;
+#pragma unroll
+        for (int i = 0; i < NL; i++)
+#pragma unroll
+            for (int j = 0; j < NL; j++) {
+                col[i + j] += (uint64_t)a.c0.l[i] * b.c1.l[j];
+                col[i + j] += (uint64_t)a.c1.l[i] * b.c0.l[j];
+                col[i + j] += (uint64_t)nc0.l[i] * d.c1.l[j];
+                col[i + j] += (uint64_t)nc1.l[i] * d.c0.l[j];
+            }
+        r.c1 = f29_reduce_cols<P>(col);
+    }
+    return r;
+}
+
 template <class P>
 GA_HD_BIG F29<P> f29_sqr(const F29<P>& a) {
 #if GA_F29_CHAINED

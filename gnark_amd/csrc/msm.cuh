@@ -310,7 +310,7 @@ __device__ __forceinline__ void madd29(const LdsAcc29<Fe<P>>& A, const F29<P>& q
     F29<P> Q = f29_mul(ax, PP);
     F29<P> X3 = f29_sub<4>(f29_sqr(R), f29_add(PPP, f29_add(Q, Q)));
     A.put(0, X3);
-    A.put(1, f29_sub<2>(f29_mul(R, f29_sub<8>(Q, X3)), f29_mul(ay, PPP)));
+    A.put(1, f29_mul_sub<8>(R, f29_sub<8>(Q, X3), ay, PPP));   // Y3 = R*(Q - X3) - Y1*PPP, one reduction
 }
 
 template <class P>
@@ -331,7 +331,7 @@ __device__ __forceinline__ void madd29(const LdsAcc29<Fe2<P>>& A, const F29x2<P>
     T Q = f29_mul(ax, PP);
     T X3 = f29_partial_reduce(f29_sub<16>(f29_sqr(R), f29_add(PPP, f29_add(Q, Q))));
     A.put(0, X3);
-    A.put(1, f29_sub<8>(f29_mul(R, f29_sub<8>(Q, X3)), f29_mul(ay, PPP)));
+    A.put(1, f29_mul_sub<P::FP2Z_K>(R, f29_sub<8>(Q, X3), ay, PPP));   // Y3 = R*(Q - X3) - Y1*PPP, two reductions instead of four
 }
 
 template <class F>

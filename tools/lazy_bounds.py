@@ -97,8 +97,15 @@ def check(curve: str, fp2: bool, verbose=False):
             X3 = pr(X3)
         need(k["Kq"], X3, "Kq")
         t = Q + k["Kq"] * p
-        need(k["Ky3"], mul(by, PPP), "Ky3")
-        Y3 = mul(Rr, t) + k["Ky3"] * p
+        # Y3 = R*t - Y1*PPP as ONE column accumulation R*t + (K*p - Y1)*PPP (f29_mul_sub): K = 8 (G1), FP2Z_K = 16 (G2)
+        Kms = 16 if fp2 else 8
+        assert by + unit < Kms * p, ("Y1 above the negation constant of f29_mul_sub", log2(by))
+        lim(Rr), lim(t), lim(PPP)
+        if fp2:
+            Y3 = max(Rr * t + Kms * p * t + Kms * p * PPP + by * PPP, 2 * Rr * t + 2 * Kms * p * PPP) // R + p
+            assert max(Rr, t, by, PPP) < 16 * p
+        else:
+            Y3 = (Rr * t + Kms * p * PPP) // R + p
         ZZ3, ZZZ3 = mul(bzz, PP), mul(bzzz, PPP)
         for v in (Pp, Rr, PP, PPP, Q, X3, t, Y3, ZZ3, ZZZ3):
             lim(v)
