@@ -319,17 +319,17 @@ __device__ __forceinline__ void madd29(const LdsAcc29<Fe2<P>>& A, const F29x2<P>
     T zz = A.get(2);
     T U2 = f29_mul(qx, zz);
     T ax = A.get(0);
-    T Pp = f29_partial_reduce(f29_sub<16>(U2, ax));
+    T Pp = f29_sub<4>(U2, ax);
     T zzz = A.get(3);
     T S2 = f29_mul(qy, zzz);
     T ay = A.get(1);
-    T R = f29_partial_reduce(f29_sub<16>(S2, ay));
+    T R = f29_sub<4>(S2, ay);
     T PP = f29_sqr(Pp);
     A.put(2, f29_mul(zz, PP));
-    T PPP = f29_partial_reduce(f29_mul(Pp, PP));
+    T PPP = f29_mul(Pp, PP);
     A.put(3, f29_mul(zzz, PPP));
     T Q = f29_mul(ax, PP);
-    T X3 = f29_partial_reduce(f29_sub<16>(f29_sqr(R), f29_add(PPP, f29_add(Q, Q))));
+    T X3 = f29_partial_reduce(f29_sub<4>(f29_sqr(R), f29_add(PPP, f29_add(Q, Q))));
     A.put(0, X3);
     A.put(1, f29_mul_sub<P::FP2Z_K>(R, f29_sub<8>(Q, X3), ay, PPP));   // Y3 = R*(Q - X3) - Y1*PPP, two reductions instead of four
 }

@@ -15,7 +15,7 @@ CURVES = {"bn254": (BN254_P, 29, 9, 254), "bls12-381": (BLS12_381_P, 28, 14, 381
 
 # constants used by msm.cuh::madd29 (G1) and its Fp2 overload (G2), and by field29.cuh's Fp2 product / square
 G1 = dict(Kx=8, Ky=8, K3=4, Kq=8, Ky3=2)
-G2 = dict(Kx=16, Ky=16, K3=16, Kq=8, Ky3=8, KV=2, KS=4, KQ=8, partial_reduce=("P", "R", "PPP", "X"))
+G2 = dict(Kx=4, Ky=4, K3=4, Kq=8, Ky3=8, KV=2, KS=4, KQ=8, partial_reduce=("X",))
 
 
 def check(curve: str, fp2: bool, verbose=False):
