@@ -44,6 +44,9 @@ namespace ga {
 #ifndef GA_ACC_LDS_BYTES
 #define GA_ACC_LDS_BYTES 128  // accumulators of at least this many bytes live in LDS (all groups; measured best)
 #endif
+#ifndef GA_REDUCE_LAZY
+#define GA_REDUCE_LAZY 1      // window reduction of large bucket sets in the lazy representation (msm_reduce_groups29_kernel)
+#endif
 constexpr uint32_t MSM_SIGN = 0x80000000u;
 constexpr int MSM_HOT_TASKS = 16;     // buckets with more partials than this go to the wave-parallel merge
 constexpr int MSM_GROUP = 32;         // buckets per running-sum group in the window reduction
@@ -515,6 +518,142 @@ msm_reduce_groups_kernel(const XYZZ<F>* __restrict__ bsum, uint32_t half, uint32
     store_pod(&gsum[gid], local);
 }
 
+// ---- the same pass in the lazy representation ---------------------------------------------------------------------------
+// General XYZZ + XYZZ addition (add-2008-s) on unreduced limbs: 14 limb products with 13 reductions (Y3 fused), no modular
+// corrections.  Exceptional inputs (equal or opposite points) are NOT handled: they make ZZ3 = 0 (mod p), which sticks to every
+// later sum, so the caller tests ZZ once at the end and falls back to the exact kernel.  Constants: tools/lazy_bounds.py
+// check_add.
+template <class F>
+struct Lazy4 {
+    typename Lazy<F>::T x, y, zz, zzz;
+};
+template <class F>
+__device__ __forceinline__ Lazy4<F> lazy4_from_mem(const XYZZ<F>& p) {
+    return {Lazy<F>::from_mem(p.x), Lazy<F>::from_mem(p.y), Lazy<F>::from_mem(p.zz), Lazy<F>::from_mem(p.zzz)};
+}
+template <class F>
+__device__ __forceinline__ void add29(Lazy4<F>& a, const Lazy4<F>& b) {
+    typedef typename Lazy<F>::T T;
+    typedef typename Lazy<F>::Params P;
+    constexpr int KMS = Lazy<F>::FP2 ? P::FP2Z_K : 8;
+    T U1 = f29_mul(a.x, b.zz);
+    T U2 = f29_mul(b.x, a.zz);
+    T S1 = f29_mul(a.y, b.zzz);
+    T S2 = f29_mul(b.y, a.zzz);
+    T Pp = f29_sub<4>(U2, U1);
+    T R = f29_sub<4>(S2, S1);
+    T PP = f29_sqr(Pp);
+    T PPP = f29_mul(Pp, PP);
+    T Q = f29_mul(U1, PP);
+    T X3 = f29_sub<4>(f29_sqr(R), f29_add(PPP, f29_add(Q, Q)));
+    if constexpr (Lazy<F>::FP2) X3 = f29_partial_reduce(X3);
+    a.y = f29_mul_sub<KMS>(R, f29_sub<8>(Q, X3), S1, PPP);
+    a.x = X3;
+    a.zz = f29_mul(f29_mul(a.zz, b.zz), PP);
+    a.zzz = f29_mul(f29_mul(a.zzz, b.zzz), PPP);
+}
+
+// lsum[g] = sum_j (j+1)*B_j and rsum[g] = sum_j B_j over the m buckets of group g (no scalar multiplication: the term
+// sum_g (g*m)*rsum[g] is assembled from per-bit tree sums, msm_bit_partial_kernel).  Groups in which an exceptional addition
+// occurred (e.g. local + running when they are the same point because a bucket was empty) are appended to redo_list.
+template <class F>
+__global__ void __launch_bounds__(64)
+msm_reduce_groups29_kernel(const XYZZ<F>* __restrict__ bsum, uint32_t half, uint32_t m, uint32_t groups_per_win,
+                           uint32_t total_groups, XYZZ<F>* __restrict__ lsum, XYZZ<F>* __restrict__ rsum,
+                           uint32_t* __restrict__ redo_list, uint32_t* __restrict__ redo_count) {
+    uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total_groups) return;
+    uint32_t w = gid / groups_per_win, g = gid % groups_per_win;
+    const XYZZ<F>* B = bsum + (uint64_t)w * half + (uint64_t)g * m;   // B[j] = bucket of digit g*m + j + 1
+    Lazy4<F> running, local;
+    bool r_inf = true, l_inf = true;
+    for (int j = (int)m - 1; j >= 0; j--) {
+        XYZZ<F> b = load_pod<XYZZ<F>>(&B[j]);
+        if (!is_inf(b)) {
+            Lazy4<F> lb = lazy4_from_mem<F>(b);
+            if (r_inf) {
+                running = lb;
+                r_inf = false;
+            } else {
+                add29<F>(running, lb);
+            }
+        }
+        if (!r_inf) {
+            if (l_inf) {
+                local = running;
+                l_inf = false;
+            } else {
+                add29<F>(local, running);
+            }
+        }
+    }
+    XYZZ<F> lo = xyzz_inf<F>(), ro = xyzz_inf<F>();
+    bool bad = false;
+    if (!r_inf) {
+        ro.zz = Lazy<F>::to_mem(running.zz);
+        lo.zz = Lazy<F>::to_mem(local.zz);
+        bad = is_zero(ro.zz) | is_zero(lo.zz);
+        ro.x = Lazy<F>::to_mem(running.x);
+        ro.y = Lazy<F>::to_mem(running.y);
+        ro.zzz = Lazy<F>::to_mem(running.zzz);
+        lo.x = Lazy<F>::to_mem(local.x);
+        lo.y = Lazy<F>::to_mem(local.y);
+        lo.zzz = Lazy<F>::to_mem(local.zzz);
+    }
+    if (bad) {
+        redo_list[atomicAdd(redo_count, 1u)] = gid;
+        return;
+    }
+    store_pod(&lsum[gid], lo);
+    store_pod(&rsum[gid], ro);
+}
+
+// exact re-run (complete formulas) of the groups the lazy kernel flagged
+template <class F>
+__global__ void __launch_bounds__(64)
+msm_reduce_groups_redo_kernel(const XYZZ<F>* __restrict__ bsum, uint32_t half, uint32_t m, uint32_t groups_per_win,
+                              const uint32_t* __restrict__ redo_list, const uint32_t* __restrict__ redo_count,
+                              XYZZ<F>* __restrict__ lsum, XYZZ<F>* __restrict__ rsum) {
+    const uint32_t nredo = *redo_count;
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nredo; r += gridDim.x * blockDim.x) {
+        const uint32_t gid = redo_list[r];
+        uint32_t w = gid / groups_per_win, g = gid % groups_per_win;
+        const XYZZ<F>* B = bsum + (uint64_t)w * half + (uint64_t)g * m;
+        XYZZ<F> running = xyzz_inf<F>(), local = xyzz_inf<F>();
+        for (int j = (int)m - 1; j >= 0; j--) {
+            running = add(running, load_pod<XYZZ<F>>(&B[j]));
+            local = add(local, running);
+        }
+        store_pod(&lsum[gid], local);
+        store_pod(&rsum[gid], running);
+    }
+}
+
+// part[((w*nbits + b)*chunks + ch)] = sum of rsum[w][g] over the groups g of chunk ch (chunk_len groups, a power of two)
+// whose index has bit b set.  grid = (chunks, nbits, nsets), one wave per block.
+template <class F>
+__global__ void __launch_bounds__(64)
+msm_bit_partial_kernel(const XYZZ<F>* __restrict__ rsum, uint32_t groups_per_win, uint32_t chunk_len, int log_chunk,
+                       XYZZ<F>* __restrict__ part) {
+    __shared__ XYZZ<F> sh[64];
+    const uint32_t ch = blockIdx.x, b = blockIdx.y, w = blockIdx.z;
+    const uint32_t nbits = gridDim.y, chunks = gridDim.x;
+    const uint32_t base = ch * chunk_len;
+    const XYZZ<F>* R = rsum + (uint64_t)w * groups_per_win;
+    XYZZ<F> acc = xyzz_inf<F>();
+    if ((int)b >= log_chunk) {
+        if ((base >> b) & 1)   // the whole chunk has the bit set
+            for (uint32_t i = threadIdx.x; i < chunk_len; i += 64) acc = add(acc, load_pod<XYZZ<F>>(&R[base + i]));
+    } else {
+        for (uint32_t i = threadIdx.x; i < chunk_len / 2; i += 64) {   // insert a 1 at bit position b of the local index
+            uint32_t g = ((i >> b) << (b + 1)) | (1u << b) | (i & ((1u << b) - 1));
+            acc = add(acc, load_pod<XYZZ<F>>(&R[base + g]));
+        }
+    }
+    acc = wave_tree_sum(acc, sh);
+    if (threadIdx.x == 0) store_pod(&part[((uint64_t)w * nbits + b) * chunks + ch], acc);
+}
+
 // out[b] = sum of in[b*seg_len .. (b+1)*seg_len): one wave per segment, strided partial sums + LDS tree
 template <class F>
 __global__ void __launch_bounds__(64)
@@ -702,7 +841,14 @@ int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, X
                            (const uint32_t*)hot_list, (const uint32_t*)hot_count, bsum);
         GA_KERNEL_CHECK();
     }
-    {
+    // Window reduction.  Large bucket sets: lazy per-group pass without the per-lane scalar multiplication,
+    //   set sum = sum_g lsum[g] + m * sum_b 2^b * T_b,   T_b = sum of rsum[g] over the groups whose index has bit b set,
+    // the T_b being plain tree sums and the last line host arithmetic.  Small sets keep the exact kernel: their time is
+    // launch/dependency latency, and empty buckets (which the lazy formulas cannot add to themselves) are common there.
+    uint64_t lazy_min = 1u << 18;   // buckets; GA_REDUCE_LAZY_MIN overrides (tests force the lazy path on tiny inputs with 0)
+    if (const char* e = getenv("GA_REDUCE_LAZY_MIN")) lazy_min = strtoull(e, nullptr, 10);
+    const bool lazy_reduce = GA_REDUCE_LAZY && (uint64_t)half * nsets >= lazy_min;
+    if (!lazy_reduce) {
         StageTimer tm(ctx, "msm_reduce");
         hipLaunchKernelGGL((msm_reduce_groups_kernel<F>), dim3((total_groups + 63) / 64), dim3(64), 0, st, (const XYZZ<F>*)bsum,
                            half, m_groups, groups_per_win, total_groups, gsum);
@@ -717,9 +863,58 @@ int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, X
             hipLaunchKernelGGL((msm_segment_sum_kernel<F>), dim3(nsets), dim3(64), 0, st, (const XYZZ<F>*)gsum, groups_per_win, wsum);
         }
         GA_KERNEL_CHECK();
+        GA_HIP_CHECK(hipMemcpyAsync(out, wsum, (size_t)nsets * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
+        GA_HIP_CHECK(hipStreamSynchronize(st));
+        return GA_OK;
     }
+    int nbits = 0;
+    while ((1u << nbits) < groups_per_win) nbits++;
+    const uint32_t sg = 1024;
+    const uint32_t chunk_len = groups_per_win > sg ? sg : groups_per_win;   // powers of two
+    const uint32_t chunks = groups_per_win / chunk_len;
+    int log_chunk = 0;
+    while ((1u << log_chunk) < chunk_len) log_chunk++;
+    XYZZ<F>*rsum = nullptr, *bpart = nullptr, *bits = nullptr;
+    uint32_t *rg_list, *rg_count;
+    GA_CHECK(ctx->scratch_get("msm_rsum", (uint64_t)total_groups * sizeof(XYZZ<F>), (void**)&rsum));
+    GA_CHECK(ctx->scratch_get("msm_bpart", ((uint64_t)nsets * (nbits + 1) * chunks + 64) * sizeof(XYZZ<F>), (void**)&bpart));
+    GA_CHECK(ctx->scratch_get("msm_bits", ((uint64_t)nsets * (nbits + 1) + 64) * sizeof(XYZZ<F>), (void**)&bits));
+    GA_CHECK(ctx->scratch_get("msm_redo_groups", ((uint64_t)total_groups + 2) * 4, (void**)&rg_list));
+    GA_CHECK(ctx->scratch_get("msm_redo_groups_count", 256, (void**)&rg_count));
+    GA_HIP_CHECK(hipMemsetAsync(rg_count, 0, 4, st));
+    {
+        StageTimer tm(ctx, "msm_reduce");
+        hipLaunchKernelGGL((msm_reduce_groups29_kernel<F>), dim3((total_groups + 63) / 64), dim3(64), 0, st, (const XYZZ<F>*)bsum,
+                           half, m_groups, groups_per_win, total_groups, gsum, rsum, rg_list, rg_count);
+        hipLaunchKernelGGL((msm_reduce_groups_redo_kernel<F>), dim3(256), dim3(64), 0, st, (const XYZZ<F>*)bsum, half, m_groups,
+                           groups_per_win, (const uint32_t*)rg_list, (const uint32_t*)rg_count, gsum, rsum);
+        if (groups_per_win > 2 * sg) {
+            const uint32_t nseg = groups_per_win / sg;   // powers of two: exact
+            hipLaunchKernelGGL((msm_segment_sum_kernel<F>), dim3(nseg * nsets), dim3(64), 0, st, (const XYZZ<F>*)gsum, sg, gsum2);
+            hipLaunchKernelGGL((msm_segment_sum_kernel<F>), dim3(nsets), dim3(64), 0, st, (const XYZZ<F>*)gsum2, nseg, wsum);
+        } else {
+            hipLaunchKernelGGL((msm_segment_sum_kernel<F>), dim3(nsets), dim3(64), 0, st, (const XYZZ<F>*)gsum, groups_per_win, wsum);
+        }
+        if (nbits > 0) {
+            hipLaunchKernelGGL((msm_bit_partial_kernel<F>), dim3(chunks, (unsigned)nbits, (unsigned)nsets), dim3(64), 0, st,
+                               (const XYZZ<F>*)rsum, groups_per_win, chunk_len, log_chunk, bpart);
+            hipLaunchKernelGGL((msm_segment_sum_kernel<F>), dim3((unsigned)(nsets * nbits)), dim3(64), 0, st, (const XYZZ<F>*)bpart,
+                               chunks, bits);
+        }
+        GA_KERNEL_CHECK();
+    }
+    std::vector<XYZZ<F>> hb((size_t)nsets * (nbits > 0 ? nbits : 1));
     GA_HIP_CHECK(hipMemcpyAsync(out, wsum, (size_t)nsets * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
+    if (nbits > 0) GA_HIP_CHECK(hipMemcpyAsync(hb.data(), bits, (size_t)nsets * nbits * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
     GA_HIP_CHECK(hipStreamSynchronize(st));
+    int log_m = 0;
+    while ((1u << log_m) < m_groups) log_m++;
+    for (int w = 0; w < nsets && nbits > 0; w++) {   // host: ~nbits + log2(m) doublings and nbits additions per set
+        XYZZ<F> acc = xyzz_inf<F>();
+        for (int b = nbits - 1; b >= 0; b--) acc = add(dbl(acc), hb[(size_t)w * nbits + b]);
+        for (int k = 0; k < log_m; k++) acc = dbl(acc);
+        out[w] = add(out[w], acc);
+    }
     return GA_OK;
 }
 

@@ -90,6 +90,16 @@ def test_emu_msm_matches_naive(emu_ctx, c, group):
     assert jac_to_affine_py(c, group, got2) == want
 
 
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("group", [0, 1], ids=["G1", "G2"])
+def test_emu_msm_lazy_window_reduction(emu_ctx, c, group, monkeypatch):
+    """the lazy window reduction (msm_reduce_groups29_kernel + per-bit sums + exact redo of the groups with an exceptional
+    addition) forced on inputs where most buckets are empty, so both the lazy path and the redo path run"""
+    monkeypatch.setenv("GA_REDUCE_LAZY_MIN", "0")
+    test_emu_msm_matches_naive(emu_ctx, c, group)
+    test_emu_msm_precomputed_table(emu_ctx, c, group)
+
+
 def test_emu_msm_hot_bucket_and_windows(emu_ctx):
     # witness-like scalars: many equal small values -> one bucket holds most points (task splitting + hot merge)
     c, group = BN254, 0

@@ -35,3 +35,21 @@ def test_constants_match_the_kernels():
     assert subs(kar) == [k["KV"], k["KS"]]
     sq = f29[f29.index("GA_HD_BIG F29x2<P> f29_sqr("):f29.index("GA_HD_BIG F29<P> f29_sqr(")]
     assert subs(sq) == [k["KQ"]]
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12-381"])
+@pytest.mark.parametrize("fp2", [False, True], ids=["G1", "G2"])
+def test_general_addition_bounds(curve, fp2):
+    """msm.cuh::add29 (lazy window reduction): fixed point of the bounds when both operands are earlier sums"""
+    out = lazy_bounds.check_add(curve, fp2)
+    assert max(out["X"], out["Y"], out["P"], out["R"]) < out["limit"] - 2.5
+
+
+def test_general_addition_constants_match_the_kernel():
+    src = open(os.path.join(ROOT, "gnark_amd", "csrc", "msm.cuh")).read()
+    body = src[src.index("__device__ __forceinline__ void add29(Lazy4<F>& a"):src.index("msm_reduce_groups29_kernel(")]
+    subs = [int(x) for x in re.findall(r"f29_sub<(\d+)>", body)]
+    for k in (lazy_bounds.ADD_G1, lazy_bounds.ADD_G2):
+        assert subs == [k["KP"], k["KR"], k["K3"], k["Kq"]]
+    assert "Lazy<F>::FP2 ? P::FP2Z_K : 8" in body and lazy_bounds.ADD_G1["Kms"] == 8 and lazy_bounds.ADD_G2["Kms"] == 16
+    assert body.count("f29_partial_reduce(") == len(lazy_bounds.ADD_G2["partial_reduce"]) and not lazy_bounds.ADD_G1["partial_reduce"]

@@ -121,7 +121,96 @@ def check(curve: str, fp2: bool, verbose=False):
     return out
 
 
+# ---- general XYZZ + XYZZ addition in the lazy representation (msm.cuh::add29, window reduction) -------------------------
+ADD_G1 = dict(KP=4, KR=4, K3=4, Kq=8, Kms=8, partial_reduce=())
+ADD_G2 = dict(KP=4, KR=4, K3=4, Kq=8, Kms=16, partial_reduce=("X",))
+
+
+def check_add(curve: str, fp2: bool, verbose=False):
+    """Fixed point of the coordinate bounds under a = add29(a, b) when both operands are earlier results (running sums added
+    into running sums); every subtraction constant and every Fp2 operand bound of msm.cuh::add29 is asserted."""
+    p, L, NL, bits = CURVES[curve]
+    R = 1 << (L * NL)
+    unit = 1 << (L * (NL - 1))
+    k = ADD_G2 if fp2 else ADD_G1
+    red = set(k["partial_reduce"])
+
+    def lim(v):
+        assert v < R // 4, ("value exceeds R'/4", log2(v))
+        return v
+
+    def need(K, b, what):
+        assert K * p - b > unit, (what, K, log2(b), log2(K * p))
+
+    def mul1(a, b):
+        lim(a), lim(b)
+        return a * b // R + p
+
+    def pr(v):
+        q = v >> bits
+        return (1 << bits) + q * ((1 << bits) - p)
+
+    if fp2:
+        from gen_constants import FP2_LAZY_K as FK
+
+        def mul(a, b):   # f29_mul(F29x2): real a0*b0 + (FK*p - a1)*b1, imaginary a0*b1 + a1*b0
+            assert a + unit < FK * p and b < FK * p, ("Fp2 operand above FP2Z_K*p", log2(a), log2(b))
+            lim(a), lim(b)
+            return max((a * b + (FK * p + unit) * b) // R + p, 2 * a * b // R + p)
+
+        def sqr(a):
+            need(G2["KQ"], a, "KQ")
+            return max(mul1(lim(2 * a), a + G2["KQ"] * p), 2 * mul1(a, a))
+
+        def mulsub(K, a, b, c, d):
+            assert max(a, c) + unit < K * p and max(a, b, c, d) < FK * p
+            return max(a * b + K * p * b + K * p * d + c * d, 2 * a * b + 2 * K * p * d) // R + p
+    else:
+        mul = mul1
+
+        def sqr(a):
+            return mul1(a, a)
+
+        def mulsub(K, a, b, c, d):
+            assert c + unit < K * p
+            lim(a), lim(b), lim(d)
+            return (a * b + K * p * d) // R + p
+
+    bx = by = bzz = bzzz = p
+    for _ in range(1000):
+        U = mul(bx, bzz)           # U1 = X1*ZZ2, U2 = X2*ZZ1: same bound
+        S = mul(by, bzzz)
+        need(k["KP"], U, "KP")
+        need(k["KR"], S, "KR")
+        Pp, Rr = U + k["KP"] * p, S + k["KR"] * p
+        PP = sqr(Pp)
+        PPP, Q = mul(Pp, PP), mul(U, PP)
+        need(k["K3"], PPP + 2 * Q, "K3")
+        X3 = sqr(Rr) + k["K3"] * p
+        if "X" in red:
+            X3 = pr(X3)
+        need(k["Kq"], X3, "Kq")
+        t = Q + k["Kq"] * p
+        Y3 = mulsub(k["Kms"], Rr, t, S, PPP)
+        ZZ3, ZZZ3 = mul(mul(bzz, bzz), PP), mul(mul(bzzz, bzzz), PPP)
+        for v in (Pp, Rr, PP, PPP, Q, X3, t, Y3, ZZ3, ZZZ3):
+            lim(v)
+        nb = (max(bx, X3), max(by, Y3), max(bzz, ZZ3), max(bzzz, ZZZ3))
+        if nb == (bx, by, bzz, bzzz):
+            break
+        bx, by, bzz, bzzz = nb
+    else:
+        raise AssertionError("bounds of the general addition do not converge")
+    out = {"X": log2(bx), "Y": log2(by), "ZZ": log2(bzz), "ZZZ": log2(bzzz), "P": log2(Pp), "R": log2(Rr), "limit": L * NL}
+    if verbose:
+        print(curve, "add G2" if fp2 else "add G1", {a: round(b, 2) for a, b in out.items()})
+    return out
+
+
 if __name__ == "__main__":
+    for c in CURVES:
+        for fp2 in (False, True):
+            check_add(c, fp2, verbose=True)
     for c in CURVES:
         for fp2 in (False, True):
             check(c, fp2, verbose=True)
