@@ -6,17 +6,24 @@
 // raises if it is missing; tests/emu builds a separate libgnark_amd_emu.so (tests/emu/build_emu.sh) by
 // compiling the unmodified product sources with this directory first on the include path.
 //
-// Model: blocks of a launch run one after another; the threads of a block are real OS threads that meet at
-// pthread barriers for __syncthreads(); a wave is 64 consecutive threads with its own barrier for
-// __shfl*/__ballot.  `__shared__` maps to `static` (blocks are sequential, so one copy is enough).
+// Model: a small pool of OS worker threads takes the blocks of a launch; the threads of a block are ucontext fibers inside
+// one worker, scheduled round-robin and parked at __syncthreads() (block barrier) or at the two meeting points of a
+// __shfl*/__ballot (wave barrier: 64 consecutive threads); a thread that has returned no longer counts for either barrier,
+// as on the GPU.  `__shared__` maps to `static thread_local` (one copy per worker = per resident block).
 #pragma once
 #include <pthread.h>
 #include <stdint.h>
+#include <sys/mman.h>
+#include <ucontext.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <tuple>
 #include <utility>
@@ -28,7 +35,7 @@
 #define __device__
 #define __global__
 #define __forceinline__ inline __attribute__((always_inline))
-#define __shared__ static
+#define __shared__ static thread_local
 #define __launch_bounds__(...)
 #define __restrict__ __restrict
 #define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(::hipemu::dyn_smem());
@@ -48,23 +55,33 @@ static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) {
 
 namespace hipemu {
 struct Wave {
-    pthread_barrier_t bar;
     uint64_t scratch[64];
-    uint64_t ballot;
+    unsigned live = 0, arrived = 0;
 };
-struct Block {
-    pthread_barrier_t bar;
-    std::vector<Wave> waves;
-    std::vector<char> smem;
+struct Fiber {
+    ucontext_t ctx;
+    int state = 3;   // 0 runnable, 1 parked at the block barrier, 2 parked at its wave barrier, 3 finished
+    char* stack = nullptr;
 };
-inline Block*& cur_block() {
-    static Block* b = nullptr;
-    return b;
-}
-inline void* dyn_smem() { return cur_block()->smem.data(); }
 struct Idx {
     unsigned x, y, z;
 };
+// one per worker thread: the block it is currently running
+struct Block {
+    std::vector<Fiber> fibers;
+    ucontext_t sched;
+    unsigned cur = 0, nthreads = 0, live = 0, arrived = 0;
+    std::vector<Wave> waves;
+    std::vector<char> smem;
+    std::function<void()> body;
+};
+inline Block*& cur_block() {
+    static thread_local Block* b = nullptr;
+    return b;
+}
+inline void* dyn_smem() { return cur_block()->smem.data(); }
+void block_barrier();
+void wave_barrier();
 }  // namespace hipemu
 
 extern thread_local hipemu::Idx threadIdx;
@@ -80,11 +97,11 @@ thread_local dim3 gridDim;
 
 static const int warpSize = 64;
 
-inline void __syncthreads() { pthread_barrier_wait(&hipemu::cur_block()->bar); }
+inline void __syncthreads() { hipemu::block_barrier(); }
 
 namespace hipemu {
-inline Wave& my_wave() { return cur_block()->waves[threadIdx.x / 64]; }
-inline unsigned lane() { return threadIdx.x % 64; }
+inline Wave& my_wave() { return cur_block()->waves[cur_block()->cur / 64]; }
+inline unsigned lane() { return cur_block()->cur % 64; }
 template <class T>
 inline T wave_exchange(T v, unsigned src) {
     static_assert(sizeof(T) <= 8, "shuffle of <= 8 bytes only");
@@ -92,9 +109,9 @@ inline T wave_exchange(T v, unsigned src) {
     uint64_t raw = 0;
     memcpy(&raw, &v, sizeof(T));
     w.scratch[lane()] = raw;
-    pthread_barrier_wait(&w.bar);
+    wave_barrier();
     uint64_t got = w.scratch[src % 64];
-    pthread_barrier_wait(&w.bar);
+    wave_barrier();
     T out;
     memcpy(&out, &got, sizeof(T));
     return out;
@@ -130,10 +147,11 @@ inline T __shfl_up(T v, unsigned d, int width = 64) {
 inline unsigned long long __ballot(int pred) {
     hipemu::Wave& w = hipemu::my_wave();
     w.scratch[hipemu::lane()] = pred ? 1 : 0;
-    pthread_barrier_wait(&w.bar);
+    hipemu::wave_barrier();
     unsigned long long m = 0;
-    for (int i = 0; i < 64; i++) m |= (unsigned long long)(w.scratch[i] & 1) << i;
-    pthread_barrier_wait(&w.bar);
+    const unsigned nl = std::min(64u, hipemu::cur_block()->nthreads - (hipemu::cur_block()->cur / 64) * 64);
+    for (unsigned i = 0; i < nl; i++) m |= (unsigned long long)(w.scratch[i] & 1) << i;
+    hipemu::wave_barrier();
     return m;
 }
 inline int __any(int p) { return __ballot(p) != 0; }
@@ -269,58 +287,15 @@ inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
 
 // ---- kernel launch --------------------------------------------------------------------------------
 namespace hipemu {
-template <class F, class Tuple>
-struct LaunchCtx {
-    F f;
-    Tuple args;
-    dim3 grid, block;
-    Block* blk;
-    pthread_barrier_t* blockbar;
-};
-
-template <class F, class Tuple>
-void worker(LaunchCtx<F, Tuple>* c, unsigned tid) {
-    blockDim = c->block;
-    gridDim = c->grid;
-    threadIdx.x = tid % c->block.x;
-    threadIdx.y = (tid / c->block.x) % c->block.y;
-    threadIdx.z = tid / (c->block.x * c->block.y);
-    for (unsigned bz = 0; bz < c->grid.z; bz++)
-        for (unsigned by = 0; by < c->grid.y; by++)
-            for (unsigned bx = 0; bx < c->grid.x; bx++) {
-                blockIdx.x = bx;
-                blockIdx.y = by;
-                blockIdx.z = bz;
-                std::apply(c->f, c->args);
-                pthread_barrier_wait(c->blockbar);   // next block reuses the `static` LDS
-            }
-}
+// runs `body` once per thread of one block, as fibers of the calling worker (implemented in emu_impl.cpp)
+void run_block(unsigned nthreads, size_t shmem, dim3 block_dim, dim3 grid_dim, Idx block_idx, const std::function<void()>& body);
+// distributes the blocks of a grid over the worker pool and waits for all of them
+void run_grid(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
 }  // namespace hipemu
 
 template <class F, class... Args>
 inline void hipLaunchKernelGGL(F kernel, dim3 grid, dim3 block, size_t shmem, hipStream_t, Args... args) {
-    using namespace hipemu;
-    unsigned nthreads = block.x * block.y * block.z;
-    Block blk;
-    pthread_barrier_init(&blk.bar, nullptr, nthreads);
-    blk.waves.resize((nthreads + 63) / 64);
-    for (size_t w = 0; w < blk.waves.size(); w++) {
-        unsigned cnt = std::min<unsigned>(64, nthreads - w * 64);
-        pthread_barrier_init(&blk.waves[w].bar, nullptr, cnt);
-    }
-    blk.smem.resize(shmem + 64);
-    pthread_barrier_t blockbar;
-    pthread_barrier_init(&blockbar, nullptr, nthreads);
-    cur_block() = &blk;
     auto tup = std::make_tuple(args...);
-    LaunchCtx<F, decltype(tup)> ctx{kernel, tup, grid, block, &blk, &blockbar};
-    if (nthreads == 1) {
-        worker(&ctx, 0);
-    } else {
-        std::vector<std::thread> th;
-        th.reserve(nthreads);
-        for (unsigned t = 0; t < nthreads; t++) th.emplace_back(worker<F, decltype(tup)>, &ctx, t);
-        for (auto& t : th) t.join();
-    }
-    cur_block() = nullptr;
+    std::function<void()> body = [&]() { std::apply(kernel, tup); };
+    hipemu::run_grid(grid, block, shmem, body);
 }

@@ -392,7 +392,7 @@ def _plonk_case(c, n, seed, nb_bsb):
 
 
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
-@pytest.mark.parametrize("n,nb_bsb", [(4, 0), (8, 1), (64, 2)])
+@pytest.mark.parametrize("n,nb_bsb", [(4, 0), (8, 1), (64, 2), (512, 1)])
 def test_emu_plonk_quotient(emu_ctx, c, n, nb_bsb, seed=11):
     """computeNumerator + divideByZH on the device == the oracle's restatement of prove.go:841-1123,1287-1350,
     coefficient for coefficient, from canonical inputs, from Lagrange inputs and from a mix; and h(x)(x^n-1) equals the blinded

@@ -266,6 +266,12 @@ def test_groth16_bsb22_commitments_bytes(gpu_ctx, c, precompute):
     cases.test_emu_groth16_bsb22_commitments(gpu_ctx, c, precompute)
 
 
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("group", [0, 1], ids=["G1", "G2"])
+def test_msm_lazy_window_reduction_forced(gpu_ctx, c, group, monkeypatch):
+    cases.test_emu_msm_lazy_window_reduction(gpu_ctx, c, group, monkeypatch)
+
+
 def test_hash_to_field_host(gpu_ctx):
     cases.test_emu_hash_to_field(gpu_ctx)
 
