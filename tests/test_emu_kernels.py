@@ -3,8 +3,10 @@ big-integer oracle.  These run on CPU (`-m "not gpu"`); the same cases run on th
 import numpy as np
 import pytest
 
+import oracle
 import pyref
 from gnark_amd import ecc, fft, groth16, plonk
+from gnark_amd.device import affine_words
 from helpers import BLS12_381, BN254, arr_to_fr, arr_to_g1_affine, arr_to_g2_affine, fr_to_arr, gen_of, group_of, jac_to_affine_py, pts_to_arr
 
 CURVES = [BN254, BLS12_381]
@@ -445,3 +447,88 @@ def test_emu_plonk_build_z_and_batch_invert(emu_ctx, c, n):
     finally:
         d0.close()
     assert arr_to_fr(c, got) == want
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_emu_groth16_synthetic_vs_c_oracle(emu_ctx, c, logn=7):
+    """Synthetic instance (SURVEY 8d config 3 shape, scaled down; 2^7 under the emulation, 2^10 on the GPU): bases [k_i]G
+    generated on the device, proof points identical to the C oracle's prover, with and without window tables."""
+    ctx = emu_ctx
+    lib = ctx.lib
+    n = 1 << logn
+    nw = n
+    nb_public = 3
+
+    def gen(group, count, seed):
+        buf = ctx.malloc(count * affine_words(c.cid, group) * 8)
+        lib.check(lib.ga_gen_bases(ctx.handle, c.cid, group, seed, count, buf.ptr, None))
+        h = buf.to_host((count, affine_words(c.cid, group)))
+        buf.free()
+        return h
+
+    def scal(count, seed):
+        buf = ctx.malloc(count * 32)
+        lib.check(lib.ga_gen_scalars(ctx.handle, c.cid, seed, count, buf.ptr))
+        h = buf.to_host((count, 4))
+        buf.free()
+        return h
+    infA = np.zeros(nw, np.uint8)
+    infB = np.zeros(nw, np.uint8)
+    infA[[1, 5, nw - 1]] = 1
+    infB[[0, 7]] = 1
+    m1, m2 = gen(0, 3, 1), gen(1, 2, 2)
+    key = dict(n=n, alpha1=m1[0:1], beta1=m1[1:2], delta1=m1[2:3], A=gen(0, nw - 3, 3), B=gen(0, nw - 2, 4), Z=gen(0, n - 1, 5),
+               K=gen(0, nw - nb_public, 6), beta2=m2[0:1], delta2=m2[1:2], B2=gen(1, nw - 2, 7), infinityA=infA, infinityB=infB)
+    m = n - 9
+    W, A, B = scal(nw, 10), scal(m, 11), scal(m, 12)
+    Cc = oracle.fr_mul(c.cid, A, B)
+    rs = scal(2, 13)
+    want = oracle.groth16_prove(c.cid, key, W, A, B, Cc, nb_public, rs[0], rs[1], nthreads=8)
+    for precompute in (1, -1):
+        pk = groth16.ProvingKey(ctx, c.name, domain_cardinality=n, precompute=precompute, **{k: v for k, v in key.items() if k != "n"})
+        try:
+            proof = groth16.Prove(pk, groth16.Solution(W, A, B, Cc), nb_public, rs[0], rs[1])
+        finally:
+            pk.FreeGPUResources()
+        assert np.array_equal(proof.Ar, want[0]) and np.array_equal(proof.Bs, want[1]) and np.array_equal(proof.Krs, want[2]), precompute
+    assert len(proof.WriteTo()) == (164 if c.cid == 0 else 244)
+
+
+def _device_inputs(ctx, c, group, n, seed):
+    lib = ctx.lib
+    wa = affine_words(c.cid, group)
+    bases, dlogs, scal = ctx.malloc(n * wa * 8), ctx.malloc(n * 32), ctx.malloc(n * 32)
+    lib.check(lib.ga_gen_bases(ctx.handle, c.cid, group, seed, n, bases.ptr, dlogs.ptr))
+    lib.check(lib.ga_gen_scalars(ctx.handle, c.cid, seed + 1, n, scal.ptr))
+    return bases, dlogs, scal
+
+
+def _expect_from_dlogs(c, group, S_host, K_host):
+    k = oracle.fr_dot(c.cid, S_host, K_host)
+    return oracle.jac_to_affine(c.cid, group, oracle.generator_mul(c.cid, group, k))
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("group", [0, 1], ids=["G1", "G2"])
+def test_emu_msm_vs_c_oracle_and_dlogs(emu_ctx, c, group, logn=11):
+    """device-generated bases [k_i]G with known discrete logs: MSM == C oracle's Pippenger == [sum s_i k_i]G (2^11 under the
+    emulation, 2^14 on the GPU), device-resident and host-pointer inputs"""
+    gpu_ctx = emu_ctx
+    n = 1 << logn
+    bases, dlogs, scal = _device_inputs(gpu_ctx, c, group, n, 0xABC0 + group)
+    P = bases.to_host((n, affine_words(c.cid, group)))
+    S = scal.to_host((n, 4))
+    K = dlogs.to_host((n, 4))
+    # the generated bases really are [k_i]G (spot-check against the oracle's generator multiplication)
+    for i in (0, 1, n - 1):
+        want = oracle.jac_to_affine(c.cid, group, oracle.generator_mul(c.cid, group, int(K[i, 0])))
+        assert np.array_equal(P[i], want)
+    got = oracle.jac_to_affine(c.cid, group, ecc.MultiExp(gpu_ctx, c.name, group, bases, scal, n=n))
+    want = oracle.jac_to_affine(c.cid, group, oracle.msm(c.cid, group, P, S, nthreads=8))
+    assert np.array_equal(got, want)
+    assert np.array_equal(got, _expect_from_dlogs(c, group, S, K))
+    # host-pointer path (what a cgo caller passes) gives the same point
+    got2 = oracle.jac_to_affine(c.cid, group, ecc.MultiExp(gpu_ctx, c.name, group, P, S))
+    assert np.array_equal(got2, want)
+    for b in (bases, dlogs, scal):
+        b.free()
