@@ -1,4 +1,5 @@
 /* Plain-C client of include/gnark_amd.h -- what a cgo binding compiles against (no C++, no Python, no torch).
+ * (also: PLONK grand product / batch inversion / hash-to-field entry points)
  * Builds known-discrete-log bases on the device, runs ga_msm and ga_msm_table_run, checks MSM(s, [k_i]G) == [sum s_i k_i]G
  * with the library's own host helpers, runs an NTT round trip, and prints "ABI_CLIENT_OK".
  *   gcc -O2 -I include tests/c_abi/abi_client.c -L gnark_amd -lgnark_amd -Wl,-rpath,$PWD/gnark_amd -o abi_client */
@@ -25,7 +26,10 @@ int main(void) {
     CHECK(ga_device_info(ctx, name, sizeof name, &total, &freeb));
     printf("device: %s, %.0f GiB\n", name, total / 1073741824.0);
 
-    const size_t n = 1u << 16;
+#ifndef ABI_CLIENT_N
+#define ABI_CLIENT_N (1u << 16)
+#endif
+    const size_t n = ABI_CLIENT_N;
     void *bases = NULL, *dlogs = NULL, *scalars = NULL;
     CHECK(ga_malloc(ctx, n * 64, &bases));
     CHECK(ga_malloc(ctx, n * 32, &dlogs));
@@ -65,6 +69,42 @@ int main(void) {
     if (memcmp(a, b, n * 32)) {
         fprintf(stderr, "NTT round trip mismatch\n");
         return 1;
+    }
+    /* PLONK grand product with the identity permutation: every ratio is 1, so Z is the constant 1 (Montgomery one = a[..]
+     * of ga_generator... no helper needed: Z[0] is 1 by definition and all entries must equal it) */
+    {
+        int64_t* perm = malloc(3 * n * sizeof(int64_t));
+        for (size_t i = 0; i < 3 * n; i++) perm[i] = (int64_t)i;
+        uint64_t* z = malloc(n * 32);
+        CHECK(ga_plonk_build_z(d, a, a, a, perm, a, a + 4, 0, z));   /* l = r = o = the random vector, beta/gamma from it */
+        for (size_t i = 1; i < n; i++)
+            if (memcmp(z, z + 4 * i, 32)) {
+                fprintf(stderr, "grand product with the identity permutation is not constant\n");
+                return 1;
+            }
+        /* fr.BatchInvert is an involution (and keeps zeros) */
+        memcpy(b, a, n * 32);
+        memset(b, 0, 32);
+        CHECK(ga_fr_batch_invert(ctx, GA_BN254, b, n, 0));
+        CHECK(ga_fr_batch_invert(ctx, GA_BN254, b, n, 0));
+        memset(a, 0, 32);
+        if (memcmp(a, b, n * 32)) {
+            fprintf(stderr, "batch inversion is not an involution\n");
+            return 1;
+        }
+        free(perm);
+        free(z);
+    }
+    /* hash-to-field host code: first expand_message_xmd vector of the reference (std/hash/expand/expand_test.go:52-56) */
+    {
+        static const char dst[] = "QUUX-V01-CS02-with-expander-SHA256-128";
+        static const uint8_t want32[4] = {0x68, 0xa9, 0x85, 0xb8};
+        uint8_t out[32];
+        CHECK(ga_expand_message_xmd((const uint8_t*)"", 0, (const uint8_t*)dst, sizeof dst - 1, 32, out));
+        if (memcmp(out, want32, 4)) {
+            fprintf(stderr, "expand_message_xmd mismatch\n");
+            return 1;
+        }
     }
     ga_domain_destroy(d);
     free(a);

@@ -59,3 +59,18 @@ def test_missing_library_fails_loudly(tmp_path):
     from gnark_amd import _lib
     with pytest.raises(_lib.GnarkAmdError, match="no CPU fallback"):
         _lib.Library(str(tmp_path / "nope.so"))
+
+
+def test_plain_c_client_runs_against_the_emulation_build(tmp_path, emu_lib):
+    """the C99 client of include/gnark_amd.h (tests/c_abi/abi_client.c: MSM, table MSM, NTT round trip, PLONK grand product,
+    batch inversion, hash-to-field) compiled with gcc and linked against the emulation build of the same sources -- the header
+    is plain C and the flows work without Python in between; the GPU suite runs the same program against the HIP build"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "abi_client_emu")
+    emu_dir = os.path.join(root, "tests", "emu")
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-DABI_CLIENT_N=256", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "c_abi", "abi_client.c"), os.path.join(emu_dir, "libgnark_amd_emu.so"),
+                           "-Wl,-rpath," + emu_dir, "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ABI_CLIENT_OK" in r.stdout, r.stdout + r.stderr
