@@ -39,7 +39,13 @@ namespace ga {
 #define GA_ACC_MINW_BIG 2     // BLS12-381 G2 (384 B), 128-thread workgroups
 #endif
 #ifndef GA_ACC29_MINW
-#define GA_ACC29_MINW 3       // lazy-representation table kernel (G1)
+#define GA_ACC29_MINW 4       // lazy-representation table kernel (G1)
+#endif
+#ifndef GA_ACC29_TOUCH
+#define GA_ACC29_TOUCH 0      // 1: touch the next table entry one addition ahead (L2 prefetch); measured -3 % with the final loop
+#endif
+#ifndef GA_ACC29_PIPELINE
+#define GA_ACC29_PIPELINE 0   // 1: load the next table entry into registers one addition ahead
 #endif
 #ifndef GA_ACC_LDS_BYTES
 #define GA_ACC_LDS_BYTES 128  // accumulators of at least this many bytes live in LDS (all groups; measured best)
@@ -358,14 +364,25 @@ msm_accumulate29_kernel(const uint32_t* __restrict__ table, const uint32_t* __re
     const T one = Lazy<F>::from_mem(FieldTraits<F>::one());
     bool have = false;
     uint32_t v = vals[start];
+#if GA_ACC29_PIPELINE
+    // the next table entry travels into registers (packed: WORDS dwords) while the current addition runs
+    Affine<F> nxt = load_pod<Affine<F>>(table + (uint64_t)(v & ~MSM_SIGN) * Table29<F>::WORDS);
+#endif
     for (uint32_t p = start; p < end; p++) {
         const uint32_t vn = p + 1 < end ? vals[p + 1] : v;
         T qx, qy;
+#if GA_ACC29_PIPELINE
+        qx = Lazy<F>::unpack(nxt.x);
+        qy = Lazy<F>::unpack(nxt.y);
+        nxt = load_pod<Affine<F>>(table + (uint64_t)(vn & ~MSM_SIGN) * Table29<F>::WORDS);
+        const uint32_t touch = 0;
+#else
         load_point29<F>(table, v & ~MSM_SIGN, qx, qy);
-#ifndef GA_NO_TOUCH
+#if GA_ACC29_TOUCH
         const uint32_t touch = *reinterpret_cast<const volatile uint32_t*>(table + (uint64_t)(vn & ~MSM_SIGN) * Table29<F>::WORDS);
 #else
         const uint32_t touch = 0;
+#endif
 #endif
         if (!(f29_is_zero_limbs(qx) & f29_is_zero_limbs(qy))) {   // (0,0) = infinity: skip
             if (v & MSM_SIGN) qy = f29_sub<2>(Lazy<F>::from_mem(FieldTraits<F>::zero()), qy);   // 2p - y
