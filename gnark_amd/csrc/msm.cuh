@@ -650,15 +650,20 @@ msm_reduce_groups_redo_kernel(const XYZZ<F>* __restrict__ bsum, uint32_t half, u
 // whose index has bit b set.  grid = (chunks, nbits, nsets), one wave per block.
 template <class F>
 __global__ void __launch_bounds__(64)
-msm_bit_partial_kernel(const XYZZ<F>* __restrict__ rsum, uint32_t groups_per_win, uint32_t chunk_len, int log_chunk,
-                       XYZZ<F>* __restrict__ part) {
+msm_bit_partial_kernel(const XYZZ<F>* __restrict__ rsum, const XYZZ<F>* __restrict__ lsum, uint32_t groups_per_win,
+                       uint32_t chunk_len, int log_chunk, XYZZ<F>* __restrict__ part) {
+    // blockIdx.y == nbits - 1 (the last row of the grid) is not a bit: it sums the chunk of lsum, so that one launch and one
+    // final segment sum produce every quantity the host needs
     __shared__ XYZZ<F> sh[64];
     const uint32_t ch = blockIdx.x, b = blockIdx.y, w = blockIdx.z;
     const uint32_t nbits = gridDim.y, chunks = gridDim.x;
     const uint32_t base = ch * chunk_len;
     const XYZZ<F>* R = rsum + (uint64_t)w * groups_per_win;
     XYZZ<F> acc = xyzz_inf<F>();
-    if ((int)b >= log_chunk) {
+    if (b == nbits - 1) {
+        const XYZZ<F>* Lp = lsum + (uint64_t)w * groups_per_win;
+        for (uint32_t i = threadIdx.x; i < chunk_len; i += 64) acc = add(acc, load_pod<XYZZ<F>>(&Lp[base + i]));
+    } else if ((int)b >= log_chunk) {
         if ((base >> b) & 1)   // the whole chunk has the bit set
             for (uint32_t i = threadIdx.x; i < chunk_len; i += 64) acc = add(acc, load_pod<XYZZ<F>>(&R[base + i]));
     } else {
@@ -905,32 +910,24 @@ int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, X
                            half, m_groups, groups_per_win, total_groups, gsum, rsum, rg_list, rg_count);
         hipLaunchKernelGGL((msm_reduce_groups_redo_kernel<F>), dim3(256), dim3(64), 0, st, (const XYZZ<F>*)bsum, half, m_groups,
                            groups_per_win, (const uint32_t*)rg_list, (const uint32_t*)rg_count, gsum, rsum);
-        if (groups_per_win > 2 * sg) {
-            const uint32_t nseg = groups_per_win / sg;   // powers of two: exact
-            hipLaunchKernelGGL((msm_segment_sum_kernel<F>), dim3(nseg * nsets), dim3(64), 0, st, (const XYZZ<F>*)gsum, sg, gsum2);
-            hipLaunchKernelGGL((msm_segment_sum_kernel<F>), dim3(nsets), dim3(64), 0, st, (const XYZZ<F>*)gsum2, nseg, wsum);
-        } else {
-            hipLaunchKernelGGL((msm_segment_sum_kernel<F>), dim3(nsets), dim3(64), 0, st, (const XYZZ<F>*)gsum, groups_per_win, wsum);
-        }
-        if (nbits > 0) {
-            hipLaunchKernelGGL((msm_bit_partial_kernel<F>), dim3(chunks, (unsigned)nbits, (unsigned)nsets), dim3(64), 0, st,
-                               (const XYZZ<F>*)rsum, groups_per_win, chunk_len, log_chunk, bpart);
-            hipLaunchKernelGGL((msm_segment_sum_kernel<F>), dim3((unsigned)(nsets * nbits)), dim3(64), 0, st, (const XYZZ<F>*)bpart,
-                               chunks, bits);
-        }
+        // rows 0..nbits-1: per-bit sums of rsum; row nbits: sum of lsum
+        hipLaunchKernelGGL((msm_bit_partial_kernel<F>), dim3(chunks, (unsigned)nbits + 1, (unsigned)nsets), dim3(64), 0, st,
+                           (const XYZZ<F>*)rsum, (const XYZZ<F>*)gsum, groups_per_win, chunk_len, log_chunk, bpart);
+        hipLaunchKernelGGL((msm_segment_sum_kernel<F>), dim3((unsigned)(nsets * (nbits + 1))), dim3(64), 0, st, (const XYZZ<F>*)bpart,
+                           chunks, bits);
         GA_KERNEL_CHECK();
     }
-    std::vector<XYZZ<F>> hb((size_t)nsets * (nbits > 0 ? nbits : 1));
-    GA_HIP_CHECK(hipMemcpyAsync(out, wsum, (size_t)nsets * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
-    if (nbits > 0) GA_HIP_CHECK(hipMemcpyAsync(hb.data(), bits, (size_t)nsets * nbits * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
+    const int rows = nbits + 1;
+    std::vector<XYZZ<F>> hb((size_t)nsets * rows);
+    GA_HIP_CHECK(hipMemcpyAsync(hb.data(), bits, (size_t)nsets * rows * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
     GA_HIP_CHECK(hipStreamSynchronize(st));
     int log_m = 0;
     while ((1u << log_m) < m_groups) log_m++;
-    for (int w = 0; w < nsets && nbits > 0; w++) {   // host: ~nbits + log2(m) doublings and nbits additions per set
+    for (int w = 0; w < nsets; w++) {   // host: ~nbits + log2(m) doublings and nbits additions per set
         XYZZ<F> acc = xyzz_inf<F>();
-        for (int b = nbits - 1; b >= 0; b--) acc = add(dbl(acc), hb[(size_t)w * nbits + b]);
+        for (int b = nbits - 1; b >= 0; b--) acc = add(dbl(acc), hb[(size_t)w * rows + b]);
         for (int k = 0; k < log_m; k++) acc = dbl(acc);
-        out[w] = add(out[w], acc);
+        out[w] = add(hb[(size_t)w * rows + nbits], acc);
     }
     return GA_OK;
 }
