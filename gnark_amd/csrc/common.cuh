@@ -144,6 +144,7 @@ struct MsmPrepared {
     uint64_t m = 0, max_tasks = 0;
     uint32_t *vals = nullptr, *task_off = nullptr, *task_start = nullptr, *task_key = nullptr, *task_perm = nullptr;
     uint32_t* task_key_by_id = nullptr;   // unsorted: seg - len of task id
+    uint32_t* task_dest = nullptr;        // slot of the task's sum in [bucket sums | partial sums]
 };
 
 template <class C, int G>

@@ -121,7 +121,8 @@ static __global__ void msm_iota_kernel(uint32_t* __restrict__ out, uint32_t n) {
 }
 
 static __global__ void msm_task_list_kernel(const uint32_t* __restrict__ off, const uint32_t* __restrict__ task_off, uint32_t nb,
-                                            uint32_t seg, uint32_t* __restrict__ task_start, uint32_t* __restrict__ task_key) {
+                                            uint32_t seg, uint32_t* __restrict__ task_start, uint32_t* __restrict__ task_key,
+                                            uint32_t* __restrict__ task_dest) {
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
     uint32_t t0 = task_off[b], t1 = task_off[b + 1];
@@ -129,6 +130,9 @@ static __global__ void msm_task_list_kernel(const uint32_t* __restrict__ off, co
     for (uint32_t t = t0; t < t1; t++) {
         uint32_t len = end - start < seg ? end - start : seg;
         task_start[t] = start;
+        // where the task's sum goes in the array [nb bucket sums | partial sums]: the only task of a bucket writes the bucket
+        // sum itself (the merge pass then has nothing to do for that bucket)
+        task_dest[t] = (t1 - t0 == 1) ? b : nb + t;
         task_key[t] = seg - len;
         start += len;
     }
@@ -205,7 +209,8 @@ template <class F>
 __global__ void __launch_bounds__(AccumulateTuning<F>::THREADS, AccumulateTuning<F>::MIN_WAVES)
 msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ vals,
                       const uint32_t* __restrict__ task_start, const uint32_t* __restrict__ task_key_sorted,
-                      const uint32_t* __restrict__ task_perm, uint32_t max_tasks, uint32_t seg, XYZZ<F>* __restrict__ partial) {
+                      const uint32_t* __restrict__ task_perm, uint32_t max_tasks, uint32_t seg,
+                      const uint32_t* __restrict__ task_dest, XYZZ<F>* __restrict__ sums) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= max_tasks) return;
     const uint32_t key = task_key_sorted[t];
@@ -238,7 +243,7 @@ msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __res
             acc.y = A.get(1);
             acc.zzz = A.get(3);
         }
-        store_pod(&partial[tid], acc);
+        store_pod(&sums[task_dest[tid]], acc);
     } else {
         XYZZ<F> acc = xyzz_inf<F>();
         uint32_t v = vals[start];
@@ -251,7 +256,7 @@ msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __res
             GA_KEEP_LIVE(touch);
             v = vn;
         }
-        store_pod(&partial[tid], acc);
+        store_pod(&sums[task_dest[tid]], acc);
     }
 }
 
@@ -348,7 +353,8 @@ __global__ void __launch_bounds__(Table29<F>::THREADS, Table29<F>::MIN_WAVES)
 msm_accumulate29_kernel(const uint32_t* __restrict__ table, const uint32_t* __restrict__ vals,
                         const uint32_t* __restrict__ task_start, const uint32_t* __restrict__ task_key_sorted,
                         const uint32_t* __restrict__ task_perm, uint32_t max_tasks, uint32_t seg,
-                        XYZZ<F>* __restrict__ partial, uint32_t* __restrict__ redo_list, uint32_t* __restrict__ redo_count) {
+                        const uint32_t* __restrict__ task_dest, XYZZ<F>* __restrict__ sums, uint32_t* __restrict__ redo_list,
+                        uint32_t* __restrict__ redo_count) {
     typedef typename Lazy<F>::T T;
     typedef typename Lazy<F>::Params P;
     constexpr int NW = Lazy<F>::NW;
@@ -411,7 +417,7 @@ msm_accumulate29_kernel(const uint32_t* __restrict__ table, const uint32_t* __re
         acc.zz = zz;
         acc.zzz = Lazy<F>::to_mem(A.get(3));
     }
-    store_pod(&partial[tid], acc);
+    store_pod(&sums[task_dest[tid]], acc);
 }
 
 // exact re-run of the tasks the lazy kernel flagged (complete formulas; table points converted back to gnark's form)
@@ -420,7 +426,7 @@ __global__ void __launch_bounds__(64)
 msm_accumulate29_redo_kernel(const uint32_t* __restrict__ table, const uint32_t* __restrict__ vals,
                              const uint32_t* __restrict__ task_start, const uint32_t* __restrict__ task_key_by_tid,
                              uint32_t seg, const uint32_t* __restrict__ redo_list, const uint32_t* __restrict__ redo_count,
-                             XYZZ<F>* __restrict__ partial) {
+                             const uint32_t* __restrict__ task_dest, XYZZ<F>* __restrict__ sums) {
     typedef typename Lazy<F>::T T;
     const uint32_t nredo = *redo_count;
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nredo; r += gridDim.x * blockDim.x) {
@@ -436,7 +442,7 @@ msm_accumulate29_redo_kernel(const uint32_t* __restrict__ table, const uint32_t*
             if (v & MSM_SIGN) q.y = neg(q.y);
             acc = madd(acc, q);
         }
-        store_pod(&partial[tid], acc);
+        store_pod(&sums[task_dest[tid]], acc);
     }
 }
 
@@ -467,6 +473,7 @@ __global__ void msm_merge_kernel(const XYZZ<F>* __restrict__ partial, const uint
     if (b >= nb) return;
     uint32_t t0 = task_off[b], t1 = task_off[b + 1];
     uint32_t nt = t1 - t0;
+    if (nt == 1) return;   // its only task wrote bsum[b] directly (task_dest)
     if (nt > MSM_HOT_TASKS) {
         hot_list[atomicAdd(hot_count, 1u)] = b;
         return;
@@ -745,6 +752,8 @@ int msm_prepare(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, in
     GA_CHECK(ctx->scratch_get(key("msm_task_key2").c_str(), max_tasks * 4, (void**)&task_key2));
     GA_CHECK(ctx->scratch_get(key("msm_task_id").c_str(), max_tasks * 4, (void**)&task_id));
     GA_CHECK(ctx->scratch_get(key("msm_task_perm").c_str(), max_tasks * 4, (void**)&task_perm));
+    uint32_t* task_dest;
+    GA_CHECK(ctx->scratch_get(key("msm_task_dest").c_str(), max_tasks * 4, (void**)&task_dest));
 
     {
         StageTimer tm(ctx, "msm_digits", st);
@@ -773,7 +782,7 @@ int msm_prepare(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, in
         // explicit task list, ordered by decreasing length (padding slots keep key = 0xFFFFFFFF >= seg)
         GA_HIP_CHECK(hipMemsetAsync(task_key, 0xFF, max_tasks * 4, st));
         hipLaunchKernelGGL(msm_task_list_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, (const uint32_t*)off, (const uint32_t*)task_off,
-                           nb, seg, task_start, task_key);
+                           nb, seg, task_start, task_key, task_dest);
         hipLaunchKernelGGL(msm_iota_kernel, dim3((unsigned)((max_tasks + 255) / 256)), dim3(256), 0, st, task_id, (uint32_t)max_tasks);
         GA_KERNEL_CHECK();
         int kbits = 1;
@@ -802,6 +811,7 @@ int msm_prepare(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, in
     P->task_key = task_key2;
     P->task_key_by_id = task_key;
     P->task_perm = task_perm;
+    P->task_dest = task_dest;
     return GA_OK;
 }
 
@@ -826,8 +836,9 @@ int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, X
     XYZZ<F>*partial, *bsum, *gsum, *gsum2, *wsum;
     GA_CHECK(ctx->scratch_get("msm_hot", ((uint64_t)nb + 2) * 4, (void**)&hot_list));
     GA_CHECK(ctx->scratch_get("msm_hot_count", 256, (void**)&hot_count));
-    GA_CHECK(ctx->scratch_get("msm_partial", P.max_tasks * sizeof(XYZZ<F>), (void**)&partial));
-    GA_CHECK(ctx->scratch_get("msm_bsum", (uint64_t)nb * sizeof(XYZZ<F>), (void**)&bsum));
+    // one array [nb bucket sums | max_tasks partial sums]: tasks write at task_dest (see msm_task_list_kernel)
+    GA_CHECK(ctx->scratch_get("msm_bsum_partial", ((uint64_t)nb + P.max_tasks) * sizeof(XYZZ<F>), (void**)&bsum));
+    partial = bsum + nb;
     GA_CHECK(ctx->scratch_get("msm_gsum", (uint64_t)total_groups * sizeof(XYZZ<F>), (void**)&gsum));
     GA_CHECK(ctx->scratch_get("msm_gsum2", ((uint64_t)total_groups / 1024 + 64) * sizeof(XYZZ<F>), (void**)&gsum2));
     GA_CHECK(ctx->scratch_get("msm_wsum", (uint64_t)nsets * sizeof(XYZZ<F>), (void**)&wsum));
@@ -842,17 +853,17 @@ int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, X
         constexpr unsigned AT = Table29<F>::THREADS;
         hipLaunchKernelGGL((msm_accumulate29_kernel<F>), dim3((unsigned)((P.max_tasks + AT - 1) / AT)), dim3(AT), 0, st,
                            (const uint32_t*)d_bases, (const uint32_t*)P.vals, (const uint32_t*)P.task_start, (const uint32_t*)P.task_key,
-                           (const uint32_t*)P.task_perm, (uint32_t)P.max_tasks, seg, partial, redo_list, redo_count);
+                           (const uint32_t*)P.task_perm, (uint32_t)P.max_tasks, seg, (const uint32_t*)P.task_dest, bsum, redo_list, redo_count);
         hipLaunchKernelGGL((msm_accumulate29_redo_kernel<F>), dim3(1024), dim3(64), 0, st, (const uint32_t*)d_bases,
                            (const uint32_t*)P.vals, (const uint32_t*)P.task_start, (const uint32_t*)P.task_key_by_id, seg,
-                           (const uint32_t*)redo_list, (const uint32_t*)redo_count, partial);
+                           (const uint32_t*)redo_list, (const uint32_t*)redo_count, (const uint32_t*)P.task_dest, bsum);
         GA_KERNEL_CHECK();
     } else {
         StageTimer tm(ctx, "msm_accumulate");
         constexpr unsigned AT = AccumulateTuning<F>::THREADS;
         hipLaunchKernelGGL((msm_accumulate_kernel<F>), dim3((unsigned)((P.max_tasks + AT - 1) / AT)), dim3(AT), 0, st,
                            (const Affine<F>*)d_bases, (const uint32_t*)P.vals, (const uint32_t*)P.task_start, (const uint32_t*)P.task_key,
-                           (const uint32_t*)P.task_perm, (uint32_t)P.max_tasks, seg, partial);
+                           (const uint32_t*)P.task_perm, (uint32_t)P.max_tasks, seg, (const uint32_t*)P.task_dest, bsum);
         GA_KERNEL_CHECK();
     }
     {
