@@ -876,9 +876,9 @@ int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, X
     }
     // Window reduction.  Large bucket sets: lazy per-group pass without the per-lane scalar multiplication,
     //   set sum = sum_g lsum[g] + m * sum_b 2^b * T_b,   T_b = sum of rsum[g] over the groups whose index has bit b set,
-    // the T_b being plain tree sums and the last line host arithmetic.  Small sets keep the exact kernel: their time is
-    // launch/dependency latency, and empty buckets (which the lazy formulas cannot add to themselves) are common there.
-    uint64_t lazy_min = 1u << 18;   // buckets; GA_REDUCE_LAZY_MIN overrides (tests force the lazy path on tiny inputs with 0)
+    // the T_b being plain tree sums and the last line host arithmetic.  Tiny sets keep the exact kernel: empty buckets (which
+    // the lazy formulas cannot add to themselves) are the rule there and every group would be redone.
+    uint64_t lazy_min = 1u << 14;   // buckets (measured: 2^20 points / 2^16 buckets 2.82 -> 2.53 ms); GA_REDUCE_LAZY_MIN overrides (tests use 0)
     if (const char* e = getenv("GA_REDUCE_LAZY_MIN")) lazy_min = strtoull(e, nullptr, 10);
     const bool lazy_reduce = GA_REDUCE_LAZY && (uint64_t)half * nsets >= lazy_min;
     if (!lazy_reduce) {
