@@ -44,6 +44,9 @@ namespace ga {
 #ifndef GA_ACC29_TOUCH
 #define GA_ACC29_TOUCH 0      // 1: touch the next table entry one addition ahead (L2 prefetch); measured -3 % with the final loop
 #endif
+#ifndef GA_ACC_TOUCH
+#define GA_ACC_TOUCH 0        // raw-bases kernel: 1 = touch the next base one addition ahead (measured -3 %)
+#endif
 #ifndef GA_ACC29_PIPELINE
 #define GA_ACC29_PIPELINE 0   // 1: load the next table entry into registers one addition ahead
 #endif
@@ -229,7 +232,7 @@ msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __res
             const uint32_t vn = p + 1 < end ? vals[p + 1] : v;
             Affine<F> q = load_pod<Affine<F>>(&bases[v & ~MSM_SIGN]);
             // issued AFTER the current point's loads: vector loads retire in order, so the waitcnt for q leaves this one in flight
-            const uint32_t touch = *reinterpret_cast<const volatile uint32_t*>(&bases[vn & ~MSM_SIGN]);
+            const uint32_t touch = GA_ACC_TOUCH ? *reinterpret_cast<const volatile uint32_t*>(&bases[vn & ~MSM_SIGN]) : 0u;
             if (v & MSM_SIGN) q.y = neg(q.y);
             madd_lds(A, q);
             GA_KEEP_LIVE(touch);
@@ -250,7 +253,7 @@ msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __res
         for (uint32_t p = start; p < end; p++) {
             const uint32_t vn = p + 1 < end ? vals[p + 1] : v;
             Affine<F> q = load_pod<Affine<F>>(&bases[v & ~MSM_SIGN]);
-            const uint32_t touch = *reinterpret_cast<const volatile uint32_t*>(&bases[vn & ~MSM_SIGN]);
+            const uint32_t touch = GA_ACC_TOUCH ? *reinterpret_cast<const volatile uint32_t*>(&bases[vn & ~MSM_SIGN]) : 0u;
             if (v & MSM_SIGN) q.y = neg(q.y);
             acc = madd_t<true>(acc, q);
             GA_KEEP_LIVE(touch);
