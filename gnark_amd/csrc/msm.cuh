@@ -47,6 +47,9 @@ namespace ga {
 #ifndef GA_ACC_TOUCH
 #define GA_ACC_TOUCH 0        // raw-bases kernel: 1 = touch the next base one addition ahead (measured -3 %)
 #endif
+#ifndef GA_RAW_LAZY
+#define GA_RAW_LAZY 1         // raw-bases MSM: convert the bases once per call and use the lazy bucket kernel
+#endif
 #ifndef GA_ACC29_PIPELINE
 #define GA_ACC29_PIPELINE 0   // 1: load the next table entry into registers one addition ahead
 #endif
@@ -858,6 +861,25 @@ int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, X
                            (const uint32_t*)d_bases, (const uint32_t*)P.vals, (const uint32_t*)P.task_start, (const uint32_t*)P.task_key,
                            (const uint32_t*)P.task_perm, (uint32_t)P.max_tasks, seg, (const uint32_t*)P.task_dest, bsum, redo_list, redo_count);
         hipLaunchKernelGGL((msm_accumulate29_redo_kernel<F>), dim3(1024), dim3(64), 0, st, (const uint32_t*)d_bases,
+                           (const uint32_t*)P.vals, (const uint32_t*)P.task_start, (const uint32_t*)P.task_key_by_id, seg,
+                           (const uint32_t*)redo_list, (const uint32_t*)redo_count, (const uint32_t*)P.task_dest, bsum);
+        GA_KERNEL_CHECK();
+    } else if (GA_RAW_LAZY) {
+        // raw (not precomputed) bases: one conversion pass to the packed hat-domain format (a one-window "table"), then the
+        // same lazy bucket kernel as the table path -- the exact packed kernel below costs ~1.5x more per addition
+        uint32_t *hat, *redo_list, *redo_count;
+        GA_CHECK(ctx->scratch_get("msm_hat_bases", (uint64_t)P.n * sizeof(Affine<F>) + 256, (void**)&hat));
+        GA_CHECK(ctx->scratch_get("msm_redo", (P.max_tasks + 2) * 4, (void**)&redo_list));
+        GA_CHECK(ctx->scratch_get("msm_redo_count", 256, (void**)&redo_count));
+        GA_HIP_CHECK(hipMemsetAsync(redo_count, 0, 4, st));
+        StageTimer tm(ctx, "msm_accumulate");
+        hipLaunchKernelGGL((msm_table29_kernel<F>), dim3((unsigned)((P.n + 63) / 64)), dim3(64), 0, st, (const Affine<F>*)d_bases,
+                           (uint64_t)P.n, P.c, 1, hat);
+        constexpr unsigned AT = Table29<F>::THREADS;
+        hipLaunchKernelGGL((msm_accumulate29_kernel<F>), dim3((unsigned)((P.max_tasks + AT - 1) / AT)), dim3(AT), 0, st,
+                           (const uint32_t*)hat, (const uint32_t*)P.vals, (const uint32_t*)P.task_start, (const uint32_t*)P.task_key,
+                           (const uint32_t*)P.task_perm, (uint32_t)P.max_tasks, seg, (const uint32_t*)P.task_dest, bsum, redo_list, redo_count);
+        hipLaunchKernelGGL((msm_accumulate29_redo_kernel<F>), dim3(1024), dim3(64), 0, st, (const uint32_t*)hat,
                            (const uint32_t*)P.vals, (const uint32_t*)P.task_start, (const uint32_t*)P.task_key_by_id, seg,
                            (const uint32_t*)redo_list, (const uint32_t*)redo_count, (const uint32_t*)P.task_dest, bsum);
         GA_KERNEL_CHECK();
