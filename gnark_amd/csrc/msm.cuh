@@ -834,7 +834,9 @@ int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, X
     // buckets per running-sum group: MSM_GROUP when there are plenty of buckets, smaller (down to 2) when a set has few so
     // that the reduction still spreads over >= 2^15 lanes (small n, or table mode's single bucket set)
     uint32_t m_groups = (uint32_t)MSM_GROUP;
-    while (m_groups > 2 && (uint64_t)half * nsets / m_groups < 32768) m_groups >>= 1;
+    uint64_t min_lanes = 32768;
+    if (const char* e = getenv("GA_REDUCE_MIN_LANES")) min_lanes = strtoull(e, nullptr, 10);   // experiments
+    while (m_groups > 2 && (uint64_t)half * nsets / m_groups < min_lanes) m_groups >>= 1;
     if (m_groups > half) m_groups = half;
     const uint32_t groups_per_win = half / m_groups;
     const uint32_t total_groups = groups_per_win * nsets;

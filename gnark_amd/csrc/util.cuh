@@ -129,19 +129,23 @@ int util_gather_fr(Ctx* ctx, void* d_dst, const void* d_src, const uint32_t* d_i
 template <class C>
 int msm_plan(int group, size_t n, int* c_out, int* nwin_out) {
     const int bits = C::FrP::BITS;
-    // cost ~ windows * (n mixed adds + the per-bucket reduction work, ~6 mixed-add equivalents per bucket as measured on
-    // MI355X: profiles/r01_*); G2 scales both terms alike
+    // cost ~ windows * (n mixed adds + the per-bucket reduction work, ~2 mixed-add equivalents per bucket with the lazy
+    // window reduction: measured best c = 17 at 2^20 and c = 20 at 2^24 on MI355X); G2 scales both terms alike
     double best = 1e300;
     int bc = 4;
     for (int c = 4; c <= 22; c++) {
         int nwin = bits / c + 1;
-        double cost = (double)nwin * ((double)n + 6.0 * (double)(1u << (c - 1)));
+        double cost = (double)nwin * ((double)n + 2.0 * (double)(1u << (c - 1)));
         if (cost < best) {
             best = cost;
             bc = c;
         }
     }
     (void)group;
+    if (const char* e = getenv("GA_MSM_C")) {   // experiments only: force the window width of the raw-bases plan
+        int v = atoi(e);
+        if (v >= 4 && v <= 22) bc = v;
+    }
     *c_out = bc;
     *nwin_out = bits / bc + 1;
     return GA_OK;
@@ -155,11 +159,18 @@ int msm_plan_table(size_t n, int* c_out, int* nwin_out) {
     for (int c = 4; c <= 23; c++) {
         int nwin = bits / c + 1;
         if ((double)nwin * (double)n >= 2147483648.0) continue;   // table index must fit 31 bits
-        double cost = (double)nwin * (double)n + 6.0 * (double)(1u << (c - 1));
+        // one shared bucket set: its reduction costs ~6 mixed-add equivalents per bucket for mid-size inputs (latency-bound
+        // kernels) and ~2.5 from 2^22 points up (measured: c = 17 best at 2^20, c = 22 best at 2^22 and 2^24)
+        const double per_bucket = n >= (1u << 22) ? 2.5 : 6.0;
+        double cost = (double)nwin * (double)n + per_bucket * (double)(1u << (c - 1));
         if (cost < best) {
             best = cost;
             bc = c;
         }
+    }
+    if (const char* e = getenv("GA_MSM_TABLE_C")) {   // experiments only
+        int v = atoi(e);
+        if (v >= 4 && v <= 23 && (double)(bits / v + 1) * (double)n < 2147483648.0) bc = v;
     }
     *c_out = bc;
     *nwin_out = bits / bc + 1;
