@@ -9,6 +9,8 @@ Workload (BASELINE.json `metric`: "G1 MSM Mscalar-mul/s + Groth16 proofs/s, BN25
     owns 2^24 pairs); the exchange step is an RCCL all_gather of one Jacobian partial per rank + a local add.
   * the Groth16 leg (proofs/s at the same size: computeH + 4 G1 MSMs + 1 G2 MSM + host epilogue, key pinned,
     solver excluded) is timed separately on rank 0 and reported in the "groth16" object of the same line.
+  * the PLONK leg (BASELINE config 5: kernel work of one BN254 proof at 2^22 gates -- 10 KZG-commit MSMs over a pinned SRS,
+    grand product, quotient) is reported in the "plonk" object (N = 1, BN254; `--plonk-log-n 0` disables it).
   * "roofline": dominant kernel (msm_accumulate) vs the 8 TB/s HBM peak using the ALGORITHMIC 96 B per scalar-mul
     (32 B scalar + 64 B affine base); durations come from hipEvents recorded by the library on its own
     stream.  "cpu_baseline": the C oracle's Pippenger (oracle/oracle.c, kind "port") on a bounded sample.
@@ -33,6 +35,7 @@ def parse():
     ap.add_argument("--log-n", type=int, default=int(os.environ.get("GA_BENCH_LOGN", "24")))
     ap.add_argument("--groth16-proofs", type=int, default=int(os.environ.get("GA_BENCH_PROOFS", "1")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--plonk-log-n", type=int, default=int(os.environ.get("GA_BENCH_PLONK_LOGN", "22")), help="0 disables the PLONK leg")
     ap.add_argument("--curve", default="bn254")
     return ap.parse_args()
 
@@ -246,6 +249,16 @@ def main():
                           "computeH_hbm_frac": round(448.0 * n / (ntt_ms * 1e-3) / 8e12, 5) if ntt_ms > 0 else None,
                           "proof_sha": __import__("hashlib").sha256(proof.WriteTo()).hexdigest()[:16],
                           "stages_ms": gst}
+
+    # ---- PLONK (BASELINE config 5): kernel work of one BN254 proof at 2^22 gates -- 10 KZG-commit MSMs over a pinned SRS, the
+    # grand product and the quotient (computeNumerator + divideByZH) on the device; N = 1, BN254 only
+    if rank == 0 and world == 1 and args.plonk_log_n > 0 and cid == 0:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_plonk_kernels
+            out["plonk"] = bench_plonk_kernels.run(ctx, args.plonk_log_n, reps=2, reference_count=False)[0]
+        except Exception as e:   # never lose the headline line over the secondary leg
+            out["plonk"] = {"error": str(e)[:300]}
 
     # ---- Groth16 across ranks (N > 1): key sharded by base-point range, partial MSM sums all-gathered (multigpu.py) -------
     if world > 1 and args.groth16_proofs > 0 and os.environ.get("GA_BENCH_SHARDED_G16", "1") != "0":

@@ -13,10 +13,10 @@ import gnark_amd  # noqa: E402
 from gnark_amd import _lib, ecc, fft  # noqa: E402
 
 
-def main():
-    logn = int(os.environ.get("GA_PLONK_LOGN", "22"))
+def run(ctx, logn=22, reps=3, reference_count=True):
+    """returns [fused-pipeline result, (optionally) the reference's transform count issued one by one]"""
+    results = []
     n = 1 << logn
-    ctx = gnark_amd.Context(0)
     lib = ctx.lib
     srs = ctx.malloc(n * 64)
     lib.check(lib.ga_gen_bases(ctx.handle, 0, 0, 0x5EED0007, n, srs.ptr, None))
@@ -66,20 +66,20 @@ def main():
                                        host_small[11:].ctypes.data, 1, zbuf.ptr))
         lib.check(lib.ga_plonk_quotient(d.handle, d4.handle, C.byref(qin), big.ptr))
 
-    if os.environ.get("GA_PLONK_FUSED", "1") == "1":
+    if True:
         proof_fused()
         ctx.profile(True)
         ctx.profile_reset()
         ctx.sync()
         t0 = time.perf_counter()
-        for _ in range(3):
+        for _ in range(reps):
             proof_fused()
         ctx.sync()
-        el = (time.perf_counter() - t0) / 3
+        el = (time.perf_counter() - t0) / reps
         st = {}
         for name, ms in ctx.profile_read():
-            st[name] = st.get(name, 0.0) + ms / 3
-        print(json.dumps({"workload": "PLONK BN254 2^%d, fused quotient: 10 G1 MSM + BuildRatioCopyConstraint + computeNumerator/divideByZH on device" % logn,
+            st[name] = st.get(name, 0.0) + ms / reps
+        results.append(({"workload": "PLONK BN254 2^%d, fused quotient: 10 G1 MSM + BuildRatioCopyConstraint + computeNumerator/divideByZH on device" % logn,
                           "ms_per_proof_kernels": round(el * 1e3, 2),
                           "msm_ms": round(sum(v for k, v in st.items() if k.startswith("msm_")), 2),
                           "ntt_ms": round(sum(v for k, v in st.items() if k.startswith("ntt_")), 2),
@@ -87,12 +87,21 @@ def main():
                           "stages_ms": {k: round(v, 3) for k, v in st.items()}}))
         ctx.profile(False)
 
+    def cleanup():
+        for b in polys + [srs, big, small, perm, zbuf]:
+            b.free()
+        srs_table.free()
+        d.close()
+        d4.close()
+
+    if not reference_count:
+        cleanup()
+        return results
     proof_kernels()
     ctx.profile(True)
     ctx.profile_reset()
     ctx.sync()
     t0 = time.perf_counter()
-    reps = 3
     for _ in range(reps):
         proof_kernels()
     ctx.sync()
@@ -103,12 +112,17 @@ def main():
     alg = 10 * 96 * n + 108 * 64 * n + 64 * 4 * n
     msm_ms = sum(v for k, v in st.items() if k.startswith("msm_"))
     ntt_ms = sum(v for k, v in st.items() if k.startswith("ntt_"))
-    print(json.dumps({"workload": "PLONK BN254 2^%d kernels: 10 G1 MSM + 108 NTT(2^%d) + 1 iNTT(2^%d)" % (logn, logn, logn + 2),
+    results.append(({"workload": "PLONK BN254 2^%d kernels: 10 G1 MSM + 108 NTT(2^%d) + 1 iNTT(2^%d)" % (logn, logn, logn + 2),
                       "ms_per_proof_kernels": round(el * 1e3, 2), "msm_ms": round(msm_ms, 2), "ntt_ms": round(ntt_ms, 2),
                       "algorithmic_bytes": alg, "hbm_frac": round(alg / el / 8e12, 5),
                       "ntt_hbm_frac": round((108 * 64 * n + 64 * 4 * n) / (ntt_ms * 1e-3) / 8e12, 5),
                       "stages_ms": {k: round(v, 3) for k, v in st.items()}}))
+    ctx.profile(False)
+    cleanup()
+    return results
 
 
 if __name__ == "__main__":
-    main()
+    with gnark_amd.Context(0) as _ctx:
+        for _r in run(_ctx, int(os.environ.get("GA_PLONK_LOGN", "22"))):
+            print(json.dumps(_r))
