@@ -23,6 +23,9 @@
 namespace ga {
 
 constexpr int NTT_LG_TILE = 10;               // 1024 elements = 32 KiB of LDS per workgroup
+#ifndef GA_NTT_R4_DIF
+#define GA_NTT_R4_DIF 1   // radix-4 register blocking for the DIF passes too
+#endif
 constexpr int NTT_THREADS = 256;
 constexpr int NTT_POW_LO_BITS = 12;
 
@@ -254,6 +257,163 @@ ntt_pass29_kernel(uint32_t* data, const uint32_t* src, const uint32_t* __restric
     }
 }
 
+// ---- the lazy pass with two stages per LDS round trip (radix-4 in registers) ------------------------------------------------
+// Same arithmetic, twiddles and bounds as ntt_pass29_kernel, stage for stage; what changes is the bookkeeping: a thread keeps a
+// quad (index bits t and t+1) in registers across two stages, so there is one LDS read + write, one index computation and one
+// barrier per TWO stages, three twiddle loads instead of four (both butterflies of the first stage share theirs; the second
+// stage uses w^e and w^(e + n/4)), and the intermediate values are not carry-normalised: limb-wise sums stay below 2^32 and a
+// 2^31-limb multiplicand still keeps the product columns below 2^64.  An odd stage count ends with one plain radix-2 stage.
+template <class P>
+GA_HD F29<P> f29_add_raw(const F29<P>& a, const F29<P>& b) {   // limb-wise, no carry sweep
+    F29<P> r;
+#pragma unroll
+    for (int i = 0; i < F29<P>::NL; i++) r.l[i] = a.l[i] + b.l[i];
+    return r;
+}
+template <int K, class P>
+GA_HD F29<P> f29_sub_raw(const F29<P>& a, const F29<P>& b) {   // a - b + K*p limb-wise, b normalised, no carry sweep
+    F29<P> r;
+#pragma unroll
+    for (int i = 0; i < F29<P>::NL; i++) r.l[i] = a.l[i] + kp_limb<P, K>(i) - b.l[i];
+    return r;
+}
+
+template <class FrP, bool DIT_>
+__global__ void __launch_bounds__(NTT_THREADS)
+ntt_pass29r4_kernel(uint32_t* data, const uint32_t* src, const uint32_t* __restrict__ tw, int logn, int lg_tile, int s_lo, int K,
+                    int lc, NttScale pre, NttScale post) {
+    static_assert(FrP::N == 8, "Fr is 4x64-bit limbs on both curves");
+    typedef F29<FrP> E;
+    __shared__ uint32_t lds[Radix<FrP>::NL << NTT_LG_TILE];
+    LdsTile29<FrP> T{lds};
+    const uint32_t tile_elems = 1u << lg_tile;
+    const uint64_t tile = blockIdx.x;
+    const uint32_t tid = threadIdx.x;
+    auto twid = [&](uint64_t e) { return f29_unpack(load_fe_plain<FrP>(tw + e * 8)); };
+
+    for (uint32_t l = tid; l < tile_elems; l += NTT_THREADS) {
+        uint64_t i = ntt_gidx(l, tile, lg_tile, s_lo, K, lc);
+        E v = f29_unpack(load_fe<FrP>(src + i * 8));
+        if (pre.mode != 0) v = f29_mul(v, ntt_scale_factor29<FrP>(pre, i, logn));
+        T.put(l, v);
+    }
+    __syncthreads();
+
+    int k = 0;
+    for (; k + 1 < K; k += 2) {
+        // stage order: DIT ascending (t, t+1); DIF descending (t+1, t) with t = K-2-k
+        const int t = DIT_ ? k : (K - 2 - k);
+        const int lb = lc + t;
+        const int s = s_lo + t;
+        for (uint32_t q = tid; q < tile_elems / 4; q += NTT_THREADS) {
+            const uint32_t l00 = ((q >> lb) << (lb + 2)) | (q & ((1u << lb) - 1));
+            const uint32_t l01 = l00 | (1u << lb), l10 = l00 | (2u << lb), l11 = l00 | (3u << lb);
+            const uint64_t i0 = ntt_gidx(l00, tile, lg_tile, s_lo, K, lc);
+            const uint64_t x = i0 & ((1ull << s) - 1);
+            const uint64_t e1 = x << (logn - 1 - s);        // stage s: both butterflies of the quad
+            const uint64_t e2 = x << (logn - 2 - s);        // stage s+1: w^e2 for (.0), w^(e2 + n/4) for (.1)
+            const uint64_t e3 = e2 + (1ull << (logn - 2));
+            E a00 = T.get(l00), a01 = T.get(l01), a10 = T.get(l10), a11 = T.get(l11);
+            if (DIT_) {
+                // stage s: (a00, a01) and (a10, a11); products (or, for w = 1, the operand itself) are brought below 3p
+                E m0, m1;
+                if (e1 != 0) {
+                    const E w1 = twid(e1);
+                    m0 = f29_mul(a01, w1);
+                    m1 = f29_mul(a11, w1);
+                } else {
+                    m0 = f29_reduce_3p(a01);
+                    m1 = f29_reduce_3p(a11);
+                }
+                E b00 = f29_add_raw(a00, m0), b01 = f29_sub_raw<4>(a00, m0);
+                E b10 = f29_add_raw(a10, m1), b11 = f29_sub_raw<4>(a10, m1);
+                // stage s+1: (b00, b10) with w^e2, (b01, b11) with w^e3; multiplicand limbs < 2^31
+                E m2;
+                if (e2 != 0) {
+                    m2 = f29_mul(b10, twid(e2));
+                } else {
+                    f29_normalize(b10);
+                    m2 = f29_reduce_3p(b10);
+                }
+                E m3 = f29_mul(b11, twid(e3));
+                E c00 = f29_add_raw(b00, m2), c10 = f29_sub_raw<4>(b00, m2);
+                E c01 = f29_add_raw(b01, m3), c11 = f29_sub_raw<4>(b01, m3);
+                f29_normalize(c00);
+                f29_normalize(c01);
+                f29_normalize(c10);
+                f29_normalize(c11);
+                T.put(l00, c00);
+                T.put(l01, c01);
+                T.put(l10, c10);
+                T.put(l11, c11);
+            } else {
+                // stage s+1 (count k): (a00, a10) with w^e2, (a01, a11) with w^e3
+                E d0 = f29_sub<32>(a00, a10), d1 = f29_sub<32>(a01, a11);
+                d0 = e2 != 0 ? f29_mul(d0, twid(e2)) : f29_reduce_3p(d0);
+                d1 = f29_mul(d1, twid(e3));
+                E s0 = f29_add(a00, a10), s1 = f29_add(a01, a11);
+                if ((k % 3) == 2) {
+                    s0 = f29_reduce_3p(s0);
+                    s1 = f29_reduce_3p(s1);
+                }
+                // stage s (count k+1): (s0, s1) and (d0, d1), both with w^e1
+                E o01 = f29_sub<32>(s0, s1), o11 = f29_sub<32>(d0, d1);
+                if (e1 != 0) {
+                    const E w1 = twid(e1);
+                    o01 = f29_mul(o01, w1);
+                    o11 = f29_mul(o11, w1);
+                } else {
+                    o01 = f29_reduce_3p(o01);
+                    o11 = f29_reduce_3p(o11);
+                }
+                E o00 = f29_add(s0, s1), o10 = f29_add(d0, d1);
+                if (((k + 1) % 3) == 2) {
+                    o00 = f29_reduce_3p(o00);
+                    o10 = f29_reduce_3p(o10);
+                }
+                T.put(l00, o00);
+                T.put(l01, o01);
+                T.put(l10, o10);
+                T.put(l11, o11);
+            }
+        }
+        __syncthreads();
+    }
+    if (k < K) {   // odd stage count: the last stage as a plain radix-2 stage (DIT: t = K-1, DIF: t = 0)
+        const int t = DIT_ ? k : 0;
+        const int lb = lc + t;
+        const int s = s_lo + t;
+        const bool reduce_sum = (k % 3) == 2;
+        for (uint32_t q = tid; q < tile_elems / 2; q += NTT_THREADS) {
+            uint32_t l0 = ((q >> lb) << (lb + 1)) | (q & ((1u << lb) - 1));
+            uint32_t l1 = l0 | (1u << lb);
+            uint64_t i0 = ntt_gidx(l0, tile, lg_tile, s_lo, K, lc);
+            uint64_t e = (i0 & ((1ull << s) - 1)) << (logn - 1 - s);
+            E x = T.get(l0), y = T.get(l1);
+            if (DIT_) {
+                E m = e != 0 ? f29_mul(y, twid(e)) : f29_reduce_3p(y);
+                T.put(l0, f29_add(x, m));
+                T.put(l1, f29_sub<4>(x, m));
+            } else {
+                E d = f29_sub<32>(x, y);
+                d = e != 0 ? f29_mul(d, twid(e)) : f29_reduce_3p(d);
+                E sum = f29_add(x, y);
+                if (reduce_sum) sum = f29_reduce_3p(sum);
+                T.put(l0, sum);
+                T.put(l1, d);
+            }
+        }
+        __syncthreads();
+    }
+
+    for (uint32_t l = tid; l < tile_elems; l += NTT_THREADS) {
+        uint64_t i = ntt_gidx(l, tile, lg_tile, s_lo, K, lc);
+        E v = T.get(l);
+        if (post.mode != 0) v = f29_mul(v, ntt_scale_factor29<FrP>(post, i, logn));
+        store_fe(data + i * 8, f29_pack_canonical(f29_reduce_3p(v)));
+    }
+}
+
 // tw[e] = w^e for e < count, from the table of w^(2^k)
 template <class FrP>
 __global__ void ntt_twiddle_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ pow2, uint64_t count,
@@ -296,6 +456,7 @@ struct Domain {
     uint32_t* d_gi_hi = nullptr;
     uint32_t* d_gn_lo = nullptr;    // g^k / n   (computeH: coset FFT fused with the 1/n of the preceding iFFT)
     bool lazy = true;               // tables in the hat domain, ntt_pass29_kernel (GA_NTT_LAZY=0 selects the packed kernel)
+    bool radix4 = true;             // two stages per LDS round trip (ntt_pass29r4_kernel; GA_NTT_R4=0 selects the radix-2 pass)
     uint32_t ninv[8];               // 1/n (Montgomery; hat-packed when lazy)
     uint32_t den[8];                // (g^n - 1)^-1 (Montgomery), prove.go:370-373
     std::vector<NttPass> passes;    // ascending stage order
@@ -337,7 +498,14 @@ int ntt_run(Domain* d, uint32_t* d_data, bool inverse, bool dit, const NttScale&
         const NttScale& post = (p == np - 1) ? post_last : none;
         const uint32_t* src = (p == 0 && d_src) ? d_src : d_data;
         StageTimer st(ctx, dit ? "ntt_pass_dit" : "ntt_pass_dif");
-        if (d->lazy) {
+        if (d->lazy && d->radix4 && (dit || GA_NTT_R4_DIF) && d->logn >= 2) {
+            if (dit)
+                hipLaunchKernelGGL((ntt_pass29r4_kernel<FrP, true>), dim3((unsigned)tiles), dim3(NTT_THREADS), 0, ctx->stream,
+                                   d_data, src, tw, d->logn, lg_tile, ps.s_lo, ps.K, ps.lc, pre, post);
+            else
+                hipLaunchKernelGGL((ntt_pass29r4_kernel<FrP, false>), dim3((unsigned)tiles), dim3(NTT_THREADS), 0, ctx->stream,
+                                   d_data, src, tw, d->logn, lg_tile, ps.s_lo, ps.K, ps.lc, pre, post);
+        } else if (d->lazy) {
             if (dit)
                 hipLaunchKernelGGL((ntt_pass29_kernel<FrP, true>), dim3((unsigned)tiles), dim3(NTT_THREADS), 0, ctx->stream,
                                    d_data, src, tw, d->logn, lg_tile, ps.s_lo, ps.K, ps.lc, pre, post);
@@ -436,6 +604,8 @@ int domain_init(Ctx* ctx, Domain* d, int curve, uint64_t n) {
     {
         const char* env = getenv("GA_NTT_LAZY");
         d->lazy = !(env && env[0] == '0');
+        const char* r4 = getenv("GA_NTT_R4");
+        d->radix4 = !(r4 && r4[0] == '0');
     }
     // host: w = ROOT^(2^(adicity-logn)), inverse likewise; tables of w^(2^k)
     F w = fe_const<FrP>(FrP::ROOT), wi = fe_const<FrP>(FrP::ROOT_INV);
