@@ -11,9 +11,9 @@ import gnark_amd, json
 ctx = gnark_amd.Context(0)
 print(json.dumps(ctx.microbench()))
 " > gpurun_out/microbench.json 2>&1
-timeout 1500 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_stats -o bench24 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/prof_stats.log 2>&1
-timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/prof_fetch -o b24 -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/prof_fetch.log 2>&1
-timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/prof_write -o b24 -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/prof_write.log 2>&1
+timeout 1500 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_stats -o bench24 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --plonk-log-n 0 > gpurun_out/prof_stats.log 2>&1
+timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/prof_fetch -o b24 -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --plonk-log-n 0 > gpurun_out/prof_fetch.log 2>&1
+timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/prof_write -o b24 -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --plonk-log-n 0 > gpurun_out/prof_write.log 2>&1
 tail -3 gpurun_out/pytest_gpu.log
 for f in bench_bn254_24 bench_bls_24 bench_plonk_22; do echo "== $f"; tail -c 400 gpurun_out/$f.err; python - <<PY
 import json
