@@ -86,6 +86,9 @@ _PROTOS = {
     "ga_fft": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ga_compute_h": (C.c_int, [_P, _P, _P, _P, C.c_uint64, _P, C.c_int]),
     "ga_plonk_quotient": (C.c_int, [_P, _P, C.POINTER(PlonkQuotientIn), _P]),
+    "ga_plonk_pk_create": (C.c_int, [_P, _P, C.POINTER(PlonkQuotientIn), C.POINTER(_P)]),
+    "ga_plonk_pk_destroy": (None, [_P]),
+    "ga_plonk_quotient_pinned": (C.c_int, [_P, C.POINTER(PlonkQuotientIn), _P]),
     "ga_plonk_build_z": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
     "ga_fr_batch_invert": (C.c_int, [_P, C.c_int, _P, C.c_uint64, C.c_int]),
     "ga_g16_pk_create": (C.c_int, [_P, C.POINTER(G16Key), C.POINTER(_P)]),

@@ -468,6 +468,81 @@ int ga_plonk_quotient(ga_domain* dh0, ga_domain* dh1, const ga_plonk_quotient_in
     return GA_OK;
 }
 
+static int plonk_args_from(const ga_plonk_quotient_in* in, bool need_fixed, bool need_var, PlonkQuotientArgs* a) {
+    memset(a, 0, sizeof(*a));
+    if (in->nb_bsb > (uint32_t)PLONK_MAX_BSB) {
+        set_error("plonk: more than %d BSB22 gates", PLONK_MAX_BSB);
+        return GA_ERR_INVALID;
+    }
+    a->nb_bsb = in->nb_bsb;
+    const void* fixed[PLONK_NB_FIXED] = {in->l, in->r, in->o, in->z, in->ql, in->qr, in->qm, in->qo, in->qk, in->s1, in->s2, in->s3};
+    const bool is_fixed[PLONK_NB_FIXED] = {false, false, false, false, true, true, true, true, false, true, true, true};
+    for (int k = 0; k < PLONK_NB_FIXED; k++) {
+        if ((is_fixed[k] ? need_fixed : need_var) && !fixed[k]) {
+            set_error("plonk: polynomial %d of the input is null", k);
+            return GA_ERR_INVALID;
+        }
+        a->polys[k] = fixed[k];
+    }
+    for (uint32_t k = 0; k < in->nb_bsb; k++) {
+        if ((need_fixed && (!in->qcp || !in->qcp[k])) || (need_var && (!in->pi2 || !in->pi2[k]))) {
+            set_error("plonk: null Qcp / Pi2 polynomial %u", k);
+            return GA_ERR_INVALID;
+        }
+        a->polys[PLONK_NB_FIXED + 2 * k] = in->qcp ? in->qcp[k] : nullptr;
+        a->polys[PLONK_NB_FIXED + 2 * k + 1] = in->pi2 ? in->pi2[k] : nullptr;
+    }
+    if (need_var && (!in->bl || !in->br || !in->bo || !in->bz || !in->alpha || !in->beta || !in->gamma)) {
+        set_error("plonk: blinding polynomials and challenges are required");
+        return GA_ERR_INVALID;
+    }
+    a->lagrange_mask = in->lagrange_mask;
+    a->on_device = (in->flags & GA_PLONK_ON_DEVICE) != 0;
+    a->bl = in->bl; a->br = in->br; a->bo = in->bo; a->bz = in->bz;
+    a->alpha = in->alpha; a->beta = in->beta; a->gamma = in->gamma;
+    return GA_OK;
+}
+
+int ga_plonk_pk_create(ga_domain* dh0, ga_domain* dh1, const ga_plonk_quotient_in* in, ga_plonk_pk** out) {
+    Domain *d0 = reinterpret_cast<Domain*>(dh0), *d1 = reinterpret_cast<Domain*>(dh1);
+    if (!d0 || !d1 || !in || !out || ntt_domain_curve(d0) != ntt_domain_curve(d1) || ntt_domain_ctx(d0) != ntt_domain_ctx(d1)) {
+        set_error("ga_plonk_pk_create: null argument, or the two domains differ in curve/context");
+        return GA_ERR_INVALID;
+    }
+    Ctx* c = ntt_domain_ctx(d0);
+    Lock l(c);
+    PlonkQuotientArgs a;
+    GA_CHECK(plonk_args_from(in, true, false, &a));
+    PlonkFixed* fx = nullptr;
+    GA_DISPATCH_CURVE(ntt_domain_curve(d0), GA_CHECK(plonk_domain_fixed_create<C>(d0, d1, a, &fx)));
+    *out = reinterpret_cast<ga_plonk_pk*>(fx);
+    return GA_OK;
+}
+
+void ga_plonk_pk_destroy(ga_plonk_pk* p) {
+    PlonkFixed* fx = reinterpret_cast<PlonkFixed*>(p);
+    if (!fx) return;
+    Ctx* c = ntt_domain_ctx(plonk_fixed_domain0(fx));
+    Lock l(c);
+    hipStreamSynchronize(c->stream);
+    plonk_fixed_delete(fx);
+}
+
+int ga_plonk_quotient_pinned(ga_plonk_pk* p, const ga_plonk_quotient_in* in, void* h_out) {
+    PlonkFixed* fx = reinterpret_cast<PlonkFixed*>(p);
+    if (!fx || !in || !h_out) {
+        set_error("ga_plonk_quotient_pinned: null argument");
+        return GA_ERR_INVALID;
+    }
+    Domain* d0 = plonk_fixed_domain0(fx);
+    Ctx* c = ntt_domain_ctx(d0);
+    Lock l(c);
+    PlonkQuotientArgs a;
+    GA_CHECK(plonk_args_from(in, false, true, &a));
+    GA_DISPATCH_CURVE(ntt_domain_curve(d0), GA_CHECK(plonk_domain_quotient_pinned<C>(fx, a, h_out)));
+    return GA_OK;
+}
+
 int ga_plonk_build_z(ga_domain* dh0, const void* lv, const void* rv, const void* ov, const int64_t* permutation, const void* beta,
                      const void* gamma, int on_device, void* z_out) {
     Domain* d0 = reinterpret_cast<Domain*>(dh0);

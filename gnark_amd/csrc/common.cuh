@@ -182,7 +182,12 @@ struct PlonkQuotientArgs {
     const void *bl, *br, *bo, *bz;   // blinding polynomials: 2, 2, 2, 3 coefficients
     const void *alpha, *beta, *gamma;
 };
+struct PlonkFixed;   // plonk.cuh: the circuit-constant coset evaluations pinned in HBM
 template <class C> int plonk_domain_quotient(Domain* d0, Domain* d1, const PlonkQuotientArgs& args, void* h_out);
+template <class C> int plonk_domain_fixed_create(Domain* d0, Domain* d1, const PlonkQuotientArgs& args, PlonkFixed** out);
+template <class C> int plonk_domain_quotient_pinned(PlonkFixed* fx, const PlonkQuotientArgs& args, void* h_out);
+void plonk_fixed_delete(PlonkFixed* fx);
+Domain* plonk_fixed_domain0(PlonkFixed* fx);
 template <class C> int plonk_domain_build_z(Domain* d0, const void* L, const void* R, const void* O, const int64_t* perm, const void* beta,
                                             const void* gamma, bool on_device, void* z_out);
 template <class C> int fr_vec_batch_inverse(Ctx* ctx, void* v, uint64_t n, bool on_device);

@@ -1,6 +1,8 @@
 // Non-templated accessors of the fft.Domain analogue (see ntt.cuh).
-#include "ntt.cuh"
+#include "plonk.cuh"
 namespace ga {
+void plonk_fixed_delete(PlonkFixed* fx) { plonk_fixed_destroy(fx); }
+Domain* plonk_fixed_domain0(PlonkFixed* fx) { return fx->d0; }
 void ntt_domain_delete(Domain* d) {
     if (!d) return;
     domain_free(d);

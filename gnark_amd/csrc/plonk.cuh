@@ -272,14 +272,37 @@ Fe<FrP> plonk_root_of_unity(int logn) {
     return w;
 }
 
+// Circuit-constant part of the quotient, pinned in HBM (the "huge memory footprint" precomputation prove.go:1030-1034 decides
+// against on a CPU): the evaluations of Ql, Qr, Qm, Qo, S1, S2, S3 and every Qcp on each of the rho cosets, and 1/(x-1) on
+// each coset -- (7 + k + 1) * rho * n * 32 B, 4.3 GB at n = 2^22.  Per proof only L, R, O, Z, Qk and the BSB22 commitment
+// polynomials are transformed: 6 + 4*6 + 1 transforms instead of 12 + 4*12 + 1.
+struct PlonkFixed {
+    Ctx* ctx = nullptr;
+    Domain *d0 = nullptr, *d1 = nullptr;
+    uint32_t nb_bsb = 0;
+    int nslots = 0;
+    int slot[PLONK_NB_FIXED + 2 * PLONK_MAX_BSB];   // -1: per-proof polynomial; else index into evals
+    uint32_t* evals = nullptr;     // [rho][nslots][n] fr
+    uint32_t* inv_xm1 = nullptr;   // [rho][n] fr
+};
+inline bool plonk_is_fixed(int p) {
+    if (p >= PLONK_NB_FIXED) return ((p - PLONK_NB_FIXED) & 1) == 0;               // Qcp_i fixed, Pi2_i per proof
+    return p == PX_QL || p == PX_QR || p == PX_QM || p == PX_QO || p == PX_S1 || p == PX_S2 || p == PX_S3;
+}
+
+// mode 0: everything per call; mode 1: build `fx` from the fixed polynomials of A (no quotient); mode 2: quotient with `fx`
 template <class FrP>
-int plonk_quotient(Domain* d0, Domain* d1, const PlonkQuotientArgs& A, void* h_out) {
+int plonk_quotient(Domain* d0, Domain* d1, const PlonkQuotientArgs& A, void* h_out, int mode = 0, PlonkFixed* fx = nullptr) {
     typedef Fe<FrP> F;
     Ctx* ctx = d0->ctx;
     const uint64_t n = d0->n, N = d1->n;
     const int logn = d0->logn;
     if (n < 2 || N < n || N % n != 0 || A.nb_bsb > (uint32_t)PLONK_MAX_BSB || d1->ctx != ctx) {
         set_error("plonk quotient: need n >= 2, |domain1| a multiple of |domain0|, at most %d BSB22 gates", PLONK_MAX_BSB);
+        return GA_ERR_INVALID;
+    }
+    if (mode == 2 && (fx->nb_bsb != A.nb_bsb || fx->d0 != d0 || fx->d1 != d1)) {
+        set_error("plonk quotient: the pinned key was built for %u BSB22 gates / other domains", fx->nb_bsb);
         return GA_ERR_INVALID;
     }
     const uint64_t rho = N / n;
@@ -293,8 +316,10 @@ int plonk_quotient(Domain* d0, Domain* d1, const PlonkQuotientArgs& A, void* h_o
     GA_CHECK(ctx->scratch_get("plonk_tmp", n * 32, (void**)&tmpb));
     GA_CHECK(ctx->scratch_get("plonk_cres", N * 32, (void**)&cres));
     const unsigned blocks = (unsigned)((n + 255) / 256);
+    auto skip = [&](int p) { return mode == 1 ? !plonk_is_fixed(p) : (mode == 2 && plonk_is_fixed(p)); };
     // ---- canonical coefficients in bit-reversed order, once ---------------------------------------------------------
     for (int p = 0; p < np; p++) {
+        if (skip(p)) continue;
         uint32_t* dst = canon + (size_t)p * n * 8;
         uint32_t* stage = work + (size_t)p * n * 8;
         const bool lag = (A.lagrange_mask >> p) & 1;
@@ -326,51 +351,65 @@ int plonk_quotient(Domain* d0, Domain* d1, const PlonkQuotientArgs& A, void* h_o
     }
     PlonkConsts K;
     auto put = [](uint32_t* dst, const F& v) { memcpy(dst, v.l, 32); };
-    put(K.alpha, ld(A.alpha));
-    put(K.beta, ld(A.beta));
-    put(K.gamma, ld(A.gamma));
+    memset(&K, 0, sizeof(K));
+    if (mode != 1) {
+        put(K.alpha, ld(A.alpha));
+        put(K.beta, ld(A.beta));
+        put(K.gamma, ld(A.gamma));
+    }
     put(K.cs, g);              // prove.go:891-893
     put(K.css, sqr(g));
     put(K.omega, w0);
     PlonkPtrs P;
     memset(&P, 0, sizeof(P));
     P.nb_bsb = (int)A.nb_bsb;
-    for (int p = 0; p < np; p++) P.p[p] = work + (size_t)p * n * 8;
     F coset = fe_one<FrP>();
     for (uint64_t i = 0; i < rho; i++) {
+        for (int p = 0; p < np; p++)
+            P.p[p] = (mode == 2 && plonk_is_fixed(p)) ? fx->evals + ((size_t)(i * fx->nslots + fx->slot[p])) * n * 8 : work + (size_t)p * n * 8;
         coset = mul(coset, i == 0 ? g : w1);                       // shifters, prove.go:936-941,998
         const F cexp = sub(plonk_host_pow<FrP>(coset, n), fe_one<FrP>());   // (coset^n - 1), prove.go:999-1000
+        if (mode != 1)
         for (int k = 0; k < 2; k++) {
             put(K.bl[k], mul(ld(A.bl, k), cexp));
             put(K.br[k], mul(ld(A.br, k), cexp));
             put(K.bo[k], mul(ld(A.bo, k), cexp));
         }
-        for (int k = 0; k < 3; k++) put(K.bz[k], mul(ld(A.bz, k), cexp));
+        if (mode != 1)
+            for (int k = 0; k < 3; k++) put(K.bz[k], mul(ld(A.bz, k), cexp));
         put(K.lone, mul(cexp, ninv));
         put(K.zh_inv, inv(cexp));
         // evaluations on coset*H: forward DIT with the coset powers fused into the first pass (prove.go:1033-1058)
         uint32_t *s_lo, *s_hi, *x_lo, *x_hi;
         GA_CHECK(plonk_pow_tables<FrP>(ctx, "plonk_scale_tab", coset, fe_one<FrP>(), n, d0->lazy, &s_lo, &s_hi));
         GA_CHECK(plonk_pow_tables<FrP>(ctx, "plonk_x_tab", w0, coset, n, false, &x_lo, &x_hi));
-        for (int p = 0; p < np; p++)
-            GA_CHECK(ntt_run<FrP>(d0, work + (size_t)p * n * 8, /*inverse=*/false, /*dit=*/true, scale_pow(s_lo, s_hi, /*bitrev=*/true),
-                                  scale_none(), canon + (size_t)p * n * 8));
-        {
+        for (int p = 0; p < np; p++) {
+            if (skip(p)) continue;
+            uint32_t* dst = mode == 1 ? fx->evals + ((size_t)(i * fx->nslots + fx->slot[p])) * n * 8 : work + (size_t)p * n * 8;
+            GA_CHECK(ntt_run<FrP>(d0, dst, /*inverse=*/false, /*dit=*/true, scale_pow(s_lo, s_hi, /*bitrev=*/true), scale_none(),
+                                  canon + (size_t)p * n * 8));
+        }
+        uint32_t* inv_i = mode == 0 ? invb : fx->inv_xm1 + (size_t)i * n * 8;
+        if (mode != 2) {
             StageTimer tm(ctx, "plonk_batch_inverse");
-            hipLaunchKernelGGL((plonk_x_minus_one_kernel<FrP>), dim3(blocks), dim3(256), 0, st, invb, x_lo, x_hi, NTT_POW_LO_BITS, n);
+            hipLaunchKernelGGL((plonk_x_minus_one_kernel<FrP>), dim3(blocks), dim3(256), 0, st, inv_i, x_lo, x_hi, NTT_POW_LO_BITS, n);
             const uint64_t threads = n < 65536 ? (n + 63) / 64 : n / 64;   // >= 64 elements per thread amortise the inversion
             const unsigned ib = (unsigned)((threads + 63) / 64);
-            hipLaunchKernelGGL((fr_batch_inverse_kernel<FrP>), dim3(ib), dim3(64), 0, st, invb, tmpb, n);
+            hipLaunchKernelGGL((fr_batch_inverse_kernel<FrP>), dim3(ib), dim3(64), 0, st, inv_i, tmpb, n);
             GA_KERNEL_CHECK();
         }
-        {
+        if (mode != 1) {
             StageTimer tm(ctx, "plonk_constraints");
             uint64_t block = 0;   // bitrev_N(rho*j + i) = bitrev_rho(i)*n + bitrev_n(j)
             for (int b = 0; b < logrho; b++) block |= ((i >> b) & 1) << (logrho - 1 - b);
             hipLaunchKernelGGL((plonk_constraints_kernel<FrP>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, P, K, x_lo, x_hi,
-                               NTT_POW_LO_BITS, invb, cres + block * n * 8, n, logn);
+                               NTT_POW_LO_BITS, inv_i, cres + block * n * 8, n, logn);
             GA_KERNEL_CHECK();
         }
+    }
+    if (mode == 1) {
+        GA_HIP_CHECK(hipStreamSynchronize(st));
+        return GA_OK;
     }
     // ---- a.ToCanonical(bigDomain).ToRegular() from LagrangeCoset/BitReverse (prove.go:1319): inverse DIT on the coset ----
     GA_CHECK(ntt_fft<FrP>(d1, cres, GA_FFT_INVERSE, GA_DIT, 1));
@@ -380,6 +419,44 @@ int plonk_quotient(Domain* d0, Domain* d1, const PlonkQuotientArgs& A, void* h_o
     }
     GA_HIP_CHECK(hipStreamSynchronize(st));
     return GA_OK;
+}
+
+template <class FrP>
+int plonk_fixed_create(Domain* d0, Domain* d1, const PlonkQuotientArgs& A, PlonkFixed** out) {
+    const uint64_t n = d0->n, rho = d1->n / (d0->n ? d0->n : 1);
+    if (n < 2 || d1->n % n != 0 || A.nb_bsb > (uint32_t)PLONK_MAX_BSB || d1->ctx != d0->ctx) {
+        set_error("plonk key: need n >= 2, |domain1| a multiple of |domain0|, at most %d BSB22 gates", PLONK_MAX_BSB);
+        return GA_ERR_INVALID;
+    }
+    PlonkFixed* fx = new PlonkFixed();
+    fx->ctx = d0->ctx;
+    fx->d0 = d0;
+    fx->d1 = d1;
+    fx->nb_bsb = A.nb_bsb;
+    const int np = PLONK_NB_FIXED + 2 * (int)A.nb_bsb;
+    for (int p = 0; p < PLONK_NB_FIXED + 2 * PLONK_MAX_BSB; p++) fx->slot[p] = (p < np && plonk_is_fixed(p)) ? fx->nslots++ : -1;
+    const size_t ev = (size_t)rho * fx->nslots * n * 32, iv = (size_t)rho * n * 32;
+    if (hipMalloc((void**)&fx->evals, ev) != hipSuccess || hipMalloc((void**)&fx->inv_xm1, iv) != hipSuccess) {
+        set_error("plonk key: hipMalloc of %zu bytes failed", ev + iv);
+        hipFree(fx->evals);
+        delete fx;
+        return GA_ERR_NOMEM;
+    }
+    int rc = plonk_quotient<FrP>(d0, d1, A, nullptr, 1, fx);
+    if (rc != GA_OK) {
+        hipFree(fx->evals);
+        hipFree(fx->inv_xm1);
+        delete fx;
+        return rc;
+    }
+    *out = fx;
+    return GA_OK;
+}
+inline void plonk_fixed_destroy(PlonkFixed* fx) {
+    if (!fx) return;
+    hipFree(fx->evals);
+    hipFree(fx->inv_xm1);
+    delete fx;
 }
 
 // fr.BatchInvert on a vector (host or device memory), in place

@@ -6,6 +6,14 @@ int plonk_domain_quotient<Bn254>(Domain* d0, Domain* d1, const PlonkQuotientArgs
     return plonk_quotient<Bn254::FrP>(d0, d1, args, h_out);
 }
 template <>
+int plonk_domain_fixed_create<Bn254>(Domain* d0, Domain* d1, const PlonkQuotientArgs& args, PlonkFixed** out) {
+    return plonk_fixed_create<Bn254::FrP>(d0, d1, args, out);
+}
+template <>
+int plonk_domain_quotient_pinned<Bn254>(PlonkFixed* fx, const PlonkQuotientArgs& args, void* h_out) {
+    return plonk_quotient<Bn254::FrP>(fx->d0, fx->d1, args, h_out, 2, fx);
+}
+template <>
 int plonk_domain_build_z<Bn254>(Domain* d0, const void* L, const void* R, const void* O, const int64_t* perm, const void* beta,
                                 const void* gamma, bool on_device, void* z_out) {
     return plonk_build_z<Bn254::FrP>(d0, L, R, O, perm, beta, gamma, on_device, z_out);

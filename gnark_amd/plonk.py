@@ -20,6 +20,83 @@ def Rho(n: int) -> int:
     return 8 if n < 6 else 4
 
 
+FIXED_IDS = ("Ql", "Qr", "Qm", "Qo", "S1", "S2", "S3")     # circuit constants (with every Qcp<i>): pinned by ProvingKey
+PROOF_IDS = ("L", "R", "O", "Z", "Qk")                      # per proof (with every Pi2<i>)
+
+
+def _fill(a, names, polys, lagrange, n, keep):
+    low = {"L": "l", "R": "r", "O": "o", "Z": "z", "Ql": "ql", "Qr": "qr", "Qm": "qm", "Qo": "qo", "Qk": "qk", "S1": "s1", "S2": "s2", "S3": "s3"}
+    for k in names:
+        arr = as_u64(np.asarray(polys[k]).reshape(-1, 4), 4)
+        if arr.shape[0] != n:
+            raise ValueError(f"every polynomial must have {n} coefficients")
+        keep.append(arr)
+        setattr(a, low[k], arr.ctypes.data)
+    for nm in lagrange:
+        if nm in IDS:
+            a.lagrange_mask |= 1 << IDS.index(nm)
+        else:   # "Qcp<i>" / "Pi2<i>"
+            i = int(nm[3:])
+            a.lagrange_mask |= 1 << (len(IDS) + 2 * i + (0 if nm.startswith("Qcp") else 1))
+
+
+def _ptr_array(arrs, n, keep):
+    out = [as_u64(np.asarray(x).reshape(-1, 4), 4) for x in arrs]
+    for x in out:
+        if x.shape[0] != n:
+            raise ValueError(f"every polynomial must have {n} coefficients")
+    keep.extend(out)
+    pa = (C.c_void_p * len(out))(*[x.ctypes.data for x in out])
+    keep.append(pa)
+    return pa
+
+
+class ProvingKey:
+    """The circuit-constant half of the quotient pinned on the device (ga_plonk_pk_create): Ql, Qr, Qm, Qo, S1, S2, S3, Qcp_i
+    evaluated on every coset once -- the precomputation prove.go:1030-1034 rules out on a CPU for its memory footprint."""
+
+    def __init__(self, domain0: Domain, domain1: Domain, fixed: dict, qcp=(), lagrange=()):
+        self.d0, self.d1, self.nb_bsb = domain0, domain1, len(qcp)
+        lib = domain0.ctx.lib
+        keep = []
+        a = _lib.PlonkQuotientIn()
+        a.nb_bsb = len(qcp)
+        _fill(a, FIXED_IDS, fixed, lagrange, domain0.Cardinality, keep)
+        if qcp:
+            a.qcp = _ptr_array(qcp, domain0.Cardinality, keep)
+        h = C.c_void_p()
+        lib.check(lib.ga_plonk_pk_create(domain0.handle, domain1.handle, C.byref(a), C.byref(h)))
+        self.handle = h
+
+    def ComputeQuotient(self, polys: dict, pi2=(), *, bp: dict, alpha, beta, gamma, lagrange=()):
+        """s.h from the per-proof polynomials L, R, O, Z, Qk (and the BSB22 commitment polynomials): ga_plonk_quotient_pinned"""
+        lib = self.d0.ctx.lib
+        if len(pi2) != self.nb_bsb:
+            raise ValueError("one committed polynomial per Qcp")
+        keep = []
+        a = _lib.PlonkQuotientIn()
+        a.nb_bsb = self.nb_bsb
+        _fill(a, PROOF_IDS, polys, lagrange, self.d0.Cardinality, keep)
+        if pi2:
+            a.pi2 = _ptr_array(pi2, self.d0.Cardinality, keep)
+        for k, cnt in (("Bl", 2), ("Br", 2), ("Bo", 2), ("Bz", 3)):
+            v = as_u64(np.asarray(bp[k]).reshape(cnt, 4), 4)
+            keep.append(v)
+            setattr(a, k.lower(), v.ctypes.data)
+        for k, v in (("alpha", alpha), ("beta", beta), ("gamma", gamma)):
+            v = as_u64(np.asarray(v).reshape(1, 4), 4)
+            keep.append(v)
+            setattr(a, k, v.ctypes.data)
+        out = np.zeros((self.d1.Cardinality, 4), dtype=np.uint64)
+        lib.check(lib.ga_plonk_quotient_pinned(self.handle, C.byref(a), _ptr(out)))
+        return out
+
+    def close(self):
+        if self.handle:
+            self.d0.ctx.lib.ga_plonk_pk_destroy(self.handle)
+            self.handle = None
+
+
 def ComputeQuotient(domain0: Domain, domain1: Domain, polys: dict, qcp=(), pi2=(), *, bp: dict, alpha, beta, gamma, lagrange=()):
     """s.h = divideByZH(computeNumerator()).  polys: {id: (n, 4) fr images} for IDS, canonical coefficients unless the id is
     listed in `lagrange` (then evaluations on domain0, regular order; "Qcp<i>"/"Pi2<i>" name the BSB22 pairs);

@@ -154,6 +154,16 @@ typedef struct ga_plonk_quotient_in {
     uint32_t flags;
 } ga_plonk_quotient_in;
 int ga_plonk_quotient(ga_domain* domain0, ga_domain* domain1, const ga_plonk_quotient_in* in, void* h_out);
+/* The circuit-constant half of the quotient pinned in HBM -- the precomputation prove.go:1030-1034 rules out on a CPU ("we could
+ * pre-compute these rho*2 FFTs and store them at the cost of a huge memory footprint"): the evaluations of Ql, Qr, Qm, Qo, S1,
+ * S2, S3 and every Qcp_i on each of the rho cosets, plus 1/(x-1) on each coset: (8 + nb_bsb) * rho * n * 32 bytes (4.3 GB at
+ * n = 2^22).  ga_plonk_pk_create reads only ql, qr, qm, qo, s1, s2, s3, qcp, nb_bsb, lagrange_mask and flags of `in`;
+ * ga_plonk_quotient_pinned reads only l, r, o, z, qk, pi2, the blinding polynomials, the challenges, lagrange_mask and flags
+ * (6 + nb_bsb inverse/forward transform chains per proof instead of 12 + 2*nb_bsb).  The domains must outlive the key. */
+typedef struct ga_plonk_pk ga_plonk_pk;
+int ga_plonk_pk_create(ga_domain* domain0, ga_domain* domain1, const ga_plonk_quotient_in* in, ga_plonk_pk** out);
+void ga_plonk_pk_destroy(ga_plonk_pk* pk);
+int ga_plonk_quotient_pinned(ga_plonk_pk* pk, const ga_plonk_quotient_in* in, void* h_out);
 /* Z in Lagrange form, regular order (n elements): Z[0] = 1, Z[i+1] = Z[i] * prod_k (e_k[i] + beta*id_k(i) + gamma) /
  * prod_k (e_k[i] + beta*id(perm[k*n+i]) + gamma), id over {1, g, g^2} * w^i.  l, r, o: evaluations on domain0; permutation:
  * 3n int64 (s.trace.S). */

@@ -418,6 +418,14 @@ def test_emu_plonk_quotient(emu_ctx, c, n, nb_bsb, seed=11):
             pi = [pick(f"Pi2{i}", T["pi_can"][i], T["pi2"][i]) for i in range(nb_bsb)]
             got = plonk.ComputeQuotient(d0, d1, polys, qc, pi, lagrange=lagr, **kw)
             assert arr_to_fr(c, got) == want, lagr
+            # the same proof with the circuit constants pinned (ga_plonk_pk_create / ga_plonk_quotient_pinned), two proofs per key
+            ppk = plonk.ProvingKey(d0, d1, {k: polys[k] for k in plonk.FIXED_IDS}, qc, lagrange=[x for x in lagr if x in plonk.FIXED_IDS or x.startswith("Qcp")])
+            try:
+                for _ in range(2):
+                    got = ppk.ComputeQuotient({k: polys[k] for k in plonk.PROOF_IDS}, pi, lagrange=[x for x in lagr if x in plonk.PROOF_IDS or x.startswith("Pi2")], **kw)
+                    assert arr_to_fr(c, got) == want, ("pinned", lagr)
+            finally:
+                ppk.close()
     finally:
         d0.close()
         d1.close()
