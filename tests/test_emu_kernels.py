@@ -540,3 +540,32 @@ def test_emu_msm_vs_c_oracle_and_dlogs(emu_ctx, c, group, logn=11):
     assert np.array_equal(got2, want)
     for b in (bases, dlogs, scal):
         b.free()
+
+
+def test_emu_groth16_sharded_key_with_commitments(emu_ctx):
+    """base-range sharded key (multi-GPU partition B) on the circuit with BSB22 commitments: the K filter is sliced per shard;
+    summed partials + finish give the oracle's proof"""
+    c = BN254
+    rng = pyref.Xoshiro(99)
+    cs = pyref.commit_r1cs()
+    pk, _, _ = pyref.groth16_setup(c, cs, [rng.field(c.r) for _ in range(8)])
+    w = pyref.commit_solve(c, cs, 4, 9, lambda i, ww: pyref.commitment_hint(pk, cs, i, ww)[1])
+    r, s_ = rng.field(c.r), rng.field(c.r)
+    A, B, Cc = pyref.r1cs_solve(c, cs, w)
+    sol = groth16.Solution(W=fr_to_arr(c, w), A=fr_to_arr(c, A), B=fr_to_arr(c, B), C=fr_to_arr(c, Cc))
+    removed = sorted({j for cm in cs.commitments for j in cm.private_committed} | {cm.commitment_index for cm in cs.commitments})
+    kw = dict(domain_cardinality=pk.n, alpha1=pts_to_arr(c, 0, [pk.alpha1]), beta1=pts_to_arr(c, 0, [pk.beta1]),
+              delta1=pts_to_arr(c, 0, [pk.delta1]), A=pts_to_arr(c, 0, pk.A), B=pts_to_arr(c, 0, pk.B), Z=pts_to_arr(c, 0, pk.Z),
+              K=pts_to_arr(c, 0, pk.K), beta2=pts_to_arr(c, 1, [pk.beta2]), delta2=pts_to_arr(c, 1, [pk.delta2]),
+              B2=pts_to_arr(c, 1, pk.B2), infinityA=pk.infinityA, infinityB=pk.infinityB, k_remove=removed,
+              commitment_keys=[(pts_to_arr(c, 0, b), pts_to_arr(c, 0, e)) for b, e in pk.commitment_keys])
+    world, parts, keys = 2, [], []
+    for k in range(world):
+        dpk = groth16.ProvingKey(emu_ctx, c.name, shard=(k, world), **kw)
+        keys.append(dpk)
+        parts.append(groth16.ProvePartial(dpk, sol, cs.nb_public))
+    proof = groth16.Finish(keys[0], groth16.SumPartials(c.name, parts, lib=emu_ctx.lib), fr_to_arr(c, [r]), fr_to_arr(c, [s_]))
+    for dpk in keys:
+        dpk.FreeGPUResources()
+    ar, bs, krs, _, _ = pyref.groth16_prove_bsb22(pk, cs, w, r, s_)
+    assert (arr_to_g1_affine(c, proof.Ar), arr_to_g2_affine(c, proof.Bs), arr_to_g1_affine(c, proof.Krs)) == (ar, bs, krs)
