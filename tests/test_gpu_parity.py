@@ -147,6 +147,25 @@ def test_msm_2_24_bn254_g1_dlog(gpu_ctx):
         b.free()
 
 
+def test_msm_2_26_bn254_g1_table_and_raw_dlog(gpu_ctx):
+    """four times the headline size (2^26 points: 4 GiB of bases, a 48 GiB window table, 805 M (bucket, point) pairs): the
+    pinned-table MSM and the raw-bases MSM both equal [sum s_i k_i]G"""
+    c, group, n = BN254, 0, 1 << 26
+    bases, dlogs, scal = _device_inputs(gpu_ctx, c, group, n, 0x5EED0026)
+    S, K = scal.to_host((n, 4)), dlogs.to_host((n, 4))
+    want = _expect_from_dlogs(c, group, S, K)
+    raw = oracle.jac_to_affine(c.cid, group, ecc.MultiExp(gpu_ctx, c.name, group, bases, scal, n=n))
+    assert np.array_equal(raw, want)
+    table = ecc.PrecomputedBases(gpu_ctx, c.name, group, bases, n=n)
+    try:
+        got = oracle.jac_to_affine(c.cid, group, table.MultiExp(scal))
+    finally:
+        table.free()
+    assert np.array_equal(got, want)
+    for b in (bases, dlogs, scal):
+        b.free()
+
+
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
 def test_fft_2_16_vs_c_oracle(gpu_ctx, c):
     n = 1 << 16
