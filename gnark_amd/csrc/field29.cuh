@@ -86,6 +86,40 @@ GA_HD F29<P> f29_sub(const F29<P>& a, const F29<P>& b) {
     return r;
 }
 
+// limb-wise sum without the carry sweep (limbs grow by one bit; the consumer must tolerate it)
+template <class P>
+GA_HD F29<P> f29_add_raw(const F29<P>& a, const F29<P>& b) {
+    F29<P> r;
+#pragma unroll
+    for (int i = 0; i < F29<P>::NL; i++) r.l[i] = a.l[i] + b.l[i];
+    return r;
+}
+// a - b + K*p limb-wise without the carry sweep (b normalized, b < K*p)
+template <int K, class P>
+GA_HD F29<P> f29_sub_raw(const F29<P>& a, const F29<P>& b) {
+    F29<P> r;
+#pragma unroll
+    for (int i = 0; i < F29<P>::NL; i++) r.l[i] = a.l[i] + kp_limb<P, K>(i) - b.l[i];
+    return r;
+}
+// a - b + K*p where b is an UN-normalized sum with limbs below W*2^L (b < K*p as a value): every limb but the top lends
+// W*2^L to its lower neighbour, so no limb goes negative; one carry sweep at the end.  Lets sums like PPP + 2Q skip their own
+// sweeps.
+template <int K, int W, class P>
+GA_HD F29<P> f29_sub_wide(const F29<P>& a, const F29<P>& b) {
+    typedef Radix<P> R;
+    F29<P> r;
+#pragma unroll
+    for (int i = 0; i < R::NL; i++) {
+        uint32_t k = kp_limb<P, K>(i);   // = limb + 2^L (not top) - 1 (not bottom): widen the loan from 1 to W units
+        if (i < R::NL - 1) k += (uint32_t)(W - 1) << R::L;
+        if (i > 0) k -= (uint32_t)(W - 1);
+        r.l[i] = a.l[i] + k - b.l[i];
+    }
+    f29_normalize(r);
+    return r;
+}
+
 // a*b / 2^(NL*L) (+ a multiple of p): normalized limbs in, normalized limbs out; result < a*b/2^(NL*L) + p.
 // Default: column accumulators (the compiler keeps independent per-column MAD chains and merges the carries).
 // GA_F29_CHAINED=1 selects product scanning with ONE running accumulator kept opaque between columns (saves ~9 64-bit adds
@@ -336,6 +370,10 @@ struct F29x2 {
 template <class P> GA_HD F29x2<P> f29_add(const F29x2<P>& a, const F29x2<P>& b) { return {f29_add(a.c0, b.c0), f29_add(a.c1, b.c1)}; }
 template <int K, class P> GA_HD F29x2<P> f29_sub(const F29x2<P>& a, const F29x2<P>& b) {
     return {f29_sub<K>(a.c0, b.c0), f29_sub<K>(a.c1, b.c1)};
+}
+template <class P> GA_HD F29x2<P> f29_add_raw(const F29x2<P>& a, const F29x2<P>& b) { return {f29_add_raw(a.c0, b.c0), f29_add_raw(a.c1, b.c1)}; }
+template <int K, int W, class P> GA_HD F29x2<P> f29_sub_wide(const F29x2<P>& a, const F29x2<P>& b) {
+    return {f29_sub_wide<K, W>(a.c0, b.c0), f29_sub_wide<K, W>(a.c1, b.c1)};
 }
 template <class P> GA_HD F29x2<P> f29_partial_reduce(const F29x2<P>& a) { return {f29_partial_reduce(a.c0), f29_partial_reduce(a.c1)}; }
 template <class P> GA_HD bool f29_is_zero_limbs(const F29x2<P>& a) { return f29_is_zero_limbs(a.c0) & f29_is_zero_limbs(a.c1); }

@@ -328,9 +328,12 @@ __device__ __forceinline__ void madd29(const LdsAcc29<Fe<P>>& A, const F29<P>& q
     F29<P> PPP = f29_mul(Pp, PP);
     A.put(3, f29_mul(zzz, PPP));
     F29<P> Q = f29_mul(ax, PP);
-    F29<P> X3 = f29_sub<4>(f29_sqr(R), f29_add(PPP, f29_add(Q, Q)));
+    // X3 = R^2 - (PPP + 2Q): the sum stays un-normalized (limbs < 3*2^L) and is subtracted with a 4-unit loan: one carry
+    // sweep instead of three; t = Q - X3 + 8p also stays raw (limbs < 3*2^L): a 2^31-limb multiplicand keeps the two product
+    // columns of f29_mul_sub below 2^64
+    F29<P> X3 = f29_sub_wide<4, 4>(f29_sqr(R), f29_add_raw(PPP, f29_add_raw(Q, Q)));
     A.put(0, X3);
-    A.put(1, f29_mul_sub<8>(R, f29_sub<8>(Q, X3), ay, PPP));   // Y3 = R*(Q - X3) - Y1*PPP, one reduction
+    A.put(1, f29_mul_sub<8>(R, f29_sub_raw<8>(Q, X3), ay, PPP));   // Y3 = R*(Q - X3) - Y1*PPP, one reduction
 }
 
 template <class P>
@@ -349,7 +352,7 @@ __device__ __forceinline__ void madd29(const LdsAcc29<Fe2<P>>& A, const F29x2<P>
     T PPP = f29_mul(Pp, PP);
     A.put(3, f29_mul(zzz, PPP));
     T Q = f29_mul(ax, PP);
-    T X3 = f29_partial_reduce(f29_sub<4>(f29_sqr(R), f29_add(PPP, f29_add(Q, Q))));
+    T X3 = f29_partial_reduce(f29_sub_wide<4, 4>(f29_sqr(R), f29_add_raw(PPP, f29_add_raw(Q, Q))));
     A.put(0, X3);
     A.put(1, f29_mul_sub<P::FP2Z_K>(R, f29_sub<8>(Q, X3), ay, PPP));   // Y3 = R*(Q - X3) - Y1*PPP, two reductions instead of four
 }

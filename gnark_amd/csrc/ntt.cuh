@@ -263,21 +263,6 @@ ntt_pass29_kernel(uint32_t* data, const uint32_t* src, const uint32_t* __restric
 // barrier per TWO stages, three twiddle loads instead of four (both butterflies of the first stage share theirs; the second
 // stage uses w^e and w^(e + n/4)), and the intermediate values are not carry-normalised: limb-wise sums stay below 2^32 and a
 // 2^31-limb multiplicand still keeps the product columns below 2^64.  An odd stage count ends with one plain radix-2 stage.
-template <class P>
-GA_HD F29<P> f29_add_raw(const F29<P>& a, const F29<P>& b) {   // limb-wise, no carry sweep
-    F29<P> r;
-#pragma unroll
-    for (int i = 0; i < F29<P>::NL; i++) r.l[i] = a.l[i] + b.l[i];
-    return r;
-}
-template <int K, class P>
-GA_HD F29<P> f29_sub_raw(const F29<P>& a, const F29<P>& b) {   // a - b + K*p limb-wise, b normalised, no carry sweep
-    F29<P> r;
-#pragma unroll
-    for (int i = 0; i < F29<P>::NL; i++) r.l[i] = a.l[i] + kp_limb<P, K>(i) - b.l[i];
-    return r;
-}
-
 template <class FrP, bool DIT_>
 __global__ void __launch_bounds__(NTT_THREADS)
 ntt_pass29r4_kernel(uint32_t* data, const uint32_t* src, const uint32_t* __restrict__ tw, int logn, int lg_tile, int s_lo, int K,

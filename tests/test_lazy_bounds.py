@@ -22,7 +22,7 @@ def test_constants_match_the_kernels():
     src = open(os.path.join(ROOT, "gnark_amd", "csrc", "msm.cuh")).read()
     g1 = src[src.index("__device__ __forceinline__ void madd29(const LdsAcc29<Fe<P>>"):src.index("__device__ __forceinline__ void madd29(const LdsAcc29<Fe2<P>>")]
     g2 = src[src.index("__device__ __forceinline__ void madd29(const LdsAcc29<Fe2<P>>"):src.index("msm_accumulate29_kernel(")]
-    subs = lambda s: [int(x) for x in re.findall(r"f29_sub<(\d+)>", s)]
+    subs = lambda s: [int(x) for x in re.findall(r"f29_sub(?:_wide|_raw)?<(\d+)", s)]   # K of every subtraction flavour
     k = lazy_bounds.G1
     assert subs(g1) == [k["Kx"], k["Ky"], k["K3"], k["Kq"]]
     assert "f29_mul_sub<8>(" in g1            # Y3: negation constant checked in lazy_bounds.check (Kms)
