@@ -102,6 +102,7 @@ _PROTOS = {
     "ga_hash_to_field": (C.c_int, [C.c_int, _P, C.c_size_t, _P, C.c_size_t, C.c_uint32, _P]),
     "ga_expand_message_xmd": (C.c_int, [_P, C.c_size_t, _P, C.c_size_t, C.c_size_t, _P]),
     "ga_g16_proof_marshal_bsb22": (C.c_int, [C.c_int, _P, _P, C.c_uint32, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "ga_g16_proof_marshal_raw": (C.c_int, [C.c_int, _P, _P, C.c_uint32, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "ga_g1_marshal_uncompressed": (C.c_int, [C.c_int, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "ga_profile_enable": (C.c_int, [_P, C.c_int]),
     "ga_profile_reset": (C.c_int, [_P]),

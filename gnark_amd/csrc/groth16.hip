@@ -535,30 +535,67 @@ static size_t compress_g2(const void* aff, uint8_t* out) {
     return 2 * nb;
 }
 
+// uncompressed encodings (curve.RawEncoding(), Proof.WriteRawTo marshal.go:25-30): x | y big-endian, G2 coordinates A1 | A0;
+// infinity = flag byte 0x40 followed by zeros
 template <class C>
-static int marshal(const void* proof, const void* commitments, uint32_t ncom, const void* pok, uint8_t* out, size_t cap, size_t* len) {
+static size_t raw_g1(const void* aff, uint8_t* out) {
+    typedef typename C::FpP P;
+    Affine<Fe<P>> a;
+    memcpy(&a, aff, sizeof(a));
+    const size_t nb = P::N * 4;
+    memset(out, 0, 2 * nb);
+    if (is_inf(a)) {
+        out[0] = 0x40;
+        return 2 * nb;
+    }
+    be_bytes<P>(a.x, out);
+    be_bytes<P>(a.y, out + nb);
+    return 2 * nb;
+}
+template <class C>
+static size_t raw_g2(const void* aff, uint8_t* out) {
+    typedef typename C::FpP P;
+    Affine<Fe2<P>> a;
+    memcpy(&a, aff, sizeof(a));
+    const size_t nb = P::N * 4;
+    memset(out, 0, 4 * nb);
+    if (is_inf(a)) {
+        out[0] = 0x40;
+        return 4 * nb;
+    }
+    be_bytes<P>(a.x.c1, out);
+    be_bytes<P>(a.x.c0, out + nb);
+    be_bytes<P>(a.y.c1, out + 2 * nb);
+    be_bytes<P>(a.y.c0, out + 3 * nb);
+    return 4 * nb;
+}
+
+template <class C>
+static int marshal(const void* proof, const void* commitments, uint32_t ncom, const void* pok, uint8_t* out, size_t cap, size_t* len,
+                   bool raw = false) {
     typedef Fe<typename C::FpP> F1;
     typedef Fe2<typename C::FpP> F2;
     const size_t nb = C::FpP::N * 4;
-    const size_t need = nb + 2 * nb + nb + 4 + (size_t)ncom * nb + nb;
+    const size_t need = (raw ? 2 : 1) * (nb + 2 * nb + nb + (size_t)ncom * nb + nb) + 4;
     if (cap < need) {
         set_error("proof marshal: buffer too small (%zu < %zu)", cap, need);
         return GA_ERR_INVALID;
     }
     const char* p = reinterpret_cast<const char*>(proof);
     size_t o = 0;
-    o += compress_g1<C>(p, out + o);
-    o += compress_g2<C>(p + sizeof(Affine<F1>), out + o);
-    o += compress_g1<C>(p + sizeof(Affine<F1>) + sizeof(Affine<F2>), out + o);
+    auto g1 = [&](const void* a, uint8_t* dst) { return raw ? raw_g1<C>(a, dst) : compress_g1<C>(a, dst); };
+    o += g1(p, out + o);
+    o += raw ? raw_g2<C>(p + sizeof(Affine<F1>), out + o) : compress_g2<C>(p + sizeof(Affine<F1>), out + o);
+    o += g1(p + sizeof(Affine<F1>) + sizeof(Affine<F2>), out + o);
     out[o] = ncom >> 24;   // uint32 big-endian number of commitments (the slice encoder's length prefix)
     out[o + 1] = ncom >> 16;
     out[o + 2] = ncom >> 8;
     out[o + 3] = ncom;
     o += 4;
-    for (uint32_t i = 0; i < ncom; i++) o += compress_g1<C>((const char*)commitments + i * sizeof(Affine<F1>), out + o);
+    for (uint32_t i = 0; i < ncom; i++) o += g1((const char*)commitments + i * sizeof(Affine<F1>), out + o);
     Affine<F1> inf;
     memset(&inf, 0, sizeof(inf));
-    o += compress_g1<C>(pok ? pok : &inf, out + o);   // CommitmentPok (infinity without commitments)
+    o += g1(pok ? pok : &inf, out + o);   // CommitmentPok (infinity without commitments)
     *len = o;
     return GA_OK;
 }
@@ -670,6 +707,16 @@ int ga_g16_proof_marshal_bsb22(int curve, const void* proof, const void* commitm
         return GA_ERR_INVALID;
     }
     GA_DISPATCH_CURVE(curve, return marshal<C>(proof, commitments, n, pok, out, cap, len));
+    return GA_OK;
+}
+
+int ga_g16_proof_marshal_raw(int curve, const void* proof, const void* commitments, uint32_t n, const void* pok, uint8_t* out,
+                             size_t cap, size_t* len) {
+    if (!proof || !out || !len || (n && !commitments)) {
+        set_error("ga_g16_proof_marshal_raw: null argument");
+        return GA_ERR_INVALID;
+    }
+    GA_DISPATCH_CURVE(curve, return marshal<C>(proof, commitments, n, pok, out, cap, len, true));
     return GA_OK;
 }
 

@@ -55,6 +55,21 @@ class Proof:
         return out[: n.value].tobytes()
 
 
+    def WriteRawTo(self) -> bytes:
+        """Proof.WriteRawTo (marshal.go:25-30): uncompressed points."""
+        lib = self._lib or _lib.load()
+        raw = self.raw()
+        fp = FP_LIMBS[self.curve]
+        ncom = 0 if self.Commitments is None else len(self.Commitments)
+        com = as_u64(np.asarray(self.Commitments).reshape(-1, 2 * fp), 2 * fp) if ncom else None
+        pok = as_u64(np.asarray(self.CommitmentPok).reshape(1, 2 * fp), 2 * fp) if self.CommitmentPok is not None else None
+        out = np.zeros(1024 + 128 * ncom, dtype=np.uint8)
+        n = C.c_size_t()
+        lib.check(lib.ga_g16_proof_marshal_raw(self.curve, _ptr(raw), _ptr(com) if ncom else None, ncom,
+                                               _ptr(pok) if pok is not None else None, _ptr(out), out.nbytes, C.byref(n)))
+        return out[: n.value].tobytes()
+
+
 class ProvingKey:
     """setup.go:25-48 fields, uploaded once ("PinToGPU"); free with FreeGPUResources() (icicle.go:1493)."""
 

@@ -254,6 +254,9 @@ int ga_expand_message_xmd(const uint8_t* msg, size_t msg_len, const uint8_t* dst
  * commitments: n G1Affine (may be NULL when n = 0), pok: G1Affine or NULL (= infinity). */
 int ga_g16_proof_marshal_bsb22(int curve, const void* proof, const void* commitments, uint32_t n, const void* pok,
                                uint8_t* out, size_t cap, size_t* len);
+/* Proof.WriteRawTo (marshal.go:25-30): the same layout with uncompressed points (G1 x | y, G2 x.A1 | x.A0 | y.A1 | y.A0). */
+int ga_g16_proof_marshal_raw(int curve, const void* proof, const void* commitments, uint32_t n, const void* pok,
+                             uint8_t* out, size_t cap, size_t* len);
 /* G1Affine.Marshal() (uncompressed big-endian x | y; what SerializeCommitment hashes, constraint/commitment.go:76-89,
  * prove.go:88).  out: 64 bytes (BN254) / 96 bytes (BLS12-381). */
 int ga_g1_marshal_uncompressed(int curve, const void* affine, uint8_t* out, size_t cap, size_t* len);

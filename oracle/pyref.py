@@ -913,6 +913,22 @@ def proof_bytes(c: Curve, ar, bs, krs, commitments=(), pok=None) -> bytes:
             + b"".join(g1_compress(c, P) for P in commitments) + g1_compress(c, pok))
 
 
+def g2_marshal_uncompressed(c: Curve, P) -> bytes:
+    """G2Affine.RawBytes [EXT]: x.A1 | x.A0 | y.A1 | y.A0 big-endian; infinity = 0x40 then zeros."""
+    nb = c.fp_bytes
+    if P is None:
+        return bytes([0x40]) + bytes(4 * nb - 1)
+    (x0, x1), (y0, y1) = P
+    return b"".join(v.to_bytes(nb, "big") for v in (x1, x0, y1, y0))
+
+
+def proof_bytes_raw(c: Curve, ar, bs, krs, commitments=(), pok=None) -> bytes:
+    """Proof.WriteRawTo, marshal.go:25-30: the WriteTo layout with uncompressed points."""
+    return (g1_marshal_uncompressed(c, ar) + g2_marshal_uncompressed(c, bs) + g1_marshal_uncompressed(c, krs)
+            + len(commitments).to_bytes(4, "big") + b"".join(g1_marshal_uncompressed(c, P) for P in commitments)
+            + g1_marshal_uncompressed(c, pok))
+
+
 def sha_tag(*parts) -> str:
     h = hashlib.sha256()
     for p in parts:

@@ -287,6 +287,7 @@ def test_emu_groth16_cubic(emu_ctx, c, precompute):
     assert arr_to_g2_affine(c, proof.Bs) == bs
     assert arr_to_g1_affine(c, proof.Krs) == krs
     assert proof.WriteTo() == pyref.proof_bytes(c, ar, bs, krs)
+    assert proof.WriteRawTo() == pyref.proof_bytes_raw(c, ar, bs, krs)
 
 
 def _xmd_vectors():
@@ -369,6 +370,7 @@ def test_emu_groth16_bsb22_commitments(emu_ctx, c, precompute):
     assert arr_to_g1_affine(c, proof.CommitmentPok) == opok
     assert (arr_to_g1_affine(c, proof.Ar), arr_to_g2_affine(c, proof.Bs), arr_to_g1_affine(c, proof.Krs)) == (ar, bs, krs)
     assert proof.WriteTo() == pyref.proof_bytes(c, ar, bs, krs, ocoms, opok)
+    assert proof.WriteRawTo() == pyref.proof_bytes_raw(c, ar, bs, krs, ocoms, opok)
     # pedersen verification in the exponent: pok_i = [sigma_i] commitment_i, folded with the challenge powers
     G1 = group_of(c, 0)
     sig = toxic[5:7]
