@@ -722,6 +722,126 @@ int oracle_fft(int curve, u64* a, u64 n, int direction, int decimation, int on_c
     return 0;
 }
 
+/* ---------------- PLONK quotient: computeNumerator + divideByZH (backend/plonk/bn254/prove.go:841-1123,1287-1350) ----------
+ * polys: np = 12 + 2*nb_bsb canonical coefficient vectors of n elements each, order L R O Z Ql Qr Qm Qo Qk S1 S2 S3
+ * (Qcp_i, Pi2_i)...; bl/br/bo: 2 coefficients, bz: 3; everything Montgomery.  h_out: rho*n canonical coefficients.
+ * Structure follows the reference: for each coset g*w1^i scale the coefficients, FFT on the small domain (:1033-1058), apply
+ * allConstraints pointwise (:950-981), place at the bit-reversed slot (:1073); then divideByZH's factor and the inverse coset
+ * transform on the big domain (:1311-1319). */
+int oracle_plonk_quotient(int curve, u64 n, int nb_bsb, const u64* const* polys, const u64* bl, const u64* br, const u64* bo,
+                          const u64* bz, const u64* alpha, const u64* beta, const u64* gamma, u64* h_out) {
+    const curve_t* cv = &CURVES[curve];
+    const field_t* f = &cv->fr;
+    const u64 rho = n < 6 ? 8 : 4, N = rho * n;
+    const int logn = ilog2(n), logN = ilog2(N), np = 12 + 2 * nb_bsb;
+    if (((u64)1 << logn) != n || n < 2) return -1;
+    u64 w0[4], w1[4], cs[4], css[4], ninv[4], two[4], one[4];
+    fe_copy(f, one, f->one);
+    root_of_unity(cv, n, 0, w0);
+    root_of_unity(cv, N, 0, w1);
+    fe_copy(f, cs, cv->fr_gen);
+    fe_mul(f, css, cs, cs);
+    fe_add(f, two, one, one);
+    fe_inv(f, two, two);
+    fe_copy(f, ninv, one);
+    for (int k = 0; k < logn; k++) fe_mul(f, ninv, ninv, two);
+    u64* tw = (u64*)malloc(32 * n);         /* twiddles0: w0^j */
+    fe_copy(f, tw, one);
+    for (u64 j = 1; j < n; j++) fe_mul(f, tw + 4 * j, tw + 4 * (j - 1), w0);
+    u64* ev = (u64*)malloc(32 * n * (size_t)np);
+    u64* den = (u64*)malloc(32 * n);
+    u64* pre = (u64*)malloc(32 * n);
+    u64* cres = (u64*)malloc(32 * N);
+    u64 coset[4];
+    fe_copy(f, coset, one);
+    for (u64 i = 0; i < rho; i++) {
+        fe_mul(f, coset, coset, i == 0 ? cv->fr_gen : w1);           /* shifters, :936-941,998 */
+        u64 cexp[4], e[1] = {n};
+        fe_pow(f, cexp, coset, e, 1);
+        fe_sub(f, cexp, cexp, one);                                  /* coset^n - 1, :999-1000 */
+        /* evaluations of every polynomial on coset*H, natural order: scale by coset^k, DIF, undo the bit reversal */
+        for (int p = 0; p < np; p++) {
+            u64* dst = ev + 4 * n * (size_t)p;
+            u64 acc[4];
+            fe_copy(f, acc, one);
+            for (u64 k = 0; k < n; k++) {
+                fe_mul(f, pre + 4 * k, polys[p] + 4 * k, acc);
+                fe_mul(f, acc, acc, coset);
+            }
+            if (oracle_fft(curve, pre, n, 0, 0, 0) != 0) return -1;
+            for (u64 k = 0; k < n; k++) fe_copy(f, dst + 4 * bitrev_u64(k, logn), pre + 4 * k);
+        }
+        /* 1/(x_j - 1) by Montgomery's trick (batchInvert, :1134-1147) */
+        for (u64 j = 0; j < n; j++) {
+            fe_mul(f, den + 4 * j, coset, tw + 4 * j);
+            fe_sub(f, den + 4 * j, den + 4 * j, one);
+        }
+        fe_copy(f, pre, den);
+        for (u64 j = 1; j < n; j++) fe_mul(f, pre + 4 * j, pre + 4 * (j - 1), den + 4 * j);
+        u64 inv[4];
+        fe_inv(f, inv, pre + 4 * (n - 1));
+        for (u64 j = n - 1; j > 0; j--) {
+            u64 t[4];
+            fe_mul(f, t, inv, pre + 4 * (j - 1));
+            fe_mul(f, inv, inv, den + 4 * j);
+            fe_copy(f, den + 4 * j, t);
+        }
+        fe_copy(f, den, inv);
+        u64 zhinv[4];
+        fe_inv(f, zhinv, cexp);                                      /* evaluateXnMinusOneDomainBigCoset, :1327-1350 */
+        for (u64 j = 0; j < n; j++) {
+#define EV(p, idx) (ev + 4 * n * (size_t)(p) + 4 * (idx))
+            u64 x[4], xw[4], t[4], u[4], l[4], r[4], o[4], z[4], zs[4];
+            fe_mul(f, x, coset, tw + 4 * j);
+            fe_mul(f, xw, x, w0);
+            /* blinded wires: p + b(x) * (coset^n - 1)  (:957-973; the reference pre-scales the blinding coefficients) */
+            fe_mul(f, t, bl + 4, x); fe_add(f, t, t, bl); fe_mul(f, t, t, cexp); fe_add(f, l, EV(0, j), t);
+            fe_mul(f, t, br + 4, x); fe_add(f, t, t, br); fe_mul(f, t, t, cexp); fe_add(f, r, EV(1, j), t);
+            fe_mul(f, t, bo + 4, x); fe_add(f, t, t, bo); fe_mul(f, t, t, cexp); fe_add(f, o, EV(2, j), t);
+            fe_mul(f, t, bz + 8, x); fe_add(f, t, t, bz + 4); fe_mul(f, t, t, x); fe_add(f, t, t, bz); fe_mul(f, t, t, cexp);
+            fe_add(f, z, EV(3, j), t);
+            fe_mul(f, t, bz + 8, xw); fe_add(f, t, t, bz + 4); fe_mul(f, t, t, xw); fe_add(f, t, t, bz); fe_mul(f, t, t, cexp);
+            fe_add(f, zs, EV(3, (j + 1) % n), t);
+            /* gate (:868-885) */
+            u64 gate[4];
+            fe_mul(f, gate, EV(4, j), l);
+            fe_mul(f, t, EV(5, j), r); fe_add(f, gate, gate, t);
+            fe_mul(f, t, EV(6, j), l); fe_mul(f, t, t, r); fe_add(f, gate, gate, t);
+            fe_mul(f, t, EV(7, j), o); fe_add(f, gate, gate, t);
+            fe_add(f, gate, gate, EV(8, j));
+            for (int k = 0; k < nb_bsb; k++) {
+                fe_mul(f, t, EV(12 + 2 * k, j), EV(13 + 2 * k, j));
+                fe_add(f, gate, gate, t);
+            }
+            /* ordering (:898-923) */
+            u64 id[4], a[4], b[4], c[4], rr[4], ll[4];
+            fe_mul(f, id, x, beta);
+            fe_add(f, a, gamma, l); fe_add(f, a, a, id);
+            fe_mul(f, b, id, cs); fe_add(f, b, b, r); fe_add(f, b, b, gamma);
+            fe_mul(f, c, id, css); fe_add(f, c, c, o); fe_add(f, c, c, gamma);
+            fe_mul(f, rr, a, b); fe_mul(f, rr, rr, c); fe_mul(f, rr, rr, z);
+            fe_mul(f, a, EV(9, j), beta); fe_add(f, a, a, l); fe_add(f, a, a, gamma);
+            fe_mul(f, b, EV(10, j), beta); fe_add(f, b, b, r); fe_add(f, b, b, gamma);
+            fe_mul(f, c, EV(11, j), beta); fe_add(f, c, c, o); fe_add(f, c, c, gamma);
+            fe_mul(f, ll, a, b); fe_mul(f, ll, ll, c); fe_mul(f, ll, ll, zs);
+            fe_sub(f, ll, ll, rr);
+            /* local (:926-934, :380-385) */
+            fe_mul(f, t, cexp, ninv); fe_mul(f, t, t, den + 4 * j);
+            fe_sub(f, u, z, one); fe_mul(f, u, u, t);
+            /* ((local*alpha) + ordering)*alpha + gate, times 1/(x^n - 1) on this coset */
+            fe_mul(f, u, u, alpha); fe_add(f, u, u, ll); fe_mul(f, u, u, alpha); fe_add(f, u, u, gate);
+            fe_mul(f, u, u, zhinv);
+            fe_copy(f, cres + 4 * bitrev_u64(rho * j + i, logN), u);   /* :1073 */
+#undef EV
+        }
+    }
+    /* a.ToCanonical(bigDomain).ToRegular() from LagrangeCoset / BitReverse (:1319): inverse DIT on the coset */
+    int rc = oracle_fft(curve, cres, N, 1, 1, 1);
+    memcpy(h_out, cres, 32 * N);
+    free(tw); free(ev); free(den); free(pre); free(cres);
+    return rc;
+}
+
 /* computeH, prove.go:346-389.  a,b,c: m elements; h_out: n elements (bit-reversed coefficient order). */
 int oracle_compute_h(int curve, const u64* a, const u64* b, const u64* c, u64 m, u64 n, u64* h_out) {
     const curve_t* cv = &CURVES[curve];

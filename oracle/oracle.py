@@ -132,6 +132,19 @@ def fft(curve, a, direction, decimation, on_coset):
     return out
 
 
+def plonk_quotient(curve, n, polys, bl, br, bo, bz, alpha, beta, gamma, nb_bsb=0):
+    """computeNumerator + divideByZH on canonical coefficient vectors (order L R O Z Ql Qr Qm Qo Qk S1 S2 S3, then Qcp_i, Pi2_i)"""
+    arrs = [_u64(x).reshape(-1, 4) for x in polys]
+    assert len(arrs) == 12 + 2 * nb_bsb and all(a.shape[0] == n for a in arrs)
+    ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+    rho = 8 if n < 6 else 4
+    out = np.zeros((rho * n, 4), dtype=np.uint64)
+    small = [_u64(x).reshape(-1, 4) for x in (bl, br, bo, bz, alpha, beta, gamma)]
+    rc = dll().oracle_plonk_quotient(curve, C.c_uint64(n), nb_bsb, ptrs, *[_p(x) for x in small], _p(out))
+    assert rc == 0
+    return out
+
+
 def compute_h(curve, a, b, c, n):
     a, b, c = (_u64(x).reshape(-1, 4) for x in (a, b, c))
     out = np.zeros((n, 4), dtype=np.uint64)

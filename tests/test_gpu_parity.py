@@ -298,6 +298,41 @@ def test_plonk_build_z_and_batch_invert(gpu_ctx, c, n):
     cases.test_emu_plonk_build_z_and_batch_invert(gpu_ctx, c, n)
 
 
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_plonk_quotient_2_14_vs_c_oracle(gpu_ctx, c):
+    """n = 2^14 (big domain 2^16: multi-pass transforms), random polynomials (the quotient map is defined for any input), one
+    BSB22 gate: every one of the 65536 coefficients of h equals the C oracle's, for the plain call and for the pinned key"""
+    from gnark_amd import plonk
+    n, lib = 1 << 14, gpu_ctx.lib
+
+    def scal(count, seed):
+        buf = gpu_ctx.malloc(count * 32)
+        lib.check(lib.ga_gen_scalars(gpu_ctx.handle, c.cid, seed, count, buf.ptr))
+        h = buf.to_host((count, 4))
+        buf.free()
+        return h
+    names = list(plonk.IDS) + ["Qcp0", "Pi20"]
+    P = {k: scal(n, 700 + i) for i, k in enumerate(names)}
+    small = scal(12, 999)
+    bp = {"Bl": small[0:2], "Br": small[2:4], "Bo": small[4:6], "Bz": small[6:9]}
+    alpha, beta, gamma = small[9:10], small[10:11], small[11:12]
+    want = oracle.plonk_quotient(c.cid, n, [P[k] for k in names], bp["Bl"], bp["Br"], bp["Bo"], bp["Bz"], alpha, beta, gamma, 1)
+    d0, d1 = fft.Domain(gpu_ctx, c.name, n), fft.Domain(gpu_ctx, c.name, 4 * n)
+    try:
+        kw = dict(bp=bp, alpha=alpha, beta=beta, gamma=gamma)
+        got = plonk.ComputeQuotient(d0, d1, {k: P[k] for k in plonk.IDS}, [P["Qcp0"]], [P["Pi20"]], **kw)
+        assert np.array_equal(got, want)
+        ppk = plonk.ProvingKey(d0, d1, {k: P[k] for k in plonk.FIXED_IDS}, [P["Qcp0"]])
+        try:
+            got = ppk.ComputeQuotient({k: P[k] for k in plonk.PROOF_IDS}, [P["Pi20"]], **kw)
+        finally:
+            ppk.close()
+        assert np.array_equal(got, want)
+    finally:
+        d0.close()
+        d1.close()
+
+
 def test_plonk_quotient_2_16_identity(gpu_ctx):
     """n = 2^16 (4n = 2^18: multi-pass transforms): a satisfying synthetic trace built with the C oracle's FFT, Z from the device
     grand product (checked against a Python prefix product at sampled positions and to close), then

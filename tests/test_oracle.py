@@ -122,3 +122,28 @@ def test_groth16_cubic_matches_python_and_dlog(c):
         for wi, k in cs.O[i].items(): Cv[wi] = (Cv[wi] + k * lag[i]) % mod
     pub = sum(w[i] * (beta * Av[i] + alpha * Bv[i] + Cv[i]) for i in range(cs.nb_public)) % mod
     assert a_dl * b_dl % mod == (alpha * beta + pub + krs_dl * delta) % mod
+
+
+@pytest.mark.parametrize("c", [BN254, BLS12_381], ids=lambda c: c.name)
+def test_c_oracle_plonk_quotient_matches_python(c):
+    """oracle.c's computeNumerator + divideByZH (the checker used at 2^14 on the GPU) == pyref's restatement, coefficient for
+    coefficient, on a satisfying trace and on random polynomials"""
+    mod = c.r
+    for n, nb, satisfying in ((8, 1, True), (64, 2, True), (32, 0, False)):
+        lag, qcp, pi2, perm, rng = pyref.plonk_synthetic_instance(c, n, 17 + n, nb)
+        beta, gamma, alpha = rng.field(mod), rng.field(mod), rng.field(mod)
+        lag["Z"] = pyref.plonk_build_z(c, n, lag["L"], lag["R"], lag["O"], perm, beta, gamma)
+        if not satisfying:
+            lag = {k: [rng.field(mod) for _ in range(n)] for k in lag}
+        w0, ninv = c.fr_root_of_unity(n), pow(n, -1, mod)
+        can = lambda v: [x * ninv % mod for x in pyref._ntt_natural(v, pow(w0, -1, mod), mod)]
+        x = {k: can(v) for k, v in lag.items()}
+        qc, pi = [can(v) for v in qcp], [can(v) for v in pi2]
+        bp = {k: [rng.field(mod) for _ in range(3 if k == "Bz" else 2)] for k in ("Bl", "Br", "Bo", "Bz")}
+        want = pyref.plonk_quotient(c, n, x, qc, pi, bp, alpha, beta, gamma)
+        polys = [fr_to_arr(c, x[k]) for k in pyref.PLONK_IDS]
+        for a, b in zip(qc, pi):
+            polys += [fr_to_arr(c, a), fr_to_arr(c, b)]
+        got = oracle.plonk_quotient(c.cid, n, polys, fr_to_arr(c, bp["Bl"]), fr_to_arr(c, bp["Br"]), fr_to_arr(c, bp["Bo"]),
+                                    fr_to_arr(c, bp["Bz"]), fr_to_arr(c, [alpha]), fr_to_arr(c, [beta]), fr_to_arr(c, [gamma]), nb)
+        assert arr_to_fr(c, got) == want
