@@ -364,6 +364,35 @@ int ga_msm_table_run(ga_msm_table* th, const void* scalars, unsigned flags, void
     return GA_OK;
 }
 
+// kzg.Open(p, point, pk): claimed value p(point) and the commitment to (p(X) - p(point)) / (X - point) over the pinned SRS
+int ga_kzg_open(ga_msm_table* th, const void* poly, size_t n, unsigned flags, const void* point, void* claimed_value_out, void* h_out) {
+    MsmTable* t = reinterpret_cast<MsmTable*>(th);
+    if (!t || !poly || !point || !claimed_value_out || !h_out || n == 0) {
+        set_error("ga_kzg_open: null argument or empty polynomial");
+        return GA_ERR_INVALID;
+    }
+    if (t->group != GA_G1 || n - 1 > t->n) {
+        set_error("ga_kzg_open: the SRS table must be G1 and hold at least len(p) - 1 = %zu points (it has %zu)", n - 1, t->n);
+        return GA_ERR_INVALID;
+    }
+    Ctx* c = t->ctx;
+    Lock l(c);
+    GA_DISPATCH_CURVE(t->curve, {
+        typedef typename GroupField<C, GA_G1>::F F;
+        Staged sp{c};
+        GA_CHECK(sp.stage(poly, n * 32, flags & GA_SCALARS_ON_DEVICE));
+        const size_t qn = n > t->n ? n : t->n;
+        void* q;
+        GA_CHECK(c->scratch_get("kzg_quotient", qn * 32, &q));
+        GA_HIP_CHECK(hipMemsetAsync(q, 0, qn * 32, c->stream));
+        GA_CHECK(kzg_domain_divide<C>(c, sp.dev, n, point, q, claimed_value_out));
+        XYZZ<F> sum;
+        GA_CHECK((msm_table_device<C, GA_G1>(c, t->d_table, q, t->n, true, t->c, &sum)));
+        host_store_jac<F>(h_out, sum);
+    });
+    return GA_OK;
+}
+
 // ---- host group helpers ---------------------------------------------------------------------------------
 int ga_jac_add(int curve, int group, const void* a, const void* b, void* out) {
     GA_DISPATCH_CURVE(curve, GA_DISPATCH_GROUP(group, {

@@ -459,6 +459,111 @@ inline void plonk_fixed_destroy(PlonkFixed* fx) {
     delete fx;
 }
 
+// ---- kzg.Open: p(z) and the coefficients of (p(X) - p(z)) / (X - z) -----------------------------------------------------
+// gnark-crypto's dividePolyByXminusA is a sequential Horner recurrence q_{k-1} = p_k + z*q_k (call sites
+// backend/plonk/bn254/prove.go:681,788,827).  Unrolled, q_k = z^-(k+1) * sum_{j>k} p_j z^j: an element-wise scaling by z^j, a
+// suffix SUM (field additions only, three-phase scan) and an element-wise scaling by z^-(k+1); p(z) is the total sum.
+template <class FrP>
+__global__ void kzg_scale_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, const uint32_t* __restrict__ lo,
+                                 const uint32_t* __restrict__ hi, int lo_bits, uint64_t n, uint64_t shift) {
+    // out[i] = in[i + shift] * pow(i + shift)  (pow from the two-level table), i < n
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    store_fe(out + i * 8, mul(load_fe<FrP>(in + (i + shift) * 8), plonk_point<FrP>(lo, hi, lo_bits, i + shift)));
+}
+constexpr int SUM_CHUNK = 256;
+template <class FrP>
+__global__ void fr_chunk_sum_kernel(const uint32_t* __restrict__ t, uint32_t* __restrict__ chunk_sum, uint64_t n) {
+    uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t lo = c * SUM_CHUNK;
+    if (lo >= n) return;
+    uint64_t hi = lo + SUM_CHUNK < n ? lo + SUM_CHUNK : n;
+    Fe<FrP> acc = fe_zero<FrP>();
+    for (uint64_t i = lo; i < hi; i++) acc = add(acc, load_fe<FrP>(t + i * 8));
+    store_fe(chunk_sum + c * 8, acc);
+}
+template <class FrP>
+__global__ void __launch_bounds__(256) fr_chunk_suffix_scan_kernel(uint32_t* __restrict__ chunk_sum, uint64_t nchunks) {
+    // chunk_sum[c] <- sum of the chunks AFTER c (exclusive suffix sum); one block, segment per thread + LDS scan
+    __shared__ uint32_t sh[256 * 8];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t seg = (nchunks + 255) / 256;
+    const uint64_t lo = (uint64_t)tid * seg < nchunks ? (uint64_t)tid * seg : nchunks;
+    const uint64_t hi = lo + seg < nchunks ? lo + seg : nchunks;
+    Fe<FrP> acc = fe_zero<FrP>();
+    for (uint64_t c = lo; c < hi; c++) acc = add(acc, load_fe<FrP>(chunk_sum + c * 8));
+    store_fe(sh + tid * 8, acc);
+    __syncthreads();
+    for (uint32_t off = 1; off < 256; off <<= 1) {   // inclusive suffix scan over the 256 segment sums
+        Fe<FrP> v = load_fe<FrP>(sh + tid * 8);
+        if (tid + off < 256) v = add(v, load_fe<FrP>(sh + (tid + off) * 8));
+        __syncthreads();
+        store_fe(sh + tid * 8, v);
+        __syncthreads();
+    }
+    acc = tid + 1 < 256 ? load_fe<FrP>(sh + (tid + 1) * 8) : fe_zero<FrP>();   // everything after this thread's segment
+    for (uint64_t c = hi; c-- > lo;) {
+        Fe<FrP> v = load_fe<FrP>(chunk_sum + c * 8);
+        store_fe(chunk_sum + c * 8, acc);
+        acc = add(acc, v);
+    }
+}
+template <class FrP>
+__global__ void fr_chunk_suffix_apply_kernel(uint32_t* __restrict__ t, const uint32_t* __restrict__ chunk_after, uint64_t n) {
+    // t[i] <- sum_{j >= i} t[j]  (inclusive suffix sum)
+    uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t lo = c * SUM_CHUNK;
+    if (lo >= n) return;
+    uint64_t hi = lo + SUM_CHUNK < n ? lo + SUM_CHUNK : n;
+    Fe<FrP> acc = load_fe<FrP>(chunk_after + c * 8);
+    for (uint64_t i = hi; i-- > lo;) {
+        acc = add(acc, load_fe<FrP>(t + i * 8));
+        store_fe(t + i * 8, acc);
+    }
+}
+
+// d_quot (device, n elements: n-1 quotient coefficients then a zero) and *value (host, Montgomery) from d_poly (device, n coeffs)
+template <class FrP>
+int kzg_divide_by_linear(Ctx* ctx, const uint32_t* d_poly, uint64_t n, const void* z_mont, uint32_t* d_quot, void* value_out) {
+    typedef Fe<FrP> F;
+    hipStream_t st = ctx->stream;
+    F z;
+    memcpy(z.l, z_mont, 32);
+    if (n == 0) {
+        memset(value_out, 0, 32);
+        return GA_OK;
+    }
+    uint32_t *t, *cs;
+    const uint64_t nchunks = (n + SUM_CHUNK - 1) / SUM_CHUNK;
+    GA_CHECK(ctx->scratch_get("kzg_t", n * 32, (void**)&t));
+    GA_CHECK(ctx->scratch_get("kzg_chunks", nchunks * 32, (void**)&cs));
+    const unsigned blocks = (unsigned)((n + 255) / 256), cb = (unsigned)((nchunks + 63) / 64);
+    uint32_t *lo, *hi;
+    StageTimer tm(ctx, "kzg_divide");
+    GA_CHECK(plonk_pow_tables<FrP>(ctx, "plonk_x_tab", z, fe_one<FrP>(), n, false, &lo, &hi));
+    hipLaunchKernelGGL((kzg_scale_kernel<FrP>), dim3(blocks), dim3(256), 0, st, d_poly, t, lo, hi, NTT_POW_LO_BITS, n, (uint64_t)0);
+    hipLaunchKernelGGL((fr_chunk_sum_kernel<FrP>), dim3(cb), dim3(64), 0, st, t, cs, n);
+    hipLaunchKernelGGL((fr_chunk_suffix_scan_kernel<FrP>), dim3(1), dim3(256), 0, st, cs, nchunks);
+    hipLaunchKernelGGL((fr_chunk_suffix_apply_kernel<FrP>), dim3(cb), dim3(64), 0, st, t, cs, n);
+    GA_KERNEL_CHECK();
+    GA_HIP_CHECK(hipMemcpyAsync(value_out, t, 32, hipMemcpyDeviceToHost, st));   // S_0 = p(z)
+    GA_HIP_CHECK(hipMemsetAsync(d_quot + (n - 1) * 8, 0, 32, st));
+    if (n > 1) {
+        if (is_zero(z)) {
+            // q_k = p_{k+1}
+            GA_HIP_CHECK(hipMemcpyAsync(d_quot, d_poly + 8, (n - 1) * 32, hipMemcpyDeviceToDevice, st));
+        } else {
+            // q_k = S_{k+1} * z^-(k+1): table of zinv^j, element i of the output reads index i+1
+            GA_CHECK(plonk_pow_tables<FrP>(ctx, "plonk_scale_tab", inv(z), fe_one<FrP>(), n, false, &lo, &hi));
+            hipLaunchKernelGGL((kzg_scale_kernel<FrP>), dim3((unsigned)((n - 1 + 255) / 256)), dim3(256), 0, st, t, d_quot, lo, hi,
+                               NTT_POW_LO_BITS, n - 1, (uint64_t)1);
+            GA_KERNEL_CHECK();
+        }
+    }
+    GA_HIP_CHECK(hipStreamSynchronize(st));
+    return GA_OK;
+}
+
 // fr.BatchInvert on a vector (host or device memory), in place
 template <class FrP>
 int fr_batch_inverse(Ctx* ctx, void* v, uint64_t n, bool on_device) {

@@ -22,4 +22,8 @@ template <>
 int fr_vec_batch_inverse<Bn254>(Ctx* ctx, void* v, uint64_t n, bool on_device) {
     return fr_batch_inverse<Bn254::FrP>(ctx, v, n, on_device);
 }
+template <>
+int kzg_domain_divide<Bn254>(Ctx* ctx, const void* d_poly, uint64_t n, const void* z_mont, void* d_quot, void* value_out) {
+    return kzg_divide_by_linear<Bn254::FrP>(ctx, (const uint32_t*)d_poly, n, z_mont, (uint32_t*)d_quot, value_out);
+}
 }  // namespace ga

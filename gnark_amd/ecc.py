@@ -81,6 +81,21 @@ class PrecomputedBases:
         self.ctx.lib.check(self.ctx.lib.ga_msm_table_run(self.handle, sp, f2 | (_lib.SCALARS_MONTGOMERY if montgomery else 0), _ptr(out)))
         return out
 
+    def KzgOpen(self, poly, point):
+        """kzg.Open(p, point, pk) over this (monomial G1) SRS: returns (ClaimedValue fr image, H as G1Jac)."""
+        n = None
+        if not isinstance(poly, (DeviceBuffer, int)):
+            poly = as_u64(poly, 4)
+            n = poly.shape[0]
+        else:
+            raise ValueError("pass the coefficient array (host); device polynomials go through ga_kzg_open directly")
+        pp, f = _arg(poly, _lib.SCALARS_ON_DEVICE)
+        z = as_u64(np.asarray(point).reshape(1, 4), 4)
+        val = np.zeros(4, dtype=np.uint64)
+        out = np.zeros(jac_words(self.curve, self.group), dtype=np.uint64)
+        self.ctx.lib.check(self.ctx.lib.ga_kzg_open(self.handle, pp, n, f, _ptr(z), _ptr(val), _ptr(out)))
+        return val, out
+
     def free(self):
         if self.handle:
             self.ctx.lib.ga_msm_table_destroy(self.handle)

@@ -169,6 +169,12 @@ int ga_plonk_quotient_pinned(ga_plonk_pk* pk, const ga_plonk_quotient_in* in, vo
  * 3n int64 (s.trace.S). */
 int ga_plonk_build_z(ga_domain* domain0, const void* l, const void* r, const void* o, const int64_t* permutation,
                      const void* beta, const void* gamma, int on_device, void* z_out);
+/* kzg.Open(p, point, pk) -> OpeningProof{H, ClaimedValue} (gnark-crypto kzg, call sites backend/plonk/bn254/prove.go:681,788,827):
+ * claimed value p(point) and H = commitment to (p(X) - p(point)) / (X - point) over the pinned monomial SRS.  The reference's
+ * division is a sequential Horner recurrence on the CPU; here it is a scaling, a suffix sum and a scaling on the device, followed
+ * by the table MSM.  srs: ga_msm_table over pk.Kzg.G1 with at least len(p) - 1 points; poly: n fr coefficients (Montgomery; device
+ * pointer with GA_SCALARS_ON_DEVICE); point, claimed_value_out: fr Montgomery; h_out: G1Jac. */
+int ga_kzg_open(ga_msm_table* srs, const void* poly, size_t n, unsigned flags, const void* point, void* claimed_value_out, void* h_out);
 /* fr.BatchInvert in place (zeros stay zero): the batchInvert of prove.go:1134-1147 */
 int ga_fr_batch_invert(ga_ctx* ctx, int curve, void* v, uint64_t n, int on_device);
 

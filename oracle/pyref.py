@@ -311,6 +311,20 @@ def _poly_eval(coeffs, x, mod):
     return acc
 
 
+def kzg_open(c: Curve, srs_g1, poly, z):
+    """kzg.Open (gnark-crypto [EXT]; call sites backend/plonk/bn254/prove.go:681,788,827): claimed value p(z) and the commitment
+    to the quotient (p(X) - p(z)) / (X - z) computed by the Horner recurrence q_{k-1} = p_k + z*q_k."""
+    mod = c.r
+    n = len(poly)
+    q = [0] * max(n - 1, 0)
+    acc = 0
+    for k in range(n - 1, 0, -1):
+        acc = (poly[k] + z * acc) % mod
+        q[k - 1] = acc
+    value = (poly[0] + z * acc) % mod if n else 0
+    return value, g1_group(c).msm(srs_g1[: len(q)], q)
+
+
 def plonk_rho(n: int) -> int:
     """domain1 = 8n below 6 constraints, else 4n (prove.go:247-251)"""
     return 8 if n < 6 else 4

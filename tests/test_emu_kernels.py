@@ -571,3 +571,40 @@ def test_emu_groth16_sharded_key_with_commitments(emu_ctx):
         dpk.FreeGPUResources()
     ar, bs, krs, _, _ = pyref.groth16_prove_bsb22(pk, cs, w, r, s_)
     assert (arr_to_g1_affine(c, proof.Ar), arr_to_g2_affine(c, proof.Bs), arr_to_g1_affine(c, proof.Krs)) == (ar, bs, krs)
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("n", [1, 2, 7, 300])
+def test_emu_kzg_open(emu_ctx, c, n, srs_len=None):
+    """kzg.Open over a pinned monomial SRS with known tau (test/unsafekzg-style, kzgsrs.go:186-200): the device division by
+    (X - z) + table MSM against the oracle's Horner recurrence, for a random point, z = 0 and a polynomial shorter than the SRS;
+    and H = [(p(tau) - p(z)) / (tau - z)]G in the exponent"""
+    mod = c.r
+    rng = pyref.Xoshiro(1000 + n)
+    tau = rng.field(mod)
+    srs_len = srs_len or max(n, 4)
+    G1 = group_of(c, 0)
+    taus = [pow(tau, i, mod) for i in range(srs_len)]
+    if srs_len <= 512:
+        srs_pts = [G1.mul(c.g1, t) for t in taus]
+        srs_arr = pts_to_arr(c, 0, srs_pts)
+    else:   # large SRS: the C oracle multiplies the generator
+        srs_arr = np.stack([oracle.jac_to_affine(c.cid, 0, oracle.generator_mul(c.cid, 0, t)) for t in taus])
+        srs_pts = None
+    srs = ecc.PrecomputedBases(emu_ctx, c.name, 0, srs_arr)
+    try:
+        for z in (rng.field(mod), 0, 1):
+            poly = [rng.field(mod) for _ in range(n)]
+            val, H = srs.KzgOpen(fr_to_arr(c, poly), fr_to_arr(c, [z]))
+            pz = pyref._poly_eval(poly, z, mod)
+            assert arr_to_fr(c, val.reshape(1, 4))[0] == pz
+            got = jac_to_affine_py(c, 0, H)
+            if n > 1:
+                qt = (pyref._poly_eval(poly, tau, mod) - pz) * pow((tau - z) % mod, -1, mod) % mod
+                assert got == G1.mul(c.g1, qt)
+            if srs_pts is not None:
+                assert got == pyref.kzg_open(c, srs_pts, poly, z)[1]
+        with pytest.raises(Exception, match="at least"):
+            srs.KzgOpen(fr_to_arr(c, [1] * (srs_len + 2)), fr_to_arr(c, [5]))
+    finally:
+        srs.free()

@@ -333,6 +333,37 @@ def test_plonk_quotient_2_14_vs_c_oracle(gpu_ctx, c):
         d1.close()
 
 
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("n,srs_len", [(1, 4), (2, 4), (7, 7), (300, 300), (4096, 4100)])
+def test_kzg_open_vs_oracle(gpu_ctx, c, n, srs_len):
+    cases.test_emu_kzg_open(gpu_ctx, c, n, srs_len)
+
+
+def test_kzg_open_2_20_known_dlogs(gpu_ctx):
+    """kzg.Open at 2^20 coefficients over 2^20 pinned bases [k_i]G with known k_i: claimed value == Horner (C oracle) and
+    H == [sum q_i k_i]G with the quotient coefficients from the sequential recurrence on the host"""
+    c, n = BN254, 1 << 20
+    mod = c.r
+    bases, dlogs, scal = _device_inputs(gpu_ctx, c, 0, n, 0x4B5A)
+    poly_arr, K = scal.to_host((n, 4)), dlogs.to_host((n, 4))
+    z = pyref.Xoshiro(77).field(mod)
+    table = ecc.PrecomputedBases(gpu_ctx, c.name, 0, bases, n=n)
+    try:
+        val, H = table.KzgOpen(poly_arr, fr_to_arr(c, [z]))
+    finally:
+        table.free()
+        for b in (bases, dlogs, scal):
+            b.free()
+    assert np.array_equal(val, oracle.fr_horner(c.cid, poly_arr, fr_to_arr(c, [z])[0]))
+    poly = arr_to_fr(c, poly_arr)
+    q, acc = [0] * n, 0
+    for k in range(n - 1, 0, -1):
+        acc = (poly[k] + z * acc) % mod
+        q[k - 1] = acc
+    want = oracle.jac_to_affine(c.cid, 0, oracle.generator_mul(c.cid, 0, oracle.fr_dot(c.cid, fr_to_arr(c, q), K)))
+    assert np.array_equal(oracle.jac_to_affine(c.cid, 0, H), want)
+
+
 def test_plonk_quotient_2_16_identity(gpu_ctx):
     """n = 2^16 (4n = 2^18: multi-pass transforms): a satisfying synthetic trace built with the C oracle's FFT, Z from the device
     grand product (checked against a Python prefix product at sampled positions and to close), then
