@@ -364,6 +364,23 @@ int ga_msm_table_run(ga_msm_table* th, const void* scalars, unsigned flags, void
     return GA_OK;
 }
 
+int ga_fr_linear_combination(ga_ctx* h, int curve, uint64_t n, int k, const void* const* vecs, const void* scalars, void* out,
+                             int on_device) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    if (!c || !vecs || !scalars || (!out && n)) {
+        set_error("ga_fr_linear_combination: null argument");
+        return GA_ERR_INVALID;
+    }
+    for (int j = 0; j < k; j++)
+        if (!vecs[j]) {
+            set_error("ga_fr_linear_combination: vector %d is null", j);
+            return GA_ERR_INVALID;
+        }
+    Lock l(c);
+    GA_DISPATCH_CURVE(curve, GA_CHECK(fr_vec_lincomb<C>(c, n, k, vecs, scalars, out, on_device != 0)));
+    return GA_OK;
+}
+
 // kzg.Open(p, point, pk): claimed value p(point) and the commitment to (p(X) - p(point)) / (X - point) over the pinned SRS
 int ga_kzg_open(ga_msm_table* th, const void* poly, size_t n, unsigned flags, const void* point, void* claimed_value_out, void* h_out) {
     MsmTable* t = reinterpret_cast<MsmTable*>(th);

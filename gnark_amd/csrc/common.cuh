@@ -191,6 +191,7 @@ Domain* plonk_fixed_domain0(PlonkFixed* fx);
 template <class C> int plonk_domain_build_z(Domain* d0, const void* L, const void* R, const void* O, const int64_t* perm, const void* beta,
                                             const void* gamma, bool on_device, void* z_out);
 template <class C> int fr_vec_batch_inverse(Ctx* ctx, void* v, uint64_t n, bool on_device);
+template <class C> int fr_vec_lincomb(Ctx* ctx, uint64_t n, int k, const void* const* vecs, const void* scalars, void* out, bool on_device);
 template <class C> int kzg_domain_divide(Ctx* ctx, const void* d_poly, uint64_t n, const void* z_mont, void* d_quot, void* value_out);
 
 // utility kernels (util_*.hip)

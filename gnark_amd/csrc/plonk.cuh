@@ -564,6 +564,57 @@ int kzg_divide_by_linear(Ctx* ctx, const uint32_t* d_poly, uint64_t n, const voi
     return GA_OK;
 }
 
+// out[i] = sum_k s_k * v_k[i]: the folding of kzg.BatchOpenSinglePoint and the linear combinations of the linearised polynomial
+// (backend/plonk/bn254/prove.go:1352-1460) as one pass over the vectors
+constexpr int LINCOMB_MAX = 16;
+struct LinCombArgs {
+    const uint32_t* v[LINCOMB_MAX];
+    uint32_t s[LINCOMB_MAX][8];
+    int k;
+};
+template <class FrP>
+__global__ void fr_lincomb_kernel(LinCombArgs A, uint32_t* __restrict__ out, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fe<FrP> acc = fe_zero<FrP>();
+    for (int k = 0; k < A.k; k++) acc = add(acc, mul_val(load_fe<FrP>(A.v[k] + i * 8), plonk_c<FrP>(A.s[k])));
+    store_fe(out + i * 8, acc);
+}
+template <class FrP>
+int fr_lincomb(Ctx* ctx, uint64_t n, int k, const void* const* vecs, const void* scalars, void* out, bool on_device) {
+    if (k < 1 || k > LINCOMB_MAX) {
+        set_error("linear combination of %d vectors: 1..%d supported per call", k, LINCOMB_MAX);
+        return GA_ERR_INVALID;
+    }
+    if (n == 0) return GA_OK;
+    hipStream_t st = ctx->stream;
+    LinCombArgs A;
+    memset(&A, 0, sizeof(A));
+    A.k = k;
+    uint32_t *stage = nullptr, *dout = (uint32_t*)out;
+    if (!on_device) {
+        GA_CHECK(ctx->scratch_get("lincomb_in", (size_t)(k + 1) * n * 32, (void**)&stage));
+        dout = stage + (size_t)k * n * 8;
+    }
+    for (int j = 0; j < k; j++) {
+        memcpy(A.s[j], (const char*)scalars + 32 * j, 32);
+        if (on_device) {
+            A.v[j] = (const uint32_t*)vecs[j];
+        } else {
+            GA_HIP_CHECK(hipMemcpyAsync(stage + (size_t)j * n * 8, vecs[j], n * 32, hipMemcpyHostToDevice, st));
+            A.v[j] = stage + (size_t)j * n * 8;
+        }
+    }
+    {
+        StageTimer tm(ctx, "fr_lincomb");
+        hipLaunchKernelGGL((fr_lincomb_kernel<FrP>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, A, dout, n);
+        GA_KERNEL_CHECK();
+    }
+    if (!on_device) GA_HIP_CHECK(hipMemcpyAsync(out, dout, n * 32, hipMemcpyDeviceToHost, st));
+    GA_HIP_CHECK(hipStreamSynchronize(st));
+    return GA_OK;
+}
+
 // fr.BatchInvert on a vector (host or device memory), in place
 template <class FrP>
 int fr_batch_inverse(Ctx* ctx, void* v, uint64_t n, bool on_device) {

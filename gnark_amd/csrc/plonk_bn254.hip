@@ -26,4 +26,8 @@ template <>
 int kzg_domain_divide<Bn254>(Ctx* ctx, const void* d_poly, uint64_t n, const void* z_mont, void* d_quot, void* value_out) {
     return kzg_divide_by_linear<Bn254::FrP>(ctx, (const uint32_t*)d_poly, n, z_mont, (uint32_t*)d_quot, value_out);
 }
+template <>
+int fr_vec_lincomb<Bn254>(Ctx* ctx, uint64_t n, int k, const void* const* vecs, const void* scalars, void* out, bool on_device) {
+    return fr_lincomb<Bn254::FrP>(ctx, n, k, vecs, scalars, out, on_device);
+}
 }  // namespace ga

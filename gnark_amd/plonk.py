@@ -157,3 +157,16 @@ def BatchInvert(ctx, curve, v) -> np.ndarray:
     a = as_u64(np.asarray(v).reshape(-1, 4), 4).copy()
     ctx.lib.check(ctx.lib.ga_fr_batch_invert(ctx.handle, curve_id(curve), _ptr(a), a.shape[0], 0))
     return a
+
+
+def LinearCombination(ctx, curve, scalars, vectors) -> np.ndarray:
+    """sum_j scalars[j] * vectors[j] (polynomial folding / linearised polynomial): ga_fr_linear_combination, <= 16 terms"""
+    from .device import curve_id
+    vs = [as_u64(np.asarray(v).reshape(-1, 4), 4) for v in vectors]
+    sc = as_u64(np.asarray(scalars).reshape(-1, 4), 4)
+    if sc.shape[0] != len(vs) or any(v.shape != vs[0].shape for v in vs):
+        raise ValueError("one scalar per vector, vectors of equal length")
+    ptrs = (C.c_void_p * len(vs))(*[v.ctypes.data for v in vs])
+    out = np.zeros_like(vs[0])
+    ctx.lib.check(ctx.lib.ga_fr_linear_combination(ctx.handle, curve_id(curve), vs[0].shape[0], len(vs), ptrs, _ptr(sc), _ptr(out), 0))
+    return out

@@ -175,6 +175,11 @@ int ga_plonk_build_z(ga_domain* domain0, const void* l, const void* r, const voi
  * by the table MSM.  srs: ga_msm_table over pk.Kzg.G1 with at least len(p) - 1 points; poly: n fr coefficients (Montgomery; device
  * pointer with GA_SCALARS_ON_DEVICE); point, claimed_value_out: fr Montgomery; h_out: G1Jac. */
 int ga_kzg_open(ga_msm_table* srs, const void* poly, size_t n, unsigned flags, const void* point, void* claimed_value_out, void* h_out);
+/* out[i] = sum_{j<k} scalars[j] * vecs[j][i], k <= 16 per call: the polynomial folding of kzg.BatchOpenSinglePoint and the
+ * linear combinations of innerComputeLinearizedPoly (backend/plonk/bn254/prove.go:1352-1460) in one pass.  scalars: k fr
+ * (Montgomery, host); vecs/out: n fr each, all host or all device (on_device). */
+int ga_fr_linear_combination(ga_ctx* ctx, int curve, uint64_t n, int k, const void* const* vecs, const void* scalars, void* out,
+                             int on_device);
 /* fr.BatchInvert in place (zeros stay zero): the batchInvert of prove.go:1134-1147 */
 int ga_fr_batch_invert(ga_ctx* ctx, int curve, void* v, uint64_t n, int on_device);
 

@@ -608,3 +608,16 @@ def test_emu_kzg_open(emu_ctx, c, n, srs_len=None):
             srs.KzgOpen(fr_to_arr(c, [1] * (srs_len + 2)), fr_to_arr(c, [5]))
     finally:
         srs.free()
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_emu_fr_linear_combination(emu_ctx, c, n=300):
+    mod = c.r
+    rng = pyref.Xoshiro(5)
+    for k in (1, 3, 16):
+        vs = [[rng.field(mod) for _ in range(n)] for _ in range(k)]
+        sc = [rng.field(mod) for _ in range(k)]
+        got = plonk.LinearCombination(emu_ctx, c.name, fr_to_arr(c, sc), [fr_to_arr(c, v) for v in vs])
+        assert arr_to_fr(c, got) == [sum(s * v[i] for s, v in zip(sc, vs)) % mod for i in range(n)]
+    with pytest.raises(Exception, match="1..16"):
+        plonk.LinearCombination(emu_ctx, c.name, fr_to_arr(c, [1] * 17), [fr_to_arr(c, [1, 2])] * 17)

@@ -339,6 +339,11 @@ def test_kzg_open_vs_oracle(gpu_ctx, c, n, srs_len):
     cases.test_emu_kzg_open(gpu_ctx, c, n, srs_len)
 
 
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_fr_linear_combination(gpu_ctx, c):
+    cases.test_emu_fr_linear_combination(gpu_ctx, c, n=5000)
+
+
 def test_kzg_open_2_20_known_dlogs(gpu_ctx):
     """kzg.Open at 2^20 coefficients over 2^20 pinned bases [k_i]G with known k_i: claimed value == Horner (C oracle) and
     H == [sum q_i k_i]G with the quotient coefficients from the sequential recurrence on the host"""
