@@ -381,6 +381,26 @@ int ga_fr_linear_combination(ga_ctx* h, int curve, uint64_t n, int k, const void
     return GA_OK;
 }
 
+// p(point) for a polynomial in canonical form (iop.Polynomial.Evaluate / evaluateBlinded, prove.go:1186-1215)
+int ga_fr_poly_evaluate(ga_ctx* h, int curve, const void* poly, uint64_t n, const void* point, void* value_out, int on_device) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    if (!c || (!poly && n) || !point || !value_out) {
+        set_error("ga_fr_poly_evaluate: null argument");
+        return GA_ERR_INVALID;
+    }
+    Lock l(c);
+    if (n == 0) {
+        memset(value_out, 0, 32);
+        return GA_OK;
+    }
+    Staged sp{c};
+    GA_CHECK(sp.stage(poly, n * 32, on_device));
+    void* q;
+    GA_CHECK(c->scratch_get("kzg_quotient", n * 32, &q));
+    GA_DISPATCH_CURVE(curve, GA_CHECK(kzg_domain_divide<C>(c, sp.dev, n, point, q, value_out)));
+    return GA_OK;
+}
+
 // kzg.Open(p, point, pk): claimed value p(point) and the commitment to (p(X) - p(point)) / (X - point) over the pinned SRS
 int ga_kzg_open(ga_msm_table* th, const void* poly, size_t n, unsigned flags, const void* point, void* claimed_value_out, void* h_out) {
     MsmTable* t = reinterpret_cast<MsmTable*>(th);

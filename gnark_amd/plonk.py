@@ -170,3 +170,13 @@ def LinearCombination(ctx, curve, scalars, vectors) -> np.ndarray:
     out = np.zeros_like(vs[0])
     ctx.lib.check(ctx.lib.ga_fr_linear_combination(ctx.handle, curve_id(curve), vs[0].shape[0], len(vs), ptrs, _ptr(sc), _ptr(out), 0))
     return out
+
+
+def Evaluate(ctx, curve, poly, point) -> np.ndarray:
+    """p(point) for canonical coefficients (iop.Polynomial.Evaluate): ga_fr_poly_evaluate"""
+    from .device import curve_id
+    a = as_u64(np.asarray(poly).reshape(-1, 4), 4)
+    z = as_u64(np.asarray(point).reshape(1, 4), 4)
+    out = np.zeros(4, dtype=np.uint64)
+    ctx.lib.check(ctx.lib.ga_fr_poly_evaluate(ctx.handle, curve_id(curve), _ptr(a), a.shape[0], _ptr(z), _ptr(out), 0))
+    return out

@@ -180,6 +180,8 @@ int ga_kzg_open(ga_msm_table* srs, const void* poly, size_t n, unsigned flags, c
  * (Montgomery, host); vecs/out: n fr each, all host or all device (on_device). */
 int ga_fr_linear_combination(ga_ctx* ctx, int curve, uint64_t n, int k, const void* const* vecs, const void* scalars, void* out,
                              int on_device);
+/* p(point) of a canonical-form polynomial (iop.Polynomial.Evaluate, evaluateBlinded prove.go:1186-1215). */
+int ga_fr_poly_evaluate(ga_ctx* ctx, int curve, const void* poly, uint64_t n, const void* point, void* value_out, int on_device);
 /* fr.BatchInvert in place (zeros stay zero): the batchInvert of prove.go:1134-1147 */
 int ga_fr_batch_invert(ga_ctx* ctx, int curve, void* v, uint64_t n, int on_device);
 

@@ -619,5 +619,9 @@ def test_emu_fr_linear_combination(emu_ctx, c, n=300):
         sc = [rng.field(mod) for _ in range(k)]
         got = plonk.LinearCombination(emu_ctx, c.name, fr_to_arr(c, sc), [fr_to_arr(c, v) for v in vs])
         assert arr_to_fr(c, got) == [sum(s * v[i] for s, v in zip(sc, vs)) % mod for i in range(n)]
+    for m in (1, 2, 257, 1000):   # polynomial evaluation (iop.Polynomial.Evaluate)
+        poly, z = [rng.field(mod) for _ in range(m)], rng.field(mod)
+        got = plonk.Evaluate(emu_ctx, c.name, fr_to_arr(c, poly), fr_to_arr(c, [z]))
+        assert arr_to_fr(c, got.reshape(1, 4))[0] == pyref._poly_eval(poly, z, mod)
     with pytest.raises(Exception, match="1..16"):
         plonk.LinearCombination(emu_ctx, c.name, fr_to_arr(c, [1] * 17), [fr_to_arr(c, [1, 2])] * 17)
