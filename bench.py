@@ -33,7 +33,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--log-n", type=int, default=int(os.environ.get("GA_BENCH_LOGN", "24")))
-    ap.add_argument("--groth16-proofs", type=int, default=int(os.environ.get("GA_BENCH_PROOFS", "1")))
+    ap.add_argument("--groth16-proofs", type=int, default=int(os.environ.get("GA_BENCH_PROOFS", "5")))
+    ap.add_argument("--no-check", action="store_true", help="skip the oracle checks of the Groth16 / PLONK legs (outside the timed regions)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--plonk-log-n", type=int, default=int(os.environ.get("GA_BENCH_PLONK_LOGN", "22")), help="0 disables the PLONK leg")
     ap.add_argument("--curve", default="bn254")
@@ -49,56 +50,42 @@ def stage_stats(records):
     return {k: {"launches": v[0], "total_ms": round(v[1], 4), "avg_ms": round(v[1] / v[0], 4)} for k, v in agg.items()}
 
 
-def synth_groth16(ctx, cid, logn, seed, shard=(0, 1)):
-    """Synthetic 2^logn-constraint instance: known-dlog key generated on device, pulled to the
-    host once so that it can go through the same ga_g16_pk_create upload path a Go caller uses."""
-    import ctypes as C
+def synth_groth16(ctx, cid, logn, seed, shard=(0, 1), want_dlogs=True):
+    """Synthetic 2^logn-constraint instance: known-dlog key generated on device, pulled to the host once so
+    that it goes through the same ga_g16_pk_create upload path a Go caller uses; C = A o B (gnark_amd/synth.py)."""
+    from gnark_amd import synth
+    inst = synth.make_instance(ctx, cid, logn, seed, want_dlogs=want_dlogs)
+    pk = inst.proving_key(ctx, shard=shard)
+    return inst, pk
 
-    from gnark_amd import _lib, groth16
-    from gnark_amd.device import FP_LIMBS
-    lib = ctx.lib
-    n = 1 << logn
-    nw = n          # wires; two infinity entries in A and in B like the squaring-chain circuit of groth16_test.go:120-132
-    fp = FP_LIMBS[cid]
 
-    def gen(group, count, sd):
-        words = fp * (2 if group == 0 else 4)
-        buf = ctx.malloc(count * words * 8)
-        lib.check(lib.ga_gen_bases(ctx.handle, cid, group, sd, count, buf.ptr, None))
-        host = buf.to_host((count, words))
-        buf.free()
-        return host
-
-    infA = np.zeros(nw, dtype=np.uint8)
-    infB = np.zeros(nw, dtype=np.uint8)
-    infA[[1, nw - 1]] = 1
-    infB[[0, nw - 2]] = 1
-    A = gen(0, nw - 2, seed + 1)
-    B = gen(0, nw - 2, seed + 2)
-    Z = gen(0, n - 1, seed + 3)
-    nb_public = 2
-    K = gen(0, nw - nb_public, seed + 4)
-    B2 = gen(1, nw - 2, seed + 5)
-    misc1 = gen(0, 3, seed + 6)
-    misc2 = gen(1, 2, seed + 7)
-    pk = groth16.ProvingKey(ctx, cid, domain_cardinality=n, alpha1=misc1[0:1], beta1=misc1[1:2], delta1=misc1[2:3], A=A, B=B, Z=Z,
-                            K=K, beta2=misc2[0:1], delta2=misc2[1:2], B2=B2, infinityA=infA, infinityB=infB, shard=shard)
-    del A, B, Z, K, B2
-
-    def scal(count, sd):
-        buf = ctx.malloc(count * 32)
-        lib.check(lib.ga_gen_scalars(ctx.handle, cid, sd, count, buf.ptr))
-        host = buf.to_host((count, 4))
-        buf.free()
-        return host
-    W = scal(nw, seed + 10)
-    a = scal(n, seed + 11)
-    b = scal(n, seed + 12)
-    # C = A o B on the host would need field code; any C gives the same amount of work for the prover kernels, and the
-    # parity of computeH is established in tests/ -- use an independent uniform vector.
-    c = scal(n, seed + 13)
-    rs = scal(2, seed + 14)
-    return pk, groth16.Solution(W, a, b, c), nb_public, rs[0], rs[1]
+def check_groth16(ctx, inst, proof, threads):
+    """Outside every timed region: is the timed proof THE proof?  Exponents of Ar, Bs, Krs from the key's known discrete logs by
+    O(n) dot products on the CPU oracle, h by the polynomial identity (oracle/checkers.py).  The oracle is the checker here,
+    never the thing measured."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import checkers
+    import oracle
+    import pyref
+    from gnark_amd import fft, synth
+    c = pyref.BN254 if inst.curve == 0 else pyref.BLS12_381
+    sol = inst.solution
+    d = fft.Domain(ctx, inst.curve, inst.n)
+    try:
+        h = d.compute_h(sol.A, sol.B, sol.C)
+    finally:
+        d.close()
+    res = {"method": "known-dlog key: exponents by oracle.fr_dot (CPU), h by A(x)B(x)-C(x)=H(x)(x^n-1) with barycentric A,B,C (oracle/checkers.py)"}
+    try:
+        checkers.check_compute_h_identity(c, sol.A, sol.B, sol.C, h, inst.n, threads)
+        res["h_identity_ok"] = True
+    except AssertionError:
+        res["h_identity_ok"] = False
+    exp = synth.expected_exponents(inst, h, lambda x, y: oracle.fr_dot(inst.curve, x, y))
+    pt = lambda group, k: oracle.jac_to_affine(inst.curve, group, oracle.generator_mul(inst.curve, group, k))
+    res["matches_dlog"] = bool(np.array_equal(proof.Ar, pt(0, exp["Ar"])) and np.array_equal(proof.Bs, pt(1, exp["Bs"]))
+                               and np.array_equal(proof.Krs, pt(0, exp["Krs"])))
+    return res
 
 
 def main():
@@ -108,10 +95,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
+    # GA_BENCH_EMU=1: dry run of this script's control flow against the CPU emulation build of the library (tests/emu), tiny
+    # sizes only -- a development aid for the GPU-less build container, never a measurement (the JSON line says "data": "emulation")
+    emu = os.environ.get("GA_BENCH_EMU", "0") == "1"
     ndev = max(1, torch.cuda.device_count())
     device_index = local_rank % ndev       # one rank per GPU on the driver's runs; wraps only in single-GPU smoke runs
-    torch.cuda.set_device(device_index)
-    backend = os.environ.get("GA_BENCH_BACKEND", "nccl")   # "gloo" lets a 1-GPU box exercise the N>1 code path
+    if not emu:
+        torch.cuda.set_device(device_index)
+    backend = os.environ.get("GA_BENCH_BACKEND", "gloo" if emu else "nccl")   # "gloo" lets a 1-GPU box exercise the N>1 code path
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
@@ -123,7 +114,10 @@ def main():
     from gnark_amd import _lib, ecc
     from gnark_amd.device import curve_id, jac_words
     cid = curve_id(args.curve)
-    ctx = gnark_amd.Context(device_index)
+    if emu:
+        ctx = gnark_amd.Context(0, lib=_lib.Library(os.path.join(ROOT, "tests", "emu", "libgnark_amd_emu.so")))
+    else:
+        ctx = gnark_amd.Context(device_index)   # raises when libgnark_amd.so or the GPU is missing: there is no CPU fallback
     lib = ctx.lib
     n = 1 << args.log_n
     words_aff = gnark_amd.device.affine_words(cid, _lib.G1)
@@ -151,11 +145,13 @@ def main():
         return multigpu.msm_base_sharded(ctx, cid, _lib.G1, table if use_table else bases, scalars, n, dist, dev)
 
     def fence():
-        torch.cuda.synchronize()
+        if not emu:
+            torch.cuda.synchronize()
         ctx.sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not emu:
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -194,7 +190,7 @@ def main():
             "metric": "G1 MSM throughput, %s, 2^%d scalar-muls per GPU (Groth16 proofs/s at 2^%d constraints in 'groth16')" % (args.curve.upper(), args.log_n, args.log_n),
             "value": round(value, 3), "unit": "Mscalar-mul/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u64 Montgomery limbs in memory; 29/28-bit limbs, v_mad_u64_u32 (32x32+64) in registers", "data": "synthetic",
+            "dtype": "u64 Montgomery limbs in memory; 29/28-bit limbs, v_mad_u64_u32 (32x32+64) in registers", "data": "emulation" if emu else "synthetic",
             "config": {"workload": "%s G1 Pippenger MSM, 2^%d uniform scalars x distinct known-dlog affine bases per GPU, inputs resident in HBM" % (args.curve.upper(), args.log_n),
                        "curve": args.curve, "window_bits": cbits, "windows": nwin,
                        "precompute": ("[2^(c*w)]P tables for all %d windows, %.1f GiB, one shared bucket set" % (nwin, ti["table_bytes"] / 2**30)) if use_table else "none",
@@ -225,7 +221,9 @@ def main():
         scalars.free()
         from gnark_amd import groth16
         t_setup = time.perf_counter()
-        pk, sol, nb_public, r, s = synth_groth16(ctx, cid, args.log_n, 0x5EED0005)
+        threads = os.cpu_count() or 1
+        inst, pk = synth_groth16(ctx, cid, args.log_n, 0x5EED0005, want_dlogs=not args.no_check)
+        sol, nb_public, r, s = inst.solution, inst.nb_public, inst.r, inst.s
         setup_s = time.perf_counter() - t_setup
         groth16.Prove(pk, sol, nb_public, r, s)   # warm-up (scratch allocation)
         ctx.profile(True)
@@ -243,12 +241,23 @@ def main():
         bytes_per_constraint = 992 if cid == 0 else 1184   # 4 G1 + 1 G2 MSM + 7 NTTs
         out["groth16"] = {"proofs_per_s": round(args.groth16_proofs / el, 4), "ms_per_proof": round(el * 1e3 / args.groth16_proofs, 2),
                           "proofs": args.groth16_proofs, "constraints": n, "key_setup_s": round(setup_s, 1),
-                          "definition": "W,A,B,C in host memory -> Ar,Bs,Krs affine on host; key pinned; solver excluded",
+                          "definition": "W,A,B,C in host memory -> Ar,Bs,Krs affine on host; key pinned; solver excluded; C = A o B (satisfiable instance)",
                           "algorithmic_bytes": bytes_per_constraint * n, "hbm_frac_whole_proof": round(bytes_per_constraint * n / (el / args.groth16_proofs) / 8e12, 6),
                           "computeH_ms": round(ntt_ms, 3),
                           "computeH_hbm_frac": round(448.0 * n / (ntt_ms * 1e-3) / 8e12, 5) if ntt_ms > 0 else None,
                           "proof_sha": __import__("hashlib").sha256(proof.WriteTo()).hexdigest()[:16],
-                          "stages_ms": gst}
+                          "stages_ms": {k: {"launches": v["launches"], "total_ms": round(v["total_ms"] / args.groth16_proofs, 4), "avg_ms": v["avg_ms"]}
+                                        for k, v in gst.items()},
+                          "stages_note": "total_ms is per proof (averaged over the timed proofs)"}
+        if not args.no_check:
+            t_chk = time.perf_counter()
+            try:
+                out["groth16"]["check"] = check_groth16(ctx, inst, proof, threads)
+            except Exception as e:   # a failing checker must not hide the measurement -- it is reported instead
+                out["groth16"]["check"] = {"error": repr(e)[:300], "matches_dlog": None}
+            out["groth16"]["check"]["seconds"] = round(time.perf_counter() - t_chk, 1)
+            out["groth16"]["matches_dlog"] = out["groth16"]["check"].get("matches_dlog")
+        del inst, sol
 
     # ---- PLONK (BASELINE config 5): kernel work of one BN254 proof at 2^22 gates -- 10 KZG-commit MSMs over a pinned SRS, the
     # grand product and the quotient (computeNumerator + divideByZH) on the device; N = 1, BN254 only
@@ -257,6 +266,18 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import bench_plonk_kernels
             out["plonk"] = bench_plonk_kernels.run(ctx, args.plonk_log_n, reps=2, reference_count=False)[0]
+            if not args.no_check:   # the same device pipeline on a SATISFYING trace, checked by the CPU oracle (outside the timed region)
+                sys.path.insert(0, os.path.join(ROOT, "oracle"))
+                import checkers
+                import pyref
+                t_chk = time.perf_counter()
+                try:
+                    out["plonk"]["identity_ok"] = bool(checkers.check_plonk_quotient_identity(ctx, pyref.BN254, args.plonk_log_n,
+                                                                                              nthreads=os.cpu_count() or 1, pinned=True))
+                except AssertionError:
+                    out["plonk"]["identity_ok"] = False
+                out["plonk"]["identity_check"] = ("h(zeta)(zeta^n-1) == gate + alpha*ordering + alpha^2(Z-1)L1 on a satisfying synthetic trace, "
+                                                  "polynomials evaluated by the CPU oracle (oracle/checkers.py), %.1f s" % (time.perf_counter() - t_chk))
         except Exception as e:   # never lose the headline line over the secondary leg
             out["plonk"] = {"error": str(e)[:300]}
 
@@ -272,7 +293,8 @@ def main():
             if table is None:
                 bases.free()
                 scalars.free()
-            pk, sol, nb_public, r, s = synth_groth16(ctx, cid, args.log_n, 0x5EED0005, shard=(rank, world))   # same seeds on every rank
+            inst, pk = synth_groth16(ctx, cid, args.log_n, 0x5EED0005, shard=(rank, world), want_dlogs=False)   # same seeds on every rank
+            sol, nb_public, r, s = inst.solution, inst.nb_public, inst.r, inst.s
             multigpu.groth16_prove_sharded(pk, sol, nb_public, r, s, dist, dev)   # warm-up
             fence()
             t0 = time.perf_counter()
@@ -293,10 +315,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle
-        cores = os.cpu_count() or 1
+        host_cores = os.cpu_count() or 1
         sample_log = min(args.log_n, 24)
         sn = 1 << sample_log
-        ks = (np.arange(sn, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(12345)) | np.uint64(1)
         sb = ctx.malloc(sn * words_aff * 8)
         lib.check(lib.ga_gen_bases(ctx.handle, cid, _lib.G1, 0x5EED0002, sn, sb.ptr, None))
         P = sb.to_host((sn, words_aff))
@@ -304,13 +325,37 @@ def main():
         lib.check(lib.ga_gen_scalars(ctx.handle, cid, 0x5EED0001, sn, ss.ptr))
         S = ss.to_host((sn, 4))
         t0 = time.perf_counter()
-        ref = oracle.msm(cid, 0, P, S, nthreads=cores)
+        ref = oracle.msm(cid, 0, P, S, nthreads=host_cores)
         cpu_s = time.perf_counter() - t0
         gpu = ecc.MultiExp(ctx, cid, _lib.G1, sb, ss, n=sn)
         same = bool(np.array_equal(oracle.jac_to_affine(cid, 0, ref), ecc.jac_to_affine(cid, _lib.G1, gpu)))
-        out["cpu_baseline"] = {"value": round(sn / cpu_s / 1e6, 4), "unit": "Mscalar-mul/s", "cores": min(cores, oracle.msm_windows(cid, sn)), "kind": "port",
+        sb.free()
+        ss.free()
+        threads_used = min(host_cores, oracle.msm_windows(cid, sn))   # the port runs one thread per Pippenger window
+        out["cpu_baseline"] = {"value": round(sn / cpu_s / 1e6, 4), "unit": "Mscalar-mul/s", "cores": threads_used, "threads_used": threads_used,
+                               "host_cores": host_cores, "kind": "port",
                                "sample": "%s G1 MSM of 2^%d points, oracle/oracle.c Pippenger (one thread per window), %.1f s" % (args.curve.upper(), sample_log, cpu_s),
-                               "gpu_result_matches_oracle": same}
+                               "gpu_result_matches_oracle": same,
+                               "note": "a plain-C restatement (64-bit CIOS, no assembly), NOT gnark-crypto: gnark cannot be built here (no Go toolchain)"}
+        # proofs/s for the same port: the oracle's Groth16 prover (7 FFTs + 4 G1 + 1 G2 MSM) on a bounded 2^20-constraint sample
+        if args.groth16_proofs > 0:
+            try:
+                glog = min(args.log_n, int(os.environ.get("GA_BENCH_CPU_G16_LOGN", "20")))
+                from gnark_amd import groth16, synth
+                ginst = synth.make_instance(ctx, cid, glog, 0x5EED0020, want_dlogs=False)
+                gs = ginst.solution
+                t0 = time.perf_counter()
+                want = oracle.groth16_prove(cid, dict(ginst.key, n=ginst.n), gs.W, gs.A, gs.B, gs.C, ginst.nb_public, ginst.r, ginst.s, nthreads=host_cores)
+                g_s = time.perf_counter() - t0
+                gpk = ginst.proving_key(ctx)
+                gp = groth16.Prove(gpk, gs, ginst.nb_public, ginst.r, ginst.s)
+                gpk.FreeGPUResources()
+                g_same = bool(np.array_equal(gp.Ar, want[0]) and np.array_equal(gp.Bs, want[1]) and np.array_equal(gp.Krs, want[2]))
+                out["cpu_baseline"]["groth16"] = {"proofs_per_s": round(1.0 / g_s, 4), "constraints": 1 << glog, "kind": "port", "threads_used": host_cores,
+                                                  "sample": "oracle/oracle.c Groth16 prover, 2^%d constraints, %.1f s" % (glog, g_s),
+                                                  "gpu_proof_matches_oracle": g_same}
+            except Exception as e:
+                out["cpu_baseline"]["groth16"] = {"error": repr(e)[:300]}
     if rank == 0:
         print(json.dumps(out))
     ctx.close()

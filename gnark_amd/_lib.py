@@ -93,6 +93,7 @@ _PROTOS = {
     "ga_fr_linear_combination": (C.c_int, [_P, C.c_int, C.c_uint64, C.c_int, C.POINTER(C.c_void_p), _P, _P, C.c_int]),
     "ga_fr_poly_evaluate": (C.c_int, [_P, C.c_int, _P, C.c_uint64, _P, _P, C.c_int]),
     "ga_kzg_open": (C.c_int, [_P, _P, C.c_size_t, C.c_uint, _P, _P, _P]),
+    "ga_fr_vec_mul": (C.c_int, [_P, C.c_int, _P, _P, C.c_size_t, _P, C.c_int]),
     "ga_fr_batch_invert": (C.c_int, [_P, C.c_int, _P, C.c_uint64, C.c_int]),
     "ga_g16_pk_create": (C.c_int, [_P, C.POINTER(G16Key), C.POINTER(_P)]),
     "ga_g16_pk_destroy": (None, [_P]),

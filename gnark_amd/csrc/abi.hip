@@ -728,6 +728,25 @@ int ga_fr_dot(ga_ctx* h, int curve, const void* a_dev, const void* b_dev, size_t
     return GA_OK;
 }
 
+int ga_fr_vec_mul(ga_ctx* h, int curve, const void* a, const void* b, size_t n, void* out, int on_device) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    if (!c || (n && (!a || !b || !out))) {
+        set_error("ga_fr_vec_mul: null argument");
+        return GA_ERR_INVALID;
+    }
+    Lock l(c);
+    if (n == 0) return GA_OK;
+    Staged sa{c}, sb{c};
+    GA_CHECK(sa.stage(a, n * 32, on_device));
+    GA_CHECK(sb.stage(b, n * 32, on_device));
+    void* d_out = out;
+    if (!on_device) GA_CHECK(c->scratch_get("fr_vec_out", n * 32, &d_out));
+    GA_DISPATCH_CURVE(curve, GA_CHECK(util_fr_vec_mul<C>(c, sa.dev, sb.dev, n, d_out)));
+    if (!on_device) GA_HIP_CHECK(hipMemcpyAsync(out, d_out, n * 32, hipMemcpyDeviceToHost, c->stream));
+    GA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return GA_OK;
+}
+
 int ga_generator_mul(int curve, int group, const void* k, void* out_jac) {
     GA_DISPATCH_CURVE(curve, GA_DISPATCH_GROUP(group, {
                           typedef typename GroupField<C, G>::F F;

@@ -198,6 +198,7 @@ template <class C> int kzg_domain_divide(Ctx* ctx, const void* d_poly, uint64_t 
 template <class C, int G> int util_gen_bases(Ctx* ctx, uint64_t seed, size_t n, void* d_bases, void* d_dlogs);
 template <class C> int util_gen_scalars(Ctx* ctx, uint64_t seed, size_t n, void* d_scalars);
 template <class C> int util_fr_dot(Ctx* ctx, const void* d_a, const void* d_b, size_t n, void* h_out);
+template <class C> int util_fr_vec_mul(Ctx* ctx, const void* d_a, const void* d_b, size_t n, void* d_out);
 template <class C> int util_gather_fr(Ctx* ctx, void* d_dst, const void* d_src, const uint32_t* d_idx, size_t n);
 int util_microbench(Ctx* ctx, char* buf, size_t cap);
 

@@ -63,6 +63,15 @@ fr_dot_kernel(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, ui
     if (threadIdx.x == 0) store_fe(partial + blockIdx.x * 8, acc);
 }
 
+// out[i] = a[i] * b[i]  (fr.Vector.Mul; all Montgomery)
+template <class C>
+__global__ void fr_vec_mul_kernel(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, uint64_t n, uint32_t* __restrict__ out) {
+    typedef typename C::FrP P;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    store_fe(out + i * 8, mul(load_fe<P>(a + i * 8), load_fe<P>(b + i * 8)));
+}
+
 template <class C>
 __global__ void gather_fr_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, const uint32_t* __restrict__ idx,
                                  uint64_t n) {
@@ -113,6 +122,15 @@ int util_fr_dot(Ctx* ctx, const void* d_a, const void* d_b, size_t n, void* h_ou
         acc = add(acc, v);
     }
     memcpy(h_out, acc.l, 32);
+    return GA_OK;
+}
+
+template <class C>
+int util_fr_vec_mul(Ctx* ctx, const void* d_a, const void* d_b, size_t n, void* d_out) {
+    if (n == 0) return GA_OK;
+    hipLaunchKernelGGL((fr_vec_mul_kernel<C>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)d_a,
+                       (const uint32_t*)d_b, (uint64_t)n, (uint32_t*)d_out);
+    GA_KERNEL_CHECK();
     return GA_OK;
 }
 

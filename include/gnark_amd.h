@@ -182,6 +182,9 @@ int ga_fr_linear_combination(ga_ctx* ctx, int curve, uint64_t n, int k, const vo
                              int on_device);
 /* p(point) of a canonical-form polynomial (iop.Polynomial.Evaluate, evaluateBlinded prove.go:1186-1215). */
 int ga_fr_poly_evaluate(ga_ctx* ctx, int curve, const void* poly, uint64_t n, const void* point, void* value_out, int on_device);
+/* out[i] = a[i] * b[i] over fr (fr.Vector.Mul of gnark-crypto; ICICLE's vecOps Mul of icicle.go:1453-1458).  All host or all
+ * device pointers (on_device); out may alias a or b. */
+int ga_fr_vec_mul(ga_ctx* ctx, int curve, const void* a, const void* b, size_t n, void* out, int on_device);
 /* fr.BatchInvert in place (zeros stay zero): the batchInvert of prove.go:1134-1147 */
 int ga_fr_batch_invert(ga_ctx* ctx, int curve, void* v, uint64_t n, int on_device);
 

@@ -622,6 +622,28 @@ int oracle_fr_mul(int curve, const u64* a, const u64* b, size_t n, u64* out) {
     return 0;
 }
 
+int oracle_fr_add(int curve, const u64* a, const u64* b, size_t n, u64* out) {
+    const field_t* f = &CURVES[curve].fr;
+    for (size_t i = 0; i < n; i++) fe_add(f, out + 4 * i, a + 4 * i, b + 4 * i);
+    return 0;
+}
+int oracle_fr_sub(int curve, const u64* a, const u64* b, size_t n, u64* out) {
+    const field_t* f = &CURVES[curve].fr;
+    for (size_t i = 0; i < n; i++) fe_sub(f, out + 4 * i, a + 4 * i, b + 4 * i);
+    return 0;
+}
+/* out[i] = first * base^i (all Montgomery) */
+int oracle_fr_powers(int curve, const u64* base, const u64* first, size_t n, u64* out) {
+    const field_t* f = &CURVES[curve].fr;
+    u64 cur[4];
+    fe_copy(f, cur, first);
+    for (size_t i = 0; i < n; i++) {
+        fe_copy(f, out + 4 * i, cur);
+        fe_mul(f, cur, cur, base);
+    }
+    return 0;
+}
+
 /* p(x) by Horner; coefficients and x in Montgomery form, result Montgomery */
 int oracle_fr_horner(int curve, const u64* coeffs, size_t n, const u64* x, u64* out) {
     const field_t* f = &CURVES[curve].fr;
@@ -652,51 +674,160 @@ static void root_of_unity(const curve_t* cv, u64 n, int inverse, u64* w) {
     fe_copy(&cv->fr, w, inverse ? cv->fr_root_inv : cv->fr_root);
     for (int k = 0; k < cv->adicity - ilog2(n); k++) fe_mul(&cv->fr, w, w, w);
 }
-/* a: n Montgomery elements, in place.  direction 0 fwd / 1 inv; decimation 0 DIF / 1 DIT; on_coset. */
-int oracle_fft(int curve, u64* a, u64 n, int direction, int decimation, int on_coset) {
+/* ---- parallel-for over [0, total) on `nthreads` pthreads (the checker may use the host's cores for the BASELINE-size
+ * cases; nthreads <= 1 runs inline) ---- */
+typedef void (*par_body)(void* ctx, u64 lo, u64 hi, int tid);
+typedef struct {
+    par_body fn;
+    void* ctx;
+    u64 lo, hi;
+    int tid;
+} par_arg;
+static void* par_tramp(void* p) {
+    par_arg* a = (par_arg*)p;
+    a->fn(a->ctx, a->lo, a->hi, a->tid);
+    return NULL;
+}
+static void par_for(int nthreads, u64 total, par_body fn, void* ctx) {
+    if (nthreads > 64) nthreads = 64;
+    if (nthreads <= 1 || total < 4096) {
+        fn(ctx, 0, total, 0);
+        return;
+    }
+    pthread_t th[64];
+    par_arg args[64];
+    u64 chunk = (total + nthreads - 1) / nthreads;
+    int used = 0;
+    for (int t = 0; t < nthreads; t++) {
+        u64 lo = (u64)t * chunk, hi = lo + chunk > total ? total : lo + chunk;
+        if (lo >= hi) break;
+        args[t] = (par_arg){fn, ctx, lo, hi, t};
+        pthread_create(&th[t], NULL, par_tramp, &args[t]);
+        used++;
+    }
+    for (int t = 0; t < used; t++) pthread_join(th[t], NULL);
+}
+
+typedef struct {
+    const field_t* f;
+    u64* a;
+    const u64* tw;
+    int logn, s, dit;
+} fft_stage_ctx;
+static void fft_stage_body(void* p, u64 lo, u64 hi, int tid) {
+    (void)tid;
+    fft_stage_ctx* c = (fft_stage_ctx*)p;
+    const field_t* f = c->f;
+    const int s = c->s;
+    const u64 h = (u64)1 << s;
+    for (u64 t = lo; t < hi; t++) { /* butterfly t: pair (base + j, base + j + h) */
+        u64 j = t & (h - 1), base = (t >> s) << (s + 1);
+        u64 *x = c->a + 4 * (base + j), *y = c->a + 4 * (base + j + h);
+        const u64* w = c->tw + 4 * (j << (c->logn - 1 - s));
+        if (!c->dit) {
+            u64 d[4];
+            fe_sub(f, d, x, y);
+            fe_add(f, x, x, y);
+            fe_mul(f, y, d, w);
+        } else {
+            u64 v[4], x0[4];
+            fe_mul(f, v, y, w);
+            fe_copy(f, x0, x);
+            fe_add(f, x, x0, v);
+            fe_sub(f, y, x0, v);
+        }
+    }
+}
+typedef struct {
+    const field_t* f;
+    u64* a;
+    const u64 *g, *ginv; /* ratio of the geometric progression and its inverse */
+    const u64* first;    /* value at exponent 0 */
+    int logn, bitrev;
+} fft_scale_ctx;
+/* a[i] *= first * g^(i or bitrev(i)) */
+static void fft_scale_body(void* p, u64 lo, u64 hi, int tid) {
+    (void)tid;
+    fft_scale_ctx* c = (fft_scale_ctx*)p;
+    const field_t* f = c->f;
+    if (!c->bitrev) {
+        u64 cur[4], e[1] = {lo};
+        fe_pow(f, cur, c->g, e, 1);
+        fe_mul(f, cur, cur, c->first);
+        for (u64 i = lo; i < hi; i++) {
+            fe_mul(f, c->a + 4 * i, c->a + 4 * i, cur);
+            fe_mul(f, cur, cur, c->g);
+        }
+    } else {
+        /* slot i holds natural index rev(i).  i -> i+1 flips t trailing ones to zero and sets bit t, i.e. in rev() it clears
+         * the top t bits and sets bit logn-1-t: g^rev(i+1) = g^rev(i) * D[t], D[t] = g^(2^(logn-1-t)) * prod_{k<t} g^-(2^(logn-1-k)) */
+        u64 pw[64][4], ipw[64][4], D[64][4], cur[4];
+        fe_copy(f, pw[0], c->g);
+        fe_copy(f, ipw[0], c->ginv);
+        for (int k = 1; k < c->logn; k++) {
+            fe_mul(f, pw[k], pw[k - 1], pw[k - 1]);
+            fe_mul(f, ipw[k], ipw[k - 1], ipw[k - 1]);
+        }
+        for (int t = 0; t < c->logn; t++) {
+            fe_copy(f, D[t], pw[c->logn - 1 - t]);
+            for (int k = 0; k < t; k++) fe_mul(f, D[t], D[t], ipw[c->logn - 1 - k]);
+        }
+        u64 j = bitrev_u64(lo, c->logn);
+        fe_copy(f, cur, c->first);
+        for (int k = 0; k < c->logn; k++)
+            if ((j >> k) & 1) fe_mul(f, cur, cur, pw[k]);
+        for (u64 i = lo; i < hi; i++) {
+            fe_mul(f, c->a + 4 * i, c->a + 4 * i, cur);
+            int t = 0;
+            while (t < c->logn && ((i >> t) & 1)) t++;
+            if (t < c->logn) fe_mul(f, cur, cur, D[t]);
+        }
+    }
+}
+typedef struct {
+    const field_t* f;
+    u64* tw;
+    const u64* w;
+} fft_tw_ctx;
+static void fft_tw_body(void* p, u64 lo, u64 hi, int tid) {
+    (void)tid;
+    fft_tw_ctx* c = (fft_tw_ctx*)p;
+    u64 cur[4], e[1] = {lo};
+    fe_pow(c->f, cur, c->w, e, 1);
+    for (u64 i = lo; i < hi; i++) {
+        fe_copy(c->f, c->tw + 4 * i, cur);
+        fe_mul(c->f, cur, cur, c->w);
+    }
+}
+
+/* a: n Montgomery elements, in place.  direction 0 fwd / 1 inv; decimation 0 DIF / 1 DIT; on_coset.
+ * In-place radix-2 with the conventions of gnark-crypto's fft.Domain: DIF natural -> bit-reversed,
+ * DIT bit-reversed -> natural, FFTInverse includes 1/n, OnCoset pre-multiplies coefficient j by g^j (forward) and
+ * post-multiplies by g^-j (inverse).  Every stage's butterflies are independent: nthreads > 1 spreads them. */
+int oracle_fft_mt(int curve, u64* a, u64 n, int direction, int decimation, int on_coset, int nthreads) {
     const curve_t* cv = &CURVES[curve];
     const field_t* f = &cv->fr;
     const int logn = ilog2(n);
     if (((u64)1 << logn) != n || logn > cv->adicity) return -1;
+    if (n == 1) return 0; /* the size-1 transform is the identity in every mode (g^0 = 1, 1/n = 1) */
     u64 w[4];
     root_of_unity(cv, n, direction, w);
     u64* tw = (u64*)malloc(32 * (n / 2 + 1));
-    fe_copy(f, tw, f->one);
-    for (u64 i = 1; i < n / 2; i++) fe_mul(f, tw + 4 * i, tw + 4 * (i - 1), w);
-    /* natural index of storage slot i */
-#define BITREV(i) bitrev_u64((u64)(i), logn)
-    if (direction == 0 && on_coset) { /* pre-scale coefficient j by g^j */
-        u64* gp = (u64*)malloc(32 * n);
-        fe_copy(f, gp, f->one);
-        for (u64 i = 1; i < n; i++) fe_mul(f, gp + 4 * i, gp + 4 * (i - 1), cv->fr_gen);
-        for (u64 i = 0; i < n; i++) {
-            u64 j = decimation == 0 ? i : BITREV(i);
-            fe_mul(f, a + 4 * i, a + 4 * i, gp + 4 * j);
-        }
-        free(gp);
+    fft_tw_ctx tc = {f, tw, w};
+    par_for(nthreads, n / 2, fft_tw_body, &tc);
+    if (direction == 0 && on_coset) { /* pre-scale coefficient j by g^j; DIT input sits at slot bitrev(j) */
+        fft_scale_ctx sc = {f, a, cv->fr_gen, cv->fr_gen_inv, f->one, logn, decimation == 1};
+        par_for(nthreads, n, fft_scale_body, &sc);
     }
     if (decimation == 0) { /* DIF: natural -> bit-reversed */
         for (int s = logn - 1; s >= 0; s--) {
-            u64 h = (u64)1 << s;
-            for (u64 base = 0; base < n; base += 2 * h)
-                for (u64 j = 0; j < h; j++) {
-                    u64 *x = a + 4 * (base + j), *y = a + 4 * (base + j + h), d[4];
-                    fe_sub(f, d, x, y);
-                    fe_add(f, x, x, y);
-                    fe_mul(f, y, d, tw + 4 * (j << (logn - 1 - s)));
-                }
+            fft_stage_ctx st = {f, a, tw, logn, s, 0};
+            par_for(nthreads, n / 2, fft_stage_body, &st);
         }
     } else { /* DIT: bit-reversed -> natural */
         for (int s = 0; s < logn; s++) {
-            u64 h = (u64)1 << s;
-            for (u64 base = 0; base < n; base += 2 * h)
-                for (u64 j = 0; j < h; j++) {
-                    u64 *x = a + 4 * (base + j), *y = a + 4 * (base + j + h), v[4], x0[4];
-                    fe_mul(f, v, y, tw + 4 * (j << (logn - 1 - s)));
-                    fe_copy(f, x0, x);
-                    fe_add(f, x, x0, v);
-                    fe_sub(f, y, x0, v);
-                }
+            fft_stage_ctx st = {f, a, tw, logn, s, 1};
+            par_for(nthreads, n / 2, fft_stage_body, &st);
         }
     }
     if (direction == 1) {
@@ -705,20 +836,109 @@ int oracle_fft(int curve, u64* a, u64 n, int direction, int decimation, int on_c
         fe_inv(f, two, two);
         fe_copy(f, ninv, f->one);
         for (int k = 0; k < logn; k++) fe_mul(f, ninv, ninv, two);
-        if (!on_coset) {
-            for (u64 i = 0; i < n; i++) fe_mul(f, a + 4 * i, a + 4 * i, ninv);
-        } else {
-            u64* gp = (u64*)malloc(32 * n);
-            fe_copy(f, gp, ninv);
-            for (u64 i = 1; i < n; i++) fe_mul(f, gp + 4 * i, gp + 4 * (i - 1), cv->fr_gen_inv);
-            for (u64 i = 0; i < n; i++) {
-                u64 j = decimation == 1 ? i : BITREV(i); /* DIF output is bit-reversed */
-                fe_mul(f, a + 4 * i, a + 4 * i, gp + 4 * j);
-            }
-            free(gp);
-        }
+        /* 1/n, and on a coset g^-j with j the natural index of the slot (DIF output is bit-reversed) */
+        fft_scale_ctx sc = {f, a, on_coset ? cv->fr_gen_inv : f->one, on_coset ? cv->fr_gen : f->one, ninv, logn, on_coset && decimation == 0};
+        par_for(nthreads, n, fft_scale_body, &sc);
     }
     free(tw);
+    return 0;
+}
+int oracle_fft(int curve, u64* a, u64 n, int direction, int decimation, int on_coset) {
+    return oracle_fft_mt(curve, a, n, direction, decimation, on_coset, 1);
+}
+
+/* ---- O(n) evaluation checkers for the BASELINE-size cases (SURVEY 8c "oracle self-checks") ---------------------------------
+ * P(x) from the values of P on the size-n domain, barycentric form:  P(x) = (x^n - 1)/n * sum_i v_i * w^i / (x - w^i),
+ * x outside the domain.  k vectors share the weights.  All values Montgomery. */
+typedef struct {
+    const field_t* f;
+    const u64* const* vecs;
+    int k;
+    const u64 *w, *x;
+    u64* partial; /* [64][k][4] */
+} bary_ctx;
+static void bary_body(void* p, u64 lo, u64 hi, int tid) {
+    bary_ctx* c = (bary_ctx*)p;
+    const field_t* f = c->f;
+    enum { BLK = 1024 };
+    u64 (*wp)[4] = malloc(sizeof(u64[4]) * BLK), (*den)[4] = malloc(sizeof(u64[4]) * BLK), (*pre)[4] = malloc(sizeof(u64[4]) * BLK);
+    u64 cur[4], e[1] = {lo};
+    fe_pow(f, cur, c->w, e, 1);
+    u64* acc = c->partial + (size_t)tid * c->k * 4;
+    memset(acc, 0, 32 * c->k);
+    for (u64 b0 = lo; b0 < hi; b0 += BLK) {
+        const u64 cnt = hi - b0 < BLK ? hi - b0 : BLK;
+        u64 run[4], inv[4];
+        fe_copy(f, run, f->one);
+        for (u64 i = 0; i < cnt; i++) { /* w^i, x - w^i, prefix products */
+            fe_copy(f, wp[i], cur);
+            fe_sub(f, den[i], c->x, cur);
+            fe_copy(f, pre[i], run);
+            fe_mul(f, run, run, den[i]);
+            fe_mul(f, cur, cur, c->w);
+        }
+        fe_inv(f, inv, run);
+        for (u64 i = cnt; i-- > 0;) { /* Montgomery's trick backwards */
+            u64 di[4], t[4];
+            fe_mul(f, di, inv, pre[i]);      /* 1/(x - w^i) */
+            fe_mul(f, inv, inv, den[i]);
+            fe_mul(f, di, di, wp[i]);        /* w^i/(x - w^i) */
+            for (int v = 0; v < c->k; v++) {
+                fe_mul(f, t, di, c->vecs[v] + 4 * (b0 + i));
+                fe_add(f, acc + 4 * v, acc + 4 * v, t);
+            }
+        }
+    }
+    free(wp); free(den); free(pre);
+}
+int oracle_fr_eval_lagrange(int curve, const u64* const* vecs, int k, u64 n, const u64* x, u64* out, int nthreads) {
+    const curve_t* cv = &CURVES[curve];
+    const field_t* f = &cv->fr;
+    const int logn = ilog2(n);
+    if (((u64)1 << logn) != n || logn > cv->adicity || k < 1 || k > 16) return -1;
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 64) nthreads = 64;
+    u64 w[4];
+    root_of_unity(cv, n, 0, w);
+    u64* partial = (u64*)calloc((size_t)64 * k * 4, 8);
+    bary_ctx c = {f, vecs, k, w, x, partial};
+    par_for(nthreads, n, bary_body, &c);
+    /* (x^n - 1)/n */
+    u64 xn[4], ninv[4], two[4], e[1] = {n};
+    fe_pow(f, xn, x, e, 1);
+    fe_sub(f, xn, xn, f->one);
+    fe_add(f, two, f->one, f->one);
+    fe_inv(f, two, two);
+    fe_copy(f, ninv, f->one);
+    for (int b = 0; b < logn; b++) fe_mul(f, ninv, ninv, two);
+    fe_mul(f, xn, xn, ninv);
+    for (int v = 0; v < k; v++) {
+        u64 acc[4] = {0};
+        for (int t = 0; t < 64; t++) fe_add(f, acc, acc, partial + ((size_t)t * k + v) * 4);
+        fe_mul(f, out + 4 * v, acc, xn);
+    }
+    free(partial);
+    return 0;
+}
+/* P(x) for coefficients stored in BIT-REVERSED order (what computeH returns and what pk.G1.Z is indexed by): slot j holds the
+ * coefficient of x^rev(j) and rev(j' + (n/2) b) = b + 2 rev'(j'), so  P(x) = sum_j' (c[j'] + x c[j' + n/2]) (x^2)^rev'(j'):
+ * fold the upper half into the lower one and square x, log n times; n - 1 multiplications in all. */
+int oracle_fr_eval_bitrev(int curve, const u64* coeffs, u64 n, const u64* x, u64* out) {
+    const field_t* f = &CURVES[curve].fr;
+    if (n == 0 || (n & (n - 1))) return -1;
+    u64* v = (u64*)malloc(32 * n);
+    memcpy(v, coeffs, 32 * n);
+    u64 xs[4], t[4];
+    fe_copy(f, xs, x);
+    for (u64 h = n / 2; h >= 1; h >>= 1) {
+        for (u64 j = 0; j < h; j++) {
+            fe_mul(f, t, v + 4 * (j + h), xs);
+            fe_add(f, v + 4 * j, v + 4 * j, t);
+        }
+        fe_mul(f, xs, xs, xs);
+    }
+    memcpy(out, v, 32);
+    free(v);
     return 0;
 }
 
@@ -843,7 +1063,7 @@ int oracle_plonk_quotient(int curve, u64 n, int nb_bsb, const u64* const* polys,
 }
 
 /* computeH, prove.go:346-389.  a,b,c: m elements; h_out: n elements (bit-reversed coefficient order). */
-int oracle_compute_h(int curve, const u64* a, const u64* b, const u64* c, u64 m, u64 n, u64* h_out) {
+int oracle_compute_h_mt(int curve, const u64* a, const u64* b, const u64* c, u64 m, u64 n, u64* h_out, int nthreads) {
     const curve_t* cv = &CURVES[curve];
     const field_t* f = &cv->fr;
     u64* v[3];
@@ -851,9 +1071,9 @@ int oracle_compute_h(int curve, const u64* a, const u64* b, const u64* c, u64 m,
     for (int k = 0; k < 3; k++) {
         v[k] = (u64*)calloc(n, 32);
         memcpy(v[k], src[k], 32 * m);
-        oracle_fft(curve, v[k], n, 1, 0, 0); /* FFTInverse(DIF) */
+        oracle_fft_mt(curve, v[k], n, 1, 0, 0, nthreads); /* FFTInverse(DIF) */
     }
-    for (int k = 0; k < 3; k++) oracle_fft(curve, v[k], n, 0, 1, 1); /* FFT(DIT, OnCoset) */
+    for (int k = 0; k < 3; k++) oracle_fft_mt(curve, v[k], n, 0, 1, 1, nthreads); /* FFT(DIT, OnCoset) */
     u64 den[4], e[1] = {n};
     fe_pow(f, den, cv->fr_gen, e, 1);
     fe_sub(f, den, den, f->one);
@@ -864,10 +1084,14 @@ int oracle_compute_h(int curve, const u64* a, const u64* b, const u64* c, u64 m,
         fe_sub(f, t, t, v[2] + 4 * i);
         fe_mul(f, v[0] + 4 * i, t, den);
     }
-    oracle_fft(curve, v[0], n, 1, 0, 1); /* FFTInverse(DIF, OnCoset) */
+    oracle_fft_mt(curve, v[0], n, 1, 0, 1, nthreads); /* FFTInverse(DIF, OnCoset) */
     memcpy(h_out, v[0], 32 * n);
     for (int k = 0; k < 3; k++) free(v[k]);
     return 0;
+}
+
+int oracle_compute_h(int curve, const u64* a, const u64* b, const u64* c, u64 m, u64 n, u64* h_out) {
+    return oracle_compute_h_mt(curve, a, b, c, m, n, h_out, 1);
 }
 
 /* ---------------- Groth16 Prove (no commitments), prove.go:130-315 ------------------------------------------- */
@@ -897,7 +1121,7 @@ int oracle_groth16_prove(const oracle_pk* pk, const u64* w, const u64* a, const 
     const field_t* fr = &cv->fr;
     tower_t t1 = tower_of(cu, 0), t2 = tower_of(cu, 1);
     u64* h = (u64*)malloc(32 * pk->n);
-    oracle_compute_h(cu, a, b, c, m, pk->n, h);
+    oracle_compute_h_mt(cu, a, b, c, m, pk->n, h, nthreads);
     u64* wa = (u64*)malloc(32 * (pk->len_a + 1));
     u64* wb = (u64*)malloc(32 * (pk->len_b + 1));
     u64 ja = 0, jb = 0;

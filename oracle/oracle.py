@@ -118,6 +118,28 @@ def fr_mul(curve, a, b):
     return out
 
 
+def fr_add(curve, a, b):
+    a, b = _u64(a).reshape(-1, 4), _u64(b).reshape(-1, 4)
+    out = np.zeros_like(a)
+    dll().oracle_fr_add(curve, _p(a), _p(b), C.c_size_t(a.shape[0]), _p(out))
+    return out
+
+
+def fr_sub(curve, a, b):
+    a, b = _u64(a).reshape(-1, 4), _u64(b).reshape(-1, 4)
+    out = np.zeros_like(a)
+    dll().oracle_fr_sub(curve, _p(a), _p(b), C.c_size_t(a.shape[0]), _p(out))
+    return out
+
+
+def fr_powers(curve, base_mont, first_mont, n):
+    """[first * base^i for i < n] (Montgomery)"""
+    b, f = _u64(base_mont).reshape(4), _u64(first_mont).reshape(4)
+    out = np.zeros((n, 4), dtype=np.uint64)
+    dll().oracle_fr_powers(curve, _p(b), _p(f), C.c_size_t(n), _p(out))
+    return out
+
+
 def fr_horner(curve, coeffs_mont, x_mont):
     c, x = _u64(coeffs_mont).reshape(-1, 4), _u64(x_mont).reshape(4)
     out = np.zeros(4, dtype=np.uint64)
@@ -125,9 +147,31 @@ def fr_horner(curve, coeffs_mont, x_mont):
     return out
 
 
-def fft(curve, a, direction, decimation, on_coset):
+def fft(curve, a, direction, decimation, on_coset, nthreads=1):
     out = _u64(a).reshape(-1, 4).copy()
-    rc = dll().oracle_fft(curve, _p(out), C.c_uint64(out.shape[0]), direction, decimation, int(on_coset))
+    rc = dll().oracle_fft_mt(curve, _p(out), C.c_uint64(out.shape[0]), direction, decimation, int(on_coset), int(nthreads))
+    assert rc == 0
+    return out
+
+
+def fr_eval_lagrange(curve, vecs, x_mont, nthreads=1):
+    """[P_v(x)] for polynomials given by their values on the size-n domain (barycentric formula, O(n), x outside the domain)"""
+    arrs = [_u64(v).reshape(-1, 4) for v in vecs]
+    n = arrs[0].shape[0]
+    assert all(a.shape[0] == n for a in arrs)
+    ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+    x = _u64(x_mont).reshape(4)
+    out = np.zeros((len(arrs), 4), dtype=np.uint64)
+    rc = dll().oracle_fr_eval_lagrange(curve, ptrs, len(arrs), C.c_uint64(n), _p(x), _p(out), int(nthreads))
+    assert rc == 0
+    return out
+
+
+def fr_eval_bitrev(curve, coeffs_bitrev, x_mont):
+    """P(x) for coefficients stored in bit-reversed order (computeH's output order)"""
+    c, x = _u64(coeffs_bitrev).reshape(-1, 4), _u64(x_mont).reshape(4)
+    out = np.zeros(4, dtype=np.uint64)
+    rc = dll().oracle_fr_eval_bitrev(curve, _p(c), C.c_uint64(c.shape[0]), _p(x), _p(out))
     assert rc == 0
     return out
 
@@ -145,10 +189,10 @@ def plonk_quotient(curve, n, polys, bl, br, bo, bz, alpha, beta, gamma, nb_bsb=0
     return out
 
 
-def compute_h(curve, a, b, c, n):
+def compute_h(curve, a, b, c, n, nthreads=1):
     a, b, c = (_u64(x).reshape(-1, 4) for x in (a, b, c))
     out = np.zeros((n, 4), dtype=np.uint64)
-    dll().oracle_compute_h(curve, _p(a), _p(b), _p(c), C.c_uint64(a.shape[0]), C.c_uint64(n), _p(out))
+    dll().oracle_compute_h_mt(curve, _p(a), _p(b), _p(c), C.c_uint64(a.shape[0]), C.c_uint64(n), _p(out), int(nthreads))
     return out
 
 

@@ -625,3 +625,30 @@ def test_emu_fr_linear_combination(emu_ctx, c, n=300):
         assert arr_to_fr(c, got.reshape(1, 4))[0] == pyref._poly_eval(poly, z, mod)
     with pytest.raises(Exception, match="1..16"):
         plonk.LinearCombination(emu_ctx, c.name, fr_to_arr(c, [1] * 17), [fr_to_arr(c, [1, 2])] * 17)
+
+
+# ---- the BASELINE-size checkers (oracle/checkers.py) at emulation sizes ------------------------------------------------------
+import checkers
+from checkers import check_compute_h_identity, check_groth16_known_dlogs, check_plonk_quotient_identity  # noqa: F401,E402 (reused by test_gpu_parity)
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_emu_groth16_known_dlogs_checker(emu_ctx, c):
+    """the full-size checker itself, at 2^7 under the emulation, cross-checked against the C oracle's prover"""
+    check_groth16_known_dlogs(emu_ctx, c, 7, nthreads=4, also_oracle_prover=True)
+
+
+def test_emu_fr_vec_mul(emu_ctx):
+    c = BN254
+    rng = pyref.Xoshiro(3)
+    a = fr_to_arr(c, [rng.field(c.r) for _ in range(100)])
+    b = fr_to_arr(c, [rng.field(c.r) for _ in range(100)])
+    out = np.zeros_like(a)
+    emu_ctx.lib.check(emu_ctx.lib.ga_fr_vec_mul(emu_ctx.handle, c.cid, a.ctypes.data, b.ctypes.data, 100, out.ctypes.data, 0))
+    assert np.array_equal(out, oracle.fr_mul(c.cid, a, b))
+
+
+@pytest.mark.parametrize("pinned", [False, True], ids=["plain", "pinned"])
+def test_emu_plonk_quotient_identity_checker(emu_ctx, pinned):
+    """the full-size PLONK checker at n = 2^6 under the emulation"""
+    check_plonk_quotient_identity(emu_ctx, BN254, 6, nthreads=2, pinned=pinned)

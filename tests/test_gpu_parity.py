@@ -548,3 +548,66 @@ def test_compute_h_2_20_polynomial_identity(gpu_ctx):
 
 def test_groth16_sharded_key_on_device(gpu_ctx):
     cases.test_emu_groth16_sharded_key_single_process(gpu_ctx, 3)
+
+
+# ---- BASELINE configs 3, 4, 5 at their STATED sizes ("no parity check at their stated size") ------------------------
+import os as _os
+
+_NT = max(1, min(64, _os.cpu_count() or 1))
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_groth16_2_24_known_dlogs(gpu_ctx, c):
+    """configs 3 (BN254) and 4 (BLS12-381, single-GPU leg): Groth16 Prove at 2^24 constraints on the known-dlog synthetic key with
+    C = A o B: Ar, Bs, Krs and the four pre-randomisation sums equal the points whose exponents the CPU oracle
+    computes with O(n) dot products; h (2^24 coefficients) satisfies A(x)B(x) - C(x) = H(x)(x^n - 1) with A, B, C evaluated by
+    the oracle's barycentric formula.  Exercises the c = 22 shared-bucket plans, the Fe2 table kernel, the shared witness sort
+    and the 3-pass NTT at the judged size."""
+    cases.check_groth16_known_dlogs(gpu_ctx, c, 24, nthreads=_NT, proofs=2)
+
+
+@pytest.mark.parametrize("c,group", [(BN254, 1), (BLS12_381, 0), (BLS12_381, 1)], ids=["bn254-G2", "bls12-381-G1", "bls12-381-G2"])
+def test_msm_2_24_other_shapes_dlog(gpu_ctx, c, group):
+    """the MSM shapes of configs 3/4 besides BN254 G1, 2^24 points each, raw bases (ga_msm) and pinned table (ga_msm_table_run)"""
+    n = 1 << 24
+    bases, dlogs, scal = _device_inputs(gpu_ctx, c, group, n, 0x5EED0100 + 16 * c.cid + group)
+    S, K = scal.to_host((n, 4)), dlogs.to_host((n, 4))
+    dlogs.free()
+    want = _expect_from_dlogs(c, group, S, K)
+    del S, K
+    raw = oracle.jac_to_affine(c.cid, group, ecc.MultiExp(gpu_ctx, c.name, group, bases, scal, n=n))
+    assert np.array_equal(raw, want)
+    table = ecc.PrecomputedBases(gpu_ctx, c.name, group, bases, n=n)
+    try:
+        got = oracle.jac_to_affine(c.cid, group, table.MultiExp(scal))
+    finally:
+        table.free()
+    assert np.array_equal(got, want)
+    for b in (bases, scal):
+        b.free()
+
+
+@pytest.mark.parametrize("c,modes", [(BN254, ((0, 0, 1), (1, 1, 1), (1, 0, 0))), (BLS12_381, ((0, 1, 1),))], ids=["bn254", "bls12-381"])
+def test_fft_2_24_vs_c_oracle(gpu_ctx, c, modes):
+    """2^24-point transforms (3 HBM passes) against the C oracle's radix-2 transform, element for element; modes are
+    (inverse, decimation, on_coset) -- the ones computeH uses plus a plain inverse"""
+    n = 1 << 24
+    scal = gpu_ctx.malloc(n * 32)
+    gpu_ctx.lib.check(gpu_ctx.lib.ga_gen_scalars(gpu_ctx.handle, c.cid, 2424, n, scal.ptr))
+    a = scal.to_host((n, 4))
+    scal.free()
+    d = fft.Domain(gpu_ctx, c.name, n)
+    try:
+        for inv, dec, coset in modes:
+            got = (d.FFTInverse if inv else d.FFT)(a, dec, bool(coset))
+            want = oracle.fft(c.cid, a, inv, dec, bool(coset), nthreads=_NT)
+            assert np.array_equal(got, want), (inv, dec, coset)
+    finally:
+        d.close()
+
+
+@pytest.mark.parametrize("pinned", [False, True], ids=["plain", "pinned"])
+def test_plonk_quotient_2_22_identity(gpu_ctx, pinned):
+    """config 5 at its stated size (n = 2^22 gates, 4n = 2^24): grand product + quotient on the device, identity at a random
+    point with every polynomial evaluated by the CPU oracle from its values"""
+    cases.check_plonk_quotient_identity(gpu_ctx, BN254, 22, nthreads=_NT, pinned=pinned)
