@@ -55,9 +55,9 @@ def check_groth16_known_dlogs(ctx, c, logn, nthreads=1, seed=0x5EED0005, also_or
     exp = synth.expected_exponents(inst, h, lambda a, b: oracle.fr_dot(c.cid, a, b))
     pk = inst.proving_key(ctx, **pk_kw)
     try:
-        for _ in range(proofs):
+        part = groth16.ProvePartial(pk, sol, inst.nb_public)
+        for _ in range(proofs):   # repeated proofs reuse the context's scratch: the last one is the one compared
             proof = groth16.Prove(pk, sol, inst.nb_public, inst.r, inst.s)
-            part = groth16.ProvePartial(pk, sol, inst.nb_public) if _ == 0 else None
     finally:
         pk.FreeGPUResources()
     pt = lambda group, k: oracle.jac_to_affine(c.cid, group, oracle.generator_mul(c.cid, group, k))
