@@ -97,9 +97,24 @@ _PROTOS = {
     "ga_fr_batch_invert": (C.c_int, [_P, C.c_int, _P, C.c_uint64, C.c_int]),
     "ga_g16_pk_create": (C.c_int, [_P, C.POINTER(G16Key), C.POINTER(_P)]),
     "ga_g16_pk_destroy": (None, [_P]),
+    "ga_g16_builder_create": (C.c_int, [_P, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
+    "ga_g16_builder_reserve": (C.c_int, [_P, C.c_int, C.c_uint64]),
+    "ga_g16_builder_append": (C.c_int, [_P, C.c_int, _P, C.c_uint64]),
+    "ga_g16_builder_set_point": (C.c_int, [_P, C.c_int, _P]),
+    "ga_g16_builder_set_infinity": (C.c_int, [_P, C.c_int, _P, C.c_uint64]),
+    "ga_g16_builder_add_commitment_key": (C.c_int, [_P, _P, _P, C.c_uint64]),
+    "ga_g16_builder_set_k_remove": (C.c_int, [_P, _P, C.c_uint64]),
+    "ga_g16_builder_finish": (C.c_int, [_P, C.c_int32, C.POINTER(_P)]),
+    "ga_g16_builder_destroy": (None, [_P]),
     "ga_g16_prove": (C.c_int, [_P, _P, _P, _P, _P, C.c_uint64, C.c_uint64, _P, _P, _P]),
     "ga_g16_prove_partial": (C.c_int, [_P, _P, _P, _P, _P, C.c_uint64, C.c_uint64, _P]),
     "ga_g16_finish": (C.c_int, [_P, _P, _P, _P, _P]),
+    "ga_g16_shard_layout": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "ga_g16_witness_partial": (C.c_int, [_P, _P, C.c_uint64, _P]),
+    "ga_g16_h_chain": (C.c_int, [_P, _P, C.c_uint64, _P]),
+    "ga_g16_h_combine": (C.c_int, [_P, _P, _P, _P]),
+    "ga_g16_z_partial": (C.c_int, [_P, _P, _P]),
+    "ga_g16_prove_multi": (C.c_int, [C.POINTER(_P), C.c_uint32, _P, _P, _P, _P, C.c_uint64, C.c_uint64, _P, _P, _P]),
     "ga_g16_proof_marshal": (C.c_int, [C.c_int, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "ga_g16_commit": (C.c_int, [_P, C.c_uint32, _P, C.c_uint64, _P, _P]),
     "ga_g16_fold_pok": (C.c_int, [C.c_int, _P, C.c_uint64, _P, _P]),

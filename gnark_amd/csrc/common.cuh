@@ -166,6 +166,8 @@ struct Domain;   // ntt.cuh
 template <class C> int ntt_domain_new(Ctx* ctx, uint64_t n, Domain** out);
 template <class C> int ntt_domain_fft(Domain* d, void* d_data, int direction, int decimation, int on_coset);
 template <class C> int ntt_domain_compute_h(Domain* d, void* d_a, void* d_b, void* d_c);
+template <class C> int ntt_domain_h_chain(Domain* d, void* d_v);                                        // v <- FFT_coset(iFFT(v))
+template <class C> int ntt_domain_h_combine(Domain* d, void* d_a, const void* d_b, const void* d_c);    // a <- h (bit-reversed)
 void ntt_domain_delete(Domain* d);
 int ntt_domain_curve(const Domain* d);
 uint64_t ntt_domain_size(const Domain* d);

@@ -5,6 +5,7 @@
 // (r, s); BSB22 commitments are the two extra MSMs per commitment of ga_g16_commit (prove.go:84,114) plus the K filter.  The host side is C++ because the reference's host side is compiled Go and no Go
 // toolchain exists in the build image (INTEGRATION.md shows the cgo binding that calls this file's two entry points).
 #include <algorithm>
+#include <condition_variable>
 #include <string>
 #include <thread>
 
@@ -45,6 +46,7 @@ struct G16Pk {
     // multi-GPU partition B: this key holds slice [off, off+len) of every base vector (ga_g16_key.shard_index/count)
     uint32_t shard_index = 0, shard_count = 1;
     uint64_t off_k = 0, off_z = 0, full_len_k = 0;
+    uint64_t w_lo = 0, w_hi = 0;   // wire range [w_lo, w_hi) the A and B gather lists (and a filtered K list) of this shard touch
     std::vector<uint8_t> alpha1, beta1, delta1, beta2, delta2;   // affine images (host)
 };
 
@@ -75,112 +77,206 @@ static void pk_free(G16Pk* pk) {
     delete pk;
 }
 
-template <class C>
-static int pk_create(Ctx* ctx, const ga_g16_key* key, G16Pk** out) {
-    typedef Fe<typename C::FpP> F1;
-    typedef Fe2<typename C::FpP> F2;
-    const size_t s1 = sizeof(Affine<F1>), s2 = sizeof(Affine<F2>);
-    if (key->len_z + 1 != key->domain_cardinality) {
-        set_error("proving key: len(G1.Z)=%llu but domain cardinality is %llu (expected n-1, setup.go:248-249)",
-                  (unsigned long long)key->len_z, (unsigned long long)key->domain_cardinality);
+// ---- staged key construction (ga_g16_builder_*) -------------------------------------------------------------------------------
+// The proving key reaches the device vector by vector, chunk by chunk: every call takes ONE flat pointer to pointer-free memory
+// and has copied what it needs when it returns.  This is the shape cgo wants (no Go pointer stored inside a C struct, nothing
+// retained after the call) and the shape a streaming reader of the 6-9 GiB key files wants (keyio.hip: ReadDump / ReadFrom feed
+// chunks from a pinned staging buffer).  ga_g16_pk_create(struct) is a thin wrapper over it.
+struct G16Stage {
+    Ctx* ctx = nullptr;
+    int curve = 0;
+    uint64_t n = 0, nb_wires = 0;
+    uint32_t shard_index = 0, shard_count = 1;
+    struct Vec {
+        void* d = nullptr;
+        uint64_t total = 0, lo = 0, cnt = 0, seen = 0;
+        bool reserved = false;
+    } v[GA_KEY_NB_VECTORS];
+    std::vector<uint8_t> inf[2];                 // InfinityA, InfinityB (Go []bool images)
+    bool have_inf[2] = {false, false};
+    std::vector<uint8_t> pts[GA_KEY_NB_POINTS];  // alpha1, beta1, delta1, beta2, delta2
+    std::vector<void*> d_ck_basis, d_ck_sigma;
+    std::vector<uint64_t> ck_len;
+    std::vector<uint64_t> k_remove;
+    ~G16Stage() {
+        for (auto& x : v) hipFree(x.d);
+        for (void* p : d_ck_basis) hipFree(p);
+        for (void* p : d_ck_sigma) hipFree(p);
+    }
+};
+
+static size_t stage_point_bytes(int curve, int which) {
+    const size_t fp = curve == GA_BN254 ? 32 : 48;
+    return which == GA_KEY_G2_B ? 4 * fp : 2 * fp;
+}
+
+static int stage_reserve(G16Stage* st, int which, uint64_t total) {
+    if (which < 0 || which >= GA_KEY_NB_VECTORS) {
+        set_error("proving key: unknown vector id %d", which);
         return GA_ERR_INVALID;
     }
-    if (key->len_a + key->nb_infinity_a != key->nb_wires || key->len_b + key->nb_infinity_b != key->nb_wires ||
-        key->len_b2 != key->len_b) {
-        set_error("proving key: len(A)+NbInfinityA, len(B)+NbInfinityB must equal nbWires and len(G2.B)==len(G1.B)");
+    G16Stage::Vec& x = st->v[which];
+    if (x.reserved) {
+        set_error("proving key: vector %d reserved twice", which);
+        return GA_ERR_STATE;
+    }
+    const uint64_t base = total / st->shard_count, rem = total % st->shard_count, k = st->shard_index;   // same split as multigpu.shard_range
+    x.total = total;
+    x.lo = k * base + (k < rem ? k : rem);
+    x.cnt = base + (k < rem ? 1 : 0);
+    const size_t bytes = x.cnt * stage_point_bytes(st->curve, which);
+    hipError_t e = hipMalloc(&x.d, bytes ? bytes : 16);
+    if (e != hipSuccess) {
+        set_error("proving key upload: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return GA_ERR_NOMEM;
+    }
+    x.reserved = true;
+    return GA_OK;
+}
+
+// points [seen, seen + count) of the full vector; only the part inside this shard's range is copied.  `pinned`: the source is
+// page-locked memory owned by the caller for the duration of the call (keyio's staging buffers) -- the copy is then truly
+// asynchronous and the caller synchronises; otherwise the stream is drained before returning.
+static int stage_append(G16Stage* st, int which, const void* points, uint64_t count, bool pinned = false) {
+    if (which < 0 || which >= GA_KEY_NB_VECTORS || !st->v[which].reserved) {
+        set_error("proving key: append to vector %d before ga_g16_builder_reserve", which);
+        return GA_ERR_STATE;
+    }
+    G16Stage::Vec& x = st->v[which];
+    if (x.seen + count > x.total) {
+        set_error("proving key: vector %d overflows its reserved length %llu", which, (unsigned long long)x.total);
+        return GA_ERR_INVALID;
+    }
+    const size_t psz = stage_point_bytes(st->curve, which);
+    const uint64_t b0 = x.seen > x.lo ? x.seen : x.lo;
+    const uint64_t e0 = x.seen + count < x.lo + x.cnt ? x.seen + count : x.lo + x.cnt;
+    if (e0 > b0) {
+        GA_HIP_CHECK(hipMemcpyAsync((char*)x.d + (b0 - x.lo) * psz, (const char*)points + (b0 - x.seen) * psz, (e0 - b0) * psz,
+                                    hipMemcpyHostToDevice, st->ctx->stream));
+        if (!pinned) GA_HIP_CHECK(hipStreamSynchronize(st->ctx->stream));   // no host pointer survives this call
+    }
+    x.seen += count;
+    return GA_OK;
+}
+
+template <class C>
+static int stage_finish(G16Stage* st, int precompute, G16Pk** out) {
+    typedef Fe<typename C::FpP> F1;
+    typedef Fe2<typename C::FpP> F2;
+    Ctx* ctx = st->ctx;
+    const size_t s1 = sizeof(Affine<F1>), s2 = sizeof(Affine<F2>);
+    for (int w = 0; w < GA_KEY_NB_VECTORS; w++)
+        if (!st->v[w].reserved || st->v[w].seen != st->v[w].total) {
+            set_error("proving key: vector %d incomplete (%llu of %llu points)", w, (unsigned long long)st->v[w].seen,
+                      (unsigned long long)st->v[w].total);
+            return GA_ERR_STATE;
+        }
+    for (int q = 0; q < GA_KEY_NB_POINTS; q++)
+        if (st->pts[q].empty()) {
+            set_error("proving key: point %d (alpha1, beta1, delta1, beta2, delta2) not set", q);
+            return GA_ERR_STATE;
+        }
+    if (!st->have_inf[0] || !st->have_inf[1]) {
+        set_error("proving key: InfinityA / InfinityB not set");
+        return GA_ERR_STATE;
+    }
+    const uint64_t len_a = st->v[GA_KEY_G1_A].total, len_b = st->v[GA_KEY_G1_B].total, len_z = st->v[GA_KEY_G1_Z].total,
+                   len_k = st->v[GA_KEY_G1_K].total, len_b2 = st->v[GA_KEY_G2_B].total;
+    if (len_z + 1 != st->n) {
+        set_error("proving key: len(G1.Z)=%llu but domain cardinality is %llu (expected n-1, setup.go:248-249)",
+                  (unsigned long long)len_z, (unsigned long long)st->n);
+        return GA_ERR_INVALID;
+    }
+    if (st->nb_wires >= (1ull << 32)) {
+        set_error("proving key: %llu wires exceed the 32-bit wire index space", (unsigned long long)st->nb_wires);
+        return GA_ERR_INVALID;
+    }
+    std::vector<uint32_t> ia, ib;
+    ia.reserve(len_a);
+    ib.reserve(len_b);
+    for (uint64_t i = 0; i < st->nb_wires; i++) {
+        if (!st->inf[0][i]) ia.push_back((uint32_t)i);
+        if (!st->inf[1][i]) ib.push_back((uint32_t)i);
+    }
+    if (ia.size() != len_a || ib.size() != len_b || len_b2 != len_b) {
+        set_error("proving key: InfinityA/B masks disagree with len(A)/len(B), or len(G2.B) != len(G1.B)");
         return GA_ERR_INVALID;
     }
     G16Pk* pk = new G16Pk();
     pk->ctx = ctx;
     pk->curve = C::ID;
-    pk->n = key->domain_cardinality;
-    pk->nb_wires = key->nb_wires;
-    pk->shard_count = key->shard_count ? key->shard_count : 1;
-    pk->shard_index = key->shard_index;
-    if (pk->shard_index >= pk->shard_count) {
-        set_error("proving key: shard_index %u >= shard_count %u", pk->shard_index, pk->shard_count);
-        delete pk;
-        return GA_ERR_INVALID;
-    }
-    auto slice = [&](uint64_t len, uint64_t* lo, uint64_t* cnt) {   // same split as gnark_amd/multigpu.py shard_range
-        uint64_t base = len / pk->shard_count, rem = len % pk->shard_count, k = pk->shard_index;
-        *lo = k * base + (k < rem ? k : rem);
-        *cnt = base + (k < rem ? 1 : 0);
+    pk->n = st->n;
+    pk->nb_wires = st->nb_wires;
+    pk->shard_count = st->shard_count;
+    pk->shard_index = st->shard_index;
+    auto take = [&](int which, void** slot, uint64_t* len) {   // the device buffer changes owner
+        *slot = st->v[which].d;
+        *len = st->v[which].cnt;
+        st->v[which].d = nullptr;
     };
-    uint64_t lo_a, lo_b, lo_z, lo_k;
-    slice(key->len_a, &lo_a, &pk->len_a);
-    slice(key->len_b, &lo_b, &pk->len_b);
-    slice(key->len_z, &lo_z, &pk->len_z);
-    slice(key->len_k, &lo_k, &pk->len_k);
-    pk->len_b2 = pk->len_b;
+    take(GA_KEY_G1_A, &pk->d_a, &pk->len_a);
+    take(GA_KEY_G1_B, &pk->d_b, &pk->len_b);
+    take(GA_KEY_G1_Z, &pk->d_z, &pk->len_z);
+    take(GA_KEY_G1_K, &pk->d_k, &pk->len_k);
+    take(GA_KEY_G2_B, &pk->d_b2, &pk->len_b2);
+    const uint64_t lo_a = st->v[GA_KEY_G1_A].lo, lo_b = st->v[GA_KEY_G1_B].lo, lo_k = st->v[GA_KEY_G1_K].lo;
     pk->off_k = lo_k;
-    pk->off_z = lo_z;
-    pk->full_len_k = key->len_k;
-    int rc = ntt_domain_new<C>(ctx, pk->n, &pk->dom);
-    if (rc == GA_OK) rc = upload(ctx, (const char*)key->g1_a + lo_a * s1, pk->len_a * s1, &pk->d_a);
-    if (rc == GA_OK) rc = upload(ctx, (const char*)key->g1_b + lo_b * s1, pk->len_b * s1, &pk->d_b);
-    if (rc == GA_OK) rc = upload(ctx, (const char*)key->g1_z + lo_z * s1, pk->len_z * s1, &pk->d_z);
-    if (rc == GA_OK) rc = upload(ctx, (const char*)key->g1_k + lo_k * s1, pk->len_k * s1, &pk->d_k);
-    if (rc == GA_OK) rc = upload(ctx, (const char*)key->g2_b + lo_b * s2, pk->len_b2 * s2, &pk->d_b2);
-    std::vector<uint32_t> ia, ib;
-    if (rc == GA_OK) {
-        ia.reserve(key->len_a);
-        ib.reserve(key->len_b);
-        for (uint64_t i = 0; i < key->nb_wires; i++) {
-            if (!key->infinity_a[i]) ia.push_back((uint32_t)i);
-            if (!key->infinity_b[i]) ib.push_back((uint32_t)i);
-        }
-        if (ia.size() != key->len_a || ib.size() != key->len_b) {
-            set_error("proving key: InfinityA/B masks disagree with len(A)/len(B)");
-            rc = GA_ERR_INVALID;
-        }
+    pk->off_z = st->v[GA_KEY_G1_Z].lo;
+    pk->full_len_k = len_k;
+    {   // wire range of this shard: the sorted gather lists are sliced contiguously, so min/max are the slice ends
+        uint64_t lo = st->nb_wires, hi = 0;
+        auto span = [&](const std::vector<uint32_t>& v, uint64_t off, uint64_t cnt) {
+            if (cnt == 0) return;
+            lo = lo < v[off] ? lo : v[off];
+            hi = hi > (uint64_t)v[off + cnt - 1] + 1 ? hi : (uint64_t)v[off + cnt - 1] + 1;
+        };
+        span(ia, lo_a, pk->len_a);
+        span(ib, lo_b, pk->len_b);
+        pk->w_lo = st->shard_count == 1 ? 0 : lo;
+        pk->w_hi = st->shard_count == 1 ? st->nb_wires : hi;
     }
+    int rc = ntt_domain_new<C>(ctx, pk->n, &pk->dom);
     if (rc == GA_OK) rc = upload(ctx, ia.data() + lo_a, pk->len_a * 4, (void**)&pk->d_idx_a);
     if (rc == GA_OK) rc = upload(ctx, ib.data() + lo_b, pk->len_b * 4, (void**)&pk->d_idx_b);
     // K filter with commitments: wireValues[nbPublic:] minus the private committed and commitment wires (prove.go:231-235)
     std::vector<uint32_t> ik;
-    pk->len_k_remove = key->len_k_remove;
-    if (rc == GA_OK && key->len_k_remove) {
-        if (!key->k_remove || key->len_k + key->len_k_remove > key->nb_wires) {
-            set_error("proving key: k_remove missing or len(K)+len(k_remove) > nbWires");
+    pk->len_k_remove = st->k_remove.size();
+    if (rc == GA_OK && pk->len_k_remove) {
+        const uint64_t nrem = st->k_remove.size();
+        if (len_k + nrem > st->nb_wires) {
+            set_error("proving key: len(K)+len(k_remove) > nbWires");
             rc = GA_ERR_INVALID;
         } else {
-            const uint64_t nb_public = key->nb_wires - key->len_k - key->len_k_remove;
-            ik.reserve(key->len_k);
+            const uint64_t nb_public = st->nb_wires - len_k - nrem;
+            ik.reserve(len_k);
             uint64_t j = 0;
             bool ok = true;
-            for (uint64_t i = 0; i < key->len_k_remove; i++)
-                ok = ok && key->k_remove[i] >= nb_public && key->k_remove[i] < key->nb_wires && (i == 0 || key->k_remove[i] > key->k_remove[i - 1]);
-            for (uint64_t i = nb_public; ok && i < key->nb_wires; i++) {
-                if (j < key->len_k_remove && key->k_remove[j] == i) j++;
+            for (uint64_t i = 0; i < nrem; i++)
+                ok = ok && st->k_remove[i] >= nb_public && st->k_remove[i] < st->nb_wires && (i == 0 || st->k_remove[i] > st->k_remove[i - 1]);
+            for (uint64_t i = nb_public; ok && i < st->nb_wires; i++) {
+                if (j < nrem && st->k_remove[j] == i) j++;
                 else ik.push_back((uint32_t)i);
             }
-            if (!ok || ik.size() != key->len_k) {
+            if (!ok || ik.size() != len_k) {
                 set_error("proving key: k_remove must be strictly increasing wire ids in [nbPublic, nbWires)");
                 rc = GA_ERR_INVALID;
             }
         }
         if (rc == GA_OK) rc = upload(ctx, ik.data() + lo_k, pk->len_k * 4, (void**)&pk->d_idx_k);
-    }
-    for (uint32_t i = 0; rc == GA_OK && i < key->nb_commitments; i++) {
-        if (!key->ck_basis || !key->ck_basis_exp_sigma || !key->ck_len) {
-            set_error("proving key: nb_commitments > 0 but the commitment key arrays are null");
-            rc = GA_ERR_INVALID;
-            break;
+        if (rc == GA_OK && pk->len_k && st->shard_count > 1) {
+            pk->w_lo = pk->w_lo < ik[lo_k] ? pk->w_lo : ik[lo_k];
+            pk->w_hi = pk->w_hi > (uint64_t)ik[lo_k + pk->len_k - 1] + 1 ? pk->w_hi : (uint64_t)ik[lo_k + pk->len_k - 1] + 1;
         }
-        void *db = nullptr, *ds = nullptr;
-        rc = upload(ctx, key->ck_basis[i], key->ck_len[i] * s1, &db);
-        if (rc == GA_OK) rc = upload(ctx, key->ck_basis_exp_sigma[i], key->ck_len[i] * s1, &ds);
-        pk->d_ck_basis.push_back(db);
-        pk->d_ck_sigma.push_back(ds);
-        pk->ck_len.push_back(key->ck_len[i]);
     }
+    pk->d_ck_basis.swap(st->d_ck_basis);
+    pk->d_ck_sigma.swap(st->d_ck_sigma);
+    pk->ck_len = st->ck_len;
     if (rc == GA_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) {   // no host pointer survives this call
         set_error("proving key upload: stream synchronize failed");
         rc = GA_ERR_HIP;
     }
     // ---- optional precomputation: [2^(c*w)]P for every window (one shared bucket set per MSM afterwards) ----------
-    if (rc == GA_OK && key->precompute >= 0) {
+    if (rc == GA_OK && precompute >= 0) {
         int nw;
         const size_t t1 = msm_table_point_bytes<C, GA_G1>(), t2 = msm_table_point_bytes<C, GA_G2>();
         // share the witness sort between the vectors that cover at least GA_G16_SHARE_MIN_PCT % of the wires (default 90: a
@@ -207,7 +303,7 @@ static int pk_create(Ctx* ctx, const ga_g16_key* key, G16Pk** out) {
         hipMemGetInfo(&free_b, &total_b);
         // leave room for the per-proof scratch (~0.6 KB per constraint measured) and some slack
         const bool fits = (double)need + (double)pk->n * 1024.0 < 0.85 * (double)free_b;
-        if (key->precompute > 0 || fits) {
+        if (precompute > 0 || fits) {
             auto make = [&](void** slot, uint64_t len, int c, size_t psz, auto build) -> int {
                 if (len == 0) return GA_OK;
                 const int nwin = C::FrP::BITS / c + 1;
@@ -270,77 +366,135 @@ static int pk_create(Ctx* ctx, const ga_g16_key* key, G16Pk** out) {
         pk_free(pk);
         return rc;
     }
-    auto cp = [](std::vector<uint8_t>& v, const void* p, size_t n) { v.assign((const uint8_t*)p, (const uint8_t*)p + n); };
-    cp(pk->alpha1, key->g1_alpha, s1);
-    cp(pk->beta1, key->g1_beta, s1);
-    cp(pk->delta1, key->g1_delta, s1);
-    cp(pk->beta2, key->g2_beta, s2);
-    cp(pk->delta2, key->g2_delta, s2);
+    pk->alpha1 = st->pts[GA_KEY_G1_ALPHA];
+    pk->beta1 = st->pts[GA_KEY_G1_BETA];
+    pk->delta1 = st->pts[GA_KEY_G1_DELTA];
+    pk->beta2 = st->pts[GA_KEY_G2_BETA];
+    pk->delta2 = st->pts[GA_KEY_G2_DELTA];
+    (void)s2;
     *out = pk;
     return GA_OK;
 }
 
-// The device part of a proof on this key's shard: computeH + the five MSMs over the pinned slices.
-// Outputs (before randomisation): A-sum, B1-sum, K-sum + Z-sum (G1), B2-sum (G2) -- to be added across shards.
+static int stage_set_point(G16Stage* st, int which, const void* affine) {
+    if (which < 0 || which >= GA_KEY_NB_POINTS || !affine) {
+        set_error("proving key: bad point id %d or null pointer", which);
+        return GA_ERR_INVALID;
+    }
+    const size_t fp = st->curve == GA_BN254 ? 32 : 48;
+    const size_t bytes = (which == GA_KEY_G2_BETA || which == GA_KEY_G2_DELTA) ? 4 * fp : 2 * fp;
+    st->pts[which].assign((const uint8_t*)affine, (const uint8_t*)affine + bytes);
+    return GA_OK;
+}
+
+static int stage_add_commitment_key(G16Stage* st, const void* basis, const void* sigma, uint64_t len) {
+    if (len && (!basis || !sigma)) {
+        set_error("proving key: null commitment key basis");
+        return GA_ERR_INVALID;
+    }
+    const size_t s1 = stage_point_bytes(st->curve, GA_KEY_G1_A);
+    void *db = nullptr, *ds = nullptr;
+    int rc = upload(st->ctx, basis, len * s1, &db);
+    if (rc == GA_OK) rc = upload(st->ctx, sigma, len * s1, &ds);
+    if (rc == GA_OK && hipStreamSynchronize(st->ctx->stream) != hipSuccess) rc = GA_ERR_HIP;
+    if (rc != GA_OK) {
+        hipFree(db);
+        hipFree(ds);
+        return rc;
+    }
+    st->d_ck_basis.push_back(db);
+    st->d_ck_sigma.push_back(ds);
+    st->ck_len.push_back(len);
+    return GA_OK;
+}
+
+// ga_g16_pk_create: the struct-of-pointers form of the same thing (C and ctypes callers; from Go only with runtime.Pinner)
+static int pk_create_from_struct(Ctx* ctx, const ga_g16_key* key, G16Pk** out) {
+    if (!key->g1_alpha || !key->g1_beta || !key->g1_delta || !key->g2_beta || !key->g2_delta || !key->infinity_a || !key->infinity_b ||
+        (key->len_a && !key->g1_a) || (key->len_b && !key->g1_b) || (key->len_z && !key->g1_z) || (key->len_k && !key->g1_k) ||
+        (key->len_b2 && !key->g2_b)) {
+        set_error("ga_g16_pk_create: null pointer inside ga_g16_key");
+        return GA_ERR_INVALID;
+    }
+    if (key->len_a + key->nb_infinity_a != key->nb_wires || key->len_b + key->nb_infinity_b != key->nb_wires) {
+        set_error("proving key: len(A)+NbInfinityA, len(B)+NbInfinityB must equal nbWires and len(G2.B)==len(G1.B)");
+        return GA_ERR_INVALID;
+    }
+    if (key->nb_commitments && (!key->ck_basis || !key->ck_basis_exp_sigma || !key->ck_len)) {
+        set_error("proving key: nb_commitments > 0 but the commitment key arrays are null");
+        return GA_ERR_INVALID;
+    }
+    if (key->len_k_remove && !key->k_remove) {
+        set_error("proving key: k_remove missing");
+        return GA_ERR_INVALID;
+    }
+    G16Stage st;
+    st.ctx = ctx;
+    st.curve = key->curve;
+    st.n = key->domain_cardinality;
+    st.nb_wires = key->nb_wires;
+    st.shard_count = key->shard_count ? key->shard_count : 1;
+    st.shard_index = key->shard_index;
+    if (st.shard_index >= st.shard_count) {
+        set_error("proving key: shard_index %u >= shard_count %u", st.shard_index, st.shard_count);
+        return GA_ERR_INVALID;
+    }
+    const void* vec[GA_KEY_NB_VECTORS] = {key->g1_a, key->g1_b, key->g1_z, key->g1_k, key->g2_b};
+    const uint64_t len[GA_KEY_NB_VECTORS] = {key->len_a, key->len_b, key->len_z, key->len_k, key->len_b2};
+    for (int w = 0; w < GA_KEY_NB_VECTORS; w++) {
+        GA_CHECK(stage_reserve(&st, w, len[w]));
+        GA_CHECK(stage_append(&st, w, vec[w], len[w], /*pinned=*/true));   // one drain below instead of five
+    }
+    GA_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    const void* pt[GA_KEY_NB_POINTS] = {key->g1_alpha, key->g1_beta, key->g1_delta, key->g2_beta, key->g2_delta};
+    for (int q = 0; q < GA_KEY_NB_POINTS; q++) GA_CHECK(stage_set_point(&st, q, pt[q]));
+    st.inf[0].assign(key->infinity_a, key->infinity_a + key->nb_wires);
+    st.inf[1].assign(key->infinity_b, key->infinity_b + key->nb_wires);
+    st.have_inf[0] = st.have_inf[1] = true;
+    for (uint32_t i = 0; i < key->nb_commitments; i++) GA_CHECK(stage_add_commitment_key(&st, key->ck_basis[i], key->ck_basis_exp_sigma[i], key->ck_len[i]));
+    if (key->len_k_remove) st.k_remove.assign(key->k_remove, key->k_remove + key->len_k_remove);
+    G16Pk* pk = nullptr;
+    GA_DISPATCH_CURVE(key->curve, GA_CHECK(stage_finish<C>(&st, key->precompute, &pk)));
+    *out = pk;
+    return GA_OK;
+}
+
+
+// ---- the device part of a proof, in pieces (a multi-GPU proof runs them on different devices) ----------------------------------
+// witness_msms : upload W (only the wire range this shard's bases cover), filter, MSM A, B (G1 + G2), K      prove.go:147-237,283
+// h_chain      : v <- FFT_coset(iFFT(v)) for one of the solver's A, B, C                                       prove.go:362-368
+// h_combine    : h <- iFFT_coset((a*b - c) * den), bit-reversed like pk.G1.Z                                  prove.go:377-386
+// z_msm        : MSM over this shard's slice of pk.G1.Z and h                                                  prove.go:225-227
 template <class C>
-static int prove_partial(G16Pk* pk, const void* w, const void* a, const void* b, const void* c, uint64_t n_constraints,
-                         uint64_t nb_public, XYZZ<Fe<typename C::FpP>>* o_ar, XYZZ<Fe<typename C::FpP>>* o_bs1,
-                         XYZZ<Fe<typename C::FpP>>* o_krs, XYZZ<Fe2<typename C::FpP>>* o_bs2) {
+static int witness_msms(G16Pk* pk, const void* w, uint64_t nb_public, XYZZ<Fe<typename C::FpP>>* o_ar,
+                        XYZZ<Fe<typename C::FpP>>* o_bs1, XYZZ<Fe<typename C::FpP>>* o_k, XYZZ<Fe2<typename C::FpP>>* o_bs2) {
     typedef Fe<typename C::FpP> F1;
     typedef Fe2<typename C::FpP> F2;
     Ctx* ctx = pk->ctx;
-    const uint64_t n = pk->n;
-    if (n_constraints > n || nb_public > pk->nb_wires || pk->nb_wires - nb_public != pk->full_len_k + pk->len_k_remove) {
-        set_error("prove: inconsistent sizes (constraints %llu > n %llu, or nbWires-nbPublic != len(K)+len(k_remove))",
-                  (unsigned long long)n_constraints, (unsigned long long)n);
+    if (nb_public > pk->nb_wires || pk->nb_wires - nb_public != pk->full_len_k + pk->len_k_remove) {
+        set_error("prove: inconsistent sizes (nbWires %llu - nbPublic %llu != len(K) %llu + len(k_remove) %llu)", (unsigned long long)pk->nb_wires,
+                  (unsigned long long)nb_public, (unsigned long long)pk->full_len_k, (unsigned long long)pk->len_k_remove);
         return GA_ERR_INVALID;
     }
     hipStream_t st = ctx->stream;
-    // ---- upload the solution ----------------------------------------------------------------------
-    void *d_w, *d_ha, *d_hb, *d_hc, *d_wa, *d_wb;
+    void *d_w, *d_wa, *d_wb;
     GA_CHECK(ctx->scratch_get("g16_w", pk->nb_wires * 32, &d_w));
-    GA_CHECK(ctx->scratch_get("h_a", n * 32, &d_ha));
-    GA_CHECK(ctx->scratch_get("h_b", n * 32, &d_hb));
-    GA_CHECK(ctx->scratch_get("h_c", n * 32, &d_hc));
     GA_CHECK(ctx->scratch_get("g16_wa", pk->len_a * 32 + 32, &d_wa));
     GA_CHECK(ctx->scratch_get("g16_wb", pk->len_b * 32 + 32, &d_wb));
-    // W first (the four witness MSMs only need W); A, B, C are uploaded by a helper thread on a second stream while
-    // those MSMs run -- pageable H2D copies block the calling thread, hence the thread.  Everything is joined before
-    // this function returns, so no host pointer outlives the call.
+    // the wire range this shard reads: everything for an unsharded key, ~1/N of W for shard k of N (the gather lists of a
+    // shard are contiguous pieces of the sorted wire lists); K's range depends on nbPublic
+    uint64_t lo = pk->w_lo, hi = pk->w_hi;
+    if (pk->len_k && !pk->d_idx_k) {
+        const uint64_t klo = nb_public + pk->off_k, khi = klo + pk->len_k;
+        lo = lo < klo ? lo : klo;
+        hi = hi > khi ? hi : khi;
+    }
+    if (hi > pk->nb_wires) hi = pk->nb_wires;
+    if (lo > hi) lo = hi;
     {
         StageTimer tm(ctx, "g16_h2d_w");
-        GA_HIP_CHECK(hipMemcpyAsync(d_w, w, pk->nb_wires * 32, hipMemcpyHostToDevice, st));
+        if (hi > lo) GA_HIP_CHECK(hipMemcpyAsync((char*)d_w + lo * 32, (const char*)w + lo * 32, (hi - lo) * 32, hipMemcpyHostToDevice, st));
     }
-    hipEvent_t ev_abc;
-    GA_HIP_CHECK(hipEventCreateWithFlags(&ev_abc, hipEventDisableTiming));
-    int up_rc = GA_OK;
-    std::string up_err;
-    std::thread uploader([&]() {
-        if (hipSetDevice(ctx->device) != hipSuccess) {
-            up_rc = GA_ERR_HIP;
-            return;
-        }
-        const void* src[3] = {a, b, c};
-        void* dst[3] = {d_ha, d_hb, d_hc};
-        hipError_t e = hipSuccess;
-        for (int k = 0; k < 3 && e == hipSuccess; k++) {
-            e = hipMemcpyAsync(dst[k], src[k], n_constraints * 32, hipMemcpyHostToDevice, ctx->copy_stream);
-            if (e == hipSuccess && n > n_constraints)   // computeH pads to the domain size (prove.go:356-359)
-                e = hipMemsetAsync((char*)dst[k] + n_constraints * 32, 0, (n - n_constraints) * 32, ctx->copy_stream);
-        }
-        if (e == hipSuccess) e = hipEventRecord(ev_abc, ctx->copy_stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->copy_stream);
-        if (e != hipSuccess) {
-            up_rc = GA_ERR_HIP;
-            up_err = hipGetErrorString(e);
-        }
-    });
-    struct Joiner {
-        std::thread& t;
-        ~Joiner() {
-            if (t.joinable()) t.join();
-        }
-    } joiner{uploader};
     // ---- wire filtering (prove.go:147-168) ------------------------------------------------------------
     if (!pk->share_a) GA_CHECK(util_gather_fr<C>(ctx, d_wa, d_w, pk->d_idx_a, pk->len_a));
     if (!pk->share_b) GA_CHECK(util_gather_fr<C>(ctx, d_wb, d_w, pk->d_idx_b, pk->len_b));
@@ -352,7 +506,7 @@ static int prove_partial(G16Pk* pk, const void* w, const void* a, const void* b,
         d_wk = g;
     }
     // ---- the four witness MSMs (prove.go:194,207,237,283) ----------------------------------------------
-    XYZZ<F1> ar, bs1, krs, krs2;
+    XYZZ<F1> ar, bs1, krs;
     XYZZ<F2> bs2;
     MsmPrepared prep;
     auto table_msm_g1 = [&](const void* table, const void* scal, uint64_t len, int c, XYZZ<F1>* out) -> int {
@@ -385,23 +539,110 @@ static int prove_partial(G16Pk* pk, const void* w, const void* a, const void* b,
         GA_CHECK((host_msm<C, GA_G2>(ctx, pk->d_b2, d_wb, pk->len_b2, true, &bs2)));
         GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_k, d_wk, pk->len_k, true, &krs)));
     }
+    *o_ar = ar;
+    *o_bs1 = bs1;
+    *o_k = krs;
+    *o_bs2 = bs2;
+    return GA_OK;
+}
+
+// v (host, n_constraints elements) -> device buffer d_v (n elements, zero-padded) on `up_stream`; the main stream waits for it
+static int h_upload(G16Pk* pk, const void* v, uint64_t n_constraints, void* d_v, hipStream_t up_stream) {
+    const uint64_t n = pk->n;
+    if (n_constraints > n) {
+        set_error("prove: %llu constraints exceed the domain cardinality %llu", (unsigned long long)n_constraints, (unsigned long long)n);
+        return GA_ERR_INVALID;
+    }
+    GA_HIP_CHECK(hipMemcpyAsync(d_v, v, n_constraints * 32, hipMemcpyHostToDevice, up_stream));
+    if (n > n_constraints)   // computeH pads to the domain size (prove.go:356-359)
+        GA_HIP_CHECK(hipMemsetAsync((char*)d_v + n_constraints * 32, 0, (n - n_constraints) * 32, up_stream));
+    return GA_OK;
+}
+
+template <class C>
+static int z_msm(G16Pk* pk, const void* d_h_slice, XYZZ<Fe<typename C::FpP>>* out) {
+    typedef Fe<typename C::FpP> F1;
+    Ctx* ctx = pk->ctx;
+    if (pk->len_z == 0) {
+        *out = xyzz_inf<F1>();
+        return GA_OK;
+    }
+    if (pk->tables) {
+        MsmPrepared prep;
+        GA_CHECK(msm_prepare_table_scalars<C>(ctx, d_h_slice, pk->len_z, true, pk->c_z, &prep));
+        return msm_table_device_reuse<C, GA_G1>(ctx, pk->d_z, prep, out);
+    }
+    return host_msm<C, GA_G1>(ctx, pk->d_z, d_h_slice, pk->len_z, true, out);
+}
+
+// RAII for the pieces that must not outlive an early return
+struct EventGuard {
+    hipEvent_t ev = nullptr;
+    ~EventGuard() {
+        if (ev) hipEventDestroy(ev);
+    }
+};
+struct ThreadJoiner {
+    std::thread& t;
+    ~ThreadJoiner() {
+        if (t.joinable()) t.join();
+    }
+};
+
+// The device part of a proof on this key's shard: computeH + the five MSMs over the pinned slices.
+// Outputs (before randomisation): A-sum, B1-sum, K-sum + Z-sum (G1), B2-sum (G2) -- to be added across shards.
+template <class C>
+static int prove_partial(G16Pk* pk, const void* w, const void* a, const void* b, const void* c, uint64_t n_constraints,
+                         uint64_t nb_public, XYZZ<Fe<typename C::FpP>>* o_ar, XYZZ<Fe<typename C::FpP>>* o_bs1,
+                         XYZZ<Fe<typename C::FpP>>* o_krs, XYZZ<Fe2<typename C::FpP>>* o_bs2) {
+    typedef Fe<typename C::FpP> F1;
+    Ctx* ctx = pk->ctx;
+    const uint64_t n = pk->n;
+    if (n_constraints > n) {
+        set_error("prove: %llu constraints exceed the domain cardinality %llu", (unsigned long long)n_constraints, (unsigned long long)n);
+        return GA_ERR_INVALID;
+    }
+    void *d_ha, *d_hb, *d_hc;
+    GA_CHECK(ctx->scratch_get("h_a", n * 32, &d_ha));
+    GA_CHECK(ctx->scratch_get("h_b", n * 32, &d_hb));
+    GA_CHECK(ctx->scratch_get("h_c", n * 32, &d_hc));
+    // W first (the four witness MSMs only need W); A, B, C are uploaded by a helper thread on a second stream while
+    // those MSMs run -- pageable H2D copies block the calling thread, hence the thread.  Everything is joined before
+    // this function returns, so no host pointer outlives the call.
+    EventGuard abc;
+    GA_HIP_CHECK(hipEventCreateWithFlags(&abc.ev, hipEventDisableTiming));
+    int up_rc = GA_OK;
+    std::string up_err;
+    std::thread uploader([&]() {
+        if (hipSetDevice(ctx->device) != hipSuccess) {
+            up_rc = GA_ERR_HIP;
+            return;
+        }
+        const void* src[3] = {a, b, c};
+        void* dst[3] = {d_ha, d_hb, d_hc};
+        for (int k = 0; k < 3 && up_rc == GA_OK; k++) up_rc = h_upload(pk, src[k], n_constraints, dst[k], ctx->copy_stream);
+        hipError_t e = hipSuccess;
+        if (up_rc == GA_OK) e = hipEventRecord(abc.ev, ctx->copy_stream);
+        if (up_rc == GA_OK && e == hipSuccess) e = hipStreamSynchronize(ctx->copy_stream);
+        if (up_rc != GA_OK) up_err = get_error();
+        else if (e != hipSuccess) {
+            up_rc = GA_ERR_HIP;
+            up_err = hipGetErrorString(e);
+        }
+    });
+    ThreadJoiner joiner{uploader};
+    XYZZ<F1> krs, krs2;
+    GA_CHECK(witness_msms<C>(pk, w, nb_public, o_ar, o_bs1, &krs, o_bs2));
     // ---- H (prove.go:134,346-389), then the MSM over pk.G1.Z (prove.go:225-227) ----------------------------
     uploader.join();
     if (up_rc != GA_OK) {
         set_error("prove: uploading A,B,C failed: %s", up_err.c_str());
-        hipEventDestroy(ev_abc);
         return up_rc;
     }
-    GA_HIP_CHECK(hipStreamWaitEvent(st, ev_abc, 0));
+    GA_HIP_CHECK(hipStreamWaitEvent(ctx->stream, abc.ev, 0));
     GA_CHECK(ntt_domain_compute_h<C>(pk->dom, d_ha, d_hb, d_hc));   // h in d_ha, bit-reversed like pk.G1.Z
-    const void* d_hz = (const char*)d_ha + pk->off_z * 32;   // this shard's slice of h[:n-1]
-    if (pk->tables) GA_CHECK(table_msm_g1(pk->d_z, d_hz, pk->len_z, pk->c_z, &krs2));
-    else GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_z, d_hz, pk->len_z, true, &krs2)));
-    hipEventDestroy(ev_abc);
-    *o_ar = ar;
-    *o_bs1 = bs1;
+    GA_CHECK(z_msm<C>(pk, (const char*)d_ha + pk->off_z * 32, &krs2));
     *o_krs = add(krs, krs2);
-    *o_bs2 = bs2;
     return GA_OK;
 }
 
@@ -600,6 +841,163 @@ static int marshal(const void* proof, const void* commitments, uint32_t ncom, co
     return GA_OK;
 }
 
+// One proof over several devices from ONE process: keys[i] = shard i of n of the same proving key, each in a context on its own
+// device.  One host thread per device; the three chains of computeH run on the first three devices (a, b, c uploaded over three
+// different PCIe links), b and c travel to device 0 over xGMI (hipMemcpyPeerAsync), device 0 finishes h and sends every device
+// its slice; partial sums are added on the host.  With n = 1 this is ga_g16_prove.
+struct MultiShared {
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived[4] = {0, 0, 0, 0};
+    bool failed = false;
+    std::string err;
+    uint32_t n = 0;
+    void fail(const char* msg) {
+        std::lock_guard<std::mutex> g(mu);
+        if (!failed) {
+            failed = true;
+            err = msg;
+        }
+        cv.notify_all();
+    }
+    // all n threads meet here; returns false when some thread failed (everyone then unwinds)
+    bool barrier(int k) {
+        std::unique_lock<std::mutex> g(mu);
+        arrived[k]++;
+        cv.notify_all();
+        cv.wait(g, [&] { return failed || arrived[k] == (int)n; });
+        return !failed;
+    }
+};
+
+template <class C>
+static int prove_multi(G16Pk* const* pks, uint32_t n, const void* w, const void* a, const void* b, const void* c, uint64_t n_constraints,
+                       uint64_t nb_public, const void* r, const void* s, void* proof_out) {
+    typedef Fe<typename C::FpP> F1;
+    typedef Fe2<typename C::FpP> F2;
+    struct Part {
+        XYZZ<F1> ar, bs1, k, z;
+        XYZZ<F2> bs2;
+    };
+    std::vector<Part> parts(n);
+    const uint64_t N = pks[0]->n;
+    // which device runs which chain: a on 0, b on 1 (or 0), c on 2 (or 0)
+    const uint32_t owner[3] = {0, n >= 2 ? 1u : 0u, n >= 3 ? 2u : 0u};
+    const void* src[3] = {a, b, c};
+    static const char* const names[3] = {"h_a", "h_b", "h_c"};
+    void* chain_buf[3] = {nullptr, nullptr, nullptr};   // on the owner's device
+    void* dev0_buf[3] = {nullptr, nullptr, nullptr};     // on device 0
+    std::vector<void*> h_slice(n, nullptr);
+    MultiShared sh;
+    sh.n = n;
+    auto worker = [&](uint32_t t) {
+        G16Pk* pk = pks[t];
+        Ctx* ctx = pk->ctx;
+        std::lock_guard<std::mutex> g(ctx->mu);   // one proof at a time per device (icicle.go:821-823)
+        auto bail = [&](const char* what) { sh.fail((std::string(what) + ": " + get_error()).c_str()); };
+        bool ok = hipSetDevice(ctx->device) == hipSuccess;
+        if (!ok) set_error("hipSetDevice(%d) failed", ctx->device);
+        // buffers first, so that peers can address them after barrier 0
+        for (int k = 0; ok && k < 3; k++) {
+            if (owner[k] == t) ok = ctx->scratch_get(names[k], N * 32, &chain_buf[k]) == GA_OK;
+            if (t == 0 && ok) ok = ctx->scratch_get(names[k], N * 32, &dev0_buf[k]) == GA_OK;
+        }
+        if (ok && pk->len_z) ok = t == 0 || ctx->scratch_get("h_slice", pk->len_z * 32, &h_slice[t]) == GA_OK;
+        if (!ok) bail("multi-device prove: buffers");
+        if (!sh.barrier(0)) return;
+        // upload of this device's chain input(s) on the copy stream, by a helper thread, under the witness MSMs
+        EventGuard up;
+        int up_rc = GA_OK;
+        std::string up_err;
+        bool owns = false;
+        for (int k = 0; k < 3; k++) owns = owns || owner[k] == t;
+        std::thread uploader;
+        if (owns) {
+            if (hipEventCreateWithFlags(&up.ev, hipEventDisableTiming) != hipSuccess) {
+                set_error("hipEventCreate failed");
+                bail("multi-device prove");
+                ok = false;
+            } else {
+                uploader = std::thread([&, t]() {
+                    if (hipSetDevice(ctx->device) != hipSuccess) {
+                        up_rc = GA_ERR_HIP;
+                        return;
+                    }
+                    for (int k = 0; k < 3 && up_rc == GA_OK; k++)
+                        if (owner[k] == t) up_rc = h_upload(pk, src[k], n_constraints, chain_buf[k], ctx->copy_stream);
+                    hipError_t e = up_rc == GA_OK ? hipEventRecord(up.ev, ctx->copy_stream) : hipSuccess;
+                    if (up_rc == GA_OK && e == hipSuccess) e = hipStreamSynchronize(ctx->copy_stream);
+                    if (up_rc != GA_OK) up_err = get_error();
+                    else if (e != hipSuccess) {
+                        up_rc = GA_ERR_HIP;
+                        up_err = hipGetErrorString(e);
+                    }
+                });
+            }
+        }
+        ThreadJoiner joiner{uploader};
+        if (ok && witness_msms<C>(pk, w, nb_public, &parts[t].ar, &parts[t].bs1, &parts[t].k, &parts[t].bs2) != GA_OK) {
+            bail("multi-device prove: witness MSMs");
+            ok = false;
+        }
+        if (uploader.joinable()) uploader.join();
+        if (ok && up_rc != GA_OK) {
+            set_error("%s", up_err.c_str());
+            bail("multi-device prove: uploading A, B, C");
+            ok = false;
+        }
+        // chains on their owners, then b and c go to device 0
+        if (ok && owns) {
+            ok = hipStreamWaitEvent(ctx->stream, up.ev, 0) == hipSuccess;
+            for (int k = 0; ok && k < 3; k++)
+                if (owner[k] == t) {
+                    ok = ntt_domain_h_chain<C>(pk->dom, chain_buf[k]) == GA_OK;
+                    if (ok && t != 0)
+                        ok = hipMemcpyPeerAsync(dev0_buf[k], pks[0]->ctx->device, chain_buf[k], ctx->device, N * 32, ctx->stream) == hipSuccess;
+                }
+            if (ok) ok = hipStreamSynchronize(ctx->stream) == hipSuccess;
+            if (!ok) {
+                if (!get_error()[0]) set_error("HIP error in the computeH chain");
+                bail("multi-device prove: computeH chain");
+            }
+        }
+        if (!sh.barrier(1)) return;
+        if (t == 0) {
+            ok = ntt_domain_h_combine<C>(pk->dom, dev0_buf[0], dev0_buf[1], dev0_buf[2]) == GA_OK;
+            for (uint32_t q = 1; ok && q < n; q++)   // every device gets its slice of h[:n-1]
+                if (pks[q]->len_z)
+                    ok = hipMemcpyPeerAsync(h_slice[q], pks[q]->ctx->device, (const char*)dev0_buf[0] + pks[q]->off_z * 32, ctx->device,
+                                            pks[q]->len_z * 32, ctx->stream) == hipSuccess;
+            if (ok) ok = hipStreamSynchronize(ctx->stream) == hipSuccess;
+            if (!ok) {
+                if (!get_error()[0]) set_error("HIP error while finishing / scattering h");
+                bail("multi-device prove: h");
+            }
+            h_slice[0] = (char*)dev0_buf[0] + pk->off_z * 32;
+        }
+        if (!sh.barrier(2)) return;
+        if (z_msm<C>(pk, h_slice[t], &parts[t].z) != GA_OK) bail("multi-device prove: Z MSM");
+        sh.barrier(3);
+    };
+    std::vector<std::thread> threads;
+    for (uint32_t t = 1; t < n; t++) threads.emplace_back(worker, t);
+    worker(0);
+    for (auto& th : threads) th.join();
+    if (sh.failed) {
+        set_error("%s", sh.err.c_str());
+        return GA_ERR_HIP;
+    }
+    XYZZ<F1> ar = xyzz_inf<F1>(), bs1 = xyzz_inf<F1>(), krs = xyzz_inf<F1>();
+    XYZZ<F2> bs2 = xyzz_inf<F2>();
+    for (uint32_t t = 0; t < n; t++) {
+        ar = add(ar, parts[t].ar);
+        bs1 = add(bs1, parts[t].bs1);
+        krs = add(krs, add(parts[t].k, parts[t].z));
+        bs2 = add(bs2, parts[t].bs2);
+    }
+    return finish<C>(pks[0], ar, bs1, krs, bs2, r, s, proof_out);
+}
+
 }  // namespace ga
 
 using namespace ga;
@@ -615,9 +1013,116 @@ int ga_g16_pk_create(ga_ctx* h, const ga_g16_key* key, ga_g16_pk** out) {
     std::lock_guard<std::mutex> g(ctx->mu);
     hipSetDevice(ctx->device);
     G16Pk* pk = nullptr;
-    GA_DISPATCH_CURVE(key->curve, GA_CHECK(pk_create<C>(ctx, key, &pk)));
+    GA_CHECK(pk_create_from_struct(ctx, key, &pk));
     *out = reinterpret_cast<ga_g16_pk*>(pk);
     return GA_OK;
+}
+
+int ga_g16_builder_create(ga_ctx* h, int curve, uint64_t domain_cardinality, uint64_t nb_wires, uint32_t shard_index,
+                          uint32_t shard_count, ga_g16_builder** out) {
+    Ctx* ctx = reinterpret_cast<Ctx*>(h);
+    if (!ctx || !out || (curve != GA_BN254 && curve != GA_BLS12_381) || domain_cardinality == 0) {
+        set_error("ga_g16_builder_create: bad argument");
+        return GA_ERR_INVALID;
+    }
+    if (shard_count == 0) shard_count = 1;
+    if (shard_index >= shard_count) {
+        set_error("proving key: shard_index %u >= shard_count %u", shard_index, shard_count);
+        return GA_ERR_INVALID;
+    }
+    G16Stage* st = new G16Stage();
+    st->ctx = ctx;
+    st->curve = curve;
+    st->n = domain_cardinality;
+    st->nb_wires = nb_wires;
+    st->shard_index = shard_index;
+    st->shard_count = shard_count;
+    *out = reinterpret_cast<ga_g16_builder*>(st);
+    return GA_OK;
+}
+
+#define GA_STAGE(b)                                     \
+    G16Stage* st = reinterpret_cast<G16Stage*>(b);      \
+    if (!st) {                                          \
+        set_error("ga_g16_builder: null builder");      \
+        return GA_ERR_INVALID;                          \
+    }                                                   \
+    std::lock_guard<std::mutex> g(st->ctx->mu);         \
+    hipSetDevice(st->ctx->device)
+
+int ga_g16_builder_reserve(ga_g16_builder* b, int which, uint64_t total_len) {
+    GA_STAGE(b);
+    return stage_reserve(st, which, total_len);
+}
+
+int ga_g16_builder_append(ga_g16_builder* b, int which, const void* points, uint64_t count) {
+    GA_STAGE(b);
+    if (count && !points) {
+        set_error("ga_g16_builder_append: null pointer");
+        return GA_ERR_INVALID;
+    }
+    return stage_append(st, which, points, count);
+}
+
+int ga_g16_builder_set_point(ga_g16_builder* b, int which, const void* affine) {
+    GA_STAGE(b);
+    return stage_set_point(st, which, affine);
+}
+
+int ga_g16_builder_set_infinity(ga_g16_builder* b, int which, const uint8_t* mask, uint64_t nb_wires) {
+    GA_STAGE(b);
+    if ((which != 0 && which != 1) || !mask || nb_wires != st->nb_wires) {
+        set_error("ga_g16_builder_set_infinity: which must be 0/1 and the mask must have nbWires = %llu entries", (unsigned long long)st->nb_wires);
+        return GA_ERR_INVALID;
+    }
+    st->inf[which].assign(mask, mask + nb_wires);
+    st->have_inf[which] = true;
+    return GA_OK;
+}
+
+int ga_g16_builder_add_commitment_key(ga_g16_builder* b, const void* basis, const void* sigma, uint64_t len) {
+    GA_STAGE(b);
+    return stage_add_commitment_key(st, basis, sigma, len);
+}
+
+int ga_g16_builder_set_k_remove(ga_g16_builder* b, const uint64_t* ids, uint64_t len) {
+    GA_STAGE(b);
+    if (len && !ids) {
+        set_error("ga_g16_builder_set_k_remove: null pointer");
+        return GA_ERR_INVALID;
+    }
+    st->k_remove.assign(ids, ids + len);
+    return GA_OK;
+}
+
+int ga_g16_builder_finish(ga_g16_builder* b, int32_t precompute, ga_g16_pk** out) {
+    G16Stage* st = reinterpret_cast<G16Stage*>(b);
+    if (!st || !out) {
+        set_error("ga_g16_builder_finish: null argument");
+        return GA_ERR_INVALID;
+    }
+    int rc;
+    {
+        std::lock_guard<std::mutex> g(st->ctx->mu);
+        hipSetDevice(st->ctx->device);
+        G16Pk* pk = nullptr;
+        rc = GA_ERR_INVALID;
+        if (st->curve == GA_BN254) rc = stage_finish<Bn254>(st, precompute, &pk);
+        else if (st->curve == GA_BLS12_381) rc = stage_finish<Bls12381>(st, precompute, &pk);
+        if (rc == GA_OK) *out = reinterpret_cast<ga_g16_pk*>(pk);
+    }
+    delete st;   // consumed either way: a failed finish leaves nothing half-built behind
+    return rc;
+}
+
+void ga_g16_builder_destroy(ga_g16_builder* b) {
+    G16Stage* st = reinterpret_cast<G16Stage*>(b);
+    if (!st) return;
+    Ctx* ctx = st->ctx;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    delete st;
 }
 
 void ga_g16_pk_destroy(ga_g16_pk* p) {
@@ -688,6 +1193,120 @@ int ga_g16_finish(ga_g16_pk* p, const void* partials_sum, const void* r, const v
         return finish<C>(pk, host_load_jac<F1>(i), host_load_jac<F1>(i + sizeof(Jac<F1>)), host_load_jac<F1>(i + 2 * sizeof(Jac<F1>)),
                          host_load_jac<F2>(i + 3 * sizeof(Jac<F1>)), r, s, proof_out);
     });
+    return GA_OK;
+}
+
+// ---- pieces of a sharded proof (multi-GPU orchestration by the caller: gnark_amd/multigpu.py over RCCL, or ga_g16_prove_multi) ----
+int ga_g16_shard_layout(ga_g16_pk* p, uint64_t* out6) {
+    G16Pk* pk = reinterpret_cast<G16Pk*>(p);
+    if (!pk || !out6) {
+        set_error("ga_g16_shard_layout: null argument");
+        return GA_ERR_INVALID;
+    }
+    out6[0] = pk->off_z;
+    out6[1] = pk->len_z;
+    out6[2] = pk->w_lo;
+    out6[3] = pk->w_hi;
+    out6[4] = pk->n;
+    out6[5] = pk->nb_wires;
+    return GA_OK;
+}
+
+int ga_g16_witness_partial(ga_g16_pk* p, const void* w, uint64_t nb_public, void* partials_out) {
+    G16Pk* pk = reinterpret_cast<G16Pk*>(p);
+    if (!pk || !w || !partials_out) {
+        set_error("ga_g16_witness_partial: null argument");
+        return GA_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> g(pk->ctx->mu);
+    hipSetDevice(pk->ctx->device);
+    GA_DISPATCH_CURVE(pk->curve, {
+        typedef Fe<typename C::FpP> F1;
+        typedef Fe2<typename C::FpP> F2;
+        XYZZ<F1> ar, bs1, krs;
+        XYZZ<F2> bs2;
+        GA_CHECK(witness_msms<C>(pk, w, nb_public, &ar, &bs1, &krs, &bs2));
+        char* o = reinterpret_cast<char*>(partials_out);
+        host_store_jac<F1>(o, ar);
+        host_store_jac<F1>(o + sizeof(Jac<F1>), bs1);
+        host_store_jac<F1>(o + 2 * sizeof(Jac<F1>), krs);
+        host_store_jac<F2>(o + 3 * sizeof(Jac<F1>), bs2);
+    });
+    return GA_OK;
+}
+
+int ga_g16_h_chain(ga_g16_pk* p, const void* v, uint64_t n_constraints, void* out_dev) {
+    G16Pk* pk = reinterpret_cast<G16Pk*>(p);
+    if (!pk || !v || !out_dev) {
+        set_error("ga_g16_h_chain: null argument");
+        return GA_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> g(pk->ctx->mu);
+    hipSetDevice(pk->ctx->device);
+    GA_CHECK(h_upload(pk, v, n_constraints, out_dev, pk->ctx->stream));
+    GA_DISPATCH_CURVE(pk->curve, GA_CHECK(ntt_domain_h_chain<C>(pk->dom, out_dev)));
+    GA_HIP_CHECK(hipStreamSynchronize(pk->ctx->stream));   // the buffer is handed to another stream / device next
+    return GA_OK;
+}
+
+int ga_g16_h_combine(ga_g16_pk* p, void* a_dev, const void* b_dev, const void* c_dev) {
+    G16Pk* pk = reinterpret_cast<G16Pk*>(p);
+    if (!pk || !a_dev || !b_dev || !c_dev) {
+        set_error("ga_g16_h_combine: null argument");
+        return GA_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> g(pk->ctx->mu);
+    hipSetDevice(pk->ctx->device);
+    GA_DISPATCH_CURVE(pk->curve, GA_CHECK(ntt_domain_h_combine<C>(pk->dom, a_dev, b_dev, c_dev)));
+    GA_HIP_CHECK(hipStreamSynchronize(pk->ctx->stream));
+    return GA_OK;
+}
+
+int ga_g16_z_partial(ga_g16_pk* p, const void* h_slice_dev, void* partial_out) {
+    G16Pk* pk = reinterpret_cast<G16Pk*>(p);
+    if (!pk || (!h_slice_dev && pk->len_z) || !partial_out) {
+        set_error("ga_g16_z_partial: null argument");
+        return GA_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> g(pk->ctx->mu);
+    hipSetDevice(pk->ctx->device);
+    GA_DISPATCH_CURVE(pk->curve, {
+        typedef Fe<typename C::FpP> F1;
+        XYZZ<F1> z;
+        GA_CHECK(z_msm<C>(pk, h_slice_dev, &z));
+        host_store_jac<F1>(partial_out, z);
+    });
+    return GA_OK;
+}
+
+int ga_g16_prove_multi(ga_g16_pk* const* keys, uint32_t n, const void* w, const void* a, const void* b, const void* c,
+                       uint64_t n_constraints, uint64_t nb_public, const void* r, const void* s, void* proof_out) {
+    if (!keys || n == 0 || n > 64 || !w || !a || !b || !c || !r || !s || !proof_out) {
+        set_error("ga_g16_prove_multi: null argument or unsupported device count");
+        return GA_ERR_INVALID;
+    }
+    G16Pk* const* pks = reinterpret_cast<G16Pk* const*>(keys);
+    for (uint32_t t = 0; t < n; t++) {
+        if (!pks[t] || pks[t]->curve != pks[0]->curve || pks[t]->n != pks[0]->n || pks[t]->nb_wires != pks[0]->nb_wires ||
+            pks[t]->shard_count != n || pks[t]->shard_index != t) {
+            set_error("ga_g16_prove_multi: keys[%u] must be shard %u of %u of the same proving key", t, t, n);
+            return GA_ERR_INVALID;
+        }
+        for (uint32_t q = 0; q < t; q++)
+            if (pks[q]->ctx == pks[t]->ctx) {
+                set_error("ga_g16_prove_multi: keys[%u] and keys[%u] share a context; one context per shard", q, t);
+                return GA_ERR_INVALID;
+            }
+    }
+    if (n == 1) return ga_g16_prove(keys[0], w, a, b, c, n_constraints, nb_public, r, s, proof_out);
+    for (uint32_t t = 0; t < n; t++)   // peer access both ways between device 0 and the others (errors = already enabled / same device)
+        for (uint32_t q = 0; q < n; q++)
+            if (q != t && (t == 0 || q == 0) && pks[t]->ctx->device != pks[q]->ctx->device) {
+                hipSetDevice(pks[t]->ctx->device);
+                (void)hipDeviceEnablePeerAccess(pks[q]->ctx->device, 0);
+                (void)hipGetLastError();
+            }
+    GA_DISPATCH_CURVE(pks[0]->curve, return (prove_multi<C>(pks, n, w, a, b, c, n_constraints, nb_public, r, s, proof_out)));
     return GA_OK;
 }
 

@@ -545,33 +545,39 @@ int ntt_fft(Domain* d, uint32_t* d_data, int direction, int decimation, int on_c
     return ntt_run<FrP>(d, d_data, inverse, dit, pre, post);
 }
 
-// computeH on device buffers of exactly n elements each (already zero-padded); result in d_a (bit-reversed)
+// computeH in two pieces, so that a multi-GPU proof can run the three chains on different devices:
+//   chain(v)        : v <- FFT_coset(iFFT(v))       per input vector a, b, c   (prove.go:362-368)
+//   combine(a,b,c)  : a <- iFFT_coset((a*b - c) * den)   bit-reversed h        (prove.go:377-386)
+// Buffers hold exactly n elements each (already zero-padded).
 template <class FrP>
-int ntt_compute_h(Domain* d, uint32_t* d_a, uint32_t* d_b, uint32_t* d_c) {
+int ntt_compute_h_chain(Domain* d, uint32_t* d_v) {
+    if (d->logn == 0) return GA_OK;   // n = 1: iFFT and coset FFT are identities
+    // iFFT (DIF) without its 1/n ...
+    GA_CHECK(ntt_run<FrP>(d, d_v, /*inverse=*/true, /*dit=*/false, scale_none(), scale_none()));
+    // ... which is folded into the coset pre-scale of the forward DIT: factor g^bitrev(i) / n
+    return ntt_run<FrP>(d, d_v, /*inverse=*/false, /*dit=*/true, scale_pow(d->d_gn_lo, d->d_g_hi, true), scale_none());
+}
+
+template <class FrP>
+int ntt_compute_h_combine(Domain* d, uint32_t* d_a, const uint32_t* d_b, const uint32_t* d_c) {
     Ctx* ctx = d->ctx;
-    uint32_t* v[3] = {d_a, d_b, d_c};
-    if (d->logn == 0) {
-        // n = 1: iFFT and coset FFT are identities
-        NttScale den = scale_const(d->den);
-        hipLaunchKernelGGL((ntt_pointwise_h_kernel<FrP>), dim3(1), dim3(64), 0, ctx->stream, d_a, d_b, d_c, d->n, den);
-        GA_KERNEL_CHECK();
-        return GA_OK;
-    }
-    for (int k = 0; k < 3; k++) {
-        // iFFT (DIF) without its 1/n ...
-        GA_CHECK(ntt_run<FrP>(d, v[k], /*inverse=*/true, /*dit=*/false, scale_none(), scale_none()));
-        // ... which is folded into the coset pre-scale of the forward DIT: factor g^bitrev(i) / n
-        GA_CHECK(ntt_run<FrP>(d, v[k], /*inverse=*/false, /*dit=*/true, scale_pow(d->d_gn_lo, d->d_g_hi, true),
-                              scale_none()));
-    }
     {
         StageTimer st(ctx, "h_pointwise");
         NttScale den = scale_const(d->den);
-        unsigned blocks = (unsigned)((d->n + 255) / 256);
-        hipLaunchKernelGGL((ntt_pointwise_h_kernel<FrP>), dim3(blocks), dim3(256), 0, ctx->stream, d_a, d_b, d_c, d->n, den);
+        unsigned blocks = d->logn == 0 ? 1u : (unsigned)((d->n + 255) / 256);
+        hipLaunchKernelGGL((ntt_pointwise_h_kernel<FrP>), dim3(blocks), dim3(d->logn == 0 ? 64 : 256), 0, ctx->stream, d_a, d_b, d_c, d->n, den);
         GA_KERNEL_CHECK();
     }
+    if (d->logn == 0) return GA_OK;
     return ntt_fft<FrP>(d, d_a, GA_FFT_INVERSE, GA_DIF, 1);
+}
+
+// computeH on device buffers of exactly n elements each (already zero-padded); result in d_a (bit-reversed)
+template <class FrP>
+int ntt_compute_h(Domain* d, uint32_t* d_a, uint32_t* d_b, uint32_t* d_c) {
+    uint32_t* v[3] = {d_a, d_b, d_c};
+    for (int k = 0; k < 3; k++) GA_CHECK(ntt_compute_h_chain<FrP>(d, v[k]));
+    return ntt_compute_h_combine<FrP>(d, d_a, d_b, d_c);
 }
 
 template <class FrP>

@@ -18,6 +18,14 @@ int ntt_domain_fft<Bls12381>(Domain* d, void* d_data, int direction, int decimat
     return ntt_fft<Bls12381::FrP>(d, (uint32_t*)d_data, direction, decimation, on_coset);
 }
 template <>
+int ntt_domain_h_chain<Bls12381>(Domain* d, void* d_v) {
+    return ntt_compute_h_chain<Bls12381::FrP>(d, (uint32_t*)d_v);
+}
+template <>
+int ntt_domain_h_combine<Bls12381>(Domain* d, void* d_a, const void* d_b, const void* d_c) {
+    return ntt_compute_h_combine<Bls12381::FrP>(d, (uint32_t*)d_a, (const uint32_t*)d_b, (const uint32_t*)d_c);
+}
+template <>
 int ntt_domain_compute_h<Bls12381>(Domain* d, void* d_a, void* d_b, void* d_c) {
     return ntt_compute_h<Bls12381::FrP>(d, (uint32_t*)d_a, (uint32_t*)d_b, (uint32_t*)d_c);
 }

@@ -18,6 +18,14 @@ int ntt_domain_fft<Bn254>(Domain* d, void* d_data, int direction, int decimation
     return ntt_fft<Bn254::FrP>(d, (uint32_t*)d_data, direction, decimation, on_coset);
 }
 template <>
+int ntt_domain_h_chain<Bn254>(Domain* d, void* d_v) {
+    return ntt_compute_h_chain<Bn254::FrP>(d, (uint32_t*)d_v);
+}
+template <>
+int ntt_domain_h_combine<Bn254>(Domain* d, void* d_a, const void* d_b, const void* d_c) {
+    return ntt_compute_h_combine<Bn254::FrP>(d, (uint32_t*)d_a, (const uint32_t*)d_b, (const uint32_t*)d_c);
+}
+template <>
 int ntt_domain_compute_h<Bn254>(Domain* d, void* d_a, void* d_b, void* d_c) {
     return ntt_compute_h<Bn254::FrP>(d, (uint32_t*)d_a, (uint32_t*)d_b, (uint32_t*)d_c);
 }

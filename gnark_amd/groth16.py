@@ -74,9 +74,11 @@ class ProvingKey:
     """setup.go:25-48 fields, uploaded once ("PinToGPU"); free with FreeGPUResources() (icicle.go:1493)."""
 
     def __init__(self, ctx: Context, curve, *, domain_cardinality, alpha1, beta1, delta1, A, B, Z, K, beta2, delta2, B2,
-                 infinityA, infinityB, precompute: int = 0, shard=(0, 1), commitment_keys=(), k_remove=()):
+                 infinityA, infinityB, precompute: int = 0, shard=(0, 1), commitment_keys=(), k_remove=(), staged_chunk: int = 0):
         """commitment_keys: [(Basis, BasisExpSigma)] per pk.CommitmentKeys[i] (setup.go:276-287); k_remove: sorted wire ids of the
-        private committed wires and the commitment wires, left out of the K MSM (prove.go:231-235)."""
+        private committed wires and the commitment wires, left out of the K MSM (prove.go:231-235).
+        staged_chunk > 0 builds the key through ga_g16_builder_* in chunks of that many points (the cgo-safe call pattern of
+        go/backend/accelerated/mi355x) instead of the struct-of-pointers ga_g16_pk_create."""
         cid = curve_id(curve)
         fp = FP_LIMBS[cid]
         self.ctx, self.curve = ctx, cid
@@ -88,6 +90,40 @@ class ProvingKey:
         ib = np.ascontiguousarray(infinityB, dtype=np.uint8)
         if ia.shape != ib.shape:
             raise ValueError("InfinityA and InfinityB must have nbWires entries each")
+        self.shard = (int(shard[0]), int(shard[1]))
+        self.nb_commitments = len(commitment_keys)
+        self.nb_wires = int(ia.shape[0])
+        self.domain_cardinality = int(domain_cardinality)
+        if staged_chunk:
+            lib = ctx.lib
+            b = C.c_void_p()
+            lib.check(lib.ga_g16_builder_create(ctx.handle, cid, int(domain_cardinality), ia.shape[0], int(shard[0]), int(shard[1]), C.byref(b)))
+            try:
+                for which, arr in enumerate((A, B, Z, K, B2)):
+                    lib.check(lib.ga_g16_builder_reserve(b, which, arr.shape[0]))
+                    for lo in range(0, arr.shape[0], int(staged_chunk)):
+                        part = arr[lo:lo + int(staged_chunk)].copy()   # a fresh buffer per call, wiped afterwards: nothing may be retained
+                        lib.check(lib.ga_g16_builder_append(b, which, _ptr(part), part.shape[0]))
+                        part[:] = 0
+                for which, pt in enumerate((alpha1, beta1, delta1, beta2, delta2)):
+                    lib.check(lib.ga_g16_builder_set_point(b, which, _ptr(pt)))
+                lib.check(lib.ga_g16_builder_set_infinity(b, 0, _ptr(ia), ia.shape[0]))
+                lib.check(lib.ga_g16_builder_set_infinity(b, 1, _ptr(ib), ib.shape[0]))
+                for bas, sig in commitment_keys:
+                    bas, sig = g1(bas), g1(sig)
+                    if bas.shape != sig.shape:
+                        raise ValueError("Basis and BasisExpSigma must have the same length")
+                    lib.check(lib.ga_g16_builder_add_commitment_key(b, _ptr(bas), _ptr(sig), bas.shape[0]))
+                rem = np.ascontiguousarray(k_remove, dtype=np.uint64)
+                if rem.size:
+                    lib.check(lib.ga_g16_builder_set_k_remove(b, _ptr(rem), rem.size))
+            except Exception:
+                lib.ga_g16_builder_destroy(b)
+                raise
+            h = C.c_void_p()
+            lib.check(lib.ga_g16_builder_finish(b, int(precompute), C.byref(h)))
+            self.handle = h
+            return
         key = _lib.G16Key()
         key.curve, key.domain_cardinality = cid, int(domain_cardinality)
         key.g1_alpha, key.g1_beta, key.g1_delta = alpha1.ctypes.data, beta1.ctypes.data, delta1.ctypes.data
@@ -172,6 +208,56 @@ def ProvePartial(pk: ProvingKey, solution: Solution, nb_public: int) -> np.ndarr
     lib = pk.ctx.lib
     lib.check(lib.ga_g16_prove_partial(pk.handle, _ptr(W), _ptr(A), _ptr(B), _ptr(Cc), A.shape[0], nb_public, _ptr(out)))
     return out
+
+
+def ShardLayout(pk: ProvingKey) -> dict:
+    """where this key's shard sits: slice [off_z, off_z+len_z) of h / pk.G1.Z, wire range [w_lo, w_hi) of W (ga_g16_shard_layout)"""
+    out = (C.c_uint64 * 6)()
+    pk.ctx.lib.check(pk.ctx.lib.ga_g16_shard_layout(pk.handle, out))
+    return dict(zip(("off_z", "len_z", "w_lo", "w_hi", "n", "nb_wires"), (int(v) for v in out)))
+
+
+def WitnessPartial(pk: ProvingKey, W, nb_public: int) -> np.ndarray:
+    """the four witness MSMs over this key's shard: A | B1 | K (G1Jac) | B2 (G2Jac) as one uint64 vector (ga_g16_witness_partial)"""
+    W = as_u64(W, 4)
+    if W.shape[0] != pk.nb_wires:
+        raise ValueError(f"len(W)={W.shape[0]} != nbWires={pk.nb_wires}")
+    fp = FP_LIMBS[pk.curve]
+    out = np.zeros(15 * fp, dtype=np.uint64)
+    pk.ctx.lib.check(pk.ctx.lib.ga_g16_witness_partial(pk.handle, _ptr(W), nb_public, _ptr(out)))
+    return out
+
+
+def HChain(pk: ProvingKey, v, out_dev_ptr: int):
+    """out_dev <- FFT_coset(iFFT(v)) for one of the solver's A, B, C (ga_g16_h_chain); out_dev: n fr elements on pk's device"""
+    v = as_u64(v, 4)
+    pk.ctx.lib.check(pk.ctx.lib.ga_g16_h_chain(pk.handle, _ptr(v), v.shape[0], C.c_void_p(out_dev_ptr)))
+
+
+def HCombine(pk: ProvingKey, a_dev_ptr: int, b_dev_ptr: int, c_dev_ptr: int):
+    """a_dev <- h = iFFT_coset((a*b - c)/(g^n - 1)), bit-reversed (ga_g16_h_combine)"""
+    pk.ctx.lib.check(pk.ctx.lib.ga_g16_h_combine(pk.handle, C.c_void_p(a_dev_ptr), C.c_void_p(b_dev_ptr), C.c_void_p(c_dev_ptr)))
+
+
+def ZPartial(pk: ProvingKey, h_slice_dev_ptr: int) -> np.ndarray:
+    """MSM of this shard's slice of pk.G1.Z with the matching slice of h (device pointer to element off_z): G1Jac"""
+    out = np.zeros(3 * FP_LIMBS[pk.curve], dtype=np.uint64)
+    pk.ctx.lib.check(pk.ctx.lib.ga_g16_z_partial(pk.handle, C.c_void_p(h_slice_dev_ptr), _ptr(out)))
+    return out
+
+
+def ProveMulti(pks, solution: Solution, nb_public: int, r, s) -> Proof:
+    """One proof over several devices from one process (ga_g16_prove_multi): pks[i] = shard i of len(pks), each in its own
+    Context.  What the Go shim calls under mi355x.WithDevices."""
+    W, A, B, Cc = (as_u64(x, 4) for x in (solution.W, solution.A, solution.B, solution.C))
+    r, s = as_u64(np.asarray(r).reshape(1, 4), 4), as_u64(np.asarray(s).reshape(1, 4), 4)
+    pk0 = pks[0]
+    fp = FP_LIMBS[pk0.curve]
+    out = np.zeros(8 * fp, dtype=np.uint64)
+    hs = (C.c_void_p * len(pks))(*[p.handle for p in pks])
+    lib = pk0.ctx.lib
+    lib.check(lib.ga_g16_prove_multi(hs, len(pks), _ptr(W), _ptr(A), _ptr(B), _ptr(Cc), A.shape[0], nb_public, _ptr(r), _ptr(s), _ptr(out)))
+    return Proof(pk0.curve, out[: 2 * fp].copy(), out[2 * fp: 6 * fp].copy(), out[6 * fp:].copy(), lib)
 
 
 def SumPartials(curve, parts, lib=None) -> np.ndarray:

@@ -73,12 +73,65 @@ def msm_window_sharded(ctx, curve, group: int, points, scalars, n: int, dist, de
     return ecc.combine_windows(curve, group, windows, cbits, lib=ctx.lib)
 
 
-def groth16_prove_sharded(pk, solution, nb_public: int, r, s, dist, device=None):
-    """One proof over a key sharded by base-point range (groth16.ProvingKey(..., shard=(rank, world))): every rank uploads
-    the solution, computes H redundantly (20 ms at 2^24, cheaper than shipping 512 MiB of h over xGMI) and runs the five MSMs
-    over its slices; one all_gather of 3 G1Jac + 1 G2Jac per rank, then every rank finishes identically."""
+def groth16_prove_sharded(pk, solution, nb_public: int, r, s, dist, device=None, replicate_h=False):
+    """One proof over a key sharded by base-point range (groth16.ProvingKey(..., shard=(rank, world))), one process per GPU.
+
+    Serial work is not replicated: every rank uploads only the wire range of W its bases cover; the three chains of computeH
+    (FFT_coset(iFFT(.)) of the solver's A, B, C) run on ranks 0, 1, 2 -- three uploads over three PCIe links -- and travel to rank 0
+    over xGMI (send/recv, 32 B x n each); rank 0 finishes h and scatters the slices (32 B x n / world per peer); every rank runs
+    the MSM over its slice of pk.G1.Z; one all_gather of 3 G1Jac + 1 G2Jac per rank; every rank finishes identically.
+    replicate_h=True keeps the round-1 scheme (every rank recomputes h) for comparison."""
     from . import groth16
-    part = groth16.ProvePartial(pk, solution, nb_public)
-    if dist is not None and dist.get_world_size() > 1:
-        part = groth16.SumPartials(pk.curve, _all_gather_u64(part, dist, device), lib=pk.ctx.lib)
-    return groth16.Finish(pk, part, r, s)
+    world = 1 if dist is None else dist.get_world_size()
+    if world == 1 or replicate_h:
+        part = groth16.ProvePartial(pk, solution, nb_public)
+        if world > 1:
+            part = groth16.SumPartials(pk.curve, _all_gather_u64(part, dist, device), lib=pk.ctx.lib)
+        return groth16.Finish(pk, part, r, s)
+    import torch
+    rank = dist.get_rank()
+    lay = groth16.ShardLayout(pk)
+    n = lay["n"]
+    dev = device if device is not None else torch.device("cpu")
+    sync = (lambda: torch.cuda.synchronize(dev)) if device is not None else (lambda: None)
+    owner = [0, 1, 2 if world >= 3 else 0]
+    vecs = [solution.A, solution.B, solution.C]
+    part = groth16.WitnessPartial(pk, solution.W, nb_public)
+    # device buffers as torch tensors, so that the collective library can move them; the prover library gets raw pointers
+    bufs = {}
+    for k in range(3):
+        if rank == owner[k] or rank == 0:
+            bufs[k] = torch.empty((n, 4), dtype=torch.int64, device=dev)
+    sync()
+    for k in range(3):
+        if rank == owner[k]:
+            groth16.HChain(pk, vecs[k], bufs[k].data_ptr())
+    for k in range(3):                       # b and c travel to rank 0
+        if owner[k] != 0:
+            if rank == owner[k]:
+                dist.send(bufs[k], dst=0)
+            elif rank == 0:
+                dist.recv(bufs[k], src=owner[k])
+    # rank 0: h, then one equally sized (padded) slice per rank
+    share = (n - 1 + world - 1) // world + 1
+    mine = torch.empty((share, 4), dtype=torch.int64, device=dev)
+    pieces = None
+    if rank == 0:
+        sync()
+        groth16.HCombine(pk, bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr())
+        pieces = []
+        for q in range(world):
+            lo, hi = shard_range(n - 1, q, world)
+            t = torch.zeros((share, 4), dtype=torch.int64, device=dev)
+            t[: hi - lo] = bufs[0][lo:hi]
+            pieces.append(t)
+    dist.scatter(mine, pieces, src=0)
+    sync()
+    z = groth16.ZPartial(pk, mine.data_ptr())
+    fp = part.shape[0] // 15
+    both = np.concatenate([part, z])
+    gathered = _all_gather_u64(both, dist, device)
+    total = groth16.SumPartials(pk.curve, [g[: 15 * fp] for g in gathered], lib=pk.ctx.lib)
+    zs = combine_partials(pk.curve, 0, [g[15 * fp:] for g in gathered], lib=pk.ctx.lib)
+    total[6 * fp: 9 * fp] = ecc.jac_add(pk.curve, 0, np.ascontiguousarray(total[6 * fp: 9 * fp]), zs, lib=pk.ctx.lib)
+    return groth16.Finish(pk, total, r, s)

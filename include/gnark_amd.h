@@ -226,6 +226,38 @@ typedef struct ga_g16_key {
 int ga_g16_pk_create(ga_ctx* ctx, const ga_g16_key* key, ga_g16_pk** out);
 void ga_g16_pk_destroy(ga_g16_pk* pk);   /* FreeGPUResources, icicle.go:1493-1549 */
 
+/* The same key, staged vector by vector (replaces loadG1 / loadG1Raw / loadG2, icicle.go:319-359, one call per host slice).
+ * Every call takes ONE flat pointer to pointer-free memory and has copied what it needs when it returns, so a cgo caller never
+ * stores a Go pointer inside a C struct and nothing is retained (ga_g16_key holds pointers: from Go it needs runtime.Pinner,
+ * see go/backend/accelerated/mi355x).  It is also what the key-file readers below are built on.
+ *   create -> reserve(which, len) -> append(which, chunk, count)* -> set_point x5 -> set_infinity x2
+ *          [-> add_commitment_key* -> set_k_remove] -> finish  (finish consumes the builder; destroy abandons it) */
+#define GA_KEY_G1_A 0
+#define GA_KEY_G1_B 1
+#define GA_KEY_G1_Z 2
+#define GA_KEY_G1_K 3
+#define GA_KEY_G2_B 4
+#define GA_KEY_NB_VECTORS 5
+#define GA_KEY_G1_ALPHA 0
+#define GA_KEY_G1_BETA 1
+#define GA_KEY_G1_DELTA 2
+#define GA_KEY_G2_BETA 3
+#define GA_KEY_G2_DELTA 4
+#define GA_KEY_NB_POINTS 5
+typedef struct ga_g16_builder ga_g16_builder;
+int ga_g16_builder_create(ga_ctx* ctx, int curve, uint64_t domain_cardinality, uint64_t nb_wires, uint32_t shard_index,
+                          uint32_t shard_count, ga_g16_builder** out);
+int ga_g16_builder_reserve(ga_g16_builder* b, int which_vector, uint64_t total_len);
+/* the next `count` points of vector `which_vector` (affine, Montgomery); with a sharded builder only the part inside this shard's
+ * range is copied, the caller still streams the whole vector */
+int ga_g16_builder_append(ga_g16_builder* b, int which_vector, const void* points, uint64_t count);
+int ga_g16_builder_set_point(ga_g16_builder* b, int which_point, const void* affine);
+int ga_g16_builder_set_infinity(ga_g16_builder* b, int which /* 0: InfinityA, 1: InfinityB */, const uint8_t* mask, uint64_t nb_wires);
+int ga_g16_builder_add_commitment_key(ga_g16_builder* b, const void* basis, const void* basis_exp_sigma, uint64_t len);
+int ga_g16_builder_set_k_remove(ga_g16_builder* b, const uint64_t* wire_ids, uint64_t len);
+int ga_g16_builder_finish(ga_g16_builder* b, int32_t precompute, ga_g16_pk** out);
+void ga_g16_builder_destroy(ga_g16_builder* b);
+
 /* One proof, from the solver's output to the three proof points (prove.go:130-315 minus commitments):
  *   w        : solution.W, nb_wires fr elements (Montgomery)
  *   a,b,c    : solution.A/B/C, n_constraints elements each
@@ -244,6 +276,24 @@ int ga_g16_prove(ga_g16_pk* pk, const void* w, const void* a, const void* b, con
 int ga_g16_prove_partial(ga_g16_pk* pk, const void* w, const void* a, const void* b, const void* c,
                          uint64_t n_constraints, uint64_t nb_public, void* partials_out);
 int ga_g16_finish(ga_g16_pk* pk, const void* partials_sum, const void* r, const void* s, void* proof_out);
+
+/* The same proof in pieces, for callers that orchestrate several devices themselves (gnark_amd/multigpu.py does it with one
+ * process per GPU and RCCL): the witness MSMs of this shard (A | B1 | K as G1Jac, B2 as G2Jac -- W is uploaded only over the wire
+ * range the shard's bases cover), one chain of computeH per call (v = the solver's A, B or C on the host; out_dev = n fr elements
+ * on this key's device, holding FFT_coset(iFFT(v)) afterwards), the combination h = iFFT_coset((a*b - c)/(g^n - 1)) in a_dev
+ * (bit-reversed), and the MSM of this shard's slice of pk.G1.Z with the matching slice of h (h_slice_dev points at element off_z).
+ * ga_g16_shard_layout: out6 = {off_z, len_z, w_lo, w_hi, domain cardinality, nb_wires}. */
+int ga_g16_shard_layout(ga_g16_pk* pk, uint64_t* out6);
+int ga_g16_witness_partial(ga_g16_pk* pk, const void* w, uint64_t nb_public, void* partials_out);
+int ga_g16_h_chain(ga_g16_pk* pk, const void* v, uint64_t n_constraints, void* out_dev);
+int ga_g16_h_combine(ga_g16_pk* pk, void* a_dev, const void* b_dev, const void* c_dev);
+int ga_g16_z_partial(ga_g16_pk* pk, const void* h_slice_dev, void* partial_out);
+/* One proof over the GPUs of a node from ONE process (what a Go caller uses: mi355x.WithDevices): keys[i] = shard i of n of the
+ * same proving key, each created in its own context on its own device.  One host thread per device inside the call; computeH's
+ * three chains run on the first three devices, their results and the slices of h move over xGMI (hipMemcpyPeerAsync); the
+ * partial sums are added on the host and finished with (r, s).  Arguments as ga_g16_prove. */
+int ga_g16_prove_multi(ga_g16_pk* const* keys, uint32_t n, const void* w, const void* a, const void* b, const void* c,
+                       uint64_t n_constraints, uint64_t nb_public, const void* r, const void* s, void* proof_out);
 
 /* Proof.WriteTo wire format (marshal.go:33-58, no commitments): compressed Ar | Bs | Krs | u32 0 | PoK(inf).
  * Returns the number of bytes written in *len (164 for BN254, 244 for BLS12-381). */

@@ -48,8 +48,22 @@ def main():
             B2=pts_to_arr(c, 1, pk.B2), infinityA=pk.infinityA, infinityB=pk.infinityB, precompute=precompute, shard=(rank, world))
         sol = groth16.Solution(fr_to_arr(c, wv), fr_to_arr(c, A), fr_to_arr(c, B), fr_to_arr(c, Cc))
         proof = multigpu.groth16_prove_sharded(dpk, sol, cs.nb_public, fr_to_arr(c, [r]), fr_to_arr(c, [s]), dist)
+        proof_rep = multigpu.groth16_prove_sharded(dpk, sol, cs.nb_public, fr_to_arr(c, [r]), fr_to_arr(c, [s]), dist, replicate_h=True)
         dpk.FreeGPUResources()
         assert proof.WriteTo() == pyref.proof_bytes(c, *pyref.groth16_prove(pk, cs, wv, r, s)), "sharded Groth16 proof differs"
+        assert proof_rep.WriteTo() == proof.WriteTo(), "replicated-h scheme differs"
+    # ---- a larger synthetic instance (2^8 constraints, ragged): every rank holds 1/world of the key ----------------------
+    from gnark_amd import synth
+    import checkers  # noqa: F401  (oracle/ on sys.path)
+    inst = synth.make_instance(ctx, c.name, 8, 0xD157, nb_constraints=250)
+    spk = inst.proving_key(ctx, shard=(rank, world), staged_chunk=64)
+    try:
+        sproof = multigpu.groth16_prove_sharded(spk, inst.solution, inst.nb_public, inst.r, inst.s, dist)
+    finally:
+        spk.FreeGPUResources()
+    want = oracle.groth16_prove(c.cid, dict(inst.key, n=inst.n), inst.solution.W, inst.solution.A, inst.solution.B, inst.solution.C,
+                                inst.nb_public, inst.r, inst.s, nthreads=2)
+    assert np.array_equal(sproof.Ar, want[0]) and np.array_equal(sproof.Bs, want[1]) and np.array_equal(sproof.Krs, want[2]), "sharded 2^8"
     dist.barrier()
     if rank == 0:
         print("MGPU_OK world=%d" % world)

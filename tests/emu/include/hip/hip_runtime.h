@@ -249,6 +249,8 @@ inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) {
     return hipSuccess;
 }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t = nullptr) { return hipMemcpy(d, s, n, k); }
+inline hipError_t hipMemcpyPeerAsync(void* d, int, const void* s, int, size_t n, hipStream_t = nullptr) { return hipMemcpy(d, s, n, hipMemcpyDeviceToDevice); }
+inline hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
 inline hipError_t hipMemset(void* d, int v, size_t n) {
     memset(d, v, n);
     return hipSuccess;

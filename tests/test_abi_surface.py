@@ -74,3 +74,19 @@ def test_plain_c_client_runs_against_the_emulation_build(tmp_path, emu_lib):
                            "-Wl,-rpath," + emu_dir, "-o", exe])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ABI_CLIENT_OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_cgo_call_pattern_and_concurrency_against_the_emulation_build(tmp_path, emu_lib):
+    """tests/c_abi/cgo_pattern.c: the Go shim's call sequence replayed from C (key staged through ga_g16_builder_* with every
+    source buffer poisoned after its call, struct-of-pointers variant with the struct in C heap, solutions poisoned after
+    ga_g16_prove) and the concurrency guarantees of icicle.go:77-86,821-823 (two threads on one context interleaved with ga_fft,
+    a second context on the same device) -- all proofs identical"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "cgo_pattern_emu")
+    emu_dir = os.path.join(root, "tests", "emu")
+    subprocess.check_call(["gcc", "-std=gnu99", "-O2", "-pthread", "-DCGO_LOGN=6", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "c_abi", "cgo_pattern.c"), os.path.join(emu_dir, "libgnark_amd_emu.so"),
+                           "-Wl,-rpath," + emu_dir, "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "CGO_PATTERN_OK" in r.stdout, r.stdout + r.stderr

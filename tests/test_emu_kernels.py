@@ -652,3 +652,141 @@ def test_emu_fr_vec_mul(emu_ctx):
 def test_emu_plonk_quotient_identity_checker(emu_ctx, pinned):
     """the full-size PLONK checker at n = 2^6 under the emulation"""
     check_plonk_quotient_identity(emu_ctx, BN254, 6, nthreads=2, pinned=pinned)
+
+
+# ---- staged key construction (ga_g16_builder_*): the cgo-safe call pattern ----------------------------------------------------
+def _commit_key_kwargs(c, pk, cs):
+    removed = sorted({j for cm in cs.commitments for j in cm.private_committed} | {cm.commitment_index for cm in cs.commitments})
+    return dict(domain_cardinality=pk.n, alpha1=pts_to_arr(c, 0, [pk.alpha1]), beta1=pts_to_arr(c, 0, [pk.beta1]),
+                delta1=pts_to_arr(c, 0, [pk.delta1]), A=pts_to_arr(c, 0, pk.A), B=pts_to_arr(c, 0, pk.B), Z=pts_to_arr(c, 0, pk.Z),
+                K=pts_to_arr(c, 0, pk.K), beta2=pts_to_arr(c, 1, [pk.beta2]), delta2=pts_to_arr(c, 1, [pk.delta2]),
+                B2=pts_to_arr(c, 1, pk.B2), infinityA=pk.infinityA, infinityB=pk.infinityB,
+                commitment_keys=[(pts_to_arr(c, 0, b), pts_to_arr(c, 0, e)) for b, e in pk.commitment_keys], k_remove=removed)
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("precompute", [1, -1], ids=["tables", "no-tables"])
+def test_emu_groth16_staged_builder(emu_ctx, c, precompute):
+    """the key streamed through ga_g16_builder_* in chunks of 3 points (one flat pointer per call, the source buffer wiped after
+    every call) gives the same proofs and commitments as the struct-of-pointers ga_g16_pk_create, unsharded and as shard 1 of 3"""
+    rng = pyref.Xoshiro(77)
+    cs = pyref.commit_r1cs()
+    pk, _, _ = pyref.groth16_setup(c, cs, [rng.field(c.r) for _ in range(8)])
+    w = pyref.commit_solve(c, cs, 5, 6, lambda i, ww: pyref.commitment_hint(pk, cs, i, ww)[1])
+    A, B, Cc = pyref.r1cs_solve(c, cs, w)
+    sol = groth16.Solution(W=fr_to_arr(c, w), A=fr_to_arr(c, A), B=fr_to_arr(c, B), C=fr_to_arr(c, Cc))
+    r, s = fr_to_arr(c, [rng.field(c.r)]), fr_to_arr(c, [rng.field(c.r)])
+    kw = _commit_key_kwargs(c, pk, cs)
+    vals = fr_to_arr(c, [w[j] for j in cs.commitments[0].private_committed])
+    out = {}
+    for name, extra in (("struct", {}), ("staged", {"staged_chunk": 3})):
+        dpk = groth16.ProvingKey(emu_ctx, c.name, precompute=precompute, **kw, **extra)
+        try:
+            out[name] = (groth16.Prove(dpk, sol, cs.nb_public, r, s).raw(), dpk.Commit(0, vals))
+        finally:
+            dpk.FreeGPUResources()
+        dpk = groth16.ProvingKey(emu_ctx, c.name, precompute=precompute, shard=(1, 3), **kw, **extra)
+        try:
+            out[name + "-shard"] = groth16.ProvePartial(dpk, sol, cs.nb_public)
+        finally:
+            dpk.FreeGPUResources()
+    assert np.array_equal(out["struct"][0], out["staged"][0])
+    assert np.array_equal(out["struct"][1][0], out["staged"][1][0]) and np.array_equal(out["struct"][1][1], out["staged"][1][1])
+    assert np.array_equal(out["struct-shard"], out["staged-shard"])
+    ar, bs, krs, _, _ = pyref.groth16_prove_bsb22(pk, cs, w, arr_to_fr(c, r)[0], arr_to_fr(c, s)[0])
+    fp = c.fp_limbs
+    assert (arr_to_g1_affine(c, out["staged"][0][:2 * fp]), arr_to_g2_affine(c, out["staged"][0][2 * fp:6 * fp]),
+            arr_to_g1_affine(c, out["staged"][0][6 * fp:])) == (ar, bs, krs)
+
+
+def test_emu_groth16_builder_errors(emu_ctx):
+    """state machine of the builder: append before reserve, overflow, finish on an incomplete key, null arguments"""
+    import ctypes as C
+    lib, c = emu_ctx.lib, BN254
+    b = C.c_void_p()
+    assert lib.ga_g16_builder_create(emu_ctx.handle, 7, 4, 5, 0, 1, C.byref(b)) != 0            # unknown curve
+    assert lib.ga_g16_builder_create(emu_ctx.handle, c.cid, 4, 5, 3, 3, C.byref(b)) != 0        # shard_index >= shard_count
+    lib.check(lib.ga_g16_builder_create(emu_ctx.handle, c.cid, 4, 5, 0, 1, C.byref(b)))
+    pts = pts_to_arr(c, 0, [c.g1] * 4)
+    assert lib.ga_g16_builder_append(b, 0, pts.ctypes.data, 1) == -4                             # GA_ERR_STATE: not reserved
+    lib.check(lib.ga_g16_builder_reserve(b, 0, 3))
+    assert lib.ga_g16_builder_reserve(b, 0, 3) == -4                                             # reserved twice
+    assert lib.ga_g16_builder_reserve(b, 9, 3) == -1
+    lib.check(lib.ga_g16_builder_append(b, 0, pts.ctypes.data, 2))
+    assert lib.ga_g16_builder_append(b, 0, pts.ctypes.data, 2) == -1                             # overflows the reserved length
+    assert lib.ga_g16_builder_append(b, 0, None, 1) == -1
+    assert lib.ga_g16_builder_set_point(b, 7, pts.ctypes.data) == -1
+    mask = np.zeros(4, dtype=np.uint8)
+    assert lib.ga_g16_builder_set_infinity(b, 0, mask.ctypes.data, 4) == -1                      # nb_wires is 5
+    h = C.c_void_p()
+    assert lib.ga_g16_builder_finish(b, 0, C.byref(h)) == -4 and not h.value                     # incomplete; the builder is consumed
+    assert b"incomplete" in lib.ga_last_error()
+    b2 = C.c_void_p()
+    lib.check(lib.ga_g16_builder_create(emu_ctx.handle, c.cid, 4, 5, 0, 1, C.byref(b2)))
+    lib.ga_g16_builder_destroy(b2)                                                               # abandon: frees the staged buffers
+
+
+# ---- one proof over several devices from one process (ga_g16_prove_multi) ------------------------------------------------------
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("nshards", [2, 3, 5])
+def test_emu_groth16_prove_multi(emu_ctx, c, nshards, logn=7, precompute=1):
+    """shard i of N in its own context (one context per device; here all on device 0): the native multi-device prover -- one
+    host thread per shard, computeH's chains on the first three, peer copies of b, c and of the h slices -- returns the proof of
+    the unsharded key, which equals the known-dlog closed form; also the pieces API (witness / chain / combine / z) by hand"""
+    from gnark_amd import synth
+    from gnark_amd.device import Context
+    inst = synth.make_instance(emu_ctx, c.name, logn, 0x77 + nshards, nb_constraints=(1 << logn) - 5)
+    sol = inst.solution
+    pk1 = inst.proving_key(emu_ctx, precompute=precompute)
+    try:
+        want = groth16.Prove(pk1, sol, inst.nb_public, inst.r, inst.s)
+    finally:
+        pk1.FreeGPUResources()
+    ctxs = [Context(0, lib=emu_ctx.lib) for _ in range(nshards)]
+    pks = []
+    try:
+        for i, cx in enumerate(ctxs):
+            pks.append(inst.proving_key(cx, precompute=precompute, shard=(i, nshards), staged_chunk=50))
+        got = groth16.ProveMulti(pks, sol, inst.nb_public, inst.r, inst.s)
+        assert np.array_equal(got.raw(), want.raw())
+        # wire ranges: together they cover what the bases need, each about 1/N of W
+        lays = [groth16.ShardLayout(p) for p in pks]
+        assert lays[0]["off_z"] == 0 and lays[-1]["off_z"] + lays[-1]["len_z"] == inst.n - 1
+        assert all(l["w_hi"] - l["w_lo"] <= inst.nb_wires // nshards + 4 for l in lays)
+        # the same proof assembled by hand from the pieces, h on shard 0 only
+        n = inst.n
+        bufs = [ctxs[0].malloc(n * 32) for _ in range(3)]
+        for v, b in zip((sol.A, sol.B, sol.C), bufs):
+            groth16.HChain(pks[0], v, b.ptr)
+        groth16.HCombine(pks[0], bufs[0].ptr, bufs[1].ptr, bufs[2].ptr)
+        h = bufs[0].to_host((n, 4))
+        parts = []
+        for p, cx, lay in zip(pks, ctxs, lays):
+            hs = cx.to_device(h[lay["off_z"]: lay["off_z"] + lay["len_z"]])
+            wpart = groth16.WitnessPartial(p, sol.W, inst.nb_public)
+            z = groth16.ZPartial(p, hs.ptr)
+            fp = c.fp_limbs
+            wpart[6 * fp: 9 * fp] = ecc.jac_add(c.name, 0, np.ascontiguousarray(wpart[6 * fp: 9 * fp]), z, lib=emu_ctx.lib)
+            parts.append(wpart)
+            hs.free()
+        byhand = groth16.Finish(pks[0], groth16.SumPartials(c.name, parts, lib=emu_ctx.lib), inst.r, inst.s)
+        assert np.array_equal(byhand.raw(), want.raw())
+        for b in bufs:
+            b.free()
+        # argument validation: shards out of order, shared context
+        with pytest.raises(Exception, match="must be shard"):
+            groth16.ProveMulti(pks[::-1], sol, inst.nb_public, inst.r, inst.s)
+    finally:
+        for p in pks:
+            p.FreeGPUResources()
+        for cx in ctxs:
+            cx.close()
+    # the closed form from the key's discrete logs (oracle dot products)
+    d = fft.Domain(emu_ctx, c.name, inst.n)
+    try:
+        hh = d.compute_h(sol.A, sol.B, sol.C)
+    finally:
+        d.close()
+    exp = synth.expected_exponents(inst, hh, lambda a, b: oracle.fr_dot(c.cid, a, b))
+    pt = lambda group, k: oracle.jac_to_affine(c.cid, group, oracle.generator_mul(c.cid, group, k))
+    assert np.array_equal(got.Ar, pt(0, exp["Ar"])) and np.array_equal(got.Bs, pt(1, exp["Bs"])) and np.array_equal(got.Krs, pt(0, exp["Krs"]))

@@ -515,6 +515,30 @@ def test_plain_c_client_of_the_abi(tmp_path):
     assert r.returncode == 0 and "ABI_CLIENT_OK" in r.stdout, r.stdout + r.stderr
 
 
+def test_cgo_call_pattern_and_concurrency(tmp_path):
+    """tests/c_abi/cgo_pattern.c on the device at 2^14 constraints: staged key (transient source buffers), struct key, poisoned
+    solutions, 4 host threads over 2 contexts on one GPU, proofs interleaved with ga_fft -- all proofs identical"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "cgo_pattern")
+    lib = os.path.join(root, "gnark_amd")
+    subprocess.check_call(["gcc", "-std=gnu99", "-O2", "-pthread", "-DCGO_LOGN=14", "-DCGO_THREAD_ROUNDS=8", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "c_abi", "cgo_pattern.c"), "-L", lib, "-lgnark_amd", "-Wl,-rpath," + lib, "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "CGO_PATTERN_OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("precompute", [1, -1], ids=["tables", "no-tables"])
+def test_groth16_staged_builder(gpu_ctx, c, precompute):
+    cases.test_emu_groth16_staged_builder(gpu_ctx, c, precompute)
+
+
+def test_groth16_builder_errors(gpu_ctx):
+    cases.test_emu_groth16_builder_errors(gpu_ctx)
+
+
 def test_compute_h_2_20_polynomial_identity(gpu_ctx):
     """size-independent property of computeH at 2^20: A(x)B(x) - C(x) == H(x)(x^n - 1) at a random point, with A, B, C
     interpolated by the CPU oracle and H (bit-reversed coefficients, deg <= n-2) from the device."""

@@ -19,9 +19,16 @@ def test_shard_range_partitions_exactly():
             assert max(sizes) - min(sizes) <= 1
 
 
-def test_two_rank_gloo_msm_sharding(emu_lib):
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_ranks_msm_and_groth16_sharding(emu_lib, world):
+    """world 2: rank 0 runs the a and c chains of computeH, rank 1 the b chain; world 3: one chain per rank.  Both MSM
+    partitionings, the sharded Groth16 proof (wire-range upload, chains sent to rank 0, h slices scattered) against the oracle's
+    proof bytes, and the round-1 replicate-h scheme for comparison."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29731", os.path.join(ROOT, "tests", "_mgpu_worker.py")]
-    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
-    assert r.returncode == 0 and "MGPU_OK world=2" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(29731 + world), os.path.join(ROOT, "tests", "_mgpu_worker.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0 and "MGPU_OK world=%d" % world in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
