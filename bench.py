@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--plonk-log-n", type=int, default=int(os.environ.get("GA_BENCH_PLONK_LOGN", "22")), help="0 disables the PLONK leg")
     ap.add_argument("--curve", default="bn254")
+    ap.add_argument("--partition", default=os.environ.get("GA_BENCH_PARTITION", "range"), choices=["range", "window"],
+                    help="N > 1 Groth16 leg: key sharded by base-point range (partition B) or by scalar windows (partition A, config 4's wording)")
     return ap.parse_args()
 
 
@@ -137,7 +139,7 @@ def main():
         cbits, nwin = ecc.plan(cid, _lib.G1, n)
 
     from gnark_amd import multigpu
-    dev = torch.device("cuda", device_index) if backend == "nccl" else None
+    dev = torch.device("cuda", device_index) if not emu else None   # with gloo on a GPU box device buffers are staged through the host
 
     def step():
         # N = 1: plain MSM.  N > 1: partition B (base-point range) -- every rank reduces its own 2^log_n pairs to one
@@ -281,19 +283,25 @@ def main():
         except Exception as e:   # never lose the headline line over the secondary leg
             out["plonk"] = {"error": str(e)[:300]}
 
-    # ---- Groth16 across ranks (N > 1): key sharded by base-point range, partial MSM sums all-gathered (multigpu.py) -------
+    # ---- Groth16 across ranks (N > 1): ONE 2^log_n proof over all GPUs -- strong scaling of BASELINE config 3 / 4 ------------------
+    # key sharded by base-point range (or by windows), W uploaded per wire range, computeH's chains on ranks 0..2, h slices scattered
+    # over xGMI, one all_gather of the partial sums (gnark_amd/multigpu.py)
     if world > 1 and args.groth16_proofs > 0 and os.environ.get("GA_BENCH_SHARDED_G16", "1") != "0":
         g16 = None
         try:
             import psutil
-            need = (8 << 30) * (1 << args.log_n) // (1 << 24) + (2 << 30)   # full synthetic key + solution staged on the host per rank
-            if psutil.virtual_memory().available < need * world // max(1, world // 8 or 1):
+            need = (12 << 30) * (1 << args.log_n) // (1 << 24) + (2 << 30)   # full synthetic key + solution staged on the host per rank
+            if psutil.virtual_memory().available < need * world:
                 raise RuntimeError("not enough host memory to stage %d synthetic keys" % world)
-            from gnark_amd import groth16
+            from gnark_amd import groth16, synth
             if table is None:
                 bases.free()
                 scalars.free()
-            inst, pk = synth_groth16(ctx, cid, args.log_n, 0x5EED0005, shard=(rank, world), want_dlogs=False)   # same seeds on every rank
+            inst = synth.make_instance(ctx, cid, args.log_n, 0x5EED0005, want_dlogs=False)   # same seeds on every rank
+            kw = dict(shard=(rank, world)) if args.partition == "range" else dict(window_shard=(rank, world), precompute=1)
+            t_pin = time.perf_counter()
+            pk = inst.proving_key(ctx, **kw)
+            pin_s = time.perf_counter() - t_pin
             sol, nb_public, r, s = inst.solution, inst.nb_public, inst.r, inst.s
             multigpu.groth16_prove_sharded(pk, sol, nb_public, r, s, dist, dev)   # warm-up
             fence()
@@ -302,9 +310,26 @@ def main():
                 proof = multigpu.groth16_prove_sharded(pk, sol, nb_public, r, s, dist, dev)
             fence()
             el = time.perf_counter() - t0
+            rep_ms = None
+            if os.environ.get("GA_BENCH_REPLICATE_H", "0") == "1":   # the round-1 scheme, for comparison
+                multigpu.groth16_prove_sharded(pk, sol, nb_public, r, s, dist, dev, replicate_h=True)
+                fence()
+                t0 = time.perf_counter()
+                multigpu.groth16_prove_sharded(pk, sol, nb_public, r, s, dist, dev, replicate_h=True)
+                fence()
+                rep_ms = round((time.perf_counter() - t0) * 1e3, 2)
+            lay = groth16.ShardLayout(pk)
             pk.FreeGPUResources()
+            tm = torch.tensor([el], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            el = float(tm.item())
             g16 = {"proofs_per_s": round(args.groth16_proofs / el, 4), "ms_per_proof": round(el * 1e3 / args.groth16_proofs, 2),
-                   "constraints": n, "mode": "one proof over %d GPUs: key sharded by base-point range, H replicated, all_gather of 4 partial points" % world,
+                   "proofs": args.groth16_proofs, "constraints": n, "scaling": "strong", "partition": args.partition,
+                   "mode": ("one proof over %d GPUs: key sharded by base-point range (1/%d of the tables per GPU), W uploaded per wire range "
+                            "(%d of %d wires on rank 0), computeH chains on ranks 0-2, h slices scattered, all_gather of 5 partial points" %
+                            (world, world, lay["w_hi"] - lay["w_lo"], lay["nb_wires"])) if args.partition == "range" else
+                           ("one proof over %d GPUs: whole key on every GPU, windows of every MSM shared out, h broadcast, all_gather of 5 partial points" % world),
+                   "key_pin_s": round(pin_s, 1), "replicate_h_ms_per_proof": rep_ms,
                    "proof_sha": __import__("hashlib").sha256(proof.WriteTo()).hexdigest()[:16]}
         except Exception as e:   # never lose the headline line because of the optional leg
             g16 = {"error": repr(e)[:300]}

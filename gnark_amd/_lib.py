@@ -42,6 +42,7 @@ class G16Key(C.Structure):
         ("nb_commitments", C.c_uint32),
         ("ck_basis", C.POINTER(C.c_void_p)), ("ck_basis_exp_sigma", C.POINTER(C.c_void_p)), ("ck_len", C.POINTER(C.c_uint64)),
         ("k_remove", C.POINTER(C.c_uint64)), ("len_k_remove", C.c_uint64),
+        ("window_shard_index", C.c_uint32), ("window_shard_count", C.c_uint32),
     ]
 
 
@@ -77,6 +78,7 @@ _PROTOS = {
     "ga_msm_table_create": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_size_t, C.c_uint, C.POINTER(_P)]),
     "ga_msm_table_destroy": (None, [_P]),
     "ga_msm_table_run": (C.c_int, [_P, _P, C.c_uint, _P]),
+    "ga_msm_table_run_windows": (C.c_int, [_P, _P, C.c_uint, C.c_int, C.c_int, _P]),
     "ga_msm_table_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
     "ga_jac_add": (C.c_int, [C.c_int, C.c_int, _P, _P, _P]),
     "ga_jac_to_affine": (C.c_int, [C.c_int, C.c_int, _P, _P]),
@@ -104,6 +106,7 @@ _PROTOS = {
     "ga_g16_builder_set_infinity": (C.c_int, [_P, C.c_int, _P, C.c_uint64]),
     "ga_g16_builder_add_commitment_key": (C.c_int, [_P, _P, _P, C.c_uint64]),
     "ga_g16_builder_set_k_remove": (C.c_int, [_P, _P, C.c_uint64]),
+    "ga_g16_builder_set_window_shard": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
     "ga_g16_builder_finish": (C.c_int, [_P, C.c_int32, C.POINTER(_P)]),
     "ga_g16_builder_destroy": (None, [_P]),
     "ga_g16_prove": (C.c_int, [_P, _P, _P, _P, _P, C.c_uint64, C.c_uint64, _P, _P, _P]),

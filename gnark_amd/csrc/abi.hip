@@ -364,6 +364,30 @@ int ga_msm_table_run(ga_msm_table* th, const void* scalars, unsigned flags, void
     return GA_OK;
 }
 
+int ga_msm_table_run_windows(ga_msm_table* th, const void* scalars, unsigned flags, int win_lo, int win_hi, void* out_jac) {
+    MsmTable* t = reinterpret_cast<MsmTable*>(th);
+    if (!t || !scalars || !out_jac) {
+        set_error("ga_msm_table_run_windows: null argument");
+        return GA_ERR_INVALID;
+    }
+    if (win_lo < 0 || win_hi > t->nwin || win_hi < win_lo) {
+        set_error("ga_msm_table_run_windows: window range [%d,%d) outside [0,%d)", win_lo, win_hi, t->nwin);
+        return GA_ERR_INVALID;
+    }
+    Ctx* c = t->ctx;
+    Lock l(c);
+    GA_DISPATCH_CURVE(t->curve, GA_DISPATCH_GROUP(t->group, {
+                          typedef typename GroupField<C, G>::F F;
+                          Staged ss{c};
+                          GA_CHECK(ss.stage(scalars, t->n * 32, flags & GA_SCALARS_ON_DEVICE));
+                          XYZZ<F> sum;
+                          GA_CHECK((msm_table_device<C, G>(c, t->d_table, ss.dev, t->n, (flags & GA_SCALARS_MONTGOMERY) != 0, t->c, &sum, win_lo,
+                                                           win_hi)));
+                          host_store_jac<F>(out_jac, sum);
+                      }));
+    return GA_OK;
+}
+
 int ga_fr_linear_combination(ga_ctx* h, int curve, uint64_t n, int k, const void* const* vecs, const void* scalars, void* out,
                              int on_device) {
     Ctx* c = reinterpret_cast<Ctx*>(h);

@@ -153,12 +153,13 @@ int msm_table_build(Ctx* ctx, const void* d_bases, size_t n, int c, void* d_tabl
 template <class C, int G>
 size_t msm_table_point_bytes();
 template <class C, int G>
-int msm_table_device(Ctx* ctx, const void* d_table, const void* d_scalars, size_t n, bool scalars_mont, int c, void* h_sum);
+int msm_table_device(Ctx* ctx, const void* d_table, const void* d_scalars, size_t n, bool scalars_mont, int c, void* h_sum, int win_lo = 0,
+                     int win_hi = -1);
 // slot 0/1 selects one of two scratch sets; on_aux runs the preparation on ctx->aux_stream (the caller orders it against
 // the main stream with events) so that it overlaps the previous MSM's (ALU-bound) bucket accumulation
 template <class C>
 int msm_prepare_table_scalars(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, int c, MsmPrepared* P, int slot = 0,
-                              bool on_aux = false);
+                              bool on_aux = false, int win_lo = 0, int win_hi = -1);
 template <class C, int G>
 int msm_table_device_reuse(Ctx* ctx, const void* d_table, const MsmPrepared& P, void* h_sum);
 

@@ -46,6 +46,9 @@ struct G16Pk {
     // multi-GPU partition B: this key holds slice [off, off+len) of every base vector (ga_g16_key.shard_index/count)
     uint32_t shard_index = 0, shard_count = 1;
     uint64_t off_k = 0, off_z = 0, full_len_k = 0;
+    // multi-GPU partition A (scalar windows, BASELINE config 4's wording): the WHOLE key is pinned on every device and this one
+    // accumulates only share win_index of win_count of the Pippenger windows of every MSM; partial results add up
+    uint32_t win_index = 0, win_count = 1;
     uint64_t w_lo = 0, w_hi = 0;   // wire range [w_lo, w_hi) the A and B gather lists (and a filtered K list) of this shard touch
     std::vector<uint8_t> alpha1, beta1, delta1, beta2, delta2;   // affine images (host)
 };
@@ -87,6 +90,7 @@ struct G16Stage {
     int curve = 0;
     uint64_t n = 0, nb_wires = 0;
     uint32_t shard_index = 0, shard_count = 1;
+    uint32_t win_index = 0, win_count = 1;
     struct Vec {
         void* d = nullptr;
         uint64_t total = 0, lo = 0, cnt = 0, seen = 0;
@@ -191,6 +195,11 @@ static int stage_finish(G16Stage* st, int precompute, G16Pk** out) {
         set_error("proving key: %llu wires exceed the 32-bit wire index space", (unsigned long long)st->nb_wires);
         return GA_ERR_INVALID;
     }
+    if (st->win_count > 1 && (st->shard_count > 1 || st->win_index >= st->win_count)) {
+        set_error("proving key: window sharding (%u of %u) cannot be combined with base-range sharding, and the index must be below the count",
+                  st->win_index, st->win_count);
+        return GA_ERR_INVALID;
+    }
     std::vector<uint32_t> ia, ib;
     ia.reserve(len_a);
     ib.reserve(len_b);
@@ -209,6 +218,8 @@ static int stage_finish(G16Stage* st, int precompute, G16Pk** out) {
     pk->nb_wires = st->nb_wires;
     pk->shard_count = st->shard_count;
     pk->shard_index = st->shard_index;
+    pk->win_count = st->win_count ? st->win_count : 1;
+    pk->win_index = st->win_index;
     auto take = [&](int which, void** slot, uint64_t* len) {   // the device buffer changes owner
         *slot = st->v[which].d;
         *len = st->v[which].cnt;
@@ -289,21 +300,22 @@ static int stage_finish(G16Stage* st, int precompute, G16Pk** out) {
         pk->share_a = dense(pk->len_a);
         pk->share_b = dense(pk->len_b);
         pk->share_k = dense(pk->len_k);
-        msm_plan_table<C>(pk->nb_wires, &pk->c_w, &nw);
+        bool plan_ok = msm_plan_table<C>(pk->nb_wires, &pk->c_w, &nw) == GA_OK;
         const uint64_t wide = (uint64_t)nw * pk->nb_wires;
-        msm_plan_table<C>(pk->len_a, &pk->c_a, &nw);
+        plan_ok = msm_plan_table<C>(pk->len_a, &pk->c_a, &nw) == GA_OK && plan_ok;
         uint64_t need = pk->share_a ? wide * t1 : (uint64_t)nw * pk->len_a * t1;
-        msm_plan_table<C>(pk->len_b, &pk->c_b, &nw);
+        plan_ok = msm_plan_table<C>(pk->len_b, &pk->c_b, &nw) == GA_OK && plan_ok;
         need += pk->share_b ? wide * (t1 + t2) : (uint64_t)nw * pk->len_b * (t1 + t2);
-        msm_plan_table<C>(pk->len_z, &pk->c_z, &nw);
+        plan_ok = msm_plan_table<C>(pk->len_z, &pk->c_z, &nw) == GA_OK && plan_ok;
         need += (uint64_t)nw * pk->len_z * t1;
-        msm_plan_table<C>(pk->len_k, &pk->c_k, &nw);
+        plan_ok = msm_plan_table<C>(pk->len_k, &pk->c_k, &nw) == GA_OK && plan_ok;
         need += pk->share_k ? wide * t1 : (uint64_t)nw * pk->len_k * t1;
+        if (!plan_ok && precompute > 0) rc = GA_ERR_INVALID;   // vectors beyond the table index space: the caller asked for tables explicitly
         size_t free_b = 0, total_b = 0;
         hipMemGetInfo(&free_b, &total_b);
         // leave room for the per-proof scratch (~0.6 KB per constraint measured) and some slack
-        const bool fits = (double)need + (double)pk->n * 1024.0 < 0.85 * (double)free_b;
-        if (precompute > 0 || fits) {
+        const bool fits = plan_ok && (double)need + (double)pk->n * 1024.0 < 0.85 * (double)free_b;
+        if (rc == GA_OK && (precompute > 0 || fits)) {
             auto make = [&](void** slot, uint64_t len, int c, size_t psz, auto build) -> int {
                 if (len == 0) return GA_OK;
                 const int nwin = C::FrP::BITS / c + 1;
@@ -439,6 +451,8 @@ static int pk_create_from_struct(Ctx* ctx, const ga_g16_key* key, G16Pk** out) {
         set_error("proving key: shard_index %u >= shard_count %u", st.shard_index, st.shard_count);
         return GA_ERR_INVALID;
     }
+    st.win_count = key->window_shard_count ? key->window_shard_count : 1;
+    st.win_index = key->window_shard_index;
     const void* vec[GA_KEY_NB_VECTORS] = {key->g1_a, key->g1_b, key->g1_z, key->g1_k, key->g2_b};
     const uint64_t len[GA_KEY_NB_VECTORS] = {key->len_a, key->len_b, key->len_z, key->len_k, key->len_b2};
     for (int w = 0; w < GA_KEY_NB_VECTORS; w++) {
@@ -509,35 +523,58 @@ static int witness_msms(G16Pk* pk, const void* w, uint64_t nb_public, XYZZ<Fe<ty
     XYZZ<F1> ar, bs1, krs;
     XYZZ<F2> bs2;
     MsmPrepared prep;
+    // this device's share of the windows of a table with window width c (everything unless the key is window-sharded)
+    auto share_of = [&](int c, int* lo, int* hi) { window_share(C::FrP::BITS / c + 1, pk->win_index, pk->win_count, lo, hi); };
+    bool prep_live = false;   // `prep` holds the digits of wB for G2.B
     auto table_msm_g1 = [&](const void* table, const void* scal, uint64_t len, int c, XYZZ<F1>* out) -> int {
-        if (len == 0) {
+        int lo, hi;
+        share_of(c, &lo, &hi);
+        prep_live = false;
+        if (len == 0 || hi <= lo) {
             *out = xyzz_inf<F1>();
             return GA_OK;
         }
-        GA_CHECK(msm_prepare_table_scalars<C>(ctx, scal, len, true, c, &prep));
+        GA_CHECK(msm_prepare_table_scalars<C>(ctx, scal, len, true, c, &prep, 0, false, lo, hi));
+        prep_live = true;
         return msm_table_device_reuse<C, GA_G1>(ctx, table, prep, out);
     };
     if (pk->tables) {
         // digits + sort of the WHOLE witness once (scratch slot 1), reused by every wire-indexed table
         MsmPrepared prep_w;
-        if (pk->share_a || pk->share_b || pk->share_k) GA_CHECK(msm_prepare_table_scalars<C>(ctx, d_w, pk->nb_wires, true, pk->c_w, &prep_w, 1));
-        if (pk->share_a) GA_CHECK((msm_table_device_reuse<C, GA_G1>(ctx, pk->d_a, prep_w, &ar)));
+        bool w_live = false;
+        if (pk->share_a || pk->share_b || pk->share_k) {
+            int lo, hi;
+            share_of(pk->c_w, &lo, &hi);
+            if (hi > lo) {
+                GA_CHECK(msm_prepare_table_scalars<C>(ctx, d_w, pk->nb_wires, true, pk->c_w, &prep_w, 1, false, lo, hi));
+                w_live = true;
+            }
+        }
+        auto shared_g1 = [&](const void* table, XYZZ<F1>* out) -> int {
+            if (!w_live) {
+                *out = xyzz_inf<F1>();
+                return GA_OK;
+            }
+            return msm_table_device_reuse<C, GA_G1>(ctx, table, prep_w, out);
+        };
+        if (pk->share_a) GA_CHECK(shared_g1(pk->d_a, &ar));
         else GA_CHECK(table_msm_g1(pk->d_a, d_wa, pk->len_a, pk->c_a, &ar));
         if (pk->share_b) {
-            GA_CHECK((msm_table_device_reuse<C, GA_G1>(ctx, pk->d_b, prep_w, &bs1)));
-            GA_CHECK((msm_table_device_reuse<C, GA_G2>(ctx, pk->d_b2, prep_w, &bs2)));
+            GA_CHECK(shared_g1(pk->d_b, &bs1));
+            if (w_live) GA_CHECK((msm_table_device_reuse<C, GA_G2>(ctx, pk->d_b2, prep_w, &bs2)));
+            else bs2 = xyzz_inf<F2>();
         } else {
             GA_CHECK(table_msm_g1(pk->d_b, d_wb, pk->len_b, pk->c_b, &bs1));
-            if (pk->len_b2) GA_CHECK((msm_table_device_reuse<C, GA_G2>(ctx, pk->d_b2, prep, &bs2)));   // same scalars wB: digits/sort shared
+            if (pk->len_b2 && prep_live) GA_CHECK((msm_table_device_reuse<C, GA_G2>(ctx, pk->d_b2, prep, &bs2)));   // same scalars wB: digits/sort shared
             else bs2 = xyzz_inf<F2>();
         }
-        if (pk->share_k) GA_CHECK((msm_table_device_reuse<C, GA_G1>(ctx, pk->d_k, prep_w, &krs)));
+        if (pk->share_k) GA_CHECK(shared_g1(pk->d_k, &krs));
         else GA_CHECK(table_msm_g1(pk->d_k, d_wk, pk->len_k, pk->c_k, &krs));
     } else {
-        GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_a, d_wa, pk->len_a, true, &ar)));
-        GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_b, d_wb, pk->len_b, true, &bs1)));
-        GA_CHECK((host_msm<C, GA_G2>(ctx, pk->d_b2, d_wb, pk->len_b2, true, &bs2)));
-        GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_k, d_wk, pk->len_k, true, &krs)));
+        GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_a, d_wa, pk->len_a, true, &ar, pk->win_index, pk->win_count)));
+        GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_b, d_wb, pk->len_b, true, &bs1, pk->win_index, pk->win_count)));
+        GA_CHECK((host_msm<C, GA_G2>(ctx, pk->d_b2, d_wb, pk->len_b2, true, &bs2, pk->win_index, pk->win_count)));
+        GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_k, d_wk, pk->len_k, true, &krs, pk->win_index, pk->win_count)));
     }
     *o_ar = ar;
     *o_bs1 = bs1;
@@ -568,11 +605,17 @@ static int z_msm(G16Pk* pk, const void* d_h_slice, XYZZ<Fe<typename C::FpP>>* ou
         return GA_OK;
     }
     if (pk->tables) {
+        int lo, hi;
+        window_share(C::FrP::BITS / pk->c_z + 1, pk->win_index, pk->win_count, &lo, &hi);
+        if (hi <= lo) {
+            *out = xyzz_inf<F1>();
+            return GA_OK;
+        }
         MsmPrepared prep;
-        GA_CHECK(msm_prepare_table_scalars<C>(ctx, d_h_slice, pk->len_z, true, pk->c_z, &prep));
+        GA_CHECK(msm_prepare_table_scalars<C>(ctx, d_h_slice, pk->len_z, true, pk->c_z, &prep, 0, false, lo, hi));
         return msm_table_device_reuse<C, GA_G1>(ctx, pk->d_z, prep, out);
     }
-    return host_msm<C, GA_G1>(ctx, pk->d_z, d_h_slice, pk->len_z, true, out);
+    return host_msm<C, GA_G1>(ctx, pk->d_z, d_h_slice, pk->len_z, true, out, pk->win_index, pk->win_count);
 }
 
 // RAII for the pieces that must not outlive an early return
@@ -902,6 +945,7 @@ static int prove_multi(G16Pk* const* pks, uint32_t n, const void* w, const void*
             if (owner[k] == t) ok = ctx->scratch_get(names[k], N * 32, &chain_buf[k]) == GA_OK;
             if (t == 0 && ok) ok = ctx->scratch_get(names[k], N * 32, &dev0_buf[k]) == GA_OK;
         }
+        // a base-range shard receives its slice of h, a window shard all of it
         if (ok && pk->len_z) ok = t == 0 || ctx->scratch_get("h_slice", pk->len_z * 32, &h_slice[t]) == GA_OK;
         if (!ok) bail("multi-device prove: buffers");
         if (!sh.barrier(0)) return;
@@ -1095,6 +1139,17 @@ int ga_g16_builder_set_k_remove(ga_g16_builder* b, const uint64_t* ids, uint64_t
     return GA_OK;
 }
 
+int ga_g16_builder_set_window_shard(ga_g16_builder* b, uint32_t index, uint32_t count) {
+    GA_STAGE(b);
+    if (count == 0 || index >= count) {
+        set_error("ga_g16_builder_set_window_shard: index %u must be below count %u", index, count);
+        return GA_ERR_INVALID;
+    }
+    st->win_index = index;
+    st->win_count = count;
+    return GA_OK;
+}
+
 int ga_g16_builder_finish(ga_g16_builder* b, int32_t precompute, ga_g16_pk** out) {
     G16Stage* st = reinterpret_cast<G16Stage*>(b);
     if (!st || !out) {
@@ -1143,8 +1198,9 @@ int ga_g16_prove(ga_g16_pk* p, const void* w, const void* a, const void* b, cons
     }
     std::lock_guard<std::mutex> g(pk->ctx->mu);
     hipSetDevice(pk->ctx->device);
-    if (pk->shard_count != 1) {
-        set_error("ga_g16_prove: this key holds shard %u of %u; use ga_g16_prove_partial + ga_g16_finish", pk->shard_index, pk->shard_count);
+    if (pk->shard_count != 1 || pk->win_count != 1) {
+        set_error("ga_g16_prove: this key holds one share of a sharded key (base range %u/%u, windows %u/%u); use ga_g16_prove_multi or "
+                  "ga_g16_prove_partial + ga_g16_finish", pk->shard_index, pk->shard_count, pk->win_index, pk->win_count);
         return GA_ERR_STATE;
     }
     GA_DISPATCH_CURVE(pk->curve, {
@@ -1199,6 +1255,7 @@ int ga_g16_finish(ga_g16_pk* p, const void* partials_sum, const void* r, const v
 // ---- pieces of a sharded proof (multi-GPU orchestration by the caller: gnark_amd/multigpu.py over RCCL, or ga_g16_prove_multi) ----
 int ga_g16_shard_layout(ga_g16_pk* p, uint64_t* out6) {
     G16Pk* pk = reinterpret_cast<G16Pk*>(p);
+    uint64_t* out8 = out6;
     if (!pk || !out6) {
         set_error("ga_g16_shard_layout: null argument");
         return GA_ERR_INVALID;
@@ -1209,6 +1266,8 @@ int ga_g16_shard_layout(ga_g16_pk* p, uint64_t* out6) {
     out6[3] = pk->w_hi;
     out6[4] = pk->n;
     out6[5] = pk->nb_wires;
+    out8[6] = pk->win_index;
+    out8[7] = pk->win_count;
     return GA_OK;
 }
 
@@ -1287,9 +1346,11 @@ int ga_g16_prove_multi(ga_g16_pk* const* keys, uint32_t n, const void* w, const 
     }
     G16Pk* const* pks = reinterpret_cast<G16Pk* const*>(keys);
     for (uint32_t t = 0; t < n; t++) {
+        const bool by_range = pks[t] && pks[t]->shard_count == n && pks[t]->shard_index == t && pks[t]->win_count == 1;
+        const bool by_window = pks[t] && pks[t]->win_count == n && pks[t]->win_index == t && pks[t]->shard_count == 1;
         if (!pks[t] || pks[t]->curve != pks[0]->curve || pks[t]->n != pks[0]->n || pks[t]->nb_wires != pks[0]->nb_wires ||
-            pks[t]->shard_count != n || pks[t]->shard_index != t) {
-            set_error("ga_g16_prove_multi: keys[%u] must be shard %u of %u of the same proving key", t, t, n);
+            !(n == 1 || by_range || by_window) || (pks[t]->win_count > 1) != (pks[0]->win_count > 1)) {
+            set_error("ga_g16_prove_multi: keys[%u] must be shard %u of %u of the same proving key (all by base range or all by windows)", t, t, n);
             return GA_ERR_INVALID;
         }
         for (uint32_t q = 0; q < t; q++)

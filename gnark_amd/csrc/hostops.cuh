@@ -50,15 +50,36 @@ XYZZ<F> host_horner(const XYZZ<F>* W, int nwin, int c) {
     return acc;
 }
 
-// full MSM on device + Horner on host -> XYZZ
+// contiguous share `index` of `count` of nwin windows (same split as multigpu.shard_range)
+inline void window_share(int nwin, uint32_t index, uint32_t count, int* lo, int* hi) {
+    const int base = nwin / (int)count, rem = nwin % (int)count, k = (int)index;
+    *lo = k * base + (k < rem ? k : rem);
+    *hi = *lo + base + (k < rem ? 1 : 0);
+}
+
+// MSM on device + Horner on host -> XYZZ.  Long vectors are split along the point axis (the (point, window) pair space of one
+// launch is 2^31): the analogue of msmChunkedG1/G2, icicle.go:362-467.  (win_index, win_count) restrict the accumulation to one
+// share of the windows (multi-GPU partition A): the other windows count as zero in the Horner sum, so shares add up.
 template <class C, int G>
 int host_msm(Ctx* ctx, const void* d_bases, const void* d_scalars, size_t n, bool mont,
-             XYZZ<typename GroupField<C, G>::F>* out) {
+             XYZZ<typename GroupField<C, G>::F>* out, uint32_t win_index = 0, uint32_t win_count = 1) {
     typedef typename GroupField<C, G>::F F;
     int c, nwin;
     GA_CHECK(msm_plan<C>(G, n, &c, &nwin));
-    std::vector<XYZZ<F>> W(nwin);
-    GA_CHECK((msm_windows_device<C, G>(ctx, d_bases, d_scalars, n, mont, c, 0, nwin, W.data())));
+    int lo = 0, hi = nwin;
+    window_share(nwin, win_index, win_count ? win_count : 1, &lo, &hi);
+    std::vector<XYZZ<F>> W(nwin, xyzz_inf<F>());
+    if (hi > lo && n > 0) {
+        const size_t max_chunk = ((size_t)1 << 31) / (size_t)(hi - lo) - 1;
+        std::vector<XYZZ<F>> part(hi - lo);
+        for (size_t done = 0; done < n;) {
+            const size_t cn = n - done < max_chunk ? n - done : max_chunk;
+            GA_CHECK((msm_windows_device<C, G>(ctx, (const char*)d_bases + done * sizeof(Affine<F>), (const char*)d_scalars + done * 32, cn, mont, c,
+                                              lo, hi, part.data())));
+            for (int w = lo; w < hi; w++) W[w] = add(W[w], part[w - lo]);
+            done += cn;
+        }
+    }
     *out = host_horner(W.data(), nwin, c);
     return GA_OK;
 }

@@ -718,7 +718,7 @@ int msm_prepare(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, in
     auto key = [&](const char* k) { return std::string(k) + sfx; };
     const int nwin = FrP::BITS / c + 1;
     if (win_hi < 0) win_hi = nwin;
-    if (win_lo < 0 || win_hi > nwin || win_lo >= win_hi || c < 2 || c > 24 || (table && (win_lo != 0 || win_hi != nwin))) {
+    if (win_lo < 0 || win_hi > nwin || win_lo >= win_hi || c < 2 || c > 24) {
         set_error("msm: bad window range [%d,%d) of %d (c=%d, table=%d)", win_lo, win_hi, nwin, c, (int)table);
         return GA_ERR_INVALID;
     }
@@ -730,6 +730,8 @@ int msm_prepare(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, in
     const uint32_t half = 1u << (c - 1);
     const uint64_t m = (uint64_t)nwl * n;
     const uint64_t nb64 = table ? half : (uint64_t)nwl * half;
+    // table mode: the value indexes the WHOLE table [window][point] even when only a window range is accumulated (multi-GPU
+    // partition A on pinned bases: the 2^(c*w) factors are baked into the table, so partial results simply add)
     if (m >= (1ull << 31) || nb64 >= (1ull << 31) || (table && (uint64_t)nwin * n >= (1ull << 31))) {
         set_error("msm: %d windows x %zu points exceeds the 2^31 pair index space; shard the call", nwl, n);
         return GA_ERR_INVALID;
@@ -989,17 +991,19 @@ int msm_windows_device(Ctx* ctx, const void* d_bases, const void* d_scalars, siz
     return msm_accumulate_reduce<F>(ctx, d_bases, P, out);
 }
 
-// MSM over a precomputed table: one XYZZ result (no Horner)
+// MSM over a precomputed table: one XYZZ result (no Horner); windows [win_lo, win_hi) only (win_hi < 0 = all): the partial
+// sums of disjoint window ranges add up to the full result
 template <class C, int G>
-int msm_table_device(Ctx* ctx, const void* d_table, const void* d_scalars, size_t n, bool scalars_mont, int c, void* h_sum) {
+int msm_table_device(Ctx* ctx, const void* d_table, const void* d_scalars, size_t n, bool scalars_mont, int c, void* h_sum, int win_lo,
+                     int win_hi) {
     typedef typename GroupField<C, G>::F F;
     XYZZ<F>* out = reinterpret_cast<XYZZ<F>*>(h_sum);
-    if (n == 0) {
+    if (n == 0 || (win_hi >= 0 && win_hi <= win_lo)) {
         *out = xyzz_inf<F>();
         return GA_OK;
     }
     MsmPrepared P;
-    GA_CHECK(msm_prepare<typename C::FrP>(ctx, d_scalars, n, scalars_mont, c, 0, -1, true, &P));
+    GA_CHECK(msm_prepare<typename C::FrP>(ctx, d_scalars, n, scalars_mont, c, win_lo, win_hi, true, &P));
     return msm_accumulate_reduce<F>(ctx, d_table, P, out);
 }
 
@@ -1013,8 +1017,9 @@ int msm_table_device_reuse(Ctx* ctx, const void* d_table, const MsmPrepared& P, 
 // group-independent preparation callable from translation units that do not include this header (groth16.hip)
 template <class C>
 int msm_prepare_table_scalars(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, int c, MsmPrepared* P, int slot,
-                              bool on_aux) {
-    return msm_prepare<typename C::FrP>(ctx, d_scalars, n, scalars_mont, c, 0, -1, true, P, slot, on_aux ? ctx->aux_stream : ctx->stream);
+                              bool on_aux, int win_lo, int win_hi) {
+    return msm_prepare<typename C::FrP>(ctx, d_scalars, n, scalars_mont, c, win_lo, win_hi, true, P, slot,
+                                        on_aux ? ctx->aux_stream : ctx->stream);
 }
 
 template <class C, int G>

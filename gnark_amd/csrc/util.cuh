@@ -190,6 +190,10 @@ int msm_plan_table(size_t n, int* c_out, int* nwin_out) {
         int v = atoi(e);
         if (v >= 4 && v <= 23 && (double)(bits / v + 1) * (double)n < 2147483648.0) bc = v;
     }
+    if (best == 1e300) {   // no window width keeps windows x n inside the 31-bit table index: the caller must shard the vector
+        set_error("msm table plan: %zu points do not fit the 2^31 (window, point) index space; shard the vector", n);
+        return GA_ERR_INVALID;
+    }
     *c_out = bc;
     *nwin_out = bits / bc + 1;
     return GA_OK;

@@ -71,6 +71,18 @@ class PrecomputedBases:
         self.ctx.lib.check(self.ctx.lib.ga_msm_table_info(self.handle, C.byref(c), C.byref(nw), C.byref(nb)))
         return {"window_bits": c.value, "windows": nw.value, "table_bytes": nb.value}
 
+    def MultiExpWindows(self, scalars, win_lo: int, win_hi: int, montgomery: bool = True) -> np.ndarray:
+        """windows [win_lo, win_hi) only (ga_msm_table_run_windows): partial results of disjoint ranges add up to MultiExp's"""
+        if not isinstance(scalars, (DeviceBuffer, int)):
+            scalars = as_u64(scalars, 4)
+            if scalars.shape[0] != self.n:
+                raise ValueError("len(points) != len(scalars)")
+        sp, f2 = _arg(scalars, _lib.SCALARS_ON_DEVICE)
+        out = np.zeros(jac_words(self.curve, self.group), dtype=np.uint64)
+        flags = f2 | (_lib.SCALARS_MONTGOMERY if montgomery else 0)
+        self.ctx.lib.check(self.ctx.lib.ga_msm_table_run_windows(self.handle, sp, flags, int(win_lo), int(win_hi), _ptr(out)))
+        return out
+
     def MultiExp(self, scalars, montgomery: bool = True) -> np.ndarray:
         if not isinstance(scalars, (DeviceBuffer, int)):
             scalars = as_u64(scalars, 4)

@@ -74,7 +74,8 @@ class ProvingKey:
     """setup.go:25-48 fields, uploaded once ("PinToGPU"); free with FreeGPUResources() (icicle.go:1493)."""
 
     def __init__(self, ctx: Context, curve, *, domain_cardinality, alpha1, beta1, delta1, A, B, Z, K, beta2, delta2, B2,
-                 infinityA, infinityB, precompute: int = 0, shard=(0, 1), commitment_keys=(), k_remove=(), staged_chunk: int = 0):
+                 infinityA, infinityB, precompute: int = 0, shard=(0, 1), commitment_keys=(), k_remove=(), staged_chunk: int = 0,
+                 window_shard=(0, 1)):
         """commitment_keys: [(Basis, BasisExpSigma)] per pk.CommitmentKeys[i] (setup.go:276-287); k_remove: sorted wire ids of the
         private committed wires and the commitment wires, left out of the K MSM (prove.go:231-235).
         staged_chunk > 0 builds the key through ga_g16_builder_* in chunks of that many points (the cgo-safe call pattern of
@@ -117,6 +118,8 @@ class ProvingKey:
                 rem = np.ascontiguousarray(k_remove, dtype=np.uint64)
                 if rem.size:
                     lib.check(lib.ga_g16_builder_set_k_remove(b, _ptr(rem), rem.size))
+                if int(window_shard[1]) > 1:
+                    lib.check(lib.ga_g16_builder_set_window_shard(b, int(window_shard[0]), int(window_shard[1])))
             except Exception:
                 lib.ga_g16_builder_destroy(b)
                 raise
@@ -138,6 +141,7 @@ class ProvingKey:
         key.nb_infinity_a, key.nb_infinity_b = int(ia.sum()), int(ib.sum())
         key.precompute = int(precompute)   # 0 auto, 1 always, -1 never (window-multiple tables, ga_g16_key.precompute)
         key.shard_index, key.shard_count = int(shard[0]), int(shard[1])   # multi-GPU: pin slice k of N of every base vector
+        key.window_shard_index, key.window_shard_count = int(window_shard[0]), int(window_shard[1])
         self.shard = (int(shard[0]), int(shard[1]))
         cks = [(g1(b), g1(e)) for b, e in commitment_keys]
         if cks:
@@ -212,9 +216,9 @@ def ProvePartial(pk: ProvingKey, solution: Solution, nb_public: int) -> np.ndarr
 
 def ShardLayout(pk: ProvingKey) -> dict:
     """where this key's shard sits: slice [off_z, off_z+len_z) of h / pk.G1.Z, wire range [w_lo, w_hi) of W (ga_g16_shard_layout)"""
-    out = (C.c_uint64 * 6)()
+    out = (C.c_uint64 * 8)()
     pk.ctx.lib.check(pk.ctx.lib.ga_g16_shard_layout(pk.handle, out))
-    return dict(zip(("off_z", "len_z", "w_lo", "w_hi", "n", "nb_wires"), (int(v) for v in out)))
+    return dict(zip(("off_z", "len_z", "w_lo", "w_hi", "n", "nb_wires", "win_index", "win_count"), (int(v) for v in out)))
 
 
 def WitnessPartial(pk: ProvingKey, W, nb_public: int) -> np.ndarray:

@@ -26,11 +26,48 @@ def shard_range(n: int, rank: int, world: int):
 def _all_gather_u64(arr: np.ndarray, dist, device=None):
     import torch
     t = torch.from_numpy(np.ascontiguousarray(arr).view(np.int64).copy())
-    if device is not None:
+    if device is not None and dist.get_backend() != "gloo":
         t = t.to(device)
     out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(out, t)
     return [o.cpu().numpy().view(np.uint64).reshape(arr.shape) for o in out]
+
+
+def _via_cpu(t, dist) -> bool:
+    """gloo moves CPU tensors only: on a GPU box without RCCL peers (two ranks sharing one GPU in a smoke run) device tensors
+    are staged through the host; with the nccl (= RCCL) backend they travel over xGMI directly"""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def _send(t, dst, dist):
+    dist.send(t.cpu() if _via_cpu(t, dist) else t, dst=dst)
+
+
+def _recv(t, src, dist):
+    if _via_cpu(t, dist):
+        tmp = t.cpu()
+        dist.recv(tmp, src=src)
+        t.copy_(tmp)
+    else:
+        dist.recv(t, src=src)
+
+
+def _broadcast(t, src, dist):
+    if _via_cpu(t, dist):
+        tmp = t.cpu()
+        dist.broadcast(tmp, src=src)
+        t.copy_(tmp)
+    else:
+        dist.broadcast(t, src=src)
+
+
+def _scatter(out, pieces, src, dist):
+    if _via_cpu(out, dist):
+        tmp = out.cpu()
+        dist.scatter(tmp, [p.cpu() for p in pieces] if pieces is not None else None, src=src)
+        out.copy_(tmp)
+    else:
+        dist.scatter(out, pieces, src=src)
 
 
 def combine_partials(curve, group: int, partials, lib=None) -> np.ndarray:
@@ -53,7 +90,17 @@ def msm_base_sharded(ctx, curve, group: int, points_shard, scalars_shard, n_shar
 
 
 def msm_window_sharded(ctx, curve, group: int, points, scalars, n: int, dist, device=None) -> np.ndarray:
-    """partition A: every rank passes ALL points/scalars and accumulates only its share of the Pippenger windows."""
+    """partition A: every rank passes ALL points/scalars and accumulates only its share of the Pippenger windows.
+    With pinned bases (ecc.PrecomputedBases holding the whole vector) the windows run on the table path
+    (ga_msm_table_run_windows) and the partial results simply add -- no Horner step."""
+    if isinstance(points, ecc.PrecomputedBases):
+        world = 1 if dist is None else dist.get_world_size()
+        rank = 0 if dist is None else dist.get_rank()
+        lo, hi = shard_range(points.info()["windows"], rank, world)
+        part = points.MultiExpWindows(scalars, lo, hi)
+        if world == 1:
+            return part
+        return combine_partials(curve, group, _all_gather_u64(part, dist, device), lib=ctx.lib)
     cid = curve_id(curve)
     cbits, nwin = ecc.plan(curve, group, n, lib=ctx.lib)
     world = 1 if dist is None else dist.get_world_size()
@@ -109,9 +156,19 @@ def groth16_prove_sharded(pk, solution, nb_public: int, r, s, dist, device=None,
     for k in range(3):                       # b and c travel to rank 0
         if owner[k] != 0:
             if rank == owner[k]:
-                dist.send(bufs[k], dst=0)
+                _send(bufs[k], 0, dist)
             elif rank == 0:
-                dist.recv(bufs[k], src=owner[k])
+                _recv(bufs[k], owner[k], dist)
+    if lay["win_count"] > 1:                 # window-sharded key: every rank needs all of h -> broadcast from rank 0
+        if rank != 0 and 0 not in bufs:
+            bufs[0] = torch.empty((n, 4), dtype=torch.int64, device=dev)
+        if rank == 0:
+            sync()
+            groth16.HCombine(pk, bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr())
+        _broadcast(bufs[0], 0, dist)
+        sync()
+        z = groth16.ZPartial(pk, bufs[0].data_ptr())
+        return _finish_gathered(pk, part, z, r, s, dist, device)
     # rank 0: h, then one equally sized (padded) slice per rank
     share = (n - 1 + world - 1) // world + 1
     mine = torch.empty((share, 4), dtype=torch.int64, device=dev)
@@ -125,9 +182,15 @@ def groth16_prove_sharded(pk, solution, nb_public: int, r, s, dist, device=None,
             t = torch.zeros((share, 4), dtype=torch.int64, device=dev)
             t[: hi - lo] = bufs[0][lo:hi]
             pieces.append(t)
-    dist.scatter(mine, pieces, src=0)
+    _scatter(mine, pieces, 0, dist)
     sync()
     z = groth16.ZPartial(pk, mine.data_ptr())
+    return _finish_gathered(pk, part, z, r, s, dist, device)
+
+
+def _finish_gathered(pk, part, z, r, s, dist, device):
+    """all_gather of every rank's A | B1 | K | B2 sums and Z sum, host additions, epilogue with (r, s) -- identical on every rank"""
+    from . import groth16
     fp = part.shape[0] // 15
     both = np.concatenate([part, z])
     gathered = _all_gather_u64(both, dist, device)

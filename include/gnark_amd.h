@@ -109,6 +109,10 @@ void ga_msm_table_destroy(ga_msm_table* t);
 /* scalars: exactly n fr elements (the table's n); flags: GA_SCALARS_ON_DEVICE, GA_SCALARS_MONTGOMERY */
 int ga_msm_table_run(ga_msm_table* t, const void* scalars, unsigned flags, void* out_jac);
 int ga_msm_table_info(ga_msm_table* t, int* window_bits, int* num_windows, uint64_t* table_bytes);
+/* windows [win_lo, win_hi) of the table only (multi-GPU partition A on pinned bases): the 2^(c*w) factors are part of the table,
+ * so the Jacobian results of disjoint window ranges ADD UP to ga_msm_table_run's result (ga_jac_add); no Horner step.  An empty
+ * range gives the point at infinity. */
+int ga_msm_table_run_windows(ga_msm_table* t, const void* scalars, unsigned flags, int win_lo, int win_hi, void* out_jac);
 
 /* ---- small host-side group helpers used by the Go epilogue / multi-GPU combine -------------------------
  * (curve.G1Jac.AddAssign / ScalarMultiplication / FromJacobian, prove.go:199-292).  Host arithmetic. */
@@ -221,6 +225,12 @@ typedef struct ga_g16_key {
     const uint64_t* ck_len;              /* [nb_commitments] number of points in each basis */
     const uint64_t* k_remove;            /* sorted wire ids left out of the K MSM: every PrivateCommitted wire and every */
     uint64_t len_k_remove;               /* commitment wire (the toRemove list of prove.go:233-235); len_k = nbWires - nbPublic - len_k_remove */
+    /* multi-GPU partition A (BASELINE config 4 "window-sharded"): the WHOLE key is pinned on every device and this one
+     * accumulates share window_shard_index of window_shard_count of the Pippenger windows of every MSM -- on the pinned window
+     * tables, where the 2^(c*w) factors are part of the table, so the partial results of the devices simply add.  0 / 0 or 0 / 1 =
+     * all windows.  Not combinable with shard_count > 1. */
+    uint32_t window_shard_index;
+    uint32_t window_shard_count;
 } ga_g16_key;
 
 int ga_g16_pk_create(ga_ctx* ctx, const ga_g16_key* key, ga_g16_pk** out);
@@ -255,6 +265,7 @@ int ga_g16_builder_set_point(ga_g16_builder* b, int which_point, const void* aff
 int ga_g16_builder_set_infinity(ga_g16_builder* b, int which /* 0: InfinityA, 1: InfinityB */, const uint8_t* mask, uint64_t nb_wires);
 int ga_g16_builder_add_commitment_key(ga_g16_builder* b, const void* basis, const void* basis_exp_sigma, uint64_t len);
 int ga_g16_builder_set_k_remove(ga_g16_builder* b, const uint64_t* wire_ids, uint64_t len);
+int ga_g16_builder_set_window_shard(ga_g16_builder* b, uint32_t index, uint32_t count);   /* partition A, see ga_g16_key */
 int ga_g16_builder_finish(ga_g16_builder* b, int32_t precompute, ga_g16_pk** out);
 void ga_g16_builder_destroy(ga_g16_builder* b);
 
@@ -282,8 +293,9 @@ int ga_g16_finish(ga_g16_pk* pk, const void* partials_sum, const void* r, const 
  * range the shard's bases cover), one chain of computeH per call (v = the solver's A, B or C on the host; out_dev = n fr elements
  * on this key's device, holding FFT_coset(iFFT(v)) afterwards), the combination h = iFFT_coset((a*b - c)/(g^n - 1)) in a_dev
  * (bit-reversed), and the MSM of this shard's slice of pk.G1.Z with the matching slice of h (h_slice_dev points at element off_z).
- * ga_g16_shard_layout: out6 = {off_z, len_z, w_lo, w_hi, domain cardinality, nb_wires}. */
-int ga_g16_shard_layout(ga_g16_pk* pk, uint64_t* out6);
+ * ga_g16_shard_layout: out8 = {off_z, len_z, w_lo, w_hi, domain cardinality, nb_wires, window_shard_index, window_shard_count}
+ * (a window-sharded key covers all of h and W: off_z = 0, len_z = n - 1). */
+int ga_g16_shard_layout(ga_g16_pk* pk, uint64_t* out8);
 int ga_g16_witness_partial(ga_g16_pk* pk, const void* w, uint64_t nb_public, void* partials_out);
 int ga_g16_h_chain(ga_g16_pk* pk, const void* v, uint64_t n_constraints, void* out_dev);
 int ga_g16_h_combine(ga_g16_pk* pk, void* a_dev, const void* b_dev, const void* c_dev);

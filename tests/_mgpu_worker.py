@@ -32,6 +32,11 @@ def main():
     got_a = multigpu.msm_window_sharded(ctx, c.name, group, P, S, n, dist)
     assert jac_to_affine_py(c, group, got_b) == want, "base-range sharding mismatch"
     assert jac_to_affine_py(c, group, got_a) == want, "window sharding mismatch"
+    from gnark_amd import ecc
+    table = ecc.PrecomputedBases(ctx, c.name, group, P)          # whole vector pinned on every rank: windows on the table path
+    got_t = multigpu.msm_window_sharded(ctx, c.name, group, table, S, n, dist)
+    table.free()
+    assert jac_to_affine_py(c, group, got_t) == want, "window sharding on pinned tables mismatch"
     # ---- Groth16 with the key sharded by base-point range: same proof bytes as the oracle -----------------
     from gnark_amd import groth16
     from helpers import pts_to_arr
@@ -61,6 +66,12 @@ def main():
         sproof = multigpu.groth16_prove_sharded(spk, inst.solution, inst.nb_public, inst.r, inst.s, dist)
     finally:
         spk.FreeGPUResources()
+    wpk = inst.proving_key(ctx, window_shard=(rank, world), precompute=1)      # partition A: whole key per rank, windows shared out
+    try:
+        wproof = multigpu.groth16_prove_sharded(wpk, inst.solution, inst.nb_public, inst.r, inst.s, dist)
+    finally:
+        wpk.FreeGPUResources()
+    assert np.array_equal(wproof.raw(), sproof.raw()), "window-sharded Groth16 differs from base-range sharded"
     want = oracle.groth16_prove(c.cid, dict(inst.key, n=inst.n), inst.solution.W, inst.solution.A, inst.solution.B, inst.solution.C,
                                 inst.nb_public, inst.r, inst.s, nthreads=2)
     assert np.array_equal(sproof.Ar, want[0]) and np.array_equal(sproof.Bs, want[1]) and np.array_equal(sproof.Krs, want[2]), "sharded 2^8"

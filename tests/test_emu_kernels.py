@@ -729,7 +729,8 @@ def test_emu_groth16_builder_errors(emu_ctx):
 # ---- one proof over several devices from one process (ga_g16_prove_multi) ------------------------------------------------------
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
 @pytest.mark.parametrize("nshards", [2, 3, 5])
-def test_emu_groth16_prove_multi(emu_ctx, c, nshards, logn=7, precompute=1):
+@pytest.mark.parametrize("precompute", [1, -1], ids=["tables", "no-tables"])
+def test_emu_groth16_prove_multi(emu_ctx, c, nshards, precompute, logn=7):
     """shard i of N in its own context (one context per device; here all on device 0): the native multi-device prover -- one
     host thread per shard, computeH's chains on the first three, peer copies of b, c and of the h slices -- returns the proof of
     the unsharded key, which equals the known-dlog closed form; also the pieces API (witness / chain / combine / z) by hand"""
@@ -776,6 +777,18 @@ def test_emu_groth16_prove_multi(emu_ctx, c, nshards, logn=7, precompute=1):
         # argument validation: shards out of order, shared context
         with pytest.raises(Exception, match="must be shard"):
             groth16.ProveMulti(pks[::-1], sol, inst.nb_public, inst.r, inst.s)
+        with pytest.raises(Exception, match="one share of a sharded key"):
+            groth16.Prove(pks[0], sol, inst.nb_public, inst.r, inst.s)
+        # partition A (BASELINE config 4 "window-sharded"): whole key on every device, share i of the windows of every MSM
+        for p in pks:
+            p.FreeGPUResources()
+        pks = [inst.proving_key(cx, precompute=precompute, window_shard=(i, nshards), staged_chunk=(64 if i % 2 else 0)) for i, cx in enumerate(ctxs)]
+        lays = [groth16.ShardLayout(p) for p in pks]
+        assert all(l["len_z"] == inst.n - 1 and l["off_z"] == 0 and l["win_count"] == nshards for l in lays)
+        gotw = groth16.ProveMulti(pks, sol, inst.nb_public, inst.r, inst.s)
+        assert np.array_equal(gotw.raw(), want.raw())
+        with pytest.raises(Exception, match="cannot be combined"):
+            inst.proving_key(ctxs[0], shard=(0, 2), window_shard=(0, 2))
     finally:
         for p in pks:
             p.FreeGPUResources()
@@ -790,3 +803,30 @@ def test_emu_groth16_prove_multi(emu_ctx, c, nshards, logn=7, precompute=1):
     exp = synth.expected_exponents(inst, hh, lambda a, b: oracle.fr_dot(c.cid, a, b))
     pt = lambda group, k: oracle.jac_to_affine(c.cid, group, oracle.generator_mul(c.cid, group, k))
     assert np.array_equal(got.Ar, pt(0, exp["Ar"])) and np.array_equal(got.Bs, pt(1, exp["Bs"])) and np.array_equal(got.Krs, pt(0, exp["Krs"]))
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("group", [0, 1], ids=["G1", "G2"])
+def test_emu_msm_table_window_ranges(emu_ctx, c, group):
+    """window ranges on the pinned-table path (multi-GPU partition A on the fast path): the partial results of disjoint ranges
+    ADD UP to the full MSM -- no Horner step, because the 2^(c*w) factors are part of the table; an empty range is infinity"""
+    n = 300
+    bases, dlogs, scal = _device_inputs(emu_ctx, c, group, n, 0x71AB + group)
+    t = ecc.PrecomputedBases(emu_ctx, c.name, group, bases, n=n)
+    try:
+        nwin = t.info()["windows"]
+        full = oracle.jac_to_affine(c.cid, group, t.MultiExp(scal))
+        assert np.array_equal(full, _expect_from_dlogs(c, group, scal.to_host((n, 4)), dlogs.to_host((n, 4))))
+        for cuts in ((0, nwin // 3, nwin), (0, 1, 2, nwin - 1, nwin), (0, 0, nwin)):
+            acc = None
+            for lo, hi in zip(cuts[:-1], cuts[1:]):
+                part = t.MultiExpWindows(scal, lo, hi)
+                acc = part if acc is None else ecc.jac_add(c.name, group, acc, part, lib=emu_ctx.lib)
+            assert np.array_equal(oracle.jac_to_affine(c.cid, group, acc), full), cuts
+        assert not t.MultiExpWindows(scal, 2, 2)[-c.fp_limbs:].any()          # empty range: Z = 0
+        with pytest.raises(Exception, match="window range"):
+            t.MultiExpWindows(scal, 0, nwin + 1)
+    finally:
+        t.free()
+        for b in (bases, dlogs, scal):
+            b.free()

@@ -539,6 +539,20 @@ def test_groth16_builder_errors(gpu_ctx):
     cases.test_emu_groth16_builder_errors(gpu_ctx)
 
 
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("nshards,precompute", [(2, 1), (3, 1), (3, -1)], ids=["2-tables", "3-tables", "3-no-tables"])
+def test_groth16_prove_multi_contexts_on_one_device(gpu_ctx, c, nshards, precompute):
+    """ga_g16_prove_multi at 2^12 constraints with one context per shard (all on this box's single GPU: the peer copies become
+    device-to-device copies): base-range shards, window shards and the pieces API give the unsharded proof"""
+    cases.test_emu_groth16_prove_multi(gpu_ctx, c, nshards, precompute, logn=12)
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("group", [0, 1], ids=["G1", "G2"])
+def test_msm_table_window_ranges(gpu_ctx, c, group):
+    cases.test_emu_msm_table_window_ranges(gpu_ctx, c, group)
+
+
 def test_compute_h_2_20_polynomial_identity(gpu_ctx):
     """size-independent property of computeH at 2^20: A(x)B(x) - C(x) == H(x)(x^n - 1) at a random point, with A, B, C
     interpolated by the CPU oracle and H (bit-reversed coefficients, deg <= n-2) from the device."""
