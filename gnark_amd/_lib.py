@@ -118,6 +118,11 @@ _PROTOS = {
     "ga_g16_h_combine": (C.c_int, [_P, _P, _P, _P]),
     "ga_g16_z_partial": (C.c_int, [_P, _P, _P]),
     "ga_g16_prove_multi": (C.c_int, [C.POINTER(_P), C.c_uint32, _P, _P, _P, _P, C.c_uint64, C.c_uint64, _P, _P, _P]),
+    "ga_g16_pk_read_mem": (C.c_int, [_P, C.c_int, _P, C.c_size_t, C.c_int32, C.c_uint32, C.c_uint32, _P, C.c_uint64, C.POINTER(_P), C.POINTER(C.c_uint64)]),
+    "ga_g16_pk_read_fd": (C.c_int, [_P, C.c_int, C.c_int, C.c_int32, C.c_uint32, C.c_uint32, _P, C.c_uint64, C.POINTER(_P), C.POINTER(C.c_uint64)]),
+    "ga_g16_key_write_fd": (C.c_int, [_P, C.POINTER(G16Key), C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
+    "ga_g16_proof_unmarshal": (C.c_int, [C.c_int, _P, C.c_size_t, _P, _P, C.c_uint32, C.POINTER(C.c_uint32), _P, C.POINTER(C.c_size_t)]),
+    "ga_point_unmarshal": (C.c_int, [C.c_int, C.c_int, _P, C.c_size_t, _P, C.POINTER(C.c_size_t)]),
     "ga_g16_proof_marshal": (C.c_int, [C.c_int, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "ga_g16_commit": (C.c_int, [_P, C.c_uint32, _P, C.c_uint64, _P, _P]),
     "ga_g16_fold_pok": (C.c_int, [C.c_int, _P, C.c_uint64, _P, _P]),

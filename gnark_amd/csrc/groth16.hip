@@ -10,6 +10,7 @@
 #include <thread>
 
 #include "hostops.cuh"
+#include "keyio.cuh"
 
 namespace ga {
 
@@ -473,6 +474,410 @@ static int pk_create_from_struct(Ctx* ctx, const ga_g16_key* key, G16Pk** out) {
     return GA_OK;
 }
 
+
+// ---- key files -> staged key (keyio.cuh has the formats) --------------------------------------------------------------------------
+// `count` encoded points of group G from `src`: decoded on the device, the part inside [keep_lo, keep_lo + keep_cnt) lands at d_dst
+template <class C, int G>
+static int decode_stream(Ctx* ctx, Staging& sg, ByteSource& src, uint64_t count, bool compressed, void* d_dst, uint64_t keep_lo,
+                         uint64_t keep_cnt) {
+    typedef typename GroupField<C, G>::F F;
+    const size_t enc = compressed ? sizeof(F) : 2 * sizeof(F), psz = sizeof(Affine<F>);
+    const uint64_t per_chunk = Staging::BYTES / enc;
+    GA_HIP_CHECK(hipMemsetAsync(sg.d_bad, 0, 4, ctx->stream));
+    int k = 0;
+    for (uint64_t done = 0; done < count; k ^= 1) {
+        const uint64_t cn = count - done < per_chunk ? count - done : per_chunk;
+        GA_HIP_CHECK(hipEventSynchronize(sg.ev[k]));   // the previous copy out of this staging buffer has finished
+        GA_CHECK(src.read(sg.h[k], cn * enc));
+        GA_HIP_CHECK(hipMemcpyAsync(sg.d_bytes, sg.h[k], cn * enc, hipMemcpyHostToDevice, ctx->stream));
+        GA_HIP_CHECK(hipEventRecord(sg.ev[k], ctx->stream));
+        hipLaunchKernelGGL((key_decode_kernel<C, G>), dim3((unsigned)((cn + 63) / 64)), dim3(64), 0, ctx->stream, (const uint8_t*)sg.d_bytes, cn,
+                           compressed ? 1 : 0, sg.d_points, sg.d_bad);
+        GA_KERNEL_CHECK();
+        const uint64_t b0 = done > keep_lo ? done : keep_lo;
+        const uint64_t e0 = done + cn < keep_lo + keep_cnt ? done + cn : keep_lo + keep_cnt;
+        if (e0 > b0)
+            GA_HIP_CHECK(hipMemcpyAsync((char*)d_dst + (b0 - keep_lo) * psz, (const char*)sg.d_points + (b0 - done) * psz, (e0 - b0) * psz,
+                                        hipMemcpyDeviceToDevice, ctx->stream));
+        done += cn;
+    }
+    uint32_t bad = 0;
+    GA_HIP_CHECK(hipMemcpyAsync(&bad, sg.d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+    GA_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (bad) {
+        set_error("key file: %u of %llu points do not decode (bad flag bits, coordinate >= p, or not on the curve)", bad,
+                  (unsigned long long)count);
+        return GA_ERR_INVALID;
+    }
+    return GA_OK;
+}
+
+// a []G1Affine / []G2Affine of the Encoder: u32 BE length, then the points (all compressed or all uncompressed)
+template <class C, int G>
+static int read_encoded_vector(G16Stage* st, Staging& sg, ByteSource& src, int which, void** d_plain, uint64_t* len_out) {
+    typedef typename GroupField<C, G>::F F;
+    uint32_t len = 0;
+    GA_CHECK(src.u32be(&len));
+    bool compressed = true;
+    if (len) {
+        uint8_t b0;
+        GA_CHECK(src.peek(&b0, 1));
+        PointFlags f;
+        if (!point_flags<C>(b0, &f)) {
+            set_error("key file: malformed flag bits 0x%02x at the head of a point vector", b0);
+            return GA_ERR_INVALID;
+        }
+        compressed = f.compressed || (f.infinity && C::ID == GA_BLS12_381 && (b0 & 0x80));
+    }
+    if (len_out) *len_out = len;
+    if (which >= 0) {
+        GA_CHECK(stage_reserve(st, which, len));
+        G16Stage::Vec& x = st->v[which];
+        GA_CHECK((decode_stream<C, G>(st->ctx, sg, src, len, compressed, x.d, x.lo, x.cnt)));
+        x.seen = len;
+        return GA_OK;
+    }
+    *d_plain = nullptr;   // a commitment basis: kept whole
+    hipError_t e = hipMalloc(d_plain, len ? (size_t)len * sizeof(Affine<F>) : 16);
+    if (e != hipSuccess) {
+        set_error("key file: hipMalloc of a commitment basis failed: %s", hipGetErrorString(e));
+        return GA_ERR_NOMEM;
+    }
+    return decode_stream<C, G>(st->ctx, sg, src, len, compressed, *d_plain, 0, len);
+}
+
+// a slice of unsafe.WriteSlice: u64 LE length + gnark's own memory image; no arithmetic, file -> pinned buffer -> HBM
+template <class C, int G>
+static int read_dumped_vector(G16Stage* st, Staging& sg, ByteSource& src, int which, void** d_plain, uint64_t* len_out) {
+    typedef typename GroupField<C, G>::F F;
+    const size_t psz = sizeof(Affine<F>);
+    uint64_t len = 0;
+    GA_CHECK(src.u64le(&len));
+    if (len >= (1ull << 40)) {
+        set_error("key dump: implausible slice length %llu", (unsigned long long)len);
+        return GA_ERR_INVALID;
+    }
+    if (len_out) *len_out = len;
+    char* plain = nullptr;
+    if (which >= 0) GA_CHECK(stage_reserve(st, which, len));
+    else {
+        hipError_t e = hipMalloc((void**)&plain, len ? len * psz : 16);
+        if (e != hipSuccess) {
+            set_error("key dump: hipMalloc of a commitment basis failed: %s", hipGetErrorString(e));
+            return GA_ERR_NOMEM;
+        }
+        *d_plain = plain;
+    }
+    const uint64_t per_chunk = Staging::BYTES / psz;
+    int k = 0;
+    for (uint64_t done = 0; done < len; k ^= 1) {
+        const uint64_t cn = len - done < per_chunk ? len - done : per_chunk;
+        GA_HIP_CHECK(hipEventSynchronize(sg.ev[k]));
+        GA_CHECK(src.read(sg.h[k], cn * psz));
+        if (which >= 0) GA_CHECK(stage_append(st, which, sg.h[k], cn, /*pinned=*/true));
+        else GA_HIP_CHECK(hipMemcpyAsync(plain + done * psz, sg.h[k], cn * psz, hipMemcpyHostToDevice, st->ctx->stream));
+        GA_HIP_CHECK(hipEventRecord(sg.ev[k], st->ctx->stream));
+        done += cn;
+    }
+    GA_HIP_CHECK(hipStreamSynchronize(st->ctx->stream));
+    return GA_OK;
+}
+
+// one point of the header (alpha, beta, delta): host arithmetic; advances the source by its encoded length
+// *mode: -1 = not known yet, 0 = the stream holds uncompressed points, 1 = compressed; set by the first finite point.  BN254 has
+// one flag value (0b01) for infinity in both modes, so an infinity point takes the size of the stream's mode (compressed when the
+// mode is still unknown -- the size gnark-crypto's SetBytes consumes for it).
+template <class C, int G>
+static int read_header_point(ByteSource& src, std::vector<uint8_t>* out_image, int* mode = nullptr) {
+    typedef typename GroupField<C, G>::F F;
+    uint8_t buf[2 * sizeof(F)];
+    GA_CHECK(src.peek(buf, 1));
+    PointFlags f;
+    if (!point_flags<C>(buf[0], &f)) {
+        set_error("key file: malformed flag bits 0x%02x", buf[0]);
+        return GA_ERR_INVALID;
+    }
+    bool compressed = f.compressed;
+    if (f.infinity && C::ID == GA_BN254) compressed = !(mode && *mode == 0);
+    if (!f.infinity && mode && *mode < 0) *mode = f.compressed ? 1 : 0;
+    const size_t len = compressed ? sizeof(F) : 2 * sizeof(F);
+    GA_CHECK(src.read(buf, len));
+    Affine<F> p;
+    if (!point_decode<C, G>(buf, f.compressed, &p)) {
+        set_error("key file: header point does not decode");
+        return GA_ERR_INVALID;
+    }
+    out_image->assign(reinterpret_cast<const uint8_t*>(&p), reinterpret_cast<const uint8_t*>(&p) + sizeof(p));
+    return GA_OK;
+}
+
+// fft.Domain.WriteTo: cardinality + five fr elements (+ the withPrecompute byte of newer gnark-crypto versions, detected by
+// trying to decode [alpha]1 right after it)
+template <class C>
+static int read_domain(ByteSource& src, uint64_t* cardinality) {
+    typedef Fe<typename C::FpP> F1;
+    GA_CHECK(src.u64be(cardinality));
+    uint8_t skip[5 * 32];
+    GA_CHECK(src.read(skip, sizeof skip));
+    if (*cardinality == 0 || (*cardinality & (*cardinality - 1)) || *cardinality > (1ull << C::FrP::ADICITY)) {
+        set_error("key file: domain cardinality %llu is not a power of two within the field's 2-adicity", (unsigned long long)*cardinality);
+        return GA_ERR_INVALID;
+    }
+    uint8_t win[1 + 2 * sizeof(F1)];
+    GA_CHECK(src.peek(win, sizeof win));
+    auto decodes = [&](const uint8_t* b) {
+        PointFlags f;
+        Affine<F1> p;
+        return point_flags<C>(b[0], &f) && !f.infinity && point_decode<C, GA_G1>(b, f.compressed, &p);
+    };
+    if (win[0] <= 1 && decodes(win + 1)) {
+        uint8_t flag;
+        return src.read(&flag, 1);   // withPrecompute
+    }
+    if (decodes(win)) return GA_OK;
+    set_error("key file: [alpha]1 does not decode after the domain block (neither with nor without the withPrecompute byte)");
+    return GA_ERR_INVALID;
+}
+
+static bool source_is_dump(ByteSource& src) {
+    uint8_t m[8];
+    static const uint8_t marker[8] = {0xef, 0xbe, 0xad, 0xde, 0, 0, 0, 0};   // uint64(0xdeadbeef) as this (little-endian) platform stores it
+    return src.peek(m, 8) == GA_OK && memcmp(m, marker, 8) == 0;
+}
+
+template <class C>
+static int pk_read(Ctx* ctx, ByteSource& src, int32_t precompute, uint32_t shard_index, uint32_t shard_count, const uint64_t* k_remove,
+                   uint64_t len_k_remove, G16Pk** out) {
+    G16Stage st;
+    st.ctx = ctx;
+    st.curve = C::ID;
+    st.shard_index = shard_index;
+    st.shard_count = shard_count ? shard_count : 1;
+    if (st.shard_index >= st.shard_count) {
+        set_error("proving key: shard_index %u >= shard_count %u", st.shard_index, st.shard_count);
+        return GA_ERR_INVALID;
+    }
+    Staging sg;
+    GA_CHECK(sg.init());
+    const bool dump = source_is_dump(src);
+    if (dump) {
+        uint8_t m[8];
+        GA_CHECK(src.read(m, 8));
+    }
+    GA_CHECK(read_domain<C>(src, &st.n));
+    auto header_tail = [&]() -> int {   // nbWires, NbInfinityA, NbInfinityB, InfinityA, InfinityB, nbCommitments (marshal.go:263-270,335-349)
+        uint64_t nb_wires, nia, nib;
+        GA_CHECK(src.u64be(&nb_wires));
+        GA_CHECK(src.u64be(&nia));
+        GA_CHECK(src.u64be(&nib));
+        if (nb_wires >= (1ull << 32)) {
+            set_error("key file: %llu wires", (unsigned long long)nb_wires);
+            return GA_ERR_INVALID;
+        }
+        st.nb_wires = nb_wires;
+        for (int k = 0; k < 2; k++) {
+            st.inf[k].resize(nb_wires);
+            GA_CHECK(src.read(st.inf[k].data(), nb_wires));
+            st.have_inf[k] = true;
+        }
+        return GA_OK;
+    };
+    uint32_t nb_commitments = 0;
+    if (!dump) {   // ReadFrom order, marshal.go:316-330
+        GA_CHECK((read_header_point<C, GA_G1>(src, &st.pts[GA_KEY_G1_ALPHA])));
+        GA_CHECK((read_header_point<C, GA_G1>(src, &st.pts[GA_KEY_G1_BETA])));
+        GA_CHECK((read_header_point<C, GA_G1>(src, &st.pts[GA_KEY_G1_DELTA])));
+        for (int w : {GA_KEY_G1_A, GA_KEY_G1_B, GA_KEY_G1_Z, GA_KEY_G1_K}) GA_CHECK((read_encoded_vector<C, GA_G1>(&st, sg, src, w, nullptr, nullptr)));
+        GA_CHECK((read_header_point<C, GA_G2>(src, &st.pts[GA_KEY_G2_BETA])));
+        GA_CHECK((read_header_point<C, GA_G2>(src, &st.pts[GA_KEY_G2_DELTA])));
+        GA_CHECK((read_encoded_vector<C, GA_G2>(&st, sg, src, GA_KEY_G2_B, nullptr, nullptr)));
+        GA_CHECK(header_tail());
+        GA_CHECK(src.u32be(&nb_commitments));
+    } else {       // ReadDump order, marshal.go:459-478
+        GA_CHECK((read_header_point<C, GA_G1>(src, &st.pts[GA_KEY_G1_ALPHA])));
+        GA_CHECK((read_header_point<C, GA_G1>(src, &st.pts[GA_KEY_G1_BETA])));
+        GA_CHECK((read_header_point<C, GA_G1>(src, &st.pts[GA_KEY_G1_DELTA])));
+        GA_CHECK((read_header_point<C, GA_G2>(src, &st.pts[GA_KEY_G2_BETA])));
+        GA_CHECK((read_header_point<C, GA_G2>(src, &st.pts[GA_KEY_G2_DELTA])));
+        GA_CHECK(header_tail());
+        GA_CHECK(src.u32be(&nb_commitments));
+        for (int w : {GA_KEY_G1_A, GA_KEY_G1_B, GA_KEY_G1_Z, GA_KEY_G1_K}) GA_CHECK((read_dumped_vector<C, GA_G1>(&st, sg, src, w, nullptr, nullptr)));
+        GA_CHECK((read_dumped_vector<C, GA_G2>(&st, sg, src, GA_KEY_G2_B, nullptr, nullptr)));
+    }
+    if (nb_commitments > 4096) {
+        set_error("key file: implausible number of commitment keys %u", nb_commitments);
+        return GA_ERR_INVALID;
+    }
+    for (uint32_t i = 0; i < nb_commitments; i++) {   // pedersen.ProvingKey: Basis, BasisExpSigma
+        void *db = nullptr, *ds = nullptr;
+        uint64_t lb = 0, ls = 0;
+        int rc = dump ? read_dumped_vector<C, GA_G1>(&st, sg, src, -1, &db, &lb) : read_encoded_vector<C, GA_G1>(&st, sg, src, -1, &db, &lb);
+        if (rc == GA_OK) rc = dump ? read_dumped_vector<C, GA_G1>(&st, sg, src, -1, &ds, &ls) : read_encoded_vector<C, GA_G1>(&st, sg, src, -1, &ds, &ls);
+        if (rc == GA_OK && lb != ls) {
+            set_error("key file: commitment key %u has %llu basis points and %llu sigma points", i, (unsigned long long)lb, (unsigned long long)ls);
+            rc = GA_ERR_INVALID;
+        }
+        if (rc != GA_OK) {
+            hipFree(db);
+            hipFree(ds);
+            return rc;
+        }
+        st.d_ck_basis.push_back(db);
+        st.d_ck_sigma.push_back(ds);
+        st.ck_len.push_back(lb);
+    }
+    if (len_k_remove) st.k_remove.assign(k_remove, k_remove + len_k_remove);
+    return stage_finish<C>(&st, precompute, out);
+}
+
+// ---- key writers: the host description (ga_g16_key) -> WriteTo / WriteRawTo / WriteDump bytes ------------------------------------------
+template <class C, int G>
+static int write_encoded_vector(Ctx* ctx, Staging& sg, ByteSink& dst, const void* pts, uint64_t len, bool compressed) {
+    typedef typename GroupField<C, G>::F F;
+    if (len >= (1ull << 32)) {
+        set_error("key writer: a vector of %llu points does not fit the u32 length prefix", (unsigned long long)len);
+        return GA_ERR_INVALID;
+    }
+    GA_CHECK(dst.u32be((uint32_t)len));
+    const size_t enc = compressed ? sizeof(F) : 2 * sizeof(F), psz = sizeof(Affine<F>);
+    const uint64_t per_chunk = Staging::BYTES / psz;
+    for (uint64_t done = 0; done < len;) {
+        const uint64_t cn = len - done < per_chunk ? len - done : per_chunk;
+        GA_HIP_CHECK(hipMemcpyAsync(sg.d_points, (const char*)pts + done * psz, cn * psz, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL((key_encode_kernel<C, G>), dim3((unsigned)((cn + 63) / 64)), dim3(64), 0, ctx->stream, (const void*)sg.d_points, cn,
+                           compressed ? 1 : 0, sg.d_bytes);
+        GA_KERNEL_CHECK();
+        GA_HIP_CHECK(hipMemcpyAsync(sg.h[0], sg.d_bytes, cn * enc, hipMemcpyDeviceToHost, ctx->stream));
+        GA_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        GA_CHECK(dst.write(sg.h[0], cn * enc));
+        done += cn;
+    }
+    return GA_OK;
+}
+template <class C, int G>
+static int write_header_point(ByteSink& dst, const void* affine, bool compressed) {
+    typedef typename GroupField<C, G>::F F;
+    Affine<F> p;
+    memcpy(&p, affine, sizeof p);
+    uint8_t buf[2 * sizeof(F)];
+    point_encode<C, G>(p, compressed, buf);
+    return dst.write(buf, compressed ? sizeof(F) : 2 * sizeof(F));
+}
+template <class C>
+static int write_domain(ByteSink& dst, uint64_t n) {
+    typedef typename C::FrP FrP;
+    typedef Fe<FrP> F;
+    const int logn = ilog2_u64(n);
+    if ((1ull << logn) != n || logn > FrP::ADICITY) {
+        set_error("key writer: domain cardinality %llu", (unsigned long long)n);
+        return GA_ERR_INVALID;
+    }
+    F w = fe_const<FrP>(FrP::ROOT), wi = fe_const<FrP>(FrP::ROOT_INV);
+    for (int k = 0; k < FrP::ADICITY - logn; k++) {
+        w = sqr(w);
+        wi = sqr(wi);
+    }
+    F card = fe_zero<FrP>();
+    card.l[0] = (uint32_t)n;
+    card.l[1] = (uint32_t)(n >> 32);
+    const F elems[5] = {inv(to_mont(card)), w, wi, fe_const<FrP>(FrP::GEN), fe_const<FrP>(FrP::GEN_INV)};
+    GA_CHECK(dst.u64be(n));
+    for (const F& e : elems) {
+        uint8_t b[32];
+        fe_to_be_bytes(e, b);
+        GA_CHECK(dst.write(b, 32));
+    }
+    const uint8_t with_precompute = 1;
+    return dst.write(&with_precompute, 1);
+}
+template <class C>
+static int key_write(Ctx* ctx, const ga_g16_key* key, int format, ByteSink& dst) {
+    typedef Fe<typename C::FpP> F1;
+    typedef Fe2<typename C::FpP> F2;
+    const bool dump = format == GA_KEY_FORMAT_DUMP, compressed = format == GA_KEY_FORMAT_COMPRESSED;
+    Staging sg;
+    GA_CHECK(sg.init());
+    if (dump) GA_CHECK(dst.u64le(0xdeadbeefull));
+    GA_CHECK(write_domain<C>(dst, key->domain_cardinality));
+    const bool hc = compressed;   // header points follow the encoder's mode (raw for the dump)
+    auto tail = [&]() -> int {
+        GA_CHECK(dst.u64be(key->nb_wires));
+        GA_CHECK(dst.u64be(key->nb_infinity_a));
+        GA_CHECK(dst.u64be(key->nb_infinity_b));
+        GA_CHECK(dst.write(key->infinity_a, key->nb_wires));
+        GA_CHECK(dst.write(key->infinity_b, key->nb_wires));
+        return dst.u32be(key->nb_commitments);
+    };
+    auto slice = [&](const void* p, uint64_t len, size_t psz) -> int {
+        GA_CHECK(dst.u64le(len));
+        return dst.write(p, len * psz);
+    };
+    GA_CHECK((write_header_point<C, GA_G1>(dst, key->g1_alpha, hc)));
+    GA_CHECK((write_header_point<C, GA_G1>(dst, key->g1_beta, hc)));
+    GA_CHECK((write_header_point<C, GA_G1>(dst, key->g1_delta, hc)));
+    if (!dump) {
+        GA_CHECK((write_encoded_vector<C, GA_G1>(ctx, sg, dst, key->g1_a, key->len_a, compressed)));
+        GA_CHECK((write_encoded_vector<C, GA_G1>(ctx, sg, dst, key->g1_b, key->len_b, compressed)));
+        GA_CHECK((write_encoded_vector<C, GA_G1>(ctx, sg, dst, key->g1_z, key->len_z, compressed)));
+        GA_CHECK((write_encoded_vector<C, GA_G1>(ctx, sg, dst, key->g1_k, key->len_k, compressed)));
+    }
+    GA_CHECK((write_header_point<C, GA_G2>(dst, key->g2_beta, hc)));
+    GA_CHECK((write_header_point<C, GA_G2>(dst, key->g2_delta, hc)));
+    if (!dump) GA_CHECK((write_encoded_vector<C, GA_G2>(ctx, sg, dst, key->g2_b, key->len_b2, compressed)));
+    GA_CHECK(tail());
+    if (dump) {
+        GA_CHECK(slice(key->g1_a, key->len_a, sizeof(Affine<F1>)));
+        GA_CHECK(slice(key->g1_b, key->len_b, sizeof(Affine<F1>)));
+        GA_CHECK(slice(key->g1_z, key->len_z, sizeof(Affine<F1>)));
+        GA_CHECK(slice(key->g1_k, key->len_k, sizeof(Affine<F1>)));
+        GA_CHECK(slice(key->g2_b, key->len_b2, sizeof(Affine<F2>)));
+    }
+    for (uint32_t i = 0; i < key->nb_commitments; i++) {
+        if (dump) {
+            GA_CHECK(slice(key->ck_basis[i], key->ck_len[i], sizeof(Affine<F1>)));
+            GA_CHECK(slice(key->ck_basis_exp_sigma[i], key->ck_len[i], sizeof(Affine<F1>)));
+        } else {
+            GA_CHECK((write_encoded_vector<C, GA_G1>(ctx, sg, dst, key->ck_basis[i], key->ck_len[i], compressed)));
+            GA_CHECK((write_encoded_vector<C, GA_G1>(ctx, sg, dst, key->ck_basis_exp_sigma[i], key->ck_len[i], compressed)));
+        }
+    }
+    return GA_OK;
+}
+
+// Proof.ReadFrom (marshal.go:62-86): Ar | Bs | Krs | u32 n | n commitments | CommitmentPok, compressed or uncompressed points
+template <class C>
+static int proof_unmarshal(const uint8_t* data, size_t len, void* proof_out, void* commitments_out, uint32_t max_commitments,
+                           uint32_t* n_commitments, void* pok_out, size_t* consumed) {
+    typedef Fe<typename C::FpP> F1;
+    typedef Fe2<typename C::FpP> F2;
+    ByteSource src;
+    src.mem = data;
+    src.mem_len = len;
+    std::vector<uint8_t> img;
+    int mode = -1;
+    char* o = reinterpret_cast<char*>(proof_out);
+    GA_CHECK((read_header_point<C, GA_G1>(src, &img, &mode)));
+    memcpy(o, img.data(), sizeof(Affine<F1>));
+    GA_CHECK((read_header_point<C, GA_G2>(src, &img, &mode)));
+    memcpy(o + sizeof(Affine<F1>), img.data(), sizeof(Affine<F2>));
+    GA_CHECK((read_header_point<C, GA_G1>(src, &img, &mode)));
+    memcpy(o + sizeof(Affine<F1>) + sizeof(Affine<F2>), img.data(), sizeof(Affine<F1>));
+    uint32_t n = 0;
+    GA_CHECK(src.u32be(&n));
+    if (n > max_commitments || (n && !commitments_out)) {
+        set_error("proof: %u commitments, room for %u", n, max_commitments);
+        return GA_ERR_INVALID;
+    }
+    for (uint32_t i = 0; i < n; i++) {
+        GA_CHECK((read_header_point<C, GA_G1>(src, &img, &mode)));
+        memcpy(reinterpret_cast<char*>(commitments_out) + (size_t)i * sizeof(Affine<F1>), img.data(), sizeof(Affine<F1>));
+    }
+    GA_CHECK((read_header_point<C, GA_G1>(src, &img, &mode)));
+    if (pok_out) memcpy(pok_out, img.data(), sizeof(Affine<F1>));
+    if (n_commitments) *n_commitments = n;
+    if (consumed) *consumed = src.mem_pos;
+    return GA_OK;
+}
 
 // ---- the device part of a proof, in pieces (a multi-GPU proof runs them on different devices) ----------------------------------
 // witness_msms : upload W (only the wire range this shard's bases cover), filter, MSM A, B (G1 + G2), K      prove.go:147-237,283
@@ -1368,6 +1773,99 @@ int ga_g16_prove_multi(ga_g16_pk* const* keys, uint32_t n, const void* w, const 
                 (void)hipGetLastError();
             }
     GA_DISPATCH_CURVE(pks[0]->curve, return (prove_multi<C>(pks, n, w, a, b, c, n_constraints, nb_public, r, s, proof_out)));
+    return GA_OK;
+}
+
+// ---- key files and proof bytes ------------------------------------------------------------------------------------------------
+static int pk_read_any(ga_ctx* h, int curve, ByteSource& src, int32_t precompute, uint32_t shard_index, uint32_t shard_count,
+                       const uint64_t* k_remove, uint64_t len_k_remove, ga_g16_pk** out, uint64_t* bytes_read) {
+    Ctx* ctx = reinterpret_cast<Ctx*>(h);
+    if (!ctx || !out || (len_k_remove && !k_remove)) {
+        set_error("ga_g16_pk_read: null argument");
+        return GA_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> g(ctx->mu);
+    hipSetDevice(ctx->device);
+    G16Pk* pk = nullptr;
+    GA_DISPATCH_CURVE(curve, GA_CHECK(pk_read<C>(ctx, src, precompute, shard_index, shard_count, k_remove, len_k_remove, &pk)));
+    *out = reinterpret_cast<ga_g16_pk*>(pk);
+    if (bytes_read) *bytes_read = src.consumed;
+    return GA_OK;
+}
+
+int ga_g16_pk_read_mem(ga_ctx* h, int curve, const uint8_t* data, size_t len, int32_t precompute, uint32_t shard_index, uint32_t shard_count,
+                       const uint64_t* k_remove, uint64_t len_k_remove, ga_g16_pk** out, uint64_t* bytes_read) {
+    if (!data) {
+        set_error("ga_g16_pk_read_mem: null data");
+        return GA_ERR_INVALID;
+    }
+    ByteSource src;
+    src.mem = data;
+    src.mem_len = len;
+    return pk_read_any(h, curve, src, precompute, shard_index, shard_count, k_remove, len_k_remove, out, bytes_read);
+}
+
+int ga_g16_pk_read_fd(ga_ctx* h, int curve, int fd, int32_t precompute, uint32_t shard_index, uint32_t shard_count, const uint64_t* k_remove,
+                      uint64_t len_k_remove, ga_g16_pk** out, uint64_t* bytes_read) {
+    if (fd < 0) {
+        set_error("ga_g16_pk_read_fd: bad file descriptor");
+        return GA_ERR_INVALID;
+    }
+    ByteSource src;
+    src.fd = fd;
+    return pk_read_any(h, curve, src, precompute, shard_index, shard_count, k_remove, len_k_remove, out, bytes_read);
+}
+
+int ga_g16_key_write_fd(ga_ctx* h, const ga_g16_key* key, int format, int fd, uint64_t* bytes_written) {
+    Ctx* ctx = reinterpret_cast<Ctx*>(h);
+    if (!ctx || !key || fd < 0 || format < GA_KEY_FORMAT_COMPRESSED || format > GA_KEY_FORMAT_DUMP) {
+        set_error("ga_g16_key_write_fd: bad argument");
+        return GA_ERR_INVALID;
+    }
+    if (!key->g1_alpha || !key->g1_beta || !key->g1_delta || !key->g2_beta || !key->g2_delta || !key->infinity_a || !key->infinity_b ||
+        (key->len_a && !key->g1_a) || (key->len_b && !key->g1_b) || (key->len_z && !key->g1_z) || (key->len_k && !key->g1_k) ||
+        (key->len_b2 && !key->g2_b) || (key->nb_commitments && (!key->ck_basis || !key->ck_basis_exp_sigma || !key->ck_len))) {
+        set_error("ga_g16_key_write_fd: null pointer inside ga_g16_key");
+        return GA_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> g(ctx->mu);
+    hipSetDevice(ctx->device);
+    ByteSink dst;
+    dst.fd = fd;
+    GA_DISPATCH_CURVE(key->curve, GA_CHECK(key_write<C>(ctx, key, format, dst)));
+    if (bytes_written) *bytes_written = dst.written;
+    return GA_OK;
+}
+
+int ga_g16_proof_unmarshal(int curve, const uint8_t* data, size_t len, void* proof_out, void* commitments_out, uint32_t max_commitments,
+                           uint32_t* n_commitments, void* pok_out, size_t* consumed) {
+    if (!data || !proof_out) {
+        set_error("ga_g16_proof_unmarshal: null argument");
+        return GA_ERR_INVALID;
+    }
+    GA_DISPATCH_CURVE(curve, return proof_unmarshal<C>(data, len, proof_out, commitments_out, max_commitments, n_commitments, pok_out, consumed));
+    return GA_OK;
+}
+
+int ga_point_unmarshal(int curve, int group, const uint8_t* data, size_t len, void* affine_out, size_t* consumed) {
+    if (!data || !affine_out) {
+        set_error("ga_point_unmarshal: null argument");
+        return GA_ERR_INVALID;
+    }
+    ByteSource src;
+    src.mem = data;
+    src.mem_len = len;
+    std::vector<uint8_t> img;
+    GA_DISPATCH_CURVE(curve, {
+        if (group == GA_G1) GA_CHECK((read_header_point<C, GA_G1>(src, &img)));
+        else if (group == GA_G2) GA_CHECK((read_header_point<C, GA_G2>(src, &img)));
+        else {
+            set_error("unknown group id %d", group);
+            return GA_ERR_INVALID;
+        }
+    });
+    memcpy(affine_out, img.data(), img.size());
+    if (consumed) *consumed = src.mem_pos;
     return GA_OK;
 }
 

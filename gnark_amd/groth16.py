@@ -70,8 +70,92 @@ class Proof:
         return out[: n.value].tobytes()
 
 
+KEY_FORMAT_COMPRESSED, KEY_FORMAT_RAW, KEY_FORMAT_DUMP = 0, 1, 2
+
+
+def _key_struct(curve, *, domain_cardinality, alpha1, beta1, delta1, A, B, Z, K, beta2, delta2, B2, infinityA, infinityB,
+                commitment_keys=(), **_ignored):
+    """ga_g16_key over host arrays (returned together with the arrays that must stay alive)"""
+    cid = curve_id(curve)
+    fp = FP_LIMBS[cid]
+    g1 = lambda v: as_u64(np.asarray(v).reshape(-1, 2 * fp), 2 * fp)
+    g2 = lambda v: as_u64(np.asarray(v).reshape(-1, 4 * fp), 4 * fp)
+    keep = dict(A=g1(A), B=g1(B), Z=g1(Z), K=g1(K), B2=g2(B2), alpha1=g1(alpha1), beta1=g1(beta1), delta1=g1(delta1), beta2=g2(beta2),
+                delta2=g2(delta2), ia=np.ascontiguousarray(infinityA, dtype=np.uint8), ib=np.ascontiguousarray(infinityB, dtype=np.uint8))
+    key = _lib.G16Key()
+    key.curve, key.domain_cardinality = cid, int(domain_cardinality)
+    key.g1_alpha, key.g1_beta, key.g1_delta = (keep[k].ctypes.data for k in ("alpha1", "beta1", "delta1"))
+    key.g1_a, key.len_a = keep["A"].ctypes.data, keep["A"].shape[0]
+    key.g1_b, key.len_b = keep["B"].ctypes.data, keep["B"].shape[0]
+    key.g1_z, key.len_z = keep["Z"].ctypes.data, keep["Z"].shape[0]
+    key.g1_k, key.len_k = keep["K"].ctypes.data, keep["K"].shape[0]
+    key.g2_beta, key.g2_delta = keep["beta2"].ctypes.data, keep["delta2"].ctypes.data
+    key.g2_b, key.len_b2 = keep["B2"].ctypes.data, keep["B2"].shape[0]
+    key.infinity_a, key.infinity_b = keep["ia"].ctypes.data, keep["ib"].ctypes.data
+    key.nb_wires = keep["ia"].shape[0]
+    key.nb_infinity_a, key.nb_infinity_b = int(keep["ia"].sum()), int(keep["ib"].sum())
+    cks = [(g1(b), g1(e)) for b, e in commitment_keys]
+    if cks:
+        nck = len(cks)
+        keep["cks"] = cks
+        keep["bas"] = (C.c_void_p * nck)(*[b.ctypes.data for b, _ in cks])
+        keep["sig"] = (C.c_void_p * nck)(*[e.ctypes.data for _, e in cks])
+        keep["lens"] = (C.c_uint64 * nck)(*[b.shape[0] for b, _ in cks])
+        key.nb_commitments, key.ck_basis, key.ck_basis_exp_sigma, key.ck_len = nck, keep["bas"], keep["sig"], keep["lens"]
+    return key, keep
+
+
+def WriteKey(ctx: Context, curve, fileobj, fmt: int = KEY_FORMAT_COMPRESSED, **key_fields) -> int:
+    """ProvingKey.WriteTo (compressed) / WriteRawTo / WriteDump (marshal.go:231-300,378-445) of a key given by its host arrays
+    (same keyword fields as ProvingKey); fileobj: an open binary file.  Returns the number of bytes written."""
+    key, keep = _key_struct(curve, **key_fields)
+    fileobj.flush()
+    n = C.c_uint64()
+    ctx.lib.check(ctx.lib.ga_g16_key_write_fd(ctx.handle, C.byref(key), int(fmt), fileobj.fileno(), C.byref(n)))
+    del keep
+    return int(n.value)
+
+
+def ParseProof(curve, data: bytes, lib=None, max_commitments: int = 64) -> "Proof":
+    """Proof.ReadFrom (marshal.go:62-86) on WriteTo or WriteRawTo bytes"""
+    lib = lib or _lib.load()
+    cid = curve_id(curve)
+    fp = FP_LIMBS[cid]
+    buf = np.frombuffer(bytes(data), dtype=np.uint8)
+    out = np.zeros(8 * fp, dtype=np.uint64)
+    coms = np.zeros((max_commitments, 2 * fp), dtype=np.uint64)
+    pok = np.zeros(2 * fp, dtype=np.uint64)
+    n, used = C.c_uint32(), C.c_size_t()
+    lib.check(lib.ga_g16_proof_unmarshal(cid, _ptr(buf), buf.shape[0], _ptr(out), _ptr(coms), max_commitments, C.byref(n), _ptr(pok), C.byref(used)))
+    p = Proof(cid, out[: 2 * fp].copy(), out[2 * fp: 6 * fp].copy(), out[6 * fp:].copy(), lib)
+    p.Commitments, p.CommitmentPok, p.bytes_read = coms[: n.value].copy(), pok, int(used.value)
+    return p
+
+
 class ProvingKey:
     """setup.go:25-48 fields, uploaded once ("PinToGPU"); free with FreeGPUResources() (icicle.go:1493)."""
+
+    @classmethod
+    def ReadFrom(cls, ctx: Context, curve, source, *, precompute: int = 0, shard=(0, 1), k_remove=()):
+        """ProvingKey.ReadFrom / UnsafeReadFrom / ReadDump (marshal.go:305-373,449-539) straight into HBM: source is bytes or an
+        open binary file; the format (compressed / raw points / dump) is recognised from the stream.  k_remove: see __init__."""
+        cid = curve_id(curve)
+        self = cls.__new__(cls)
+        self.ctx, self.curve, self.shard = ctx, cid, (int(shard[0]), int(shard[1]))
+        rem = np.ascontiguousarray(k_remove, dtype=np.uint64)
+        h, used = C.c_void_p(), C.c_uint64()
+        lib = ctx.lib
+        if isinstance(source, (bytes, bytearray, memoryview)):
+            buf = np.frombuffer(bytes(source), dtype=np.uint8)
+            lib.check(lib.ga_g16_pk_read_mem(ctx.handle, cid, _ptr(buf), buf.shape[0], int(precompute), int(shard[0]), int(shard[1]),
+                                             _ptr(rem) if rem.size else None, rem.size, C.byref(h), C.byref(used)))
+        else:
+            lib.check(lib.ga_g16_pk_read_fd(ctx.handle, cid, source.fileno(), int(precompute), int(shard[0]), int(shard[1]),
+                                            _ptr(rem) if rem.size else None, rem.size, C.byref(h), C.byref(used)))
+        self.handle, self.bytes_read = h, int(used.value)
+        lay = ShardLayout(self)
+        self.nb_wires, self.domain_cardinality, self.nb_commitments = lay["nb_wires"], lay["n"], None
+        return self
 
     def __init__(self, ctx: Context, curve, *, domain_cardinality, alpha1, beta1, delta1, A, B, Z, K, beta2, delta2, B2,
                  infinityA, infinityB, precompute: int = 0, shard=(0, 1), commitment_keys=(), k_remove=(), staged_chunk: int = 0,

@@ -5,6 +5,7 @@ package bn254
 import (
 	"fmt"
 	"math/big"
+	"os"
 	"slices"
 	"time"
 	"unsafe"
@@ -133,6 +134,42 @@ func (pk *ProvingKey) setupDevicePointers(cfg *mi355x.Config, info constraint.Gr
 	return nil
 }
 
+// PinFromFile loads the device copy of the key directly from a key file written by WriteTo, WriteRawTo or WriteDump
+// (the format is recognised from the stream): the counterpart of ReadFrom / ReadDump (marshal.go:305-373,449-539) for
+// provers that never need the key on the host -- the file goes through pinned staging buffers into HBM and is decoded
+// there.  Every configured device reads the file once and keeps its shard.  The embedded native key stays empty, so
+// such a key can prove but cannot be re-serialized; commitment information comes from the constraint system.
+func (pk *ProvingKey) PinFromFile(path string, cfg *mi355x.Config, info constraint.Groth16Commitments) error {
+	pk.setupMu.Lock()
+	defer pk.setupMu.Unlock()
+	pk.freeLocked()
+	devices := cfg.DeviceIDs()
+	di := &deviceInfo{devices: slices.Clone(devices), precompute: int32(cfg.Precompute)}
+	remove := kRemoveList(info)
+	for shard, dev := range devices {
+		ctx, err := ga.ContextFor(dev)
+		if err != nil {
+			di.free()
+			return err
+		}
+		f, err := os.Open(path)
+		if err != nil {
+			di.free()
+			return err
+		}
+		key, _, err := ctx.ReadKeyFd(curveID, f.Fd(), int32(cfg.Precompute), shard, len(devices), remove)
+		f.Close()
+		if err != nil {
+			di.free()
+			return fmt.Errorf("device %d: %w", dev, err)
+		}
+		di.keys = append(di.keys, key)
+	}
+	pk.deviceInfo = di
+	pk.PinToGPU = true
+	return nil
+}
+
 func (di *deviceInfo) free() {
 	for _, k := range di.keys {
 		k.Free()
@@ -175,8 +212,10 @@ func Prove(r1cs *cs.R1CS, pk *ProvingKey, fullWitness witness.Witness, cfg *mi35
 	if pk.deviceInfo == nil {
 		log.Debug().Msg("pinning proving key in HBM")
 	}
-	if err := pk.setupDevicePointers(cfg, commitmentInfo); err != nil {
-		return nil, fmt.Errorf("setup device pointers: %w", err)
+	if !(pk.deviceInfo != nil && len(pk.InfinityA) == 0) { // a key pinned by PinFromFile has no host copy to (re)pin from
+		if err := pk.setupDevicePointers(cfg, commitmentInfo); err != nil {
+			return nil, fmt.Errorf("setup device pointers: %w", err)
+		}
 	}
 	if !pk.PinToGPU {
 		defer pk.FreeGPUResources()

@@ -251,6 +251,38 @@ type ProvingKey struct {
 	h *C.ga_g16_pk
 }
 
+// ReadKeyFd loads a key file -- ProvingKey.WriteTo, WriteRawTo or WriteDump output, recognised from the stream -- from an
+// open file descriptor straight into HBM (ga_g16_pk_read_fd): the file streams through pinned staging buffers and the
+// points are decoded by a device kernel, so the 6-9 GiB key never exists as Go slices.  kRemove is the toRemove list of
+// prove.go:231-235 (it comes from the constraint system, not from the key file).
+func (c *Context) ReadKeyFd(curve Curve, fd uintptr, precompute int32, shardIndex, shardCount int, kRemove []uint64) (*ProvingKey, uint64, error) {
+	pk := &ProvingKey{}
+	var used C.uint64_t
+	var rem *C.uint64_t
+	if len(kRemove) > 0 {
+		rem = (*C.uint64_t)(unsafe.Pointer(unsafe.SliceData(kRemove)))
+	}
+	err := call("ga_g16_pk_read_fd", func() C.int {
+		return C.ga_g16_pk_read_fd(c.h, C.int(curve), C.int(fd), C.int32_t(precompute), C.uint32_t(shardIndex), C.uint32_t(shardCount),
+			rem, C.uint64_t(len(kRemove)), &pk.h, &used)
+	})
+	if err != nil {
+		return nil, 0, err
+	}
+	return pk, uint64(used), nil
+}
+
+// ParseProof is Proof.ReadFrom on WriteTo / WriteRawTo bytes (ga_g16_proof_unmarshal); proofOut: Ar | Bs | Krs affine.
+func ParseProof(curve Curve, data []byte, proofOut, commitmentsOut unsafe.Pointer, maxCommitments int, pokOut unsafe.Pointer) (nbCommitments int, consumed int, err error) {
+	var n C.uint32_t
+	var used C.size_t
+	p := (*C.uint8_t)(unsafe.Pointer(unsafe.SliceData(data)))
+	err = call("ga_g16_proof_unmarshal", func() C.int {
+		return C.ga_g16_proof_unmarshal(C.int(curve), p, C.size_t(len(data)), proofOut, commitmentsOut, C.uint32_t(maxCommitments), &n, pokOut, &used)
+	})
+	return int(n), int(used), err
+}
+
 // Prove runs computeH, the five MSMs and the (r, s) epilogue: w, a, b, c point to the solver's W, A, B, C;
 // out receives Ar | Bs | Krs (G1Affine, G2Affine, G1Affine).
 func (pk *ProvingKey) Prove(w, a, b, c unsafe.Pointer, nbConstraints, nbPublic uint64, r, s, out unsafe.Pointer) error {

@@ -307,6 +307,31 @@ int ga_g16_z_partial(ga_g16_pk* pk, const void* h_slice_dev, void* partial_out);
 int ga_g16_prove_multi(ga_g16_pk* const* keys, uint32_t n, const void* w, const void* a, const void* b, const void* c,
                        uint64_t n_constraints, uint64_t nb_public, const void* r, const void* s, void* proof_out);
 
+/* ---- proving-key files -----------------------------------------------------------------------
+ * replaces: ProvingKey.ReadFrom / UnsafeReadFrom (marshal.go:305-373: compressed or uncompressed points, told apart by their
+ * flag bits) and ReadDump (marshal.go:449-539: raw memory images), read straight into HBM: the file streams through pinned
+ * staging buffers, points are decoded (big-endian -> Montgomery, on-curve check, square roots of compressed points) by a device
+ * kernel, and the dump's slices are copied without any arithmetic.  The format is recognised from the stream (the 0xdeadbeef
+ * marker of WriteDump).  Subgroup membership of G2 points is not checked (UnsafeReadFrom semantics).
+ *   k_remove: the toRemove wire list of prove.go:231-235 -- it comes from the constraint system, not from the key file; NULL / 0
+ *   for circuits without commitments.  precompute, shard_index, shard_count: as in ga_g16_key.
+ * ga_g16_key_write_fd writes the host description of a key in the WriteTo (GA_KEY_FORMAT_COMPRESSED), WriteRawTo (RAW) or
+ * WriteDump (DUMP) layout (marshal.go:231-300,378-445); points are encoded on the device. */
+#define GA_KEY_FORMAT_COMPRESSED 0
+#define GA_KEY_FORMAT_RAW 1
+#define GA_KEY_FORMAT_DUMP 2
+int ga_g16_pk_read_mem(ga_ctx* ctx, int curve, const uint8_t* data, size_t len, int32_t precompute, uint32_t shard_index,
+                       uint32_t shard_count, const uint64_t* k_remove, uint64_t len_k_remove, ga_g16_pk** out, uint64_t* bytes_read);
+int ga_g16_pk_read_fd(ga_ctx* ctx, int curve, int fd, int32_t precompute, uint32_t shard_index, uint32_t shard_count,
+                      const uint64_t* k_remove, uint64_t len_k_remove, ga_g16_pk** out, uint64_t* bytes_read);
+int ga_g16_key_write_fd(ga_ctx* ctx, const ga_g16_key* key, int format, int fd, uint64_t* bytes_written);
+/* Proof.ReadFrom (marshal.go:62-86): Ar | Bs | Krs | u32 n | n commitments | CommitmentPok, compressed (WriteTo) or uncompressed
+ * (WriteRawTo) points.  proof_out: Ar | Bs | Krs affine (Montgomery), commitments_out: room for max_commitments G1Affine. */
+int ga_g16_proof_unmarshal(int curve, const uint8_t* data, size_t len, void* proof_out, void* commitments_out,
+                           uint32_t max_commitments, uint32_t* n_commitments, void* pok_out, size_t* consumed);
+/* one G1Affine / G2Affine from its wire encoding (curve.Decoder for a single point; host arithmetic) */
+int ga_point_unmarshal(int curve, int group, const uint8_t* data, size_t len, void* affine_out, size_t* consumed);
+
 /* Proof.WriteTo wire format (marshal.go:33-58, no commitments): compressed Ar | Bs | Krs | u32 0 | PoK(inf).
  * Returns the number of bytes written in *len (164 for BN254, 244 for BLS12-381). */
 int ga_g16_proof_marshal(int curve, const void* proof, uint8_t* out, size_t cap, size_t* len);

@@ -948,3 +948,120 @@ def sha_tag(*parts) -> str:
     for p in parts:
         h.update(p if isinstance(p, bytes) else repr(p).encode())
     return h.hexdigest()
+
+
+# ----------------------------------------------------------------------------------------------
+# proving-key wire formats (backend/groth16/bn254/marshal.go:231-539) and Proof.ReadFrom (:62-86)
+# Framing owned by gnark-crypto v0.21.0 [EXT, restated from its published code, see gnark_amd/csrc/keyio.cuh]:
+# Encoder integers big-endian, []G1Affine = u32 BE length + points, []bool one byte per entry without a
+# length, fft.Domain.WriteTo = cardinality + 5 fr elements (+ withPrecompute byte), unsafe.WriteSlice = u64 LE
+# length + memory image, unsafe.WriteMarker = uint64(0xdeadbeef) in native byte order.
+# ----------------------------------------------------------------------------------------------
+
+
+def domain_bytes(c: Curve, n: int, with_precompute_byte: bool = True) -> bytes:
+    """fft.Domain.WriteTo: Cardinality, CardinalityInv, Generator, GeneratorInv, FrMultiplicativeGen, FrMultiplicativeGenInv"""
+    w = c.fr_root_of_unity(n)
+    elems = [pow(n, -1, c.r), w, pow(w, -1, c.r), c.fr_gen, pow(c.fr_gen, -1, c.r)]
+    out = n.to_bytes(8, "big") + b"".join(e.to_bytes(32, "big") for e in elems)
+    return out + (b"\x01" if with_precompute_byte else b"")
+
+
+def _enc_g1(c, P, raw):
+    return g1_marshal_uncompressed(c, P) if raw else g1_compress(c, P)
+
+
+def _enc_g2(c, P, raw):
+    return g2_marshal_uncompressed(c, P) if raw else g2_compress(c, P)
+
+
+def _enc_vec(c, pts, raw, g2=False):
+    f = _enc_g2 if g2 else _enc_g1
+    return len(pts).to_bytes(4, "big") + b"".join(f(c, P, raw) for P in pts)
+
+
+def _key_tail(pk: "ProvingKey") -> bytes:
+    nw = len(pk.infinityA)
+    return (nw.to_bytes(8, "big") + sum(map(bool, pk.infinityA)).to_bytes(8, "big") + sum(map(bool, pk.infinityB)).to_bytes(8, "big")
+            + bytes(1 if x else 0 for x in pk.infinityA) + bytes(1 if x else 0 for x in pk.infinityB)
+            + len(pk.commitment_keys).to_bytes(4, "big"))
+
+
+def pk_write(pk: "ProvingKey", raw: bool = False, with_precompute_byte: bool = True) -> bytes:
+    """ProvingKey.WriteTo / WriteRawTo, marshal.go:243-299"""
+    c = pk.curve
+    out = domain_bytes(c, pk.n, with_precompute_byte)
+    out += _enc_g1(c, pk.alpha1, raw) + _enc_g1(c, pk.beta1, raw) + _enc_g1(c, pk.delta1, raw)
+    out += _enc_vec(c, pk.A, raw) + _enc_vec(c, pk.B, raw) + _enc_vec(c, pk.Z, raw) + _enc_vec(c, pk.K, raw)
+    out += _enc_g2(c, pk.beta2, raw) + _enc_g2(c, pk.delta2, raw) + _enc_vec(c, pk.B2, raw, g2=True)
+    out += _key_tail(pk)
+    for basis, sigma in pk.commitment_keys:      # pedersen.ProvingKey.WriteTo / WriteRawTo: Basis, BasisExpSigma
+        out += _enc_vec(c, basis, raw) + _enc_vec(c, sigma, raw)
+    return out
+
+
+def _mem_g1(c, P):
+    if P is None:
+        return bytes(2 * c.fp_bytes)
+    return b"".join(int(l).to_bytes(8, "little") for v in P for l in to_mont_limbs(v, c.p, c.fp_limbs))
+
+
+def _mem_g2(c, P):
+    if P is None:
+        return bytes(4 * c.fp_bytes)
+    (x0, x1), (y0, y1) = P
+    return b"".join(int(l).to_bytes(8, "little") for v in (x0, x1, y0, y1) for l in to_mont_limbs(v, c.p, c.fp_limbs))
+
+
+def _dump_slice(c, pts, g2=False):
+    f = _mem_g2 if g2 else _mem_g1
+    return len(pts).to_bytes(8, "little") + b"".join(f(c, P) for P in pts)
+
+
+def pk_write_dump(pk: "ProvingKey", with_precompute_byte: bool = True) -> bytes:
+    """ProvingKey.WriteDump, marshal.go:378-445: marker, domain, header points (raw encoding), nbWires / infinity masks,
+    then the slices as memory images (Montgomery limbs, little-endian: gnark-crypto's fp.Element layout on amd64)"""
+    c = pk.curve
+    out = (0xdeadbeef).to_bytes(8, "little") + domain_bytes(c, pk.n, with_precompute_byte)
+    out += _enc_g1(c, pk.alpha1, True) + _enc_g1(c, pk.beta1, True) + _enc_g1(c, pk.delta1, True)
+    out += _enc_g2(c, pk.beta2, True) + _enc_g2(c, pk.delta2, True)
+    out += _key_tail(pk)
+    out += _dump_slice(c, pk.A) + _dump_slice(c, pk.B) + _dump_slice(c, pk.Z) + _dump_slice(c, pk.K) + _dump_slice(c, pk.B2, g2=True)
+    for basis, sigma in pk.commitment_keys:
+        out += _dump_slice(c, basis) + _dump_slice(c, sigma)
+    return out
+
+
+def g1_unmarshal(c: Curve, data: bytes):
+    """uncompressed G1 point: x | y big-endian, 0x40 = infinity"""
+    n = c.fp_bytes
+    if data[0] & 0x40 and not (data[0] & 0x80):
+        return None
+    return (int.from_bytes(data[:n], "big"), int.from_bytes(data[n:2 * n], "big"))
+
+
+def g2_unmarshal(c: Curve, data: bytes):
+    n = c.fp_bytes
+    if data[0] & 0x40 and not (data[0] & 0x80):
+        return None
+    x1, x0, y1, y0 = (int.from_bytes(data[i * n:(i + 1) * n], "big") for i in range(4))
+    return ((x0, x1), (y0, y1))
+
+
+def proof_read(c: Curve, data: bytes):
+    """Proof.ReadFrom, marshal.go:62-86: (ar, bs, krs, commitments, pok); points compressed or uncompressed by their flag bits"""
+    n = c.fp_bytes
+    raw = (data[0] >> 6) == 0 if c.name == "bn254" else not (data[0] & 0x80)
+    s1, s2 = (2 * n, 4 * n) if raw else (n, 2 * n)
+    g1 = (lambda b: g1_unmarshal(c, b)) if raw else (lambda b: g1_decompress(c, b))
+    g2 = (lambda b: g2_unmarshal(c, b)) if raw else (lambda b: g2_decompress(c, b))
+    off = 0
+    ar = g1(data[off:off + s1]); off += s1
+    bs = g2(data[off:off + s2]); off += s2
+    krs = g1(data[off:off + s1]); off += s1
+    k = int.from_bytes(data[off:off + 4], "big"); off += 4
+    coms = []
+    for _ in range(k):
+        coms.append(g1(data[off:off + s1])); off += s1
+    pok = g1(data[off:off + s1]); off += s1
+    return ar, bs, krs, coms, pok, off

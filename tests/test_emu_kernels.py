@@ -830,3 +830,126 @@ def test_emu_msm_table_window_ranges(emu_ctx, c, group):
         t.free()
         for b in (bases, dlogs, scal):
             b.free()
+
+
+# ---- proving-key files and proof bytes (marshal.go:62-86,231-539) --------------------------------------------------
+def _py_key_fields(c, pk):
+    return dict(domain_cardinality=pk.n, alpha1=pts_to_arr(c, 0, [pk.alpha1]), beta1=pts_to_arr(c, 0, [pk.beta1]),
+                delta1=pts_to_arr(c, 0, [pk.delta1]), A=pts_to_arr(c, 0, pk.A), B=pts_to_arr(c, 0, pk.B), Z=pts_to_arr(c, 0, pk.Z),
+                K=pts_to_arr(c, 0, pk.K), beta2=pts_to_arr(c, 1, [pk.beta2]), delta2=pts_to_arr(c, 1, [pk.delta2]),
+                B2=pts_to_arr(c, 1, pk.B2), infinityA=pk.infinityA, infinityB=pk.infinityB,
+                commitment_keys=[(pts_to_arr(c, 0, b), pts_to_arr(c, 0, e)) for b, e in pk.commitment_keys])
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("circuit", ["cubic", "commit"])
+def test_emu_proving_key_files(emu_ctx, c, circuit, tmp_path):
+    """the three key layouts of marshal.go (WriteTo compressed, WriteRawTo, WriteDump), both ways against the oracle's
+    restatement: the library's writer produces the oracle's bytes; a key READ from the oracle's bytes -- from memory and from a
+    file descriptor, whole and as shard 1 of 2, with and without the withPrecompute byte of the domain block -- proves exactly like
+    the key built from the host arrays (proof bytes == oracle)."""
+    rng = pyref.Xoshiro(31337)
+    cs = pyref.cubic_r1cs() if circuit == "cubic" else pyref.commit_r1cs()
+    pk, _, _ = pyref.groth16_setup(c, cs, [rng.field(c.r) for _ in range(5 + len(cs.commitments) + 1)])
+    if circuit == "cubic":
+        w = pyref.cubic_witness(3)
+        removed = []
+    else:
+        w = pyref.commit_solve(c, cs, 4, 9, lambda i, ww: pyref.commitment_hint(pk, cs, i, ww)[1])
+        removed = sorted({j for cm in cs.commitments for j in cm.private_committed} | {cm.commitment_index for cm in cs.commitments})
+    A, B, Cc = pyref.r1cs_solve(c, cs, w)
+    sol = groth16.Solution(W=fr_to_arr(c, w), A=fr_to_arr(c, A), B=fr_to_arr(c, B), C=fr_to_arr(c, Cc))
+    r, s = fr_to_arr(c, [rng.field(c.r)]), fr_to_arr(c, [rng.field(c.r)])
+    fields = _py_key_fields(c, pk)
+    ref = groth16.ProvingKey(emu_ctx, c.name, k_remove=removed, **fields)
+    try:
+        want = groth16.Prove(ref, sol, cs.nb_public, r, s).raw()
+        want_part = None
+    finally:
+        ref.FreeGPUResources()
+    images = {groth16.KEY_FORMAT_COMPRESSED: pyref.pk_write(pk, raw=False), groth16.KEY_FORMAT_RAW: pyref.pk_write(pk, raw=True),
+              groth16.KEY_FORMAT_DUMP: pyref.pk_write_dump(pk)}
+    for fmt, img in images.items():
+        path = tmp_path / f"key{fmt}.bin"
+        with open(path, "wb") as f:                         # writer: byte parity with the oracle
+            n = groth16.WriteKey(emu_ctx, c.name, f, fmt, **fields)
+        assert n == len(img) and open(path, "rb").read() == img, fmt
+        for source in ("mem", "fd"):
+            if source == "mem":
+                dpk = groth16.ProvingKey.ReadFrom(emu_ctx, c.name, img, k_remove=removed)
+            else:
+                with open(path, "rb") as f:
+                    dpk = groth16.ProvingKey.ReadFrom(emu_ctx, c.name, f, k_remove=removed)
+            try:
+                assert dpk.bytes_read == len(img) and dpk.nb_wires == len(pk.infinityA)
+                assert np.array_equal(groth16.Prove(dpk, sol, cs.nb_public, r, s).raw(), want), (fmt, source)
+            finally:
+                dpk.FreeGPUResources()
+    # older gnark-crypto domain block (no withPrecompute byte), and a sharded read
+    old = pyref.pk_write(pk, raw=False, with_precompute_byte=False)
+    dpk = groth16.ProvingKey.ReadFrom(emu_ctx, c.name, old, k_remove=removed)
+    try:
+        assert dpk.bytes_read == len(old)
+        assert np.array_equal(groth16.Prove(dpk, sol, cs.nb_public, r, s).raw(), want)
+    finally:
+        dpk.FreeGPUResources()
+    parts = []
+    for k in range(2):
+        spk = groth16.ProvingKey.ReadFrom(emu_ctx, c.name, images[groth16.KEY_FORMAT_DUMP if k else groth16.KEY_FORMAT_COMPRESSED],
+                                          shard=(k, 2), k_remove=removed)
+        try:
+            parts.append(groth16.ProvePartial(spk, sol, cs.nb_public))
+            fin = groth16.Finish(spk, groth16.SumPartials(c.name, parts, lib=emu_ctx.lib), r, s) if k else None
+        finally:
+            spk.FreeGPUResources()
+    assert np.array_equal(fin.raw(), want)
+    # malformed input fails cleanly
+    bad = bytearray(images[groth16.KEY_FORMAT_COMPRESSED])
+    bad[8 + 160 + 1 + 3 * c.fp_bytes + 4 + 5] ^= 0x55        # a byte inside the first point of G1.A: (almost surely) not on the curve
+    with pytest.raises(Exception, match="do not decode|does not decode"):
+        groth16.ProvingKey.ReadFrom(emu_ctx, c.name, bytes(bad), k_remove=removed)
+    with pytest.raises(Exception, match="end of input"):
+        groth16.ProvingKey.ReadFrom(emu_ctx, c.name, images[groth16.KEY_FORMAT_RAW][:-7], k_remove=removed)
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_emu_proof_unmarshal(emu_ctx, c):
+    """Proof.ReadFrom (marshal.go:62-86) on the oracle's WriteTo and WriteRawTo bytes, with and without commitments; the single
+    point decoder on the reference's serialized verifying keys (backend/solidity/testdata/*.vk)"""
+    import os
+    lib = emu_ctx.lib
+    rng = pyref.Xoshiro(99)
+    G1, G2 = group_of(c, 0), group_of(c, 1)
+    pt1 = lambda: G1.mul(c.g1, rng.field(c.r))
+    pt2 = lambda: G2.mul(c.g2, rng.field(c.r))
+    for ncom in (0, 3):
+        ar, bs, krs = pt1(), pt2(), pt1()
+        coms = [pt1() for _ in range(ncom)]
+        pok = pt1() if ncom else None
+        for data in (pyref.proof_bytes(c, ar, bs, krs, coms, pok), pyref.proof_bytes_raw(c, ar, bs, krs, coms, pok)):
+            p = groth16.ParseProof(c.name, data + b"trailing", lib=lib)
+            assert p.bytes_read == len(data)
+            assert (arr_to_g1_affine(c, p.Ar), arr_to_g2_affine(c, p.Bs), arr_to_g1_affine(c, p.Krs)) == (ar, bs, krs)
+            assert [arr_to_g1_affine(c, x) for x in p.Commitments] == coms and arr_to_g1_affine(c, p.CommitmentPok) == pok
+            assert pyref.proof_read(c, data)[:5] == (ar, bs, krs, coms, pok)
+            assert p.WriteTo() == pyref.proof_bytes(c, ar, bs, krs, coms, pok)      # and back out through the marshaller
+    with pytest.raises(Exception, match="does not decode|end of input|malformed"):
+        groth16.ParseProof(c.name, b"\x00" * 20, lib=lib)
+    # the reference's own serialized keys: alpha1 beta1 beta2 gamma2 delta1 delta2, u32 4, 4 x K  (marshal.go:99-125)
+    name = "bn254" if c.cid == 0 else "bls12381"
+    raw = open(os.path.join(os.path.dirname(__file__), "golden", f"vk_blank_groth16_{name}_nocommit.bin"), "rb").read()
+    b, off = c.fp_bytes, 0
+    import ctypes as C
+    for group in (0, 0, 1, 1, 0, 1, None, 0, 0, 0, 0):
+        if group is None:
+            off += 4
+            continue
+        ln = b if group == 0 else 2 * b
+        out = np.zeros(2 * c.fp_limbs * (1 if group == 0 else 2), dtype=np.uint64)
+        used = C.c_size_t()
+        buf = np.frombuffer(raw[off:], dtype=np.uint8)
+        lib.check(lib.ga_point_unmarshal(c.cid, group, buf.ctypes.data, buf.shape[0], out.ctypes.data, C.byref(used)))
+        assert used.value == ln
+        want = pyref.g1_decompress(c, raw[off:off + ln]) if group == 0 else pyref.g2_decompress(c, raw[off:off + ln])
+        assert (arr_to_g1_affine(c, out) if group == 0 else arr_to_g2_affine(c, out)) == want
+        off += ln
