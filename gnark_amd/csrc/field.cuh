@@ -356,30 +356,47 @@ struct alignas(16) u32x4 {
     uint32_t x, y, z, w;
 };
 
-// One 16-byte vector load that the compiler may neither split nor narrow.  Without the `volatile`, LLVM fuses a point
-// load with the 29-bit limb extraction that follows and emits dozens of 2-byte global_load_ushort at odd offsets
-// (52 per G2 point) instead of eight global_load_dwordx4.
+// One 16-byte vector load that the compiler may neither split nor narrow.  Left alone, LLVM fuses a point load with the 29-bit
+// limb extraction that follows and emits dozens of 2-byte global_load_ushort at odd offsets (52 per G2 point) instead of eight
+// global_load_dwordx4.  Round 1 stopped that with a `volatile` access -- which also made every 16-byte piece a system-scope
+// (sc0 sc1) load followed by its own s_waitcnt vmcnt(0): four serialized memory round trips per G1 table entry, eight per G2
+// entry, up to 24 per bucket in the window reduction.  An empty asm on the loaded VALUE hides it from the combiner just as well
+// and leaves the load an ordinary one: the pieces of a point are issued back to back and waited for once.
 typedef uint32_t ga_v4u __attribute__((vector_size(16)));
+// n consecutive 16-byte pieces: all loads first, then the values are made opaque (an asm right after each load would make the
+// compiler wait for that load before issuing the next one)
+template <int NV>
+GA_HD void load16n(const void* p, ga_v4u (&v)[NV]) {
+    const ga_v4u* q = reinterpret_cast<const ga_v4u*>(p);
+#pragma unroll
+    for (int i = 0; i < NV; i++) v[i] = q[i];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int i = 0; i < NV; i++) asm volatile("" : "+v"(v[i]));
+#endif
+}
 GA_HD u32x4 load16(const void* p) {
-    ga_v4u v = *reinterpret_cast<const volatile ga_v4u*>(p);
+    ga_v4u v[1];
+    load16n<1>(p, v);
     u32x4 r;
-    r.x = v[0];
-    r.y = v[1];
-    r.z = v[2];
-    r.w = v[3];
+    r.x = v[0][0];
+    r.y = v[0][1];
+    r.z = v[0][2];
+    r.w = v[0][3];
     return r;
 }
 
 template <class P>
 GA_HD Fe<P> load_fe(const void* p) {
     Fe<P> r;
+    ga_v4u v[P::N / 4];
+    load16n<P::N / 4>(p, v);
 #pragma unroll
     for (int i = 0; i < P::N / 4; i++) {
-        u32x4 v = load16(reinterpret_cast<const char*>(p) + 16 * i);
-        r.l[4 * i + 0] = v.x;
-        r.l[4 * i + 1] = v.y;
-        r.l[4 * i + 2] = v.z;
-        r.l[4 * i + 3] = v.w;
+        r.l[4 * i + 0] = v[i][0];
+        r.l[4 * i + 1] = v[i][1];
+        r.l[4 * i + 2] = v[i][2];
+        r.l[4 * i + 3] = v[i][3];
     }
     return r;
 }
@@ -419,11 +436,10 @@ template <class T>
 GA_HD T load_pod(const void* p) {
     static_assert(sizeof(T) % 16 == 0, "16-byte multiples only");
     T r;
+    ga_v4u v[sizeof(T) / 16];
+    load16n<(int)(sizeof(T) / 16)>(p, v);
 #pragma unroll
-    for (size_t i = 0; i < sizeof(T) / 16; i++) {
-        u32x4 v = load16(reinterpret_cast<const char*>(p) + 16 * i);
-        memcpy(reinterpret_cast<char*>(&r) + 16 * i, &v, 16);
-    }
+    for (size_t i = 0; i < sizeof(T) / 16; i++) memcpy(reinterpret_cast<char*>(&r) + 16 * i, &v[i], 16);
     return r;
 }
 

@@ -884,8 +884,34 @@ static int proof_unmarshal(const uint8_t* data, size_t len, void* proof_out, voi
 // h_chain      : v <- FFT_coset(iFFT(v)) for one of the solver's A, B, C                                       prove.go:362-368
 // h_combine    : h <- iFFT_coset((a*b - c) * den), bit-reversed like pk.G1.Z                                  prove.go:377-386
 // z_msm        : MSM over this shard's slice of pk.G1.Z and h                                                  prove.go:225-227
+// W -> device, only the wire range this shard reads.  Returns when the copy has been handed to the DMA engine from pageable
+// memory, i.e. when the host buffer has been consumed -- callers start the (PCIe-competing) upload of A, B, C only after it.
+static int witness_upload(G16Pk* pk, const void* w, uint64_t nb_public) {
+    Ctx* ctx = pk->ctx;
+    if (nb_public > pk->nb_wires || pk->nb_wires - nb_public != pk->full_len_k + pk->len_k_remove) {
+        set_error("prove: inconsistent sizes (nbWires %llu - nbPublic %llu != len(K) %llu + len(k_remove) %llu)", (unsigned long long)pk->nb_wires,
+                  (unsigned long long)nb_public, (unsigned long long)pk->full_len_k, (unsigned long long)pk->len_k_remove);
+        return GA_ERR_INVALID;
+    }
+    void* d_w;
+    GA_CHECK(ctx->scratch_get("g16_w", pk->nb_wires * 32, &d_w));
+    // the wire range this shard reads: everything for an unsharded key, ~1/N of W for shard k of N (the gather lists of a
+    // shard are contiguous pieces of the sorted wire lists); K's range depends on nbPublic
+    uint64_t lo = pk->w_lo, hi = pk->w_hi;
+    if (pk->len_k && !pk->d_idx_k) {
+        const uint64_t klo = nb_public + pk->off_k, khi = klo + pk->len_k;
+        lo = lo < klo ? lo : klo;
+        hi = hi > khi ? hi : khi;
+    }
+    if (hi > pk->nb_wires) hi = pk->nb_wires;
+    if (lo > hi) lo = hi;
+    StageTimer tm(ctx, "g16_h2d_w");
+    if (hi > lo) GA_HIP_CHECK(hipMemcpyAsync((char*)d_w + lo * 32, (const char*)w + lo * 32, (hi - lo) * 32, hipMemcpyHostToDevice, ctx->stream));
+    return GA_OK;
+}
+
 template <class C>
-static int witness_msms(G16Pk* pk, const void* w, uint64_t nb_public, XYZZ<Fe<typename C::FpP>>* o_ar,
+static int witness_msms(G16Pk* pk, uint64_t nb_public, XYZZ<Fe<typename C::FpP>>* o_ar,
                         XYZZ<Fe<typename C::FpP>>* o_bs1, XYZZ<Fe<typename C::FpP>>* o_k, XYZZ<Fe2<typename C::FpP>>* o_bs2) {
     typedef Fe<typename C::FpP> F1;
     typedef Fe2<typename C::FpP> F2;
@@ -900,20 +926,6 @@ static int witness_msms(G16Pk* pk, const void* w, uint64_t nb_public, XYZZ<Fe<ty
     GA_CHECK(ctx->scratch_get("g16_w", pk->nb_wires * 32, &d_w));
     GA_CHECK(ctx->scratch_get("g16_wa", pk->len_a * 32 + 32, &d_wa));
     GA_CHECK(ctx->scratch_get("g16_wb", pk->len_b * 32 + 32, &d_wb));
-    // the wire range this shard reads: everything for an unsharded key, ~1/N of W for shard k of N (the gather lists of a
-    // shard are contiguous pieces of the sorted wire lists); K's range depends on nbPublic
-    uint64_t lo = pk->w_lo, hi = pk->w_hi;
-    if (pk->len_k && !pk->d_idx_k) {
-        const uint64_t klo = nb_public + pk->off_k, khi = klo + pk->len_k;
-        lo = lo < klo ? lo : klo;
-        hi = hi > khi ? hi : khi;
-    }
-    if (hi > pk->nb_wires) hi = pk->nb_wires;
-    if (lo > hi) lo = hi;
-    {
-        StageTimer tm(ctx, "g16_h2d_w");
-        if (hi > lo) GA_HIP_CHECK(hipMemcpyAsync((char*)d_w + lo * 32, (const char*)w + lo * 32, (hi - lo) * 32, hipMemcpyHostToDevice, st));
-    }
     // ---- wire filtering (prove.go:147-168) ------------------------------------------------------------
     if (!pk->share_a) GA_CHECK(util_gather_fr<C>(ctx, d_wa, d_w, pk->d_idx_a, pk->len_a));
     if (!pk->share_b) GA_CHECK(util_gather_fr<C>(ctx, d_wb, d_w, pk->d_idx_b, pk->len_b));
@@ -1057,6 +1069,7 @@ static int prove_partial(G16Pk* pk, const void* w, const void* a, const void* b,
     // W first (the four witness MSMs only need W); A, B, C are uploaded by a helper thread on a second stream while
     // those MSMs run -- pageable H2D copies block the calling thread, hence the thread.  Everything is joined before
     // this function returns, so no host pointer outlives the call.
+    GA_CHECK(witness_upload(pk, w, nb_public));
     EventGuard abc;
     GA_HIP_CHECK(hipEventCreateWithFlags(&abc.ev, hipEventDisableTiming));
     int up_rc = GA_OK;
@@ -1080,7 +1093,7 @@ static int prove_partial(G16Pk* pk, const void* w, const void* a, const void* b,
     });
     ThreadJoiner joiner{uploader};
     XYZZ<F1> krs, krs2;
-    GA_CHECK(witness_msms<C>(pk, w, nb_public, o_ar, o_bs1, &krs, o_bs2));
+    GA_CHECK(witness_msms<C>(pk, nb_public, o_ar, o_bs1, &krs, o_bs2));
     // ---- H (prove.go:134,346-389), then the MSM over pk.G1.Z (prove.go:225-227) ----------------------------
     uploader.join();
     if (up_rc != GA_OK) {
@@ -1354,6 +1367,10 @@ static int prove_multi(G16Pk* const* pks, uint32_t n, const void* w, const void*
         if (ok && pk->len_z) ok = t == 0 || ctx->scratch_get("h_slice", pk->len_z * 32, &h_slice[t]) == GA_OK;
         if (!ok) bail("multi-device prove: buffers");
         if (!sh.barrier(0)) return;
+        if (witness_upload(pk, w, nb_public) != GA_OK) {
+            bail("multi-device prove: uploading W");
+            ok = false;
+        }
         // upload of this device's chain input(s) on the copy stream, by a helper thread, under the witness MSMs
         EventGuard up;
         int up_rc = GA_OK;
@@ -1385,7 +1402,7 @@ static int prove_multi(G16Pk* const* pks, uint32_t n, const void* w, const void*
             }
         }
         ThreadJoiner joiner{uploader};
-        if (ok && witness_msms<C>(pk, w, nb_public, &parts[t].ar, &parts[t].bs1, &parts[t].k, &parts[t].bs2) != GA_OK) {
+        if (ok && witness_msms<C>(pk, nb_public, &parts[t].ar, &parts[t].bs1, &parts[t].k, &parts[t].bs2) != GA_OK) {
             bail("multi-device prove: witness MSMs");
             ok = false;
         }
@@ -1689,7 +1706,8 @@ int ga_g16_witness_partial(ga_g16_pk* p, const void* w, uint64_t nb_public, void
         typedef Fe2<typename C::FpP> F2;
         XYZZ<F1> ar, bs1, krs;
         XYZZ<F2> bs2;
-        GA_CHECK(witness_msms<C>(pk, w, nb_public, &ar, &bs1, &krs, &bs2));
+        GA_CHECK(witness_upload(pk, w, nb_public));
+        GA_CHECK(witness_msms<C>(pk, nb_public, &ar, &bs1, &krs, &bs2));
         char* o = reinterpret_cast<char*>(partials_out);
         host_store_jac<F1>(o, ar);
         host_store_jac<F1>(o + sizeof(Jac<F1>), bs1);
