@@ -4,7 +4,7 @@
 #include <stdarg.h>
 #include <stdlib.h>
 
-#include "hostops.cuh"
+#include "hostops.hip.h"
 
 namespace ga {
 
@@ -45,10 +45,14 @@ void Ctx::scratch_free_all() {
     scratch.clear();
 }
 
-struct Lock {
-    std::lock_guard<std::mutex> g;
-    explicit Lock(Ctx* c) : g(c->mu) { hipSetDevice(c->device); }
-};
+void Tunables::read_env() {
+    *this = Tunables();
+    if (const char* e = getenv("GA_MSM_MAX_CHUNK")) msm_max_chunk = strtoull(e, nullptr, 10);
+    if (const char* e = getenv("GA_REDUCE_LAZY_MIN")) reduce_lazy_min = strtoull(e, nullptr, 10);
+    if (const char* e = getenv("GA_G16_SHARE_MIN_PCT")) g16_share_min_pct = atoi(e);
+}
+
+typedef CtxLock Lock;
 
 // Bring inputs to the device when they are host pointers.
 struct Staged {
@@ -91,10 +95,8 @@ static int msm_impl(Ctx* ctx, const void* bases, const void* scalars, size_t n, 
     // Split along the point axis when one call would overflow the 2^31 (point, window) pair space -- the analogue of
     // msmChunkedG1/G2 (icicle.go:362-467); partial results are added on the host.  Never needed up to 2^26 points.
     size_t max_chunk = ((size_t)1 << 31) / (size_t)(win_hi - win_lo) - 1;
-    if (const char* cap = getenv("GA_MSM_MAX_CHUNK")) {   // test hook, like ICICLE's chunk-cap override (icicle.go:577-584)
-        size_t v = strtoull(cap, nullptr, 10);
-        if (v > 0 && v < max_chunk) max_chunk = v;
-    }
+    if (ctx->tun.msm_max_chunk > 0 && ctx->tun.msm_max_chunk < max_chunk)   // GA_MSM_MAX_CHUNK, like ICICLE's chunk-cap override (icicle.go:577-584)
+        max_chunk = (size_t)ctx->tun.msm_max_chunk;
     std::vector<XYZZ<F>> W(win_hi - win_lo, xyzz_inf<F>());
     for (size_t done = 0; done < n || n == 0; ) {
         const size_t cn = n - done < max_chunk ? n - done : max_chunk;
@@ -161,9 +163,17 @@ int ga_ctx_create(int device, ga_ctx** out) {
     GA_HIP_CHECK(hipSetDevice(device));
     Ctx* c = new Ctx();
     c->device = device;
-    GA_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    GA_HIP_CHECK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-    GA_HIP_CHECK(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+    hipStream_t* slots[3] = {&c->stream, &c->copy_stream, &c->aux_stream};
+    for (int k = 0; k < 3; k++) {
+        hipError_t se = hipStreamCreateWithFlags(slots[k], hipStreamNonBlocking);
+        if (se != hipSuccess) {
+            set_error("hipStreamCreate failed: %s", hipGetErrorString(se));
+            for (int q = 0; q < k; q++) hipStreamDestroy(*slots[q]);
+            delete c;
+            return GA_ERR_HIP;
+        }
+    }
+    c->tun.read_env();
     *out = reinterpret_cast<ga_ctx*>(c);
     return GA_OK;
 }

@@ -12,7 +12,7 @@
 #include <vector>
 
 #include "../../include/gnark_amd.h"
-#include "ec.cuh"
+#include "ec.hip.h"
 
 namespace ga {
 
@@ -77,8 +77,20 @@ struct StageRec {
     hipEvent_t a, b;
 };
 
+// Run-time knobs, read from the environment ONCE per ABI entry point (Lock's constructor), never inside the launch paths:
+//   GA_MSM_MAX_CHUNK      split an MSM along the point axis into chunks of at most this many points (msmChunkedG1/G2 analogue)
+//   GA_REDUCE_LAZY_MIN    bucket count from which the window reduction runs in the lazy representation
+//   GA_G16_SHARE_MIN_PCT  a Groth16 base vector shares the single witness sort when it covers at least this % of the wires
+struct Tunables {
+    uint64_t msm_max_chunk = 0;          // 0 = only the 2^31 pair-space limit
+    uint64_t reduce_lazy_min = 1u << 14;
+    int g16_share_min_pct = 90;
+    void read_env();
+};
+
 struct Ctx {
     int device = 0;
+    Tunables tun;
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;   // uploads that overlap kernels (groth16.hip)
     hipStream_t aux_stream = nullptr;    // digit/sort preparation of the NEXT MSM while the current one accumulates
@@ -90,6 +102,16 @@ struct Ctx {
 
     int scratch_get(const char* key, size_t bytes, void** out);
     void scratch_free_all();
+};
+
+// every ABI entry point: take the context's mutex (one proof at a time per device, icicle.go:821-823), select its device (HIP's
+// current device is per OS thread and goroutines migrate) and refresh the run-time knobs
+struct CtxLock {
+    std::lock_guard<std::mutex> g;
+    explicit CtxLock(Ctx* c) : g(c->mu) {
+        hipSetDevice(c->device);
+        c->tun.read_env();
+    }
 };
 
 struct StageTimer {
@@ -149,7 +171,7 @@ struct MsmPrepared {
 
 template <class C, int G>
 int msm_table_build(Ctx* ctx, const void* d_bases, size_t n, int c, void* d_table);
-// bytes per table entry: tables are stored unpacked (field29.cuh: 29/28-bit limbs, one per word, padded to 16 B)
+// bytes per table entry: tables are stored unpacked (field29.hip.h: 29/28-bit limbs, one per word, padded to 16 B)
 template <class C, int G>
 size_t msm_table_point_bytes();
 template <class C, int G>
@@ -163,7 +185,7 @@ int msm_prepare_table_scalars(Ctx* ctx, const void* d_scalars, size_t n, bool sc
 template <class C, int G>
 int msm_table_device_reuse(Ctx* ctx, const void* d_table, const MsmPrepared& P, void* h_sum);
 
-struct Domain;   // ntt.cuh
+struct Domain;   // ntt.hip.h
 template <class C> int ntt_domain_new(Ctx* ctx, uint64_t n, Domain** out);
 template <class C> int ntt_domain_fft(Domain* d, void* d_data, int direction, int decimation, int on_coset);
 template <class C> int ntt_domain_compute_h(Domain* d, void* d_a, void* d_b, void* d_c);
@@ -174,7 +196,7 @@ int ntt_domain_curve(const Domain* d);
 uint64_t ntt_domain_size(const Domain* d);
 Ctx* ntt_domain_ctx(const Domain* d);
 
-// PLONK quotient / grand product on device (plonk.cuh)
+// PLONK quotient / grand product on device (plonk.hip.h)
 constexpr int PLONK_MAX_BSB = 16;
 constexpr int PLONK_NB_FIXED = 12;   // L R O Z Ql Qr Qm Qo Qk S1 S2 S3 (plonk prove.go:44-59; ZS is Z shifted by one)
 struct PlonkQuotientArgs {
@@ -185,7 +207,7 @@ struct PlonkQuotientArgs {
     const void *bl, *br, *bo, *bz;   // blinding polynomials: 2, 2, 2, 3 coefficients
     const void *alpha, *beta, *gamma;
 };
-struct PlonkFixed;   // plonk.cuh: the circuit-constant coset evaluations pinned in HBM
+struct PlonkFixed;   // plonk.hip.h: the circuit-constant coset evaluations pinned in HBM
 template <class C> int plonk_domain_quotient(Domain* d0, Domain* d1, const PlonkQuotientArgs& args, void* h_out);
 template <class C> int plonk_domain_fixed_create(Domain* d0, Domain* d1, const PlonkQuotientArgs& args, PlonkFixed** out);
 template <class C> int plonk_domain_quotient_pinned(PlonkFixed* fx, const PlonkQuotientArgs& args, void* h_out);

@@ -6,7 +6,7 @@
 // ZZ^3 = ZZZ^2): a mixed addition costs 8M+2S and the formulas below are made complete by branching on
 // P == 0 (doubling / inverse), which DummySetup-style keys with identical bases need (setup.go:526-540).
 #pragma once
-#include "field.cuh"
+#include "field.hip.h"
 
 namespace ga {
 

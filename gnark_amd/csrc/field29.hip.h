@@ -9,7 +9,7 @@
 // modular correction: values are only kept below 2^(NL*L - 2), far above p (7 spare bits for BN254, 11 for BLS12-381),
 // by adding fixed multiples of p on subtraction.  Exact reduction happens once, when a result leaves the hot loop.
 #pragma once
-#include "ec.cuh"
+#include "ec.hip.h"
 
 namespace ga {
 
@@ -121,50 +121,14 @@ GA_HD F29<P> f29_sub_wide(const F29<P>& a, const F29<P>& b) {
 }
 
 // a*b / 2^(NL*L) (+ a multiple of p): normalized limbs in, normalized limbs out; result < a*b/2^(NL*L) + p.
-// Default: column accumulators (the compiler keeps independent per-column MAD chains and merges the carries).
-// GA_F29_CHAINED=1 selects product scanning with ONE running accumulator kept opaque between columns (saves ~9 64-bit adds
-// per product); measured on MI355X it is no faster for the 9-limb fields and 13x slower for the 14-limb field (the serial
-// 392-MAD chain spills), so it stays off.
-#ifndef GA_F29_CHAINED
-#define GA_F29_CHAINED 0
-#endif
-#if defined(__HIP_DEVICE_COMPILE__)
-#define GA_OPAQUE64(x) asm volatile("" : "+v"(x))
-#else
-#define GA_OPAQUE64(x) asm volatile("" : "+r"(x))
-#endif
+// Column accumulators: the compiler keeps independent per-column MAD chains and merges the carries.  (Product scanning with one
+// running accumulator was measured in round 1: no faster for the 9-limb fields, 13x slower for the 14-limb field -- dropped.)
 template <class P>
 GA_HD_BIG F29<P> f29_mul(const F29<P>& a, const F29<P>& b) {
     typedef Radix<P> R;
     constexpr int NL = R::NL, L = R::L;
     const uint32_t inv = P::INV & R::MASK;
     F29<P> r;
-#if GA_F29_CHAINED
-    uint32_t ml[NL];
-    uint64_t acc = 0;
-#pragma unroll
-    for (int k = 0; k < 2 * NL - 1; k++) {
-#pragma unroll
-        for (int i = 0; i < NL; i++) {
-            const int j = k - i;
-            if (j >= 0 && j < NL) acc += (uint64_t)a.l[i] * b.l[j];
-        }
-#pragma unroll
-        for (int i = 0; i < NL; i++) {
-            const int j = k - i;
-            if (j >= 1 && j < NL) acc += (uint64_t)ml[i] * mod_limb<P>(j);   // j >= 1: i < k, so m_i is known
-        }
-        if (k < NL) {
-            ml[k] = ((uint32_t)acc * inv) & R::MASK;
-            acc += (uint64_t)ml[k] * mod_limb<P>(0);   // clears the low L bits
-        } else {
-            r.l[k - NL] = (uint32_t)acc & R::MASK;
-        }
-        acc >>= L;
-        GA_OPAQUE64(acc);
-    }
-    r.l[NL - 1] = (uint32_t)acc;
-#else
     uint64_t col[2 * NL];
 #pragma unroll
     for (int k = 0; k < 2 * NL; k++) col[k] = 0;
@@ -188,7 +152,6 @@ GA_HD_BIG F29<P> f29_mul(const F29<P>& a, const F29<P>& b) {
             r.l[k] = (uint32_t)col[NL + k];
         }
     }
-#endif
     return r;
 }
 
@@ -378,28 +341,15 @@ template <int K, int W, class P> GA_HD F29x2<P> f29_sub_wide(const F29x2<P>& a, 
 template <class P> GA_HD F29x2<P> f29_partial_reduce(const F29x2<P>& a) { return {f29_partial_reduce(a.c0), f29_partial_reduce(a.c1)}; }
 template <class P> GA_HD bool f29_is_zero_limbs(const F29x2<P>& a) { return f29_is_zero_limbs(a.c0) & f29_is_zero_limbs(a.c1); }
 
-// Karatsuba; requires component sums < 2^(NL*L) (bounds: DESIGN.md "lazy bounds")
-// Fp2 product.  GA_FP2_LAZY (9-limb fields): Karatsuba on the UNREDUCED product columns -- three limb products, the
-// combinations  a0*b0 - a1*b1 + Z  and  (a0+a1)(b0+b1) - a0*b0 - a1*b1  formed column by column in 64-bit arithmetic, then
-// TWO Montgomery reductions instead of three (405 instead of 486 v_mad_u64_u32, and none of the five limb-wise add/sub
-// sweeps of the reduced-operand version).  The imaginary part's columns are sums of non-negative terms a0_i*b1_j + a1_i*b0_j;
-// the real part needs the offset Z = P::FP2Z, a multiple of p written with redundant digits so that every column dominates the
-// matching column of a1*b1 for operands below FP2Z_K*p (tools/gen_constants.py; bounds in tools/lazy_bounds.py).
-// Operand-sum limbs are < 2^(L+1): NL * 2^(2L+2) < 2^64.
-#ifndef GA_FP2_LAZY
-#define GA_FP2_LAZY 2
-#endif
-#ifndef GA_FP2_LAZY_MAX_NL
-#define GA_FP2_LAZY_MAX_NL 14
-#endif
+// Fp2 product, schoolbook on unreduced columns: real part a0*b0 + (K*p - a1)*b1, imaginary part a0*b1 + a1*b0 -- every term is
+// non-negative, so there is no 64-bit subtraction (a v_sub_co/v_subb pair costs more than a multiply on gfx950) and only two
+// column sets are live; 4*NL^2 limb products + 2 reductions.  K = P::FP2Z_K (operands below K*p; bounds in tools/lazy_bounds.py).
+// Measured against it in round 1 and dropped: Karatsuba on the unreduced columns (fewer multiplies, 51 64-bit subtractions:
+// slower) and Karatsuba on reduced operands (three reductions and five limb-wise sweeps).
 template <class P>
 GA_HD_BIG F29x2<P> f29_mul(const F29x2<P>& a, const F29x2<P>& b) {
     typedef Radix<P> R;
     constexpr int NL = R::NL;
-    if constexpr (GA_FP2_LAZY == 2 && NL <= GA_FP2_LAZY_MAX_NL) {
-        // schoolbook on unreduced columns: real part a0*b0 + (K*p - a1)*b1, imaginary part a0*b1 + a1*b0 -- every term is
-        // non-negative, so there is no 64-bit subtraction (a v_sub_co/v_subb pair costs more than a multiply on gfx950) and
-        // only two column sets are live; 324 limb products + 2 reductions
         constexpr int K = P::FP2Z_K;
         F29<P> n1;
 #pragma unroll
@@ -433,33 +383,6 @@ GA_HD_BIG F29x2<P> f29_mul(const F29x2<P>& a, const F29x2<P>& b) {
             r.c1 = f29_reduce_cols<P>(c1);
         }
         return r;
-    } else if constexpr (GA_FP2_LAZY == 1 && NL <= 9) {
-        uint64_t c0[2 * NL], c1[2 * NL], cs[2 * NL];
-#pragma unroll
-        for (int k = 0; k < 2 * NL; k++) c0[k] = c1[k] = cs[k] = 0;
-#pragma unroll
-        for (int i = 0; i < NL; i++)
-#pragma unroll
-            for (int j = 0; j < NL; j++) {
-                c0[i + j] += (uint64_t)a.c0.l[i] * b.c0.l[j];
-                c1[i + j] += (uint64_t)a.c1.l[i] * b.c1.l[j];
-                cs[i + j] += (uint64_t)(a.c0.l[i] + a.c1.l[i]) * (b.c0.l[j] + b.c1.l[j]);
-            }
-#pragma unroll
-        for (int k = 0; k < 2 * NL - 1; k++) {
-            cs[k] = cs[k] - c0[k] - c1[k];
-            c0[k] = c0[k] + P::FP2Z[k] - c1[k];
-        }
-        F29x2<P> r;
-        r.c0 = f29_reduce_cols<P>(c0);
-        r.c1 = f29_reduce_cols<P>(cs);
-        return r;
-    } else {
-        F29<P> v0 = f29_mul(a.c0, b.c0);
-        F29<P> v1 = f29_mul(a.c1, b.c1);
-        F29<P> s = f29_mul(f29_add(a.c0, a.c1), f29_add(b.c0, b.c1));
-        return {f29_sub<2>(v0, v1), f29_sub<4>(s, f29_add(v0, v1))};
-    }
 }
 // complex squaring: (a0+a1)(a0-a1) + 2 a0 a1 u
 template <class P>
@@ -521,9 +444,6 @@ GA_HD_BIG F29x2<P> f29_mul_sub(const F29x2<P>& a, const F29x2<P>& b, const F29x2
 
 template <class P>
 GA_HD_BIG F29<P> f29_sqr(const F29<P>& a) {
-#if GA_F29_CHAINED
-    return f29_mul(a, a);
-#else
     // a_i*a_j (i<j) computed once against the doubled limb: NL(NL+1)/2 products instead of NL^2 (45 vs 81 for 9 limbs).
     // Doubled limbs stay below 2^(L+1), a column holds at most NL/2 doubled products + one square + the NL reduction
     // products: < 2^(2L+1) * NL < 2^63 for both limb layouts.
@@ -560,7 +480,6 @@ GA_HD_BIG F29<P> f29_sqr(const F29<P>& a) {
         }
     }
     return r;
-#endif
 }
 
 // ---- uniform view used by the table kernels: Lazy<Fe<P>> / Lazy<Fe2<P>> ------------------------------------------------

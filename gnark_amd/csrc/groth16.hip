@@ -9,8 +9,8 @@
 #include <string>
 #include <thread>
 
-#include "hostops.cuh"
-#include "keyio.cuh"
+#include "hostops.hip.h"
+#include "keyio.hip.h"
 
 namespace ga {
 
@@ -36,7 +36,7 @@ struct G16Pk {
     uint64_t len_k_remove = 0;
     std::vector<void*> d_ck_basis, d_ck_sigma;   // pinned pedersen keys (setup.go:260-287, icicle.go:231-261)
     std::vector<uint64_t> ck_len;
-    // precomputed window-multiple tables (msm.cuh): d_a.. then point to windows x len points and c_* is the window width
+    // precomputed window-multiple tables (msm.hip.h): d_a.. then point to windows x len points and c_* is the window width
     bool tables = false;
     int c_a = 0, c_b = 0, c_z = 0, c_k = 0;
     // Wire-indexed tables: when a base vector covers (almost) every wire, its table is laid out by WIRE id with (0,0) at the
@@ -293,8 +293,7 @@ static int stage_finish(G16Stage* st, int precompute, G16Pk** out) {
         const size_t t1 = msm_table_point_bytes<C, GA_G1>(), t2 = msm_table_point_bytes<C, GA_G2>();
         // share the witness sort between the vectors that cover at least GA_G16_SHARE_MIN_PCT % of the wires (default 90: a
         // sparse vector would make the lanes of the bucket kernel idle on its missing wires, and waste table memory)
-        int share_pct = 90;
-        if (const char* e = getenv("GA_G16_SHARE_MIN_PCT")) share_pct = atoi(e);
+        const int share_pct = ctx->tun.g16_share_min_pct;
         auto dense = [&](uint64_t len) {
             return pk->shard_count == 1 && pk->nb_wires < (1ull << 27) && len > 0 && (double)len * 100.0 >= (double)pk->nb_wires * share_pct;
         };
@@ -340,13 +339,20 @@ static int stage_finish(G16Stage* st, int precompute, G16Pk** out) {
                     set_error("proving key: hipMalloc of a wire-indexed base array failed");
                     return GA_ERR_NOMEM;
                 }
-                GA_HIP_CHECK(hipMemsetAsync(wide_arr, 0, pk->nb_wires * psz, ctx->stream));
+                hipError_t we = hipMemsetAsync(wide_arr, 0, pk->nb_wires * psz, ctx->stream);
                 const uint32_t chunks = (uint32_t)(psz / 16);
                 const uint64_t threads = len * chunks;
-                hipLaunchKernelGGL(g16_scatter_points_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream,
-                                   (u32x4*)wide_arr, (const u32x4*)*slot, d_idx, len, chunks);
-                GA_KERNEL_CHECK();
-                GA_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+                if (we == hipSuccess) {
+                    hipLaunchKernelGGL(g16_scatter_points_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream,
+                                       (u32x4*)wide_arr, (const u32x4*)*slot, d_idx, len, chunks);
+                    we = hipGetLastError();
+                }
+                if (we == hipSuccess) we = hipStreamSynchronize(ctx->stream);
+                if (we != hipSuccess) {
+                    set_error("proving key: building a wire-indexed base array failed: %s", hipGetErrorString(we));
+                    hipFree(wide_arr);
+                    return GA_ERR_HIP;
+                }
                 hipFree(*slot);
                 *slot = wide_arr;
                 return GA_OK;
@@ -475,7 +481,7 @@ static int pk_create_from_struct(Ctx* ctx, const ga_g16_key* key, G16Pk** out) {
 }
 
 
-// ---- key files -> staged key (keyio.cuh has the formats) --------------------------------------------------------------------------
+// ---- key files -> staged key (keyio.hip.h has the formats) --------------------------------------------------------------------------
 // `count` encoded points of group G from `src`: decoded on the device, the part inside [keep_lo, keep_lo + keep_cnt) lands at d_dst
 template <class C, int G>
 static int decode_stream(Ctx* ctx, Staging& sg, ByteSource& src, uint64_t count, bool compressed, void* d_dst, uint64_t keep_lo,
@@ -1355,6 +1361,7 @@ static int prove_multi(G16Pk* const* pks, uint32_t n, const void* w, const void*
         G16Pk* pk = pks[t];
         Ctx* ctx = pk->ctx;
         std::lock_guard<std::mutex> g(ctx->mu);   // one proof at a time per device (icicle.go:821-823)
+        ctx->tun.read_env();
         auto bail = [&](const char* what) { sh.fail((std::string(what) + ": " + get_error()).c_str()); };
         bool ok = hipSetDevice(ctx->device) == hipSuccess;
         if (!ok) set_error("hipSetDevice(%d) failed", ctx->device);
@@ -1476,8 +1483,7 @@ int ga_g16_pk_create(ga_ctx* h, const ga_g16_key* key, ga_g16_pk** out) {
         set_error("ga_g16_pk_create: null argument");
         return GA_ERR_INVALID;
     }
-    std::lock_guard<std::mutex> g(ctx->mu);
-    hipSetDevice(ctx->device);
+    CtxLock g(ctx);
     G16Pk* pk = nullptr;
     GA_CHECK(pk_create_from_struct(ctx, key, &pk));
     *out = reinterpret_cast<ga_g16_pk*>(pk);
@@ -1513,8 +1519,7 @@ int ga_g16_builder_create(ga_ctx* h, int curve, uint64_t domain_cardinality, uin
         set_error("ga_g16_builder: null builder");      \
         return GA_ERR_INVALID;                          \
     }                                                   \
-    std::lock_guard<std::mutex> g(st->ctx->mu);         \
-    hipSetDevice(st->ctx->device)
+    CtxLock g(st->ctx)
 
 int ga_g16_builder_reserve(ga_g16_builder* b, int which, uint64_t total_len) {
     GA_STAGE(b);
@@ -1580,8 +1585,7 @@ int ga_g16_builder_finish(ga_g16_builder* b, int32_t precompute, ga_g16_pk** out
     }
     int rc;
     {
-        std::lock_guard<std::mutex> g(st->ctx->mu);
-        hipSetDevice(st->ctx->device);
+        CtxLock g(st->ctx);
         G16Pk* pk = nullptr;
         rc = GA_ERR_INVALID;
         if (st->curve == GA_BN254) rc = stage_finish<Bn254>(st, precompute, &pk);
@@ -1596,8 +1600,7 @@ void ga_g16_builder_destroy(ga_g16_builder* b) {
     G16Stage* st = reinterpret_cast<G16Stage*>(b);
     if (!st) return;
     Ctx* ctx = st->ctx;
-    std::lock_guard<std::mutex> g(ctx->mu);
-    hipSetDevice(ctx->device);
+    CtxLock g(ctx);
     hipStreamSynchronize(ctx->stream);
     delete st;
 }
@@ -1605,8 +1608,7 @@ void ga_g16_builder_destroy(ga_g16_builder* b) {
 void ga_g16_pk_destroy(ga_g16_pk* p) {
     G16Pk* pk = reinterpret_cast<G16Pk*>(p);
     if (!pk) return;
-    std::lock_guard<std::mutex> g(pk->ctx->mu);
-    hipSetDevice(pk->ctx->device);
+    CtxLock g(pk->ctx);
     hipStreamSynchronize(pk->ctx->stream);
     pk_free(pk);
 }
@@ -1618,8 +1620,7 @@ int ga_g16_prove(ga_g16_pk* p, const void* w, const void* a, const void* b, cons
         set_error("ga_g16_prove: null argument");
         return GA_ERR_INVALID;
     }
-    std::lock_guard<std::mutex> g(pk->ctx->mu);
-    hipSetDevice(pk->ctx->device);
+    CtxLock g(pk->ctx);
     if (pk->shard_count != 1 || pk->win_count != 1) {
         set_error("ga_g16_prove: this key holds one share of a sharded key (base range %u/%u, windows %u/%u); use ga_g16_prove_multi or "
                   "ga_g16_prove_partial + ga_g16_finish", pk->shard_index, pk->shard_count, pk->win_index, pk->win_count);
@@ -1641,8 +1642,7 @@ int ga_g16_prove_partial(ga_g16_pk* p, const void* w, const void* a, const void*
         set_error("ga_g16_prove_partial: null argument");
         return GA_ERR_INVALID;
     }
-    std::lock_guard<std::mutex> g(pk->ctx->mu);
-    hipSetDevice(pk->ctx->device);
+    CtxLock g(pk->ctx);
     GA_DISPATCH_CURVE(pk->curve, {
         typedef Fe<typename C::FpP> F1;
         typedef Fe2<typename C::FpP> F2;
@@ -1699,8 +1699,7 @@ int ga_g16_witness_partial(ga_g16_pk* p, const void* w, uint64_t nb_public, void
         set_error("ga_g16_witness_partial: null argument");
         return GA_ERR_INVALID;
     }
-    std::lock_guard<std::mutex> g(pk->ctx->mu);
-    hipSetDevice(pk->ctx->device);
+    CtxLock g(pk->ctx);
     GA_DISPATCH_CURVE(pk->curve, {
         typedef Fe<typename C::FpP> F1;
         typedef Fe2<typename C::FpP> F2;
@@ -1723,8 +1722,7 @@ int ga_g16_h_chain(ga_g16_pk* p, const void* v, uint64_t n_constraints, void* ou
         set_error("ga_g16_h_chain: null argument");
         return GA_ERR_INVALID;
     }
-    std::lock_guard<std::mutex> g(pk->ctx->mu);
-    hipSetDevice(pk->ctx->device);
+    CtxLock g(pk->ctx);
     GA_CHECK(h_upload(pk, v, n_constraints, out_dev, pk->ctx->stream));
     GA_DISPATCH_CURVE(pk->curve, GA_CHECK(ntt_domain_h_chain<C>(pk->dom, out_dev)));
     GA_HIP_CHECK(hipStreamSynchronize(pk->ctx->stream));   // the buffer is handed to another stream / device next
@@ -1737,8 +1735,7 @@ int ga_g16_h_combine(ga_g16_pk* p, void* a_dev, const void* b_dev, const void* c
         set_error("ga_g16_h_combine: null argument");
         return GA_ERR_INVALID;
     }
-    std::lock_guard<std::mutex> g(pk->ctx->mu);
-    hipSetDevice(pk->ctx->device);
+    CtxLock g(pk->ctx);
     GA_DISPATCH_CURVE(pk->curve, GA_CHECK(ntt_domain_h_combine<C>(pk->dom, a_dev, b_dev, c_dev)));
     GA_HIP_CHECK(hipStreamSynchronize(pk->ctx->stream));
     return GA_OK;
@@ -1750,8 +1747,7 @@ int ga_g16_z_partial(ga_g16_pk* p, const void* h_slice_dev, void* partial_out) {
         set_error("ga_g16_z_partial: null argument");
         return GA_ERR_INVALID;
     }
-    std::lock_guard<std::mutex> g(pk->ctx->mu);
-    hipSetDevice(pk->ctx->device);
+    CtxLock g(pk->ctx);
     GA_DISPATCH_CURVE(pk->curve, {
         typedef Fe<typename C::FpP> F1;
         XYZZ<F1> z;
@@ -1802,8 +1798,7 @@ static int pk_read_any(ga_ctx* h, int curve, ByteSource& src, int32_t precompute
         set_error("ga_g16_pk_read: null argument");
         return GA_ERR_INVALID;
     }
-    std::lock_guard<std::mutex> g(ctx->mu);
-    hipSetDevice(ctx->device);
+    CtxLock g(ctx);
     G16Pk* pk = nullptr;
     GA_DISPATCH_CURVE(curve, GA_CHECK(pk_read<C>(ctx, src, precompute, shard_index, shard_count, k_remove, len_k_remove, &pk)));
     *out = reinterpret_cast<ga_g16_pk*>(pk);
@@ -1846,8 +1841,7 @@ int ga_g16_key_write_fd(ga_ctx* h, const ga_g16_key* key, int format, int fd, ui
         set_error("ga_g16_key_write_fd: null pointer inside ga_g16_key");
         return GA_ERR_INVALID;
     }
-    std::lock_guard<std::mutex> g(ctx->mu);
-    hipSetDevice(ctx->device);
+    CtxLock g(ctx);
     ByteSink dst;
     dst.fd = fd;
     GA_DISPATCH_CURVE(key->curve, GA_CHECK(key_write<C>(ctx, key, format, dst)));
@@ -1948,8 +1942,7 @@ int ga_g16_commit(ga_g16_pk* p, uint32_t index, const void* values, uint64_t n_v
         set_error("ga_g16_commit: null argument");
         return GA_ERR_INVALID;
     }
-    std::lock_guard<std::mutex> g(pk->ctx->mu);
-    hipSetDevice(pk->ctx->device);
+    CtxLock g(pk->ctx);
     GA_DISPATCH_CURVE(pk->curve, return commit<C>(pk, index, values, n_values, commitment_out, pok_out));
     return GA_OK;
 }

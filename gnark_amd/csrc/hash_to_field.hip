@@ -2,12 +2,13 @@
 //
 // Used by the BSB22 commitment flow around the device MSMs: the solver hint turns a commitment point into a field element
 // with hash_to_field.New("bsb22-commitment") (backend/groth16/bn254/prove.go:57-58,88-98) and the PoK fold challenge is
-// fr.Hash(commitments, "G16-BSB22", 1) (prove.go:118-127).  gnark-crypto is not in the reference tree; the element-level code
+// fr.Hash(m, "G16-BSB22", 1) where m is the concatenation of the commitment WIRE VALUES sol.W[CommitmentIndex].Marshal() -- 32-byte
+// big-endian fr elements, NOT the commitment points (prove.go:118-127).  gnark-crypto is not in the reference tree; the element-level code
 // shape is visible in internal/smallfields/tinyfield/element.go:456-481 (L = 16 + Bytes pseudo-random bytes per element,
 // big-endian, reduced mod r) and expand_message_xmd is RFC 9380 section 5.3.1, pinned by the 16 vectors of
 // std/hash/expand/expand_test.go:52-140 (tests/test_oracle_fixtures.py).  A Go host would keep calling gnark-crypto; this
 // file exists so that a C/C++ host of the library can run the whole commitment flow.
-#include "common.cuh"
+#include "common.hip.h"
 
 namespace ga {
 

@@ -3,7 +3,7 @@
 // multiplications and additions per proof, which the reference also keeps on the CPU
 // (icicle.go:1096-1097,1144-1146,1249-1259,1309-1314).
 #pragma once
-#include "common.cuh"
+#include "common.hip.h"
 
 namespace ga {
 

@@ -27,7 +27,7 @@
 #include <errno.h>
 #include <unistd.h>
 
-#include "hostops.cuh"
+#include "hostops.hip.h"
 
 namespace ga {
 

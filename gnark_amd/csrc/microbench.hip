@@ -1,8 +1,8 @@
 // Issue-rate microbenchmarks for the integer / FP64 instructions a big-integer multiplier can be built from on
 // gfx950 ("microbenchmark v_mad_u64_u32 issue rate and report achieved MAD/s fraction"), plus the
 // achieved throughput of this library's own Montgomery multiplication.
-#include "common.cuh"
-#include "field29.cuh"
+#include "common.hip.h"
+#include "field29.hip.h"
 
 namespace ga {
 

@@ -24,41 +24,12 @@
 
 #include <string>
 
-#include "common.cuh"
-#include "field29.cuh"
+#include "common.hip.h"
+#include "field29.hip.h"
 
 namespace ga {
 
-#ifndef GA_ACC_MINW_SMALL
-#define GA_ACC_MINW_SMALL 4   // BN254 G1 (XYZZ = 128 B)
-#endif
-#ifndef GA_ACC_MINW_MID
-#define GA_ACC_MINW_MID 2     // BN254 G2 (256 B), BLS12-381 G1 (192 B)
-#endif
-#ifndef GA_ACC_MINW_BIG
-#define GA_ACC_MINW_BIG 2     // BLS12-381 G2 (384 B), 128-thread workgroups
-#endif
-#ifndef GA_ACC29_MINW
-#define GA_ACC29_MINW 4       // lazy-representation table kernel (G1)
-#endif
-#ifndef GA_ACC29_TOUCH
-#define GA_ACC29_TOUCH 0      // 1: touch the next table entry one addition ahead (L2 prefetch); measured -3 % with the final loop
-#endif
-#ifndef GA_ACC_TOUCH
-#define GA_ACC_TOUCH 0        // raw-bases kernel: 1 = touch the next base one addition ahead (measured -3 %)
-#endif
-#ifndef GA_RAW_LAZY
-#define GA_RAW_LAZY 1         // raw-bases MSM: convert the bases once per call and use the lazy bucket kernel
-#endif
-#ifndef GA_ACC29_PIPELINE
-#define GA_ACC29_PIPELINE 0   // 1: load the next table entry into registers one addition ahead
-#endif
-#ifndef GA_ACC_LDS_BYTES
-#define GA_ACC_LDS_BYTES 128  // accumulators of at least this many bytes live in LDS (all groups; measured best)
-#endif
-#ifndef GA_REDUCE_LAZY
-#define GA_REDUCE_LAZY 1      // window reduction of large bucket sets in the lazy representation (msm_reduce_groups29_kernel)
-#endif
+constexpr int GA_ACC29_MINW = 4;      // waves per SIMD requested for the G1 bucket kernel (2 for Fp2 points: 72 KiB of LDS per workgroup)
 constexpr uint32_t MSM_SIGN = 0x80000000u;
 constexpr int MSM_HOT_TASKS = 16;     // buckets with more partials than this go to the wave-parallel merge
 constexpr int MSM_GROUP = 32;         // buckets per running-sum group in the window reduction
@@ -71,6 +42,12 @@ __global__ void msm_digits_kernel(const uint32_t* __restrict__ scalars, uint64_t
     if (i >= n) return;
     Fe<FrP> s = load_fe<FrP>(scalars + i * 8);
     if (mont) s = from_mont(s);
+    else {
+        // canonical input may be any 256-bit integer (a caller's big.Int bytes): bring it below r, at most 2^256 / r < 6 steps,
+        // so that only (BITS mod c) bits are live in the top window as the digit loop assumes
+#pragma unroll 1
+        for (int k = 0; k < 6; k++) reduce_once<FrP>(s.l);
+    }
     const uint32_t half = 1u << (c - 1);
     const uint32_t mask = (1u << c) - 1;
     // table mode: every window shares ONE bucket set and the value indexes the precomputed table [window][point]
@@ -144,130 +121,8 @@ static __global__ void msm_task_list_kernel(const uint32_t* __restrict__ off, co
     }
 }
 
-// ---- 4. accumulate --------------------------------------------------------------------------------
-// minimum waves per SIMD requested from the register allocator, by point size (tuned on MI355X):
-// the bucket loop is a long dependent chain of v_mad_u64_u32, so it needs >= 2 resident waves per SIMD to stay busy.
-template <class F> struct AccumulateTuning {
-    static constexpr int MIN_WAVES = sizeof(XYZZ<F>) <= 128 ? GA_ACC_MINW_SMALL : (sizeof(XYZZ<F>) <= 256 ? GA_ACC_MINW_MID : GA_ACC_MINW_BIG);
-    // workgroup size: the LDS-resident accumulators of one workgroup must leave room for >= 2 workgroups per CU
-    static constexpr int THREADS = sizeof(XYZZ<F>) <= 256 ? 256 : 128;
-};
-
-// Accumulator kept in LDS, word-major ([word][lane]: conflict-free) -- used for the Fp2 points, whose XYZZ accumulator
-// (256 / 384 B per lane) would otherwise be spilled to scratch by the register allocator at 2 waves per SIMD.
-template <class F>
-struct LdsAcc {
-    uint32_t* base;   // &lds[threadIdx.x], stride THREADS words
-    static constexpr int FW = sizeof(F) / 4;
-    static constexpr int STRIDE = AccumulateTuning<F>::THREADS;
-    __device__ __forceinline__ F get(int field) const {
-        F r;
-        uint32_t* w = reinterpret_cast<uint32_t*>(&r);
-#pragma unroll
-        for (int i = 0; i < FW; i++) w[i] = base[(field * FW + i) * STRIDE];
-        return r;
-    }
-    __device__ __forceinline__ void put(int field, const F& v) const {
-        const uint32_t* w = reinterpret_cast<const uint32_t*>(&v);
-#pragma unroll
-        for (int i = 0; i < FW; i++) base[(field * FW + i) * STRIDE] = w[i];
-    }
-};
-
-// acc (in LDS) += q   -- same formulas as madd_t<true>, loading accumulator coordinates only where they are consumed
-template <class F>
-__device__ __forceinline__ void madd_lds(const LdsAcc<F>& A, const Affine<F>& q) {
-    if (is_inf(q)) return;
-    F zz = A.get(2);
-    if (is_zero(zz)) {   // accumulator is infinity
-        A.put(0, q.x);
-        A.put(1, q.y);
-        A.put(2, FieldTraits<F>::one());
-        A.put(3, FieldTraits<F>::one());
-        return;
-    }
-    F U2 = mul_inl(q.x, zz);
-    F ax = A.get(0);
-    F Pp = sub(U2, ax);
-    F zzz = A.get(3);
-    F S2 = mul_inl(q.y, zzz);
-    F ay = A.get(1);
-    F R = sub(S2, ay);
-    if (is_zero(Pp)) {
-        XYZZ<F> d = is_zero(R) ? dbl_affine_t<true>(q) : xyzz_inf<F>();
-        A.put(0, d.x);
-        A.put(1, d.y);
-        A.put(2, d.zz);
-        A.put(3, d.zzz);
-        return;
-    }
-    F PP = sqr_body(Pp);
-    A.put(2, mul_inl(zz, PP));
-    F PPP = mul_inl(Pp, PP);
-    A.put(3, mul_inl(zzz, PPP));
-    F Q = mul_inl(ax, PP);
-    F X3 = sub(sub(sqr_body(R), PPP), dbl(Q));
-    A.put(0, X3);
-    A.put(1, sub(mul_inl(R, sub(Q, X3)), mul_inl(ay, PPP)));
-}
-
-template <class F>
-__global__ void __launch_bounds__(AccumulateTuning<F>::THREADS, AccumulateTuning<F>::MIN_WAVES)
-msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ vals,
-                      const uint32_t* __restrict__ task_start, const uint32_t* __restrict__ task_key_sorted,
-                      const uint32_t* __restrict__ task_perm, uint32_t max_tasks, uint32_t seg,
-                      const uint32_t* __restrict__ task_dest, XYZZ<F>* __restrict__ sums) {
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= max_tasks) return;
-    const uint32_t key = task_key_sorted[t];
-    if (key >= seg) return;              // padding slots (length 0) sort last
-    const uint32_t tid = task_perm[t];
-    const uint32_t start = task_start[tid];
-    const uint32_t end = start + (seg - key);
-    if constexpr (sizeof(XYZZ<F>) >= GA_ACC_LDS_BYTES) {
-        __shared__ uint32_t lds[sizeof(XYZZ<F>) / 4 * AccumulateTuning<F>::THREADS];
-        LdsAcc<F> A{lds + threadIdx.x};
-        A.put(2, FieldTraits<F>::zero());
-        uint32_t v = vals[start];
-        for (uint32_t p = start; p < end; p++) {
-            // touch the NEXT base now (one dword: pulls its cache line towards the CU while this addition runs);
-            // the gather over a multi-GiB table is otherwise a dependent HBM miss per addition
-            const uint32_t vn = p + 1 < end ? vals[p + 1] : v;
-            Affine<F> q = load_pod<Affine<F>>(&bases[v & ~MSM_SIGN]);
-            // issued AFTER the current point's loads: vector loads retire in order, so the waitcnt for q leaves this one in flight
-            const uint32_t touch = GA_ACC_TOUCH ? *reinterpret_cast<const volatile uint32_t*>(&bases[vn & ~MSM_SIGN]) : 0u;
-            if (v & MSM_SIGN) q.y = neg(q.y);
-            madd_lds(A, q);
-            GA_KEEP_LIVE(touch);
-            v = vn;
-        }
-        XYZZ<F> acc;
-        acc.zz = A.get(2);
-        if (is_zero(acc.zz)) acc = xyzz_inf<F>();
-        else {
-            acc.x = A.get(0);
-            acc.y = A.get(1);
-            acc.zzz = A.get(3);
-        }
-        store_pod(&sums[task_dest[tid]], acc);
-    } else {
-        XYZZ<F> acc = xyzz_inf<F>();
-        uint32_t v = vals[start];
-        for (uint32_t p = start; p < end; p++) {
-            const uint32_t vn = p + 1 < end ? vals[p + 1] : v;
-            Affine<F> q = load_pod<Affine<F>>(&bases[v & ~MSM_SIGN]);
-            const uint32_t touch = GA_ACC_TOUCH ? *reinterpret_cast<const volatile uint32_t*>(&bases[vn & ~MSM_SIGN]) : 0u;
-            if (v & MSM_SIGN) q.y = neg(q.y);
-            acc = madd_t<true>(acc, q);
-            GA_KEEP_LIVE(touch);
-            v = vn;
-        }
-        store_pod(&sums[task_dest[tid]], acc);
-    }
-}
-
-// ---- 4b. accumulate over a precomputed table in the unpacked ("29-bit limb") format, G1 ---------------------------
-// Table entry = hat(x) | hat(y) as NL limbs each (field29.cuh), padded to a multiple of 16 bytes; (0,0) = infinity.
+// ---- 4. accumulate over a table in the unpacked ("29-bit limb") format ---------------------------------------------------------
+// Table entry = hat(x) | hat(y) as NL limbs each (field29.hip.h), padded to a multiple of 16 bytes; (0,0) = infinity.
 // The bucket loop runs entirely in the lazy representation: per mixed addition 10 products of 2*NL^2 MADs + one
 // shift/mask per column, limb-wise add/sub with a carry sweep, no unpacking, no conditional subtractions.  The
 // exceptional cases of the addition law (doubling, P + (-P), accumulator at infinity) are not branched on: they all
@@ -379,26 +234,10 @@ msm_accumulate29_kernel(const uint32_t* __restrict__ table, const uint32_t* __re
     const T one = Lazy<F>::from_mem(FieldTraits<F>::one());
     bool have = false;
     uint32_t v = vals[start];
-#if GA_ACC29_PIPELINE
-    // the next table entry travels into registers (packed: WORDS dwords) while the current addition runs
-    Affine<F> nxt = load_pod<Affine<F>>(table + (uint64_t)(v & ~MSM_SIGN) * Table29<F>::WORDS);
-#endif
     for (uint32_t p = start; p < end; p++) {
         const uint32_t vn = p + 1 < end ? vals[p + 1] : v;
         T qx, qy;
-#if GA_ACC29_PIPELINE
-        qx = Lazy<F>::unpack(nxt.x);
-        qy = Lazy<F>::unpack(nxt.y);
-        nxt = load_pod<Affine<F>>(table + (uint64_t)(vn & ~MSM_SIGN) * Table29<F>::WORDS);
-        const uint32_t touch = 0;
-#else
         load_point29<F>(table, v & ~MSM_SIGN, qx, qy);
-#if GA_ACC29_TOUCH
-        const uint32_t touch = *reinterpret_cast<const volatile uint32_t*>(table + (uint64_t)(vn & ~MSM_SIGN) * Table29<F>::WORDS);
-#else
-        const uint32_t touch = 0;
-#endif
-#endif
         if (!(f29_is_zero_limbs(qx) & f29_is_zero_limbs(qy))) {   // (0,0) = infinity: skip
             if (v & MSM_SIGN) qy = f29_sub<2>(Lazy<F>::from_mem(FieldTraits<F>::zero()), qy);   // 2p - y
             if (!have) {
@@ -411,7 +250,6 @@ msm_accumulate29_kernel(const uint32_t* __restrict__ table, const uint32_t* __re
                 madd29<P>(A, qx, qy);
             }
         }
-        GA_KEEP_LIVE(touch);
         v = vn;
     }
     XYZZ<F> acc = xyzz_inf<F>();
@@ -839,8 +677,7 @@ int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, X
     // buckets per running-sum group: MSM_GROUP when there are plenty of buckets, smaller (down to 2) when a set has few so
     // that the reduction still spreads over >= 2^15 lanes (small n, or table mode's single bucket set)
     uint32_t m_groups = (uint32_t)MSM_GROUP;
-    uint64_t min_lanes = 32768;
-    if (const char* e = getenv("GA_REDUCE_MIN_LANES")) min_lanes = strtoull(e, nullptr, 10);   // experiments
+    const uint64_t min_lanes = 32768;
     while (m_groups > 2 && (uint64_t)half * nsets / m_groups < min_lanes) m_groups >>= 1;
     if (m_groups > half) m_groups = half;
     const uint32_t groups_per_win = half / m_groups;
@@ -871,9 +708,9 @@ int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, X
                            (const uint32_t*)P.vals, (const uint32_t*)P.task_start, (const uint32_t*)P.task_key_by_id, seg,
                            (const uint32_t*)redo_list, (const uint32_t*)redo_count, (const uint32_t*)P.task_dest, bsum);
         GA_KERNEL_CHECK();
-    } else if (GA_RAW_LAZY) {
+    } else {
         // raw (not precomputed) bases: one conversion pass to the packed hat-domain format (a one-window "table"), then the
-        // same lazy bucket kernel as the table path -- the exact packed kernel below costs ~1.5x more per addition
+        // same lazy bucket kernel as the table path (an exact packed-arithmetic kernel cost ~1.5x more per addition: dropped)
         uint32_t *hat, *redo_list, *redo_count;
         GA_CHECK(ctx->scratch_get("msm_hat_bases", (uint64_t)P.n * sizeof(Affine<F>) + 256, (void**)&hat));
         GA_CHECK(ctx->scratch_get("msm_redo", (P.max_tasks + 2) * 4, (void**)&redo_list));
@@ -890,13 +727,6 @@ int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, X
                            (const uint32_t*)P.vals, (const uint32_t*)P.task_start, (const uint32_t*)P.task_key_by_id, seg,
                            (const uint32_t*)redo_list, (const uint32_t*)redo_count, (const uint32_t*)P.task_dest, bsum);
         GA_KERNEL_CHECK();
-    } else {
-        StageTimer tm(ctx, "msm_accumulate");
-        constexpr unsigned AT = AccumulateTuning<F>::THREADS;
-        hipLaunchKernelGGL((msm_accumulate_kernel<F>), dim3((unsigned)((P.max_tasks + AT - 1) / AT)), dim3(AT), 0, st,
-                           (const Affine<F>*)d_bases, (const uint32_t*)P.vals, (const uint32_t*)P.task_start, (const uint32_t*)P.task_key,
-                           (const uint32_t*)P.task_perm, (uint32_t)P.max_tasks, seg, (const uint32_t*)P.task_dest, bsum);
-        GA_KERNEL_CHECK();
     }
     {
         StageTimer tm(ctx, "msm_merge");
@@ -910,9 +740,9 @@ int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, X
     //   set sum = sum_g lsum[g] + m * sum_b 2^b * T_b,   T_b = sum of rsum[g] over the groups whose index has bit b set,
     // the T_b being plain tree sums and the last line host arithmetic.  Tiny sets keep the exact kernel: empty buckets (which
     // the lazy formulas cannot add to themselves) are the rule there and every group would be redone.
-    uint64_t lazy_min = 1u << 14;   // buckets (measured: 2^20 points / 2^16 buckets 2.82 -> 2.53 ms); GA_REDUCE_LAZY_MIN overrides (tests use 0)
-    if (const char* e = getenv("GA_REDUCE_LAZY_MIN")) lazy_min = strtoull(e, nullptr, 10);
-    const bool lazy_reduce = GA_REDUCE_LAZY && (uint64_t)half * nsets >= lazy_min;
+    // buckets from which the lazy pass pays (measured: 2^20 points / 2^16 buckets 2.82 -> 2.53 ms); ctx->tun is read from the
+    // environment once per entry point (GA_REDUCE_LAZY_MIN: tests force the lazy path on sparse bucket sets with 0)
+    const bool lazy_reduce = (uint64_t)half * nsets >= ctx->tun.reduce_lazy_min;
     if (!lazy_reduce) {
         StageTimer tm(ctx, "msm_reduce");
         hipLaunchKernelGGL((msm_reduce_groups_kernel<F>), dim3((total_groups + 63) / 64), dim3(64), 0, st, (const XYZZ<F>*)bsum,

@@ -1,5 +1,5 @@
-// Explicit instantiation: Pippenger MSM, bn254 G1 (see msm.cuh).
-#include "msm.cuh"
+// Explicit instantiation: Pippenger MSM, bn254 G1 (see msm.hip.h).
+#include "msm.hip.h"
 namespace ga {
 template int msm_windows_device<Bn254, GA_G1>(Ctx*, const void*, const void*, size_t, bool, int, int, int, void*);
 template int msm_table_device<Bn254, GA_G1>(Ctx*, const void*, const void*, size_t, bool, int, void*, int, int);

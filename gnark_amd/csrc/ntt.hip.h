@@ -16,16 +16,13 @@
 //   * coset scaling and the 1/n factor are fused into the first / last pass (two small power tables:
 //     g^k for k < 2^12 and g^(k*2^12)), so OnCoset transforms cost no extra HBM pass.
 #pragma once
-#include "common.cuh"
-#include "field29.cuh"
+#include "common.hip.h"
+#include "field29.hip.h"
 #include <stdlib.h>
 
 namespace ga {
 
 constexpr int NTT_LG_TILE = 10;               // 1024 elements = 32 KiB of LDS per workgroup
-#ifndef GA_NTT_R4_DIF
-#define GA_NTT_R4_DIF 1   // radix-4 register blocking for the DIF passes too
-#endif
 constexpr int NTT_THREADS = 256;
 constexpr int NTT_POW_LO_BITS = 12;
 
@@ -75,97 +72,8 @@ __device__ __forceinline__ Fe<FrP> ntt_scale_factor(const NttScale& sc, uint64_t
     return mul(a, b);
 }
 
-template <class FrP>
-struct LdsTile {
-    u32x4* p0;
-    u32x4* p1;
-    __device__ __forceinline__ Fe<FrP> get(uint32_t l) const {
-        Fe<FrP> r;
-        u32x4 a = p0[l], b = p1[l];
-        r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
-        r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
-        return r;
-    }
-    __device__ __forceinline__ void put(uint32_t l, const Fe<FrP>& v) const {
-        u32x4 a, b;
-        a.x = v.l[0]; a.y = v.l[1]; a.z = v.l[2]; a.w = v.l[3];
-        b.x = v.l[4]; b.y = v.l[5]; b.z = v.l[6]; b.w = v.l[7];
-        p0[l] = a;
-        p1[l] = b;
-    }
-};
-
-// One pass over stages [s_lo, s_lo+K).  DIT_ = false: DIF butterflies, stages descending; true: DIT, ascending.
-template <class FrP, bool DIT_>
-__global__ void __launch_bounds__(NTT_THREADS)
-ntt_pass_kernel(uint32_t* data, const uint32_t* src, const uint32_t* __restrict__ tw, int logn, int lg_tile, int s_lo, int K,
-                int lc, NttScale pre, NttScale post) {
-    static_assert(FrP::N == 8, "Fr is 4x64-bit limbs on both curves");
-    __shared__ u32x4 lds[2 << NTT_LG_TILE];
-    LdsTile<FrP> T{lds, lds + (1 << NTT_LG_TILE)};
-    const uint32_t tile_elems = 1u << lg_tile;
-    const uint64_t tile = blockIdx.x;
-    const uint32_t tid = threadIdx.x;
-    u32x4* g = reinterpret_cast<u32x4*>(data);
-    const u32x4* gs = reinterpret_cast<const u32x4*>(src);   // == data for an in-place pass
-
-    // ---- load: chunk = 16 bytes; consecutive lanes -> consecutive chunks
-    for (uint32_t ch = tid; ch < 2 * tile_elems; ch += NTT_THREADS) {
-        uint32_t l = ch >> 1, half = ch & 1;
-        uint64_t i = ntt_gidx(l, tile, lg_tile, s_lo, K, lc);
-        u32x4 v = gs[i * 2 + half];
-        (half ? T.p1 : T.p0)[l] = v;
-    }
-    __syncthreads();
-
-    if (pre.mode != 0) {
-        for (uint32_t l = tid; l < tile_elems; l += NTT_THREADS) {
-            uint64_t i = ntt_gidx(l, tile, lg_tile, s_lo, K, lc);
-            T.put(l, mul(T.get(l), ntt_scale_factor<FrP>(pre, i, logn)));
-        }
-        __syncthreads();
-    }
-
-    for (int k = 0; k < K; k++) {
-        const int t = DIT_ ? k : (K - 1 - k);
-        const int lb = lc + t;
-        const int s = s_lo + t;
-        for (uint32_t q = tid; q < tile_elems / 2; q += NTT_THREADS) {
-            uint32_t l0 = ((q >> lb) << (lb + 1)) | (q & ((1u << lb) - 1));
-            uint32_t l1 = l0 | (1u << lb);
-            uint64_t i0 = ntt_gidx(l0, tile, lg_tile, s_lo, K, lc);
-            uint64_t e = (i0 & ((1ull << s) - 1)) << (logn - 1 - s);
-            Fe<FrP> x = T.get(l0), y = T.get(l1);
-            if (DIT_) {
-                if (e != 0) y = mul(y, load_fe_plain<FrP>(tw + e * 8));
-                T.put(l0, add(x, y));
-                T.put(l1, sub(x, y));
-            } else {
-                Fe<FrP> d = sub(x, y);
-                if (e != 0) d = mul(d, load_fe_plain<FrP>(tw + e * 8));
-                T.put(l0, add(x, y));
-                T.put(l1, d);
-            }
-        }
-        __syncthreads();
-    }
-
-    if (post.mode != 0) {
-        for (uint32_t l = tid; l < tile_elems; l += NTT_THREADS) {
-            uint64_t i = ntt_gidx(l, tile, lg_tile, s_lo, K, lc);
-            T.put(l, mul(T.get(l), ntt_scale_factor<FrP>(post, i, logn)));
-        }
-        __syncthreads();
-    }
-
-    for (uint32_t ch = tid; ch < 2 * tile_elems; ch += NTT_THREADS) {
-        uint32_t l = ch >> 1, half = ch & 1;
-        uint64_t i = ntt_gidx(l, tile, lg_tile, s_lo, K, lc);
-        g[i * 2 + half] = (half ? T.p1 : T.p0)[l];
-    }
-}
-
-// ---- the same pass in the lazy unpacked representation (field29.cuh) ------------------------------------------------
+// ---- one pass over stages [s_lo, s_lo+K) in the lazy unpacked representation (field29.hip.h) ----------------------------------
+// DIT_ = false: DIF butterflies, stages descending; true: DIT, ascending.
 // Elements stay in gnark's Montgomery form x*2^256 but as 9 limbs of 29 bits, unreduced; twiddles and scale factors are
 // tables of hat(w) = w*2^261, so  f29_mul(v, hat(w)) = v*w  is again in gnark's form -- no domain change at load/store.
 // Butterfly sums double per DIF stage and are Barrett-reduced to < 3p every third stage (subtractions add 32p); DIT adds a
@@ -440,8 +348,7 @@ struct Domain {
     uint32_t* d_gi_lo = nullptr;    // g^-k / n
     uint32_t* d_gi_hi = nullptr;
     uint32_t* d_gn_lo = nullptr;    // g^k / n   (computeH: coset FFT fused with the 1/n of the preceding iFFT)
-    bool lazy = true;               // tables in the hat domain, ntt_pass29_kernel (GA_NTT_LAZY=0 selects the packed kernel)
-    bool radix4 = true;             // two stages per LDS round trip (ntt_pass29r4_kernel; GA_NTT_R4=0 selects the radix-2 pass)
+    static constexpr bool lazy = true;   // twiddle / scale tables are kept in the hat domain (w * 2^261) for the lazy passes
     uint32_t ninv[8];               // 1/n (Montgomery; hat-packed when lazy)
     uint32_t den[8];                // (g^n - 1)^-1 (Montgomery), prove.go:370-373
     std::vector<NttPass> passes;    // ascending stage order
@@ -483,26 +390,21 @@ int ntt_run(Domain* d, uint32_t* d_data, bool inverse, bool dit, const NttScale&
         const NttScale& post = (p == np - 1) ? post_last : none;
         const uint32_t* src = (p == 0 && d_src) ? d_src : d_data;
         StageTimer st(ctx, dit ? "ntt_pass_dit" : "ntt_pass_dif");
-        if (d->lazy && d->radix4 && (dit || GA_NTT_R4_DIF) && d->logn >= 2) {
+        if (d->logn >= 2) {
             if (dit)
                 hipLaunchKernelGGL((ntt_pass29r4_kernel<FrP, true>), dim3((unsigned)tiles), dim3(NTT_THREADS), 0, ctx->stream,
                                    d_data, src, tw, d->logn, lg_tile, ps.s_lo, ps.K, ps.lc, pre, post);
             else
                 hipLaunchKernelGGL((ntt_pass29r4_kernel<FrP, false>), dim3((unsigned)tiles), dim3(NTT_THREADS), 0, ctx->stream,
                                    d_data, src, tw, d->logn, lg_tile, ps.s_lo, ps.K, ps.lc, pre, post);
-        } else if (d->lazy) {
+        } else {   // n = 2: a single stage, the one-stage-per-round-trip pass
             if (dit)
                 hipLaunchKernelGGL((ntt_pass29_kernel<FrP, true>), dim3((unsigned)tiles), dim3(NTT_THREADS), 0, ctx->stream,
                                    d_data, src, tw, d->logn, lg_tile, ps.s_lo, ps.K, ps.lc, pre, post);
             else
                 hipLaunchKernelGGL((ntt_pass29_kernel<FrP, false>), dim3((unsigned)tiles), dim3(NTT_THREADS), 0, ctx->stream,
                                    d_data, src, tw, d->logn, lg_tile, ps.s_lo, ps.K, ps.lc, pre, post);
-        } else if (dit)
-            hipLaunchKernelGGL((ntt_pass_kernel<FrP, true>), dim3((unsigned)tiles), dim3(NTT_THREADS), 0, ctx->stream,
-                               d_data, src, tw, d->logn, lg_tile, ps.s_lo, ps.K, ps.lc, pre, post);
-        else
-            hipLaunchKernelGGL((ntt_pass_kernel<FrP, false>), dim3((unsigned)tiles), dim3(NTT_THREADS), 0, ctx->stream,
-                               d_data, src, tw, d->logn, lg_tile, ps.s_lo, ps.K, ps.lc, pre, post);
+        }
         GA_KERNEL_CHECK();
     }
     return GA_OK;
@@ -592,12 +494,6 @@ int domain_init(Ctx* ctx, Domain* d, int curve, uint64_t n) {
         return GA_ERR_INVALID;
     }
     d->passes = ntt_plan(d->logn);
-    {
-        const char* env = getenv("GA_NTT_LAZY");
-        d->lazy = !(env && env[0] == '0');
-        const char* r4 = getenv("GA_NTT_R4");
-        d->radix4 = !(r4 && r4[0] == '0');
-    }
     // host: w = ROOT^(2^(adicity-logn)), inverse likewise; tables of w^(2^k)
     F w = fe_const<FrP>(FrP::ROOT), wi = fe_const<FrP>(FrP::ROOT_INV);
     for (int k = 0; k < FrP::ADICITY - d->logn; k++) {
@@ -631,8 +527,12 @@ int domain_init(Ctx* ctx, Domain* d, int curve, uint64_t n) {
             a = sqr(a);
             b = sqr(b);
         }
-        void* d_p2 = nullptr;
-        GA_HIP_CHECK(hipMalloc(&d_p2, p2.size() * 4));
+        struct DevTmp {   // released on every return path (the domain's own tables are released by domain_free in the caller)
+            void* p = nullptr;
+            ~DevTmp() { hipFree(p); }
+        } tmp_p2;
+        GA_HIP_CHECK(hipMalloc(&tmp_p2.p, p2.size() * 4));
+        void* const d_p2 = tmp_p2.p;
         GA_HIP_CHECK(hipMemcpy(d_p2, p2.data(), p2.size() * 4, hipMemcpyHostToDevice));
         GA_HIP_CHECK(hipMalloc((void**)&d->d_tw, half_n * 32));
         GA_HIP_CHECK(hipMalloc((void**)&d->d_tw_inv, half_n * 32));
@@ -643,7 +543,6 @@ int domain_init(Ctx* ctx, Domain* d, int curve, uint64_t n) {
                            (const uint32_t*)d_p2 + 32 * 8, half_n, nb, d->lazy ? 1 : 0);
         GA_KERNEL_CHECK();
         GA_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        GA_HIP_CHECK(hipFree(d_p2));
     }
     // coset power tables (host-computed: <= 2^12 + n/2^12 entries each)
     uint64_t nlo = 1ull << NTT_POW_LO_BITS;

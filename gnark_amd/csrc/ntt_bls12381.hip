@@ -1,5 +1,5 @@
-// Explicit instantiation: Fr NTT / computeH, bls12381 (see ntt.cuh).
-#include "ntt.cuh"
+// Explicit instantiation: Fr NTT / computeH, bls12381 (see ntt.hip.h).
+#include "ntt.hip.h"
 namespace ga {
 template <>
 int ntt_domain_new<Bls12381>(Ctx* ctx, uint64_t n, Domain** out) {

@@ -1,5 +1,5 @@
-// Explicit instantiation: Fr NTT / computeH, bn254 (see ntt.cuh).
-#include "ntt.cuh"
+// Explicit instantiation: Fr NTT / computeH, bn254 (see ntt.hip.h).
+#include "ntt.hip.h"
 namespace ga {
 template <>
 int ntt_domain_new<Bn254>(Ctx* ctx, uint64_t n, Domain** out) {

@@ -1,5 +1,5 @@
-// Non-templated accessors of the fft.Domain analogue (see ntt.cuh).
-#include "plonk.cuh"
+// Non-templated accessors of the fft.Domain analogue (see ntt.hip.h).
+#include "plonk.hip.h"
 namespace ga {
 void plonk_fixed_delete(PlonkFixed* fx) { plonk_fixed_destroy(fx); }
 Domain* plonk_fixed_domain0(PlonkFixed* fx) { return fx->d0; }

@@ -11,11 +11,11 @@
 // 1/(x-1) for L1 comes from a batched Montgomery-trick inversion kernel (the reference's batchInvert, prove.go:1134-1147).
 // Field elements are mathematically unique, so the coefficients equal the reference's bit for bit.
 #pragma once
-#include "ntt.cuh"
+#include "ntt.hip.h"
 
 namespace ga {
 
-// PLONK_MAX_BSB, PLONK_NB_FIXED and PlonkQuotientArgs live in common.cuh (shared with the ABI translation unit)
+// PLONK_MAX_BSB, PLONK_NB_FIXED and PlonkQuotientArgs live in common.hip.h (shared with the ABI translation unit)
 enum { PX_L = 0, PX_R, PX_O, PX_Z, PX_QL, PX_QR, PX_QM, PX_QO, PX_QK, PX_S1, PX_S2, PX_S3 };
 
 struct PlonkPtrs {
@@ -636,6 +636,12 @@ int fr_batch_inverse(Ctx* ctx, void* v, uint64_t n, bool on_device) {
     return GA_OK;
 }
 
+// entries of a device-resident permutation outside [0, 3n) would index the identity tables out of bounds
+static __global__ void plonk_perm_check_kernel(const int64_t* __restrict__ perm, uint64_t n3, uint32_t* __restrict__ bad) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n3 && (perm[i] < 0 || (uint64_t)perm[i] >= n3)) atomicAdd(bad, 1u);
+}
+
 // iop.BuildRatioCopyConstraint: Z in Lagrange form (regular layout) from L, R, O (Lagrange regular) and the permutation.
 template <class FrP>
 int plonk_build_z(Domain* d0, const void* L, const void* R, const void* O, const int64_t* perm, const void* beta, const void* gamma,
@@ -658,6 +664,20 @@ int plonk_build_z(Domain* d0, const void* L, const void* R, const void* O, const
     const void* src[3] = {L, R, O};
     for (int k = 0; k < 3; k++) GA_HIP_CHECK(hipMemcpyAsync(lro + (size_t)k * n * 8, src[k], n * 32, kin, st));
     GA_HIP_CHECK(hipMemcpyAsync(dperm, perm, 3 * n * 8, kin, st));
+    if (on_device) {   // a host permutation was range-checked by the entry point
+        uint32_t* d_bad;
+        GA_CHECK(ctx->scratch_get("plonk_perm_bad", 256, (void**)&d_bad));
+        GA_HIP_CHECK(hipMemsetAsync(d_bad, 0, 4, st));
+        hipLaunchKernelGGL(plonk_perm_check_kernel, dim3((unsigned)((3 * n + 255) / 256)), dim3(256), 0, st, (const int64_t*)dperm, 3 * n, d_bad);
+        GA_KERNEL_CHECK();
+        uint32_t bad = 0;
+        GA_HIP_CHECK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, st));
+        GA_HIP_CHECK(hipStreamSynchronize(st));
+        if (bad) {
+            set_error("ga_plonk_build_z: %u entries of the device-resident permutation are outside [0, 3n)", bad);
+            return GA_ERR_INVALID;
+        }
+    }
     PlonkConsts K;
     memset(&K, 0, sizeof(K));
     memcpy(K.beta, beta, 32);

@@ -1,5 +1,5 @@
-// Explicit instantiation: PLONK quotient / grand product / batch inversion, bn254 (see plonk.cuh).
-#include "plonk.cuh"
+// Explicit instantiation: PLONK quotient / grand product / batch inversion, bn254 (see plonk.hip.h).
+#include "plonk.hip.h"
 namespace ga {
 template <>
 int plonk_domain_quotient<Bn254>(Domain* d0, Domain* d1, const PlonkQuotientArgs& args, void* h_out) {

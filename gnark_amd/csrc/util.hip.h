@@ -1,7 +1,7 @@
 // Synthetic key material with known discrete logs, field dot products and gathers: what tests, bench.py and the
 // Groth16 wire filtering (prove.go:147-168) need around the MSM/NTT kernels; plus the window-size planner.
 #pragma once
-#include "common.cuh"
+#include "common.hip.h"
 
 namespace ga {
 
@@ -160,10 +160,6 @@ int msm_plan(int group, size_t n, int* c_out, int* nwin_out) {
         }
     }
     (void)group;
-    if (const char* e = getenv("GA_MSM_C")) {   // experiments only: force the window width of the raw-bases plan
-        int v = atoi(e);
-        if (v >= 4 && v <= 22) bc = v;
-    }
     *c_out = bc;
     *nwin_out = bits / bc + 1;
     return GA_OK;
@@ -185,10 +181,6 @@ int msm_plan_table(size_t n, int* c_out, int* nwin_out) {
             best = cost;
             bc = c;
         }
-    }
-    if (const char* e = getenv("GA_MSM_TABLE_C")) {   // experiments only
-        int v = atoi(e);
-        if (v >= 4 && v <= 23 && (double)(bits / v + 1) * (double)n < 2147483648.0) bc = v;
     }
     if (best == 1e300) {   // no window width keeps windows x n inside the 31-bit table index: the caller must shard the vector
         set_error("msm table plan: %zu points do not fit the 2^31 (window, point) index space; shard the vector", n);

@@ -1,5 +1,5 @@
-// Explicit instantiation: synthetic-input / checking kernels, bls12381 (see util.cuh).
-#include "util.cuh"
+// Explicit instantiation: synthetic-input / checking kernels, bls12381 (see util.hip.h).
+#include "util.hip.h"
 namespace ga {
 template int util_gen_bases<Bls12381, GA_G1>(Ctx*, uint64_t, size_t, void*, void*);
 template int util_gen_bases<Bls12381, GA_G2>(Ctx*, uint64_t, size_t, void*, void*);

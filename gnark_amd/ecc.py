@@ -119,6 +119,10 @@ def MultiExpWindows(ctx: Context, curve, group: int, points, scalars, n: int, wi
     cid = curve_id(curve)
     c, nw = plan(curve, group, n, lib=ctx.lib)
     hi = nw if win_hi < 0 else win_hi
+    if not isinstance(points, (DeviceBuffer, int)):
+        points = as_u64(points, affine_words(cid, group))
+    if not isinstance(scalars, (DeviceBuffer, int)):
+        scalars = as_u64(scalars, 4)
     bp, f1 = _arg(points, _lib.BASES_ON_DEVICE)
     sp, f2 = _arg(scalars, _lib.SCALARS_ON_DEVICE)
     flags = f1 | f2 | (_lib.SCALARS_MONTGOMERY if montgomery else 0)

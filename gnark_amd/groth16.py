@@ -374,7 +374,7 @@ def Finish(pk: ProvingKey, partials_sum: np.ndarray, r: np.ndarray, s: np.ndarra
 
 # ---- BSB22 host helpers (what the Go shim gets from gnark-crypto; here through the library's host code) -------------------
 COMMITMENT_DST = b"bsb22-commitment"   # constraint/commitment.go:7
-FOLD_DST = b"G16-BSB22"                # prove.go:123
+FOLD_DST = b"G16-BSB22"                # prove.go:123: the fold challenge hashes the commitment WIRE VALUES (32-byte BE each), not the points
 
 
 def HashToField(curve, msg: bytes, dst: bytes, count: int = 1, lib=None) -> np.ndarray:

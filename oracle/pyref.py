@@ -952,7 +952,7 @@ def sha_tag(*parts) -> str:
 
 # ----------------------------------------------------------------------------------------------
 # proving-key wire formats (backend/groth16/bn254/marshal.go:231-539) and Proof.ReadFrom (:62-86)
-# Framing owned by gnark-crypto v0.21.0 [EXT, restated from its published code, see gnark_amd/csrc/keyio.cuh]:
+# Framing owned by gnark-crypto v0.21.0 [EXT, restated from its published code, see gnark_amd/csrc/keyio.hip.h]:
 # Encoder integers big-endian, []G1Affine = u32 BE length + points, []bool one byte per entry without a
 # length, fft.Domain.WriteTo = cardinality + 5 fr elements (+ withPrecompute byte), unsafe.WriteSlice = u64 LE
 # length + memory image, unsafe.WriteMarker = uint64(0xdeadbeef) in native byte order.

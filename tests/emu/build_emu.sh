@@ -10,7 +10,7 @@ mkdir -p "$OUT"
 FLAGS="-O2 -g0 -std=c++17 -fPIC -I$HERE/include -I$SRC -I$HERE/../../include -w"
 pids=()
 for f in abi groth16 hash_to_field plonk_bn254 plonk_bls12381 ntt_domain msm_bn254_g1 msm_bn254_g2 msm_bls12381_g1 msm_bls12381_g2 ntt_bn254 ntt_bls12381 util_bn254 util_bls12381; do
-  if [ ! -f "$OUT/$f.o" ] || [ -n "$(find "$SRC" "$HERE/include" -newer "$OUT/$f.o" \( -name '*.cuh' -o -name '*.h' -o -name '*.hpp' -o -name "$f.hip" \) | head -1)" ]; then
+  if [ ! -f "$OUT/$f.o" ] || [ -n "$(find "$SRC" "$HERE/include" -newer "$OUT/$f.o" \( -name '*.hip.h' -o -name '*.h' -o -name '*.hpp' -o -name "$f.hip" \) | head -1)" ]; then
     g++ $FLAGS -x c++ -c "$SRC/$f.hip" -o "$OUT/$f.o" &
     pids+=($!)
   fi

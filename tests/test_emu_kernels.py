@@ -953,3 +953,37 @@ def test_emu_proof_unmarshal(emu_ctx, c):
         want = pyref.g1_decompress(c, raw[off:off + ln]) if group == 0 else pyref.g2_decompress(c, raw[off:off + ln])
         assert (arr_to_g1_affine(c, out) if group == 0 else arr_to_g2_affine(c, out)) == want
         off += ln
+
+
+def test_emu_msm_unreduced_canonical_scalars(emu_ctx):
+    """canonical (non-Montgomery) scalars need not be below r -- r itself, 2r+5 and 2^256-1 give the same point as
+    their residues"""
+    c, group, n = BN254, 0, 64
+    rng = pyref.Xoshiro(8)
+    ks = np.array([rng.next() for _ in range(n)], dtype=np.uint64)
+    P = oracle.gen_bases(c.cid, group, ks)
+    vals = [rng.field(c.r) for _ in range(n)]
+    vals[0], vals[1], vals[2], vals[3] = c.r, 2 * c.r + 5, (1 << 256) - 1, c.r - 1
+    S = np.array([pyref.to_limbs(v, 4) for v in vals], dtype=np.uint64)
+    got = jac_to_affine_py(c, group, ecc.MultiExp(emu_ctx, c.name, group, P, S, montgomery=False))
+    red = fr_to_arr(c, [v % c.r for v in vals])
+    want = jac_to_affine_py(c, group, oracle.msm(c.cid, group, P, red))
+    assert got == want
+
+
+def test_emu_plonk_build_z_rejects_bad_device_permutation(emu_ctx):
+    c, n = BN254, 8
+    d0 = fft.Domain(emu_ctx, c.name, n)
+    try:
+        v = emu_ctx.to_device(fr_to_arr(c, list(range(1, n + 1))))
+        perm = np.arange(3 * n, dtype=np.int64)
+        perm[5] = 3 * n            # out of range
+        dp = emu_ctx.to_device(perm)
+        one = fr_to_arr(c, [1])
+        out = emu_ctx.malloc(n * 32)
+        rc = emu_ctx.lib.ga_plonk_build_z(d0.handle, v.ptr, v.ptr, v.ptr, dp.ptr, one.ctypes.data, one.ctypes.data, 1, out.ptr)
+        assert rc == -1 and b"outside [0, 3n)" in emu_ctx.lib.ga_last_error()
+        for b in (v, dp, out):
+            b.free()
+    finally:
+        d0.close()

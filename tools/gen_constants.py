@@ -29,7 +29,7 @@ FP2_LAZY_K = 16   # operands of the lazy Fp2 product are below 16p (asserted by 
 
 
 def fp2_lazy_offset(mod, n64, K=FP2_LAZY_K):
-    """Column constants Z[0..2NL-2] for field29.cuh's Fp2 product: a multiple of p in a redundant base-2^L representation whose
+    """Column constants Z[0..2NL-2] for field29.hip.h's Fp2 product: a multiple of p in a redundant base-2^L representation whose
     every column dominates the corresponding column of a1*b1 (operands < K*p, normalized limbs), so that
     a0*b0 - a1*b1 + Z can be formed column by column in unsigned 64-bit arithmetic before ONE Montgomery reduction."""
     n32 = 2 * n64
@@ -68,10 +68,10 @@ def field_block(name, mod, n64, w, extra=None):
     out.append(f"    static constexpr {ty} ONE[{n}] = {arr(R % mod, n, w)};   // R mod p")
     out.append(f"    static constexpr {ty} R2[{n}] = {arr(R * R % mod, n, w)};    // R^2 mod p")
     out.append(f"    static constexpr {ty} PM2[{n}] = {arr(mod - 2, n, w)};   // p-2 (Fermat inverse exponent)")
-    out.append(f"    static constexpr uint32_t MU12 = {(1 << (mod.bit_length() + 8)) // mod}u;   // floor(2^(BITS+8) / p): Barrett quotient estimate (field29.cuh)")
+    out.append(f"    static constexpr uint32_t MU12 = {(1 << (mod.bit_length() + 8)) // mod}u;   // floor(2^(BITS+8) / p): Barrett quotient estimate (field29.hip.h)")
     if w == 32 and name.endswith("_Fp"):
         Z, zint, add = fp2_lazy_offset(mod, n64)
-        out.append(f"    // lazy Fp2 product (field29.cuh): redundant-digit columns of a multiple of p dominating a1*b1 for operands < {FP2_LAZY_K}p;")
+        out.append(f"    // lazy Fp2 product (field29.hip.h): redundant-digit columns of a multiple of p dominating a1*b1 for operands < {FP2_LAZY_K}p;")
         out.append(f"    // it adds < {add / mod:.3f} p to the reduced real part")
         out.append(f"    static constexpr int FP2Z_K = {FP2_LAZY_K};")
         out.append(f"    static constexpr uint64_t FP2Z[{len(Z)}] = {{" + ", ".join(f"0x{v:x}ull" for v in Z) + "};")

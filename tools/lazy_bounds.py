@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Interval analysis behind the lazy (unreduced) arithmetic of gnark_amd/csrc/field29.cuh + msm.cuh::madd29.
+"""Interval analysis behind the lazy (unreduced) arithmetic of gnark_amd/csrc/field29.hip.h + msm.hip.h::madd29.
 
 Every value is tracked by an upper bound.  The representation needs (NL limbs of L bits, R' = 2^(NL*L)):
   * values < R' (the top limb must stay below 2^L so that column sums of 2*NL products fit 64 bits);
   * for every  a - b + K*p :  b < K*p  (with a margin of one top-limb unit, 2^(L*(NL-1)));
-  * Karatsuba operand sums (Fp2) < R'.
+  * Fp2 operands below FP2Z_K*p (the negation constant of the schoolbook-on-columns product).
 `check(...)` iterates the mixed-addition formulas to a fixed point of the accumulator bounds and asserts all of the
 above with exactly the constants the kernels use.  tests/test_lazy_bounds.py runs it for both curves."""
 from math import log2
@@ -13,9 +13,9 @@ BN254_P = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
 BLS12_381_P = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
 CURVES = {"bn254": (BN254_P, 29, 9, 254), "bls12-381": (BLS12_381_P, 28, 14, 381)}
 
-# constants used by msm.cuh::madd29 (G1) and its Fp2 overload (G2), and by field29.cuh's Fp2 product / square
+# constants used by msm.hip.h::madd29 (G1) and its Fp2 overload (G2), and by field29.hip.h's Fp2 product / square
 G1 = dict(Kx=8, Ky=8, K3=4, Kq=8, Ky3=2)
-G2 = dict(Kx=4, Ky=4, K3=4, Kq=8, Ky3=8, KV=2, KS=4, KQ=8, partial_reduce=("X",))
+G2 = dict(Kx=4, Ky=4, K3=4, Kq=8, Ky3=8, KQ=8, partial_reduce=("X",))
 
 
 def check(curve: str, fp2: bool, verbose=False):
@@ -39,31 +39,19 @@ def check(curve: str, fp2: bool, verbose=False):
         q = v >> bits
         return (1 << bits) + q * ((1 << bits) - p)
 
-    if fp2 and NL <= int(__import__("os").environ.get("GA_FP2_LAZY_MAX_NL", "14")):
-        # lazy Fp2 product (field29.cuh, GA_FP2_LAZY): Karatsuba on unreduced columns, offset Z (gen_constants.fp2_lazy_offset)
+    if fp2:
+        # Fp2 product (field29.hip.h f29_mul on F29x2): schoolbook on unreduced columns, real part a0*b0 + (K*p - a1)*b1 with
+        # K = P::FP2Z_K (gen_constants.FP2_LAZY_K), imaginary part a0*b1 + a1*b0; two reductions
         import os
         import sys
         sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-        from gen_constants import FP2_LAZY_K, fp2_lazy_offset
-        _, zint, _ = fp2_lazy_offset(p, (bits + 63) // 64)
-        assert NL * (1 << (2 * L + 2)) < 1 << 64, "operand-sum columns overflow 64 bits"
-
-        variant = int(os.environ.get("GA_FP2_LAZY", "2"))   # 1: Karatsuba on columns with the offset Z; 2: schoolbook with K*p - a1
+        from gen_constants import FP2_LAZY_K
 
         def mul(a, b):
             assert a < FP2_LAZY_K * p and b < FP2_LAZY_K * p, ("Fp2 operand above FP2Z_K*p", log2(a), log2(b))
             lim(a), lim(b)
-            if variant == 2:
-                assert 2 * NL * (1 << (2 * L)) + NL * (1 << (2 * L)) < 1 << 64
-                return max((a * b + (FP2_LAZY_K * p + unit) * b) // R + p, 2 * a * b // R + p)
-            return max((a * b + zint) // R + p, 2 * a * b // R + p)
-    elif fp2:
-        def mul(a, b):
-            lim(2 * a), lim(2 * b)
-            v, s = mul1(a, b), mul1(2 * a, 2 * b)
-            need(k["KV"], v, "KV")
-            need(k["KS"], 2 * v, "KS")
-            return max(v + k["KV"] * p, s + k["KS"] * p)
+            assert 2 * NL * (1 << (2 * L)) + NL * (1 << (2 * L)) < 1 << 64
+            return max((a * b + (FP2_LAZY_K * p + unit) * b) // R + p, 2 * a * b // R + p)
 
     if fp2:
         def sqr(a):
@@ -121,14 +109,14 @@ def check(curve: str, fp2: bool, verbose=False):
     return out
 
 
-# ---- general XYZZ + XYZZ addition in the lazy representation (msm.cuh::add29, window reduction) -------------------------
+# ---- general XYZZ + XYZZ addition in the lazy representation (msm.hip.h::add29, window reduction) -------------------------
 ADD_G1 = dict(KP=4, KR=4, K3=4, Kq=8, Kms=8, partial_reduce=())
 ADD_G2 = dict(KP=4, KR=4, K3=4, Kq=8, Kms=16, partial_reduce=("X",))
 
 
 def check_add(curve: str, fp2: bool, verbose=False):
     """Fixed point of the coordinate bounds under a = add29(a, b) when both operands are earlier results (running sums added
-    into running sums); every subtraction constant and every Fp2 operand bound of msm.cuh::add29 is asserted."""
+    into running sums); every subtraction constant and every Fp2 operand bound of msm.hip.h::add29 is asserted."""
     p, L, NL, bits = CURVES[curve]
     R = 1 << (L * NL)
     unit = 1 << (L * (NL - 1))
