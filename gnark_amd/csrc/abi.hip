@@ -19,6 +19,7 @@ void set_error(const char* fmt, ...) {
 const char* get_error() { return g_err; }
 
 int Ctx::scratch_get(const char* key, size_t bytes, void** out) {
+    std::lock_guard<std::mutex> g(scratch_mu);
     auto it = scratch.find(key);
     if (it != scratch.end() && it->second.second >= bytes) {
         *out = it->second.first;
@@ -41,6 +42,7 @@ int Ctx::scratch_get(const char* key, size_t bytes, void** out) {
 }
 
 void Ctx::scratch_free_all() {
+    std::lock_guard<std::mutex> g(scratch_mu);
     for (auto& kv : scratch) hipFree(kv.second.first);
     scratch.clear();
 }
@@ -163,8 +165,8 @@ int ga_ctx_create(int device, ga_ctx** out) {
     GA_HIP_CHECK(hipSetDevice(device));
     Ctx* c = new Ctx();
     c->device = device;
-    hipStream_t* slots[3] = {&c->stream, &c->copy_stream, &c->aux_stream};
-    for (int k = 0; k < 3; k++) {
+    hipStream_t* slots[5] = {&c->stream, &c->copy_stream, &c->aux_stream, &c->slot_stream[0], &c->slot_stream[1]};
+    for (int k = 0; k < 5; k++) {
         hipError_t se = hipStreamCreateWithFlags(slots[k], hipStreamNonBlocking);
         if (se != hipSuccess) {
             set_error("hipStreamCreate failed: %s", hipGetErrorString(se));
@@ -191,6 +193,8 @@ void ga_ctx_destroy(ga_ctx* h) {
     hipStreamDestroy(c->stream);
     hipStreamDestroy(c->copy_stream);
     hipStreamDestroy(c->aux_stream);
+    hipStreamDestroy(c->slot_stream[0]);
+    hipStreamDestroy(c->slot_stream[1]);
     delete c;
 }
 
@@ -686,9 +690,9 @@ int ga_compute_h(ga_domain* dh, const void* a, const void* b, const void* cc, ui
     const uint64_t n = ntt_domain_size(d);
     const size_t full = n * 32, part = n_constraints * 32;
     void *da, *db, *dc;
-    GA_CHECK(c->scratch_get("h_a", full, &da));
-    GA_CHECK(c->scratch_get("h_b", full, &db));
-    GA_CHECK(c->scratch_get("h_c", full, &dc));
+    GA_CHECK(c->scratch_get("compute_h_a", full, &da));
+    GA_CHECK(c->scratch_get("compute_h_b", full, &db));
+    GA_CHECK(c->scratch_get("compute_h_c", full, &dc));
     const void* src[3] = {a, b, cc};
     void* dst[3] = {da, db, dc};
     for (int k = 0; k < 3; k++) {

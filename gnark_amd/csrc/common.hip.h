@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <condition_variable>
 #include <map>
 #include <mutex>
 #include <string>
@@ -95,6 +96,14 @@ struct Ctx {
     hipStream_t copy_stream = nullptr;   // uploads that overlap kernels (groth16.hip)
     hipStream_t aux_stream = nullptr;    // digit/sort preparation of the NEXT MSM while the current one accumulates
     std::mutex mu;
+    // Two input slots per context (W, A, B, C staging buffers each): while one proof computes under `mu`, a second caller of
+    // ga_g16_prove stages its solution in the other slot over PCIe, so that back-to-back proofs from two host threads (two
+    // goroutines) hide the upload of the next proof behind the kernels of the current one.
+    std::mutex slot_mu;
+    std::condition_variable slot_cv;
+    bool slot_busy[2] = {false, false};
+    hipStream_t slot_stream[2] = {nullptr, nullptr};
+    std::mutex scratch_mu;   // the scratch map is touched by the staging thread outside `mu`
     bool profiling = false;
     std::vector<StageRec> stages;
     // reusable device scratch, grown on demand (keyed by purpose)
@@ -114,12 +123,33 @@ struct CtxLock {
     }
 };
 
+// ownership of one input slot of a context for the duration of a proof
+struct SlotLease {
+    Ctx* ctx;
+    int slot;
+    explicit SlotLease(Ctx* c) : ctx(c), slot(0) {
+        std::unique_lock<std::mutex> g(c->slot_mu);
+        c->slot_cv.wait(g, [&] { return !c->slot_busy[0] || !c->slot_busy[1]; });
+        slot = c->slot_busy[0] ? 1 : 0;
+        c->slot_busy[slot] = true;
+    }
+    ~SlotLease() {
+        {
+            std::lock_guard<std::mutex> g(ctx->slot_mu);
+            ctx->slot_busy[slot] = false;
+        }
+        ctx->slot_cv.notify_one();
+    }
+    // per-slot scratch name: "g16_w" -> "g16_w#1"
+    std::string name(const char* base) const { return std::string(base) + (slot ? "#1" : "#0"); }
+};
+
 struct StageTimer {
     Ctx* ctx;
     int idx = -1;
     hipStream_t st;
-    StageTimer(Ctx* c, const char* name, hipStream_t stream = nullptr) : ctx(c), st(stream ? stream : c->stream) {
-        if (!c->profiling) return;
+    StageTimer(Ctx* c, const char* name, hipStream_t stream = nullptr) : ctx(c), st(stream ? stream : (c ? c->stream : nullptr)) {
+        if (!c || !c->profiling) return;
         StageRec r;
         r.name = name;
         if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;

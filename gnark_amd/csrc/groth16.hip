@@ -892,7 +892,7 @@ static int proof_unmarshal(const uint8_t* data, size_t len, void* proof_out, voi
 // z_msm        : MSM over this shard's slice of pk.G1.Z and h                                                  prove.go:225-227
 // W -> device, only the wire range this shard reads.  Returns when the copy has been handed to the DMA engine from pageable
 // memory, i.e. when the host buffer has been consumed -- callers start the (PCIe-competing) upload of A, B, C only after it.
-static int witness_upload(G16Pk* pk, const void* w, uint64_t nb_public) {
+static int witness_upload(G16Pk* pk, const SlotLease& slot, const void* w, uint64_t nb_public, hipStream_t up_stream = nullptr) {
     Ctx* ctx = pk->ctx;
     if (nb_public > pk->nb_wires || pk->nb_wires - nb_public != pk->full_len_k + pk->len_k_remove) {
         set_error("prove: inconsistent sizes (nbWires %llu - nbPublic %llu != len(K) %llu + len(k_remove) %llu)", (unsigned long long)pk->nb_wires,
@@ -900,7 +900,8 @@ static int witness_upload(G16Pk* pk, const void* w, uint64_t nb_public) {
         return GA_ERR_INVALID;
     }
     void* d_w;
-    GA_CHECK(ctx->scratch_get("g16_w", pk->nb_wires * 32, &d_w));
+    GA_CHECK(ctx->scratch_get(slot.name("g16_w").c_str(), pk->nb_wires * 32, &d_w));
+    if (!up_stream) up_stream = ctx->stream;
     // the wire range this shard reads: everything for an unsharded key, ~1/N of W for shard k of N (the gather lists of a
     // shard are contiguous pieces of the sorted wire lists); K's range depends on nbPublic
     uint64_t lo = pk->w_lo, hi = pk->w_hi;
@@ -911,13 +912,14 @@ static int witness_upload(G16Pk* pk, const void* w, uint64_t nb_public) {
     }
     if (hi > pk->nb_wires) hi = pk->nb_wires;
     if (lo > hi) lo = hi;
-    StageTimer tm(ctx, "g16_h2d_w");
-    if (hi > lo) GA_HIP_CHECK(hipMemcpyAsync((char*)d_w + lo * 32, (const char*)w + lo * 32, (hi - lo) * 32, hipMemcpyHostToDevice, ctx->stream));
+    // (timed only on the main stream: a staging thread runs outside the device lock that guards the profiler's stage list)
+    StageTimer tm(up_stream == ctx->stream ? ctx : nullptr, "g16_h2d_w", up_stream);
+    if (hi > lo) GA_HIP_CHECK(hipMemcpyAsync((char*)d_w + lo * 32, (const char*)w + lo * 32, (hi - lo) * 32, hipMemcpyHostToDevice, up_stream));
     return GA_OK;
 }
 
 template <class C>
-static int witness_msms(G16Pk* pk, uint64_t nb_public, XYZZ<Fe<typename C::FpP>>* o_ar,
+static int witness_msms(G16Pk* pk, const SlotLease& slot, uint64_t nb_public, XYZZ<Fe<typename C::FpP>>* o_ar,
                         XYZZ<Fe<typename C::FpP>>* o_bs1, XYZZ<Fe<typename C::FpP>>* o_k, XYZZ<Fe2<typename C::FpP>>* o_bs2) {
     typedef Fe<typename C::FpP> F1;
     typedef Fe2<typename C::FpP> F2;
@@ -929,7 +931,7 @@ static int witness_msms(G16Pk* pk, uint64_t nb_public, XYZZ<Fe<typename C::FpP>>
     }
     hipStream_t st = ctx->stream;
     void *d_w, *d_wa, *d_wb;
-    GA_CHECK(ctx->scratch_get("g16_w", pk->nb_wires * 32, &d_w));
+    GA_CHECK(ctx->scratch_get(slot.name("g16_w").c_str(), pk->nb_wires * 32, &d_w));
     GA_CHECK(ctx->scratch_get("g16_wa", pk->len_a * 32 + 32, &d_wa));
     GA_CHECK(ctx->scratch_get("g16_wb", pk->len_b * 32 + 32, &d_wb));
     // ---- wire filtering (prove.go:147-168) ------------------------------------------------------------
@@ -1055,11 +1057,31 @@ struct ThreadJoiner {
     }
 };
 
+// all four vectors of a solution into the slot's staging buffers on the slot's own stream (a caller that found the device busy
+// with another proof does this while it waits); returns when the copies have completed, so the host buffers are free again
+static int preload_solution(G16Pk* pk, const SlotLease& slot, const void* w, const void* a, const void* b, const void* c,
+                            uint64_t n_constraints, uint64_t nb_public) {
+    Ctx* ctx = pk->ctx;
+    const uint64_t n = pk->n;
+    hipStream_t st = ctx->slot_stream[slot.slot];
+    GA_CHECK(witness_upload(pk, slot, w, nb_public, st));
+    const void* src[3] = {a, b, c};
+    static const char* const names[3] = {"h_a", "h_b", "h_c"};
+    for (int k = 0; k < 3; k++) {
+        void* d;
+        GA_CHECK(ctx->scratch_get(slot.name(names[k]).c_str(), n * 32, &d));
+        GA_CHECK(h_upload(pk, src[k], n_constraints, d, st));
+    }
+    GA_HIP_CHECK(hipStreamSynchronize(st));
+    return GA_OK;
+}
+
 // The device part of a proof on this key's shard: computeH + the five MSMs over the pinned slices.
 // Outputs (before randomisation): A-sum, B1-sum, K-sum + Z-sum (G1), B2-sum (G2) -- to be added across shards.
+// preloaded: W, A, B, C already sit in the slot's buffers (preload_solution).
 template <class C>
-static int prove_partial(G16Pk* pk, const void* w, const void* a, const void* b, const void* c, uint64_t n_constraints,
-                         uint64_t nb_public, XYZZ<Fe<typename C::FpP>>* o_ar, XYZZ<Fe<typename C::FpP>>* o_bs1,
+static int prove_partial(G16Pk* pk, const SlotLease& slot, bool preloaded, const void* w, const void* a, const void* b, const void* c,
+                         uint64_t n_constraints, uint64_t nb_public, XYZZ<Fe<typename C::FpP>>* o_ar, XYZZ<Fe<typename C::FpP>>* o_bs1,
                          XYZZ<Fe<typename C::FpP>>* o_krs, XYZZ<Fe2<typename C::FpP>>* o_bs2) {
     typedef Fe<typename C::FpP> F1;
     Ctx* ctx = pk->ctx;
@@ -1069,44 +1091,48 @@ static int prove_partial(G16Pk* pk, const void* w, const void* a, const void* b,
         return GA_ERR_INVALID;
     }
     void *d_ha, *d_hb, *d_hc;
-    GA_CHECK(ctx->scratch_get("h_a", n * 32, &d_ha));
-    GA_CHECK(ctx->scratch_get("h_b", n * 32, &d_hb));
-    GA_CHECK(ctx->scratch_get("h_c", n * 32, &d_hc));
-    // W first (the four witness MSMs only need W); A, B, C are uploaded by a helper thread on a second stream while
-    // those MSMs run -- pageable H2D copies block the calling thread, hence the thread.  Everything is joined before
-    // this function returns, so no host pointer outlives the call.
-    GA_CHECK(witness_upload(pk, w, nb_public));
-    EventGuard abc;
-    GA_HIP_CHECK(hipEventCreateWithFlags(&abc.ev, hipEventDisableTiming));
-    int up_rc = GA_OK;
-    std::string up_err;
-    std::thread uploader([&]() {
-        if (hipSetDevice(ctx->device) != hipSuccess) {
-            up_rc = GA_ERR_HIP;
-            return;
-        }
-        const void* src[3] = {a, b, c};
-        void* dst[3] = {d_ha, d_hb, d_hc};
-        for (int k = 0; k < 3 && up_rc == GA_OK; k++) up_rc = h_upload(pk, src[k], n_constraints, dst[k], ctx->copy_stream);
-        hipError_t e = hipSuccess;
-        if (up_rc == GA_OK) e = hipEventRecord(abc.ev, ctx->copy_stream);
-        if (up_rc == GA_OK && e == hipSuccess) e = hipStreamSynchronize(ctx->copy_stream);
-        if (up_rc != GA_OK) up_err = get_error();
-        else if (e != hipSuccess) {
-            up_rc = GA_ERR_HIP;
-            up_err = hipGetErrorString(e);
-        }
-    });
-    ThreadJoiner joiner{uploader};
+    GA_CHECK(ctx->scratch_get(slot.name("h_a").c_str(), n * 32, &d_ha));
+    GA_CHECK(ctx->scratch_get(slot.name("h_b").c_str(), n * 32, &d_hb));
+    GA_CHECK(ctx->scratch_get(slot.name("h_c").c_str(), n * 32, &d_hc));
     XYZZ<F1> krs, krs2;
-    GA_CHECK(witness_msms<C>(pk, nb_public, o_ar, o_bs1, &krs, o_bs2));
-    // ---- H (prove.go:134,346-389), then the MSM over pk.G1.Z (prove.go:225-227) ----------------------------
-    uploader.join();
-    if (up_rc != GA_OK) {
-        set_error("prove: uploading A,B,C failed: %s", up_err.c_str());
-        return up_rc;
+    if (preloaded) {
+        GA_CHECK(witness_msms<C>(pk, slot, nb_public, o_ar, o_bs1, &krs, o_bs2));
+    } else {
+        // W first (the four witness MSMs only need W); A, B, C are uploaded by a helper thread on a second stream while
+        // those MSMs run -- pageable H2D copies block the calling thread, hence the thread.  Everything is joined before
+        // this function returns, so no host pointer outlives the call.
+        GA_CHECK(witness_upload(pk, slot, w, nb_public));
+        EventGuard abc;
+        GA_HIP_CHECK(hipEventCreateWithFlags(&abc.ev, hipEventDisableTiming));
+        int up_rc = GA_OK;
+        std::string up_err;
+        std::thread uploader([&]() {
+            if (hipSetDevice(ctx->device) != hipSuccess) {
+                up_rc = GA_ERR_HIP;
+                return;
+            }
+            const void* src[3] = {a, b, c};
+            void* dst[3] = {d_ha, d_hb, d_hc};
+            for (int k = 0; k < 3 && up_rc == GA_OK; k++) up_rc = h_upload(pk, src[k], n_constraints, dst[k], ctx->copy_stream);
+            hipError_t e = hipSuccess;
+            if (up_rc == GA_OK) e = hipEventRecord(abc.ev, ctx->copy_stream);
+            if (up_rc == GA_OK && e == hipSuccess) e = hipStreamSynchronize(ctx->copy_stream);
+            if (up_rc != GA_OK) up_err = get_error();
+            else if (e != hipSuccess) {
+                up_rc = GA_ERR_HIP;
+                up_err = hipGetErrorString(e);
+            }
+        });
+        ThreadJoiner joiner{uploader};
+        GA_CHECK(witness_msms<C>(pk, slot, nb_public, o_ar, o_bs1, &krs, o_bs2));
+        uploader.join();
+        if (up_rc != GA_OK) {
+            set_error("prove: uploading A,B,C failed: %s", up_err.c_str());
+            return up_rc;
+        }
+        GA_HIP_CHECK(hipStreamWaitEvent(ctx->stream, abc.ev, 0));
     }
-    GA_HIP_CHECK(hipStreamWaitEvent(ctx->stream, abc.ev, 0));
+    // ---- H (prove.go:134,346-389), then the MSM over pk.G1.Z (prove.go:225-227) ----------------------------
     GA_CHECK(ntt_domain_compute_h<C>(pk->dom, d_ha, d_hb, d_hc));   // h in d_ha, bit-reversed like pk.G1.Z
     GA_CHECK(z_msm<C>(pk, (const char*)d_ha + pk->off_z * 32, &krs2));
     *o_krs = add(krs, krs2);
@@ -1360,6 +1386,7 @@ static int prove_multi(G16Pk* const* pks, uint32_t n, const void* w, const void*
     auto worker = [&](uint32_t t) {
         G16Pk* pk = pks[t];
         Ctx* ctx = pk->ctx;
+        SlotLease slot(ctx);
         std::lock_guard<std::mutex> g(ctx->mu);   // one proof at a time per device (icicle.go:821-823)
         ctx->tun.read_env();
         auto bail = [&](const char* what) { sh.fail((std::string(what) + ": " + get_error()).c_str()); };
@@ -1367,14 +1394,14 @@ static int prove_multi(G16Pk* const* pks, uint32_t n, const void* w, const void*
         if (!ok) set_error("hipSetDevice(%d) failed", ctx->device);
         // buffers first, so that peers can address them after barrier 0
         for (int k = 0; ok && k < 3; k++) {
-            if (owner[k] == t) ok = ctx->scratch_get(names[k], N * 32, &chain_buf[k]) == GA_OK;
-            if (t == 0 && ok) ok = ctx->scratch_get(names[k], N * 32, &dev0_buf[k]) == GA_OK;
+            if (owner[k] == t) ok = ctx->scratch_get(slot.name(names[k]).c_str(), N * 32, &chain_buf[k]) == GA_OK;
+            if (t == 0 && ok) ok = ctx->scratch_get(slot.name(names[k]).c_str(), N * 32, &dev0_buf[k]) == GA_OK;
         }
         // a base-range shard receives its slice of h, a window shard all of it
         if (ok && pk->len_z) ok = t == 0 || ctx->scratch_get("h_slice", pk->len_z * 32, &h_slice[t]) == GA_OK;
         if (!ok) bail("multi-device prove: buffers");
         if (!sh.barrier(0)) return;
-        if (witness_upload(pk, w, nb_public) != GA_OK) {
+        if (witness_upload(pk, slot, w, nb_public) != GA_OK) {
             bail("multi-device prove: uploading W");
             ok = false;
         }
@@ -1409,7 +1436,7 @@ static int prove_multi(G16Pk* const* pks, uint32_t n, const void* w, const void*
             }
         }
         ThreadJoiner joiner{uploader};
-        if (ok && witness_msms<C>(pk, nb_public, &parts[t].ar, &parts[t].bs1, &parts[t].k, &parts[t].bs2) != GA_OK) {
+        if (ok && witness_msms<C>(pk, slot, nb_public, &parts[t].ar, &parts[t].bs1, &parts[t].k, &parts[t].bs2) != GA_OK) {
             bail("multi-device prove: witness MSMs");
             ok = false;
         }
@@ -1620,16 +1647,32 @@ int ga_g16_prove(ga_g16_pk* p, const void* w, const void* a, const void* b, cons
         set_error("ga_g16_prove: null argument");
         return GA_ERR_INVALID;
     }
-    CtxLock g(pk->ctx);
     if (pk->shard_count != 1 || pk->win_count != 1) {
         set_error("ga_g16_prove: this key holds one share of a sharded key (base range %u/%u, windows %u/%u); use ga_g16_prove_multi or "
                   "ga_g16_prove_partial + ga_g16_finish", pk->shard_index, pk->shard_count, pk->win_index, pk->win_count);
         return GA_ERR_STATE;
     }
+    // Two callers may be inside at once (two goroutines proving on one device): the one that finds the device busy stages its
+    // solution in the free input slot while the other proof computes, then takes the device; the host epilogue runs after the
+    // device has been released.  A single caller keeps the latency-optimal schedule (W first, A, B, C under the witness MSMs).
+    Ctx* ctx = pk->ctx;
+    SlotLease slot(ctx);
+    bool preloaded = false;
+    std::unique_lock<std::mutex> dev(ctx->mu, std::try_to_lock);
+    if (!dev.owns_lock()) {
+        hipSetDevice(ctx->device);
+        GA_CHECK(preload_solution(pk, slot, w, a, b, c, n_constraints, nb_public));
+        preloaded = true;
+        dev.lock();
+    }
+    hipSetDevice(ctx->device);
+    ctx->tun.read_env();
     GA_DISPATCH_CURVE(pk->curve, {
         XYZZ<Fe<typename C::FpP>> ar, bs1, krs;
         XYZZ<Fe2<typename C::FpP>> bs2;
-        GA_CHECK(prove_partial<C>(pk, w, a, b, c, n_constraints, nb_public, &ar, &bs1, &krs, &bs2));
+        GA_CHECK(prove_partial<C>(pk, slot, preloaded, w, a, b, c, n_constraints, nb_public, &ar, &bs1, &krs, &bs2));
+        const bool profiling = ctx->profiling;
+        if (!profiling) dev.unlock();   // the stage list of the profiler is guarded by the device lock
         return finish<C>(pk, ar, bs1, krs, bs2, r, s, proof_out);
     });
     return GA_OK;
@@ -1642,13 +1685,14 @@ int ga_g16_prove_partial(ga_g16_pk* p, const void* w, const void* a, const void*
         set_error("ga_g16_prove_partial: null argument");
         return GA_ERR_INVALID;
     }
+    SlotLease slot(pk->ctx);   // always slot first, device lock second (ga_g16_prove's order)
     CtxLock g(pk->ctx);
     GA_DISPATCH_CURVE(pk->curve, {
         typedef Fe<typename C::FpP> F1;
         typedef Fe2<typename C::FpP> F2;
         XYZZ<F1> ar, bs1, krs;
         XYZZ<F2> bs2;
-        GA_CHECK(prove_partial<C>(pk, w, a, b, c, n_constraints, nb_public, &ar, &bs1, &krs, &bs2));
+        GA_CHECK(prove_partial<C>(pk, slot, false, w, a, b, c, n_constraints, nb_public, &ar, &bs1, &krs, &bs2));
         char* o = reinterpret_cast<char*>(partials_out);
         host_store_jac<F1>(o, ar);
         host_store_jac<F1>(o + sizeof(Jac<F1>), bs1);
@@ -1699,14 +1743,15 @@ int ga_g16_witness_partial(ga_g16_pk* p, const void* w, uint64_t nb_public, void
         set_error("ga_g16_witness_partial: null argument");
         return GA_ERR_INVALID;
     }
+    SlotLease slot(pk->ctx);
     CtxLock g(pk->ctx);
     GA_DISPATCH_CURVE(pk->curve, {
         typedef Fe<typename C::FpP> F1;
         typedef Fe2<typename C::FpP> F2;
         XYZZ<F1> ar, bs1, krs;
         XYZZ<F2> bs2;
-        GA_CHECK(witness_upload(pk, w, nb_public));
-        GA_CHECK(witness_msms<C>(pk, nb_public, &ar, &bs1, &krs, &bs2));
+        GA_CHECK(witness_upload(pk, slot, w, nb_public));
+        GA_CHECK(witness_msms<C>(pk, slot, nb_public, &ar, &bs1, &krs, &bs2));
         char* o = reinterpret_cast<char*>(partials_out);
         host_store_jac<F1>(o, ar);
         host_store_jac<F1>(o + sizeof(Jac<F1>), bs1);
