@@ -39,3 +39,15 @@ if [[ $PASSES == *sq* ]]; then
   cat $OUT/${TAG}_sq_counters.txt
 fi
 rm -rf $OUT/*_stats $OUT/*_FETCH_SIZE $OUT/*_WRITE_SIZE $OUT/sq1 $OUT/sq2 $OUT/sq3   # keep the text summaries only (64 MiB merge limit)
+# plain bench lines for both curves (no profiler attached), for profiles/
+if [[ $PASSES == *bench* ]]; then
+  python bench.py > $OUT/${TAG}_bench_bn254_2p24.json 2> $OUT/bench_bn254.err
+  python bench.py --curve bls12-381 --plonk-log-n 0 > $OUT/${TAG}_bench_bls12381_2p24.json 2> $OUT/bench_bls.err
+  python - <<PY
+import json
+for c in ("bn254", "bls12381"):
+    d = json.load(open("$OUT/${TAG}_bench_%s_2p24.json" % c))
+    g = d["groth16"]
+    print(c, "msm", d["ms_per_step"], d["value"], "acc", d["stages_ms"]["msm_accumulate"]["avg_ms"], "| g16", g["ms_per_proof"], g["proofs_per_s"], g.get("matches_dlog"), "pipelined", g["pipelined"]["ms_per_proof"], g["pipelined"]["proofs_per_s"], "| cpu", d["cpu_baseline"]["value"], d["cpu_baseline"].get("groth16"))
+PY
+fi
