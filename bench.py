@@ -200,7 +200,13 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "msm_accumulate29_kernel" if use_table else "msm_accumulate_kernel", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 6), "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": acc["avg_ms"],
-                         "note": "MSM is integer-multiplier bound (SURVEY 8d): ~2.4e4 32-bit MADs per scalar-mul vs 96 B"},
+                         "note": "MSM is integer-multiplier bound (SURVEY 8d): ~2.4e4 32-bit MADs per scalar-mul vs 96 B",
+                         # "report achieved MAD/s fraction": v_mad_u64_u32 per mixed addition from the shipped ISA
+                         # (tools/isa_count.py) x (windows x n) additions per launch, against the issue rate ga_microbench measures
+                         "integer_multiplier": (lambda mads: {"v_mad_u64_u32_per_addition": mads, "additions_per_launch": nwin * n,
+                                                              "achieved_Tmad_per_s": round(mads * nwin * n / (acc["avg_ms"] * 1e-3) / 1e12, 2),
+                                                              "peak_Tmad_per_s": 30.0, "frac": round(mads * nwin * n / (acc["avg_ms"] * 1e-3) / 30e12, 3),
+                                                              "peak_source": "ga_microbench v_mad_u64_u32 issue rate (profiles/r01_e_microbench.json)"})(1467 if cid == 0 else 3543)},
             "stages_ms": stages,
         }
 

@@ -170,7 +170,9 @@ _default = None
 
 
 def load() -> Library:
+    """The in-tree HIP build.  GA_LIB_PATH points at another hipcc build of the same sources (A/B experiments with compile-time
+    knobs, tools/build_variant.sh); there is no CPU fallback either way."""
     global _default
     if _default is None:
-        _default = Library(DEFAULT_PATH)
+        _default = Library(os.environ.get("GA_LIB_PATH", DEFAULT_PATH))
     return _default

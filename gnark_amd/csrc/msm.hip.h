@@ -222,7 +222,10 @@ msm_accumulate29_kernel(const uint32_t* __restrict__ table, const uint32_t* __re
     typedef typename Lazy<F>::T T;
     typedef typename Lazy<F>::Params P;
     constexpr int NW = Lazy<F>::NW;
-    __shared__ uint32_t lds[4 * NW * Table29<F>::THREADS];
+#ifndef GA_ACC_LDS_PAD
+#define GA_ACC_LDS_PAD 0   // experiment: extra LDS words per workgroup, to lower the number of co-resident workgroups
+#endif
+    __shared__ uint32_t lds[4 * NW * Table29<F>::THREADS + GA_ACC_LDS_PAD];
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= max_tasks) return;
     const uint32_t key = task_key_sorted[t];
