@@ -8,7 +8,7 @@
 //                          (point, window): key = window*2^(c-1) + |digit|-1, value = point index | sign<<31.
 //                          Zero digits get key = SKIP (sorts last), so zero scalars and the constant-0 wires of a
 //                          witness cost nothing downstream.
-//   2. radix sort          of the pairs by key (hipcub DeviceRadixSort on the significant bits only) -- the utility
+//   2. radix sort          of the pairs by key (rocprim onesweep on the significant bits only, msm_sort_pairs) -- the utility
 //                          step; after it every bucket is a contiguous run of point indices.
 //   3. msm_offsets_kernel  bucket boundaries by binary search; msm_tasks_kernel splits buckets into tasks of at most
 //                          SEG points so that a hot bucket (witness values 0/1 make bucket 1 of window 0 huge) is spread
@@ -20,7 +20,9 @@
 //                          -- ~256 sequential doublings are latency-bound on a GPU lane and free on a host core, and the
 //                          multi-GPU window-sharded mode needs the window sums on the host anyway.
 #pragma once
+#include <cstring>
 #include <hipcub/hipcub.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include <string>
 
@@ -33,6 +35,35 @@ constexpr int GA_ACC29_MINW = 4;      // waves per SIMD requested for the G1 buc
 constexpr uint32_t MSM_SIGN = 0x80000000u;
 constexpr int MSM_HOT_TASKS = 16;     // buckets with more partials than this go to the wave-parallel merge
 constexpr int MSM_GROUP = 32;         // buckets per running-sum group in the window reduction
+
+// Onesweep configuration for the bucket keys of large MSMs (17..22 significant bits at c = 18..22): two 11-bit passes instead of
+// the library default's three 8-bit ones.  Measured on 12 x 2^24 pairs with 22-bit keys (tools/exp/sortbench.hip,
+// profiles/r02_e_sort_configs.txt): default 4.34 ms, 1024 threads x 21 items with 11-bit digits 3.47 ms; 512-thread blocks,
+// 12-bit digits (LDS) and more items per thread are slower or do not fit.
+typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                   rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 21>, rocprim::kernel_config<1024, 21>, 11,
+                                                                       rocprim::block_radix_rank_algorithm::match>>
+    MsmSortWide;
+
+// Sort (key, value) pairs on the low `end_bit` key bits, ping-ponging between the two buffer pairs (no third copy of the data);
+// on return keys2/vals2 point at the sorted arrays and keys/vals at the other pair.
+inline int msm_sort_pairs(Ctx* ctx, const std::string& tmp_name, uint32_t*& keys, uint32_t*& keys2, uint32_t*& vals, uint32_t*& vals2, size_t m,
+                          int end_bit, hipStream_t st) {
+    rocprim::double_buffer<uint32_t> dk(keys, keys2), dv(vals, vals2);
+    const bool wide = (end_bit + 10) / 11 < (end_bit + 7) / 8;   // fewer passes with 11-bit digits than with 8-bit ones
+    size_t tmp_bytes = 0;
+    void* tmp = nullptr;
+    if (wide) GA_HIP_CHECK((rocprim::radix_sort_pairs<MsmSortWide>(nullptr, tmp_bytes, dk, dv, m, 0, (unsigned)end_bit, st)));
+    else GA_HIP_CHECK((rocprim::radix_sort_pairs(nullptr, tmp_bytes, dk, dv, m, 0, (unsigned)end_bit, st)));
+    GA_CHECK(ctx->scratch_get(tmp_name.c_str(), tmp_bytes + 256, &tmp));
+    if (wide) GA_HIP_CHECK((rocprim::radix_sort_pairs<MsmSortWide>(tmp, tmp_bytes, dk, dv, m, 0, (unsigned)end_bit, st)));
+    else GA_HIP_CHECK((rocprim::radix_sort_pairs(tmp, tmp_bytes, dk, dv, m, 0, (unsigned)end_bit, st)));
+    keys2 = dk.current();
+    keys = dk.alternate();
+    vals2 = dv.current();
+    vals = dv.alternate();
+    return GA_OK;
+}
 
 // ---- 1. digits ------------------------------------------------------------------------------------
 template <class FrP>
@@ -617,10 +648,7 @@ int msm_prepare(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, in
         StageTimer tm(ctx, "msm_sort", st);
         int end_bit = 1;
         while ((1ull << end_bit) <= nb64) end_bit++;   // keys take values 0..nb (nb = SKIP)
-        size_t tmp_bytes = 0;
-        GA_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, (unsigned)m, 0, end_bit, st));
-        GA_CHECK(ctx->scratch_get(key("msm_sort_tmp").c_str(), tmp_bytes + 256, &tmp));
-        GA_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys2, vals, vals2, (unsigned)m, 0, end_bit, st));
+        GA_CHECK(msm_sort_pairs(ctx, key("msm_sort_tmp"), keys, keys2, vals, vals2, (size_t)m, end_bit, st));
     }
     {
         StageTimer tm(ctx, "msm_tasks", st);
