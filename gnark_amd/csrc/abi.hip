@@ -18,7 +18,15 @@ void set_error(const char* fmt, ...) {
 }
 const char* get_error() { return g_err; }
 
-int Ctx::scratch_get(const char* key, size_t bytes, void** out) {
+static thread_local int g_lane = 0;
+int current_lane() { return g_lane; }
+LaneScope::LaneScope(int lane) : prev(g_lane) { g_lane = lane; }
+LaneScope::~LaneScope() { g_lane = prev; }
+
+int Ctx::scratch_get(const char* base_key, size_t bytes, void** out) {
+    // every lane has its own namespace: a lane-1 proof never shares a buffer with the lane-0 work running beside it
+    const std::string lane_key = current_lane() ? std::string(base_key) + "@1" : std::string(base_key);
+    const char* key = lane_key.c_str();
     std::lock_guard<std::mutex> g(scratch_mu);
     auto it = scratch.find(key);
     if (it != scratch.end() && it->second.second >= bytes) {
@@ -52,6 +60,7 @@ void Tunables::read_env() {
     if (const char* e = getenv("GA_MSM_MAX_CHUNK")) msm_max_chunk = strtoull(e, nullptr, 10);
     if (const char* e = getenv("GA_REDUCE_LAZY_MIN")) reduce_lazy_min = strtoull(e, nullptr, 10);
     if (const char* e = getenv("GA_G16_SHARE_MIN_PCT")) g16_share_min_pct = atoi(e);
+    if (const char* e = getenv("GA_G16_LANES")) g16_lanes = atoi(e);
 }
 
 typedef CtxLock Lock;
@@ -165,7 +174,7 @@ int ga_ctx_create(int device, ga_ctx** out) {
     GA_HIP_CHECK(hipSetDevice(device));
     Ctx* c = new Ctx();
     c->device = device;
-    hipStream_t* slots[5] = {&c->stream, &c->copy_stream, &c->aux_stream, &c->slot_stream[0], &c->slot_stream[1]};
+    hipStream_t* slots[5] = {&c->stream, &c->copy_stream, &c->lane1_stream, &c->slot_stream[0], &c->slot_stream[1]};
     for (int k = 0; k < 5; k++) {
         hipError_t se = hipStreamCreateWithFlags(slots[k], hipStreamNonBlocking);
         if (se != hipSuccess) {
@@ -185,6 +194,7 @@ void ga_ctx_destroy(ga_ctx* h) {
     Ctx* c = reinterpret_cast<Ctx*>(h);
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
+    hipStreamSynchronize(c->lane1_stream);
     c->scratch_free_all();
     for (auto& s : c->stages) {
         hipEventDestroy(s.a);
@@ -192,7 +202,7 @@ void ga_ctx_destroy(ga_ctx* h) {
     }
     hipStreamDestroy(c->stream);
     hipStreamDestroy(c->copy_stream);
-    hipStreamDestroy(c->aux_stream);
+    hipStreamDestroy(c->lane1_stream);
     hipStreamDestroy(c->slot_stream[0]);
     hipStreamDestroy(c->slot_stream[1]);
     delete c;
@@ -246,10 +256,11 @@ int ga_copy_to_host(ga_ctx* h, void* dst, const void* src, size_t bytes) {
     return GA_OK;
 }
 
-int ga_sync(ga_ctx* h) {
+int ga_sync(ga_ctx* h) {   // (every entry point returns with its own work finished; this waits for both lanes' streams)
     Ctx* c = reinterpret_cast<Ctx*>(h);
     Lock l(c);
     GA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    GA_HIP_CHECK(hipStreamSynchronize(c->lane1_stream));
     return GA_OK;
 }
 

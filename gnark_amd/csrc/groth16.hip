@@ -901,7 +901,7 @@ static int witness_upload(G16Pk* pk, const SlotLease& slot, const void* w, uint6
     }
     void* d_w;
     GA_CHECK(ctx->scratch_get(slot.name("g16_w").c_str(), pk->nb_wires * 32, &d_w));
-    if (!up_stream) up_stream = ctx->stream;
+    if (!up_stream) up_stream = ctx->work_stream();
     // the wire range this shard reads: everything for an unsharded key, ~1/N of W for shard k of N (the gather lists of a
     // shard are contiguous pieces of the sorted wire lists); K's range depends on nbPublic
     uint64_t lo = pk->w_lo, hi = pk->w_hi;
@@ -913,7 +913,7 @@ static int witness_upload(G16Pk* pk, const SlotLease& slot, const void* w, uint6
     if (hi > pk->nb_wires) hi = pk->nb_wires;
     if (lo > hi) lo = hi;
     // (timed only on the main stream: a staging thread runs outside the device lock that guards the profiler's stage list)
-    StageTimer tm(up_stream == ctx->stream ? ctx : nullptr, "g16_h2d_w", up_stream);
+    StageTimer tm(up_stream == ctx->work_stream() ? ctx : nullptr, "g16_h2d_w", up_stream);
     if (hi > lo) GA_HIP_CHECK(hipMemcpyAsync((char*)d_w + lo * 32, (const char*)w + lo * 32, (hi - lo) * 32, hipMemcpyHostToDevice, up_stream));
     return GA_OK;
 }
@@ -929,7 +929,7 @@ static int witness_msms(G16Pk* pk, const SlotLease& slot, uint64_t nb_public, XY
                   (unsigned long long)nb_public, (unsigned long long)pk->full_len_k, (unsigned long long)pk->len_k_remove);
         return GA_ERR_INVALID;
     }
-    hipStream_t st = ctx->stream;
+    hipStream_t st = ctx->work_stream();
     void *d_w, *d_wa, *d_wb;
     GA_CHECK(ctx->scratch_get(slot.name("g16_w").c_str(), pk->nb_wires * 32, &d_w));
     GA_CHECK(ctx->scratch_get("g16_wa", pk->len_a * 32 + 32, &d_wa));
@@ -959,7 +959,7 @@ static int witness_msms(G16Pk* pk, const SlotLease& slot, uint64_t nb_public, XY
             *out = xyzz_inf<F1>();
             return GA_OK;
         }
-        GA_CHECK(msm_prepare_table_scalars<C>(ctx, scal, len, true, c, &prep, 0, false, lo, hi));
+        GA_CHECK(msm_prepare_table_scalars<C>(ctx, scal, len, true, c, &prep, 0, lo, hi));
         prep_live = true;
         return msm_table_device_reuse<C, GA_G1>(ctx, table, prep, out);
     };
@@ -971,7 +971,7 @@ static int witness_msms(G16Pk* pk, const SlotLease& slot, uint64_t nb_public, XY
             int lo, hi;
             share_of(pk->c_w, &lo, &hi);
             if (hi > lo) {
-                GA_CHECK(msm_prepare_table_scalars<C>(ctx, d_w, pk->nb_wires, true, pk->c_w, &prep_w, 1, false, lo, hi));
+                GA_CHECK(msm_prepare_table_scalars<C>(ctx, d_w, pk->nb_wires, true, pk->c_w, &prep_w, 1, lo, hi));
                 w_live = true;
             }
         }
@@ -1037,7 +1037,7 @@ static int z_msm(G16Pk* pk, const void* d_h_slice, XYZZ<Fe<typename C::FpP>>* ou
             return GA_OK;
         }
         MsmPrepared prep;
-        GA_CHECK(msm_prepare_table_scalars<C>(ctx, d_h_slice, pk->len_z, true, pk->c_z, &prep, 0, false, lo, hi));
+        GA_CHECK(msm_prepare_table_scalars<C>(ctx, d_h_slice, pk->len_z, true, pk->c_z, &prep, 0, lo, hi));
         return msm_table_device_reuse<C, GA_G1>(ctx, pk->d_z, prep, out);
     }
     return host_msm<C, GA_G1>(ctx, pk->d_z, d_h_slice, pk->len_z, true, out, pk->win_index, pk->win_count);
@@ -1106,6 +1106,7 @@ static int prove_partial(G16Pk* pk, const SlotLease& slot, bool preloaded, const
         GA_HIP_CHECK(hipEventCreateWithFlags(&abc.ev, hipEventDisableTiming));
         int up_rc = GA_OK;
         std::string up_err;
+        hipStream_t up = ctx->slot_stream[slot.slot];   // the slot's own copy stream: two proofs in flight do not queue their uploads
         std::thread uploader([&]() {
             if (hipSetDevice(ctx->device) != hipSuccess) {
                 up_rc = GA_ERR_HIP;
@@ -1113,10 +1114,10 @@ static int prove_partial(G16Pk* pk, const SlotLease& slot, bool preloaded, const
             }
             const void* src[3] = {a, b, c};
             void* dst[3] = {d_ha, d_hb, d_hc};
-            for (int k = 0; k < 3 && up_rc == GA_OK; k++) up_rc = h_upload(pk, src[k], n_constraints, dst[k], ctx->copy_stream);
+            for (int k = 0; k < 3 && up_rc == GA_OK; k++) up_rc = h_upload(pk, src[k], n_constraints, dst[k], up);
             hipError_t e = hipSuccess;
-            if (up_rc == GA_OK) e = hipEventRecord(abc.ev, ctx->copy_stream);
-            if (up_rc == GA_OK && e == hipSuccess) e = hipStreamSynchronize(ctx->copy_stream);
+            if (up_rc == GA_OK) e = hipEventRecord(abc.ev, up);
+            if (up_rc == GA_OK && e == hipSuccess) e = hipStreamSynchronize(up);
             if (up_rc != GA_OK) up_err = get_error();
             else if (e != hipSuccess) {
                 up_rc = GA_ERR_HIP;
@@ -1130,7 +1131,7 @@ static int prove_partial(G16Pk* pk, const SlotLease& slot, bool preloaded, const
             set_error("prove: uploading A,B,C failed: %s", up_err.c_str());
             return up_rc;
         }
-        GA_HIP_CHECK(hipStreamWaitEvent(ctx->stream, abc.ev, 0));
+        GA_HIP_CHECK(hipStreamWaitEvent(ctx->work_stream(), abc.ev, 0));
     }
     // ---- H (prove.go:134,346-389), then the MSM over pk.G1.Z (prove.go:225-227) ----------------------------
     GA_CHECK(ntt_domain_compute_h<C>(pk->dom, d_ha, d_hb, d_hc));   // h in d_ha, bit-reversed like pk.G1.Z
@@ -1652,27 +1653,37 @@ int ga_g16_prove(ga_g16_pk* p, const void* w, const void* a, const void* b, cons
                   "ga_g16_prove_partial + ga_g16_finish", pk->shard_index, pk->shard_count, pk->win_index, pk->win_count);
         return GA_ERR_STATE;
     }
-    // Two callers may be inside at once (two goroutines proving on one device): the one that finds the device busy stages its
-    // solution in the free input slot while the other proof computes, then takes the device; the host epilogue runs after the
-    // device has been released.  A single caller keeps the latency-optimal schedule (W first, A, B, C under the witness MSMs).
+    // Two callers may be inside at once (two goroutines proving on one device).  The first holds the device lock and works on
+    // lane 0 (the context's main stream).  The second finds the device busy and computes its proof on lane 1 -- own stream, own
+    // scratch namespace -- so the two proofs run CONCURRENTLY: uploads hide behind the other proof's kernels and the kernels
+    // interleave (sorts / transforms / reduction tails of one proof fill the other's bucket kernel).  When lane 1 is taken as
+    // well (the device lock was held by some other entry point), or while the profiler records stages, the caller stages its
+    // solution in its input slot and queues for the device as before.  The host epilogue always runs outside the device lock.
     Ctx* ctx = pk->ctx;
     SlotLease slot(ctx);
     bool preloaded = false;
+    int lane = 0;
     std::unique_lock<std::mutex> dev(ctx->mu, std::try_to_lock);
-    if (!dev.owns_lock()) {
-        hipSetDevice(ctx->device);
-        GA_CHECK(preload_solution(pk, slot, w, a, b, c, n_constraints, nb_public));
-        preloaded = true;
-        dev.lock();
-    }
+    std::unique_lock<std::mutex> lane1(ctx->lane_mu, std::defer_lock);
     hipSetDevice(ctx->device);
-    ctx->tun.read_env();
+    if (!dev.owns_lock()) {
+        if (!ctx->profiling && ctx->tun.g16_lanes > 1 && lane1.try_lock()) {
+            lane = 1;
+        } else {
+            GA_CHECK(preload_solution(pk, slot, w, a, b, c, n_constraints, nb_public));
+            preloaded = true;
+            dev.lock();
+        }
+    }
+    LaneScope on_lane(lane);
+    if (lane == 0) ctx->tun.read_env();
     GA_DISPATCH_CURVE(pk->curve, {
         XYZZ<Fe<typename C::FpP>> ar, bs1, krs;
         XYZZ<Fe2<typename C::FpP>> bs2;
         GA_CHECK(prove_partial<C>(pk, slot, preloaded, w, a, b, c, n_constraints, nb_public, &ar, &bs1, &krs, &bs2));
         const bool profiling = ctx->profiling;
-        if (!profiling) dev.unlock();   // the stage list of the profiler is guarded by the device lock
+        if (lane == 0 && !profiling) dev.unlock();   // the stage list of the profiler is guarded by the device lock
+        if (lane == 1) lane1.unlock();
         return finish<C>(pk, ar, bs1, krs, bs2, r, s, proof_out);
     });
     return GA_OK;

@@ -584,8 +584,8 @@ msm_segment_sum_kernel(const XYZZ<F>* __restrict__ in, uint32_t seg_len, XYZZ<F>
 
 template <class FrP>
 int msm_prepare(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, int c, int win_lo, int win_hi, bool table,
-                MsmPrepared* P, int slot = 0, hipStream_t st = nullptr) {
-    if (!st) st = ctx->stream;
+                MsmPrepared* P, int slot = 0) {
+    hipStream_t st = ctx->work_stream();
     const std::string sfx = slot ? "#1" : "";
     auto key = [&](const char* k) { return std::string(k) + sfx; };
     const int nwin = FrP::BITS / c + 1;
@@ -723,7 +723,7 @@ int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, X
     GA_CHECK(ctx->scratch_get("msm_gsum", (uint64_t)total_groups * sizeof(XYZZ<F>), (void**)&gsum));
     GA_CHECK(ctx->scratch_get("msm_gsum2", ((uint64_t)total_groups / 1024 + 64) * sizeof(XYZZ<F>), (void**)&gsum2));
     GA_CHECK(ctx->scratch_get("msm_wsum", (uint64_t)nsets * sizeof(XYZZ<F>), (void**)&wsum));
-    hipStream_t st = ctx->stream;
+    hipStream_t st = ctx->work_stream();
     GA_HIP_CHECK(hipMemsetAsync(hot_count, 0, 4, st));
     if (P.table) {
         uint32_t *redo_list, *redo_count;
@@ -877,10 +877,9 @@ int msm_table_device_reuse(Ctx* ctx, const void* d_table, const MsmPrepared& P, 
 
 // group-independent preparation callable from translation units that do not include this header (groth16.hip)
 template <class C>
-int msm_prepare_table_scalars(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, int c, MsmPrepared* P, int slot,
-                              bool on_aux, int win_lo, int win_hi) {
-    return msm_prepare<typename C::FrP>(ctx, d_scalars, n, scalars_mont, c, win_lo, win_hi, true, P, slot,
-                                        on_aux ? ctx->aux_stream : ctx->stream);
+int msm_prepare_table_scalars(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, int c, MsmPrepared* P, int slot, int win_lo,
+                              int win_hi) {
+    return msm_prepare<typename C::FrP>(ctx, d_scalars, n, scalars_mont, c, win_lo, win_hi, true, P, slot);
 }
 
 template <class C, int G>
@@ -895,7 +894,7 @@ int msm_table_build(Ctx* ctx, const void* d_bases, size_t n, int c, void* d_tabl
     if (n == 0) return GA_OK;
     const int nwin = C::FrP::BITS / c + 1;
     StageTimer tm(ctx, "msm_table_build");
-    hipLaunchKernelGGL((msm_table29_kernel<F>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream,
+    hipLaunchKernelGGL((msm_table29_kernel<F>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->work_stream(),
                        (const Affine<F>*)d_bases, (uint64_t)n, c, nwin, (uint32_t*)d_table);
     GA_KERNEL_CHECK();
     return GA_OK;

@@ -392,17 +392,17 @@ int ntt_run(Domain* d, uint32_t* d_data, bool inverse, bool dit, const NttScale&
         StageTimer st(ctx, dit ? "ntt_pass_dit" : "ntt_pass_dif");
         if (d->logn >= 2) {
             if (dit)
-                hipLaunchKernelGGL((ntt_pass29r4_kernel<FrP, true>), dim3((unsigned)tiles), dim3(NTT_THREADS), 0, ctx->stream,
+                hipLaunchKernelGGL((ntt_pass29r4_kernel<FrP, true>), dim3((unsigned)tiles), dim3(NTT_THREADS), 0, ctx->work_stream(),
                                    d_data, src, tw, d->logn, lg_tile, ps.s_lo, ps.K, ps.lc, pre, post);
             else
-                hipLaunchKernelGGL((ntt_pass29r4_kernel<FrP, false>), dim3((unsigned)tiles), dim3(NTT_THREADS), 0, ctx->stream,
+                hipLaunchKernelGGL((ntt_pass29r4_kernel<FrP, false>), dim3((unsigned)tiles), dim3(NTT_THREADS), 0, ctx->work_stream(),
                                    d_data, src, tw, d->logn, lg_tile, ps.s_lo, ps.K, ps.lc, pre, post);
         } else {   // n = 2: a single stage, the one-stage-per-round-trip pass
             if (dit)
-                hipLaunchKernelGGL((ntt_pass29_kernel<FrP, true>), dim3((unsigned)tiles), dim3(NTT_THREADS), 0, ctx->stream,
+                hipLaunchKernelGGL((ntt_pass29_kernel<FrP, true>), dim3((unsigned)tiles), dim3(NTT_THREADS), 0, ctx->work_stream(),
                                    d_data, src, tw, d->logn, lg_tile, ps.s_lo, ps.K, ps.lc, pre, post);
             else
-                hipLaunchKernelGGL((ntt_pass29_kernel<FrP, false>), dim3((unsigned)tiles), dim3(NTT_THREADS), 0, ctx->stream,
+                hipLaunchKernelGGL((ntt_pass29_kernel<FrP, false>), dim3((unsigned)tiles), dim3(NTT_THREADS), 0, ctx->work_stream(),
                                    d_data, src, tw, d->logn, lg_tile, ps.s_lo, ps.K, ps.lc, pre, post);
         }
         GA_KERNEL_CHECK();
@@ -467,7 +467,7 @@ int ntt_compute_h_combine(Domain* d, uint32_t* d_a, const uint32_t* d_b, const u
         StageTimer st(ctx, "h_pointwise");
         NttScale den = scale_const(d->den);
         unsigned blocks = d->logn == 0 ? 1u : (unsigned)((d->n + 255) / 256);
-        hipLaunchKernelGGL((ntt_pointwise_h_kernel<FrP>), dim3(blocks), dim3(d->logn == 0 ? 64 : 256), 0, ctx->stream, d_a, d_b, d_c, d->n, den);
+        hipLaunchKernelGGL((ntt_pointwise_h_kernel<FrP>), dim3(blocks), dim3(d->logn == 0 ? 64 : 256), 0, ctx->work_stream(), d_a, d_b, d_c, d->n, den);
         GA_KERNEL_CHECK();
     }
     if (d->logn == 0) return GA_OK;
@@ -537,12 +537,12 @@ int domain_init(Ctx* ctx, Domain* d, int curve, uint64_t n) {
         GA_HIP_CHECK(hipMalloc((void**)&d->d_tw, half_n * 32));
         GA_HIP_CHECK(hipMalloc((void**)&d->d_tw_inv, half_n * 32));
         unsigned blocks = (unsigned)((half_n + 255) / 256);
-        hipLaunchKernelGGL((ntt_twiddle_kernel<FrP>), dim3(blocks), dim3(256), 0, ctx->stream, d->d_tw,
+        hipLaunchKernelGGL((ntt_twiddle_kernel<FrP>), dim3(blocks), dim3(256), 0, ctx->work_stream(), d->d_tw,
                            (const uint32_t*)d_p2, half_n, nb, d->lazy ? 1 : 0);
-        hipLaunchKernelGGL((ntt_twiddle_kernel<FrP>), dim3(blocks), dim3(256), 0, ctx->stream, d->d_tw_inv,
+        hipLaunchKernelGGL((ntt_twiddle_kernel<FrP>), dim3(blocks), dim3(256), 0, ctx->work_stream(), d->d_tw_inv,
                            (const uint32_t*)d_p2 + 32 * 8, half_n, nb, d->lazy ? 1 : 0);
         GA_KERNEL_CHECK();
-        GA_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        GA_HIP_CHECK(hipStreamSynchronize(ctx->work_stream()));
     }
     // coset power tables (host-computed: <= 2^12 + n/2^12 entries each)
     uint64_t nlo = 1ull << NTT_POW_LO_BITS;

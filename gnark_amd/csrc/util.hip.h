@@ -88,7 +88,7 @@ template <class C, int G>
 int util_gen_bases(Ctx* ctx, uint64_t seed, size_t n, void* d_bases, void* d_dlogs) {
     if (n == 0) return GA_OK;
     StageTimer tm(ctx, "gen_bases");
-    hipLaunchKernelGGL((gen_bases_kernel<C, G>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, seed, (uint64_t)n,
+    hipLaunchKernelGGL((gen_bases_kernel<C, G>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->work_stream(), seed, (uint64_t)n,
                        d_bases, (uint32_t*)d_dlogs);
     GA_KERNEL_CHECK();
     return GA_OK;
@@ -97,7 +97,7 @@ int util_gen_bases(Ctx* ctx, uint64_t seed, size_t n, void* d_bases, void* d_dlo
 template <class C>
 int util_gen_scalars(Ctx* ctx, uint64_t seed, size_t n, void* d_scalars) {
     if (n == 0) return GA_OK;
-    hipLaunchKernelGGL((gen_scalars_kernel<C>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, seed, (uint64_t)n,
+    hipLaunchKernelGGL((gen_scalars_kernel<C>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->work_stream(), seed, (uint64_t)n,
                        (uint32_t*)d_scalars);
     GA_KERNEL_CHECK();
     return GA_OK;
@@ -109,12 +109,12 @@ int util_fr_dot(Ctx* ctx, const void* d_a, const void* d_b, size_t n, void* h_ou
     const unsigned blocks = 512;
     uint32_t* d_part;
     GA_CHECK(ctx->scratch_get("fr_dot_partial", blocks * 32, (void**)&d_part));
-    hipLaunchKernelGGL((fr_dot_kernel<C>), dim3(blocks), dim3(256), 0, ctx->stream, (const uint32_t*)d_a, (const uint32_t*)d_b,
+    hipLaunchKernelGGL((fr_dot_kernel<C>), dim3(blocks), dim3(256), 0, ctx->work_stream(), (const uint32_t*)d_a, (const uint32_t*)d_b,
                        (uint64_t)n, d_part);
     GA_KERNEL_CHECK();
     std::vector<uint32_t> part(blocks * 8);
-    GA_HIP_CHECK(hipMemcpyAsync(part.data(), d_part, blocks * 32, hipMemcpyDeviceToHost, ctx->stream));
-    GA_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    GA_HIP_CHECK(hipMemcpyAsync(part.data(), d_part, blocks * 32, hipMemcpyDeviceToHost, ctx->work_stream()));
+    GA_HIP_CHECK(hipStreamSynchronize(ctx->work_stream()));
     Fe<P> acc = fe_zero<P>();
     for (unsigned b = 0; b < blocks; b++) {
         Fe<P> v;
@@ -128,7 +128,7 @@ int util_fr_dot(Ctx* ctx, const void* d_a, const void* d_b, size_t n, void* h_ou
 template <class C>
 int util_fr_vec_mul(Ctx* ctx, const void* d_a, const void* d_b, size_t n, void* d_out) {
     if (n == 0) return GA_OK;
-    hipLaunchKernelGGL((fr_vec_mul_kernel<C>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)d_a,
+    hipLaunchKernelGGL((fr_vec_mul_kernel<C>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->work_stream(), (const uint32_t*)d_a,
                        (const uint32_t*)d_b, (uint64_t)n, (uint32_t*)d_out);
     GA_KERNEL_CHECK();
     return GA_OK;
@@ -138,7 +138,7 @@ template <class C>
 int util_gather_fr(Ctx* ctx, void* d_dst, const void* d_src, const uint32_t* d_idx, size_t n) {
     if (n == 0) return GA_OK;
     StageTimer tm(ctx, "gather_fr");
-    hipLaunchKernelGGL((gather_fr_kernel<C>), dim3((unsigned)((2 * n + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t*)d_dst,
+    hipLaunchKernelGGL((gather_fr_kernel<C>), dim3((unsigned)((2 * n + 255) / 256)), dim3(256), 0, ctx->work_stream(), (uint32_t*)d_dst,
                        (const uint32_t*)d_src, d_idx, (uint64_t)n);
     GA_KERNEL_CHECK();
     return GA_OK;
