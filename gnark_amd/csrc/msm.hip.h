@@ -795,7 +795,7 @@ int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, X
     }
     int nbits = 0;
     while ((1u << nbits) < groups_per_win) nbits++;
-    const uint32_t sg = 1024;
+    const uint32_t sg = 1024;   // (256 / 128 measured: msm_reduce 1.05 -> 1.13 / 1.34 ms, the second-level sums grow)
     const uint32_t chunk_len = groups_per_win > sg ? sg : groups_per_win;   // powers of two
     const uint32_t chunks = groups_per_win / chunk_len;
     int log_chunk = 0;
