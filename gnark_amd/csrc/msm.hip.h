@@ -327,22 +327,62 @@ msm_accumulate29_redo_kernel(const uint32_t* __restrict__ table, const uint32_t*
     }
 }
 
-// table29[w*n + i] = [2^(c*w)] P_i in the unpacked format
+// table29[w*n + i] = [2^(c*w)] P_i in the unpacked format.
+// A lane carries TABLE_BATCH points through the doubling chain together and brings them back to affine with ONE field inversion
+// per window step (Montgomery's trick on zz*zzz): the inversion (~350 products) was 2/3 of the work of the one-point-per-lane
+// version (11 of them against 242 doublings per point); lanes of a wave cannot share one (SIMD: 64 inversions cost what one
+// costs), so the batch has to be inside the lane.
+template <class F> struct TableBatch { static constexpr int K = sizeof(XYZZ<F>) <= 128 ? 4 : 2; };
+
 template <class F>
 __global__ void __launch_bounds__(64)
 msm_table29_kernel(const Affine<F>* __restrict__ bases, uint64_t n, int c, int nwin, uint32_t* __restrict__ table) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Affine<F> a = load_pod<Affine<F>>(&bases[i]);
-    XYZZ<F> p = to_xyzz(a);
+    constexpr int K = TableBatch<F>::K;
+    const uint64_t lanes = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n) return;   // point q of a lane is gid + q*lanes: nothing to do when even q = 0 is out of range
+    Affine<F> a[K];
+    XYZZ<F> p[K];
+    bool live[K];
+#pragma unroll
+    for (int q = 0; q < K; q++) {
+        const uint64_t i = gid + q * lanes;
+        live[q] = i < n;
+        a[q] = live[q] ? load_pod<Affine<F>>(&bases[i]) : Affine<F>{FieldTraits<F>::zero(), FieldTraits<F>::zero()};
+        p[q] = to_xyzz(a[q]);
+    }
     for (int w = 0; w < nwin; w++) {
         if (w > 0) {
-            for (int k = 0; k < c; k++) p = dbl(p);
-            a = to_affine(p);
-            p = to_xyzz(a);
+#pragma unroll
+            for (int q = 0; q < K; q++)
+                for (int k = 0; k < c; k++) p[q] = dbl(p[q]);
+            // batch to affine: t_q = zz_q * zzz_q (1 for a point at infinity, which stays (0,0)), one inversion of their product
+            F t[K], pre[K];
+#pragma unroll
+            for (int q = 0; q < K; q++) {
+                t[q] = is_inf(p[q]) ? FieldTraits<F>::one() : mul(p[q].zz, p[q].zzz);
+                pre[q] = q == 0 ? t[0] : mul(pre[q - 1], t[q]);
+            }
+            F run = inv(pre[K - 1]);
+#pragma unroll
+            for (int q = K - 1; q >= 0; q--) {
+                const F it = q > 0 ? mul(run, pre[q - 1]) : run;   // 1 / t_q
+                if (q > 0) run = mul(run, t[q]);
+                if (is_inf(p[q])) {
+                    a[q] = Affine<F>{FieldTraits<F>::zero(), FieldTraits<F>::zero()};
+                } else {
+                    a[q].x = mul(p[q].x, mul(it, p[q].zzz));   // X / zz
+                    a[q].y = mul(p[q].y, mul(it, p[q].zz));    // Y / zzz
+                }
+                p[q] = to_xyzz(a[q]);
+            }
         }
-        Affine<F> h{Lazy<F>::hat_packed(a.x), Lazy<F>::hat_packed(a.y)};
-        store_pod(table + ((uint64_t)w * n + i) * Table29<F>::WORDS, h);
+#pragma unroll
+        for (int q = 0; q < K; q++) {
+            if (!live[q]) continue;
+            Affine<F> h{Lazy<F>::hat_packed(a[q].x), Lazy<F>::hat_packed(a[q].y)};
+            store_pod(table + ((uint64_t)w * n + gid + q * lanes) * Table29<F>::WORDS, h);
+        }
     }
 }
 
@@ -748,7 +788,7 @@ int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, X
         GA_CHECK(ctx->scratch_get("msm_redo_count", 256, (void**)&redo_count));
         GA_HIP_CHECK(hipMemsetAsync(redo_count, 0, 4, st));
         StageTimer tm(ctx, "msm_accumulate");
-        hipLaunchKernelGGL((msm_table29_kernel<F>), dim3((unsigned)((P.n + 63) / 64)), dim3(64), 0, st, (const Affine<F>*)d_bases,
+        hipLaunchKernelGGL((msm_table29_kernel<F>), dim3((unsigned)(((P.n + TableBatch<F>::K - 1) / TableBatch<F>::K + 63) / 64)), dim3(64), 0, st, (const Affine<F>*)d_bases,
                            (uint64_t)P.n, P.c, 1, hat);
         constexpr unsigned AT = Table29<F>::THREADS;
         hipLaunchKernelGGL((msm_accumulate29_kernel<F>), dim3((unsigned)((P.max_tasks + AT - 1) / AT)), dim3(AT), 0, st,
@@ -894,7 +934,7 @@ int msm_table_build(Ctx* ctx, const void* d_bases, size_t n, int c, void* d_tabl
     if (n == 0) return GA_OK;
     const int nwin = C::FrP::BITS / c + 1;
     StageTimer tm(ctx, "msm_table_build");
-    hipLaunchKernelGGL((msm_table29_kernel<F>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->work_stream(),
+    hipLaunchKernelGGL((msm_table29_kernel<F>), dim3((unsigned)(((n + TableBatch<F>::K - 1) / TableBatch<F>::K + 63) / 64)), dim3(64), 0, ctx->work_stream(),
                        (const Affine<F>*)d_bases, (uint64_t)n, c, nwin, (uint32_t*)d_table);
     GA_KERNEL_CHECK();
     return GA_OK;
