@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--groth16-proofs", type=int, default=int(os.environ.get("GA_BENCH_PROOFS", "5")))
     ap.add_argument("--no-check", action="store_true", help="skip the oracle checks of the Groth16 / PLONK legs (outside the timed regions)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipelined", action="store_true", help="skip the two-caller Groth16 leg (rocprofv3 passes: concurrent proofs stretch per-kernel durations)")
     ap.add_argument("--plonk-log-n", type=int, default=int(os.environ.get("GA_BENCH_PLONK_LOGN", "22")), help="0 disables the PLONK leg")
     ap.add_argument("--curve", default="bn254")
     ap.add_argument("--partition", default=os.environ.get("GA_BENCH_PARTITION", "range"), choices=["range", "window"],
@@ -270,6 +271,8 @@ def main():
         def prover(k):
             for _ in range(per_thread):
                 pipe_out[k].append(groth16.Prove(pk, sol, nb_public, r, s).raw())
+        if args.no_pipelined:
+            per_thread = 0
         groth16.Prove(pk, sol, nb_public, r, s)
         ctx.sync()
         tp0 = time.perf_counter()
@@ -291,7 +294,7 @@ def main():
                           "computeH_ms": round(ntt_ms, 3),
                           "computeH_hbm_frac": round(448.0 * n / (ntt_ms * 1e-3) / 8e12, 5) if ntt_ms > 0 else None,
                           "proof_sha": __import__("hashlib").sha256(proof.WriteTo()).hexdigest()[:16],
-                          "pipelined": {"proofs_per_s": round(2 * per_thread / pipe_el, 4), "ms_per_proof": round(pipe_el * 1e3 / (2 * per_thread), 2),
+                          "pipelined": None if per_thread == 0 else {"proofs_per_s": round(2 * per_thread / pipe_el, 4), "ms_per_proof": round(pipe_el * 1e3 / (2 * per_thread), 2),
                                         "proofs": 2 * per_thread, "host_threads": 2, "same_proof_bytes": pipe_same,
                                         "how": "two host threads call ga_g16_prove on one key: two proofs in flight on two lanes (streams) of one context; every proof compared with the single-caller proof"},
                           "stages_ms": {k: {"launches": v["launches"], "total_ms": round(v["total_ms"] / args.groth16_proofs, 4), "avg_ms": v["avg_ms"]}

@@ -8,7 +8,7 @@ OUT=gpurun_out/prof_r2
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp && cd $GRAFT_REPO_ROOT
-BENCH="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-check --groth16-proofs 1"
+BENCH="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-check --groth16-proofs 1 --no-pipelined"
 run() {  # name, rocprof args..., -- cmd
   name=$1; shift
   timeout 900 rocprofv3 "$@" > $OUT/$name.log 2>&1 || echo "rocprofv3 $name failed (rc=$?)"
