@@ -726,6 +726,52 @@ def test_emu_groth16_builder_errors(emu_ctx):
     lib.ga_g16_builder_destroy(b2)                                                               # abandon: frees the staged buffers
 
 
+# ---- two proofs in flight on one context (lanes) with DIFFERENT solutions ---------------------------------------------------------
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("precompute", [1, -1], ids=["tables", "no-tables"])
+def test_emu_groth16_two_callers_distinct_solutions(emu_ctx, c, precompute, logn=7, rounds=3):
+    """Two host threads prove DIFFERENT solutions on one key at the same time (the second caller runs on lane 1 of the context,
+    groth16.hip ga_g16_prove): every proof must equal the proof of ITS solution computed alone -- identical inputs on both
+    threads would hide a buffer shared between the lanes.  A third thread keeps the context busy with transforms."""
+    import threading
+    from gnark_amd import synth
+    inst = synth.make_instance(emu_ctx, c.name, logn, 0x4C41, nb_constraints=(1 << logn) - 3)
+    others = [synth.make_instance(emu_ctx, c.name, logn, 0x4C42 + k, nb_constraints=(1 << logn) - 3, want_dlogs=False) for k in range(2)]
+    sols = [inst.solution] + [o.solution for o in others]          # same key (inst's), three unrelated solutions
+    rs = [(inst.r, inst.s)] + [(o.r, o.s) for o in others]
+    pk = inst.proving_key(emu_ctx, precompute=precompute)
+    dom = fft.Domain(emu_ctx, c.name, inst.n)
+    try:
+        want = [groth16.Prove(pk, sol, inst.nb_public, r, s_).raw() for sol, (r, s_) in zip(sols, rs)]
+        assert not np.array_equal(want[0], want[1]) and not np.array_equal(want[1], want[2])
+        fft_in = np.zeros((inst.n, 4), dtype=np.uint64)
+        fft_in[: sols[0].A.shape[0]] = sols[0].A
+        fft_want = dom.FFT(fft_in, fft.DIF)
+        bad = []
+
+        def prover(tid):
+            for k in range(rounds):
+                j = (tid + k) % len(sols)
+                got = groth16.Prove(pk, sols[j], inst.nb_public, rs[j][0], rs[j][1]).raw()
+                if not np.array_equal(got, want[j]):
+                    bad.append((tid, k, j))
+
+        def transformer():
+            for _ in range(rounds):
+                if not np.array_equal(dom.FFT(fft_in, fft.DIF), fft_want):
+                    bad.append(("fft",))
+
+        th = [threading.Thread(target=prover, args=(t,)) for t in range(3)] + [threading.Thread(target=transformer)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not bad, bad
+    finally:
+        dom.close()
+        pk.FreeGPUResources()
+
+
 # ---- one proof over several devices from one process (ga_g16_prove_multi) ------------------------------------------------------
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
 @pytest.mark.parametrize("nshards", [2, 3, 5])

@@ -535,6 +535,14 @@ def test_groth16_staged_builder(gpu_ctx, c, precompute):
     cases.test_emu_groth16_staged_builder(gpu_ctx, c, precompute)
 
 
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("precompute", [1, -1], ids=["tables", "no-tables"])
+def test_groth16_two_callers_distinct_solutions(gpu_ctx, c, precompute):
+    """three host threads proving three different solutions on one key + a fourth running transforms on the same context, at
+    2^16 constraints: every proof equals the proof of its own solution computed alone (lanes do not share buffers)"""
+    cases.test_emu_groth16_two_callers_distinct_solutions(gpu_ctx, c, precompute, logn=16, rounds=6)
+
+
 def test_groth16_builder_errors(gpu_ctx):
     cases.test_emu_groth16_builder_errors(gpu_ctx)
 
