@@ -141,6 +141,27 @@ struct CtxLock {
     }
 };
 
+// Device access for an entry point that may run BESIDE another one on the same context (ga_g16_h_chain / ga_g16_h_combine next to
+// the witness MSMs of a sharded proof): lane 0 under Ctx::mu when the device is free, lane 1 under Ctx::lane_mu when lane 0 is busy,
+// otherwise wait for lane 0.  (ga_g16_prove has its own variant that pre-stages the solution before it waits.)
+struct LaneLock {
+    std::unique_lock<std::mutex> dev, l1;
+    int lane = 0;
+    LaneScope* scope = nullptr;
+    explicit LaneLock(Ctx* c) : dev(c->mu, std::try_to_lock), l1(c->lane_mu, std::defer_lock) {
+        hipSetDevice(c->device);
+        if (!dev.owns_lock()) {
+            if (!c->profiling && c->tun.g16_lanes > 1 && l1.try_lock()) lane = 1;
+            else dev.lock();
+        }
+        if (lane == 0) c->tun.read_env();
+        scope = new LaneScope(lane);
+    }
+    ~LaneLock() { delete scope; }
+    LaneLock(const LaneLock&) = delete;
+    LaneLock& operator=(const LaneLock&) = delete;
+};
+
 // ownership of one input slot of a context for the duration of a proof
 struct SlotLease {
     Ctx* ctx;

@@ -1778,10 +1778,10 @@ int ga_g16_h_chain(ga_g16_pk* p, const void* v, uint64_t n_constraints, void* ou
         set_error("ga_g16_h_chain: null argument");
         return GA_ERR_INVALID;
     }
-    CtxLock g(pk->ctx);
-    GA_CHECK(h_upload(pk, v, n_constraints, out_dev, pk->ctx->stream));
+    LaneLock g(pk->ctx);   // beside the witness MSMs of the same shard when the caller runs them from another thread
+    GA_CHECK(h_upload(pk, v, n_constraints, out_dev, pk->ctx->work_stream()));
     GA_DISPATCH_CURVE(pk->curve, GA_CHECK(ntt_domain_h_chain<C>(pk->dom, out_dev)));
-    GA_HIP_CHECK(hipStreamSynchronize(pk->ctx->stream));   // the buffer is handed to another stream / device next
+    GA_HIP_CHECK(hipStreamSynchronize(pk->ctx->work_stream()));   // the buffer is handed to another stream / device next
     return GA_OK;
 }
 
@@ -1791,9 +1791,9 @@ int ga_g16_h_combine(ga_g16_pk* p, void* a_dev, const void* b_dev, const void* c
         set_error("ga_g16_h_combine: null argument");
         return GA_ERR_INVALID;
     }
-    CtxLock g(pk->ctx);
+    LaneLock g(pk->ctx);
     GA_DISPATCH_CURVE(pk->curve, GA_CHECK(ntt_domain_h_combine<C>(pk->dom, a_dev, b_dev, c_dev)));
-    GA_HIP_CHECK(hipStreamSynchronize(pk->ctx->stream));
+    GA_HIP_CHECK(hipStreamSynchronize(pk->ctx->work_stream()));
     return GA_OK;
 }
 

@@ -124,9 +124,10 @@ def groth16_prove_sharded(pk, solution, nb_public: int, r, s, dist, device=None,
     """One proof over a key sharded by base-point range (groth16.ProvingKey(..., shard=(rank, world))), one process per GPU.
 
     Serial work is not replicated: every rank uploads only the wire range of W its bases cover; the three chains of computeH
-    (FFT_coset(iFFT(.)) of the solver's A, B, C) run on ranks 0, 1, 2 -- three uploads over three PCIe links -- and travel to rank 0
-    over xGMI (send/recv, 32 B x n each); rank 0 finishes h and scatters the slices (32 B x n / world per peer); every rank runs
-    the MSM over its slice of pk.G1.Z; one all_gather of 3 G1Jac + 1 G2Jac per rank; every rank finishes identically.
+    (FFT_coset(iFFT(.)) of the solver's A, B, C) run on ranks 0, 1, 2 -- three uploads over three PCIe links, on a helper thread
+    BESIDE the rank's witness MSMs (second lane of the context) -- and travel to rank 0 over xGMI (send/recv, 32 B x n each);
+    rank 0 finishes h and scatters the slices (32 B x n / world per peer); every rank runs the MSM over its slice of pk.G1.Z;
+    one all_gather of 3 G1Jac + 1 G2Jac per rank; every rank finishes identically.
     replicate_h=True keeps the round-1 scheme (every rank recomputes h) for comparison."""
     from . import groth16
     world = 1 if dist is None else dist.get_world_size()
@@ -135,6 +136,7 @@ def groth16_prove_sharded(pk, solution, nb_public: int, r, s, dist, device=None,
         if world > 1:
             part = groth16.SumPartials(pk.curve, _all_gather_u64(part, dist, device), lib=pk.ctx.lib)
         return groth16.Finish(pk, part, r, s)
+    import threading
     import torch
     rank = dist.get_rank()
     lay = groth16.ShardLayout(pk)
@@ -143,46 +145,65 @@ def groth16_prove_sharded(pk, solution, nb_public: int, r, s, dist, device=None,
     sync = (lambda: torch.cuda.synchronize(dev)) if device is not None else (lambda: None)
     owner = [0, 1, 2 if world >= 3 else 0]
     vecs = [solution.A, solution.B, solution.C]
-    part = groth16.WitnessPartial(pk, solution.W, nb_public)
+    windowed = lay["win_count"] > 1          # window-sharded key: every rank needs all of h
+    share = (n - 1 + world - 1) // world + 1
     # device buffers as torch tensors, so that the collective library can move them; the prover library gets raw pointers
     bufs = {}
     for k in range(3):
         if rank == owner[k] or rank == 0:
             bufs[k] = torch.empty((n, 4), dtype=torch.int64, device=dev)
+    if windowed and 0 not in bufs:
+        bufs[0] = torch.empty((n, 4), dtype=torch.int64, device=dev)
     sync()
-    for k in range(3):
-        if rank == owner[k]:
-            groth16.HChain(pk, vecs[k], bufs[k].data_ptr())
-    for k in range(3):                       # b and c travel to rank 0
-        if owner[k] != 0:
-            if rank == owner[k]:
-                _send(bufs[k], 0, dist)
-            elif rank == 0:
-                _recv(bufs[k], owner[k], dist)
-    if lay["win_count"] > 1:                 # window-sharded key: every rank needs all of h -> broadcast from rank 0
-        if rank != 0 and 0 not in bufs:
-            bufs[0] = torch.empty((n, 4), dtype=torch.int64, device=dev)
-        if rank == 0:
-            sync()
-            groth16.HCombine(pk, bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr())
+    state = {"pieces": None, "error": None}
+
+    def h_side():
+        """the H side of the proof, beside the witness MSMs of the same rank: ga_g16_h_chain / ga_g16_h_combine take the context's
+        second lane when the device is busy with the witness MSMs (common.hip.h LaneLock), so the 512 MiB upload, the two
+        transforms and the xGMI hops of b and c hide behind them"""
+        try:
+            if device is not None:
+                torch.cuda.set_device(dev)   # the current device is per thread
+            for k in range(3):
+                if rank == owner[k]:
+                    groth16.HChain(pk, vecs[k], bufs[k].data_ptr())
+            for k in range(3):                       # b and c travel to rank 0
+                if owner[k] != 0:
+                    if rank == owner[k]:
+                        _send(bufs[k], 0, dist)
+                    elif rank == 0:
+                        _recv(bufs[k], owner[k], dist)
+            if rank == 0:
+                sync()
+                groth16.HCombine(pk, bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr())
+                if not windowed:                     # one equally sized (padded) slice per rank
+                    pieces = []
+                    for q in range(world):
+                        lo, hi = shard_range(n - 1, q, world)
+                        t = torch.zeros((share, 4), dtype=torch.int64, device=dev)
+                        t[: hi - lo] = bufs[0][lo:hi]
+                        pieces.append(t)
+                    state["pieces"] = pieces
+                sync()
+        except Exception as e:                       # re-raised on the main thread
+            state["error"] = e
+
+    helper = None
+    if rank in owner:
+        helper = threading.Thread(target=h_side)
+        helper.start()
+    part = groth16.WitnessPartial(pk, solution.W, nb_public)
+    if helper is not None:
+        helper.join()
+        if state["error"] is not None:
+            raise state["error"]
+    if windowed:
         _broadcast(bufs[0], 0, dist)
         sync()
         z = groth16.ZPartial(pk, bufs[0].data_ptr())
         return _finish_gathered(pk, part, z, r, s, dist, device)
-    # rank 0: h, then one equally sized (padded) slice per rank
-    share = (n - 1 + world - 1) // world + 1
     mine = torch.empty((share, 4), dtype=torch.int64, device=dev)
-    pieces = None
-    if rank == 0:
-        sync()
-        groth16.HCombine(pk, bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr())
-        pieces = []
-        for q in range(world):
-            lo, hi = shard_range(n - 1, q, world)
-            t = torch.zeros((share, 4), dtype=torch.int64, device=dev)
-            t[: hi - lo] = bufs[0][lo:hi]
-            pieces.append(t)
-    _scatter(mine, pieces, 0, dist)
+    _scatter(mine, state["pieces"], 0, dist)
     sync()
     z = groth16.ZPartial(pk, mine.data_ptr())
     return _finish_gathered(pk, part, z, r, s, dist, device)
