@@ -18,6 +18,8 @@ void set_error(const char* fmt, ...) {
 }
 const char* get_error() { return g_err; }
 
+static std::atomic<int> g_table_c{0};
+int table_c_override() { return g_table_c.load(); }
 static thread_local int g_lane = 0;
 int current_lane() { return g_lane; }
 LaneScope::LaneScope(int lane) : prev(g_lane) { g_lane = lane; }
@@ -61,6 +63,8 @@ void Tunables::read_env() {
     if (const char* e = getenv("GA_REDUCE_LAZY_MIN")) reduce_lazy_min = strtoull(e, nullptr, 10);
     if (const char* e = getenv("GA_G16_SHARE_MIN_PCT")) g16_share_min_pct = atoi(e);
     if (const char* e = getenv("GA_G16_LANES")) g16_lanes = atoi(e);
+    if (const char* e = getenv("GA_TABLE_C")) table_c = atoi(e);
+    g_table_c = table_c;
 }
 
 typedef CtxLock Lock;

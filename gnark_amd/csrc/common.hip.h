@@ -83,12 +83,14 @@ struct StageRec {
 //   GA_MSM_MAX_CHUNK      split an MSM along the point axis into chunks of at most this many points (msmChunkedG1/G2 analogue)
 //   GA_REDUCE_LAZY_MIN    bucket count from which the window reduction runs in the lazy representation
 //   GA_G16_SHARE_MIN_PCT  a Groth16 base vector shares the single witness sort when it covers at least this % of the wires
+//   GA_TABLE_C            force the window width of precomputed tables built from now on (experiments; 0 = planned)
 //   GA_G16_LANES          1: a second concurrent ga_g16_prove caller queues for the device instead of proving on lane 1
 struct Tunables {
     uint64_t msm_max_chunk = 0;          // 0 = only the 2^31 pair-space limit
     uint64_t reduce_lazy_min = 1u << 14;
     int g16_share_min_pct = 90;
     int g16_lanes = 2;
+    int table_c = 0;
     void read_env();
 };
 
@@ -99,6 +101,7 @@ struct Tunables {
 // is worth ~5 % of throughput on top of hiding the uploads.  The lane is a thread-local of the calling thread (abi.hip), so the
 // launch paths pick the right stream / scratch without extra parameters.
 int current_lane();
+int table_c_override();   // Tunables::table_c of the last read_env (process-wide: msm_plan_table has no context)
 struct LaneScope {
     int prev;
     explicit LaneScope(int lane);

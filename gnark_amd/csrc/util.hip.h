@@ -173,10 +173,15 @@ int msm_plan_table(size_t n, int* c_out, int* nwin_out) {
     for (int c = 4; c <= 23; c++) {
         int nwin = bits / c + 1;
         if ((double)nwin * (double)n >= 2147483648.0) continue;   // table index must fit 31 bits
+        if (table_c_override() && c != table_c_override()) continue;   // GA_TABLE_C (experiments; read with the other knobs)
         // one shared bucket set: its reduction costs ~6 mixed-add equivalents per bucket for mid-size inputs (latency-bound
         // kernels) and ~2.5 from 2^22 points up (measured: c = 17 best at 2^20, c = 22 best at 2^22 and 2^24)
         const double per_bucket = n >= (1u << 22) ? 2.5 : 6.0;
         double cost = (double)nwin * (double)n + per_bucket * (double)(1u << (c - 1));
+        // a top window of only 1-4 scalar bits puts its n additions into a handful of buckets, which the merge step then sums
+        // almost serially (measured at c = 18 and 21: merge 0.2 -> 1.2-2.3 ms, profiles/r02_e_table_c_sweep.txt): avoid those widths
+        const int top_bits = bits - (nwin - 1) * c;
+        if (top_bits >= 1 && top_bits <= 4) cost *= 1.25;
         if (cost < best) {
             best = cost;
             bc = c;
