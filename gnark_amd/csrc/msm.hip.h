@@ -34,6 +34,8 @@ namespace ga {
 constexpr int GA_ACC29_MINW = 4;      // waves per SIMD requested for the G1 bucket kernel (2 for Fp2 points: 72 KiB of LDS per workgroup)
 constexpr uint32_t MSM_SIGN = 0x80000000u;
 constexpr int MSM_HOT_TASKS = 16;     // buckets with more partials than this go to the wave-parallel merge
+constexpr uint32_t MSM_VHOT_TASKS = 512;   // ... and with more than this, to the two-stage merge over MSM_VHOT_SPLIT blocks per bucket
+constexpr uint32_t MSM_VHOT_SPLIT = 64;
 constexpr int MSM_GROUP = 32;         // buckets per running-sum group in the window reduction
 
 // Onesweep configuration for the bucket keys of large MSMs (17..22 significant bits at c = 18..22): two 11-bit passes instead of
@@ -134,13 +136,20 @@ static __global__ void msm_iota_kernel(uint32_t* __restrict__ out, uint32_t n) {
     if (i < n) out[i] = i;
 }
 
+// Buckets with more than MSM_LONG_TASKS tasks (a boolean-heavy witness puts millions of points into the digit-1 bucket of window 0)
+// are not written by their one lane: they are queued and written by msm_task_list_long_kernel, a block per bucket.
+constexpr uint32_t MSM_LONG_TASKS = 64;
 static __global__ void msm_task_list_kernel(const uint32_t* __restrict__ off, const uint32_t* __restrict__ task_off, uint32_t nb,
                                             uint32_t seg, uint32_t* __restrict__ task_start, uint32_t* __restrict__ task_key,
-                                            uint32_t* __restrict__ task_dest) {
+                                            uint32_t* __restrict__ task_dest, uint32_t* __restrict__ long_list, uint32_t* __restrict__ long_count) {
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
     uint32_t t0 = task_off[b], t1 = task_off[b + 1];
     uint32_t start = off[b], end = off[b + 1];
+    if (t1 - t0 > MSM_LONG_TASKS) {
+        long_list[atomicAdd(long_count, 1u)] = b;
+        return;
+    }
     for (uint32_t t = t0; t < t1; t++) {
         uint32_t len = end - start < seg ? end - start : seg;
         task_start[t] = start;
@@ -149,6 +158,24 @@ static __global__ void msm_task_list_kernel(const uint32_t* __restrict__ off, co
         task_dest[t] = (t1 - t0 == 1) ? b : nb + t;
         task_key[t] = seg - len;
         start += len;
+    }
+}
+
+static __global__ void msm_task_list_long_kernel(const uint32_t* __restrict__ off, const uint32_t* __restrict__ task_off, uint32_t nb, uint32_t seg,
+                                                 uint32_t* __restrict__ task_start, uint32_t* __restrict__ task_key, uint32_t* __restrict__ task_dest,
+                                                 const uint32_t* __restrict__ long_list, const uint32_t* __restrict__ long_count) {
+    const uint32_t nl = *long_count;
+    for (uint32_t h = blockIdx.x; h < nl; h += gridDim.x) {
+        const uint32_t b = long_list[h];
+        const uint32_t t0 = task_off[b], t1 = task_off[b + 1];
+        const uint32_t start = off[b], end = off[b + 1];
+        for (uint32_t t = t0 + threadIdx.x; t < t1; t += blockDim.x) {   // every task but the last is full
+            const uint32_t s0 = start + (t - t0) * seg;
+            const uint32_t len = end - s0 < seg ? end - s0 : seg;
+            task_start[t] = s0;
+            task_dest[t] = nb + t;
+            task_key[t] = seg - len;
+        }
     }
 }
 
@@ -395,12 +422,17 @@ msm_table29_kernel(const Affine<F>* __restrict__ bases, uint64_t n, int c, int n
 // ---- 5. merge partials ----------------------------------------------------------------------------
 template <class F>
 __global__ void msm_merge_kernel(const XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__ task_off, uint32_t nb,
-                                 XYZZ<F>* __restrict__ bsum, uint32_t* __restrict__ hot_list, uint32_t* __restrict__ hot_count) {
+                                 XYZZ<F>* __restrict__ bsum, uint32_t* __restrict__ hot_list, uint32_t* __restrict__ hot_count,
+                                 uint32_t* __restrict__ vhot_list, uint32_t* __restrict__ vhot_count) {
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
     uint32_t t0 = task_off[b], t1 = task_off[b + 1];
     uint32_t nt = t1 - t0;
     if (nt == 1) return;   // its only task wrote bsum[b] directly (task_dest)
+    if (nt > MSM_VHOT_TASKS) {
+        vhot_list[atomicAdd(vhot_count, 1u)] = b;
+        return;
+    }
     if (nt > MSM_HOT_TASKS) {
         hot_list[atomicAdd(hot_count, 1u)] = b;
         return;
@@ -437,6 +469,45 @@ msm_hot_kernel(const XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__
         for (uint32_t t = t0 + threadIdx.x; t < t1; t += 64) acc = add(acc, load_pod<XYZZ<F>>(&partial[t]));
         acc = wave_tree_sum(acc, sh);
         if (threadIdx.x == 0) store_pod(&bsum[b], acc);
+    }
+}
+
+// Very hot buckets (thousands of partial sums: the digit-1 bucket of a boolean-heavy witness): stage 1 gives each of
+// MSM_VHOT_SPLIT blocks a contiguous share of the bucket's partials (64 lanes strided + LDS tree), stage 2 sums the
+// MSM_VHOT_SPLIT block results of a bucket.  One block per bucket (msm_hot_kernel) would add n/2/seg/64 partials serially per lane:
+// measured 4.1 ms (G1) / 16.3 ms (G2) of merge at 2^24 with half the scalars equal to one.
+template <class F>
+__global__ void __launch_bounds__(64)
+msm_vhot_stage1_kernel(const XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__ task_off, const uint32_t* __restrict__ vhot_list,
+                       const uint32_t* __restrict__ vhot_count, XYZZ<F>* __restrict__ vtmp) {
+    __shared__ XYZZ<F> sh[64];
+    const uint32_t items = *vhot_count * MSM_VHOT_SPLIT;
+    for (uint32_t id = blockIdx.x; id < items; id += gridDim.x) {
+        const uint32_t h = id / MSM_VHOT_SPLIT, part = id % MSM_VHOT_SPLIT;
+        const uint32_t b = vhot_list[h];
+        const uint32_t t0 = task_off[b], t1 = task_off[b + 1];
+        const uint32_t per = (t1 - t0 + MSM_VHOT_SPLIT - 1) / MSM_VHOT_SPLIT;
+        const uint32_t lo = t0 + part * per < t1 ? t0 + part * per : t1;
+        const uint32_t hi = lo + per < t1 ? lo + per : t1;
+        XYZZ<F> acc = xyzz_inf<F>();
+        for (uint32_t t = lo + threadIdx.x; t < hi; t += 64) acc = add(acc, load_pod<XYZZ<F>>(&partial[t]));
+        acc = wave_tree_sum(acc, sh);
+        if (threadIdx.x == 0) store_pod(&vtmp[id], acc);
+        __syncthreads();
+    }
+}
+template <class F>
+__global__ void __launch_bounds__(64)
+msm_vhot_stage2_kernel(const XYZZ<F>* __restrict__ vtmp, const uint32_t* __restrict__ vhot_list, const uint32_t* __restrict__ vhot_count,
+                       XYZZ<F>* __restrict__ bsum) {
+    static_assert(MSM_VHOT_SPLIT == 64, "one partial result per lane");
+    __shared__ XYZZ<F> sh[64];
+    const uint32_t nv = *vhot_count;
+    for (uint32_t h = blockIdx.x; h < nv; h += gridDim.x) {
+        XYZZ<F> acc = load_pod<XYZZ<F>>(&vtmp[h * MSM_VHOT_SPLIT + threadIdx.x]);
+        acc = wave_tree_sum(acc, sh);
+        if (threadIdx.x == 0) store_pod(&bsum[vhot_list[h]], acc);
+        __syncthreads();
     }
 }
 
@@ -707,8 +778,14 @@ int msm_prepare(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, in
         GA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, ntask, task_off, (int)(nb + 1), st));
         // explicit task list, ordered by decreasing length (padding slots keep key = 0xFFFFFFFF >= seg)
         GA_HIP_CHECK(hipMemsetAsync(task_key, 0xFF, max_tasks * 4, st));
+        uint32_t *long_list, *long_count;
+        GA_CHECK(ctx->scratch_get(key("msm_long").c_str(), (max_tasks / MSM_LONG_TASKS + 2) * 4, (void**)&long_list));
+        GA_CHECK(ctx->scratch_get(key("msm_long_count").c_str(), 256, (void**)&long_count));
+        GA_HIP_CHECK(hipMemsetAsync(long_count, 0, 4, st));
         hipLaunchKernelGGL(msm_task_list_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, (const uint32_t*)off, (const uint32_t*)task_off,
-                           nb, seg, task_start, task_key, task_dest);
+                           nb, seg, task_start, task_key, task_dest, long_list, long_count);
+        hipLaunchKernelGGL(msm_task_list_long_kernel, dim3(256), dim3(256), 0, st, (const uint32_t*)off, (const uint32_t*)task_off, nb, seg,
+                           task_start, task_key, task_dest, (const uint32_t*)long_list, (const uint32_t*)long_count);
         hipLaunchKernelGGL(msm_iota_kernel, dim3((unsigned)((max_tasks + 255) / 256)), dim3(256), 0, st, task_id, (uint32_t)max_tasks);
         GA_KERNEL_CHECK();
         int kbits = 1;
@@ -762,7 +839,12 @@ int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, X
     uint32_t *hot_list, *hot_count;
     XYZZ<F>*partial, *bsum, *gsum, *gsum2, *wsum;
     GA_CHECK(ctx->scratch_get("msm_hot", ((uint64_t)nb + 2) * 4, (void**)&hot_list));
-    GA_CHECK(ctx->scratch_get("msm_hot_count", 256, (void**)&hot_count));
+    GA_CHECK(ctx->scratch_get("msm_hot_count", 256, (void**)&hot_count));   // [0] hot buckets, [1] very hot buckets
+    uint32_t* vhot_list;
+    XYZZ<F>* vtmp;
+    const uint64_t vhot_cap = P.max_tasks / MSM_VHOT_TASKS + 2;
+    GA_CHECK(ctx->scratch_get("msm_vhot", vhot_cap * 4, (void**)&vhot_list));
+    GA_CHECK(ctx->scratch_get("msm_vhot_tmp", vhot_cap * MSM_VHOT_SPLIT * sizeof(XYZZ<F>), (void**)&vtmp));
     // one array [nb bucket sums | max_tasks partial sums]: tasks write at task_dest (see msm_task_list_kernel)
     GA_CHECK(ctx->scratch_get("msm_bsum_partial", ((uint64_t)nb + P.max_tasks) * sizeof(XYZZ<F>), (void**)&bsum));
     partial = bsum + nb;
@@ -770,7 +852,7 @@ int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, X
     GA_CHECK(ctx->scratch_get("msm_gsum2", ((uint64_t)total_groups / 1024 + 64) * sizeof(XYZZ<F>), (void**)&gsum2));
     GA_CHECK(ctx->scratch_get("msm_wsum", (uint64_t)nsets * sizeof(XYZZ<F>), (void**)&wsum));
     hipStream_t st = ctx->work_stream();
-    GA_HIP_CHECK(hipMemsetAsync(hot_count, 0, 4, st));
+    GA_HIP_CHECK(hipMemsetAsync(hot_count, 0, 8, st));
     if (P.table) {
         uint32_t *redo_list, *redo_count;
         GA_CHECK(ctx->scratch_get("msm_redo", (P.max_tasks + 2) * 4, (void**)&redo_list));
@@ -808,9 +890,13 @@ int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, X
     {
         StageTimer tm(ctx, "msm_merge");
         hipLaunchKernelGGL((msm_merge_kernel<F>), dim3((nb + 255) / 256), dim3(256), 0, st, (const XYZZ<F>*)partial,
-                           (const uint32_t*)P.task_off, nb, bsum, hot_list, hot_count);
+                           (const uint32_t*)P.task_off, nb, bsum, hot_list, hot_count, vhot_list, hot_count + 1);
         hipLaunchKernelGGL((msm_hot_kernel<F>), dim3(512), dim3(64), 0, st, (const XYZZ<F>*)partial, (const uint32_t*)P.task_off,
                            (const uint32_t*)hot_list, (const uint32_t*)hot_count, bsum);
+        hipLaunchKernelGGL((msm_vhot_stage1_kernel<F>), dim3(2048), dim3(64), 0, st, (const XYZZ<F>*)partial, (const uint32_t*)P.task_off,
+                           (const uint32_t*)vhot_list, (const uint32_t*)(hot_count + 1), vtmp);
+        hipLaunchKernelGGL((msm_vhot_stage2_kernel<F>), dim3(256), dim3(64), 0, st, (const XYZZ<F>*)vtmp, (const uint32_t*)vhot_list,
+                           (const uint32_t*)(hot_count + 1), bsum);
         GA_KERNEL_CHECK();
     }
     // Window reduction.  Large bucket sets: lazy per-group pass without the per-lane scalar multiplication,

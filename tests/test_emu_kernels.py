@@ -518,6 +518,35 @@ def _expect_from_dlogs(c, group, S_host, K_host):
     return oracle.jac_to_affine(c.cid, group, oracle.generator_mul(c.cid, group, k))
 
 
+@pytest.mark.parametrize("c,group,table", [(BN254, 0, True), (BN254, 0, False), (BLS12_381, 1, False)], ids=["bn254-G1-table", "bn254-G1-raw", "bls-G2-raw"])
+def test_emu_msm_very_hot_bucket(emu_ctx, c, group, table, n=36000):
+    """boolean-heavy witness: 60 % of the scalars equal to one, 10 % zero -> the digit-1 bucket of window 0 holds 0.6 n points, i.e.
+    hundreds of tasks: the cooperative task-list writer (msm_task_list_long_kernel) and the two-stage merge of very hot buckets
+    (msm_vhot_stage1/2_kernel, > 512 partial sums) against [sum s_i k_i]G"""
+    ctx = emu_ctx
+    bases, dlogs, scal = _device_inputs(ctx, c, group, n, 0x1207 + group)
+    S = scal.to_host((n, 4))
+    K = dlogs.to_host((n, 4))
+    one = np.array(pyref.to_mont_limbs(1, c.r, 4), dtype=np.uint64)
+    u = np.random.default_rng(7).random(n)
+    S[u < 0.6] = one
+    S[(u >= 0.6) & (u < 0.7)] = 0
+    sdev = ctx.to_device(S)
+    try:
+        if table:
+            t = ecc.PrecomputedBases(ctx, c.name, group, bases, n=n)
+            try:
+                got = t.MultiExp(sdev)
+            finally:
+                t.free()
+        else:
+            got = ecc.MultiExp(ctx, c.name, group, bases, sdev, n=n)
+        assert np.array_equal(oracle.jac_to_affine(c.cid, group, got), _expect_from_dlogs(c, group, S, K))
+    finally:
+        for b in (bases, dlogs, scal, sdev):
+            b.free()
+
+
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
 @pytest.mark.parametrize("group", [0, 1], ids=["G1", "G2"])
 def test_emu_msm_vs_c_oracle_and_dlogs(emu_ctx, c, group, logn=11):

@@ -131,6 +131,14 @@ def test_msm_2_20_bn254_g1_distributions(gpu_ctx, dist):
         b.free()
 
 
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("group", [0, 1], ids=["G1", "G2"])
+@pytest.mark.parametrize("table", [True, False], ids=["table", "raw"])
+def test_msm_2_20_boolean_heavy_witness(gpu_ctx, c, group, table):
+    """60 % ones + 10 % zeros at 2^20 points: one bucket of 0.6 n points (thousands of tasks, two-stage merge) on every MSM shape"""
+    cases.test_emu_msm_very_hot_bucket(gpu_ctx, c, group, table, n=1 << 20)
+
+
 def test_msm_2_24_bn254_g1_dlog(gpu_ctx):
     """BASELINE headline size: 2^24 points, result == [sum s_i k_i]G."""
     c, group, n = BN254, 0, 1 << 24
