@@ -79,6 +79,7 @@ _PROTOS = {
     "ga_msm_table_destroy": (None, [_P]),
     "ga_msm_table_run": (C.c_int, [_P, _P, C.c_uint, _P]),
     "ga_msm_table_run_windows": (C.c_int, [_P, _P, C.c_uint, C.c_int, C.c_int, _P]),
+    "ga_msm_table_run_batch": (C.c_int, [_P, _P, C.c_uint32, C.c_uint, _P]),
     "ga_msm_table_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
     "ga_jac_add": (C.c_int, [C.c_int, C.c_int, _P, _P, _P]),
     "ga_jac_to_affine": (C.c_int, [C.c_int, C.c_int, _P, _P]),

@@ -4,6 +4,9 @@
 #include <stdarg.h>
 #include <stdlib.h>
 
+#include <memory>
+#include <vector>
+
 #include "hostops.hip.h"
 
 namespace ga {
@@ -389,6 +392,41 @@ int ga_msm_table_run(ga_msm_table* th, const void* scalars, unsigned flags, void
                           XYZZ<F> sum;
                           GA_CHECK((msm_table_device<C, G>(c, t->d_table, ss.dev, t->n, (flags & GA_SCALARS_MONTGOMERY) != 0, t->c, &sum)));
                           host_store_jac<F>(out_jac, sum);
+                      }));
+    return GA_OK;
+}
+
+int ga_msm_table_run_batch(ga_msm_table* th, const void* const* scalars, uint32_t k, unsigned flags, void* out_jacs) {
+    MsmTable* t = reinterpret_cast<MsmTable*>(th);
+    if (!t || !scalars || !out_jacs || k == 0 || k > 16) {
+        set_error("ga_msm_table_run_batch: null argument or batch size %u outside [1, 16]", k);
+        return GA_ERR_INVALID;
+    }
+    for (uint32_t j = 0; j < k; j++)
+        if (!scalars[j]) {
+            set_error("ga_msm_table_run_batch: scalars[%u] is null", j);
+            return GA_ERR_INVALID;
+        }
+    if ((uint64_t)k * t->nwin * t->n >= (1ull << 31)) {
+        set_error("ga_msm_table_run_batch: %u vectors x %d windows x %zu points exceed the 2^31 pair index space; use smaller batches", k,
+                  t->nwin, (size_t)t->n);
+        return GA_ERR_INVALID;
+    }
+    Ctx* c = t->ctx;
+    Lock l(c);
+    GA_DISPATCH_CURVE(t->curve, GA_DISPATCH_GROUP(t->group, {
+                          typedef typename GroupField<C, G>::F F;
+                          std::vector<std::unique_ptr<Staged>> st;
+                          std::vector<const void*> dev(k);
+                          for (uint32_t j = 0; j < k; j++) {
+                              st.emplace_back(new Staged{c});
+                              GA_CHECK(st.back()->stage(scalars[j], t->n * 32, flags & GA_SCALARS_ON_DEVICE));
+                              dev[j] = st.back()->dev;
+                          }
+                          std::vector<XYZZ<F>> sums(k);
+                          GA_CHECK((msm_table_device_batch<C, G>(c, t->d_table, dev.data(), (int)k, t->n, (flags & GA_SCALARS_MONTGOMERY) != 0,
+                                                                 t->c, sums.data())));
+                          for (uint32_t j = 0; j < k; j++) host_store_jac<F>((char*)out_jacs + j * sizeof(Jac<F>), sums[j]);
                       }));
     return GA_OK;
 }

@@ -249,6 +249,9 @@ size_t msm_table_point_bytes();
 template <class C, int G>
 int msm_table_device(Ctx* ctx, const void* d_table, const void* d_scalars, size_t n, bool scalars_mont, int c, void* h_sum, int win_lo = 0,
                      int win_hi = -1);
+template <class C, int G>
+int msm_table_device_batch(Ctx* ctx, const void* d_table, const void* const* d_scalars, int batch, size_t n, bool scalars_mont, int c,
+                           void* h_sums);
 // slot 0/1 selects one of two scratch sets (the witness sort shared by several tables stays live in set 1 while set 0 is reused)
 template <class C>
 int msm_prepare_table_scalars(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, int c, MsmPrepared* P, int slot = 0,

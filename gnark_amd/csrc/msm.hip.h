@@ -70,7 +70,8 @@ inline int msm_sort_pairs(Ctx* ctx, const std::string& tmp_name, uint32_t*& keys
 // ---- 1. digits ------------------------------------------------------------------------------------
 template <class FrP>
 __global__ void msm_digits_kernel(const uint32_t* __restrict__ scalars, uint64_t n, int mont, int c, int nwin, int win_lo,
-                                  int win_hi, int table, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+                                  int win_hi, int table, uint32_t key_base, uint32_t skip, uint32_t* __restrict__ keys,
+                                  uint32_t* __restrict__ vals) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Fe<FrP> s = load_fe<FrP>(scalars + i * 8);
@@ -83,8 +84,8 @@ __global__ void msm_digits_kernel(const uint32_t* __restrict__ scalars, uint64_t
     }
     const uint32_t half = 1u << (c - 1);
     const uint32_t mask = (1u << c) - 1;
-    // table mode: every window shares ONE bucket set and the value indexes the precomputed table [window][point]
-    const uint32_t skip = table ? half : (uint32_t)(win_hi - win_lo) * half;
+    // table mode: every window shares ONE bucket set (bucket set `key_base / half` of a batch of scalar vectors over the same
+    // table) and the value indexes the precomputed table [window][point]; skip = total bucket count (sorts last)
     uint32_t carry = 0;
     for (int w = 0; w < nwin; w++) {
         uint32_t d = (s.l[0] & mask) + carry;
@@ -102,7 +103,7 @@ __global__ void msm_digits_kernel(const uint32_t* __restrict__ scalars, uint64_t
         }
         if (w >= win_lo && w < win_hi) {
             uint64_t idx = (uint64_t)(w - win_lo) * n + i;
-            keys[idx] = d == 0 ? skip : (table ? 0u : (uint32_t)(w - win_lo) * half) + (d - 1);
+            keys[idx] = d == 0 ? skip : key_base + (table ? 0u : (uint32_t)(w - win_lo) * half) + (d - 1);
             vals[idx] = (table ? (uint32_t)((uint64_t)w * n + i) : (uint32_t)i) | neg;
         }
     }
@@ -699,9 +700,12 @@ msm_segment_sum_kernel(const XYZZ<F>* __restrict__ in, uint32_t seg_len, XYZZ<F>
 // (ICICLE exposes the same idea as MSMConfig.PrecomputeFactor, icicle.go:507-525.)
 // ---- host driver ------------------------------------------------------------------------------------
 
+// batch > 1 (table mode only): `d_scalars` is an array of `batch` device pointers, one scalar vector each, over the SAME table:
+// one sort, one task list, one bucket set per vector (P->nsets = batch) -- the three wire commitments or the three quotient
+// shards of a PLONK proof share every launch and every latency-bound tail.
 template <class FrP>
 int msm_prepare(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, int c, int win_lo, int win_hi, bool table,
-                MsmPrepared* P, int slot = 0) {
+                MsmPrepared* P, int slot = 0, int batch = 1) {
     hipStream_t st = ctx->work_stream();
     const std::string sfx = slot ? "#1" : "";
     auto key = [&](const char* k) { return std::string(k) + sfx; };
@@ -716,9 +720,13 @@ int msm_prepare(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, in
         set_error("msm: n=%zu outside [1, 2^31)", n);
         return GA_ERR_INVALID;
     }
+    if (batch < 1 || (batch > 1 && !table)) {
+        set_error("msm: a batch of scalar vectors needs a precomputed table (batch=%d, table=%d)", batch, (int)table);
+        return GA_ERR_INVALID;
+    }
     const uint32_t half = 1u << (c - 1);
-    const uint64_t m = (uint64_t)nwl * n;
-    const uint64_t nb64 = table ? half : (uint64_t)nwl * half;
+    const uint64_t m = (uint64_t)batch * nwl * n;
+    const uint64_t nb64 = table ? (uint64_t)batch * half : (uint64_t)nwl * half;
     // table mode: the value indexes the WHOLE table [window][point] even when only a window range is accumulated (multi-GPU
     // partition A on pinned bases: the 2^(c*w) factors are baked into the table, so partial results simply add)
     if (m >= (1ull << 31) || nb64 >= (1ull << 31) || (table && (uint64_t)nwin * n >= (1ull << 31))) {
@@ -757,8 +765,12 @@ int msm_prepare(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, in
 
     {
         StageTimer tm(ctx, "msm_digits", st);
-        hipLaunchKernelGGL((msm_digits_kernel<FrP>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint32_t*)d_scalars,
-                           (uint64_t)n, scalars_mont ? 1 : 0, c, nwin, win_lo, win_hi, table ? 1 : 0, keys, vals);
+        for (int b = 0; b < batch; b++) {
+            const uint32_t* sc = batch == 1 ? (const uint32_t*)d_scalars : reinterpret_cast<const uint32_t* const*>(d_scalars)[b];
+            hipLaunchKernelGGL((msm_digits_kernel<FrP>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sc, (uint64_t)n,
+                               scalars_mont ? 1 : 0, c, nwin, win_lo, win_hi, table ? 1 : 0, (uint32_t)b * half, (uint32_t)nb64,
+                               keys + (uint64_t)b * nwl * n, vals + (uint64_t)b * nwl * n);
+        }
         GA_KERNEL_CHECK();
     }
     {
@@ -801,7 +813,7 @@ int msm_prepare(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, in
     P->nwin = nwin;
     P->win_lo = win_lo;
     P->win_hi = win_hi;
-    P->nsets = table ? 1 : nwl;
+    P->nsets = table ? batch : nwl;
     P->table = table;
     P->half = half;
     P->nb = nb;
@@ -997,6 +1009,22 @@ int msm_table_device(Ctx* ctx, const void* d_table, const void* d_scalars, size_
     }
     MsmPrepared P;
     GA_CHECK(msm_prepare<typename C::FrP>(ctx, d_scalars, n, scalars_mont, c, win_lo, win_hi, true, &P));
+    return msm_accumulate_reduce<F>(ctx, d_table, P, out);
+}
+
+// `batch` scalar vectors (host array of device pointers) over one table: batch XYZZ results
+template <class C, int G>
+int msm_table_device_batch(Ctx* ctx, const void* d_table, const void* const* d_scalars, int batch, size_t n, bool scalars_mont, int c,
+                           void* h_sums) {
+    typedef typename GroupField<C, G>::F F;
+    XYZZ<F>* out = reinterpret_cast<XYZZ<F>*>(h_sums);
+    if (n == 0) {
+        for (int b = 0; b < batch; b++) out[b] = xyzz_inf<F>();
+        return GA_OK;
+    }
+    MsmPrepared P;
+    // (msm_prepare takes the vector itself for batch == 1, the pointer array otherwise)
+    GA_CHECK(msm_prepare<typename C::FrP>(ctx, batch == 1 ? d_scalars[0] : (const void*)d_scalars, n, scalars_mont, c, 0, -1, true, &P, 0, batch));
     return msm_accumulate_reduce<F>(ctx, d_table, P, out);
 }
 

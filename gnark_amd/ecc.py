@@ -93,6 +93,27 @@ class PrecomputedBases:
         self.ctx.lib.check(self.ctx.lib.ga_msm_table_run(self.handle, sp, f2 | (_lib.SCALARS_MONTGOMERY if montgomery else 0), _ptr(out)))
         return out
 
+    def MultiExpBatch(self, scalar_vectors, montgomery: bool = True) -> np.ndarray:
+        """k scalar vectors over these bases in one pass (ga_msm_table_run_batch): (k, jac_words) -- row j equals MultiExp(vector j).
+        All vectors host arrays or all DeviceBuffers."""
+        k = len(scalar_vectors)
+        on_dev = all(isinstance(v, (DeviceBuffer, int)) for v in scalar_vectors)
+        if not on_dev:
+            if any(isinstance(v, (DeviceBuffer, int)) for v in scalar_vectors):
+                raise ValueError("a batch mixes host and device scalar vectors")
+            scalar_vectors = [as_u64(v, 4) for v in scalar_vectors]
+            if any(v.shape[0] != self.n for v in scalar_vectors):
+                raise ValueError("len(points) != len(scalars)")
+        ptrs, flags = [], (_lib.SCALARS_MONTGOMERY if montgomery else 0)
+        for v in scalar_vectors:
+            p, f = _arg(v, _lib.SCALARS_ON_DEVICE)
+            ptrs.append(p)
+            flags |= f
+        arr = (C.c_void_p * k)(*[C.cast(p, C.c_void_p).value for p in ptrs])
+        out = np.zeros((k, jac_words(self.curve, self.group)), dtype=np.uint64)
+        self.ctx.lib.check(self.ctx.lib.ga_msm_table_run_batch(self.handle, arr, k, flags, _ptr(out)))
+        return out
+
     def KzgOpen(self, poly, point):
         """kzg.Open(p, point, pk) over this (monomial G1) SRS: returns (ClaimedValue fr image, H as G1Jac)."""
         n = None

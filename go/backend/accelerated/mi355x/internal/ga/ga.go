@@ -356,6 +356,27 @@ func (t *Table) Run(scalars unsafe.Pointer, outJac unsafe.Pointer) error {
 	return call("ga_msm_table_run", func() C.int { return C.ga_msm_table_run(t.h, scalars, C.uint(ScalarsMontgomery), outJac) })
 }
 
+// RunBatch multiplies the table's bases by k scalar vectors of exactly t.N elements each in ONE pass (ga_msm_table_run_batch):
+// outJacs receives k Jacobian points.  The pointer array handed to C lives in C memory for the duration of the call and every
+// scalar vector is pinned (cgo: no Go pointer to unpinned Go memory is stored anywhere C can see).
+func (t *Table) RunBatch(scalars []unsafe.Pointer, outJacs unsafe.Pointer) error {
+	k := len(scalars)
+	if k == 0 || k > 16 {
+		return fmt.Errorf("ga: batch of %d scalar vectors outside [1, 16]", k)
+	}
+	arr := (*[16]unsafe.Pointer)(C.malloc(C.size_t(k) * C.size_t(unsafe.Sizeof(uintptr(0)))))
+	defer C.free(unsafe.Pointer(arr))
+	var pin runtime.Pinner
+	defer pin.Unpin()
+	for i, p := range scalars {
+		pin.Pin(p)
+		arr[i] = p
+	}
+	return call("ga_msm_table_run_batch", func() C.int {
+		return C.ga_msm_table_run_batch(t.h, (*unsafe.Pointer)(unsafe.Pointer(arr)), C.uint32_t(k), C.uint(ScalarsMontgomery), outJacs)
+	})
+}
+
 // Open is kzg.Open over the pinned SRS: claimed value and the Jacobian commitment to the quotient.
 func (t *Table) Open(poly unsafe.Pointer, n uint64, point, claimedOut, hOutJac unsafe.Pointer) error {
 	return call("ga_kzg_open", func() C.int {

@@ -5,11 +5,11 @@
 // the linearised polynomial and the batch opening stay in the native prover; a maintainer wires these hooks in at
 // the cited lines (each hook has the signature of the code it replaces).
 //
-//	prove.go:404-489   commitToLRO               -> Device.CommitLagrange (3 MSMs over pk.KzgLagrange.G1)
+//	prove.go:404-489   commitToLRO               -> Device.CommitLagrangeBatch (3 MSMs over pk.KzgLagrange.G1 in one pass)
 //	prove.go:530-540   commitToPolyAndBlinding   -> Device.CommitLagrange
 //	prove.go:645-655   iop.BuildRatioCopyConstraint -> Device.BuildRatioCopyConstraint
 //	prove.go:558-633   computeNumerator + divideByZH (:841-1123,1287-1350) -> Device.ComputeQuotient
-//	prove.go:1263-1285 commitToQuotient          -> Device.Commit (3 MSMs over pk.Kzg.G1)
+//	prove.go:1263-1285 commitToQuotient          -> Device.CommitBatch (3 MSMs over pk.Kzg.G1 in one pass)
 //	prove.go:681,788,827 kzg.Open                -> Device.Open
 package bn254
 
@@ -92,6 +92,40 @@ func commit(t *ga.Table, p []fr.Element) (curve.G1Affine, error) {
 	}
 	res.FromJacobian(&jac)
 	return res, nil
+}
+
+// commitBatch is len(ps) kzg.Commit calls over the same pinned SRS in one device pass (commitToLRO's three goroutines,
+// prove.go:404-489, and commitToQuotient's three shards, prove.go:1263-1285, become one call each).
+func commitBatch(t *ga.Table, ps [][]fr.Element) ([]curve.G1Affine, error) {
+	ptrs := make([]unsafe.Pointer, len(ps))
+	for i, p := range ps {
+		if uint64(len(p)) > t.N {
+			return nil, fmt.Errorf("polynomial %d has %d coefficients, the pinned SRS %d points", i, len(p), t.N)
+		}
+		scalars := p
+		if uint64(len(p)) < t.N {
+			scalars = make([]fr.Element, t.N)
+			copy(scalars, p)
+		}
+		ptrs[i] = sliceData(scalars)
+	}
+	jacs := make([]curve.G1Jac, len(ps))
+	if err := t.RunBatch(ptrs, unsafe.Pointer(&jacs[0])); err != nil {
+		return nil, err
+	}
+	res := make([]curve.G1Affine, len(ps))
+	for i := range jacs {
+		res[i].FromJacobian(&jacs[i])
+	}
+	return res, nil
+}
+
+// CommitBatch is kzg.Commit(p, pk.Kzg) for every p of ps (canonical form) in one pass.
+func (d *Device) CommitBatch(ps ...[]fr.Element) ([]curve.G1Affine, error) { return commitBatch(d.srs, ps) }
+
+// CommitLagrangeBatch is kzg.Commit(p, pk.KzgLagrange) for every p of ps (Lagrange form) in one pass.
+func (d *Device) CommitLagrangeBatch(ps ...[]fr.Element) ([]curve.G1Affine, error) {
+	return commitBatch(d.srsLagrange, ps)
 }
 
 // Commit is kzg.Commit(p, pk.Kzg): p in canonical form.

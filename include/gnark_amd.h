@@ -113,6 +113,12 @@ int ga_msm_table_info(ga_msm_table* t, int* window_bits, int* num_windows, uint6
  * so the Jacobian results of disjoint window ranges ADD UP to ga_msm_table_run's result (ga_jac_add); no Horner step.  An empty
  * range gives the point at infinity. */
 int ga_msm_table_run_windows(ga_msm_table* t, const void* scalars, unsigned flags, int win_lo, int win_hi, void* out_jac);
+/* k scalar vectors (1 <= k <= 16; scalars[j] -> n field elements each, all host or all device as `flags` says) over the SAME pinned
+ * bases in ONE pass: one sort, one task list, one launch sequence, k bucket sets; out_jacs receives k Jacobian points in order.
+ * What the three wire commitments [L],[R],[O] and the three quotient shards [H0],[H1],[H2] of a PLONK proof call
+ * (backend/plonk/bn254/prove.go:404-489,558-633: three kzg.Commit on the same SRS issued together): the latency-bound tails of
+ * an MSM (bucket reduction, task building) are paid once per batch instead of once per polynomial. */
+int ga_msm_table_run_batch(ga_msm_table* t, const void* const* scalars, uint32_t k, unsigned flags, void* out_jacs);
 
 /* ---- small host-side group helpers used by the Go epilogue / multi-GPU combine -------------------------
  * (curve.G1Jac.AddAssign / ScalarMultiplication / FromJacobian, prove.go:199-292).  Host arithmetic. */

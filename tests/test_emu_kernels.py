@@ -518,6 +518,45 @@ def _expect_from_dlogs(c, group, S_host, K_host):
     return oracle.jac_to_affine(c.cid, group, oracle.generator_mul(c.cid, group, k))
 
 
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("group", [0, 1], ids=["G1", "G2"])
+def test_emu_msm_table_batch(emu_ctx, c, group, n=300, k=3):
+    """ga_msm_table_run_batch: k scalar vectors over one table in one pass == k separate runs == [sum s_i k_i]G; host and device
+    scalars, edge vectors (all zero, all ones), argument validation"""
+    ctx = emu_ctx
+    bases, dlogs, scal = _device_inputs(ctx, c, group, n, 0xBA7C + group)
+    K = dlogs.to_host((n, 4))
+    one = np.array(pyref.to_mont_limbs(1, c.r, 4), dtype=np.uint64)
+    vecs = [scal.to_host((n, 4))]
+    for j in range(1, k):
+        b = ctx.malloc(n * 32)
+        ctx.lib.check(ctx.lib.ga_gen_scalars(ctx.handle, c.cid, 0x51 + j, n, b.ptr))
+        vecs.append(b.to_host((n, 4)))
+        b.free()
+    vecs.append(np.zeros((n, 4), dtype=np.uint64))
+    vecs.append(np.tile(one, (n, 1)))
+    t = ecc.PrecomputedBases(ctx, c.name, group, bases, n=n)
+    devs = [ctx.to_device(v) for v in vecs]
+    try:
+        single = [t.MultiExp(v) for v in vecs]
+        got_h = t.MultiExpBatch(vecs)
+        got_d = t.MultiExpBatch(devs)
+        for j, v in enumerate(vecs):
+            want = _expect_from_dlogs(c, group, v, K)
+            assert np.array_equal(oracle.jac_to_affine(c.cid, group, got_h[j]), want), j
+            assert np.array_equal(oracle.jac_to_affine(c.cid, group, got_d[j]), want), j
+            assert np.array_equal(oracle.jac_to_affine(c.cid, group, single[j]), want), j
+        assert np.array_equal(oracle.jac_to_affine(c.cid, group, t.MultiExpBatch(vecs[:1])[0]), _expect_from_dlogs(c, group, vecs[0], K))
+        with pytest.raises(Exception, match="batch size"):
+            t.MultiExpBatch([vecs[0]] * 17)
+        with pytest.raises(ValueError):
+            t.MultiExpBatch([vecs[0], devs[1]])
+    finally:
+        t.free()
+        for b in [bases, dlogs, scal] + devs:
+            b.free()
+
+
 @pytest.mark.parametrize("c,group,table", [(BN254, 0, True), (BN254, 0, False), (BLS12_381, 1, False)], ids=["bn254-G1-table", "bn254-G1-raw", "bls-G2-raw"])
 def test_emu_msm_very_hot_bucket(emu_ctx, c, group, table, n=36000):
     """boolean-heavy witness: 60 % of the scalars equal to one, 10 % zero -> the digit-1 bucket of window 0 holds 0.6 n points, i.e.

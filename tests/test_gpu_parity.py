@@ -133,6 +133,13 @@ def test_msm_2_20_bn254_g1_distributions(gpu_ctx, dist):
 
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
 @pytest.mark.parametrize("group", [0, 1], ids=["G1", "G2"])
+def test_msm_table_batch_2_18(gpu_ctx, c, group):
+    """three commitments' worth of scalars + an all-zero and an all-one vector over one pinned SRS in one pass (2^18 points)"""
+    cases.test_emu_msm_table_batch(gpu_ctx, c, group, n=1 << 18, k=3)
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("group", [0, 1], ids=["G1", "G2"])
 @pytest.mark.parametrize("table", [True, False], ids=["table", "raw"])
 def test_msm_2_20_boolean_heavy_witness(gpu_ctx, c, group, table):
     """60 % ones + 10 % zeros at 2^20 points: one bucket of 0.6 n points (thousands of tasks, two-stage merge) on every MSM shape"""
