@@ -71,7 +71,7 @@ func Setup(r1cs constraint.ConstraintSystem) (groth16.ProvingKey, groth16.Verify
 }
 
 // DummySetup wraps [groth16.DummySetup] (all bases equal: a degenerate bucket distribution that the kernels' exact
-// redo path handles, at a cost -- benchmark with real keys).
+// redo path handles, at a cost -- the bucket stage runs ~4x slower, DESIGN 4.2; benchmark with real keys).
 func DummySetup(r1cs constraint.ConstraintSystem) (groth16.ProvingKey, error) {
 	switch _r1cs := r1cs.(type) {
 	case *cs_bn254.R1CS:
