@@ -364,6 +364,7 @@ void ga_msm_table_destroy(ga_msm_table* th) {
     if (!t) return;
     Lock l(t->ctx);
     hipStreamSynchronize(t->ctx->stream);
+    t->ctx->forget_table(t->d_table);
     hipFree(t->d_table);
     delete t;
 }

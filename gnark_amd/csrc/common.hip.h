@@ -10,6 +10,7 @@
 #include <atomic>
 #include <map>
 #include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -129,6 +130,22 @@ struct Ctx {
     std::vector<StageRec> stages;
     // reusable device scratch, grown on demand (keyed by purpose)
     std::map<std::string, std::pair<void*, size_t>> scratch;
+
+    // base tables on which the fast bucket loop flagged most of its tasks (all bases equal: a DummySetup key); msm.hip.h
+    std::mutex degenerate_mu;
+    std::set<const void*> degenerate;
+    bool is_degenerate(const void* table) {
+        std::lock_guard<std::mutex> g(degenerate_mu);
+        return degenerate.count(table) != 0;
+    }
+    void mark_degenerate(const void* table) {
+        std::lock_guard<std::mutex> g(degenerate_mu);
+        degenerate.insert(table);
+    }
+    void forget_table(const void* table) {
+        std::lock_guard<std::mutex> g(degenerate_mu);
+        degenerate.erase(table);
+    }
 
     int scratch_get(const char* key, size_t bytes, void** out);
     void scratch_free_all();

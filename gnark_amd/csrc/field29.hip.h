@@ -40,6 +40,21 @@ GA_HD uint32_t kp_limb(int i) {
     return r;
 }
 
+// limb i of K*p in plain normalized limbs (the top limb keeps the overflow)
+template <class P, int K>
+GA_HD uint32_t kp_plain_limb(int i) {
+    typedef Radix<P> R;
+    uint64_t carry = 0;
+    uint32_t v = 0;
+    for (int j = 0; j <= i; j++) {
+        uint64_t t = (uint64_t)mod_limb<P>(j) * (uint32_t)K + carry;
+        v = (uint32_t)(t & R::MASK);
+        carry = t >> R::L;
+        if (j == R::NL - 1) v = (uint32_t)t;
+    }
+    return v;
+}
+
 template <class P>
 GA_HD F29<P> f29_zero() {
     F29<P> r;
@@ -303,6 +318,22 @@ GA_HD F29<P> f29_reduce_3p(const F29<P>& a) {
     return r;
 }
 
+// exact test v == 0 (mod p) of a lazy value (normalized limbs, any v < 2^(NL*L)): one Barrett step to [0, 3p), then the three
+// candidates 0, p, 2p.  Used only where the addition law needs it (the complete variant of the bucket loop, msm.hip.h).
+template <class P>
+GA_HD bool f29_is_zero_mod_p(const F29<P>& a) {
+    typedef Radix<P> R;
+    const F29<P> r = f29_reduce_3p(a);
+    uint32_t z0 = 0, z1 = 0, z2 = 0;
+#pragma unroll
+    for (int i = 0; i < R::NL; i++) {
+        z0 |= r.l[i];
+        z1 |= r.l[i] ^ kp_plain_limb<P, 1>(i);
+        z2 |= r.l[i] ^ kp_plain_limb<P, 2>(i);
+    }
+    return (z0 == 0) | (z1 == 0) | (z2 == 0);
+}
+
 // limbs (value < 3p) -> canonical packed words
 template <class P>
 GA_HD Fe<P> f29_pack_canonical(const F29<P>& v) {
@@ -340,6 +371,7 @@ template <int K, int W, class P> GA_HD F29x2<P> f29_sub_wide(const F29x2<P>& a, 
 }
 template <class P> GA_HD F29x2<P> f29_partial_reduce(const F29x2<P>& a) { return {f29_partial_reduce(a.c0), f29_partial_reduce(a.c1)}; }
 template <class P> GA_HD bool f29_is_zero_limbs(const F29x2<P>& a) { return f29_is_zero_limbs(a.c0) & f29_is_zero_limbs(a.c1); }
+template <class P> GA_HD bool f29_is_zero_mod_p(const F29x2<P>& a) { return f29_is_zero_mod_p(a.c0) & f29_is_zero_mod_p(a.c1); }
 
 // Fp2 product, schoolbook on unreduced columns: real part a0*b0 + (K*p - a1)*b1, imaginary part a0*b1 + a1*b0 -- every term is
 // non-negative, so there is no 64-bit subtraction (a v_sub_co/v_subb pair costs more than a multiply on gfx950) and only two

@@ -67,6 +67,8 @@ static int upload(Ctx* ctx, const void* src, size_t bytes, void** dst) {
 
 static void pk_free(G16Pk* pk) {
     if (!pk) return;
+    if (pk->ctx)
+        for (const void* t : {pk->d_a, pk->d_b, pk->d_z, pk->d_k, pk->d_b2}) pk->ctx->forget_table(t);
     hipFree(pk->d_a);
     hipFree(pk->d_b);
     hipFree(pk->d_z);

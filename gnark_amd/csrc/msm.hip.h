@@ -271,28 +271,52 @@ __device__ __forceinline__ void madd29(const LdsAcc29<Fe2<P>>& A, const F29x2<P>
     A.put(1, f29_mul_sub<P::FP2Z_K>(R, f29_sub<8>(Q, X3), ay, PPP));   // Y3 = R*(Q - X3) - Y1*PPP, two reductions instead of four
 }
 
+// acc = 2*(qx, qy) for an affine q in the lazy representation (mdbl-2008-s-1, a = 0); qy may be a negated 2p - y.  Bounds
+// (tools/lazy_bounds.py check_mdbl): every output stays below the fixed-point bounds of the accumulator coordinates of madd29.
 template <class F>
-__global__ void __launch_bounds__(Table29<F>::THREADS, Table29<F>::MIN_WAVES)
-msm_accumulate29_kernel(const uint32_t* __restrict__ table, const uint32_t* __restrict__ vals,
-                        const uint32_t* __restrict__ task_start, const uint32_t* __restrict__ task_key_sorted,
-                        const uint32_t* __restrict__ task_perm, uint32_t max_tasks, uint32_t seg,
-                        const uint32_t* __restrict__ task_dest, XYZZ<F>* __restrict__ sums, uint32_t* __restrict__ redo_list,
-                        uint32_t* __restrict__ redo_count) {
+__device__ __forceinline__ void mdbl29(const LdsAcc29<F>& A, const typename Lazy<F>::T& qx, const typename Lazy<F>::T& qy) {
     typedef typename Lazy<F>::T T;
     typedef typename Lazy<F>::Params P;
-    constexpr int NW = Lazy<F>::NW;
-#ifndef GA_ACC_LDS_PAD
-#define GA_ACC_LDS_PAD 0   // experiment: extra LDS words per workgroup, to lower the number of co-resident workgroups
-#endif
-    __shared__ uint32_t lds[4 * NW * Table29<F>::THREADS + GA_ACC_LDS_PAD];
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= max_tasks) return;
-    const uint32_t key = task_key_sorted[t];
-    if (key >= seg) return;
-    const uint32_t tid = task_perm[t];
-    const uint32_t start = task_start[tid];
-    const uint32_t end = start + (seg - key);
-    LdsAcc29<F> A{lds + threadIdx.x};
+    const T U = f29_add(qy, qy);
+    const T V = f29_sqr(U);
+    const T W = f29_mul(U, V);
+    const T S = f29_mul(qx, V);
+    const T xx = f29_sqr(qx);
+    const T M = f29_add(f29_add(xx, xx), xx);
+    T X3 = f29_sub<4>(f29_sqr(M), f29_add(S, S));
+    if constexpr (Lazy<F>::FP2) X3 = f29_partial_reduce(X3);
+    constexpr int KMS = Lazy<F>::FP2 ? P::FP2Z_K : 8;
+    A.put(1, f29_mul_sub<KMS>(M, f29_sub<8>(S, X3), W, qy));   // Y3 = M*(S - X3) - W*y
+    A.put(0, X3);
+    A.put(2, V);
+    A.put(3, W);
+}
+
+// acc += q with the exceptional cases of the addition law handled: same x and same y -> doubling, same x and opposite y -> the
+// accumulator becomes the point at infinity (returns false: the caller restarts it with the next point).  One exact zero test of
+// P = X2*ZZ1 - X1 per addition (~80 instructions on top of the ~2400 of madd29); R is only tested when P vanishes.
+template <class F>
+__device__ __forceinline__ bool madd29_complete(const LdsAcc29<F>& A, const typename Lazy<F>::T& qx, const typename Lazy<F>::T& qy) {
+    typedef typename Lazy<F>::T T;
+    typedef typename Lazy<F>::Params P;
+    constexpr int KS = Lazy<F>::FP2 ? 4 : 8;
+    const T Pp = f29_sub<KS>(f29_mul(qx, A.get(2)), A.get(0));
+    if (f29_is_zero_mod_p(Pp)) {
+        const T R = f29_sub<KS>(f29_mul(qy, A.get(3)), A.get(1));
+        if (!f29_is_zero_mod_p(R)) return false;
+        mdbl29<F>(A, qx, qy);
+        return true;
+    }
+    madd29<P>(A, qx, qy);   // (recomputes P: the common path stays the code the bound analysis covers)
+    return true;
+}
+
+// one task = the sorted pairs [start, end): its sum into the lane's LDS accumulator; returns whether the sum is a finite point
+template <class F, bool COMPLETE>
+__device__ __forceinline__ bool accumulate_task29(const LdsAcc29<F>& A, const uint32_t* __restrict__ table, const uint32_t* __restrict__ vals,
+                                                  uint32_t start, uint32_t end) {
+    typedef typename Lazy<F>::T T;
+    typedef typename Lazy<F>::Params P;
     const T one = Lazy<F>::from_mem(FieldTraits<F>::one());
     bool have = false;
     uint32_t v = vals[start];
@@ -308,25 +332,77 @@ msm_accumulate29_kernel(const uint32_t* __restrict__ table, const uint32_t* __re
                 A.put(2, one);
                 A.put(3, one);
                 have = true;
+            } else if constexpr (COMPLETE) {
+                have = madd29_complete<F>(A, qx, qy);
             } else {
                 madd29<P>(A, qx, qy);
             }
         }
         v = vn;
     }
+    return have;
+}
+
+// the task's sum out of the LDS accumulator: false when an exceptional addition slipped through (ZZ == 0 mod p)
+template <class F>
+__device__ __forceinline__ bool store_task29(const LdsAcc29<F>& A, bool have, XYZZ<F>* __restrict__ dst) {
     XYZZ<F> acc = xyzz_inf<F>();
     if (have) {
         F zz = Lazy<F>::to_mem(A.get(2));
-        if (is_zero(zz)) {   // an exceptional addition happened somewhere in this task: redo it exactly
-            redo_list[atomicAdd(redo_count, 1u)] = tid;
-            return;
-        }
+        if (is_zero(zz)) return false;
         acc.x = Lazy<F>::to_mem(A.get(0));
         acc.y = Lazy<F>::to_mem(A.get(1));
         acc.zz = zz;
         acc.zzz = Lazy<F>::to_mem(A.get(3));
     }
-    store_pod(&sums[task_dest[tid]], acc);
+    store_pod(dst, acc);
+    return true;
+}
+
+// COMPLETE = false: the fast loop (exceptional additions make ZZ == 0 and flag the task); true: the same loop with the exceptional
+// cases handled in place -- used directly on tables that turned out degenerate (a DummySetup key: every base the same point).
+template <class F, bool COMPLETE>
+__global__ void __launch_bounds__(Table29<F>::THREADS, Table29<F>::MIN_WAVES)
+msm_accumulate29_kernel(const uint32_t* __restrict__ table, const uint32_t* __restrict__ vals,
+                        const uint32_t* __restrict__ task_start, const uint32_t* __restrict__ task_key_sorted,
+                        const uint32_t* __restrict__ task_perm, uint32_t max_tasks, uint32_t seg,
+                        const uint32_t* __restrict__ task_dest, XYZZ<F>* __restrict__ sums, uint32_t* __restrict__ redo_list,
+                        uint32_t* __restrict__ redo_count) {
+    constexpr int NW = Lazy<F>::NW;
+#ifndef GA_ACC_LDS_PAD
+#define GA_ACC_LDS_PAD 0   // experiment: extra LDS words per workgroup, to lower the number of co-resident workgroups
+#endif
+    __shared__ uint32_t lds[4 * NW * Table29<F>::THREADS + GA_ACC_LDS_PAD];
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= max_tasks) return;
+    const uint32_t key = task_key_sorted[t];
+    if (key >= seg) return;
+    const uint32_t tid = task_perm[t];
+    const uint32_t start = task_start[tid];
+    LdsAcc29<F> A{lds + threadIdx.x};
+    const bool have = accumulate_task29<F, COMPLETE>(A, table, vals, start, start + (seg - key));
+    if (!store_task29<F>(A, have, &sums[task_dest[tid]])) redo_list[atomicAdd(redo_count, 1u)] = tid;   // redo it
+}
+
+// second chance for the tasks the fast loop flagged: the complete lazy loop over the redo list (grid-stride); what even that
+// cannot finish (a base of order 2, never on these curves) goes to the exact kernel below through a second list
+template <class F>
+__global__ void __launch_bounds__(Table29<F>::THREADS, Table29<F>::MIN_WAVES)
+msm_accumulate29_retry_kernel(const uint32_t* __restrict__ table, const uint32_t* __restrict__ vals,
+                              const uint32_t* __restrict__ task_start, const uint32_t* __restrict__ task_key_by_tid, uint32_t seg,
+                              const uint32_t* __restrict__ redo_list, const uint32_t* __restrict__ redo_count,
+                              const uint32_t* __restrict__ task_dest, XYZZ<F>* __restrict__ sums, uint32_t* __restrict__ redo2_list,
+                              uint32_t* __restrict__ redo2_count) {
+    constexpr int NW = Lazy<F>::NW;
+    __shared__ uint32_t lds[4 * NW * Table29<F>::THREADS];
+    const uint32_t nredo = *redo_count;
+    LdsAcc29<F> A{lds + threadIdx.x};
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nredo; r += gridDim.x * blockDim.x) {
+        const uint32_t tid = redo_list[r];
+        const uint32_t start = task_start[tid];
+        const bool have = accumulate_task29<F, true>(A, table, vals, start, start + (seg - task_key_by_tid[tid]));
+        if (!store_task29<F>(A, have, &sums[task_dest[tid]])) redo2_list[atomicAdd(redo2_count, 1u)] = tid;
+    }
 }
 
 // exact re-run of the tasks the lazy kernel flagged (complete formulas; table points converted back to gnark's form)
@@ -865,40 +941,49 @@ int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, X
     GA_CHECK(ctx->scratch_get("msm_wsum", (uint64_t)nsets * sizeof(XYZZ<F>), (void**)&wsum));
     hipStream_t st = ctx->work_stream();
     GA_HIP_CHECK(hipMemsetAsync(hot_count, 0, 8, st));
-    if (P.table) {
-        uint32_t *redo_list, *redo_count;
+    // bucket accumulation: the fast lazy loop, then the tasks it flagged (an exceptional addition: equal or opposite points met)
+    // once more with the complete lazy loop, then whatever is left with the exact kernel.  A table on which most tasks were flagged
+    // (a DummySetup key: every base the same point) is remembered and gets the complete loop directly from then on.
+    uint32_t h_redo = 0;
+    const uint32_t* acc_table = (const uint32_t*)d_bases;
+    {
+        uint32_t *redo_list, *redo_count, *redo2_list;
         GA_CHECK(ctx->scratch_get("msm_redo", (P.max_tasks + 2) * 4, (void**)&redo_list));
-        GA_CHECK(ctx->scratch_get("msm_redo_count", 256, (void**)&redo_count));
-        GA_HIP_CHECK(hipMemsetAsync(redo_count, 0, 4, st));
+        GA_CHECK(ctx->scratch_get("msm_redo2", (P.max_tasks + 2) * 4, (void**)&redo2_list));
+        GA_CHECK(ctx->scratch_get("msm_redo_count", 256, (void**)&redo_count));   // [0] flagged by the first loop, [1] by the retry
+        GA_HIP_CHECK(hipMemsetAsync(redo_count, 0, 8, st));
         StageTimer tm(ctx, "msm_accumulate");
+        if (!P.table) {
+            // raw (not precomputed) bases: one conversion pass to the packed hat-domain format (a one-window "table"), then the
+            // same lazy bucket kernel as the table path (an exact packed-arithmetic kernel cost ~1.5x more per addition: dropped)
+            uint32_t* hat;
+            GA_CHECK(ctx->scratch_get("msm_hat_bases", (uint64_t)P.n * sizeof(Affine<F>) + 256, (void**)&hat));
+            hipLaunchKernelGGL((msm_table29_kernel<F>), dim3((unsigned)(((P.n + TableBatch<F>::K - 1) / TableBatch<F>::K + 63) / 64)), dim3(64), 0,
+                               st, (const Affine<F>*)d_bases, (uint64_t)P.n, P.c, 1, hat);
+            acc_table = hat;
+        }
         constexpr unsigned AT = Table29<F>::THREADS;
-        hipLaunchKernelGGL((msm_accumulate29_kernel<F>), dim3((unsigned)((P.max_tasks + AT - 1) / AT)), dim3(AT), 0, st,
-                           (const uint32_t*)d_bases, (const uint32_t*)P.vals, (const uint32_t*)P.task_start, (const uint32_t*)P.task_key,
-                           (const uint32_t*)P.task_perm, (uint32_t)P.max_tasks, seg, (const uint32_t*)P.task_dest, bsum, redo_list, redo_count);
-        hipLaunchKernelGGL((msm_accumulate29_redo_kernel<F>), dim3(1024), dim3(64), 0, st, (const uint32_t*)d_bases,
-                           (const uint32_t*)P.vals, (const uint32_t*)P.task_start, (const uint32_t*)P.task_key_by_id, seg,
-                           (const uint32_t*)redo_list, (const uint32_t*)redo_count, (const uint32_t*)P.task_dest, bsum);
+        const dim3 grid((unsigned)((P.max_tasks + AT - 1) / AT));
+        if (P.table && ctx->is_degenerate(d_bases))
+            hipLaunchKernelGGL((msm_accumulate29_kernel<F, true>), grid, dim3(AT), 0, st, acc_table, (const uint32_t*)P.vals,
+                               (const uint32_t*)P.task_start, (const uint32_t*)P.task_key, (const uint32_t*)P.task_perm, (uint32_t)P.max_tasks, seg,
+                               (const uint32_t*)P.task_dest, bsum, redo2_list, redo_count + 1);
+        else
+            hipLaunchKernelGGL((msm_accumulate29_kernel<F, false>), grid, dim3(AT), 0, st, acc_table, (const uint32_t*)P.vals,
+                               (const uint32_t*)P.task_start, (const uint32_t*)P.task_key, (const uint32_t*)P.task_perm, (uint32_t)P.max_tasks, seg,
+                               (const uint32_t*)P.task_dest, bsum, redo_list, redo_count);
+        hipLaunchKernelGGL((msm_accumulate29_retry_kernel<F>), dim3(2048), dim3(AT), 0, st, acc_table, (const uint32_t*)P.vals,
+                           (const uint32_t*)P.task_start, (const uint32_t*)P.task_key_by_id, seg, (const uint32_t*)redo_list,
+                           (const uint32_t*)redo_count, (const uint32_t*)P.task_dest, bsum, redo2_list, redo_count + 1);
+        hipLaunchKernelGGL((msm_accumulate29_redo_kernel<F>), dim3(1024), dim3(64), 0, st, acc_table, (const uint32_t*)P.vals,
+                           (const uint32_t*)P.task_start, (const uint32_t*)P.task_key_by_id, seg, (const uint32_t*)redo2_list,
+                           (const uint32_t*)(redo_count + 1), (const uint32_t*)P.task_dest, bsum);
         GA_KERNEL_CHECK();
-    } else {
-        // raw (not precomputed) bases: one conversion pass to the packed hat-domain format (a one-window "table"), then the
-        // same lazy bucket kernel as the table path (an exact packed-arithmetic kernel cost ~1.5x more per addition: dropped)
-        uint32_t *hat, *redo_list, *redo_count;
-        GA_CHECK(ctx->scratch_get("msm_hat_bases", (uint64_t)P.n * sizeof(Affine<F>) + 256, (void**)&hat));
-        GA_CHECK(ctx->scratch_get("msm_redo", (P.max_tasks + 2) * 4, (void**)&redo_list));
-        GA_CHECK(ctx->scratch_get("msm_redo_count", 256, (void**)&redo_count));
-        GA_HIP_CHECK(hipMemsetAsync(redo_count, 0, 4, st));
-        StageTimer tm(ctx, "msm_accumulate");
-        hipLaunchKernelGGL((msm_table29_kernel<F>), dim3((unsigned)(((P.n + TableBatch<F>::K - 1) / TableBatch<F>::K + 63) / 64)), dim3(64), 0, st, (const Affine<F>*)d_bases,
-                           (uint64_t)P.n, P.c, 1, hat);
-        constexpr unsigned AT = Table29<F>::THREADS;
-        hipLaunchKernelGGL((msm_accumulate29_kernel<F>), dim3((unsigned)((P.max_tasks + AT - 1) / AT)), dim3(AT), 0, st,
-                           (const uint32_t*)hat, (const uint32_t*)P.vals, (const uint32_t*)P.task_start, (const uint32_t*)P.task_key,
-                           (const uint32_t*)P.task_perm, (uint32_t)P.max_tasks, seg, (const uint32_t*)P.task_dest, bsum, redo_list, redo_count);
-        hipLaunchKernelGGL((msm_accumulate29_redo_kernel<F>), dim3(1024), dim3(64), 0, st, (const uint32_t*)hat,
-                           (const uint32_t*)P.vals, (const uint32_t*)P.task_start, (const uint32_t*)P.task_key_by_id, seg,
-                           (const uint32_t*)redo_list, (const uint32_t*)redo_count, (const uint32_t*)P.task_dest, bsum);
-        GA_KERNEL_CHECK();
+        GA_HIP_CHECK(hipMemcpyAsync(&h_redo, redo_count, 4, hipMemcpyDeviceToHost, st));   // read after the stream's final sync below
     }
+    auto note_degenerate = [&]() {
+        if (P.table && (uint64_t)h_redo * 4 > P.max_tasks) ctx->mark_degenerate(d_bases);
+    };
     {
         StageTimer tm(ctx, "msm_merge");
         hipLaunchKernelGGL((msm_merge_kernel<F>), dim3((nb + 255) / 256), dim3(256), 0, st, (const XYZZ<F>*)partial,
@@ -935,6 +1020,7 @@ int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, X
         GA_KERNEL_CHECK();
         GA_HIP_CHECK(hipMemcpyAsync(out, wsum, (size_t)nsets * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
         GA_HIP_CHECK(hipStreamSynchronize(st));
+        note_degenerate();
         return GA_OK;
     }
     int nbits = 0;
@@ -969,6 +1055,7 @@ int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, X
     std::vector<XYZZ<F>> hb((size_t)nsets * rows);
     GA_HIP_CHECK(hipMemcpyAsync(hb.data(), bits, (size_t)nsets * rows * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
     GA_HIP_CHECK(hipStreamSynchronize(st));
+    note_degenerate();
     int log_m = 0;
     while ((1u << log_m) < m_groups) log_m++;
     for (int w = 0; w < nsets; w++) {   // host: ~nbits + log2(m) doublings and nbits additions per set

@@ -70,8 +70,8 @@ func Setup(r1cs constraint.ConstraintSystem) (groth16.ProvingKey, groth16.Verify
 	}
 }
 
-// DummySetup wraps [groth16.DummySetup] (all bases equal: a degenerate bucket distribution that the kernels' exact
-// redo path handles, at a cost -- the bucket stage runs ~4x slower, DESIGN 4.2; benchmark with real keys).
+// DummySetup wraps [groth16.DummySetup] (all bases equal: a degenerate bucket distribution -- every bucket meets P + P and
+// P - P; the library's complete lazy loop handles it at ~1.1x the cost of a key with distinct bases, DESIGN 4.2).
 func DummySetup(r1cs constraint.ConstraintSystem) (groth16.ProvingKey, error) {
 	switch _r1cs := r1cs.(type) {
 	case *cs_bn254.R1CS:

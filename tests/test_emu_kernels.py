@@ -557,6 +557,36 @@ def test_emu_msm_table_batch(emu_ctx, c, group, n=300, k=3):
             b.free()
 
 
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("group", [0, 1], ids=["G1", "G2"])
+def test_emu_msm_degenerate_bases(emu_ctx, c, group, n=1500):
+    """DummySetup-like key (backend/groth16/bn254/setup.go:517-543): every base the same point, so every bucket meets P + P and P - P.
+    The fast loop flags (nearly) every task, the complete lazy loop (madd29_complete / mdbl29) re-runs them; the table is then
+    remembered as degenerate and the SECOND run goes through the complete loop directly.  Also a half-degenerate vector."""
+    ctx = emu_ctx
+    bases, dlogs, scal = _device_inputs(ctx, c, group, n, 0xD0 + group)
+    wa = affine_words(c.cid, group)
+    P, K, S = bases.to_host((n, wa)), dlogs.to_host((n, 4)), scal.to_host((n, 4))
+    for variant in ("all-equal", "half-equal"):
+        Pv, Kv = P.copy(), K.copy()
+        if variant == "all-equal":
+            Pv[:], Kv[:] = P[0], K[0]
+        else:
+            Pv[::2], Kv[::2] = P[0], K[0]
+        want = _expect_from_dlogs(c, group, S, Kv)
+        dv = ctx.to_device(Pv)
+        t = ecc.PrecomputedBases(ctx, c.name, group, dv, n=n)
+        try:
+            for _ in range(2):   # second run: degenerate table -> complete loop from the start
+                assert np.array_equal(oracle.jac_to_affine(c.cid, group, t.MultiExp(scal)), want), variant
+            assert np.array_equal(oracle.jac_to_affine(c.cid, group, ecc.MultiExp(ctx, c.name, group, dv, scal, n=n)), want), variant
+        finally:
+            t.free()
+            dv.free()
+    for b in (bases, dlogs, scal):
+        b.free()
+
+
 @pytest.mark.parametrize("c,group,table", [(BN254, 0, True), (BN254, 0, False), (BLS12_381, 1, False)], ids=["bn254-G1-table", "bn254-G1-raw", "bls-G2-raw"])
 def test_emu_msm_very_hot_bucket(emu_ctx, c, group, table, n=36000):
     """boolean-heavy witness: 60 % of the scalars equal to one, 10 % zero -> the digit-1 bucket of window 0 holds 0.6 n points, i.e.

@@ -133,6 +133,13 @@ def test_msm_2_20_bn254_g1_distributions(gpu_ctx, dist):
 
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
 @pytest.mark.parametrize("group", [0, 1], ids=["G1", "G2"])
+def test_msm_degenerate_bases_2_16(gpu_ctx, c, group):
+    """all bases equal / every second base equal at 2^16 points: complete lazy loop (retry, then direct on the remembered table)"""
+    cases.test_emu_msm_degenerate_bases(gpu_ctx, c, group, n=1 << 16)
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("group", [0, 1], ids=["G1", "G2"])
 def test_msm_table_batch_2_18(gpu_ctx, c, group):
     """three commitments' worth of scalars + an all-zero and an all-one vector over one pinned SRS in one pass (2^18 points)"""
     cases.test_emu_msm_table_batch(gpu_ctx, c, group, n=1 << 18, k=3)

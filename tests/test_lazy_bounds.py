@@ -21,7 +21,9 @@ def test_bounds_hold_with_headroom(curve, fp2):
 def test_constants_match_the_kernels():
     src = open(os.path.join(ROOT, "gnark_amd", "csrc", "msm.hip.h")).read()
     g1 = src[src.index("__device__ __forceinline__ void madd29(const LdsAcc29<Fe<P>>"):src.index("__device__ __forceinline__ void madd29(const LdsAcc29<Fe2<P>>")]
-    g2 = src[src.index("__device__ __forceinline__ void madd29(const LdsAcc29<Fe2<P>>"):src.index("msm_accumulate29_kernel(")]
+    g2 = src[src.index("__device__ __forceinline__ void madd29(const LdsAcc29<Fe2<P>>"):src.index("// acc = 2*(qx, qy) for an affine q")]
+    dbl = src[src.index("__device__ __forceinline__ void mdbl29("):src.index("// acc += q with the exceptional cases")]
+    cpl = src[src.index("__device__ __forceinline__ bool madd29_complete("):src.index("// one task = the sorted pairs")]
     subs = lambda s: [int(x) for x in re.findall(r"f29_sub(?:_wide|_raw)?<(\d+)", s)]   # K of every subtraction flavour
     k = lazy_bounds.G1
     assert subs(g1) == [k["Kx"], k["Ky"], k["K3"], k["Kq"]]
@@ -30,6 +32,9 @@ def test_constants_match_the_kernels():
     assert subs(g2) == [k["Kx"], k["Ky"], k["K3"], k["Kq"]]
     assert "f29_mul_sub<P::FP2Z_K>(" in g2
     assert g2.count("f29_partial_reduce(") == len(k["partial_reduce"])
+    # the doubling and the zero tests of the complete loop use the constants lazy_bounds.check_mdbl / check() assume
+    assert [int(x) for x in re.findall(r"f29_sub<(\d+)>", dbl)] == [4, 8] and "KMS = Lazy<F>::FP2 ? P::FP2Z_K : 8" in dbl
+    assert "KS = Lazy<F>::FP2 ? 4 : 8" in cpl and lazy_bounds.G1["Kx"] == lazy_bounds.G1["Ky"] == 8 and lazy_bounds.G2["Kx"] == lazy_bounds.G2["Ky"] == 4
     f29 = open(os.path.join(ROOT, "gnark_amd", "csrc", "field29.hip.h")).read()
     prod = f29[f29.index("GA_HD_BIG F29x2<P> f29_mul("):f29.index("GA_HD_BIG F29x2<P> f29_sqr(")]
     assert subs(prod) == [] and "kp_limb<P, K>(i) - a.c1.l[i]" in prod and "constexpr int K = P::FP2Z_K;" in prod   # schoolbook on columns only
@@ -53,3 +58,13 @@ def test_general_addition_constants_match_the_kernel():
         assert subs == [k["KP"], k["KR"], k["K3"], k["Kq"]]
     assert "Lazy<F>::FP2 ? P::FP2Z_K : 8" in body and lazy_bounds.ADD_G1["Kms"] == 8 and lazy_bounds.ADD_G2["Kms"] == 16
     assert body.count("f29_partial_reduce(") == len(lazy_bounds.ADD_G2["partial_reduce"]) and not lazy_bounds.ADD_G1["partial_reduce"]
+
+
+@pytest.mark.parametrize("curve", sorted(lazy_bounds.CURVES))
+@pytest.mark.parametrize("fp2", [False, True], ids=["G1", "G2"])
+def test_affine_doubling_into_the_accumulator(curve, fp2):
+    """msm.hip.h::mdbl29 (the doubling case of the complete bucket loop): its own subtraction constants and Fp2 operand bounds,
+    and the mixed additions that follow still satisfy theirs when the accumulator starts from a doubling's output"""
+    out = lazy_bounds.check_mdbl(curve, fp2)
+    limit = lazy_bounds.CURVES[curve][1] * lazy_bounds.CURVES[curve][2]
+    assert all(v < limit - 2 for v in out.values())

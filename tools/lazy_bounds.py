@@ -18,7 +18,8 @@ G1 = dict(Kx=8, Ky=8, K3=4, Kq=8, Ky3=2)
 G2 = dict(Kx=4, Ky=4, K3=4, Kq=8, Ky3=8, KQ=8, partial_reduce=("X",))
 
 
-def check(curve: str, fp2: bool, verbose=False):
+def check(curve: str, fp2: bool, verbose=False, init=None):
+    """init: optional upper bounds (X, Y, ZZ, ZZZ) the accumulator may START from besides an affine point (the output of mdbl29)"""
     p, L, NL, bits = CURVES[curve]
     R = 1 << (L * NL)
     unit = 1 << (L * (NL - 1))
@@ -65,6 +66,9 @@ def check(curve: str, fp2: bool, verbose=False):
             return mul1(a, a)
 
     bx = by = bzz = bzzz = p                 # accumulator starts as an affine point (canonical limbs)
+    by = 2 * p                               # (a negated y is 2p - y)
+    if init is not None:
+        bx, by, bzz, bzzz = (max(a, b) for a, b in zip((bx, by, bzz, bzzz), init))
     for _ in range(1000):
         qx, qy = p, 2 * p                    # table points are canonical; a negated y is 2p - y
         U2, S2 = mul(qx, bzz), mul(qy, bzzz)
@@ -195,7 +199,85 @@ def check_add(curve: str, fp2: bool, verbose=False):
     return out
 
 
+# ---- affine doubling into the lazy accumulator (msm.hip.h::mdbl29, the complete variant of the bucket loop) ---------------------
+def check_mdbl(curve: str, fp2: bool, verbose=False):
+    """acc = 2*(qx, qy) for a table point (qx canonical, qy canonical or negated = 2p - y): every subtraction constant and Fp2
+    operand bound of mdbl29, and the outputs must not exceed the accumulator bounds madd29 was analysed with (check())."""
+    p, L, NL, bits = CURVES[curve]
+    R = 1 << (L * NL)
+    unit = 1 << (L * (NL - 1))
+
+    def lim(v):
+        assert v < R, ("value exceeds R'", log2(v))
+        return v
+
+    def need(K, b, what):
+        assert K * p - b > unit, (what, K, log2(b), log2(K * p))
+
+    def mul1(a, b):
+        lim(a), lim(b)
+        return a * b // R + p
+
+    def pr(v):
+        q = v >> bits
+        return (1 << bits) + q * ((1 << bits) - p)
+
+    if fp2:
+        import os
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from gen_constants import FP2_LAZY_K as FK
+
+        def mul(a, b):
+            assert a + unit < FK * p and b < FK * p, ("Fp2 operand above FP2Z_K*p", log2(a), log2(b))
+            return max((a * b + (FK * p + unit) * b) // R + p, 2 * a * b // R + p)
+
+        def sqr(a):
+            need(G2["KQ"], a, "KQ")
+            return max(mul1(lim(2 * a), a + G2["KQ"] * p), 2 * mul1(a, a))
+
+        def mulsub(K, a, b, c, d):
+            assert max(a, c) + unit < K * p and max(a, b, c, d) < FK * p
+            return max(a * b + K * p * b + K * p * d + c * d, 2 * a * b + 2 * K * p * d) // R + p
+        Kms = FK
+    else:
+        mul = mul1
+
+        def sqr(a):
+            return mul1(a, a)
+
+        def mulsub(K, a, b, c, d):
+            assert c + unit < K * p
+            lim(a), lim(b), lim(d)
+            return (a * b + K * p * d) // R + p
+        Kms = 8
+    qx, qy = p, 2 * p
+    U = 2 * qy
+    V = sqr(U)
+    W = mul(U, V)
+    S = mul(qx, V)
+    xx = sqr(qx)
+    M = 3 * xx
+    need(4, 2 * S, "X3: 2S below 4p")
+    X3 = sqr(M) + 4 * p
+    if fp2:
+        X3 = pr(X3)
+    need(8, X3, "t: X3 below 8p")
+    t = S + 8 * p
+    Y3 = mulsub(Kms, M, t, W, qy)
+    out = {"X": log2(X3), "Y": log2(Y3), "ZZ": log2(V), "ZZZ": log2(W)}
+    # the mixed additions that follow start from these values: every assertion of check() must hold from there too
+    acc = check(curve, fp2, init=(X3, Y3, V, W))
+    if verbose:
+        print(curve, "mdbl G2" if fp2 else "mdbl G1", {a: round(b, 2) for a, b in out.items()}, "accumulator bounds from there",
+              {k: round(acc[k], 2) for k in out})
+    return out
+
+
 if __name__ == "__main__":
+    for c in CURVES:
+        for fp2 in (False, True):
+            check_mdbl(c, fp2, verbose=True)
     for c in CURVES:
         for fp2 in (False, True):
             check_add(c, fp2, verbose=True)
