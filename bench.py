@@ -375,7 +375,7 @@ def main():
             g16 = {"proofs_per_s": round(args.groth16_proofs / el, 4), "ms_per_proof": round(el * 1e3 / args.groth16_proofs, 2),
                    "proofs": args.groth16_proofs, "constraints": n, "scaling": "strong", "partition": args.partition,
                    "mode": ("one proof over %d GPUs: key sharded by base-point range (1/%d of the tables per GPU), W uploaded per wire range "
-                            "(%d of %d wires on rank 0), computeH chains on ranks 0-2, h slices scattered, all_gather of 5 partial points" %
+                            "(%d of %d wires on rank 0), A,B,C uploaded 1/N per rank and gathered on the chain owners (N >= 3), computeH chains on ranks 0-2 beside the witness MSMs, h slices scattered, all_gather of 5 partial points" %
                             (world, world, lay["w_hi"] - lay["w_lo"], lay["nb_wires"])) if args.partition == "range" else
                            ("one proof over %d GPUs: whole key on every GPU, windows of every MSM shared out, h broadcast, all_gather of 5 partial points" % world),
                    "key_pin_s": round(pin_s, 1), "replicate_h_ms_per_proof": rep_ms,

@@ -116,6 +116,7 @@ _PROTOS = {
     "ga_g16_shard_layout": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "ga_g16_witness_partial": (C.c_int, [_P, _P, C.c_uint64, _P]),
     "ga_g16_h_chain": (C.c_int, [_P, _P, C.c_uint64, _P]),
+    "ga_g16_h_chain_dev": (C.c_int, [_P, _P, C.c_uint64]),
     "ga_g16_h_combine": (C.c_int, [_P, _P, _P, _P]),
     "ga_g16_z_partial": (C.c_int, [_P, _P, _P]),
     "ga_g16_prove_multi": (C.c_int, [C.POINTER(_P), C.c_uint32, _P, _P, _P, _P, C.c_uint64, C.c_uint64, _P, _P, _P]),

@@ -1787,6 +1787,26 @@ int ga_g16_h_chain(ga_g16_pk* p, const void* v, uint64_t n_constraints, void* ou
     return GA_OK;
 }
 
+int ga_g16_h_chain_dev(ga_g16_pk* p, void* buf_dev, uint64_t n_constraints) {
+    G16Pk* pk = reinterpret_cast<G16Pk*>(p);
+    if (!pk || !buf_dev) {
+        set_error("ga_g16_h_chain_dev: null argument");
+        return GA_ERR_INVALID;
+    }
+    if (n_constraints > pk->n) {
+        set_error("ga_g16_h_chain_dev: %llu constraints exceed the domain cardinality %llu", (unsigned long long)n_constraints,
+                  (unsigned long long)pk->n);
+        return GA_ERR_INVALID;
+    }
+    LaneLock g(pk->ctx);
+    hipStream_t st = pk->ctx->work_stream();
+    if (pk->n > n_constraints)   // computeH pads to the domain size (prove.go:356-359)
+        GA_HIP_CHECK(hipMemsetAsync((char*)buf_dev + n_constraints * 32, 0, (pk->n - n_constraints) * 32, st));
+    GA_DISPATCH_CURVE(pk->curve, GA_CHECK(ntt_domain_h_chain<C>(pk->dom, buf_dev)));
+    GA_HIP_CHECK(hipStreamSynchronize(st));
+    return GA_OK;
+}
+
 int ga_g16_h_combine(ga_g16_pk* p, void* a_dev, const void* b_dev, const void* c_dev) {
     G16Pk* pk = reinterpret_cast<G16Pk*>(p);
     if (!pk || !a_dev || !b_dev || !c_dev) {

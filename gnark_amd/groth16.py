@@ -322,6 +322,11 @@ def HChain(pk: ProvingKey, v, out_dev_ptr: int):
     pk.ctx.lib.check(pk.ctx.lib.ga_g16_h_chain(pk.handle, _ptr(v), v.shape[0], C.c_void_p(out_dev_ptr)))
 
 
+def HChainDevice(pk: ProvingKey, buf_dev_ptr: int, n_constraints: int):
+    """buf_dev (n fr elements of room, the first n_constraints filled) <- FFT_coset(iFFT(.)) in place (ga_g16_h_chain_dev)"""
+    pk.ctx.lib.check(pk.ctx.lib.ga_g16_h_chain_dev(pk.handle, C.c_void_p(buf_dev_ptr), int(n_constraints)))
+
+
 def HCombine(pk: ProvingKey, a_dev_ptr: int, b_dev_ptr: int, c_dev_ptr: int):
     """a_dev <- h = iFFT_coset((a*b - c)/(g^n - 1)), bit-reversed (ga_g16_h_combine)"""
     pk.ctx.lib.check(pk.ctx.lib.ga_g16_h_combine(pk.handle, C.c_void_p(a_dev_ptr), C.c_void_p(b_dev_ptr), C.c_void_p(c_dev_ptr)))

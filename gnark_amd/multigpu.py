@@ -61,6 +61,17 @@ def _broadcast(t, src, dist):
         dist.broadcast(t, src=src)
 
 
+def _gather(t, parts, dst, dist):
+    if _via_cpu(t, dist):
+        tmp = [p.cpu() for p in parts] if parts is not None else None
+        dist.gather(t.cpu(), tmp, dst=dst)
+        if parts is not None:
+            for p, q in zip(parts, tmp):
+                p.copy_(q)
+    else:
+        dist.gather(t, parts, dst=dst)
+
+
 def _scatter(out, pieces, src, dist):
     if _via_cpu(out, dist):
         tmp = out.cpu()
@@ -120,7 +131,7 @@ def msm_window_sharded(ctx, curve, group: int, points, scalars, n: int, dist, de
     return ecc.combine_windows(curve, group, windows, cbits, lib=ctx.lib)
 
 
-def groth16_prove_sharded(pk, solution, nb_public: int, r, s, dist, device=None, replicate_h=False):
+def groth16_prove_sharded(pk, solution, nb_public: int, r, s, dist, device=None, replicate_h=False, replicate_uploads=False):
     """One proof over a key sharded by base-point range (groth16.ProvingKey(..., shard=(rank, world))), one process per GPU.
 
     Serial work is not replicated: every rank uploads only the wire range of W its bases cover; the three chains of computeH
@@ -128,7 +139,8 @@ def groth16_prove_sharded(pk, solution, nb_public: int, r, s, dist, device=None,
     BESIDE the rank's witness MSMs (second lane of the context) -- and travel to rank 0 over xGMI (send/recv, 32 B x n each);
     rank 0 finishes h and scatters the slices (32 B x n / world per peer); every rank runs the MSM over its slice of pk.G1.Z;
     one all_gather of 3 G1Jac + 1 G2Jac per rank; every rank finishes identically.
-    replicate_h=True keeps the round-1 scheme (every rank recomputes h) for comparison."""
+    replicate_h=True keeps the round-1 scheme (every rank recomputes h) for comparison; replicate_uploads=True makes the chain
+    owners upload their whole vectors themselves even with 3+ ranks."""
     from . import groth16
     world = 1 if dist is None else dist.get_world_size()
     if world == 1 or replicate_h:
@@ -157,16 +169,36 @@ def groth16_prove_sharded(pk, solution, nb_public: int, r, s, dist, device=None,
     sync()
     state = {"pieces": None, "error": None}
 
+    nc = int(np.asarray(solution.A).shape[0])                 # constraints: the length of the solver's A, B, C
+    cshare = (nc + world - 1) // world                         # every rank uploads rows [rank*cshare, ...) of A, B and C
+    sliced = world >= 3 and not replicate_uploads              # (with one or two ranks the chain owners upload whole vectors)
+
     def h_side():
-        """the H side of the proof, beside the witness MSMs of the same rank: ga_g16_h_chain / ga_g16_h_combine take the context's
-        second lane when the device is busy with the witness MSMs (common.hip.h LaneLock), so the 512 MiB upload, the two
-        transforms and the xGMI hops of b and c hide behind them"""
+        """the H side of the proof, beside the witness MSMs of the same rank (ga_g16_h_chain* / ga_g16_h_combine take the
+        context's second lane when the device is busy, common.hip.h LaneLock).  With 3+ ranks no PCIe link carries a whole vector:
+        every rank uploads 1/N of A, B and C over its own link and the pieces are gathered on the chain owners over xGMI
+        (N x 55 GB/s of PCIe in parallel, 7 links x 150 GB/s into each owner) -- 3.6 ms of upload at N = 8 instead of 9.6 ms."""
         try:
             if device is not None:
                 torch.cuda.set_device(dev)   # the current device is per thread
-            for k in range(3):
-                if rank == owner[k]:
-                    groth16.HChain(pk, vecs[k], bufs[k].data_ptr())
+            if sliced:
+                lo, hi = min(rank * cshare, nc), min((rank + 1) * cshare, nc)
+                for k in range(3):
+                    piece = torch.zeros((cshare, 4), dtype=torch.int64, device=dev)
+                    if hi > lo:
+                        src = np.ascontiguousarray(np.asarray(vecs[k])[lo:hi]).view(np.int64)
+                        piece[: hi - lo].copy_(torch.from_numpy(src))
+                    parts = [torch.empty_like(piece) for _ in range(world)] if rank == owner[k] else None
+                    _gather(piece, parts, owner[k], dist)
+                    if rank == owner[k]:
+                        flat = torch.cat(parts)[:nc]
+                        bufs[k][:nc].copy_(flat)
+                        sync()
+                        groth16.HChainDevice(pk, bufs[k].data_ptr(), nc)
+            else:
+                for k in range(3):
+                    if rank == owner[k]:
+                        groth16.HChain(pk, vecs[k], bufs[k].data_ptr())
             for k in range(3):                       # b and c travel to rank 0
                 if owner[k] != 0:
                     if rank == owner[k]:
@@ -189,7 +221,7 @@ def groth16_prove_sharded(pk, solution, nb_public: int, r, s, dist, device=None,
             state["error"] = e
 
     helper = None
-    if rank in owner:
+    if rank in owner or sliced:                # with sliced uploads every rank takes part in the gathers
         helper = threading.Thread(target=h_side)
         helper.start()
     part = groth16.WitnessPartial(pk, solution.W, nb_public)

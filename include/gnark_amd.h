@@ -304,6 +304,10 @@ int ga_g16_finish(ga_g16_pk* pk, const void* partials_sum, const void* r, const 
 int ga_g16_shard_layout(ga_g16_pk* pk, uint64_t* out8);
 int ga_g16_witness_partial(ga_g16_pk* pk, const void* w, uint64_t nb_public, void* partials_out);
 int ga_g16_h_chain(ga_g16_pk* pk, const void* v, uint64_t n_constraints, void* out_dev);
+/* the same chain on a vector that already sits on the device (buf_dev: n fr elements of room, the first n_constraints hold the
+ * solver's vector): for callers that bring A, B, C to the chain's device in pieces -- every GPU of a node uploading 1/N of each
+ * vector over its own PCIe link and handing it on over xGMI (gnark_amd/multigpu.py) -- instead of one 512 MiB upload per chain */
+int ga_g16_h_chain_dev(ga_g16_pk* pk, void* buf_dev, uint64_t n_constraints);
 int ga_g16_h_combine(ga_g16_pk* pk, void* a_dev, const void* b_dev, const void* c_dev);
 int ga_g16_z_partial(ga_g16_pk* pk, const void* h_slice_dev, void* partial_out);
 /* One proof over the GPUs of a node from ONE process (what a Go caller uses: mi355x.WithDevices): keys[i] = shard i of n of the

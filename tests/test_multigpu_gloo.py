@@ -22,9 +22,10 @@ def test_shard_range_partitions_exactly():
 import pytest  # noqa: E402
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 5])
 def test_gloo_ranks_msm_and_groth16_sharding(emu_lib, world):
-    """world 2: rank 0 runs the a and c chains of computeH, rank 1 the b chain; world 3: one chain per rank.  Both MSM
+    """world 2: rank 0 runs the a and c chains of computeH, rank 1 the b chain; world 3: one chain per rank; world 5: two ranks own no
+    chain but still upload their fifth of A, B, C (sliced uploads gathered on the chain owners).  Both MSM
     partitionings, the sharded Groth16 proof (wire-range upload, chains sent to rank 0, h slices scattered) against the oracle's
     proof bytes, and the round-1 replicate-h scheme for comparison."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
