@@ -61,12 +61,19 @@ void Ctx::scratch_free_all() {
 }
 
 void Tunables::read_env() {
-    *this = Tunables();
-    if (const char* e = getenv("GA_MSM_MAX_CHUNK")) msm_max_chunk = strtoull(e, nullptr, 10);
-    if (const char* e = getenv("GA_REDUCE_LAZY_MIN")) reduce_lazy_min = strtoull(e, nullptr, 10);
-    if (const char* e = getenv("GA_G16_SHARE_MIN_PCT")) g16_share_min_pct = atoi(e);
-    if (const char* e = getenv("GA_G16_LANES")) g16_lanes = atoi(e);
-    if (const char* e = getenv("GA_TABLE_C")) table_c = atoi(e);
+    // parsed into a local first: a prover on lane 1 may be reading the knobs while lane 0 refreshes them, and must never see the
+    // defaults flicker; the stored copy changes only when the environment did
+    Tunables t;
+    if (const char* e = getenv("GA_MSM_MAX_CHUNK")) t.msm_max_chunk = strtoull(e, nullptr, 10);
+    if (const char* e = getenv("GA_REDUCE_LAZY_MIN")) t.reduce_lazy_min = strtoull(e, nullptr, 10);
+    if (const char* e = getenv("GA_G16_SHARE_MIN_PCT")) t.g16_share_min_pct = atoi(e);
+    if (const char* e = getenv("GA_G16_LANES")) t.g16_lanes = atoi(e);
+    if (const char* e = getenv("GA_TABLE_C")) t.table_c = atoi(e);
+    if (t.msm_max_chunk != msm_max_chunk) msm_max_chunk = t.msm_max_chunk;
+    if (t.reduce_lazy_min != reduce_lazy_min) reduce_lazy_min = t.reduce_lazy_min;
+    if (t.g16_share_min_pct != g16_share_min_pct) g16_share_min_pct = t.g16_share_min_pct;
+    if (t.g16_lanes != g16_lanes) g16_lanes = t.g16_lanes;
+    if (t.table_c != table_c) table_c = t.table_c;
     g_table_c = table_c;
 }
 
