@@ -84,6 +84,7 @@ struct StageRec {
 //   GA_MSM_MAX_CHUNK      split an MSM along the point axis into chunks of at most this many points (msmChunkedG1/G2 analogue)
 //   GA_REDUCE_LAZY_MIN    bucket count from which the window reduction runs in the lazy representation
 //   GA_G16_SHARE_MIN_PCT  a Groth16 base vector shares the single witness sort when it covers at least this % of the wires
+//   GA_MSM_MIN_SEG        shortest task length the bucket lists are cut into (points per task)
 //   GA_TABLE_C            force the window width of precomputed tables built from now on (experiments; 0 = planned)
 //   GA_G16_LANES          1: a second concurrent ga_g16_prove caller queues for the device instead of proving on lane 1
 struct Tunables {
@@ -92,6 +93,7 @@ struct Tunables {
     int g16_share_min_pct = 90;
     int g16_lanes = 2;
     int table_c = 0;
+    uint64_t msm_min_seg = 256;
     void read_env();
 };
 

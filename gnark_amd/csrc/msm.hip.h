@@ -813,7 +813,8 @@ int msm_prepare(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, in
     // task length: buckets up to 4x the mean size stay one task, unless that would leave fewer than ~2^20 tasks for the
     // 256 CUs x 16 waves x 64 lanes (few-bucket cases: small n, or table mode where all windows share 2^(c-1) buckets)
     uint64_t mean = m / nb + 1;
-    uint64_t seg64 = mean * 4 < 256 ? 256 : mean * 4;
+    const uint64_t min_seg = ctx->tun.msm_min_seg;
+    uint64_t seg64 = mean * 4 < min_seg ? min_seg : mean * 4;
     if (nb < (1u << 19)) {
         uint64_t want = (m >> 19) + 1, lo = mean / 6 > 32 ? mean / 6 : 32;   // keep a bucket's partials <= ~MSM_HOT_TASKS
         if (want < lo) want = lo;
