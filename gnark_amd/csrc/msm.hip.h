@@ -728,6 +728,70 @@ msm_reduce_groups_redo_kernel(const XYZZ<F>* __restrict__ bsum, uint32_t half, u
     }
 }
 
+// ---- block-wide sums of XYZZ points in the lazy representation ---------------------------------------------------------------
+// The tree sums after the group pass (per-bit sums, segment sums) are LATENCY-bound: one wave per block adds a handful of points
+// serially and then walks a 6-level tree, every step an addition in the exact packed arithmetic (~20 us G1, ~60 us G2 per dependent
+// addition).  In the lazy representation a dependent addition is ~3x shorter.  Exceptional additions (equal or opposite points: never
+// for sums of distinct random buckets, always for a degenerate key) leave ZZ == 0; the block then repeats its sum exactly.
+template <class F>
+struct LazyPt {
+    Lazy4<F> v;
+    uint32_t inf;
+};
+template <class F>
+__device__ __forceinline__ void lazy_acc(LazyPt<F>& acc, const XYZZ<F>& p) {
+    if (is_inf(p)) return;
+    const Lazy4<F> b = lazy4_from_mem<F>(p);
+    if (acc.inf) {
+        acc.v = b;
+        acc.inf = 0;
+    } else {
+        add29<F>(acc.v, b);
+    }
+}
+template <class F>
+__device__ __forceinline__ void lazy_acc(LazyPt<F>& acc, const LazyPt<F>& b) {
+    if (b.inf) return;
+    if (acc.inf) acc = b;
+    else add29<F>(acc.v, b.v);
+}
+// sum over the block's 64 lanes (result in lane 0) of the points src(i), i = lane, lane + 64, ... < count; written to *dst.
+// src(i) returns a pointer to the i-th input of this block.
+template <class F, class Src>
+__device__ __forceinline__ void block_sum29(uint32_t count, Src src, XYZZ<F>* dst, LazyPt<F>* sh, XYZZ<F>* shx, uint32_t* bad) {
+    const uint32_t lane = threadIdx.x;
+    LazyPt<F> acc;
+    acc.inf = 1;
+    for (uint32_t i = lane; i < count; i += 64) lazy_acc<F>(acc, load_pod<XYZZ<F>>(src(i)));
+    for (uint32_t stride = 32; stride >= 1; stride >>= 1) {
+        sh[lane] = acc;
+        __syncthreads();
+        if (lane < stride) lazy_acc<F>(acc, sh[lane + stride]);
+        __syncthreads();
+    }
+    if (lane == 0) {
+        XYZZ<F> out = xyzz_inf<F>();
+        uint32_t b = 0;
+        if (!acc.inf) {
+            out.zz = Lazy<F>::to_mem(acc.v.zz);
+            b = is_zero(out.zz) ? 1u : 0u;
+            out.x = Lazy<F>::to_mem(acc.v.x);
+            out.y = Lazy<F>::to_mem(acc.v.y);
+            out.zzz = Lazy<F>::to_mem(acc.v.zzz);
+        }
+        if (!b) store_pod(dst, out);
+        *bad = b;
+    }
+    __syncthreads();
+    if (*bad) {   // an exceptional addition somewhere in this block's sum: once more with the complete formulas
+        XYZZ<F> e = xyzz_inf<F>();
+        for (uint32_t i = lane; i < count; i += 64) e = add(e, load_pod<XYZZ<F>>(src(i)));
+        e = wave_tree_sum(e, shx);
+        if (lane == 0) store_pod(dst, e);
+    }
+    __syncthreads();
+}
+
 // part[((w*nbits + b)*chunks + ch)] = sum of rsum[w][g] over the groups g of chunk ch (chunk_len groups, a power of two)
 // whose index has bit b set.  grid = (chunks, nbits, nsets), one wave per block.
 template <class F>
@@ -736,26 +800,36 @@ msm_bit_partial_kernel(const XYZZ<F>* __restrict__ rsum, const XYZZ<F>* __restri
                        uint32_t chunk_len, int log_chunk, XYZZ<F>* __restrict__ part) {
     // blockIdx.y == nbits - 1 (the last row of the grid) is not a bit: it sums the chunk of lsum, so that one launch and one
     // final segment sum produce every quantity the host needs
-    __shared__ XYZZ<F> sh[64];
+    __shared__ LazyPt<F> sh[64];
+    __shared__ XYZZ<F> shx[64];
+    __shared__ uint32_t bad;
     const uint32_t ch = blockIdx.x, b = blockIdx.y, w = blockIdx.z;
     const uint32_t nbits = gridDim.y, chunks = gridDim.x;
     const uint32_t base = ch * chunk_len;
     const XYZZ<F>* R = rsum + (uint64_t)w * groups_per_win;
-    XYZZ<F> acc = xyzz_inf<F>();
+    XYZZ<F>* dst = &part[((uint64_t)w * nbits + b) * chunks + ch];
     if (b == nbits - 1) {
         const XYZZ<F>* Lp = lsum + (uint64_t)w * groups_per_win;
-        for (uint32_t i = threadIdx.x; i < chunk_len; i += 64) acc = add(acc, load_pod<XYZZ<F>>(&Lp[base + i]));
+        block_sum29<F>(chunk_len, [&](uint32_t i) { return &Lp[base + i]; }, dst, sh, shx, &bad);
     } else if ((int)b >= log_chunk) {
-        if ((base >> b) & 1)   // the whole chunk has the bit set
-            for (uint32_t i = threadIdx.x; i < chunk_len; i += 64) acc = add(acc, load_pod<XYZZ<F>>(&R[base + i]));
+        // the whole chunk has the bit set, or none of it
+        block_sum29<F>(((base >> b) & 1) ? chunk_len : 0u, [&](uint32_t i) { return &R[base + i]; }, dst, sh, shx, &bad);
     } else {
-        for (uint32_t i = threadIdx.x; i < chunk_len / 2; i += 64) {   // insert a 1 at bit position b of the local index
-            uint32_t g = ((i >> b) << (b + 1)) | (1u << b) | (i & ((1u << b) - 1));
-            acc = add(acc, load_pod<XYZZ<F>>(&R[base + g]));
-        }
+        // insert a 1 at bit position b of the local index
+        block_sum29<F>(chunk_len / 2, [&](uint32_t i) { return &R[base + (((i >> b) << (b + 1)) | (1u << b) | (i & ((1u << b) - 1)))]; }, dst, sh,
+                       shx, &bad);
     }
-    acc = wave_tree_sum(acc, sh);
-    if (threadIdx.x == 0) store_pod(&part[((uint64_t)w * nbits + b) * chunks + ch], acc);
+}
+
+// the same per-segment sum in the lazy representation (window reduction of large bucket sets)
+template <class F>
+__global__ void __launch_bounds__(64)
+msm_segment_sum29_kernel(const XYZZ<F>* __restrict__ in, uint32_t seg_len, XYZZ<F>* __restrict__ out) {
+    __shared__ LazyPt<F> sh[64];
+    __shared__ XYZZ<F> shx[64];
+    __shared__ uint32_t bad;
+    const uint64_t base = (uint64_t)blockIdx.x * seg_len;
+    block_sum29<F>(seg_len, [&](uint32_t i) { return &in[base + i]; }, &out[blockIdx.x], sh, shx, &bad);
 }
 
 // out[b] = sum of in[b*seg_len .. (b+1)*seg_len): one wave per segment, strided partial sums + LDS tree
@@ -1048,7 +1122,7 @@ int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, X
         // rows 0..nbits-1: per-bit sums of rsum; row nbits: sum of lsum
         hipLaunchKernelGGL((msm_bit_partial_kernel<F>), dim3(chunks, (unsigned)nbits + 1, (unsigned)nsets), dim3(64), 0, st,
                            (const XYZZ<F>*)rsum, (const XYZZ<F>*)gsum, groups_per_win, chunk_len, log_chunk, bpart);
-        hipLaunchKernelGGL((msm_segment_sum_kernel<F>), dim3((unsigned)(nsets * (nbits + 1))), dim3(64), 0, st, (const XYZZ<F>*)bpart,
+        hipLaunchKernelGGL((msm_segment_sum29_kernel<F>), dim3((unsigned)(nsets * (nbits + 1))), dim3(64), 0, st, (const XYZZ<F>*)bpart,
                            chunks, bits);
         GA_KERNEL_CHECK();
     }
