@@ -510,60 +510,7 @@ __device__ __forceinline__ XYZZ<F> wave_tree_sum(XYZZ<F> acc, XYZZ<F>* sh) {
     return acc;
 }
 
-template <class F>
-__global__ void __launch_bounds__(64)
-msm_hot_kernel(const XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__ task_off,
-               const uint32_t* __restrict__ hot_list, const uint32_t* __restrict__ hot_count, XYZZ<F>* __restrict__ bsum) {
-    __shared__ XYZZ<F> sh[64];
-    const uint32_t nh = *hot_count;
-    for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
-        uint32_t b = hot_list[h];
-        uint32_t t0 = task_off[b], t1 = task_off[b + 1];
-        XYZZ<F> acc = xyzz_inf<F>();
-        for (uint32_t t = t0 + threadIdx.x; t < t1; t += 64) acc = add(acc, load_pod<XYZZ<F>>(&partial[t]));
-        acc = wave_tree_sum(acc, sh);
-        if (threadIdx.x == 0) store_pod(&bsum[b], acc);
-    }
-}
-
-// Very hot buckets (thousands of partial sums: the digit-1 bucket of a boolean-heavy witness): stage 1 gives each of
-// MSM_VHOT_SPLIT blocks a contiguous share of the bucket's partials (64 lanes strided + LDS tree), stage 2 sums the
-// MSM_VHOT_SPLIT block results of a bucket.  One block per bucket (msm_hot_kernel) would add n/2/seg/64 partials serially per lane:
-// measured 4.1 ms (G1) / 16.3 ms (G2) of merge at 2^24 with half the scalars equal to one.
-template <class F>
-__global__ void __launch_bounds__(64)
-msm_vhot_stage1_kernel(const XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__ task_off, const uint32_t* __restrict__ vhot_list,
-                       const uint32_t* __restrict__ vhot_count, XYZZ<F>* __restrict__ vtmp) {
-    __shared__ XYZZ<F> sh[64];
-    const uint32_t items = *vhot_count * MSM_VHOT_SPLIT;
-    for (uint32_t id = blockIdx.x; id < items; id += gridDim.x) {
-        const uint32_t h = id / MSM_VHOT_SPLIT, part = id % MSM_VHOT_SPLIT;
-        const uint32_t b = vhot_list[h];
-        const uint32_t t0 = task_off[b], t1 = task_off[b + 1];
-        const uint32_t per = (t1 - t0 + MSM_VHOT_SPLIT - 1) / MSM_VHOT_SPLIT;
-        const uint32_t lo = t0 + part * per < t1 ? t0 + part * per : t1;
-        const uint32_t hi = lo + per < t1 ? lo + per : t1;
-        XYZZ<F> acc = xyzz_inf<F>();
-        for (uint32_t t = lo + threadIdx.x; t < hi; t += 64) acc = add(acc, load_pod<XYZZ<F>>(&partial[t]));
-        acc = wave_tree_sum(acc, sh);
-        if (threadIdx.x == 0) store_pod(&vtmp[id], acc);
-        __syncthreads();
-    }
-}
-template <class F>
-__global__ void __launch_bounds__(64)
-msm_vhot_stage2_kernel(const XYZZ<F>* __restrict__ vtmp, const uint32_t* __restrict__ vhot_list, const uint32_t* __restrict__ vhot_count,
-                       XYZZ<F>* __restrict__ bsum) {
-    static_assert(MSM_VHOT_SPLIT == 64, "one partial result per lane");
-    __shared__ XYZZ<F> sh[64];
-    const uint32_t nv = *vhot_count;
-    for (uint32_t h = blockIdx.x; h < nv; h += gridDim.x) {
-        XYZZ<F> acc = load_pod<XYZZ<F>>(&vtmp[h * MSM_VHOT_SPLIT + threadIdx.x]);
-        acc = wave_tree_sum(acc, sh);
-        if (threadIdx.x == 0) store_pod(&bsum[vhot_list[h]], acc);
-        __syncthreads();
-    }
-}
+// (msm_hot_kernel and the very-hot-bucket kernels follow block_sum29 below)
 
 // ---- 6. window reduction ----------------------------------------------------------------------------
 // group g of window w covers digits k in [g*m+1, (g+1)*m]; out = sum_k k*B_k over the group
@@ -767,6 +714,57 @@ __device__ __forceinline__ void block_sum29(uint32_t count, Src src, XYZZ<F>* ds
         if (lane == 0) store_pod(dst, e);
     }
     __syncthreads();
+}
+
+// hot buckets (17..512 partial sums): one block per bucket
+template <class F>
+__global__ void __launch_bounds__(64)
+msm_hot_kernel(const XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__ task_off,
+               const uint32_t* __restrict__ hot_list, const uint32_t* __restrict__ hot_count, XYZZ<F>* __restrict__ bsum) {
+    __shared__ LazyPt<F> sh[64];
+    __shared__ XYZZ<F> shx[64];
+    __shared__ uint32_t bad;
+    const uint32_t nh = *hot_count;
+    for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
+        const uint32_t b = hot_list[h];
+        const uint32_t t0 = task_off[b], t1 = task_off[b + 1];
+        block_sum29<F>(t1 - t0, [&](uint32_t i) { return &partial[t0 + i]; }, &bsum[b], sh, shx, &bad);
+    }
+}
+
+// Very hot buckets (thousands of partial sums: the digit-1 bucket of a boolean-heavy witness): stage 1 gives each of
+// MSM_VHOT_SPLIT blocks a contiguous share of the bucket's partials (64 lanes strided + LDS tree), stage 2 sums the
+// MSM_VHOT_SPLIT block results of a bucket.  One block per bucket (msm_hot_kernel) would add n/2/seg/64 partials serially per lane:
+// measured 4.1 ms (G1) / 16.3 ms (G2) of merge at 2^24 with half the scalars equal to one.
+template <class F>
+__global__ void __launch_bounds__(64)
+msm_vhot_stage1_kernel(const XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__ task_off, const uint32_t* __restrict__ vhot_list,
+                       const uint32_t* __restrict__ vhot_count, XYZZ<F>* __restrict__ vtmp) {
+    __shared__ LazyPt<F> sh[64];
+    __shared__ XYZZ<F> shx[64];
+    __shared__ uint32_t bad;
+    const uint32_t items = *vhot_count * MSM_VHOT_SPLIT;
+    for (uint32_t id = blockIdx.x; id < items; id += gridDim.x) {
+        const uint32_t h = id / MSM_VHOT_SPLIT, part = id % MSM_VHOT_SPLIT;
+        const uint32_t b = vhot_list[h];
+        const uint32_t t0 = task_off[b], t1 = task_off[b + 1];
+        const uint32_t per = (t1 - t0 + MSM_VHOT_SPLIT - 1) / MSM_VHOT_SPLIT;
+        const uint32_t lo = t0 + part * per < t1 ? t0 + part * per : t1;
+        const uint32_t hi = lo + per < t1 ? lo + per : t1;
+        block_sum29<F>(hi - lo, [&](uint32_t i) { return &partial[lo + i]; }, &vtmp[id], sh, shx, &bad);
+    }
+}
+template <class F>
+__global__ void __launch_bounds__(64)
+msm_vhot_stage2_kernel(const XYZZ<F>* __restrict__ vtmp, const uint32_t* __restrict__ vhot_list, const uint32_t* __restrict__ vhot_count,
+                       XYZZ<F>* __restrict__ bsum) {
+    static_assert(MSM_VHOT_SPLIT == 64, "one partial result per lane");
+    __shared__ LazyPt<F> sh[64];
+    __shared__ XYZZ<F> shx[64];
+    __shared__ uint32_t bad;
+    const uint32_t nv = *vhot_count;
+    for (uint32_t h = blockIdx.x; h < nv; h += gridDim.x)
+        block_sum29<F>(MSM_VHOT_SPLIT, [&](uint32_t i) { return &vtmp[h * MSM_VHOT_SPLIT + i]; }, &bsum[vhot_list[h]], sh, shx, &bad);
 }
 
 // ---- 5. merge partials ----------------------------------------------------------------------------
