@@ -70,11 +70,13 @@ void Tunables::read_env() {
     if (const char* e = getenv("GA_G16_LANES")) t.g16_lanes = atoi(e);
     if (const char* e = getenv("GA_TABLE_C")) t.table_c = atoi(e);
     if (const char* e = getenv("GA_MSM_MIN_SEG")) t.msm_min_seg = strtoull(e, nullptr, 10);
+    if (const char* e = getenv("GA_MSM_EXACT_REDO")) t.msm_exact_redo = atoi(e);
     if (t.msm_max_chunk != msm_max_chunk) msm_max_chunk = t.msm_max_chunk;
     if (t.reduce_lazy_min != reduce_lazy_min) reduce_lazy_min = t.reduce_lazy_min;
     if (t.g16_share_min_pct != g16_share_min_pct) g16_share_min_pct = t.g16_share_min_pct;
     if (t.g16_lanes != g16_lanes) g16_lanes = t.g16_lanes;
     if (t.table_c != table_c) table_c = t.table_c;
+    if (t.msm_exact_redo != msm_exact_redo) msm_exact_redo = t.msm_exact_redo;
     if (t.msm_min_seg != msm_min_seg && t.msm_min_seg >= 32) msm_min_seg = t.msm_min_seg;
     g_table_c = table_c;
 }

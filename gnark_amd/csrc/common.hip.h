@@ -85,6 +85,7 @@ struct StageRec {
 //   GA_REDUCE_LAZY_MIN    bucket count from which the window reduction runs in the lazy representation
 //   GA_G16_SHARE_MIN_PCT  a Groth16 base vector shares the single witness sort when it covers at least this % of the wires
 //   GA_MSM_MIN_SEG        shortest task length the bucket lists are cut into (points per task)
+//   GA_MSM_EXACT_REDO     1: tasks flagged by the fast bucket loop go straight to the exact-arithmetic kernel (tests)
 //   GA_TABLE_C            force the window width of precomputed tables built from now on (experiments; 0 = planned)
 //   GA_G16_LANES          1: a second concurrent ga_g16_prove caller queues for the device instead of proving on lane 1
 struct Tunables {
@@ -94,6 +95,7 @@ struct Tunables {
     int g16_lanes = 2;
     int table_c = 0;
     uint64_t msm_min_seg = 256;
+    int msm_exact_redo = 0;
     void read_env();
 };
 

@@ -1058,7 +1058,7 @@ int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, X
         }
         constexpr unsigned AT = Table29<F>::THREADS;
         const dim3 grid((unsigned)((P.max_tasks + AT - 1) / AT));
-        if (P.table && ctx->is_degenerate(d_bases))
+        if (P.table && !ctx->tun.msm_exact_redo && ctx->is_degenerate(d_bases))
             hipLaunchKernelGGL((msm_accumulate29_kernel<F, true>), grid, dim3(AT), 0, st, acc_table, (const uint32_t*)P.vals,
                                (const uint32_t*)P.task_start, (const uint32_t*)P.task_key, (const uint32_t*)P.task_perm, (uint32_t)P.max_tasks, seg,
                                (const uint32_t*)P.task_dest, bsum, redo2_list, redo_count + 1);
@@ -1066,9 +1066,14 @@ int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, X
             hipLaunchKernelGGL((msm_accumulate29_kernel<F, false>), grid, dim3(AT), 0, st, acc_table, (const uint32_t*)P.vals,
                                (const uint32_t*)P.task_start, (const uint32_t*)P.task_key, (const uint32_t*)P.task_perm, (uint32_t)P.max_tasks, seg,
                                (const uint32_t*)P.task_dest, bsum, redo_list, redo_count);
-        hipLaunchKernelGGL((msm_accumulate29_retry_kernel<F>), dim3(2048), dim3(AT), 0, st, acc_table, (const uint32_t*)P.vals,
-                           (const uint32_t*)P.task_start, (const uint32_t*)P.task_key_by_id, seg, (const uint32_t*)redo_list,
-                           (const uint32_t*)redo_count, (const uint32_t*)P.task_dest, bsum, redo2_list, redo_count + 1);
+        if (!ctx->tun.msm_exact_redo)   // (GA_MSM_EXACT_REDO=1: tests send the flagged tasks straight to the exact kernel below)
+            hipLaunchKernelGGL((msm_accumulate29_retry_kernel<F>), dim3(2048), dim3(AT), 0, st, acc_table, (const uint32_t*)P.vals,
+                               (const uint32_t*)P.task_start, (const uint32_t*)P.task_key_by_id, seg, (const uint32_t*)redo_list,
+                               (const uint32_t*)redo_count, (const uint32_t*)P.task_dest, bsum, redo2_list, redo_count + 1);
+        else
+            hipLaunchKernelGGL((msm_accumulate29_redo_kernel<F>), dim3(1024), dim3(64), 0, st, acc_table, (const uint32_t*)P.vals,
+                               (const uint32_t*)P.task_start, (const uint32_t*)P.task_key_by_id, seg, (const uint32_t*)redo_list,
+                               (const uint32_t*)redo_count, (const uint32_t*)P.task_dest, bsum);
         hipLaunchKernelGGL((msm_accumulate29_redo_kernel<F>), dim3(1024), dim3(64), 0, st, acc_table, (const uint32_t*)P.vals,
                            (const uint32_t*)P.task_start, (const uint32_t*)P.task_key_by_id, seg, (const uint32_t*)redo2_list,
                            (const uint32_t*)(redo_count + 1), (const uint32_t*)P.task_dest, bsum);

@@ -557,6 +557,14 @@ def test_emu_msm_table_batch(emu_ctx, c, group, n=300, k=3):
             b.free()
 
 
+def test_emu_msm_degenerate_bases_exact_kernel(emu_ctx, monkeypatch, c=BN254, group=0, n=600):
+    """the last line of defence, msm_accumulate29_redo_kernel (complete formulas in exact arithmetic), is what GA_MSM_EXACT_REDO=1
+    sends every flagged task to: same degenerate inputs, same results"""
+    monkeypatch.setenv("GA_MSM_EXACT_REDO", "1")
+    test_emu_msm_degenerate_bases(emu_ctx, c, group, n=n)
+    test_emu_msm_degenerate_bases(emu_ctx, BLS12_381, 1, n=200)
+
+
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
 @pytest.mark.parametrize("group", [0, 1], ids=["G1", "G2"])
 def test_emu_msm_degenerate_bases(emu_ctx, c, group, n=1500):

@@ -138,6 +138,11 @@ def test_msm_degenerate_bases_2_16(gpu_ctx, c, group):
     cases.test_emu_msm_degenerate_bases(gpu_ctx, c, group, n=1 << 16)
 
 
+def test_msm_degenerate_bases_exact_kernel(gpu_ctx, monkeypatch):
+    """GA_MSM_EXACT_REDO=1: the exact-arithmetic re-run kernel on all-equal bases (BN254 G1 2^14, BLS12-381 G2 2^12)"""
+    cases.test_emu_msm_degenerate_bases_exact_kernel(gpu_ctx, monkeypatch, n=1 << 14)
+
+
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
 @pytest.mark.parametrize("group", [0, 1], ids=["G1", "G2"])
 def test_msm_table_batch_2_18(gpu_ctx, c, group):
