@@ -1338,9 +1338,10 @@ static int marshal(const void* proof, const void* commitments, uint32_t ncom, co
 }
 
 // One proof over several devices from ONE process: keys[i] = shard i of n of the same proving key, each in a context on its own
-// device.  One host thread per device; the three chains of computeH run on the first three devices (a, b, c uploaded over three
-// different PCIe links), b and c travel to device 0 over xGMI (hipMemcpyPeerAsync), device 0 finishes h and sends every device
-// its slice; partial sums are added on the host.  With n = 1 this is ga_g16_prove.
+// device.  One host thread per device for the MSMs plus one for the H side (second lane of the context); the three chains of computeH
+// run on the first three devices beside their witness MSMs (with n >= 3 every device uploads 1/n of A, B, C over its own PCIe link and
+// forwards the rows to the chain owners over xGMI), b and c travel to device 0 (hipMemcpyPeerAsync), device 0 finishes h and sends
+// every device its slice; partial sums are added on the host.  With n = 1 this is ga_g16_prove.
 struct MultiShared {
     std::mutex mu;
     std::condition_variable cv;
@@ -1384,15 +1385,22 @@ static int prove_multi(G16Pk* const* pks, uint32_t n, const void* w, const void*
     void* chain_buf[3] = {nullptr, nullptr, nullptr};   // on the owner's device
     void* dev0_buf[3] = {nullptr, nullptr, nullptr};     // on device 0
     std::vector<void*> h_slice(n, nullptr);
-    MultiShared sh;
+    MultiShared sh, hs;   // sh: the device workers; hs: their H-side helper threads
     sh.n = n;
+    hs.n = n;
+    const bool sliced = n >= 3;
+    const uint64_t cshare = (n_constraints + n - 1) / n;
     auto worker = [&](uint32_t t) {
         G16Pk* pk = pks[t];
         Ctx* ctx = pk->ctx;
         SlotLease slot(ctx);
         std::lock_guard<std::mutex> g(ctx->mu);   // one proof at a time per device (icicle.go:821-823)
         ctx->tun.read_env();
-        auto bail = [&](const char* what) { sh.fail((std::string(what) + ": " + get_error()).c_str()); };
+        auto bail = [&](const char* what) {   // releases the workers AND the H-side helpers waiting on their barriers
+            const std::string m = std::string(what) + ": " + get_error();
+            sh.fail(m.c_str());
+            hs.fail(m.c_str());
+        };
         bool ok = hipSetDevice(ctx->device) == hipSuccess;
         if (!ok) set_error("hipSetDevice(%d) failed", ctx->device);
         // buffers first, so that peers can address them after barrier 0
@@ -1408,61 +1416,78 @@ static int prove_multi(G16Pk* const* pks, uint32_t n, const void* w, const void*
             bail("multi-device prove: uploading W");
             ok = false;
         }
-        // upload of this device's chain input(s) on the copy stream, by a helper thread, under the witness MSMs
-        EventGuard up;
-        int up_rc = GA_OK;
-        std::string up_err;
+        // The H side of this device on a helper thread, on the context's second lane (own stream and scratch), BESIDE the witness
+        // MSMs: uploads, the chain(s) this device owns, the hop of b / c to device 0.  With three or more devices no PCIe link
+        // carries a whole vector: every device uploads rows [t*cshare, ...) of A, B and C over its own link into a staging buffer
+        // and forwards them to the chain owners over xGMI (hipMemcpyPeerAsync); the owners start when all pieces have landed.
         bool owns = false;
         for (int k = 0; k < 3; k++) owns = owns || owner[k] == t;
-        std::thread uploader;
-        if (owns) {
-            if (hipEventCreateWithFlags(&up.ev, hipEventDisableTiming) != hipSuccess) {
-                set_error("hipEventCreate failed");
-                bail("multi-device prove");
-                ok = false;
-            } else {
-                uploader = std::thread([&, t]() {
-                    if (hipSetDevice(ctx->device) != hipSuccess) {
-                        up_rc = GA_ERR_HIP;
-                        return;
+        int h_rc = GA_OK;
+        std::string h_err;
+        std::thread helper;
+        if (ok && (owns || sliced)) {
+            helper = std::thread([&, t]() {
+                auto hfail = [&](const char* what) {
+                    h_rc = GA_ERR_HIP;
+                    h_err = std::string(what) + ": " + get_error();
+                    hs.fail(h_err.c_str());
+                };
+                if (hipSetDevice(ctx->device) != hipSuccess) {
+                    set_error("hipSetDevice(%d) failed", ctx->device);
+                    return hfail("multi-device prove (H side)");
+                }
+                std::lock_guard<std::mutex> l1(ctx->lane_mu);
+                LaneScope lane(1);
+                hipStream_t st = ctx->work_stream();
+                bool hok = true;
+                if (sliced) {
+                    const uint64_t lo = std::min<uint64_t>((uint64_t)t * cshare, n_constraints), hi = std::min<uint64_t>(lo + cshare, n_constraints);
+                    void* stage = nullptr;
+                    hok = ctx->scratch_get("h_stage", 3 * cshare * 32 + 32, &stage) == GA_OK;
+                    for (int k = 0; hok && k < 3; k++) {
+                        char* mine = (char*)stage + (uint64_t)k * cshare * 32;
+                        if (hi > lo) {
+                            hok = hipMemcpyAsync(mine, (const char*)src[k] + lo * 32, (hi - lo) * 32, hipMemcpyHostToDevice, st) == hipSuccess;
+                            if (hok)
+                                hok = hipMemcpyPeerAsync((char*)chain_buf[k] + lo * 32, pks[owner[k]]->ctx->device, mine, ctx->device, (hi - lo) * 32,
+                                                         st) == hipSuccess;
+                        }
+                        if (hok && owner[k] == t && N > n_constraints)   // computeH pads to the domain size (prove.go:356-359)
+                            hok = hipMemsetAsync((char*)chain_buf[k] + n_constraints * 32, 0, (N - n_constraints) * 32, st) == hipSuccess;
                     }
-                    for (int k = 0; k < 3 && up_rc == GA_OK; k++)
-                        if (owner[k] == t) up_rc = h_upload(pk, src[k], n_constraints, chain_buf[k], ctx->copy_stream);
-                    hipError_t e = up_rc == GA_OK ? hipEventRecord(up.ev, ctx->copy_stream) : hipSuccess;
-                    if (up_rc == GA_OK && e == hipSuccess) e = hipStreamSynchronize(ctx->copy_stream);
-                    if (up_rc != GA_OK) up_err = get_error();
-                    else if (e != hipSuccess) {
-                        up_rc = GA_ERR_HIP;
-                        up_err = hipGetErrorString(e);
+                    if (hok) hok = hipStreamSynchronize(st) == hipSuccess;
+                    if (!hok) {
+                        if (!get_error()[0]) set_error("HIP error while uploading / forwarding the rows of A, B, C");
+                        return hfail("multi-device prove: uploading A, B, C");
                     }
-                });
-            }
+                    if (!hs.barrier(0)) return;   // every device's rows have landed on the chain owners
+                } else {
+                    for (int k = 0; hok && k < 3; k++)
+                        if (owner[k] == t) hok = h_upload(pk, src[k], n_constraints, chain_buf[k], st) == GA_OK;
+                    if (!hok) return hfail("multi-device prove: uploading A, B, C");
+                }
+                for (int k = 0; hok && k < 3; k++)
+                    if (owner[k] == t) {
+                        hok = ntt_domain_h_chain<C>(pk->dom, chain_buf[k]) == GA_OK;
+                        if (hok && t != 0)
+                            hok = hipMemcpyPeerAsync(dev0_buf[k], pks[0]->ctx->device, chain_buf[k], ctx->device, N * 32, st) == hipSuccess;
+                    }
+                if (hok) hok = hipStreamSynchronize(st) == hipSuccess;
+                if (!hok) {
+                    if (!get_error()[0]) set_error("HIP error in the computeH chain");
+                    return hfail("multi-device prove: computeH chain");
+                }
+            });
         }
-        ThreadJoiner joiner{uploader};
+        ThreadJoiner joiner{helper};
         if (ok && witness_msms<C>(pk, slot, nb_public, &parts[t].ar, &parts[t].bs1, &parts[t].k, &parts[t].bs2) != GA_OK) {
             bail("multi-device prove: witness MSMs");
             ok = false;
         }
-        if (uploader.joinable()) uploader.join();
-        if (ok && up_rc != GA_OK) {
-            set_error("%s", up_err.c_str());
-            bail("multi-device prove: uploading A, B, C");
+        if (helper.joinable()) helper.join();
+        if (h_rc != GA_OK) {
+            sh.fail(h_err.c_str());
             ok = false;
-        }
-        // chains on their owners, then b and c go to device 0
-        if (ok && owns) {
-            ok = hipStreamWaitEvent(ctx->stream, up.ev, 0) == hipSuccess;
-            for (int k = 0; ok && k < 3; k++)
-                if (owner[k] == t) {
-                    ok = ntt_domain_h_chain<C>(pk->dom, chain_buf[k]) == GA_OK;
-                    if (ok && t != 0)
-                        ok = hipMemcpyPeerAsync(dev0_buf[k], pks[0]->ctx->device, chain_buf[k], ctx->device, N * 32, ctx->stream) == hipSuccess;
-                }
-            if (ok) ok = hipStreamSynchronize(ctx->stream) == hipSuccess;
-            if (!ok) {
-                if (!get_error()[0]) set_error("HIP error in the computeH chain");
-                bail("multi-device prove: computeH chain");
-            }
         }
         if (!sh.barrier(1)) return;
         if (t == 0) {
