@@ -15,8 +15,11 @@
  *    (icicle.go relies on RunOnDevice + LockOSThread instead).
  *  - Every function returns GA_OK (0) or a negative error code; ga_last_error() gives the message for the
  *    calling thread.  There is NO CPU fallback: without a usable HIP device ga_ctx_create fails.
- *  - One proof at a time per context: calls on one ga_ctx are serialised by an internal mutex
- *    (icicle.go:77-86,821-823 keeps a per-device prove mutex for the same reason).
+ *  - Any host thread may call any entry point on any context at any time; results never depend on the interleaving
+ *    (icicle.go:77-86,821-823 keeps a per-device prove mutex for the same guarantee).  Calls on one ga_ctx are serialised by an
+ *    internal mutex, with one exception that only adds throughput: a context has two lanes (stream + scratch), and a second
+ *    ga_g16_prove (or the ga_g16_h_chain* / ga_g16_h_combine pieces of a sharded proof) arriving while the first lane is busy
+ *    runs on the second lane beside it (GA_G16_LANES=1 restores strict queueing).
  */
 #ifndef GNARK_AMD_H
 #define GNARK_AMD_H
