@@ -515,6 +515,37 @@ GA_HD_BIG F29<P> f29_sqr(const F29<P>& a) {
 }
 
 // ---- uniform view used by the table kernels: Lazy<Fe<P>> / Lazy<Fe2<P>> ------------------------------------------------
+// ---- inversion in the lazy representation (Fermat; products only, so every intermediate stays below 2p) ---------------------
+// a = hat(x) with any value below 2^(NL*L - 2)  ->  hat(1/x)   (0 -> 0)
+template <class P>
+GA_HD_BIG F29<P> f29_inv(const F29<P>& a) {
+    // hat(1) = 2^(NL*L) mod p = ONE * 2^S: S doublings of the canonical packed value
+    Fe<P> h;
+#pragma unroll
+    for (int i = 0; i < P::N; i++) h.l[i] = P::ONE[i];
+    F29<P> r = f29_unpack(f29_hat_packed(h));
+    for (int i = P::N - 1; i >= 0; i--) {
+        const uint32_t e = P::PM2[i];
+        for (int b = 31; b >= 0; b--) {
+            r = f29_sqr(r);
+            if ((e >> b) & 1) r = f29_mul(r, a);
+        }
+    }
+    return r;
+}
+template <class P>
+GA_HD_BIG F29x2<P> f29_inv(const F29x2<P>& a) {
+    // 1/(a0 + a1 u) = (a0 - a1 u) / (a0^2 + a1^2)
+    const F29<P> n = f29_inv(f29_add(f29_sqr(a.c0), f29_sqr(a.c1)));
+    F29<P> zero = f29_zero<P>();
+    return {f29_mul(a.c0, n), f29_sub<2>(zero, f29_mul(a.c1, n))};   // the product is below 2p
+}
+// lazy value -> canonical packed words of the SAME (hat) domain: the storage format of the window tables
+template <class P>
+GA_HD Fe<P> f29_pack_hat(const F29<P>& v) { return f29_pack_canonical(f29_reduce_3p(v)); }
+template <class P>
+GA_HD Fe2<P> f29_pack_hat(const F29x2<P>& v) { return {f29_pack_hat(v.c0), f29_pack_hat(v.c1)}; }
+
 template <class F> struct Lazy;
 template <class P> struct Lazy<Fe<P>> {
     typedef P Params;

@@ -435,66 +435,7 @@ template <class F> struct BaseFieldOf;
 template <class Pp> struct BaseFieldOf<Fe<Pp>> { typedef Pp P; static constexpr bool IS_FP = true; };
 template <class Pp> struct BaseFieldOf<Fe2<Pp>> { typedef Pp P; static constexpr bool IS_FP = false; };
 
-// table29[w*n + i] = [2^(c*w)] P_i in the unpacked format.
-// A lane carries TableBatch<F>::K points through the doubling chain together and brings them back to affine with ONE field inversion
-// per window step (Montgomery's trick on zz*zzz): the inversion (~350 products) was 2/3 of the work of the one-point-per-lane
-// version (11 of them against 242 doublings per point); lanes of a wave cannot share one (SIMD: 64 inversions cost what one
-// costs), so the batch has to be inside the lane.
-// K measured at 2^22 (tools/exp/table_build_time.py, kernel time): BN254 G1 0.248 / 0.200 / 0.163 / 0.158 s for K = 1 / 2 / 4 / 8,
-// BLS12-381 G1 0.835 / 0.570 / - / 0.392 s; the Fp2 kernels are dominated by the doublings (BN254 G2 0.627 / 0.594 / - / 0.700 s).
-template <class F> struct TableBatch { static constexpr int K = BaseFieldOf<F>::IS_FP ? 8 : 2; };
-
-template <class F>
-__global__ void __launch_bounds__(64)
-msm_table29_kernel(const Affine<F>* __restrict__ bases, uint64_t n, int c, int nwin, uint32_t* __restrict__ table) {
-    constexpr int K = TableBatch<F>::K;
-    const uint64_t lanes = (uint64_t)gridDim.x * blockDim.x;
-    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= n) return;   // point q of a lane is gid + q*lanes: nothing to do when even q = 0 is out of range
-    Affine<F> a[K];
-    XYZZ<F> p[K];
-    bool live[K];
-#pragma unroll
-    for (int q = 0; q < K; q++) {
-        const uint64_t i = gid + q * lanes;
-        live[q] = i < n;
-        a[q] = live[q] ? load_pod<Affine<F>>(&bases[i]) : Affine<F>{FieldTraits<F>::zero(), FieldTraits<F>::zero()};
-        p[q] = to_xyzz(a[q]);
-    }
-    for (int w = 0; w < nwin; w++) {
-        if (w > 0) {
-#pragma unroll
-            for (int q = 0; q < K; q++)
-                for (int k = 0; k < c; k++) p[q] = dbl(p[q]);
-            // batch to affine: t_q = zz_q * zzz_q (1 for a point at infinity, which stays (0,0)), one inversion of their product
-            F t[K], pre[K];
-#pragma unroll
-            for (int q = 0; q < K; q++) {
-                t[q] = is_inf(p[q]) ? FieldTraits<F>::one() : mul(p[q].zz, p[q].zzz);
-                pre[q] = q == 0 ? t[0] : mul(pre[q - 1], t[q]);
-            }
-            F run = inv(pre[K - 1]);
-#pragma unroll
-            for (int q = K - 1; q >= 0; q--) {
-                const F it = q > 0 ? mul(run, pre[q - 1]) : run;   // 1 / t_q
-                if (q > 0) run = mul(run, t[q]);
-                if (is_inf(p[q])) {
-                    a[q] = Affine<F>{FieldTraits<F>::zero(), FieldTraits<F>::zero()};
-                } else {
-                    a[q].x = mul(p[q].x, mul(it, p[q].zzz));   // X / zz
-                    a[q].y = mul(p[q].y, mul(it, p[q].zz));    // Y / zzz
-                }
-                p[q] = to_xyzz(a[q]);
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < K; q++) {
-            if (!live[q]) continue;
-            Affine<F> h{Lazy<F>::hat_packed(a[q].x), Lazy<F>::hat_packed(a[q].y)};
-            store_pod(table + ((uint64_t)w * n + gid + q * lanes) * Table29<F>::WORDS, h);
-        }
-    }
-}
+// (msm_table29_kernel follows the lazy point helpers below)
 
 // ---- 5. merge partials (msm_merge_kernel itself follows the lazy helpers it uses, below) --------------
 // 64-lane tree reduction through LDS; result valid in lane 0
@@ -649,6 +590,101 @@ msm_reduce_groups_redo_kernel(const XYZZ<F>* __restrict__ bsum, uint32_t half, u
         }
         store_pod(&lsum[gid], local);
         store_pod(&rsum[gid], running);
+    }
+}
+
+// ---- precomputed tables: table29[w*n + i] = [2^(c*w)] P_i in the packed hat format --------------------------------------------
+// 2 P for a general XYZZ point in the lazy representation (dbl-2008-s-1, a = 0); bounds: tools/lazy_bounds.py check_dbl (the fixed
+// point of repeated doublings, the same subtraction constants as mdbl29)
+template <class F>
+__device__ __forceinline__ void dbl29(Lazy4<F>& a) {
+    typedef typename Lazy<F>::T T;
+    typedef typename Lazy<F>::Params P;
+    constexpr int KMS = Lazy<F>::FP2 ? P::FP2Z_K : 8;
+    const T U = f29_add(a.y, a.y);
+    const T V = f29_sqr(U);
+    const T W = f29_mul(U, V);
+    const T S = f29_mul(a.x, V);
+    const T xx = f29_sqr(a.x);
+    const T M = f29_add(f29_add(xx, xx), xx);
+    T X3 = f29_sub<4>(f29_sqr(M), f29_add(S, S));
+    if constexpr (Lazy<F>::FP2) X3 = f29_partial_reduce(X3);
+    const T Y3 = f29_mul_sub<KMS>(M, f29_sub<8>(S, X3), W, a.y);
+    a.zz = f29_mul(V, a.zz);
+    a.zzz = f29_mul(W, a.zzz);
+    a.x = X3;
+    a.y = Y3;
+}
+
+// A lane carries TableBatch<F>::K points through the doubling chain together, in the lazy representation (the chain is 22 doublings
+// per window step: 9 products each, no reductions in between), and brings them back to affine with ONE field inversion per window
+// step (Montgomery's trick on zz*zzz; lanes of a wave cannot share one -- SIMD: 64 inversions cost what one costs -- so the batch
+// is inside the lane).  The affine coordinates leave the lane as canonical packed hat-domain words: the table's storage format.
+// History (2^22 points, kernel time): exact arithmetic, one point per lane 0.248 s (BN254 G1) / 0.835 s (BLS12-381 G1) / 0.627 s
+// (BN254 G2); exact arithmetic with 8 / 2 points per lane 0.158 / 0.392 / 0.594 s; this version: see profiles/r02_h notes.
+template <class F> struct TableBatch { static constexpr int K = BaseFieldOf<F>::IS_FP ? (BaseFieldOf<F>::P::N <= 8 ? 4 : 2) : (BaseFieldOf<F>::P::N <= 8 ? 2 : 1); };
+
+template <class F>
+__global__ void __launch_bounds__(64)
+msm_table29_kernel(const Affine<F>* __restrict__ bases, uint64_t n, int c, int nwin, uint32_t* __restrict__ table) {
+    typedef typename Lazy<F>::T T;
+    constexpr int K = TableBatch<F>::K;
+    const uint64_t lanes = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n) return;   // point q of a lane is gid + q*lanes: nothing to do when even q = 0 is out of range
+    const T one = Lazy<F>::from_mem(FieldTraits<F>::one());
+    Lazy4<F> p[K];
+    bool live[K], inf[K];
+#pragma unroll
+    for (int q = 0; q < K; q++) {
+        const uint64_t i = gid + q * lanes;
+        live[q] = i < n;
+        Affine<F> a = live[q] ? load_pod<Affine<F>>(&bases[i]) : Affine<F>{FieldTraits<F>::zero(), FieldTraits<F>::zero()};
+        inf[q] = is_inf(a);
+        p[q].x = Lazy<F>::from_mem(a.x);
+        p[q].y = Lazy<F>::from_mem(a.y);
+        p[q].zz = one;
+        p[q].zzz = one;
+    }
+    for (int w = 0; w < nwin; w++) {
+        if (w > 0) {
+#pragma unroll
+            for (int q = 0; q < K; q++)
+                if (!inf[q])
+                    for (int k = 0; k < c; k++) dbl29<F>(p[q]);
+            // batch to affine: t_q = zz_q * zzz_q (1 for a point at infinity, which stays (0,0)), one inversion of their product
+            T t[K], pre[K];
+#pragma unroll
+            for (int q = 0; q < K; q++) {
+                t[q] = inf[q] ? one : f29_mul(p[q].zz, p[q].zzz);
+                pre[q] = q == 0 ? t[0] : f29_mul(pre[q - 1], t[q]);
+            }
+            T run = f29_inv(pre[K - 1]);
+#pragma unroll
+            for (int q = K - 1; q >= 0; q--) {
+                const T it = q > 0 ? f29_mul(run, pre[q - 1]) : run;   // 1 / t_q
+                if (q > 0) run = f29_mul(run, t[q]);
+                if (!inf[q]) {
+                    p[q].x = f29_mul(p[q].x, f29_mul(it, p[q].zzz));   // X / zz
+                    p[q].y = f29_mul(p[q].y, f29_mul(it, p[q].zz));    // Y / zzz
+                    p[q].zz = one;
+                    p[q].zzz = one;
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < K; q++) {
+            if (!live[q]) continue;
+            Affine<F> h{FieldTraits<F>::zero(), FieldTraits<F>::zero()};
+            if (!inf[q]) {
+                h.x = f29_pack_hat(p[q].x);
+                h.y = f29_pack_hat(p[q].y);
+                // restart the chain from the canonical coordinates: keeps the doublings' inputs at their smallest
+                p[q].x = Lazy<F>::unpack(h.x);
+                p[q].y = Lazy<F>::unpack(h.y);
+            }
+            store_pod(table + ((uint64_t)w * n + gid + q * lanes) * Table29<F>::WORDS, h);
+        }
     }
 }
 

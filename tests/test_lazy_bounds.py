@@ -68,3 +68,17 @@ def test_affine_doubling_into_the_accumulator(curve, fp2):
     out = lazy_bounds.check_mdbl(curve, fp2)
     limit = lazy_bounds.CURVES[curve][1] * lazy_bounds.CURVES[curve][2]
     assert all(v < limit - 2 for v in out.values())
+
+
+@pytest.mark.parametrize("curve", sorted(lazy_bounds.CURVES))
+@pytest.mark.parametrize("fp2", [False, True], ids=["G1", "G2"])
+def test_repeated_doubling_bounds(curve, fp2):
+    """msm.hip.h::dbl29 (the doubling chain of the window-table build): fixed point of the bounds, with headroom"""
+    out = lazy_bounds.check_dbl(curve, fp2)
+    assert all(v < out["limit"] - 2 for k, v in out.items() if k != "limit")
+
+
+def test_doubling_constants_match_the_kernel():
+    src = open(os.path.join(ROOT, "gnark_amd", "csrc", "msm.hip.h")).read()
+    d = src[src.index("__device__ __forceinline__ void dbl29("):src.index("// A lane carries TableBatch<F>::K points")]
+    assert [int(x) for x in re.findall(r"f29_sub<(\d+)>", d)] == [4, 8] and "KMS = Lazy<F>::FP2 ? P::FP2Z_K : 8" in d

@@ -274,7 +274,91 @@ def check_mdbl(curve: str, fp2: bool, verbose=False):
     return out
 
 
+# ---- repeated doubling of a general XYZZ point (msm.hip.h::dbl29, the window-table build) ----------------------------------------
+def check_dbl(curve: str, fp2: bool, verbose=False):
+    """fixed point of the coordinate bounds under a = dbl29(a), starting from an affine point with canonical coordinates"""
+    p, L, NL, bits = CURVES[curve]
+    R = 1 << (L * NL)
+    unit = 1 << (L * (NL - 1))
+
+    def lim(v):
+        assert v < R // 4, ("value exceeds R'/4", log2(v))
+        return v
+
+    def need(K, b, what):
+        assert K * p - b > unit, (what, K, log2(b), log2(K * p))
+
+    def mul1(a, b):
+        lim(a), lim(b)
+        return a * b // R + p
+
+    def pr(v):
+        q = v >> bits
+        return (1 << bits) + q * ((1 << bits) - p)
+
+    if fp2:
+        import os
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from gen_constants import FP2_LAZY_K as FK
+
+        def mul(a, b):
+            assert a + unit < FK * p and b < FK * p, ("Fp2 operand above FP2Z_K*p", log2(a), log2(b))
+            return max((a * b + (FK * p + unit) * b) // R + p, 2 * a * b // R + p)
+
+        def sqr(a):
+            need(G2["KQ"], a, "KQ")
+            return max(mul1(lim(2 * a), a + G2["KQ"] * p), 2 * mul1(a, a))
+
+        def mulsub(K, a, b, c, d):
+            assert max(a, c) + unit < K * p and max(a, b, c, d) < FK * p
+            return max(a * b + K * p * b + K * p * d + c * d, 2 * a * b + 2 * K * p * d) // R + p
+        Kms = FK
+    else:
+        mul = mul1
+
+        def sqr(a):
+            return mul1(a, a)
+
+        def mulsub(K, a, b, c, d):
+            assert c + unit < K * p
+            lim(a), lim(b), lim(d)
+            return (a * b + K * p * d) // R + p
+        Kms = 8
+    bx = by = bzz = bzzz = p
+    for _ in range(1000):
+        U = 2 * by
+        V = sqr(U)
+        W = mul(U, V)
+        S = mul(bx, V)
+        xx = sqr(bx)
+        M = 3 * xx
+        need(4, 2 * S, "X3: 2S below 4p")
+        X3 = sqr(M) + 4 * p
+        if fp2:
+            X3 = pr(X3)
+        need(8, X3, "t: X3 below 8p")
+        t = S + 8 * p
+        Y3 = mulsub(Kms, M, t, W, by)
+        ZZ3, ZZZ3 = mul(V, bzz), mul(W, bzzz)
+        for v in (U, V, W, S, M, X3, t, Y3, ZZ3, ZZZ3):
+            lim(v)
+        nb = (max(bx, X3), max(by, Y3), max(bzz, ZZ3), max(bzzz, ZZZ3))
+        if nb == (bx, by, bzz, bzzz):
+            break
+        bx, by, bzz, bzzz = nb
+    else:
+        raise AssertionError("bounds of the repeated doubling do not converge")
+    out = {"X": log2(bx), "Y": log2(by), "ZZ": log2(bzz), "ZZZ": log2(bzzz), "limit": L * NL}
+    if verbose:
+        print(curve, "dbl G2" if fp2 else "dbl G1", {a: round(b, 2) for a, b in out.items()})
+    return out
+
+
 if __name__ == "__main__":
+    for c in CURVES:
+        for fp2 in (False, True):
+            check_dbl(c, fp2, verbose=True)
     for c in CURVES:
         for fp2 in (False, True):
             check_mdbl(c, fp2, verbose=True)
