@@ -15,7 +15,7 @@ const (
 	// PrecomputeAlways builds them or fails.
 	PrecomputeAlways Precompute = 1
 	// PrecomputeNever keeps the plain affine vectors (6 GiB for a 2^24 BN254 key instead of 72 GiB): pinning takes 0.2 s instead of
-	// 4.9 s, a 2^24 proof 197 ms instead of 148 ms -- the choice for fewer than ~100 proofs per key.
+	// 2.4 s, a 2^24 proof 194 ms instead of 144 ms -- the choice for fewer than ~50 proofs per key.
 	PrecomputeNever Precompute = -1
 )
 
