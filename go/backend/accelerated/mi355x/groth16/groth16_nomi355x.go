@@ -10,24 +10,28 @@ import (
 	"github.com/consensys/gnark/constraint"
 )
 
-const noTag = "mi355x backend requested but program compiled without 'mi355x' build tag"
-
-// Prove generates the proof of knowledge of a r1cs with full witness (secret + public part) on the GPU.
-func Prove(r1cs constraint.ConstraintSystem, pk groth16.ProvingKey, fullWitness witness.Witness, opts ...mi355x.Option) (groth16.Proof, error) {
-	panic(noTag)
+// A build without the mi355x tag keeps the package's API and refuses to run it: the first call stops the program, as the ICICLE
+// package does for its own tag (groth16_noicicle.go:18-48) -- a mis-tagged binary must not fall back to the CPU prover unnoticed.
+func unavailable(entry string) {
+	panic("mi355x/groth16." + entry + ": this program was built without the 'mi355x' build tag (go build -tags=mi355x)")
 }
 
-// Setup generates a proving and verifying key for a given r1cs; the proving key is the accelerated type.
-func Setup(r1cs constraint.ConstraintSystem) (groth16.ProvingKey, groth16.VerifyingKey, error) {
-	panic(noTag)
+func Prove(constraint.ConstraintSystem, groth16.ProvingKey, witness.Witness, ...mi355x.Option) (proof groth16.Proof, err error) {
+	unavailable("Prove")
+	return
 }
 
-// DummySetup generates a dummy accelerated proving key for a given circuit (benchmarks and tests).
-func DummySetup(r1cs constraint.ConstraintSystem) (groth16.ProvingKey, error) {
-	panic(noTag)
+func Setup(constraint.ConstraintSystem) (pk groth16.ProvingKey, vk groth16.VerifyingKey, err error) {
+	unavailable("Setup")
+	return
 }
 
-// NewProvingKey creates an empty accelerated proving key for deserializing into.
-func NewProvingKey(curveID ecc.ID) groth16.ProvingKey {
-	panic(noTag)
+func DummySetup(constraint.ConstraintSystem) (pk groth16.ProvingKey, err error) {
+	unavailable("DummySetup")
+	return
+}
+
+func NewProvingKey(ecc.ID) (pk groth16.ProvingKey) {
+	unavailable("NewProvingKey")
+	return
 }
