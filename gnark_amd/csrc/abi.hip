@@ -98,8 +98,8 @@ struct Staged {
             set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
             return GA_ERR_NOMEM;
         }
-        GA_HIP_CHECK(hipMemcpyAsync(owned, p, bytes, hipMemcpyHostToDevice, ctx->stream));
-        GA_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // host memory must not be referenced after return
+        GA_HIP_CHECK(hipMemcpyAsync(owned, p, bytes, hipMemcpyHostToDevice, ctx->work_stream()));
+        GA_HIP_CHECK(hipStreamSynchronize(ctx->work_stream()));   // host memory must not be referenced after return
         dev = owned;
         return GA_OK;
     }
@@ -396,7 +396,7 @@ int ga_msm_table_run(ga_msm_table* th, const void* scalars, unsigned flags, void
         return GA_ERR_INVALID;
     }
     Ctx* c = t->ctx;
-    Lock l(c);
+    LaneLock l(c);   // a second caller (the PLONK prover commits from several goroutines) runs beside the first on lane 1
     GA_DISPATCH_CURVE(t->curve, GA_DISPATCH_GROUP(t->group, {
                           typedef typename GroupField<C, G>::F F;
                           Staged ss{c};
@@ -425,7 +425,7 @@ int ga_msm_table_run_batch(ga_msm_table* th, const void* const* scalars, uint32_
         return GA_ERR_INVALID;
     }
     Ctx* c = t->ctx;
-    Lock l(c);
+    LaneLock l(c);   // a second caller (the PLONK prover commits from several goroutines) runs beside the first on lane 1
     GA_DISPATCH_CURVE(t->curve, GA_DISPATCH_GROUP(t->group, {
                           typedef typename GroupField<C, G>::F F;
                           std::vector<std::unique_ptr<Staged>> st;
@@ -454,7 +454,7 @@ int ga_msm_table_run_windows(ga_msm_table* th, const void* scalars, unsigned fla
         return GA_ERR_INVALID;
     }
     Ctx* c = t->ctx;
-    Lock l(c);
+    LaneLock l(c);   // a second caller (the PLONK prover commits from several goroutines) runs beside the first on lane 1
     GA_DISPATCH_CURVE(t->curve, GA_DISPATCH_GROUP(t->group, {
                           typedef typename GroupField<C, G>::F F;
                           Staged ss{c};

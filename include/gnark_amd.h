@@ -18,8 +18,9 @@
  *  - Any host thread may call any entry point on any context at any time; results never depend on the interleaving
  *    (icicle.go:77-86,821-823 keeps a per-device prove mutex for the same guarantee).  Calls on one ga_ctx are serialised by an
  *    internal mutex, with one exception that only adds throughput: a context has two lanes (stream + scratch), and a second
- *    ga_g16_prove (or the ga_g16_h_chain* / ga_g16_h_combine pieces of a sharded proof) arriving while the first lane is busy
- *    runs on the second lane beside it (GA_G16_LANES=1 restores strict queueing).
+ *    ga_g16_prove, ga_msm_table_run* (the PLONK prover commits from several goroutines) or ga_g16_h_chain* / ga_g16_h_combine (the
+ *    pieces of a sharded proof) arriving while the first lane is busy runs on the second lane beside it (GA_G16_LANES=1 restores
+ *    strict queueing).
  */
 #ifndef GNARK_AMD_H
 #define GNARK_AMD_H

@@ -595,6 +595,43 @@ def test_emu_msm_degenerate_bases(emu_ctx, c, group, n=1500):
         b.free()
 
 
+def test_emu_msm_table_two_callers(emu_ctx, c=BN254, group=0, n=2000, rounds=3):
+    """three host threads commit DIFFERENT scalar vectors over one pinned table at the same time (the PLONK prover's goroutines): the
+    second caller runs on lane 1 of the context beside the first; every result equals the one computed alone"""
+    import threading
+    ctx = emu_ctx
+    bases, dlogs, scal = _device_inputs(ctx, c, group, n, 0x7C0 + group)
+    vecs = [scal.to_host((n, 4))]
+    for j in range(1, 3):
+        b = ctx.malloc(n * 32)
+        ctx.lib.check(ctx.lib.ga_gen_scalars(ctx.handle, c.cid, 0x91 + j, n, b.ptr))
+        vecs.append(b.to_host((n, 4)))
+        b.free()
+    t = ecc.PrecomputedBases(ctx, c.name, group, bases, n=n)
+    try:
+        want = [t.MultiExp(v) for v in vecs]
+        bad = []
+
+        def worker(tid):
+            for k in range(rounds):
+                j = (tid + k) % 3
+                if not np.array_equal(t.MultiExp(vecs[j]), want[j]):
+                    bad.append((tid, k, j))
+
+        th = [threading.Thread(target=worker, args=(i,)) for i in range(3)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        assert not bad, bad
+        K = dlogs.to_host((n, 4))
+        assert np.array_equal(oracle.jac_to_affine(c.cid, group, want[1]), _expect_from_dlogs(c, group, vecs[1], K))
+    finally:
+        t.free()
+        for b in (bases, dlogs, scal):
+            b.free()
+
+
 @pytest.mark.parametrize("c,group,table", [(BN254, 0, True), (BN254, 0, False), (BLS12_381, 1, False)], ids=["bn254-G1-table", "bn254-G1-raw", "bls-G2-raw"])
 def test_emu_msm_very_hot_bucket(emu_ctx, c, group, table, n=36000):
     """boolean-heavy witness: 60 % of the scalars equal to one, 10 % zero -> the digit-1 bucket of window 0 holds 0.6 n points, i.e.

@@ -138,6 +138,12 @@ def test_msm_degenerate_bases_2_16(gpu_ctx, c, group):
     cases.test_emu_msm_degenerate_bases(gpu_ctx, c, group, n=1 << 16)
 
 
+@pytest.mark.parametrize("c,group", [(BN254, 0), (BLS12_381, 1)], ids=["bn254-G1", "bls12-381-G2"])
+def test_msm_table_two_callers_2_18(gpu_ctx, c, group):
+    """three threads, three different scalar vectors, one pinned table of 2^18 points: concurrent results == sequential results"""
+    cases.test_emu_msm_table_two_callers(gpu_ctx, c, group, n=1 << 18, rounds=6)
+
+
 def test_msm_degenerate_bases_exact_kernel(gpu_ctx, monkeypatch):
     """GA_MSM_EXACT_REDO=1: the exact-arithmetic re-run kernel on all-equal bases (BN254 G1 2^14, BLS12-381 G2 2^12)"""
     cases.test_emu_msm_degenerate_bases_exact_kernel(gpu_ctx, monkeypatch, n=1 << 14)
