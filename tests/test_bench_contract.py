@@ -25,8 +25,8 @@ def env(emu_lib):
 
 
 def test_single_rank_line(env):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--log-n", "9", "--steps", "2", "--warmup", "1", "--groth16-proofs", "2",
-                        "--plonk-log-n", "7"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--log-n", "8", "--steps", "2", "--warmup", "1", "--groth16-proofs", "2",
+                        "--plonk-log-n", "6"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _line(r.stdout)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",

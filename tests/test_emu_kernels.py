@@ -717,7 +717,7 @@ def test_emu_groth16_sharded_key_with_commitments(emu_ctx):
 
 
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
-@pytest.mark.parametrize("n", [1, 2, 7, 300])
+@pytest.mark.parametrize("n", [1, 2, 7, 150])
 def test_emu_kzg_open(emu_ctx, c, n, srs_len=None):
     """kzg.Open over a pinned monomial SRS with known tau (test/unsafekzg-style, kzgsrs.go:186-200): the device division by
     (X - z) + table MSM against the oracle's Horner recurrence, for a random point, z = 0 and a polynomial shorter than the SRS;
@@ -925,6 +925,8 @@ def test_emu_groth16_prove_multi(emu_ctx, c, nshards, precompute, logn=7):
     the unsharded key, which equals the known-dlog closed form; also the pieces API (witness / chain / combine / z) by hand"""
     from gnark_amd import synth
     from gnark_amd.device import Context
+    if logn == 7 and c is BLS12_381 and precompute == 1:
+        logn = 6   # (the 381-bit table build dominates this case under the emulation)
     inst = synth.make_instance(emu_ctx, c.name, logn, 0x77 + nshards, nb_constraints=(1 << logn) - 5)
     sol = inst.solution
     pk1 = inst.proving_key(emu_ctx, precompute=precompute)
