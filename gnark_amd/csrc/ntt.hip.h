@@ -240,22 +240,32 @@ ntt_pass29r4_kernel(uint32_t* data, const uint32_t* src, const uint32_t* __restr
                 T.put(l10, c10);
                 T.put(l11, c11);
             } else {
-                // stage s+1 (count k): (a00, a10) with w^e2, (a01, a11) with w^e3
-                E d0 = f29_sub<32>(a00, a10), d1 = f29_sub<32>(a01, a11);
-                d0 = e2 != 0 ? f29_mul(d0, twid(e2)) : f29_reduce_3p(d0);
+                // stage s+1 (count k): (a00, a10) with w^e2, (a01, a11) with w^e3.  Carry sweeps are deferred wherever the consumer
+                // is a product (a multiplicand may carry limbs below 2^31) or a wide subtraction: differences x - y + 32p have limbs
+                // below 2^29 + 2^30, raw sums below 2^30.
+                E d0 = f29_sub_raw<32>(a00, a10), d1 = f29_sub_raw<32>(a01, a11);
+                if (e2 != 0) {
+                    d0 = f29_mul(d0, twid(e2));
+                } else {
+                    f29_normalize(d0);
+                    d0 = f29_reduce_3p(d0);
+                }
                 d1 = f29_mul(d1, twid(e3));
-                E s0 = f29_add(a00, a10), s1 = f29_add(a01, a11);
+                E s0 = f29_add_raw(a00, a10), s1 = f29_add_raw(a01, a11);
                 if ((k % 3) == 2) {
+                    f29_normalize(s0);
+                    f29_normalize(s1);
                     s0 = f29_reduce_3p(s0);
                     s1 = f29_reduce_3p(s1);
                 }
                 // stage s (count k+1): (s0, s1) and (d0, d1), both with w^e1
-                E o01 = f29_sub<32>(s0, s1), o11 = f29_sub<32>(d0, d1);
+                E o01 = f29_sub_wide<32, 2>(s0, s1), o11 = f29_sub_raw<32>(d0, d1);
                 if (e1 != 0) {
                     const E w1 = twid(e1);
                     o01 = f29_mul(o01, w1);
                     o11 = f29_mul(o11, w1);
                 } else {
+                    f29_normalize(o11);
                     o01 = f29_reduce_3p(o01);
                     o11 = f29_reduce_3p(o11);
                 }
