@@ -7,13 +7,19 @@ Workload (BASELINE.json `metric`: "G1 MSM Mscalar-mul/s + Groth16 proofs/s, BN25
     bases generated on device).  `value` = scalar-muls/s summed over all ranks, in Mscalar-mul/s.
   * with N > 1 ranks the MSM is sharded by base-point range (SURVEY 8e partitioning B, weak scaling: every rank
     owns 2^24 pairs); the exchange step is an RCCL all_gather of one Jacobian partial per rank + a local add.
-  * the Groth16 leg (proofs/s at the same size: computeH + 4 G1 MSMs + 1 G2 MSM + host epilogue, key pinned,
-    solver excluded) is timed separately on rank 0 and reported in the "groth16" object of the same line.
+  * the Groth16 leg (proofs/s at the same size: computeH + 4 G1 MSMs + 1 G2 MSM + host epilogue, key pinned with its window
+    tables, solver excluded, C = A o B) is timed separately on rank 0 and reported in the "groth16" object of the same line:
+    5 single-caller proofs (every one checked against the closed form from the key's known discrete logs + the polynomial
+    identity of h, outside the timed region: "matches_dlog", "check"), then 10 proofs from two host threads on one key (two
+    proofs in flight on the context's two lanes: "pipelined"; `--no-pipelined` leaves that leg out of profiler passes).
+    With N > 1 ranks the "groth16" object is ONE proof sharded over the N GPUs (strong scaling; gnark_amd/multigpu.py).
   * the PLONK leg (BASELINE config 5: kernel work of one BN254 proof at 2^22 gates -- 10 KZG-commit MSMs over a pinned SRS,
     grand product, quotient) is reported in the "plonk" object (N = 1, BN254; `--plonk-log-n 0` disables it).
   * "roofline": dominant kernel (msm_accumulate) vs the 8 TB/s HBM peak using the ALGORITHMIC 96 B per scalar-mul
     (32 B scalar + 64 B affine base); durations come from hipEvents recorded by the library on its own
-    stream.  "cpu_baseline": the C oracle's Pippenger (oracle/oracle.c, kind "port") on a bounded sample.
+    stream; "roofline.integer_multiplier" prices the same launches against the measured v_mad_u64_u32 issue rate (the
+    binding resource).  "cpu_baseline": the C oracle's Pippenger (oracle/oracle.c, kind "port", one thread per window;
+    "threads_used" / "host_cores") on 2^24 points and the oracle's Groth16 prover on a 2^20 sample.
 """
 import argparse
 import json
