@@ -402,15 +402,12 @@ static tower_t tower_of(int curve, int group) {
     return t;
 }
 
-/* ---------------- MSM: bucket method, signed digits; threads = windows x point-range parts ------------------------------
- * A job owns one window of one contiguous part of the points: its own bucket array, its own running-sum reduction (the window sum
- * is linear in the buckets, so the parts' results simply add).  With T threads and W windows the points are cut into max(1, T / W)
- * parts: 16 windows x 16 parts keep a 256-core host busy where one thread per window used 16 cores. */
+/* ---------------- MSM: bucket method, signed digits, one thread per window ------------------------------ */
 typedef struct {
     const tower_t* t;
     const u64* points;
     const int32_t* digits; /* [nwin][n] */
-    size_t n, lo, hi;
+    size_t n;
     int c, w;
     jac_t result;
 } win_job;
@@ -423,7 +420,7 @@ static void* msm_window(void* arg) {
     jac_t* buckets = (jac_t*)malloc(sizeof(jac_t) * nb);
     for (int b = 0; b < nb; b++) jac_set_inf(t, &buckets[b]);
     const int32_t* d = j->digits + (size_t)j->w * j->n;
-    for (size_t i = j->lo; i < j->hi; i++) {
+    for (size_t i = 0; i < j->n; i++) {
         int32_t dg = d[i];
         if (dg == 0) continue;
         aff_t a;
@@ -444,13 +441,12 @@ static void* msm_window(void* arg) {
     return NULL;
 }
 
-/* window width: per window n additions + 2 * 2^(c-1) for EACH part's reduction */
-static int msm_best_c(int bits, size_t n, int parts) {
+static int msm_best_c(int bits, size_t n) {
     double best = 1e300;
     int bc = 2;
     for (int c = 2; c <= 16; c++) {
         int nwin = bits / c + 1;
-        double cost = (double)nwin * ((double)n + 2.0 * (double)parts * (double)(1u << (c - 1)));
+        double cost = (double)nwin * ((double)n + 2.0 * (double)(1u << (c - 1)));
         if (cost < best) {
             best = cost;
             bc = c;
@@ -458,46 +454,28 @@ static int msm_best_c(int bits, size_t n, int parts) {
     }
     return bc;
 }
-/* parts of the point range for `nthreads` threads: at least ~2^12 points per part, T / W parts at most */
-static int msm_parts(int bits, size_t n, int nthreads) {
-    int nwin = bits / msm_best_c(bits, n ? n : 1, 1) + 1;
-    int parts = nthreads / nwin;
-    if (parts < 1) parts = 1;
-    while (parts > 1 && n / (size_t)parts < 4096) parts--;
-    return parts;
-}
 
-/* number of windows oracle_msm uses for n points (one part) */
+/* number of windows (= max useful threads) oracle_msm uses for n points */
 int oracle_msm_windows(int curve, size_t n) {
     const int bits = CURVES[curve].fr.bits;
-    return bits / msm_best_c(bits, n ? n : 1, 1) + 1;
-}
-/* threads oracle_msm actually runs with when offered `nthreads` */
-int oracle_msm_threads(int curve, size_t n, int nthreads) {
-    const int bits = CURVES[curve].fr.bits;
-    if (nthreads < 1) nthreads = 1;
-    const int parts = msm_parts(bits, n ? n : 1, nthreads);
-    const int nwin = bits / msm_best_c(bits, n ? n : 1, parts) + 1;
-    const int jobs = nwin * parts;
-    return jobs < nthreads ? jobs : nthreads;
+    return bits / msm_best_c(bits, n ? n : 1) + 1;
 }
 
-typedef struct {
-    const curve_t* cv;
-    const u64* scalars;
-    int32_t* digits;
-    size_t n, lo, hi;
-    int mont, c, nwin;
-} digit_job;
-static void* msm_digits(void* arg) {
-    digit_job* j = (digit_job*)arg;
-    const int c = j->c;
-    for (size_t i = j->lo; i < j->hi; i++) {
+/* sum scalars[i]*points[i] -> Jacobian image.  scalars: fr images (Montgomery if mont). */
+int oracle_msm(int curve, int group, const u64* points, const u64* scalars, size_t n, int mont, u64* out_jac,
+               int nthreads) {
+    const curve_t* cv = &CURVES[curve];
+    tower_t t = tower_of(curve, group);
+    const int bits = cv->fr.bits;
+    const int c = msm_best_c(bits, n ? n : 1);
+    const int nwin = bits / c + 1;
+    int32_t* digits = (int32_t*)malloc(sizeof(int32_t) * (size_t)nwin * (n ? n : 1));
+    for (size_t i = 0; i < n; i++) {
         u64 s[4];
-        if (j->mont) fe_from_mont(&j->cv->fr, s, j->scalars + 4 * i);
-        else memcpy(s, j->scalars + 4 * i, 32);
+        if (mont) fe_from_mont(&cv->fr, s, scalars + 4 * i);
+        else memcpy(s, scalars + 4 * i, 32);
         int carry = 0;
-        for (int w = 0; w < j->nwin; w++) {
+        for (int w = 0; w < nwin; w++) {
             int bit = w * c;
             u64 raw = 0;
             if (bit < 256) {
@@ -512,73 +490,33 @@ static void* msm_digits(void* arg) {
                 carry = 1;
             } else
                 carry = 0;
-            j->digits[(size_t)w * j->n + i] = dg;
+            digits[(size_t)w * n + i] = dg;
         }
     }
-    return NULL;
-}
-
-/* sum scalars[i]*points[i] -> Jacobian image.  scalars: fr images (Montgomery if mont). */
-int oracle_msm(int curve, int group, const u64* points, const u64* scalars, size_t n, int mont, u64* out_jac,
-               int nthreads) {
-    const curve_t* cv = &CURVES[curve];
-    tower_t t = tower_of(curve, group);
-    const int bits = cv->fr.bits;
+    win_job* jobs = (win_job*)calloc(nwin, sizeof(win_job));
+    pthread_t* th = (pthread_t*)calloc(nwin, sizeof(pthread_t));
     if (nthreads < 1) nthreads = 1;
-    const int parts = msm_parts(bits, n ? n : 1, nthreads);
-    const int c = msm_best_c(bits, n ? n : 1, parts);
-    const int nwin = bits / c + 1;
-    int32_t* digits = (int32_t*)malloc(sizeof(int32_t) * (size_t)nwin * (n ? n : 1));
-    {   /* digit extraction, the point range cut into one piece per thread */
-        int nt = nthreads;
-        if ((size_t)nt > n / 1024 + 1) nt = (int)(n / 1024 + 1);
-        digit_job* dj = (digit_job*)calloc(nt, sizeof(digit_job));
-        pthread_t* dt = (pthread_t*)calloc(nt, sizeof(pthread_t));
-        for (int k = 0; k < nt; k++) {
-            dj[k].cv = cv;
-            dj[k].scalars = scalars;
-            dj[k].digits = digits;
-            dj[k].n = n;
-            dj[k].lo = n * (size_t)k / nt;
-            dj[k].hi = n * (size_t)(k + 1) / nt;
-            dj[k].mont = mont;
-            dj[k].c = c;
-            dj[k].nwin = nwin;
-            if (nt == 1) msm_digits(&dj[k]);
-            else pthread_create(&dt[k], NULL, msm_digits, &dj[k]);
-        }
-        if (nt > 1)
-            for (int k = 0; k < nt; k++) pthread_join(dt[k], NULL);
-        free(dj);
-        free(dt);
-    }
-    const int njobs = nwin * parts;
-    win_job* jobs = (win_job*)calloc(njobs, sizeof(win_job));
-    pthread_t* th = (pthread_t*)calloc(njobs, sizeof(pthread_t));
-    for (int j0 = 0; j0 < njobs; j0 += nthreads) {
-        int cnt = njobs - j0 < nthreads ? njobs - j0 : nthreads;
+    for (int w0 = 0; w0 < nwin; w0 += nthreads) {
+        int cnt = nwin - w0 < nthreads ? nwin - w0 : nthreads;
         for (int k = 0; k < cnt; k++) {
-            win_job* j = &jobs[j0 + k];
-            const int w = (j0 + k) / parts, p = (j0 + k) % parts;
+            win_job* j = &jobs[w0 + k];
             j->t = &t;
             j->points = points;
             j->digits = digits;
             j->n = n;
-            j->lo = n * (size_t)p / parts;
-            j->hi = n * (size_t)(p + 1) / parts;
             j->c = c;
-            j->w = w;
+            j->w = w0 + k;
             if (cnt == 1) msm_window(j);
-            else pthread_create(&th[j0 + k], NULL, msm_window, j);
+            else pthread_create(&th[w0 + k], NULL, msm_window, j);
         }
         if (cnt > 1)
-            for (int k = 0; k < cnt; k++) pthread_join(th[j0 + k], NULL);
+            for (int k = 0; k < cnt; k++) pthread_join(th[w0 + k], NULL);
     }
     jac_t acc;
     jac_set_inf(&t, &acc);
     for (int w = nwin - 1; w >= 0; w--) {
         for (int k = 0; k < c; k++) jac_dbl(&t, &acc, &acc);
-        for (int p = 0; p < parts; p++) jac_add(&t, &acc, &acc, &jobs[w * parts + p].result);
+        jac_add(&t, &acc, &acc, &jobs[w].result);
     }
     store_jac(&t, out_jac, &acc);
     free(jobs);

@@ -69,11 +69,6 @@ def msm_windows(curve, n) -> int:
     return dll().oracle_msm_windows(curve, C.c_size_t(n))
 
 
-def msm_threads(curve, n, nthreads) -> int:
-    """threads oracle_msm actually runs with when offered nthreads (windows x point-range parts)"""
-    return dll().oracle_msm_threads(curve, C.c_size_t(n), int(nthreads))
-
-
 def jac_to_affine(curve, group, jac):
     jac = _u64(jac)
     out = np.zeros(aff_words(curve, group), dtype=np.uint64)

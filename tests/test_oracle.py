@@ -147,20 +147,3 @@ def test_c_oracle_plonk_quotient_matches_python(c):
         got = oracle.plonk_quotient(c.cid, n, polys, fr_to_arr(c, bp["Bl"]), fr_to_arr(c, bp["Br"]), fr_to_arr(c, bp["Bo"]),
                                     fr_to_arr(c, bp["Bz"]), fr_to_arr(c, [alpha]), fr_to_arr(c, [beta]), fr_to_arr(c, [gamma]), nb)
         assert arr_to_fr(c, got) == want
-
-
-def test_msm_threads_cut_windows_and_point_ranges():
-    """oracle_msm with many threads = windows x point-range parts (each part reduces its own buckets; the window sums add): same
-    point as with one thread, as the naive double-and-add, for a length that does not divide evenly"""
-    import oracle
-    c, group, n = pyref.BN254, 0, 9001
-    rng = pyref.Xoshiro(41)
-    base = [oracle.jac_to_affine(c.cid, group, oracle.generator_mul(c.cid, group, rng.field(c.r))) for _ in range(16)]
-    P = np.stack([base[i % 16] for i in range(n)])
-    S = np.array([pyref.to_mont_limbs(rng.field(c.r), c.r, 4) for _ in range(n)], dtype=np.uint64)
-    one = oracle.jac_to_affine(c.cid, group, oracle.msm(c.cid, group, P, S, nthreads=1))
-    many = oracle.jac_to_affine(c.cid, group, oracle.msm(c.cid, group, P, S, nthreads=128))
-    assert np.array_equal(one, many)
-    assert oracle.msm_threads(c.cid, n, 128) > oracle.msm_windows(c.cid, n) >= 1
-    small = oracle.jac_to_affine(c.cid, group, oracle.msm(c.cid, group, P[:50], S[:50], nthreads=48))
-    assert np.array_equal(small, oracle.jac_to_affine(c.cid, group, oracle.msm(c.cid, group, P[:50], S[:50], naive=True)))
