@@ -256,56 +256,80 @@ def main():
         inst, pk = synth_groth16(ctx, cid, args.log_n, 0x5EED0005, want_dlogs=not args.no_check)
         sol, nb_public, r, s = inst.solution, inst.nb_public, inst.r, inst.s
         setup_s = time.perf_counter() - t_setup
-        groth16.Prove(pk, sol, nb_public, r, s)   # warm-up (scratch allocation)
-        ctx.profile(True)
-        ctx.profile_reset()
+        for _ in range(2):   # warm-up: scratch of both lanes of the pair (witness MSMs on lane 0, H side on lane 1)
+            groth16.Prove(pk, sol, nb_public, r, s)
         ctx.sync()
+        lanes0 = ctx.lane_stats()
         t0 = time.perf_counter()
         for _ in range(args.groth16_proofs):
             proof = groth16.Prove(pk, sol, nb_public, r, s)
         ctx.sync()
         el = time.perf_counter() - t0
+        lanes1 = ctx.lane_stats()
+        # stage breakdown: a separate pass with the library's stage profiler on.  The profiler serialises a proof on ONE lane (its
+        # hipEvent pairs live on the main stream), so these are the kernels' stand-alone durations, not the overlapped schedule timed above
+        prof_proofs = 2
+        ctx.profile(True)
+        ctx.profile_reset()
+        ctx.sync()
+        tq0 = time.perf_counter()
+        for _ in range(prof_proofs):
+            groth16.Prove(pk, sol, nb_public, r, s)
+        ctx.sync()
+        el_prof = time.perf_counter() - tq0
         gst = stage_stats(ctx.profile_read())
         ctx.profile(False)
-        # the same proofs from TWO host threads (two goroutines in the Go shim): the second caller proves on the context's
-        # lane 1 (own stream and scratch) concurrently with the first, so the 2 GiB uploads hide behind the other proof's kernels
-        # and the kernels of the two proofs interleave on the device
+        # the same proofs from TWO host threads (two goroutines in the Go shim): the second caller proves on the context's second
+        # pair of lanes (own streams and scratch) concurrently with the first, so the 2 GiB uploads hide behind the other proof's
+        # kernels and the kernels of the two proofs interleave on the device.  Both pairs are warmed first (the second
+        # pair's ~10 GB of scratch is allocated on first use), and ga_g16_lane_stats says where the timed proofs ran.
         import threading
-        per_thread = max(3, args.groth16_proofs)
-        pipe_out = [[], []]
-
-        def prover(k):
-            for _ in range(per_thread):
-                pipe_out[k].append(groth16.Prove(pk, sol, nb_public, r, s).raw())
+        per_thread = max(10, args.groth16_proofs)
         if args.no_pipelined:
             per_thread = 0
-        groth16.Prove(pk, sol, nb_public, r, s)
-        ctx.sync()
+
+        def run_pair(count, sink):
+            def prover(k):
+                for _ in range(count):
+                    sink[k].append(groth16.Prove(pk, sol, nb_public, r, s).raw())
+            th = [threading.Thread(target=prover, args=(k,)) for k in range(2)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            ctx.sync()
+        pipe_out = [[], []]
+        if per_thread:
+            run_pair(2, [[], []])   # warm-up of the second lane pair
+        pl0 = ctx.lane_stats()
         tp0 = time.perf_counter()
-        provers = [threading.Thread(target=prover, args=(k,)) for k in range(2)]
-        for t in provers:
-            t.start()
-        for t in provers:
-            t.join()
-        ctx.sync()
+        if per_thread:
+            run_pair(per_thread, pipe_out)
         pipe_el = time.perf_counter() - tp0
+        pl1 = ctx.lane_stats()
         pipe_same = bool(all(len(po) == per_thread and all(np.array_equal(q, proof.raw()) for q in po) for po in pipe_out))
+        pipe_lanes = {k: pl1[k] - pl0[k] for k in ("lanes01_proofs", "lanes23_proofs", "queued_proofs", "split_proofs")}
+        pipe_lanes.update({k: pl1[k] for k in ("lanes01_scratch_bytes", "lanes23_scratch_bytes")})
         pk.FreeGPUResources()
-        ntt_ms = sum(v["total_ms"] for k, v in gst.items() if k.startswith("ntt_") or k == "h_pointwise") / args.groth16_proofs
+        ntt_ms = sum(v["total_ms"] for k, v in gst.items() if k.startswith("ntt_") or k == "h_pointwise") / prof_proofs
         bytes_per_constraint = 992 if cid == 0 else 1184   # 4 G1 + 1 G2 MSM + 7 NTTs
         out["groth16"] = {"proofs_per_s": round(args.groth16_proofs / el, 4), "ms_per_proof": round(el * 1e3 / args.groth16_proofs, 2),
                           "proofs": args.groth16_proofs, "constraints": n, "key_setup_s": round(setup_s, 1),
+                          "schedule": {"split_proofs": lanes1["split_proofs"] - lanes0["split_proofs"],
+                                       "how": "one caller: witness MSMs (A, B1, B2) on lane 0, uploads of A,B,C + computeH + Z MSM on lane 1 from a helper thread, K MSM on whichever lane is free first (GA_G16_SPLIT=0: everything on lane 0)"},
+                          "ms_per_proof_profiled_single_lane": round(el_prof * 1e3 / prof_proofs, 2),
                           "definition": "W,A,B,C in host memory -> Ar,Bs,Krs affine on host; key pinned with window tables (precompute=%s); solver excluded; C = A o B (satisfiable instance)" % os.environ.get("GA_BENCH_PRECOMPUTE", "1"),
                           "algorithmic_bytes": bytes_per_constraint * n, "hbm_frac_whole_proof": round(bytes_per_constraint * n / (el / args.groth16_proofs) / 8e12, 6),
                           "computeH_ms": round(ntt_ms, 3),
                           "computeH_hbm_frac": round(448.0 * n / (ntt_ms * 1e-3) / 8e12, 5) if ntt_ms > 0 else None,
                           "proof_sha": __import__("hashlib").sha256(proof.WriteTo()).hexdigest()[:16],
                           "pipelined": None if per_thread == 0 else {"proofs_per_s": round(2 * per_thread / pipe_el, 4), "ms_per_proof": round(pipe_el * 1e3 / (2 * per_thread), 2),
-                                        "proofs": 2 * per_thread, "host_threads": 2, "same_proof_bytes": pipe_same,
-                                        "how": "two host threads call ga_g16_prove on one key: two proofs in flight on two lanes (streams) of one context; every proof compared with the single-caller proof"},
-                          "stages_ms": {k: {"launches": v["launches"], "total_ms": round(v["total_ms"] / args.groth16_proofs, 4), "avg_ms": v["avg_ms"]}
+                                        "proofs": 2 * per_thread, "host_threads": 2, "same_proof_bytes": pipe_same, "lanes": pipe_lanes,
+                                        "vs_single_caller": round(pipe_el / (2 * per_thread) / (el / args.groth16_proofs), 4),
+                                        "how": "two host threads call ga_g16_prove on one key, both lane pairs warmed first: two proofs in flight on lanes 0/1 and 2/3 of one context; every proof compared with the single-caller proof"},
+                          "stages_ms": {k: {"launches": v["launches"], "total_ms": round(v["total_ms"] / prof_proofs, 4), "avg_ms": v["avg_ms"]}
                                         for k, v in gst.items()},
-                          "stages_note": "total_ms is per proof (averaged over the timed proofs)"}
+                          "stages_note": "total_ms is per proof, from %d extra proofs with the stage profiler on (single-lane schedule); ms_per_proof above is timed without it" % prof_proofs}
         if not args.no_check:
             t_chk = time.perf_counter()
             try:

@@ -30,7 +30,8 @@ LaneScope::~LaneScope() { g_lane = prev; }
 
 int Ctx::scratch_get(const char* base_key, size_t bytes, void** out) {
     // every lane has its own namespace: a lane-1 proof never shares a buffer with the lane-0 work running beside it
-    const std::string lane_key = current_lane() ? std::string(base_key) + "@1" : std::string(base_key);
+    const int lane = current_lane();
+    const std::string lane_key = lane ? std::string(base_key) + "@" + std::to_string(lane) : std::string(base_key);
     const char* key = lane_key.c_str();
     std::lock_guard<std::mutex> g(scratch_mu);
     auto it = scratch.find(key);
@@ -61,24 +62,28 @@ void Ctx::scratch_free_all() {
 }
 
 void Tunables::read_env() {
-    // parsed into a local first: a prover on lane 1 may be reading the knobs while lane 0 refreshes them, and must never see the
-    // defaults flicker; the stored copy changes only when the environment did
-    Tunables t;
-    if (const char* e = getenv("GA_MSM_MAX_CHUNK")) t.msm_max_chunk = strtoull(e, nullptr, 10);
-    if (const char* e = getenv("GA_REDUCE_LAZY_MIN")) t.reduce_lazy_min = strtoull(e, nullptr, 10);
-    if (const char* e = getenv("GA_G16_SHARE_MIN_PCT")) t.g16_share_min_pct = atoi(e);
-    if (const char* e = getenv("GA_G16_LANES")) t.g16_lanes = atoi(e);
-    if (const char* e = getenv("GA_TABLE_C")) t.table_c = atoi(e);
-    if (const char* e = getenv("GA_MSM_MIN_SEG")) t.msm_min_seg = strtoull(e, nullptr, 10);
-    if (const char* e = getenv("GA_MSM_EXACT_REDO")) t.msm_exact_redo = atoi(e);
-    if (t.msm_max_chunk != msm_max_chunk) msm_max_chunk = t.msm_max_chunk;
-    if (t.reduce_lazy_min != reduce_lazy_min) reduce_lazy_min = t.reduce_lazy_min;
-    if (t.g16_share_min_pct != g16_share_min_pct) g16_share_min_pct = t.g16_share_min_pct;
-    if (t.g16_lanes != g16_lanes) g16_lanes = t.g16_lanes;
-    if (t.table_c != table_c) table_c = t.table_c;
-    if (t.msm_exact_redo != msm_exact_redo) msm_exact_redo = t.msm_exact_redo;
-    if (t.msm_min_seg != msm_min_seg && t.msm_min_seg >= 32) msm_min_seg = t.msm_min_seg;
-    g_table_c = table_c;
+    // a prover on another lane may be reading the knobs while lane 0 refreshes them: every field is an atomic, parsed into a
+    // local first and stored only when the environment changed it, so a reader never sees the defaults flicker
+    auto num = [](const char* name, uint64_t dflt) -> uint64_t {
+        const char* e = getenv(name);
+        return e ? strtoull(e, nullptr, 10) : dflt;
+    };
+    auto put64 = [](std::atomic<uint64_t>& f, uint64_t v) {
+        if (f.load(std::memory_order_relaxed) != v) f.store(v, std::memory_order_relaxed);
+    };
+    auto put = [](std::atomic<int>& f, int v) {
+        if (f.load(std::memory_order_relaxed) != v) f.store(v, std::memory_order_relaxed);
+    };
+    put64(msm_max_chunk, num("GA_MSM_MAX_CHUNK", 0));
+    put64(reduce_lazy_min, num("GA_REDUCE_LAZY_MIN", 1u << 14));
+    put(g16_share_min_pct, (int)num("GA_G16_SHARE_MIN_PCT", 90));
+    put(g16_lanes, (int)num("GA_G16_LANES", 2));
+    put(g16_split, (int)num("GA_G16_SPLIT", 1));
+    put(table_c, (int)num("GA_TABLE_C", 0));
+    put(msm_exact_redo, (int)num("GA_MSM_EXACT_REDO", 0));
+    const uint64_t seg = num("GA_MSM_MIN_SEG", 256);
+    if (seg >= 32) put64(msm_min_seg, seg);
+    g_table_c = table_c.load();
 }
 
 typedef CtxLock Lock;
@@ -192,8 +197,9 @@ int ga_ctx_create(int device, ga_ctx** out) {
     GA_HIP_CHECK(hipSetDevice(device));
     Ctx* c = new Ctx();
     c->device = device;
-    hipStream_t* slots[5] = {&c->stream, &c->copy_stream, &c->lane1_stream, &c->slot_stream[0], &c->slot_stream[1]};
-    for (int k = 0; k < 5; k++) {
+    hipStream_t* slots[3 + GA_NUM_LANES] = {&c->lane_stream[0], &c->lane_stream[1], &c->lane_stream[2], &c->lane_stream[3],
+                                            &c->copy_stream, &c->slot_stream[0], &c->slot_stream[1]};
+    for (int k = 0; k < 3 + GA_NUM_LANES; k++) {
         hipError_t se = hipStreamCreateWithFlags(slots[k], hipStreamNonBlocking);
         if (se != hipSuccess) {
             set_error("hipStreamCreate failed: %s", hipGetErrorString(se));
@@ -202,6 +208,7 @@ int ga_ctx_create(int device, ga_ctx** out) {
             return GA_ERR_HIP;
         }
     }
+    c->stream = c->lane_stream[0];
     c->tun.read_env();
     *out = reinterpret_cast<ga_ctx*>(c);
     return GA_OK;
@@ -211,16 +218,14 @@ void ga_ctx_destroy(ga_ctx* h) {
     if (!h) return;
     Ctx* c = reinterpret_cast<Ctx*>(h);
     hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
-    hipStreamSynchronize(c->lane1_stream);
+    for (int l = 0; l < GA_NUM_LANES; l++) hipStreamSynchronize(c->lane_stream[l]);
     c->scratch_free_all();
     for (auto& s : c->stages) {
         hipEventDestroy(s.a);
         hipEventDestroy(s.b);
     }
-    hipStreamDestroy(c->stream);
+    for (int l = 0; l < GA_NUM_LANES; l++) hipStreamDestroy(c->lane_stream[l]);
     hipStreamDestroy(c->copy_stream);
-    hipStreamDestroy(c->lane1_stream);
     hipStreamDestroy(c->slot_stream[0]);
     hipStreamDestroy(c->slot_stream[1]);
     delete c;
@@ -277,8 +282,7 @@ int ga_copy_to_host(ga_ctx* h, void* dst, const void* src, size_t bytes) {
 int ga_sync(ga_ctx* h) {   // (every entry point returns with its own work finished; this waits for both lanes' streams)
     Ctx* c = reinterpret_cast<Ctx*>(h);
     Lock l(c);
-    GA_HIP_CHECK(hipStreamSynchronize(c->stream));
-    GA_HIP_CHECK(hipStreamSynchronize(c->lane1_stream));
+    for (int l = 0; l < GA_NUM_LANES; l++) GA_HIP_CHECK(hipStreamSynchronize(c->lane_stream[l]));
     return GA_OK;
 }
 

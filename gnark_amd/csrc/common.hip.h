@@ -87,24 +87,32 @@ struct StageRec {
 //   GA_MSM_MIN_SEG        shortest task length the bucket lists are cut into (points per task)
 //   GA_MSM_EXACT_REDO     1: tasks flagged by the fast bucket loop go straight to the exact-arithmetic kernel (tests)
 //   GA_TABLE_C            force the window width of precomputed tables built from now on (experiments; 0 = planned)
-//   GA_G16_LANES          1: a second concurrent ga_g16_prove caller queues for the device instead of proving on lane 1
+//   GA_G16_LANES          1: a second concurrent ga_g16_prove caller queues for the device instead of proving on its own lanes
+//   GA_G16_SPLIT          0: a proof keeps its H side (computeH, Z MSM) on the lane of its witness MSMs instead of a partner lane
+// The fields are relaxed atomics: the entry point that holds lane 0 refreshes them while provers on the other lanes read them.
 struct Tunables {
-    uint64_t msm_max_chunk = 0;          // 0 = only the 2^31 pair-space limit
-    uint64_t reduce_lazy_min = 1u << 14;
-    int g16_share_min_pct = 90;
-    int g16_lanes = 2;
-    int table_c = 0;
-    uint64_t msm_min_seg = 256;
-    int msm_exact_redo = 0;
+    std::atomic<uint64_t> msm_max_chunk{0};          // 0 = only the 2^31 pair-space limit
+    std::atomic<uint64_t> reduce_lazy_min{1u << 14};
+    std::atomic<int> g16_share_min_pct{90};
+    std::atomic<int> g16_lanes{2};
+    std::atomic<int> g16_split{1};
+    std::atomic<int> table_c{0};
+    std::atomic<uint64_t> msm_min_seg{256};
+    std::atomic<int> msm_exact_redo{0};
     void read_env();
 };
 
 // Lanes: a host thread inside an entry point works on ONE lane of its context = one stream + one namespace of the scratch map.
-// Lane 0 is the context's main stream, guarded by Ctx::mu (every entry point); lane 1 lets a second ga_g16_prove caller compute
-// its proof CONCURRENTLY with the lane-0 proof (guarded by Ctx::lane_mu) instead of queueing behind it: the kernels of the two
-// proofs interleave on the device (one proof's sorts, transforms and reduction tails fill the other's bucket kernel), which
-// is worth ~5 % of throughput on top of hiding the uploads.  The lane is a thread-local of the calling thread (abi.hip), so the
-// launch paths pick the right stream / scratch without extra parameters.
+// Lane 0 is the context's main stream, guarded by Ctx::mu (every entry point); lanes 1..3 are guarded by Ctx::lane_mu[lane].
+//   * a proof runs on a PAIR of lanes: the witness MSMs on the caller's lane (0, or 2 for a second concurrent caller) and its H
+//     side -- uploads of A, B, C, computeH, the Z MSM -- on the partner lane (1, or 3) from a helper thread, so that the sorts,
+//     reduction tails and host round trips of one half run under the bucket kernels of the other (groth16.hip prove_partial);
+//   * a second ga_g16_prove caller computes its proof CONCURRENTLY on lanes 2/3 instead of queueing behind the first: its
+//     uploads hide behind the other proof's kernels;
+//   * the table MSM entry points and the pieces of a sharded proof take lane 1 when lane 0 is busy (LaneLock).
+// The lane is a thread-local of the calling thread (abi.hip), so the launch paths pick the right stream / scratch without extra
+// parameters.  Results never depend on the interleaving.
+constexpr int GA_NUM_LANES = 4;
 int current_lane();
 int table_c_override();   // Tunables::table_c of the last read_env (process-wide: msm_plan_table has no context)
 struct LaneScope {
@@ -116,10 +124,12 @@ struct LaneScope {
 struct Ctx {
     int device = 0;
     Tunables tun;
-    hipStream_t stream = nullptr;
-    hipStream_t lane1_stream = nullptr;  // lane 1's compute stream
-    std::mutex lane_mu;                  // at most one thread on lane 1
-    hipStream_t work_stream() const { return current_lane() ? lane1_stream : stream; }
+    hipStream_t stream = nullptr;                        // lane 0
+    hipStream_t lane_stream[GA_NUM_LANES] = {nullptr, nullptr, nullptr, nullptr};   // [0] == stream
+    std::mutex lane_mu[GA_NUM_LANES];                    // at most one thread per lane ([0] unused: lane 0 is guarded by `mu`)
+    hipStream_t work_stream() const { return lane_stream[current_lane()]; }
+    // how ga_g16_prove calls were scheduled since the context was created (ga_g16_lane_stats)
+    std::atomic<uint64_t> stat_lane0{0}, stat_lane2{0}, stat_queued{0}, stat_split{0};
     hipStream_t copy_stream = nullptr;   // uploads that overlap kernels (groth16.hip)
     std::mutex mu;
     // Two input slots per context (W, A, B, C staging buffers each): while one proof computes under `mu`, a second caller of
@@ -172,7 +182,7 @@ struct LaneLock {
     std::unique_lock<std::mutex> dev, l1;
     int lane = 0;
     LaneScope* scope = nullptr;
-    explicit LaneLock(Ctx* c) : dev(c->mu, std::try_to_lock), l1(c->lane_mu, std::defer_lock) {
+    explicit LaneLock(Ctx* c) : dev(c->mu, std::try_to_lock), l1(c->lane_mu[1], std::defer_lock) {
         hipSetDevice(c->device);
         if (!dev.owns_lock()) {
             if (!c->profiling && c->tun.g16_lanes > 1 && l1.try_lock()) lane = 1;

@@ -6,6 +6,7 @@
 // toolchain exists in the build image (INTEGRATION.md shows the cgo binding that calls this file's two entry points).
 #include <algorithm>
 #include <condition_variable>
+#include <memory>
 #include <string>
 #include <thread>
 
@@ -55,7 +56,40 @@ struct G16Pk {
     // fixed-base tables of delta1 / delta2 for the host epilogue: entry [w*15 + d-1] = d * 2^(4w) * delta (XYZZ images), built on first use
     std::once_flag delta_tab_once;
     std::vector<uint8_t> delta1_tab, delta2_tab;
+    // In-flight users: every entry point that takes the key holds one PkUse for its whole duration (the host epilogue included,
+    // which runs outside the device lock); ga_g16_pk_destroy waits for them, so a caller that frees the key from one thread while
+    // another is still proving (Go: `defer pk.FreeGPUResources()` beside a second goroutine's Prove) gets a late free, not a
+    // use-after-free.
+    std::mutex use_mu;
+    std::condition_variable use_cv;
+    int users = 0;
+    bool dying = false;
 };
+
+struct PkUse {
+    G16Pk* pk;
+    bool ok = false;
+    explicit PkUse(G16Pk* p) : pk(p) {
+        if (!pk) return;
+        std::lock_guard<std::mutex> g(pk->use_mu);
+        if (pk->dying) return;
+        pk->users++;
+        ok = true;
+    }
+    ~PkUse() {
+        if (!ok) return;
+        std::lock_guard<std::mutex> g(pk->use_mu);
+        if (--pk->users == 0) pk->use_cv.notify_all();
+    }
+    PkUse(const PkUse&) = delete;
+    PkUse& operator=(const PkUse&) = delete;
+};
+#define GA_PK_USE(pk, what)                                                      \
+    PkUse _pk_use(pk);                                                           \
+    if (!_pk_use.ok) {                                                           \
+        set_error(what ": the proving key is being destroyed");                  \
+        return GA_ERR_STATE;                                                     \
+    }
 
 static int upload(Ctx* ctx, const void* src, size_t bytes, void** dst) {
     *dst = nullptr;
@@ -923,12 +957,107 @@ static int witness_upload(G16Pk* pk, const SlotLease& slot, const void* w, uint6
     return GA_OK;
 }
 
+// What the two halves of a split proof share (prove_partial): the sort of the whole witness, made once on the lane of the
+// witness MSMs, and the K MSM, which goes to whichever lane gets to it first.
+struct WitnessShared {
+    MsmPrepared prep_w;            // digits + sort of W (wire-indexed tables); arrays live in the witness lane's scratch
+    bool w_live = false;
+    void* d_w = nullptr;           // W on the device (the slot's buffer, in the witness lane's scratch namespace)
+    hipEvent_t w_ev = nullptr;     // recorded on the witness lane's stream once W is on the device and prep_w has been launched
+    std::mutex mu;
+    std::condition_variable cv;
+    bool posted = false, failed = false;   // host-side: prep_w / w_ev are valid (or never will be)
+    std::atomic<int> k_owner{-1};          // lane that claimed the K MSM
+    void post(bool ok) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            posted = true;
+            failed = !ok;
+        }
+        cv.notify_all();
+    }
+    bool wait_posted() {
+        std::unique_lock<std::mutex> g(mu);
+        cv.wait(g, [&] { return posted; });
+        return !failed;
+    }
+    bool claim_k(int lane) {
+        int expected = -1;
+        return k_owner.compare_exchange_strong(expected, lane);
+    }
+    ~WitnessShared() {
+        if (w_ev) hipEventDestroy(w_ev);
+    }
+};
+
+// this device's share of the windows of a table with window width c (everything unless the key is window-sharded)
 template <class C>
-static int witness_msms(G16Pk* pk, const SlotLease& slot, uint64_t nb_public, XYZZ<Fe<typename C::FpP>>* o_ar,
-                        XYZZ<Fe<typename C::FpP>>* o_bs1, XYZZ<Fe<typename C::FpP>>* o_k, XYZZ<Fe2<typename C::FpP>>* o_bs2) {
+static void g16_window_share(const G16Pk* pk, int c, int* lo, int* hi) {
+    window_share(C::FrP::BITS / c + 1, pk->win_index, pk->win_count, lo, hi);
+}
+
+// one G1 MSM over a compact (not wire-indexed) table with its own digits + sort; `prep` is left holding them
+template <class C>
+static int g16_table_msm_g1(G16Pk* pk, const void* table, const void* scal, uint64_t len, int c, MsmPrepared* prep, bool* prep_live,
+                            XYZZ<Fe<typename C::FpP>>* out) {
+    typedef Fe<typename C::FpP> F1;
+    int lo, hi;
+    g16_window_share<C>(pk, c, &lo, &hi);
+    *prep_live = false;
+    if (len == 0 || hi <= lo) {
+        *out = xyzz_inf<F1>();
+        return GA_OK;
+    }
+    GA_CHECK(msm_prepare_table_scalars<C>(pk->ctx, scal, len, true, c, prep, 0, lo, hi));
+    *prep_live = true;
+    return msm_table_device_reuse<C, GA_G1>(pk->ctx, table, *prep, out);
+}
+
+// the K MSM (prove.go:231-237) on the CALLING thread's lane: over the shared witness sort when K's table is wire-indexed,
+// otherwise over its own gather + sort (scratch of the calling lane).  `sh` must have been posted.
+template <class C>
+static int k_msm(G16Pk* pk, uint64_t nb_public, WitnessShared& sh, XYZZ<Fe<typename C::FpP>>* out) {
+    typedef Fe<typename C::FpP> F1;
+    Ctx* ctx = pk->ctx;
+    if (pk->tables && pk->share_k) {
+        if (!sh.w_live) {
+            *out = xyzz_inf<F1>();
+            return GA_OK;
+        }
+        return msm_table_device_reuse<C, GA_G1>(ctx, pk->d_k, sh.prep_w, out);
+    }
+    void* const d_w = sh.d_w;   // (not scratch_get: the calling thread may be on the partner lane, whose namespace differs)
+    const void* d_wk = (const char*)d_w + (nb_public + pk->off_k) * 32;
+    if (pk->d_idx_k) {
+        void* g;
+        GA_CHECK(ctx->scratch_get("g16_wk", pk->len_k * 32 + 32, &g));
+        GA_CHECK(util_gather_fr<C>(ctx, g, d_w, pk->d_idx_k, pk->len_k));
+        d_wk = g;
+    }
+    if (pk->tables) {
+        MsmPrepared prep;
+        bool live;
+        return g16_table_msm_g1<C>(pk, pk->d_k, d_wk, pk->len_k, pk->c_k, &prep, &live, out);
+    }
+    return host_msm<C, GA_G1>(ctx, pk->d_k, d_wk, pk->len_k, true, out, pk->win_index, pk->win_count);
+}
+
+// The witness MSMs A, B (G1 and G2) and -- unless the partner lane claims it first -- K, on the calling thread's lane.
+// `sh` is posted as soon as the shared witness sort has been launched; o_k is written only when *did_k comes back true.
+template <class C>
+static int witness_msms(G16Pk* pk, const SlotLease& slot, uint64_t nb_public, WitnessShared& sh, XYZZ<Fe<typename C::FpP>>* o_ar,
+                        XYZZ<Fe<typename C::FpP>>* o_bs1, XYZZ<Fe<typename C::FpP>>* o_k, XYZZ<Fe2<typename C::FpP>>* o_bs2, bool* did_k) {
     typedef Fe<typename C::FpP> F1;
     typedef Fe2<typename C::FpP> F2;
     Ctx* ctx = pk->ctx;
+    struct PostGuard {   // a failure before the post must still release the partner lane
+        WitnessShared& sh;
+        bool done = false;
+        ~PostGuard() {
+            if (!done) sh.post(false);
+        }
+    } pg{sh};
+    *did_k = false;
     if (nb_public > pk->nb_wires || pk->nb_wires - nb_public != pk->full_len_k + pk->len_k_remove) {
         set_error("prove: inconsistent sizes (nbWires %llu - nbPublic %llu != len(K) %llu + len(k_remove) %llu)", (unsigned long long)pk->nb_wires,
                   (unsigned long long)nb_public, (unsigned long long)pk->full_len_k, (unsigned long long)pk->len_k_remove);
@@ -939,77 +1068,58 @@ static int witness_msms(G16Pk* pk, const SlotLease& slot, uint64_t nb_public, XY
     GA_CHECK(ctx->scratch_get(slot.name("g16_w").c_str(), pk->nb_wires * 32, &d_w));
     GA_CHECK(ctx->scratch_get("g16_wa", pk->len_a * 32 + 32, &d_wa));
     GA_CHECK(ctx->scratch_get("g16_wb", pk->len_b * 32 + 32, &d_wb));
+    // digits + sort of the WHOLE witness once (scratch slot 1), reused by every wire-indexed table
+    if (pk->tables && (pk->share_a || pk->share_b || pk->share_k)) {
+        int lo, hi;
+        g16_window_share<C>(pk, pk->c_w, &lo, &hi);
+        if (hi > lo) {
+            GA_CHECK(msm_prepare_table_scalars<C>(ctx, d_w, pk->nb_wires, true, pk->c_w, &sh.prep_w, 1, lo, hi));
+            sh.w_live = true;
+        }
+    }
+    sh.d_w = d_w;
+    GA_HIP_CHECK(hipEventRecord(sh.w_ev, st));
+    pg.done = true;
+    sh.post(true);
     // ---- wire filtering (prove.go:147-168) ------------------------------------------------------------
     if (!pk->share_a) GA_CHECK(util_gather_fr<C>(ctx, d_wa, d_w, pk->d_idx_a, pk->len_a));
     if (!pk->share_b) GA_CHECK(util_gather_fr<C>(ctx, d_wb, d_w, pk->d_idx_b, pk->len_b));
-    const void* d_wk = (const char*)d_w + (nb_public + pk->off_k) * 32;
-    if (pk->d_idx_k && !pk->share_k) {
-        void* g;
-        GA_CHECK(ctx->scratch_get("g16_wk", pk->len_k * 32 + 32, &g));
-        GA_CHECK(util_gather_fr<C>(ctx, g, d_w, pk->d_idx_k, pk->len_k));
-        d_wk = g;
-    }
-    // ---- the four witness MSMs (prove.go:194,207,237,283) ----------------------------------------------
-    XYZZ<F1> ar, bs1, krs;
+    // ---- the witness MSMs (prove.go:194,207,237,283) ---------------------------------------------------
+    XYZZ<F1> ar, bs1;
     XYZZ<F2> bs2;
-    MsmPrepared prep;
-    // this device's share of the windows of a table with window width c (everything unless the key is window-sharded)
-    auto share_of = [&](int c, int* lo, int* hi) { window_share(C::FrP::BITS / c + 1, pk->win_index, pk->win_count, lo, hi); };
-    bool prep_live = false;   // `prep` holds the digits of wB for G2.B
-    auto table_msm_g1 = [&](const void* table, const void* scal, uint64_t len, int c, XYZZ<F1>* out) -> int {
-        int lo, hi;
-        share_of(c, &lo, &hi);
-        prep_live = false;
-        if (len == 0 || hi <= lo) {
-            *out = xyzz_inf<F1>();
-            return GA_OK;
-        }
-        GA_CHECK(msm_prepare_table_scalars<C>(ctx, scal, len, true, c, &prep, 0, lo, hi));
-        prep_live = true;
-        return msm_table_device_reuse<C, GA_G1>(ctx, table, prep, out);
-    };
     if (pk->tables) {
-        // digits + sort of the WHOLE witness once (scratch slot 1), reused by every wire-indexed table
-        MsmPrepared prep_w;
-        bool w_live = false;
-        if (pk->share_a || pk->share_b || pk->share_k) {
-            int lo, hi;
-            share_of(pk->c_w, &lo, &hi);
-            if (hi > lo) {
-                GA_CHECK(msm_prepare_table_scalars<C>(ctx, d_w, pk->nb_wires, true, pk->c_w, &prep_w, 1, lo, hi));
-                w_live = true;
-            }
-        }
+        MsmPrepared prep;
+        bool prep_live = false;   // `prep` holds the digits of wB for G2.B
         auto shared_g1 = [&](const void* table, XYZZ<F1>* out) -> int {
-            if (!w_live) {
+            if (!sh.w_live) {
                 *out = xyzz_inf<F1>();
                 return GA_OK;
             }
-            return msm_table_device_reuse<C, GA_G1>(ctx, table, prep_w, out);
+            return msm_table_device_reuse<C, GA_G1>(ctx, table, sh.prep_w, out);
         };
         if (pk->share_a) GA_CHECK(shared_g1(pk->d_a, &ar));
-        else GA_CHECK(table_msm_g1(pk->d_a, d_wa, pk->len_a, pk->c_a, &ar));
+        else GA_CHECK(g16_table_msm_g1<C>(pk, pk->d_a, d_wa, pk->len_a, pk->c_a, &prep, &prep_live, &ar));
         if (pk->share_b) {
             GA_CHECK(shared_g1(pk->d_b, &bs1));
-            if (w_live) GA_CHECK((msm_table_device_reuse<C, GA_G2>(ctx, pk->d_b2, prep_w, &bs2)));
+            if (sh.w_live) GA_CHECK((msm_table_device_reuse<C, GA_G2>(ctx, pk->d_b2, sh.prep_w, &bs2)));
             else bs2 = xyzz_inf<F2>();
         } else {
-            GA_CHECK(table_msm_g1(pk->d_b, d_wb, pk->len_b, pk->c_b, &bs1));
+            GA_CHECK(g16_table_msm_g1<C>(pk, pk->d_b, d_wb, pk->len_b, pk->c_b, &prep, &prep_live, &bs1));
             if (pk->len_b2 && prep_live) GA_CHECK((msm_table_device_reuse<C, GA_G2>(ctx, pk->d_b2, prep, &bs2)));   // same scalars wB: digits/sort shared
             else bs2 = xyzz_inf<F2>();
         }
-        if (pk->share_k) GA_CHECK(shared_g1(pk->d_k, &krs));
-        else GA_CHECK(table_msm_g1(pk->d_k, d_wk, pk->len_k, pk->c_k, &krs));
     } else {
         GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_a, d_wa, pk->len_a, true, &ar, pk->win_index, pk->win_count)));
         GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_b, d_wb, pk->len_b, true, &bs1, pk->win_index, pk->win_count)));
         GA_CHECK((host_msm<C, GA_G2>(ctx, pk->d_b2, d_wb, pk->len_b2, true, &bs2, pk->win_index, pk->win_count)));
-        GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_k, d_wk, pk->len_k, true, &krs, pk->win_index, pk->win_count)));
     }
     *o_ar = ar;
     *o_bs1 = bs1;
-    *o_k = krs;
     *o_bs2 = bs2;
+    if (sh.claim_k(current_lane())) {
+        GA_CHECK(k_msm<C>(pk, nb_public, sh, o_k));
+        *did_k = true;
+    }
     return GA_OK;
 }
 
@@ -1084,6 +1194,14 @@ static int preload_solution(G16Pk* pk, const SlotLease& slot, const void* w, con
 // The device part of a proof on this key's shard: computeH + the five MSMs over the pinned slices.
 // Outputs (before randomisation): A-sum, B1-sum, K-sum + Z-sum (G1), B2-sum (G2) -- to be added across shards.
 // preloaded: W, A, B, C already sit in the slot's buffers (preload_solution).
+//
+// Schedule.  The calling thread uploads W and runs the witness MSMs (A, B1, B2) on its own lane.  A helper thread uploads A, B, C
+// on the slot's copy stream (pageable H2D copies block the thread that issues them) and -- when the partner lane is free -- also
+// runs the H side there: each chain FFT_coset(iFFT(.)) as soon as its vector has landed, the point-wise step, the last
+// transform, then the Z MSM over h.  The K MSM goes to whichever lane reaches it first.  The two halves share the device: the
+// sorts, reduction tails, host round trips and launch gaps of one run under the bucket kernels of the other.  Without a partner
+// lane (profiling on, GA_G16_SPLIT=0, or the lane is taken) the helper only uploads and the H side follows on the caller's lane,
+// as in round 2.  Everything is joined before this function returns, so no host pointer outlives the call.
 template <class C>
 static int prove_partial(G16Pk* pk, const SlotLease& slot, bool preloaded, const void* w, const void* a, const void* b, const void* c,
                          uint64_t n_constraints, uint64_t nb_public, XYZZ<Fe<typename C::FpP>>* o_ar, XYZZ<Fe<typename C::FpP>>* o_bs1,
@@ -1095,53 +1213,114 @@ static int prove_partial(G16Pk* pk, const SlotLease& slot, bool preloaded, const
         set_error("prove: %llu constraints exceed the domain cardinality %llu", (unsigned long long)n_constraints, (unsigned long long)n);
         return GA_ERR_INVALID;
     }
-    void *d_ha, *d_hb, *d_hc;
-    GA_CHECK(ctx->scratch_get(slot.name("h_a").c_str(), n * 32, &d_ha));
-    GA_CHECK(ctx->scratch_get(slot.name("h_b").c_str(), n * 32, &d_hb));
-    GA_CHECK(ctx->scratch_get(slot.name("h_c").c_str(), n * 32, &d_hc));
-    XYZZ<F1> krs, krs2;
-    if (preloaded) {
-        GA_CHECK(witness_msms<C>(pk, slot, nb_public, o_ar, o_bs1, &krs, o_bs2));
-    } else {
-        // W first (the four witness MSMs only need W); A, B, C are uploaded by a helper thread on a second stream while
-        // those MSMs run -- pageable H2D copies block the calling thread, hence the thread.  Everything is joined before
-        // this function returns, so no host pointer outlives the call.
-        GA_CHECK(witness_upload(pk, slot, w, nb_public));
-        EventGuard abc;
-        GA_HIP_CHECK(hipEventCreateWithFlags(&abc.ev, hipEventDisableTiming));
-        int up_rc = GA_OK;
-        std::string up_err;
-        hipStream_t up = ctx->slot_stream[slot.slot];   // the slot's own copy stream: two proofs in flight do not queue their uploads
-        std::thread uploader([&]() {
+    void* d_h[3];
+    static const char* const names[3] = {"h_a", "h_b", "h_c"};
+    for (int k = 0; k < 3; k++) GA_CHECK(ctx->scratch_get(slot.name(names[k]).c_str(), n * 32, &d_h[k]));
+    const int lane = current_lane();
+    const int partner = lane + 1;   // lanes pair up: (0, 1) and (2, 3)
+    const bool may_split = !ctx->profiling && ctx->tun.g16_split && (lane == 0 || lane == 2);
+    WitnessShared sh;
+    GA_HIP_CHECK(hipEventCreateWithFlags(&sh.w_ev, hipEventDisableTiming));
+    EventGuard ev[3];
+    for (int k = 0; k < 3; k++) GA_HIP_CHECK(hipEventCreateWithFlags(&ev[k].ev, hipEventDisableTiming));
+    // W first: the witness MSMs only need W, and the (PCIe-competing) upload of A, B, C starts when this one has been handed over
+    if (!preloaded) GA_CHECK(witness_upload(pk, slot, w, nb_public));
+    XYZZ<F1> k_part = xyzz_inf<F1>(), k_part_h = xyzz_inf<F1>(), z_part = xyzz_inf<F1>();
+    bool split = false, h_did_k = false;
+    int h_rc = GA_OK;
+    std::string h_err;
+    hipStream_t up = ctx->slot_stream[slot.slot];   // the slot's own copy stream: two proofs in flight do not queue their uploads
+    std::thread helper;
+    if (!preloaded || may_split)
+        helper = std::thread([&]() {
+            auto fail = [&](int rc, const char* what) {
+                h_rc = rc;
+                h_err = std::string(what) + ": " + get_error();
+            };
             if (hipSetDevice(ctx->device) != hipSuccess) {
-                up_rc = GA_ERR_HIP;
+                set_error("hipSetDevice(%d) failed", ctx->device);
+                return fail(GA_ERR_HIP, "selecting the device");
+            }
+            std::unique_lock<std::mutex> pl(ctx->lane_mu[partner < GA_NUM_LANES ? partner : 1], std::defer_lock);
+            if (may_split && pl.try_lock()) split = true;
+            LaneScope on_lane(split ? partner : lane);
+            if (!preloaded) {
+                const void* src[3] = {a, b, c};
+                for (int k = 0; k < 3; k++) {
+                    if (h_upload(pk, src[k], n_constraints, d_h[k], up) != GA_OK) return fail(GA_ERR_HIP, "uploading A, B, C");
+                    if (hipEventRecord(ev[k].ev, up) != hipSuccess) {
+                        set_error("hipEventRecord failed");
+                        return fail(GA_ERR_HIP, "uploading A, B, C");
+                    }
+                }
+            }
+            auto drain_uploads = [&]() -> bool {
+                if (preloaded || hipStreamSynchronize(up) == hipSuccess) return true;
+                set_error("hipStreamSynchronize failed on the copy stream");
+                fail(GA_ERR_HIP, "uploading A, B, C");
+                return false;
+            };
+            if (!split) {
+                drain_uploads();
                 return;
             }
-            const void* src[3] = {a, b, c};
-            void* dst[3] = {d_ha, d_hb, d_hc};
-            for (int k = 0; k < 3 && up_rc == GA_OK; k++) up_rc = h_upload(pk, src[k], n_constraints, dst[k], up);
-            hipError_t e = hipSuccess;
-            if (up_rc == GA_OK) e = hipEventRecord(abc.ev, up);
-            if (up_rc == GA_OK && e == hipSuccess) e = hipStreamSynchronize(up);
-            if (up_rc != GA_OK) up_err = get_error();
-            else if (e != hipSuccess) {
-                up_rc = GA_ERR_HIP;
-                up_err = hipGetErrorString(e);
+            ctx->stat_split++;
+            hipStream_t st = ctx->work_stream();
+            int rc = GA_OK;
+            for (int k = 0; k < 3 && rc == GA_OK; k++) {
+                if (!preloaded && hipStreamWaitEvent(st, ev[k].ev, 0) != hipSuccess) {
+                    set_error("hipStreamWaitEvent failed");
+                    rc = GA_ERR_HIP;
+                    break;
+                }
+                rc = ntt_domain_h_chain<C>(pk->dom, d_h[k]);
+            }
+            if (rc == GA_OK) rc = ntt_domain_h_combine<C>(pk->dom, d_h[0], d_h[1], d_h[2]);   // h in d_h[0], bit-reversed like pk.G1.Z
+            if (rc == GA_OK) rc = z_msm<C>(pk, (const char*)d_h[0] + pk->off_z * 32, &z_part);
+            if (rc != GA_OK) {
+                hipStreamSynchronize(st);
+                drain_uploads();
+                return fail(rc, "computeH / Z MSM");
+            }
+            if (hipStreamSynchronize(st) != hipSuccess) {   // (z_msm returns synchronised unless this shard's Z slice is empty)
+                set_error("hipStreamSynchronize failed on the H lane");
+                return fail(GA_ERR_HIP, "computeH / Z MSM");
+            }
+            if (!drain_uploads()) return;
+            // the K MSM, if the witness lane has not got to it yet (its W and its witness sort are on the device: w_ev)
+            if (sh.wait_posted() && sh.claim_k(partner)) {
+                if (hipStreamWaitEvent(st, sh.w_ev, 0) != hipSuccess) {
+                    set_error("hipStreamWaitEvent failed");
+                    return fail(GA_ERR_HIP, "K MSM");
+                }
+                rc = k_msm<C>(pk, nb_public, sh, &k_part_h);
+                if (rc != GA_OK) return fail(rc, "K MSM");
+                h_did_k = true;
             }
         });
-        ThreadJoiner joiner{uploader};
-        GA_CHECK(witness_msms<C>(pk, slot, nb_public, o_ar, o_bs1, &krs, o_bs2));
-        uploader.join();
-        if (up_rc != GA_OK) {
-            set_error("prove: uploading A,B,C failed: %s", up_err.c_str());
-            return up_rc;
-        }
-        GA_HIP_CHECK(hipStreamWaitEvent(ctx->work_stream(), abc.ev, 0));
+    ThreadJoiner joiner{helper};
+    bool did_k = false;
+    const int w_rc = witness_msms<C>(pk, slot, nb_public, sh, o_ar, o_bs1, &k_part, o_bs2, &did_k);
+    if (helper.joinable()) helper.join();
+    if (w_rc != GA_OK) {
+        hipStreamSynchronize(ctx->work_stream());
+        return w_rc;
     }
-    // ---- H (prove.go:134,346-389), then the MSM over pk.G1.Z (prove.go:225-227) ----------------------------
-    GA_CHECK(ntt_domain_compute_h<C>(pk->dom, d_ha, d_hb, d_hc));   // h in d_ha, bit-reversed like pk.G1.Z
-    GA_CHECK(z_msm<C>(pk, (const char*)d_ha + pk->off_z * 32, &krs2));
-    *o_krs = add(krs, krs2);
+    if (h_rc != GA_OK) {
+        set_error("prove (H side): %s", h_err.c_str());
+        return h_rc;
+    }
+    if (!split) {
+        // ---- H (prove.go:134,346-389), then the MSM over pk.G1.Z (prove.go:225-227), on this lane ------------
+        if (!preloaded) GA_HIP_CHECK(hipStreamWaitEvent(ctx->work_stream(), ev[2].ev, 0));
+        GA_CHECK(ntt_domain_compute_h<C>(pk->dom, d_h[0], d_h[1], d_h[2]));   // h in d_h[0], bit-reversed like pk.G1.Z
+        GA_CHECK(z_msm<C>(pk, (const char*)d_h[0] + pk->off_z * 32, &z_part));
+    }
+    if (!did_k && !h_did_k) {
+        set_error("prove: the K MSM was claimed by no lane");
+        return GA_ERR_STATE;
+    }
+    *o_krs = add(did_k ? k_part : k_part_h, z_part);
     return GA_OK;
 }
 
@@ -1469,7 +1648,7 @@ static int prove_multi(G16Pk* const* pks, uint32_t n, const void* w, const void*
                     set_error("hipSetDevice(%d) failed", ctx->device);
                     return hfail("multi-device prove (H side)");
                 }
-                std::lock_guard<std::mutex> l1(ctx->lane_mu);
+                std::lock_guard<std::mutex> l1(ctx->lane_mu[1]);
                 LaneScope lane(1);
                 hipStream_t st = ctx->work_stream();
                 bool hok = true;
@@ -1513,9 +1692,14 @@ static int prove_multi(G16Pk* const* pks, uint32_t n, const void* w, const void*
             });
         }
         ThreadJoiner joiner{helper};
-        if (ok && witness_msms<C>(pk, slot, nb_public, &parts[t].ar, &parts[t].bs1, &parts[t].k, &parts[t].bs2) != GA_OK) {
-            bail("multi-device prove: witness MSMs");
-            ok = false;
+        if (ok) {
+            WitnessShared wsh;
+            bool did_k = false;
+            if (hipEventCreateWithFlags(&wsh.w_ev, hipEventDisableTiming) != hipSuccess ||
+                witness_msms<C>(pk, slot, nb_public, wsh, &parts[t].ar, &parts[t].bs1, &parts[t].k, &parts[t].bs2, &did_k) != GA_OK) {
+                bail("multi-device prove: witness MSMs");
+                ok = false;
+            }
         }
         if (helper.joinable()) helper.join();
         if (h_rc != GA_OK) {
@@ -1696,8 +1880,13 @@ void ga_g16_builder_destroy(ga_g16_builder* b) {
 void ga_g16_pk_destroy(ga_g16_pk* p) {
     G16Pk* pk = reinterpret_cast<G16Pk*>(p);
     if (!pk) return;
+    {   // wait for every entry point still working on this key (provers on other lanes, epilogues outside the device lock)
+        std::unique_lock<std::mutex> u(pk->use_mu);
+        pk->dying = true;
+        pk->use_cv.wait(u, [&] { return pk->users == 0; });
+    }
     CtxLock g(pk->ctx);
-    hipStreamSynchronize(pk->ctx->stream);
+    for (int l = 0; l < GA_NUM_LANES; l++) hipStreamSynchronize(pk->ctx->lane_stream[l]);
     pk_free(pk);
 }
 
@@ -1708,33 +1897,37 @@ int ga_g16_prove(ga_g16_pk* p, const void* w, const void* a, const void* b, cons
         set_error("ga_g16_prove: null argument");
         return GA_ERR_INVALID;
     }
+    GA_PK_USE(pk, "ga_g16_prove");
     if (pk->shard_count != 1 || pk->win_count != 1) {
         set_error("ga_g16_prove: this key holds one share of a sharded key (base range %u/%u, windows %u/%u); use ga_g16_prove_multi or "
                   "ga_g16_prove_partial + ga_g16_finish", pk->shard_index, pk->shard_count, pk->win_index, pk->win_count);
         return GA_ERR_STATE;
     }
     // Two callers may be inside at once (two goroutines proving on one device).  The first holds the device lock and works on
-    // lane 0 (the context's main stream).  The second finds the device busy and computes its proof on lane 1 -- own stream, own
-    // scratch namespace -- so the two proofs run CONCURRENTLY: uploads hide behind the other proof's kernels and the kernels
-    // interleave (sorts / transforms / reduction tails of one proof fill the other's bucket kernel).  When lane 1 is taken as
-    // well (the device lock was held by some other entry point), or while the profiler records stages, the caller stages its
-    // solution in its input slot and queues for the device as before.  The host epilogue always runs outside the device lock.
+    // lanes 0/1 (witness MSMs / H side, prove_partial).  The second finds the device busy and computes its proof on lanes 2/3 --
+    // own streams, own scratch namespaces -- so the two proofs run CONCURRENTLY: uploads hide behind the other proof's kernels
+    // and the kernels interleave.  When lane 2 is taken as well, or while the profiler records stages, or with GA_G16_LANES=1,
+    // the caller stages its solution in its input slot and queues for the device.  The host epilogue always runs outside the
+    // device lock.  ga_g16_lane_stats reports how the calls of a context were scheduled.
     Ctx* ctx = pk->ctx;
     SlotLease slot(ctx);
     bool preloaded = false;
     int lane = 0;
     std::unique_lock<std::mutex> dev(ctx->mu, std::try_to_lock);
-    std::unique_lock<std::mutex> lane1(ctx->lane_mu, std::defer_lock);
+    std::unique_lock<std::mutex> lane2(ctx->lane_mu[2], std::defer_lock);
     hipSetDevice(ctx->device);
     if (!dev.owns_lock()) {
-        if (!ctx->profiling && ctx->tun.g16_lanes > 1 && lane1.try_lock()) {
-            lane = 1;
+        if (!ctx->profiling && ctx->tun.g16_lanes > 1 && lane2.try_lock()) {
+            lane = 2;
+            ctx->stat_lane2++;
         } else {
             GA_CHECK(preload_solution(pk, slot, w, a, b, c, n_constraints, nb_public));
             preloaded = true;
             dev.lock();
+            ctx->stat_queued++;
         }
     }
+    if (lane == 0 && !preloaded) ctx->stat_lane0++;
     LaneScope on_lane(lane);
     if (lane == 0) ctx->tun.read_env();
     GA_DISPATCH_CURVE(pk->curve, {
@@ -1743,9 +1936,32 @@ int ga_g16_prove(ga_g16_pk* p, const void* w, const void* a, const void* b, cons
         GA_CHECK(prove_partial<C>(pk, slot, preloaded, w, a, b, c, n_constraints, nb_public, &ar, &bs1, &krs, &bs2));
         const bool profiling = ctx->profiling;
         if (lane == 0 && !profiling) dev.unlock();   // the stage list of the profiler is guarded by the device lock
-        if (lane == 1) lane1.unlock();
+        if (lane == 2) lane2.unlock();
         return finish<C>(pk, ar, bs1, krs, bs2, r, s, proof_out);
     });
+    return GA_OK;
+}
+
+// out[0..3] = ga_g16_prove calls of this context that ran on lanes 0/1, on lanes 2/3 beside another proof, that staged their
+// inputs and queued for the device, and proofs whose H side ran on a partner lane (any entry point); out[4..5] = device bytes
+// of scratch held by lanes 0/1 and by lanes 2/3
+int ga_g16_lane_stats(ga_ctx* h, uint64_t* out6) {
+    Ctx* ctx = reinterpret_cast<Ctx*>(h);
+    if (!ctx || !out6) {
+        set_error("ga_g16_lane_stats: null argument");
+        return GA_ERR_INVALID;
+    }
+    out6[0] = ctx->stat_lane0;
+    out6[1] = ctx->stat_lane2;
+    out6[2] = ctx->stat_queued;
+    out6[3] = ctx->stat_split;
+    out6[4] = out6[5] = 0;
+    std::lock_guard<std::mutex> g(ctx->scratch_mu);
+    for (const auto& kv : ctx->scratch) {
+        const size_t at = kv.first.rfind('@');
+        const int lane = at == std::string::npos ? 0 : atoi(kv.first.c_str() + at + 1);
+        out6[lane < 2 ? 4 : 5] += kv.second.second;
+    }
     return GA_OK;
 }
 
@@ -1756,6 +1972,7 @@ int ga_g16_prove_partial(ga_g16_pk* p, const void* w, const void* a, const void*
         set_error("ga_g16_prove_partial: null argument");
         return GA_ERR_INVALID;
     }
+    GA_PK_USE(pk, "ga_g16_prove_partial");
     SlotLease slot(pk->ctx);   // always slot first, device lock second (ga_g16_prove's order)
     CtxLock g(pk->ctx);
     GA_DISPATCH_CURVE(pk->curve, {
@@ -1779,6 +1996,7 @@ int ga_g16_finish(ga_g16_pk* p, const void* partials_sum, const void* r, const v
         set_error("ga_g16_finish: null argument");
         return GA_ERR_INVALID;
     }
+    GA_PK_USE(pk, "ga_g16_finish");
     GA_DISPATCH_CURVE(pk->curve, {
         typedef Fe<typename C::FpP> F1;
         typedef Fe2<typename C::FpP> F2;
@@ -1814,6 +2032,7 @@ int ga_g16_witness_partial(ga_g16_pk* p, const void* w, uint64_t nb_public, void
         set_error("ga_g16_witness_partial: null argument");
         return GA_ERR_INVALID;
     }
+    GA_PK_USE(pk, "ga_g16_witness_partial");
     SlotLease slot(pk->ctx);
     CtxLock g(pk->ctx);
     GA_DISPATCH_CURVE(pk->curve, {
@@ -1822,7 +2041,10 @@ int ga_g16_witness_partial(ga_g16_pk* p, const void* w, uint64_t nb_public, void
         XYZZ<F1> ar, bs1, krs;
         XYZZ<F2> bs2;
         GA_CHECK(witness_upload(pk, slot, w, nb_public));
-        GA_CHECK(witness_msms<C>(pk, slot, nb_public, &ar, &bs1, &krs, &bs2));
+        WitnessShared sh;
+        GA_HIP_CHECK(hipEventCreateWithFlags(&sh.w_ev, hipEventDisableTiming));
+        bool did_k = false;
+        GA_CHECK(witness_msms<C>(pk, slot, nb_public, sh, &ar, &bs1, &krs, &bs2, &did_k));
         char* o = reinterpret_cast<char*>(partials_out);
         host_store_jac<F1>(o, ar);
         host_store_jac<F1>(o + sizeof(Jac<F1>), bs1);
@@ -1838,6 +2060,7 @@ int ga_g16_h_chain(ga_g16_pk* p, const void* v, uint64_t n_constraints, void* ou
         set_error("ga_g16_h_chain: null argument");
         return GA_ERR_INVALID;
     }
+    GA_PK_USE(pk, "ga_g16_h_chain");
     LaneLock g(pk->ctx);   // beside the witness MSMs of the same shard when the caller runs them from another thread
     GA_CHECK(h_upload(pk, v, n_constraints, out_dev, pk->ctx->work_stream()));
     GA_DISPATCH_CURVE(pk->curve, GA_CHECK(ntt_domain_h_chain<C>(pk->dom, out_dev)));
@@ -1851,6 +2074,7 @@ int ga_g16_h_chain_dev(ga_g16_pk* p, void* buf_dev, uint64_t n_constraints) {
         set_error("ga_g16_h_chain_dev: null argument");
         return GA_ERR_INVALID;
     }
+    GA_PK_USE(pk, "ga_g16_h_chain_dev");
     if (n_constraints > pk->n) {
         set_error("ga_g16_h_chain_dev: %llu constraints exceed the domain cardinality %llu", (unsigned long long)n_constraints,
                   (unsigned long long)pk->n);
@@ -1871,6 +2095,7 @@ int ga_g16_h_combine(ga_g16_pk* p, void* a_dev, const void* b_dev, const void* c
         set_error("ga_g16_h_combine: null argument");
         return GA_ERR_INVALID;
     }
+    GA_PK_USE(pk, "ga_g16_h_combine");
     LaneLock g(pk->ctx);
     GA_DISPATCH_CURVE(pk->curve, GA_CHECK(ntt_domain_h_combine<C>(pk->dom, a_dev, b_dev, c_dev)));
     GA_HIP_CHECK(hipStreamSynchronize(pk->ctx->work_stream()));
@@ -1883,6 +2108,7 @@ int ga_g16_z_partial(ga_g16_pk* p, const void* h_slice_dev, void* partial_out) {
         set_error("ga_g16_z_partial: null argument");
         return GA_ERR_INVALID;
     }
+    GA_PK_USE(pk, "ga_g16_z_partial");
     CtxLock g(pk->ctx);
     GA_DISPATCH_CURVE(pk->curve, {
         typedef Fe<typename C::FpP> F1;
@@ -1915,6 +2141,19 @@ int ga_g16_prove_multi(ga_g16_pk* const* keys, uint32_t n, const void* w, const 
             }
     }
     if (n == 1) return ga_g16_prove(keys[0], w, a, b, c, n_constraints, nb_public, r, s, proof_out);
+    std::vector<std::unique_ptr<PkUse>> uses;
+    for (uint32_t t = 0; t < n; t++) {
+        uses.emplace_back(new PkUse(pks[t]));
+        if (!uses.back()->ok) {
+            set_error("ga_g16_prove_multi: keys[%u] is being destroyed", t);
+            return GA_ERR_STATE;
+        }
+    }
+    // One multi-device proof at a time per process: every worker thread holds its device's lock while it waits for the others at
+    // the barriers, so two calls over the same devices could each hold one lock the other needs (A holds dev0 and waits for its
+    // worker on dev1, B holds dev1 and waits for its worker on dev0).  A sharded proof occupies all its devices anyway.
+    static std::mutex multi_mu;
+    std::lock_guard<std::mutex> multi_guard(multi_mu);
     for (uint32_t t = 0; t < n; t++)   // peer access both ways between device 0 and the others (errors = already enabled / same device)
         for (uint32_t q = 0; q < n; q++)
             if (q != t && (t == 0 || q == 0) && pks[t]->ctx->device != pks[q]->ctx->device) {
@@ -2078,6 +2317,7 @@ int ga_g16_commit(ga_g16_pk* p, uint32_t index, const void* values, uint64_t n_v
         set_error("ga_g16_commit: null argument");
         return GA_ERR_INVALID;
     }
+    GA_PK_USE(pk, "ga_g16_commit");
     CtxLock g(pk->ctx);
     GA_DISPATCH_CURVE(pk->curve, return commit<C>(pk, index, values, n_values, commitment_out, pok_out));
     return GA_OK;

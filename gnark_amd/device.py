@@ -82,6 +82,13 @@ class Context:
     def sync(self):
         self.lib.check(self.lib.ga_sync(self.handle))
 
+    def lane_stats(self):
+        """how this context's ga_g16_prove calls were scheduled (ga_g16_lane_stats)"""
+        out = (C.c_uint64 * 6)()
+        self.lib.check(self.lib.ga_g16_lane_stats(self.handle, out))
+        keys = ("lanes01_proofs", "lanes23_proofs", "queued_proofs", "split_proofs", "lanes01_scratch_bytes", "lanes23_scratch_bytes")
+        return dict(zip(keys, (int(v) for v in out)))
+
     # profiling (ICICLE_STEP_PROFILE analogue)
     def profile(self, on: bool):
         self.lib.check(self.lib.ga_profile_enable(self.handle, 1 if on else 0))

@@ -17,10 +17,15 @@
  *    calling thread.  There is NO CPU fallback: without a usable HIP device ga_ctx_create fails.
  *  - Any host thread may call any entry point on any context at any time; results never depend on the interleaving
  *    (icicle.go:77-86,821-823 keeps a per-device prove mutex for the same guarantee).  Calls on one ga_ctx are serialised by an
- *    internal mutex, with one exception that only adds throughput: a context has two lanes (stream + scratch), and a second
- *    ga_g16_prove, ga_msm_table_run* (the PLONK prover commits from several goroutines) or ga_g16_h_chain* / ga_g16_h_combine (the
- *    pieces of a sharded proof) arriving while the first lane is busy runs on the second lane beside it (GA_G16_LANES=1 restores
- *    strict queueing).
+ *    internal mutex, with exceptions that only add throughput: a context has four lanes (stream + scratch namespace each).
+ *    A Groth16 proof runs on a pair of them -- the witness MSMs on one, its H side (computeH, the Z MSM) on the partner lane
+ *    from a helper thread (GA_G16_SPLIT=0 keeps one lane) --, a second ga_g16_prove arriving while the first pair is busy runs
+ *    on the second pair beside it, and a second ga_msm_table_run* (the PLONK prover commits from several goroutines) or
+ *    ga_g16_h_chain* / ga_g16_h_combine (the pieces of a sharded proof) takes lane 1 (GA_G16_LANES=1 restores strict queueing).
+ *    ga_g16_lane_stats says how the proofs of a context were scheduled.
+ *  - Destroying an object while other threads are still inside entry points that use it is safe for proving keys:
+ *    ga_g16_pk_destroy waits for them (a Go `defer pk.FreeGPUResources()` beside another goroutine's Prove); every other
+ *    destroy call must come after the last use, as with any C object.
  */
 #ifndef GNARK_AMD_H
 #define GNARK_AMD_H
@@ -244,7 +249,11 @@ typedef struct ga_g16_key {
 } ga_g16_key;
 
 int ga_g16_pk_create(ga_ctx* ctx, const ga_g16_key* key, ga_g16_pk** out);
-void ga_g16_pk_destroy(ga_g16_pk* pk);   /* FreeGPUResources, icicle.go:1493-1549 */
+void ga_g16_pk_destroy(ga_g16_pk* pk);   /* FreeGPUResources, icicle.go:1493-1549; waits for entry points still using the key */
+/* How the ga_g16_prove calls of a context were scheduled since it was created: out6[0] on lanes 0/1 (device free), [1] on lanes
+ * 2/3 beside another proof, [2] staged + queued for the device, [3] proofs whose H side ran on a partner lane; [4], [5] = bytes of
+ * device scratch held by lanes 0/1 and by lanes 2/3. */
+int ga_g16_lane_stats(ga_ctx* ctx, uint64_t* out6);
 
 /* The same key, staged vector by vector (replaces loadG1 / loadG1Raw / loadG2, icicle.go:319-359, one call per host slice).
  * Every call takes ONE flat pointer to pointer-free memory and has copied what it needs when it returns, so a cgo caller never

@@ -903,15 +903,54 @@ def test_emu_groth16_two_callers_distinct_solutions(emu_ctx, c, precompute, logn
                 if not np.array_equal(dom.FFT(fft_in, fft.DIF), fft_want):
                     bad.append(("fft",))
 
+        before = emu_ctx.lane_stats()
         th = [threading.Thread(target=prover, args=(t,)) for t in range(3)] + [threading.Thread(target=transformer)]
         for t in th:
             t.start()
         for t in th:
             t.join()
         assert not bad, bad
+        after = emu_ctx.lane_stats()
+        ran = sum(after[k] - before[k] for k in ("lanes01_proofs", "lanes23_proofs", "queued_proofs"))
+        assert ran == 3 * rounds, (before, after)                        # every call is counted exactly once
+        assert after["lanes23_scratch_bytes"] >= 0 and after["lanes01_scratch_bytes"] > 0
     finally:
         dom.close()
         pk.FreeGPUResources()
+
+
+@pytest.mark.parametrize("c,precompute", [(BN254, 1), (BLS12_381, -1)], ids=["bn254-tables", "bls12-381-no-tables"])
+def test_emu_groth16_split_schedule_and_late_free(emu_ctx, c, precompute, monkeypatch, logn=7):
+    """A proof's H side (computeH, Z MSM, possibly K) runs on the partner lane from a helper thread (prove_partial): the proof must
+    equal the single-lane one (GA_G16_SPLIT=0), and ga_g16_lane_stats must say the split happened.
+    Then FreeGPUResources from one thread while another is still proving on the key: the destroy waits (use-after-free)."""
+    import threading
+    from gnark_amd import synth
+    inst = synth.make_instance(emu_ctx, c.name, logn, 0x5350, nb_constraints=(1 << logn) - 1)
+    pk = inst.proving_key(emu_ctx, precompute=precompute)
+    s0 = emu_ctx.lane_stats()
+    split = groth16.Prove(pk, inst.solution, inst.nb_public, inst.r, inst.s).raw()
+    s1 = emu_ctx.lane_stats()
+    assert s1["split_proofs"] == s0["split_proofs"] + 1 and s1["lanes01_proofs"] == s0["lanes01_proofs"] + 1
+    monkeypatch.setenv("GA_G16_SPLIT", "0")
+    single = groth16.Prove(pk, inst.solution, inst.nb_public, inst.r, inst.s).raw()
+    assert emu_ctx.lane_stats()["split_proofs"] == s1["split_proofs"]
+    monkeypatch.delenv("GA_G16_SPLIT")
+    assert np.array_equal(split, single)   # (both also equal the known-dlog closed form: test_emu_groth16_known_dlogs_checker)
+    # free while proving: the prover thread is inside ga_g16_prove when the main thread calls ga_g16_pk_destroy
+    out, started = [], threading.Event()
+
+    def prover():
+        started.set()
+        out.append(groth16.Prove(pk, inst.solution, inst.nb_public, inst.r, inst.s).raw())
+
+    t = threading.Thread(target=prover)
+    t.start()
+    started.wait()
+    pk.FreeGPUResources()
+    t.join()
+    # either the proof was already in flight (the destroy waited and the proof is right) or it started after the key died (refused)
+    assert not out or np.array_equal(out[0], split)
 
 
 # ---- one proof over several devices from one process (ga_g16_prove_multi) ------------------------------------------------------
