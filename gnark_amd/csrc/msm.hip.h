@@ -199,18 +199,31 @@ struct Table29 {
     static constexpr int MIN_WAVES = Lazy<F>::FP2 ? 2 : GA_ACC29_MINW;
 };
 
+// GA_ACC_REGS (A/B builds): 1 keeps the G1 accumulator in registers instead of LDS, 2 the Fp2 one as well -- measured in round 3
+// (profiles/README.md): the LDS-resident accumulator stays.
+#ifndef GA_ACC_REGS
+#define GA_ACC_REGS 0
+#endif
 template <class F>
 struct LdsAcc29 {
     typedef typename Lazy<F>::T T;
+    static constexpr bool IN_REGS = GA_ACC_REGS >= (Lazy<F>::FP2 ? 2 : 1);
     uint32_t* base;
+    mutable T regs[IN_REGS ? 4 : 1];
+    __device__ __forceinline__ explicit LdsAcc29(uint32_t* b) : base(b) {}
     static constexpr int NW = Lazy<F>::NW, STRIDE = Table29<F>::THREADS;
     __device__ __forceinline__ T get(int field) const {
+        if constexpr (IN_REGS) return regs[field];
         T r;
 #pragma unroll
         for (int i = 0; i < NW; i++) Lazy<F>::set_word(r, i, base[(field * NW + i) * STRIDE]);
         return r;
     }
     __device__ __forceinline__ void put(int field, const T& v) const {
+        if constexpr (IN_REGS) {
+            regs[field] = v;
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NW; i++) base[(field * NW + i) * STRIDE] = Lazy<F>::word(v, i);
     }
@@ -372,14 +385,14 @@ msm_accumulate29_kernel(const uint32_t* __restrict__ table, const uint32_t* __re
 #ifndef GA_ACC_LDS_PAD
 #define GA_ACC_LDS_PAD 0   // experiment: extra LDS words per workgroup, to lower the number of co-resident workgroups
 #endif
-    __shared__ uint32_t lds[4 * NW * Table29<F>::THREADS + GA_ACC_LDS_PAD];
+    __shared__ uint32_t lds[(LdsAcc29<F>::IN_REGS ? 1 : 4 * NW * Table29<F>::THREADS) + GA_ACC_LDS_PAD];
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= max_tasks) return;
     const uint32_t key = task_key_sorted[t];
     if (key >= seg) return;
     const uint32_t tid = task_perm[t];
     const uint32_t start = task_start[tid];
-    LdsAcc29<F> A{lds + threadIdx.x};
+    LdsAcc29<F> A(lds + (LdsAcc29<F>::IN_REGS ? 0 : threadIdx.x));
     const bool have = accumulate_task29<F, COMPLETE>(A, table, vals, start, start + (seg - key));
     if (!store_task29<F>(A, have, &sums[task_dest[tid]])) redo_list[atomicAdd(redo_count, 1u)] = tid;   // redo it
 }
@@ -396,7 +409,7 @@ msm_accumulate29_retry_kernel(const uint32_t* __restrict__ table, const uint32_t
     constexpr int NW = Lazy<F>::NW;
     __shared__ uint32_t lds[4 * NW * Table29<F>::THREADS];
     const uint32_t nredo = *redo_count;
-    LdsAcc29<F> A{lds + threadIdx.x};
+    LdsAcc29<F> A(lds + threadIdx.x);
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nredo; r += gridDim.x * blockDim.x) {
         const uint32_t tid = redo_list[r];
         const uint32_t start = task_start[tid];

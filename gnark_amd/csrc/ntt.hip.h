@@ -19,12 +19,20 @@
 #include "common.hip.h"
 #include "field29.hip.h"
 #include <stdlib.h>
+#include <functional>
 
 namespace ga {
 
 constexpr int NTT_LG_TILE = 10;               // 1024 elements = 32 KiB of LDS per workgroup
 constexpr int NTT_THREADS = 256;
 constexpr int NTT_POW_LO_BITS = 12;
+// Twiddle tables hold hat(w^e).  GA_NTT_TW_UNPACKED=1 stores every entry as its nine 29-bit limbs, one per word, in 48 bytes
+// (two 16-byte loads + one word) instead of the packed 32 bytes: the pass kernels then skip the bit-field extraction of three
+// twiddles per quad (~60 of ~1430 instructions) at the price of 1.5x the table (384 MiB per direction at 2^24).
+#ifndef GA_NTT_TW_UNPACKED
+#define GA_NTT_TW_UNPACKED 0
+#endif
+constexpr int NTT_TW_WORDS = GA_NTT_TW_UNPACKED ? 12 : 8;
 
 struct NttScale {
     int mode;                 // 0 none, 1 constant only, 2 power tables (lo*hi), constant folded into lo
@@ -109,6 +117,23 @@ __device__ __forceinline__ F29<FrP> ntt_scale_factor29(const NttScale& sc, uint6
     return f29_mul(a, f29_unpack(load_fe_plain<FrP>(sc.hi + h * 8)));   // hat(a)*hat(b)/R' = hat(a*b)
 }
 
+// hat(w^e) as limbs from the twiddle table
+template <class FrP>
+__device__ __forceinline__ F29<FrP> ntt_twiddle29(const uint32_t* __restrict__ tw, uint64_t e) {
+#if GA_NTT_TW_UNPACKED
+    static_assert(Radix<FrP>::NL == 9, "unpacked twiddle entries hold nine limbs");
+    const uint32_t* p = tw + e * NTT_TW_WORDS;
+    const u32x4 lo = reinterpret_cast<const u32x4*>(p)[0], hi = reinterpret_cast<const u32x4*>(p)[1];
+    F29<FrP> r;
+    r.l[0] = lo.x; r.l[1] = lo.y; r.l[2] = lo.z; r.l[3] = lo.w;
+    r.l[4] = hi.x; r.l[5] = hi.y; r.l[6] = hi.z; r.l[7] = hi.w;
+    r.l[8] = p[8];
+    return r;
+#else
+    return f29_unpack(load_fe_plain<FrP>(tw + e * NTT_TW_WORDS));
+#endif
+}
+
 template <class FrP, bool DIT_>
 __global__ void __launch_bounds__(NTT_THREADS)
 ntt_pass29_kernel(uint32_t* data, const uint32_t* src, const uint32_t* __restrict__ tw, int logn, int lg_tile, int s_lo, int K,
@@ -141,13 +166,13 @@ ntt_pass29_kernel(uint32_t* data, const uint32_t* src, const uint32_t* __restric
             F29<FrP> x = T.get(l0), y = T.get(l1);
             if (DIT_) {
                 // y*w (or y itself when w = 1) brought below 3p; x grows by < 3p per stage: < 33p after 10 stages
-                F29<FrP> m = e != 0 ? f29_mul(y, f29_unpack(load_fe_plain<FrP>(tw + e * 8))) : f29_reduce_3p(y);
+                F29<FrP> m = e != 0 ? f29_mul(y, ntt_twiddle29<FrP>(tw, e)) : f29_reduce_3p(y);
                 T.put(l0, f29_add(x, m));
                 T.put(l1, f29_sub<4>(x, m));
             } else {
                 // inputs < 24p (sums double per stage, reduced every third stage): x - y + 32p < 56p
                 F29<FrP> d = f29_sub<32>(x, y);
-                d = e != 0 ? f29_mul(d, f29_unpack(load_fe_plain<FrP>(tw + e * 8))) : f29_reduce_3p(d);
+                d = e != 0 ? f29_mul(d, ntt_twiddle29<FrP>(tw, e)) : f29_reduce_3p(d);
                 F29<FrP> sum = f29_add(x, y);
                 if (reduce_sum) sum = f29_reduce_3p(sum);
                 T.put(l0, sum);
@@ -171,18 +196,35 @@ ntt_pass29_kernel(uint32_t* data, const uint32_t* src, const uint32_t* __restric
 // barrier per TWO stages, three twiddle loads instead of four (both butterflies of the first stage share theirs; the second
 // stage uses w^e and w^(e + n/4)), and the intermediate values are not carry-normalised: limb-wise sums stay below 2^32 and a
 // 2^31-limb multiplicand still keeps the product columns below 2^64.  An odd stage count ends with one plain radix-2 stage.
+//
+// natural -> bit-reversed ("DIF" in gnark's naming) also runs on COOLEY-TUKEY butterflies (multiply, then add / subtract), not on
+// Gentleman-Sande ones: the butterfly at index bit s of the element at global index i takes the twiddle of its BLOCK,
+//     w^e,  e = bitrev_{logn-1-s}(i >> (s+1)) << s,
+// instead of the twiddle of its position inside the block (the "natural order in, bit-reversed out, twiddles in bit-reversed
+// order" form of the transform, as in Longa-Naehrig's NTT^CT_{no->bo}); same function, same output order.  What it buys here:
+// (i) sums grow by < 3p per stage instead of doubling, so the Barrett steps on the sums and the 32p subtractions of the
+// Gentleman-Sande form disappear (1728 -> ~1450 instructions per radix-4 block); (ii) the twiddle depends on the index bits ABOVE
+// the butterfly, which lanes of a wave mostly share: the three twiddle loads of a quad hit a few addresses per wave instead of 64
+// lines each.  For a quad on bits (s, s+1): E = bitrev_{logn-2-s}(i >> (s+2)) << s, stage s+1 uses w^(2E) for both butterflies,
+// stage s uses w^E and w^(E + n/4) -- the same three-twiddle pattern as the DIT quad, with the roles of the two index bits
+// swapped.  -DGA_NTT_DIF_GS=1 restores the Gentleman-Sande pass (A/B builds, tools/build_variant.sh).
+#ifndef GA_NTT_DIF_GS
+#define GA_NTT_DIF_GS 0
+#endif
 template <class FrP, bool DIT_>
 __global__ void __launch_bounds__(NTT_THREADS)
 ntt_pass29r4_kernel(uint32_t* data, const uint32_t* src, const uint32_t* __restrict__ tw, int logn, int lg_tile, int s_lo, int K,
                     int lc, NttScale pre, NttScale post) {
     static_assert(FrP::N == 8, "Fr is 4x64-bit limbs on both curves");
     typedef F29<FrP> E;
+    constexpr bool CT_NOBO = !DIT_ && !GA_NTT_DIF_GS;   // natural -> bit-reversed on Cooley-Tukey butterflies
+    constexpr bool CT = DIT_ || CT_NOBO;
     __shared__ uint32_t lds[Radix<FrP>::NL << NTT_LG_TILE];
     LdsTile29<FrP> T{lds};
     const uint32_t tile_elems = 1u << lg_tile;
     const uint64_t tile = blockIdx.x;
     const uint32_t tid = threadIdx.x;
-    auto twid = [&](uint64_t e) { return f29_unpack(load_fe_plain<FrP>(tw + e * 8)); };
+    auto twid = [&](uint64_t e) { return ntt_twiddle29<FrP>(tw, e); };
 
     for (uint32_t l = tid; l < tile_elems; l += NTT_THREADS) {
         uint64_t i = ntt_gidx(l, tile, lg_tile, s_lo, K, lc);
@@ -200,14 +242,23 @@ ntt_pass29r4_kernel(uint32_t* data, const uint32_t* src, const uint32_t* __restr
         const int s = s_lo + t;
         for (uint32_t q = tid; q < tile_elems / 4; q += NTT_THREADS) {
             const uint32_t l00 = ((q >> lb) << (lb + 2)) | (q & ((1u << lb) - 1));
-            const uint32_t l01 = l00 | (1u << lb), l10 = l00 | (2u << lb), l11 = l00 | (3u << lb);
+            // (DIT: first stage on bit lb, second on bit lb+1; Cooley-Tukey natural -> bit-reversed: the other way round, which
+            // is the same code with the two middle elements of the quad exchanged)
+            const uint32_t l01 = l00 | ((CT_NOBO ? 2u : 1u) << lb), l10 = l00 | ((CT_NOBO ? 1u : 2u) << lb), l11 = l00 | (3u << lb);
             const uint64_t i0 = ntt_gidx(l00, tile, lg_tile, s_lo, K, lc);
-            const uint64_t x = i0 & ((1ull << s) - 1);
-            const uint64_t e1 = x << (logn - 1 - s);        // stage s: both butterflies of the quad
-            const uint64_t e2 = x << (logn - 2 - s);        // stage s+1: w^e2 for (.0), w^(e2 + n/4) for (.1)
+            uint64_t e1, e2;
+            if (CT_NOBO) {
+                const int L1 = logn - 2 - s;                // index bits above the quad
+                e2 = L1 > 0 ? (bitrev64(i0 >> (s + 2), L1) << s) : 0;   // stage s (second): w^e2 for block 2u, w^(e2 + n/4) for block 2u+1
+                e1 = e2 << 1;                               // stage s+1 (first): both butterflies of the quad
+            } else {
+                const uint64_t x = i0 & ((1ull << s) - 1);
+                e1 = x << (logn - 1 - s);                   // stage s: both butterflies of the quad
+                e2 = x << (logn - 2 - s);                   // stage s+1: w^e2 for (.0), w^(e2 + n/4) for (.1)
+            }
             const uint64_t e3 = e2 + (1ull << (logn - 2));
             E a00 = T.get(l00), a01 = T.get(l01), a10 = T.get(l10), a11 = T.get(l11);
-            if (DIT_) {
+            if (CT) {
                 // stage s: (a00, a01) and (a10, a11); products (or, for w = 1, the operand itself) are brought below 3p
                 E m0, m1;
                 if (e1 != 0) {
@@ -291,9 +342,15 @@ ntt_pass29r4_kernel(uint32_t* data, const uint32_t* src, const uint32_t* __restr
             uint32_t l0 = ((q >> lb) << (lb + 1)) | (q & ((1u << lb) - 1));
             uint32_t l1 = l0 | (1u << lb);
             uint64_t i0 = ntt_gidx(l0, tile, lg_tile, s_lo, K, lc);
-            uint64_t e = (i0 & ((1ull << s) - 1)) << (logn - 1 - s);
+            uint64_t e;
+            if (CT_NOBO) {
+                const int L = logn - 1 - s;
+                e = L > 0 ? (bitrev64(i0 >> (s + 1), L) << s) : 0;
+            } else {
+                e = (i0 & ((1ull << s) - 1)) << (logn - 1 - s);
+            }
             E x = T.get(l0), y = T.get(l1);
-            if (DIT_) {
+            if (CT) {
                 E m = e != 0 ? f29_mul(y, twid(e)) : f29_reduce_3p(y);
                 T.put(l0, f29_add(x, m));
                 T.put(l1, f29_sub<4>(x, m));
@@ -327,7 +384,14 @@ __global__ void ntt_twiddle_kernel(uint32_t* __restrict__ out, const uint32_t* _
     for (int k = 0; k < nbits; k++)
         if ((e >> k) & 1) r = mul(r, load_fe<FrP>(pow2 + k * 8));
     if (hat) r = f29_hat_packed(r);   // tables for the lazy kernels hold w * 2^261
-    store_fe(out + e * 8, r);
+#if GA_NTT_TW_UNPACKED
+    if (hat) {
+        const F29<FrP> u = f29_unpack(r);
+        for (int i = 0; i < 12; i++) out[e * NTT_TW_WORDS + i] = i < Radix<FrP>::NL ? u.l[i] : 0u;
+        return;
+    }
+#endif
+    store_fe(out + e * NTT_TW_WORDS, r);
 }
 
 // a[i] = (a[i]*b[i] - c[i]) * den      (prove.go:377-383)
@@ -364,23 +428,74 @@ struct Domain {
     std::vector<NttPass> passes;    // ascending stage order
 };
 
+// Passes of a size-2^logn transform, ascending stage order.  The first pass owns the contiguous low stages (up to a whole tile),
+// every further pass K strided stages over rows of 2^lc contiguous elements, lc = min(3, NTT_LG_TILE - K) (256-byte rows, 128-byte
+// ones for K = 8).  Among the splits with the fewest passes the one with the fewest ODD stage counts wins (an odd count ends
+// with a radix-2 round: a whole LDS round trip and barrier for one stage), then the most balanced one, then the larger first pass.
+// GA_NTT_PLAN="8,8,8" (read when a domain is created) forces a split -- experiments only.
 inline std::vector<NttPass> ntt_plan(int logn) {
     std::vector<NttPass> v;
     if (logn == 0) return v;
-    int k0 = logn < NTT_LG_TILE ? logn : NTT_LG_TILE;
-    v.push_back({0, k0, 0});
-    int rem = logn - k0;
-    if (rem == 0) return v;
-    const int LC = 3;                       // 8 contiguous elements = 256 B per strided row
-    const int KUP = NTT_LG_TILE - LC;
-    int np = (rem + KUP - 1) / KUP;
-    int s = k0;
-    for (int p = 0; p < np; p++) {
-        int K = rem / np + (p < rem % np ? 1 : 0);
-        v.push_back({s, K, LC});
-        s += K;
+    const int K0MAX = NTT_LG_TILE, LCMAX = 3, KUP = NTT_LG_TILE - 2;   // upper passes: K <= 8
+    auto make = [&](const std::vector<int>& ks) {
+        std::vector<NttPass> out;
+        int s = 0;
+        for (size_t p = 0; p < ks.size(); p++) {
+            int lc = 0;
+            if (p > 0) lc = NTT_LG_TILE - ks[p] < LCMAX ? NTT_LG_TILE - ks[p] : LCMAX;
+            out.push_back({s, ks[p], lc});
+            s += ks[p];
+        }
+        return out;
+    };
+    if (const char* e = getenv("GA_NTT_PLAN")) {
+        std::vector<int> ks;
+        int sum = 0;
+        bool ok = true;
+        for (const char* q = e; *q;) {
+            char* end = nullptr;
+            long k = strtol(q, &end, 10);
+            if (end == q) break;
+            ok = ok && k >= 1 && k <= (ks.empty() ? K0MAX : KUP);
+            ks.push_back((int)k);
+            sum += (int)k;
+            q = *end == ',' ? end + 1 : end;
+        }
+        if (ok && sum == logn && !ks.empty()) return make(ks);
     }
-    return v;
+    if (logn <= K0MAX) return make({logn});
+#ifndef GA_NTT_KUP
+#define GA_NTT_KUP 7   // largest stage count of an upper pass in the default plan (8 = 128-byte rows)
+#endif
+    const int kup = GA_NTT_KUP;
+    const int np = 1 + (logn - K0MAX + kup - 1) / kup;
+    std::vector<int> best, cur(np, 0);
+    int best_odd = 1 << 30, best_min = 0;
+    // enumerate k[0] <= K0MAX, k[p] <= kup, sum = logn (np <= 5 for every supported size)
+    std::function<void(int, int)> rec = [&](int p, int left) {
+        if (p == np - 1) {
+            if (left < 1 || left > kup) return;
+            cur[p] = left;
+            int odd = 0, mn = 1 << 30;
+            for (int k : cur) {
+                odd += k & 1;
+                mn = k < mn ? k : mn;
+            }
+            if (odd < best_odd || (odd == best_odd && (mn > best_min || (mn == best_min && cur[0] > best[0])))) {
+                best_odd = odd;
+                best_min = mn;
+                best = cur;
+            }
+            return;
+        }
+        const int cap = p == 0 ? K0MAX : kup;
+        for (int k = 1; k <= cap && k < left; k++) {
+            cur[p] = k;
+            rec(p + 1, left - k);
+        }
+    };
+    rec(0, logn);
+    return make(best);
 }
 
 template <class FrP>
@@ -544,8 +659,8 @@ int domain_init(Ctx* ctx, Domain* d, int curve, uint64_t n) {
         GA_HIP_CHECK(hipMalloc(&tmp_p2.p, p2.size() * 4));
         void* const d_p2 = tmp_p2.p;
         GA_HIP_CHECK(hipMemcpy(d_p2, p2.data(), p2.size() * 4, hipMemcpyHostToDevice));
-        GA_HIP_CHECK(hipMalloc((void**)&d->d_tw, half_n * 32));
-        GA_HIP_CHECK(hipMalloc((void**)&d->d_tw_inv, half_n * 32));
+        GA_HIP_CHECK(hipMalloc((void**)&d->d_tw, half_n * NTT_TW_WORDS * 4));
+        GA_HIP_CHECK(hipMalloc((void**)&d->d_tw_inv, half_n * NTT_TW_WORDS * 4));
         unsigned blocks = (unsigned)((half_n + 255) / 256);
         hipLaunchKernelGGL((ntt_twiddle_kernel<FrP>), dim3(blocks), dim3(256), 0, ctx->work_stream(), d->d_tw,
                            (const uint32_t*)d_p2, half_n, nb, d->lazy ? 1 : 0);

@@ -1,11 +1,25 @@
 #!/bin/bash
 # Build an A/B variant of the library with extra compile-time knobs, next to the shipped one:
 #   tools/build_variant.sh pad3 -DGA_ACC_LDS_PAD=3072
-# -> gnark_amd/variants/libgnark_amd_pad3.so (git-ignored; it travels to the GPU box with gpurun), used with
+#   tools/build_variant.sh --only "ntt_bn254 ntt_bls12381 ntt_domain plonk_bn254 plonk_bls12381" twu -DGA_NTT_TW_UNPACKED=1
+# -> gnark_amd/variants/libgnark_amd_<name>.so (git-ignored; it travels to the GPU box with gpurun), used with
 #   GA_LIB_PATH=$PWD/gnark_amd/variants/libgnark_amd_pad3.so python bench.py --no-cpu-baseline --no-check
+# --only: the knob touches just these translation units; every other object is taken from the shipped build (gnark_amd/csrc/build,
+# which must be up to date) instead of being recompiled.
 set -e
+only=""
+if [ "$1" = "--only" ]; then only="$2"; shift 2; fi
 name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p "$root/gnark_amd/variants"
-make -C "$root/gnark_amd/csrc" -j16 BUILD=build_$name TARGET=../variants/libgnark_amd_$name.so EXTRA="$*"
+bdir="$root/gnark_amd/csrc/build_$name"
+if [ -n "$only" ]; then
+  make -C "$root/gnark_amd/csrc" -j8 >/dev/null
+  mkdir -p "$bdir"
+  cp -p "$root"/gnark_amd/csrc/build/*.o "$root"/gnark_amd/csrc/build/*.d "$bdir"/
+  sed -i "s#^build/#build_$name/#" "$bdir"/*.d
+  touch "$bdir"/*.o          # (an object is older than its freshly edited .d file otherwise, and make would rebuild it)
+  for u in $only; do rm -f "$bdir/$u.o"; done
+fi
+make -C "$root/gnark_amd/csrc" -j8 BUILD=build_$name TARGET=../variants/libgnark_amd_$name.so EXTRA="$*"
 echo "$root/gnark_amd/variants/libgnark_amd_$name.so"
