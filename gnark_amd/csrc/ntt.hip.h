@@ -26,13 +26,6 @@ namespace ga {
 constexpr int NTT_LG_TILE = 10;               // 1024 elements = 32 KiB of LDS per workgroup
 constexpr int NTT_THREADS = 256;
 constexpr int NTT_POW_LO_BITS = 12;
-// Twiddle tables hold hat(w^e).  GA_NTT_TW_UNPACKED=1 stores every entry as its nine 29-bit limbs, one per word, in 48 bytes
-// (two 16-byte loads + one word) instead of the packed 32 bytes: the pass kernels then skip the bit-field extraction of three
-// twiddles per quad (~60 of ~1430 instructions) at the price of 1.5x the table (384 MiB per direction at 2^24).
-#ifndef GA_NTT_TW_UNPACKED
-#define GA_NTT_TW_UNPACKED 0
-#endif
-constexpr int NTT_TW_WORDS = GA_NTT_TW_UNPACKED ? 12 : 8;
 
 struct NttScale {
     int mode;                 // 0 none, 1 constant only, 2 power tables (lo*hi), constant folded into lo
@@ -81,24 +74,56 @@ __device__ __forceinline__ Fe<FrP> ntt_scale_factor(const NttScale& sc, uint64_t
 }
 
 // ---- one pass over stages [s_lo, s_lo+K) in the lazy unpacked representation (field29.hip.h) ----------------------------------
-// DIT_ = false: DIF butterflies, stages descending; true: DIT, ascending.
 // Elements stay in gnark's Montgomery form x*2^256 but as 9 limbs of 29 bits, unreduced; twiddles and scale factors are
 // tables of hat(w) = w*2^261, so  f29_mul(v, hat(w)) = v*w  is again in gnark's form -- no domain change at load/store.
-// Butterfly sums double per DIF stage and are Barrett-reduced to < 3p every third stage (subtractions add 32p); DIT adds a
-// fresh (< 3p) product per stage and needs no reduction inside a pass.  Results are made canonical once, at the store.
+// BOTH directions run on Cooley-Tukey butterflies (multiply, then add / subtract): a butterfly adds a fresh product (< 3p) to
+// its partner, so values grow by < 3p per stage (< 33p after 10 stages) and need no reduction inside a pass; results are made
+// canonical once, at the store.
+//   * bit-reversed -> natural (gnark's DIT): the classic form, stages ascending, the butterfly at index bit s of element i takes
+//     w^(x << (logn-1-s)), x = i mod 2^s -- its POSITION inside the block;
+//   * natural -> bit-reversed (gnark's DIF): stages descending, the butterfly takes the twiddle of its BLOCK,
+//     w^(bitrev_{logn-1-s}(i >> (s+1)) << s) (the "natural in, bit-reversed out, twiddles in bit-reversed order" form, as in
+//     Longa-Naehrig's NTT^CT_{no->bo}) -- same function and output order as the Gentleman-Sande form round 2 used, without its
+//     doubling sums (Barrett steps, 32p subtractions: 1728 -> 1434 instructions per radix-4 block).
+// Twiddle tables are laid out so that BOTH forms read them densely (round 3; with one natural-order table w^e the
+// twiddle-heavy stages of either form gathered 32-byte entries from distinct cache lines and the passes ran 25-30 % below
+// their arithmetic, profiles/README.md):
+//   TS ("stacked", n entries):      TS[2^s + x] = w^(x << (logn-1-s)), x < 2^s      -- DIT, stage s reads a contiguous block
+//   TB ("bit-reversed", n/2):       TB[j] = w^bitrev_{logn-1}(j)                      -- natural -> bit-reversed: stage s reads the
+//                                    prefix j < 2^(logn-1-s), block number = index
+// For a quad on index bits (s, s+1) the three twiddles are TS[2^s + x], TS[2^(s+1) + x], TS[2^(s+1) + 2^s + x] (DIT) and
+// TB[u], TB[2u], TB[2u+1] with u = i >> (s+2) (natural -> bit-reversed: the last two adjacent, all three shared by every lane
+// with the same upper index bits).
+// LDS tile: [NL][tile] words, one plane per limb.  Unit-stride lanes hit consecutive banks; the quads of the low stages do not (the
+// 32 lanes of a half-wave read slots l00 + {bits of q spread around the two butterfly bits}: for index bits lb < 5 only 8 distinct
+// banks, SQ_LDS_BANK_CONFLICT = 41 % of the LDS cycles in round 2's kernel).  GA_NTT_LDS_SWZ=1 stores slot l at l ^ m(l5, l6) with
+// m = 01010b for bit 5, 10101b for bit 6: a bijection within every aligned block of 128 slots that makes the low five address bits a
+// bijection of the five lowest FREE index bits for every butterfly position lb.
+#ifndef GA_NTT_LDS_SWZ
+#define GA_NTT_LDS_SWZ 0
+#endif
 template <class FrP>
 struct LdsTile29 {
-    uint32_t* base;   // [NL][tile] words: lane-consecutive elements hit consecutive banks
+    uint32_t* base;
     static constexpr int NL = Radix<FrP>::NL, STRIDE = 1 << NTT_LG_TILE;
+    __device__ __forceinline__ static uint32_t slot(uint32_t l) {
+#if GA_NTT_LDS_SWZ
+        return l ^ ((0x1F150A00u >> ((l >> 2) & 0x18u)) & 0x1Fu);
+#else
+        return l;
+#endif
+    }
     __device__ __forceinline__ F29<FrP> get(uint32_t l) const {
         F29<FrP> r;
+        const uint32_t p = slot(l);
 #pragma unroll
-        for (int i = 0; i < NL; i++) r.l[i] = base[i * STRIDE + l];
+        for (int i = 0; i < NL; i++) r.l[i] = base[i * STRIDE + p];
         return r;
     }
     __device__ __forceinline__ void put(uint32_t l, const F29<FrP>& v) const {
+        const uint32_t p = slot(l);
 #pragma unroll
-        for (int i = 0; i < NL; i++) base[i * STRIDE + l] = v.l[i];
+        for (int i = 0; i < NL; i++) base[i * STRIDE + p] = v.l[i];
     }
 };
 
@@ -117,118 +142,41 @@ __device__ __forceinline__ F29<FrP> ntt_scale_factor29(const NttScale& sc, uint6
     return f29_mul(a, f29_unpack(load_fe_plain<FrP>(sc.hi + h * 8)));   // hat(a)*hat(b)/R' = hat(a*b)
 }
 
-// hat(w^e) as limbs from the twiddle table
+// entry k of a twiddle table as limbs (entries are stored unpacked: nine 29-bit limbs in 48 bytes, so that the pass kernels do
+// no bit-field extraction on three twiddles per quad)
+constexpr int NTT_TW_WORDS = 12;
 template <class FrP>
-__device__ __forceinline__ F29<FrP> ntt_twiddle29(const uint32_t* __restrict__ tw, uint64_t e) {
-#if GA_NTT_TW_UNPACKED
-    static_assert(Radix<FrP>::NL == 9, "unpacked twiddle entries hold nine limbs");
-    const uint32_t* p = tw + e * NTT_TW_WORDS;
+__device__ __forceinline__ F29<FrP> ntt_twiddle29(const uint32_t* __restrict__ tw, uint64_t k) {
+    static_assert(Radix<FrP>::NL == 9, "twiddle entries hold nine limbs");
+    const uint32_t* p = tw + k * NTT_TW_WORDS;
     const u32x4 lo = reinterpret_cast<const u32x4*>(p)[0], hi = reinterpret_cast<const u32x4*>(p)[1];
     F29<FrP> r;
     r.l[0] = lo.x; r.l[1] = lo.y; r.l[2] = lo.z; r.l[3] = lo.w;
     r.l[4] = hi.x; r.l[5] = hi.y; r.l[6] = hi.z; r.l[7] = hi.w;
     r.l[8] = p[8];
     return r;
-#else
-    return f29_unpack(load_fe_plain<FrP>(tw + e * NTT_TW_WORDS));
-#endif
 }
 
-template <class FrP, bool DIT_>
-__global__ void __launch_bounds__(NTT_THREADS)
-ntt_pass29_kernel(uint32_t* data, const uint32_t* src, const uint32_t* __restrict__ tw, int logn, int lg_tile, int s_lo, int K,
-                  int lc, NttScale pre, NttScale post) {
-    static_assert(FrP::N == 8, "Fr is 4x64-bit limbs on both curves");
-    __shared__ uint32_t lds[Radix<FrP>::NL << NTT_LG_TILE];
-    LdsTile29<FrP> T{lds};
-    const uint32_t tile_elems = 1u << lg_tile;
-    const uint64_t tile = blockIdx.x;
-    const uint32_t tid = threadIdx.x;
-
-    for (uint32_t l = tid; l < tile_elems; l += NTT_THREADS) {
-        uint64_t i = ntt_gidx(l, tile, lg_tile, s_lo, K, lc);
-        F29<FrP> v = f29_unpack(load_fe<FrP>(src + i * 8));   // src == data for an in-place pass
-        if (pre.mode != 0) v = f29_mul(v, ntt_scale_factor29<FrP>(pre, i, logn));
-        T.put(l, v);
-    }
-    __syncthreads();
-
-    for (int k = 0; k < K; k++) {
-        const int t = DIT_ ? k : (K - 1 - k);
-        const int lb = lc + t;
-        const int s = s_lo + t;
-        const bool reduce_sum = (k % 3) == 2;
-        for (uint32_t q = tid; q < tile_elems / 2; q += NTT_THREADS) {
-            uint32_t l0 = ((q >> lb) << (lb + 1)) | (q & ((1u << lb) - 1));
-            uint32_t l1 = l0 | (1u << lb);
-            uint64_t i0 = ntt_gidx(l0, tile, lg_tile, s_lo, K, lc);
-            uint64_t e = (i0 & ((1ull << s) - 1)) << (logn - 1 - s);
-            F29<FrP> x = T.get(l0), y = T.get(l1);
-            if (DIT_) {
-                // y*w (or y itself when w = 1) brought below 3p; x grows by < 3p per stage: < 33p after 10 stages
-                F29<FrP> m = e != 0 ? f29_mul(y, ntt_twiddle29<FrP>(tw, e)) : f29_reduce_3p(y);
-                T.put(l0, f29_add(x, m));
-                T.put(l1, f29_sub<4>(x, m));
-            } else {
-                // inputs < 24p (sums double per stage, reduced every third stage): x - y + 32p < 56p
-                F29<FrP> d = f29_sub<32>(x, y);
-                d = e != 0 ? f29_mul(d, ntt_twiddle29<FrP>(tw, e)) : f29_reduce_3p(d);
-                F29<FrP> sum = f29_add(x, y);
-                if (reduce_sum) sum = f29_reduce_3p(sum);
-                T.put(l0, sum);
-                T.put(l1, d);
-            }
-        }
-        __syncthreads();
-    }
-
-    for (uint32_t l = tid; l < tile_elems; l += NTT_THREADS) {
-        uint64_t i = ntt_gidx(l, tile, lg_tile, s_lo, K, lc);
-        F29<FrP> v = T.get(l);
-        if (post.mode != 0) v = f29_mul(v, ntt_scale_factor29<FrP>(post, i, logn));
-        store_fe(data + i * 8, f29_pack_canonical(f29_reduce_3p(v)));
-    }
-}
-
-// ---- the lazy pass with two stages per LDS round trip (radix-4 in registers) ------------------------------------------------
-// Same arithmetic, twiddles and bounds as ntt_pass29_kernel, stage for stage; what changes is the bookkeeping: a thread keeps a
-// quad (index bits t and t+1) in registers across two stages, so there is one LDS read + write, one index computation and one
-// barrier per TWO stages, three twiddle loads instead of four (both butterflies of the first stage share theirs; the second
-// stage uses w^e and w^(e + n/4)), and the intermediate values are not carry-normalised: limb-wise sums stay below 2^32 and a
-// 2^31-limb multiplicand still keeps the product columns below 2^64.  An odd stage count ends with one plain radix-2 stage.
-//
-// natural -> bit-reversed ("DIF" in gnark's naming) also runs on COOLEY-TUKEY butterflies (multiply, then add / subtract), not on
-// Gentleman-Sande ones: the butterfly at index bit s of the element at global index i takes the twiddle of its BLOCK,
-//     w^e,  e = bitrev_{logn-1-s}(i >> (s+1)) << s,
-// instead of the twiddle of its position inside the block (the "natural order in, bit-reversed out, twiddles in bit-reversed
-// order" form of the transform, as in Longa-Naehrig's NTT^CT_{no->bo}); same function, same output order.  What it buys here:
-// (i) sums grow by < 3p per stage instead of doubling, so the Barrett steps on the sums and the 32p subtractions of the
-// Gentleman-Sande form disappear (1728 -> ~1450 instructions per radix-4 block); (ii) the twiddle depends on the index bits ABOVE
-// the butterfly, which lanes of a wave mostly share: the three twiddle loads of a quad hit a few addresses per wave instead of 64
-// lines each.  For a quad on bits (s, s+1): E = bitrev_{logn-2-s}(i >> (s+2)) << s, stage s+1 uses w^(2E) for both butterflies,
-// stage s uses w^E and w^(E + n/4) -- the same three-twiddle pattern as the DIT quad, with the roles of the two index bits
-// swapped.  -DGA_NTT_DIF_GS=1 restores the Gentleman-Sande pass (A/B builds, tools/build_variant.sh).
-#ifndef GA_NTT_DIF_GS
-#define GA_NTT_DIF_GS 0
-#endif
+// Two stages per LDS round trip (radix-4 in registers): a thread keeps a quad (index bits t and t+1) in registers across two
+// stages, so there is one LDS read + write, one index computation and one barrier per TWO stages, and the intermediate values are
+// not carry-normalised: limb-wise sums stay below 2^32 and a 2^31-limb multiplicand still keeps the product columns below 2^64.
+// An odd stage count ends with one plain radix-2 stage (ntt_plan avoids odd counts where it can).
 template <class FrP, bool DIT_>
 __global__ void __launch_bounds__(NTT_THREADS)
 ntt_pass29r4_kernel(uint32_t* data, const uint32_t* src, const uint32_t* __restrict__ tw, int logn, int lg_tile, int s_lo, int K,
                     int lc, NttScale pre, NttScale post) {
     static_assert(FrP::N == 8, "Fr is 4x64-bit limbs on both curves");
     typedef F29<FrP> E;
-    constexpr bool CT_NOBO = !DIT_ && !GA_NTT_DIF_GS;   // natural -> bit-reversed on Cooley-Tukey butterflies
-    constexpr bool CT = DIT_ || CT_NOBO;
     __shared__ uint32_t lds[Radix<FrP>::NL << NTT_LG_TILE];
     LdsTile29<FrP> T{lds};
     const uint32_t tile_elems = 1u << lg_tile;
     const uint64_t tile = blockIdx.x;
     const uint32_t tid = threadIdx.x;
-    auto twid = [&](uint64_t e) { return ntt_twiddle29<FrP>(tw, e); };
+    auto twid = [&](uint64_t k) { return ntt_twiddle29<FrP>(tw, k); };
 
     for (uint32_t l = tid; l < tile_elems; l += NTT_THREADS) {
         uint64_t i = ntt_gidx(l, tile, lg_tile, s_lo, K, lc);
-        E v = f29_unpack(load_fe<FrP>(src + i * 8));
+        E v = f29_unpack(load_fe<FrP>(src + i * 8));   // src == data for an in-place pass
         if (pre.mode != 0) v = f29_mul(v, ntt_scale_factor29<FrP>(pre, i, logn));
         T.put(l, v);
     }
@@ -236,132 +184,88 @@ ntt_pass29r4_kernel(uint32_t* data, const uint32_t* src, const uint32_t* __restr
 
     int k = 0;
     for (; k + 1 < K; k += 2) {
-        // stage order: DIT ascending (t, t+1); DIF descending (t+1, t) with t = K-2-k
+        // stage order: DIT ascending (t, t+1); natural -> bit-reversed descending (t+1, t) with t = K-2-k
         const int t = DIT_ ? k : (K - 2 - k);
         const int lb = lc + t;
         const int s = s_lo + t;
         for (uint32_t q = tid; q < tile_elems / 4; q += NTT_THREADS) {
             const uint32_t l00 = ((q >> lb) << (lb + 2)) | (q & ((1u << lb) - 1));
-            // (DIT: first stage on bit lb, second on bit lb+1; Cooley-Tukey natural -> bit-reversed: the other way round, which
-            // is the same code with the two middle elements of the quad exchanged)
-            const uint32_t l01 = l00 | ((CT_NOBO ? 2u : 1u) << lb), l10 = l00 | ((CT_NOBO ? 1u : 2u) << lb), l11 = l00 | (3u << lb);
+            // (DIT: first stage on bit lb, second on bit lb+1; natural -> bit-reversed: the other way round, which is the same
+            // code with the two middle elements of the quad exchanged)
+            const uint32_t l01 = l00 | ((DIT_ ? 1u : 2u) << lb), l10 = l00 | ((DIT_ ? 2u : 1u) << lb), l11 = l00 | (3u << lb);
             const uint64_t i0 = ntt_gidx(l00, tile, lg_tile, s_lo, K, lc);
-            uint64_t e1, e2;
-            if (CT_NOBO) {
-                const int L1 = logn - 2 - s;                // index bits above the quad
-                e2 = L1 > 0 ? (bitrev64(i0 >> (s + 2), L1) << s) : 0;   // stage s (second): w^e2 for block 2u, w^(e2 + n/4) for block 2u+1
-                e1 = e2 << 1;                               // stage s+1 (first): both butterflies of the quad
-            } else {
+            uint64_t k1, k2, k3;      // table entries: first stage (both butterflies), second stage (.0) and (.1)
+            bool unit;                // first-stage twiddle and the (.0) second-stage twiddle are 1
+            if (DIT_) {
                 const uint64_t x = i0 & ((1ull << s) - 1);
-                e1 = x << (logn - 1 - s);                   // stage s: both butterflies of the quad
-                e2 = x << (logn - 2 - s);                   // stage s+1: w^e2 for (.0), w^(e2 + n/4) for (.1)
-            }
-            const uint64_t e3 = e2 + (1ull << (logn - 2));
-            E a00 = T.get(l00), a01 = T.get(l01), a10 = T.get(l10), a11 = T.get(l11);
-            if (CT) {
-                // stage s: (a00, a01) and (a10, a11); products (or, for w = 1, the operand itself) are brought below 3p
-                E m0, m1;
-                if (e1 != 0) {
-                    const E w1 = twid(e1);
-                    m0 = f29_mul(a01, w1);
-                    m1 = f29_mul(a11, w1);
-                } else {
-                    m0 = f29_reduce_3p(a01);
-                    m1 = f29_reduce_3p(a11);
-                }
-                E b00 = f29_add_raw(a00, m0), b01 = f29_sub_raw<4>(a00, m0);
-                E b10 = f29_add_raw(a10, m1), b11 = f29_sub_raw<4>(a10, m1);
-                // stage s+1: (b00, b10) with w^e2, (b01, b11) with w^e3; multiplicand limbs < 2^31
-                E m2;
-                if (e2 != 0) {
-                    m2 = f29_mul(b10, twid(e2));
-                } else {
-                    f29_normalize(b10);
-                    m2 = f29_reduce_3p(b10);
-                }
-                E m3 = f29_mul(b11, twid(e3));
-                E c00 = f29_add_raw(b00, m2), c10 = f29_sub_raw<4>(b00, m2);
-                E c01 = f29_add_raw(b01, m3), c11 = f29_sub_raw<4>(b01, m3);
-                f29_normalize(c00);
-                f29_normalize(c01);
-                f29_normalize(c10);
-                f29_normalize(c11);
-                T.put(l00, c00);
-                T.put(l01, c01);
-                T.put(l10, c10);
-                T.put(l11, c11);
+                k1 = (1ull << s) + x;
+                k2 = (2ull << s) + x;
+                k3 = k2 + (1ull << s);
+                unit = x == 0;
             } else {
-                // stage s+1 (count k): (a00, a10) with w^e2, (a01, a11) with w^e3.  Carry sweeps are deferred wherever the consumer
-                // is a product (a multiplicand may carry limbs below 2^31) or a wide subtraction: differences x - y + 32p have limbs
-                // below 2^29 + 2^30, raw sums below 2^30.
-                E d0 = f29_sub_raw<32>(a00, a10), d1 = f29_sub_raw<32>(a01, a11);
-                if (e2 != 0) {
-                    d0 = f29_mul(d0, twid(e2));
-                } else {
-                    f29_normalize(d0);
-                    d0 = f29_reduce_3p(d0);
-                }
-                d1 = f29_mul(d1, twid(e3));
-                E s0 = f29_add_raw(a00, a10), s1 = f29_add_raw(a01, a11);
-                if ((k % 3) == 2) {
-                    f29_normalize(s0);
-                    f29_normalize(s1);
-                    s0 = f29_reduce_3p(s0);
-                    s1 = f29_reduce_3p(s1);
-                }
-                // stage s (count k+1): (s0, s1) and (d0, d1), both with w^e1
-                E o01 = f29_sub_wide<32, 2>(s0, s1), o11 = f29_sub_raw<32>(d0, d1);
-                if (e1 != 0) {
-                    const E w1 = twid(e1);
-                    o01 = f29_mul(o01, w1);
-                    o11 = f29_mul(o11, w1);
-                } else {
-                    f29_normalize(o11);
-                    o01 = f29_reduce_3p(o01);
-                    o11 = f29_reduce_3p(o11);
-                }
-                E o00 = f29_add(s0, s1), o10 = f29_add(d0, d1);
-                if (((k + 1) % 3) == 2) {
-                    o00 = f29_reduce_3p(o00);
-                    o10 = f29_reduce_3p(o10);
-                }
-                T.put(l00, o00);
-                T.put(l01, o01);
-                T.put(l10, o10);
-                T.put(l11, o11);
+                const uint64_t u = i0 >> (s + 2);
+                k1 = u;
+                k2 = 2 * u;
+                k3 = 2 * u + 1;
+                unit = u == 0;
             }
+            E a00 = T.get(l00), a01 = T.get(l01), a10 = T.get(l10), a11 = T.get(l11);
+            // first stage: (a00, a01) and (a10, a11); products (or, for w = 1, the operand itself) are brought below 3p
+            E m0, m1;
+            if (!unit) {
+                const E w1 = twid(k1);
+                m0 = f29_mul(a01, w1);
+                m1 = f29_mul(a11, w1);
+            } else {
+                m0 = f29_reduce_3p(a01);
+                m1 = f29_reduce_3p(a11);
+            }
+            E b00 = f29_add_raw(a00, m0), b01 = f29_sub_raw<4>(a00, m0);
+            E b10 = f29_add_raw(a10, m1), b11 = f29_sub_raw<4>(a10, m1);
+            // second stage: (b00, b10) with twiddle k2, (b01, b11) with twiddle k3; multiplicand limbs < 2^31
+            E m2;
+            if (!unit) {
+                m2 = f29_mul(b10, twid(k2));
+            } else {
+                f29_normalize(b10);
+                m2 = f29_reduce_3p(b10);
+            }
+            E m3 = f29_mul(b11, twid(k3));
+            E c00 = f29_add_raw(b00, m2), c10 = f29_sub_raw<4>(b00, m2);
+            E c01 = f29_add_raw(b01, m3), c11 = f29_sub_raw<4>(b01, m3);
+            f29_normalize(c00);
+            f29_normalize(c01);
+            f29_normalize(c10);
+            f29_normalize(c11);
+            T.put(l00, c00);
+            T.put(l01, c01);
+            T.put(l10, c10);
+            T.put(l11, c11);
         }
         __syncthreads();
     }
-    if (k < K) {   // odd stage count: the last stage as a plain radix-2 stage (DIT: t = K-1, DIF: t = 0)
+    if (k < K) {   // odd stage count: the last stage as a plain radix-2 stage (DIT: t = K-1, natural -> bit-reversed: t = 0)
         const int t = DIT_ ? k : 0;
         const int lb = lc + t;
         const int s = s_lo + t;
-        const bool reduce_sum = (k % 3) == 2;
         for (uint32_t q = tid; q < tile_elems / 2; q += NTT_THREADS) {
             uint32_t l0 = ((q >> lb) << (lb + 1)) | (q & ((1u << lb) - 1));
             uint32_t l1 = l0 | (1u << lb);
             uint64_t i0 = ntt_gidx(l0, tile, lg_tile, s_lo, K, lc);
-            uint64_t e;
-            if (CT_NOBO) {
-                const int L = logn - 1 - s;
-                e = L > 0 ? (bitrev64(i0 >> (s + 1), L) << s) : 0;
+            uint64_t kk;
+            bool unit;
+            if (DIT_) {
+                const uint64_t x = i0 & ((1ull << s) - 1);
+                kk = (1ull << s) + x;
+                unit = x == 0;
             } else {
-                e = (i0 & ((1ull << s) - 1)) << (logn - 1 - s);
+                kk = i0 >> (s + 1);
+                unit = kk == 0;
             }
             E x = T.get(l0), y = T.get(l1);
-            if (CT) {
-                E m = e != 0 ? f29_mul(y, twid(e)) : f29_reduce_3p(y);
-                T.put(l0, f29_add(x, m));
-                T.put(l1, f29_sub<4>(x, m));
-            } else {
-                E d = f29_sub<32>(x, y);
-                d = e != 0 ? f29_mul(d, twid(e)) : f29_reduce_3p(d);
-                E sum = f29_add(x, y);
-                if (reduce_sum) sum = f29_reduce_3p(sum);
-                T.put(l0, sum);
-                T.put(l1, d);
-            }
+            E m = !unit ? f29_mul(y, twid(kk)) : f29_reduce_3p(y);
+            T.put(l0, f29_add(x, m));
+            T.put(l1, f29_sub<4>(x, m));
         }
         __syncthreads();
     }
@@ -374,24 +278,27 @@ ntt_pass29r4_kernel(uint32_t* data, const uint32_t* src, const uint32_t* __restr
     }
 }
 
-// tw[e] = w^e for e < count, from the table of w^(2^k)
+// One twiddle table (unpacked hat(w^e) entries, NTT_TW_WORDS words each) from the table of w^(2^k):
+//   stacked = 1:  out[2^s + x] = w^(x << (logn-1-s)), x < 2^s, s < logn   (entry 0 unused)      -- n entries
+//   stacked = 0:  out[j] = w^bitrev_{logn-1}(j), j < n/2                                          -- n/2 entries
 template <class FrP>
-__global__ void ntt_twiddle_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ pow2, uint64_t count,
-                                   int nbits, int hat) {
-    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= count) return;
-    Fe<FrP> r = fe_one<FrP>();
-    for (int k = 0; k < nbits; k++)
-        if ((e >> k) & 1) r = mul(r, load_fe<FrP>(pow2 + k * 8));
-    if (hat) r = f29_hat_packed(r);   // tables for the lazy kernels hold w * 2^261
-#if GA_NTT_TW_UNPACKED
-    if (hat) {
-        const F29<FrP> u = f29_unpack(r);
-        for (int i = 0; i < 12; i++) out[e * NTT_TW_WORDS + i] = i < Radix<FrP>::NL ? u.l[i] : 0u;
-        return;
+__global__ void ntt_twiddle_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ pow2, uint64_t count, int logn, int stacked) {
+    uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    uint64_t e = 0;
+    if (stacked) {
+        if (k > 0) {
+            int s = 63 - __clzll((long long)k);
+            e = (k - (1ull << s)) << (logn - 1 - s);
+        }
+    } else {
+        e = logn > 1 ? bitrev64(k, logn - 1) : 0;
     }
-#endif
-    store_fe(out + e * NTT_TW_WORDS, r);
+    Fe<FrP> r = fe_one<FrP>();
+    for (int b = 0; b + 1 < logn; b++)
+        if ((e >> b) & 1) r = mul(r, load_fe<FrP>(pow2 + b * 8));
+    const F29<FrP> u = f29_unpack(f29_hat_packed(r));   // the pass kernels multiply by hat(w) = w * 2^261
+    for (int i = 0; i < NTT_TW_WORDS; i++) out[k * NTT_TW_WORDS + i] = i < Radix<FrP>::NL ? u.l[i] : 0u;
 }
 
 // a[i] = (a[i]*b[i] - c[i]) * den      (prove.go:377-383)
@@ -414,8 +321,12 @@ struct Domain {
     int curve = 0;
     uint64_t n = 0;
     int logn = 0;
-    uint32_t* d_tw = nullptr;       // w^e,  e < n/2
-    uint32_t* d_tw_inv = nullptr;   // w^-e
+    // twiddle tables of the pass kernels (layouts: ntt_twiddle_kernel): stacked per stage for bit-reversed -> natural transforms,
+    // bit-reversed for natural -> bit-reversed ones; forward (w) and inverse (1/w): 3n entries of 48 bytes in all (2.3 GiB at 2^24)
+    uint32_t* d_ts = nullptr;       // TS, w
+    uint32_t* d_ts_inv = nullptr;   // TS, 1/w
+    uint32_t* d_tb = nullptr;       // TB, w
+    uint32_t* d_tb_inv = nullptr;   // TB, 1/w
     // coset power tables
     uint32_t* d_g_lo = nullptr;     // g^k
     uint32_t* d_g_hi = nullptr;
@@ -503,7 +414,7 @@ int ntt_run(Domain* d, uint32_t* d_data, bool inverse, bool dit, const NttScale&
             const uint32_t* d_src = nullptr) {
     // d_src != nullptr: out-of-place transform (the first pass reads d_src, every pass writes d_data; d_src is left untouched)
     Ctx* ctx = d->ctx;
-    const uint32_t* tw = inverse ? d->d_tw_inv : d->d_tw;
+    const uint32_t* tw = dit ? (inverse ? d->d_ts_inv : d->d_ts) : (inverse ? d->d_tb_inv : d->d_tb);
     NttScale none;
     memset(&none, 0, sizeof(none));
     int np = (int)d->passes.size();
@@ -515,21 +426,12 @@ int ntt_run(Domain* d, uint32_t* d_data, bool inverse, bool dit, const NttScale&
         const NttScale& post = (p == np - 1) ? post_last : none;
         const uint32_t* src = (p == 0 && d_src) ? d_src : d_data;
         StageTimer st(ctx, dit ? "ntt_pass_dit" : "ntt_pass_dif");
-        if (d->logn >= 2) {
-            if (dit)
-                hipLaunchKernelGGL((ntt_pass29r4_kernel<FrP, true>), dim3((unsigned)tiles), dim3(NTT_THREADS), 0, ctx->work_stream(),
-                                   d_data, src, tw, d->logn, lg_tile, ps.s_lo, ps.K, ps.lc, pre, post);
-            else
-                hipLaunchKernelGGL((ntt_pass29r4_kernel<FrP, false>), dim3((unsigned)tiles), dim3(NTT_THREADS), 0, ctx->work_stream(),
-                                   d_data, src, tw, d->logn, lg_tile, ps.s_lo, ps.K, ps.lc, pre, post);
-        } else {   // n = 2: a single stage, the one-stage-per-round-trip pass
-            if (dit)
-                hipLaunchKernelGGL((ntt_pass29_kernel<FrP, true>), dim3((unsigned)tiles), dim3(NTT_THREADS), 0, ctx->work_stream(),
-                                   d_data, src, tw, d->logn, lg_tile, ps.s_lo, ps.K, ps.lc, pre, post);
-            else
-                hipLaunchKernelGGL((ntt_pass29_kernel<FrP, false>), dim3((unsigned)tiles), dim3(NTT_THREADS), 0, ctx->work_stream(),
-                                   d_data, src, tw, d->logn, lg_tile, ps.s_lo, ps.K, ps.lc, pre, post);
-        }
+        if (dit)
+            hipLaunchKernelGGL((ntt_pass29r4_kernel<FrP, true>), dim3((unsigned)tiles), dim3(NTT_THREADS), 0, ctx->work_stream(),
+                               d_data, src, tw, d->logn, lg_tile, ps.s_lo, ps.K, ps.lc, pre, post);
+        else
+            hipLaunchKernelGGL((ntt_pass29r4_kernel<FrP, false>), dim3((unsigned)tiles), dim3(NTT_THREADS), 0, ctx->work_stream(),
+                               d_data, src, tw, d->logn, lg_tile, ps.s_lo, ps.K, ps.lc, pre, post);
         GA_KERNEL_CHECK();
     }
     return GA_OK;
@@ -641,7 +543,6 @@ int domain_init(Ctx* ctx, Domain* d, int curve, uint64_t n) {
     F den = inv(sub(gn, fe_one<FrP>()));
     memcpy(d->den, den.l, 32);
 
-    const int nb = d->logn > 0 ? d->logn - 1 : 0;   // exponent bits of the twiddle tables (e < n/2)
     uint64_t half_n = n / 2;
     if (half_n > 0) {
         std::vector<uint32_t> p2(2 * 32 * 8, 0);
@@ -659,13 +560,14 @@ int domain_init(Ctx* ctx, Domain* d, int curve, uint64_t n) {
         GA_HIP_CHECK(hipMalloc(&tmp_p2.p, p2.size() * 4));
         void* const d_p2 = tmp_p2.p;
         GA_HIP_CHECK(hipMemcpy(d_p2, p2.data(), p2.size() * 4, hipMemcpyHostToDevice));
-        GA_HIP_CHECK(hipMalloc((void**)&d->d_tw, half_n * NTT_TW_WORDS * 4));
-        GA_HIP_CHECK(hipMalloc((void**)&d->d_tw_inv, half_n * NTT_TW_WORDS * 4));
-        unsigned blocks = (unsigned)((half_n + 255) / 256);
-        hipLaunchKernelGGL((ntt_twiddle_kernel<FrP>), dim3(blocks), dim3(256), 0, ctx->work_stream(), d->d_tw,
-                           (const uint32_t*)d_p2, half_n, nb, d->lazy ? 1 : 0);
-        hipLaunchKernelGGL((ntt_twiddle_kernel<FrP>), dim3(blocks), dim3(256), 0, ctx->work_stream(), d->d_tw_inv,
-                           (const uint32_t*)d_p2 + 32 * 8, half_n, nb, d->lazy ? 1 : 0);
+        uint32_t** tabs[4] = {&d->d_ts, &d->d_ts_inv, &d->d_tb, &d->d_tb_inv};
+        for (int t = 0; t < 4; t++) {
+            const bool stacked = t < 2;
+            const uint64_t count = stacked ? n : half_n;
+            GA_HIP_CHECK(hipMalloc((void**)tabs[t], count * NTT_TW_WORDS * 4));
+            hipLaunchKernelGGL((ntt_twiddle_kernel<FrP>), dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->work_stream(), *tabs[t],
+                               (const uint32_t*)d_p2 + (t & 1) * 32 * 8, count, d->logn, stacked ? 1 : 0);
+        }
         GA_KERNEL_CHECK();
         GA_HIP_CHECK(hipStreamSynchronize(ctx->work_stream()));
     }
@@ -703,8 +605,10 @@ int domain_init(Ctx* ctx, Domain* d, int curve, uint64_t n) {
 }
 
 inline void domain_free(Domain* d) {
-    hipFree(d->d_tw);
-    hipFree(d->d_tw_inv);
+    hipFree(d->d_ts);
+    hipFree(d->d_ts_inv);
+    hipFree(d->d_tb);
+    hipFree(d->d_tb_inv);
     hipFree(d->d_g_lo);
     hipFree(d->d_g_hi);
     hipFree(d->d_gi_lo);

@@ -951,6 +951,249 @@ def sha_tag(*parts) -> str:
 
 
 # ----------------------------------------------------------------------------------------------
+# pairing and the Groth16 verifier (backend/groth16/bn254/verify.go:38-145), so that proof BYTES can be checked the way the
+# reference checks them -- by Verify -- instead of through known toxic waste.  The pairing itself lives in gnark-crypto [EXT]:
+# restated here as the ate pairing a_T(Q, P) = f_{T,Q}(P)^((p^12-1)/r) with T = t - 1 (= 6x^2 for BN254, = x for BLS12-381;
+# Hess-Smart-Vercauteren).  It is not gnark-crypto's optimal-ate VALUE (BN254's differs by a fixed power), but any
+# non-degenerate bilinear pairing decides the verifier's product-of-pairings equation identically, and that predicate is what
+# the 12 tuples of backend/groth16/bellman_test.go:26-84 pin (tests/test_oracle_fixtures.py).
+# Fp12 = Fp[w]/(w^12 - 2*a*w^6 + (a^2+1)) with xi = a + u = w^6 (a = 9 BN254, 1 BLS12-381), coefficient lists of length 12.
+# ----------------------------------------------------------------------------------------------
+_PAIRING = {
+    "bn254": dict(a=9, T=6 * 4965661367192848881 ** 2, mtwist=False),   # E'/Fp2: y^2 = x^3 + 3/xi   (D-type): psi(x,y) = (x w^2, y w^3)
+    "bls12-381": dict(a=1, T=0xD201000000010000, mtwist=True),          # E'/Fp2: y^2 = x^3 + 4 xi   (M-type): psi(x,y) = (x/w^2, y/w^3); T = |x|
+}
+
+
+class Fp12Ops:
+    def __init__(self, c: Curve):
+        self.p = c.p
+        self.a = _PAIRING[c.name]["a"]
+        self.c6 = 2 * self.a                    # w^12 = c6*w^6 - c0
+        self.c0 = self.a * self.a + 1
+        self.one = [1] + [0] * 11
+
+    def mul(self, x, y):
+        p = self.p
+        t = [0] * 23
+        for i, xi in enumerate(x):
+            if xi:
+                for j, yj in enumerate(y):
+                    if yj:
+                        t[i + j] += xi * yj
+        for k in range(22, 11, -1):             # w^k = c6*w^(k-6) - c0*w^(k-12)
+            v = t[k] % p
+            if v:
+                t[k - 6] += self.c6 * v
+                t[k - 12] -= self.c0 * v
+        return [v % p for v in t[:12]]
+
+    def conj(self, x):                          # x^(p^6): w -> -w
+        return [(-v) % self.p if i & 1 else v for i, v in enumerate(x)]
+
+    def pow(self, x, e):
+        r = self.one
+        while e:
+            if e & 1:
+                r = self.mul(r, x)
+            x = self.mul(x, x)
+            e >>= 1
+        return r
+
+    def inv(self, x):
+        """x * conj(x) lies in Fp6 = Fp[w^2]; invert there by solving a 6x6 linear system, then x^-1 = conj(x) * (x conj x)^-1"""
+        p = self.p
+        n = self.mul(x, self.conj(x))           # even powers only
+        assert all(n[i] == 0 for i in range(1, 12, 2))
+        # multiplication-by-n matrix on the basis w^0, w^2, ..., w^10
+        cols = []
+        for k in range(6):
+            e = [0] * 12
+            e[2 * k] = 1
+            cols.append(self.mul(n, e)[0::2])
+        M = [[cols[k][r] for k in range(6)] + [1 if r == 0 else 0] for r in range(6)]
+        for i in range(6):                      # Gauss-Jordan mod p
+            piv = next(r for r in range(i, 6) if M[r][i] % p)
+            M[i], M[piv] = M[piv], M[i]
+            iv = pow(M[i][i], -1, p)
+            M[i] = [v * iv % p for v in M[i]]
+            for r in range(6):
+                if r != i and M[r][i]:
+                    f = M[r][i]
+                    M[r] = [(vr - f * vi) % p for vr, vi in zip(M[r], M[i])]
+        ninv = [0] * 12
+        for k in range(6):
+            ninv[2 * k] = M[k][6]
+        return self.mul(self.conj(x), ninv)
+
+    def embed_fp2(self, v, k):
+        """v = v0 + v1*u (u = w^6 - a) times w^k as a sparse coefficient list"""
+        out = [0] * 12
+        out[k] = (v[0] - self.a * v[1]) % self.p
+        out[k + 6] = v[1] % self.p
+        return out
+
+
+def miller_loop(c: Curve, P, Q):
+    """f_{T,Q}(P) for P in G1 (affine Fp), Q in G2 (affine over Fp2, on the twist); infinity on either side gives 1.
+    The running point stays on the twist; a line through twist points with slope m untwists to (scaled by an element of a proper
+    subfield, which the final exponentiation kills):  D-type: -yP + (m xP) w + (yR - m xR) w^3;  M-type: (yR - m xR) + (m xP) w^2 - yP w^3."""
+    F12, F2 = Fp12Ops(c), Fp2Ops(c.p)
+    cfg = _PAIRING[c.name]
+    f = F12.one
+    if P is None or Q is None:
+        return f
+    xP, yP = P
+    G2 = g2_group(c)
+
+    def line(R, S):
+        if R[0] == S[0] and R[1] == S[1]:
+            m = F2.mul(F2.muli(F2.mul(R[0], R[0]), 3), F2.inv(F2.muli(R[1], 2)))
+        else:
+            m = F2.mul(F2.sub(S[1], R[1]), F2.inv(F2.sub(S[0], R[0])))
+        a1 = F2.muli(m, xP)
+        a0 = F2.sub(R[1], F2.mul(m, R[0]))
+        if cfg["mtwist"]:
+            l = F12.embed_fp2(a0, 0)
+            for i, v in enumerate(F12.embed_fp2(a1, 2)):
+                l[i] = (l[i] + v) % c.p
+            l[3] = (l[3] - yP) % c.p
+        else:
+            l = F12.embed_fp2(a1, 1)
+            for i, v in enumerate(F12.embed_fp2(a0, 3)):
+                l[i] = (l[i] + v) % c.p
+            l[0] = (l[0] - yP) % c.p
+        return l
+
+    R = Q
+    T = cfg["T"]
+    for i in range(T.bit_length() - 2, -1, -1):
+        f = F12.mul(F12.mul(f, f), line(R, R))
+        R = G2.add(R, R)
+        if (T >> i) & 1:
+            if R[0] == Q[0] and R[1] != Q[1]:   # R = -Q: vertical line (an element of a proper subfield), R becomes infinity -- last step only
+                R = None
+                break
+            f = F12.mul(f, line(R, Q))
+            R = G2.add(R, Q)
+    return f
+
+
+def final_exponentiation(c: Curve, f):
+    F12 = Fp12Ops(c)
+    g = F12.mul(F12.conj(f), F12.inv(f))                      # ^(p^6 - 1)
+    e = (c.p ** 2 + 1) * ((c.p ** 4 - c.p ** 2 + 1) // c.r)
+    assert (c.p ** 4 - c.p ** 2 + 1) % c.r == 0
+    return F12.pow(g, e)
+
+
+def pairing(c: Curve, P, Q):
+    return final_exponentiation(c, miller_loop(c, P, Q))
+
+
+def pairing_check(c: Curve, pairs) -> bool:
+    """prod e(P_i, Q_i) == 1 with one final exponentiation (curve.PairingCheck [EXT])"""
+    F12 = Fp12Ops(c)
+    f = F12.one
+    for P, Q in pairs:
+        f = F12.mul(f, miller_loop(c, P, Q))
+    return final_exponentiation(c, f) == F12.one
+
+
+def groth16_verify(c: Curve, vk: "VerifyingKey", proof, public_witness, public_and_commitment_committed=()) -> bool:
+    """verify.go:38-145.  proof = (Ar, Bs, Krs, commitments, pok) affine points (commitments / pok may be () / None);
+    public_witness excludes the constant-one wire; public_and_commitment_committed = vk.PublicAndCommitmentCommitted.
+    Returns False where the reference returns an error."""
+    ar, bs, krs = proof[0], proof[1], proof[2]
+    coms = list(proof[3]) if len(proof) > 3 and proof[3] else []
+    pok = proof[4] if len(proof) > 4 else None
+    G1, G2 = g1_group(c), g2_group(c)
+    pacc = [list(x) for x in public_and_commitment_committed]
+    nb_public = len(vk.K) - len(pacc)
+    if len(vk.commitment_g2_sigma_neg) != len(pacc) or len(coms) != len(pacc) or len(public_witness) != nb_public - 1:   # :46-58
+        return False
+    # proof.isValid (:63-65): on the curve and in the prime-order subgroups
+    for P in [ar, krs] + coms + ([pok] if coms else []):
+        if not G1.on_curve(P) or G1.mul(P, c.r) is not None:
+            return False
+    if not G2.on_curve(bs) or G2.mul(bs, c.r) is not None:
+        return False
+    pw = [int(x) % c.r for x in public_witness]
+    fbytes = (c.r.bit_length() - 1) // 8 + 1
+    ser = b""
+    for i, idx in enumerate(pacc):             # solveCommitmentWire (:86-103)
+        msg = g1_marshal_uncompressed(c, coms[i]) + b"".join(pw[j - 1].to_bytes(fbytes, "big") for j in idx)
+        h = fr_hash(c, msg, COMMITMENT_DST, 1)[0]
+        pw.append(h)
+        ser += h.to_bytes(fbytes, "big")
+    if pacc:                                   # pedersen.BatchVerifyMultiVk (:104-112) [EXT]: prod e(ch^i C_i, [-sigma_i]G) e(pok, G) == 1
+        ch = fr_hash(c, ser, FOLD_DST, 1)[0]
+        pairs = [(G1.mul(C, pow(ch, i, c.r)), vk.commitment_g2_sigma_neg[i]) for i, C in enumerate(coms)] + [(pok, vk.commitment_g2)]
+        if not pairing_check(c, pairs):
+            return False
+    ksum = G1.add(G1.msm(vk.K[1:], pw), vk.K[0])            # :115-119
+    for C in coms:
+        ksum = G1.add(ksum, C)                               # :121-123
+    # e(Krs, -delta) e(Ar, Bs) e(kSum, -gamma) == e(alpha, beta)   (:70-73,128-139)
+    return pairing_check(c, [(krs, G2.neg(vk.delta2)), (ar, bs), (ksum, G2.neg(vk.gamma2)), (G1.neg(vk.alpha1), vk.beta2)])
+
+
+def vk_public_and_commitment_committed(cs: "R1CS") -> list:
+    """vk.PublicAndCommitmentCommitted as Setup fills it (setup.go:289, constraint/commitment.go:52-75): public wire ids stay,
+    the wire id of an earlier commitment becomes nbPublic + its position among the commitment wires -- i.e. its index in the
+    verifier's public-witness vector (public inputs, then the commitment hashes in order; verify.go:86-103 reads [idx - 1])."""
+    com_wires = [cm.commitment_index for cm in cs.commitments]
+    out = []
+    for cm in cs.commitments:
+        row = list(cm.public_and_commitment_committed[: cm.nb_public_committed])
+        row += [cs.nb_public + com_wires.index(j) for j in cm.public_and_commitment_committed[cm.nb_public_committed:]]
+        out.append(row)
+    return out
+
+
+def vk_read(c: Curve, data: bytes):
+    """VerifyingKey.ReadFrom, marshal.go:151-230 (compressed points): [alpha]1 [beta]1 [beta]2 [gamma]2 [delta]1 [delta]2,
+    u32 len + [K]1, then -- when present -- PublicAndCommitmentCommitted ([][]uint64: u32 count, per row u32 len + u64s),
+    u32 nbCommitments and per commitment a pedersen.VerifyingKey (G, GSigmaNeg in G2) [EXT].
+    Returns (VerifyingKey, public_and_commitment_committed, beta1, delta1, bytes consumed)."""
+    nb = c.fp_bytes
+    off = 0
+
+    def g1():
+        nonlocal off
+        P = g1_decompress(c, data[off:off + nb])
+        off += nb
+        return P
+
+    def g2():
+        nonlocal off
+        Q = g2_decompress(c, data[off:off + 2 * nb])
+        off += 2 * nb
+        return Q
+
+    def u32():
+        nonlocal off
+        v = int.from_bytes(data[off:off + 4], "big")
+        off += 4
+        return v
+    alpha1, beta1, beta2, gamma2, delta1, delta2 = g1(), g1(), g2(), g2(), g1(), g2()
+    K = [g1() for _ in range(u32())]
+    pacc, cg2, sneg = [], None, []
+    if off < len(data):
+        for _ in range(u32()):
+            row = []
+            for _ in range(u32()):
+                row.append(int.from_bytes(data[off:off + 8], "big"))
+                off += 8
+            pacc.append(row)
+        for _ in range(u32()):
+            cg2 = g2()
+            sneg.append(g2())
+    # (like the Go decoder, reading stops here: the bellman_test.go keys carry zero padding behind the last field)
+    return VerifyingKey(alpha1=alpha1, beta2=beta2, gamma2=gamma2, delta2=delta2, K=K, commitment_g2=cg2, commitment_g2_sigma_neg=sneg), pacc, beta1, delta1, off
+
+
+# ----------------------------------------------------------------------------------------------
 # proving-key wire formats (backend/groth16/bn254/marshal.go:231-539) and Proof.ReadFrom (:62-86)
 # Framing owned by gnark-crypto v0.21.0 [EXT, restated from its published code, see gnark_amd/csrc/keyio.hip.h]:
 # Encoder integers big-endian, []G1Affine = u32 BE length + points, []bool one byte per entry without a

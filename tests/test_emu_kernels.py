@@ -309,6 +309,11 @@ def test_emu_groth16_cubic(emu_ctx, c, precompute):
     assert arr_to_g1_affine(c, proof.Krs) == krs
     assert proof.WriteTo() == pyref.proof_bytes(c, ar, bs, krs)
     assert proof.WriteRawTo() == pyref.proof_bytes_raw(c, ar, bs, krs)
+    # and the way the reference itself asserts a prover: Verify accepts the proof BYTES -- the oracle's restatement of
+    # verify.go:38-145, pinned by the twelve bellman tuples (tests/test_oracle_fixtures.py) -- and rejects a wrong public input
+    got = pyref.proof_read(c, proof.WriteTo())[:5]
+    assert pyref.groth16_verify(c, vk, got, w[1:cs.nb_public])
+    assert not pyref.groth16_verify(c, vk, got, [(w[1] ^ 1) % c.r])
 
 
 def _xmd_vectors():
@@ -392,6 +397,12 @@ def test_emu_groth16_bsb22_commitments(emu_ctx, c, precompute):
     assert (arr_to_g1_affine(c, proof.Ar), arr_to_g2_affine(c, proof.Bs), arr_to_g1_affine(c, proof.Krs)) == (ar, bs, krs)
     assert proof.WriteTo() == pyref.proof_bytes(c, ar, bs, krs, ocoms, opok)
     assert proof.WriteRawTo() == pyref.proof_bytes_raw(c, ar, bs, krs, ocoms, opok)
+    # Verify (verify.go:38-145 restated, pinned by the bellman tuples) accepts the proof bytes: commitment hashes recomputed from the
+    # commitments in the proof, the folded pedersen proof of knowledge checked by pairings, then the Groth16 equation
+    got = pyref.proof_read(c, proof.WriteTo())[:5]
+    pacc = pyref.vk_public_and_commitment_committed(cs)
+    assert pyref.groth16_verify(c, vk, got, w[1:cs.nb_public], pacc)
+    assert not pyref.groth16_verify(c, vk, got, [(w[1] ^ 1) % c.r], pacc)
     # pedersen verification in the exponent: pok_i = [sigma_i] commitment_i, folded with the challenge powers
     G1 = group_of(c, 0)
     sig = toxic[5:7]

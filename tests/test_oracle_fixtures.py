@@ -178,3 +178,136 @@ def test_groth16_bsb22_equation_in_the_exponent():
         # proof wire format with commitments (marshal.go:33-58): 3 points, u32 count, commitments, pok
         nb = c.fp_bytes
         assert len(pyref.proof_bytes(c, ar, bs, krs, coms, pok)) == 4 * nb + 4 + 2 * nb + nb
+
+
+# ---- pairing + Groth16 Verify, pinned by the reference's own (vk, proof, inputs, ok) tuples ---------------------------------------
+def test_pairing_is_bilinear_and_nondegenerate():
+    """the oracle's ate pairing (pyref.miller_loop / final_exponentiation) on both curves: e(aP, bQ) = e(P, Q)^(ab) != 1, order r"""
+    for c in (BN254, BLS12_381):
+        G1, G2, F12 = pyref.g1_group(c), pyref.g2_group(c), pyref.Fp12Ops(c)
+        e = pyref.pairing(c, c.g1, c.g2)
+        assert e != F12.one and F12.pow(e, c.r) == F12.one
+        a, b = 0x1234567, 0x89ABCDEF01
+        assert pyref.pairing(c, G1.mul(c.g1, a), G2.mul(c.g2, b)) == F12.pow(e, a * b % c.r)
+        assert pyref.pairing_check(c, [(G1.mul(c.g1, a), c.g2), (G1.neg(c.g1), G2.mul(c.g2, a))])
+        assert not pyref.pairing_check(c, [(G1.mul(c.g1, a), c.g2), (G1.neg(c.g1), G2.mul(c.g2, a + 1))])
+        assert F12.mul(e, F12.inv(e)) == F12.one
+
+
+def test_bellman_tuples_pin_the_verifier():
+    """backend/groth16/bellman_test.go:26-84: twelve (vk, proof, inputs) tuples produced OUTSIDE gnark (bellman, BLS12-381); the
+    reference's Verify accepts the six marked ok.  The oracle's restatement of verify.go:38-145 accepts exactly those six and
+    rejects the other six -- the pin that lets the GPU tests check proof bytes with a verifier instead of known toxic waste."""
+    c = BLS12_381
+    t = json.load(open(os.path.join(GOLD, "bellman_bls12381.json")))["tuples"]
+    assert len(t) == 12 and sum(x["ok"] for x in t) == 6
+    for x in t:
+        vkb, prb, inb = base64.b64decode(x["vk"]), base64.b64decode(x["proof"]), base64.b64decode(x["inputs"])
+        vk, pacc, _, _, used = pyref.vk_read(c, vkb)
+        assert pacc == [] and set(vkb[used:]) <= {0}            # (the test vectors are zero-padded for "commitment stuff", :92-93)
+        ar, bs, krs = pyref.g1_decompress(c, prb[:48]), pyref.g2_decompress(c, prb[48:144]), pyref.g1_decompress(c, prb[144:192])
+        pw = [int.from_bytes(inb[i:i + 32], "big") for i in range(0, len(inb), 32)]
+        assert len(pw) == len(vk.K) - 1
+        assert pyref.groth16_verify(c, vk, (ar, bs, krs), pw) is x["ok"], x["proof"][:16]
+
+
+@pytest.mark.parametrize("c", [BN254, BLS12_381], ids=lambda c: c.name)
+def test_oracle_verifier_accepts_oracle_proofs_and_rejects_tampering(c):
+    """Setup -> Prove -> Verify inside the oracle (examples/cubic and the two-commitment circuit): the verifier pinned above
+    accepts what the oracle's prover (prove.go:52-315 restated) produces, through the proof BYTES, and rejects a wrong public input,
+    a tampered commitment and a proof point moved off its value."""
+    rng = pyref.Xoshiro(0xBE11)
+    G1 = pyref.g1_group(c)
+    # cubic
+    cs, w = pyref.cubic_r1cs(), pyref.cubic_witness(3)
+    pk, vk, _ = pyref.groth16_setup(c, cs, [rng.field(c.r) for _ in range(5)])
+    r, s = rng.field(c.r), rng.field(c.r)
+    blob = pyref.proof_bytes(c, *pyref.groth16_prove(pk, cs, w, r, s))
+    ar, bs, krs, coms, pok = pyref.proof_read(c, blob)[:5]
+    assert pyref.groth16_verify(c, vk, (ar, bs, krs, coms, pok), w[1:cs.nb_public])
+    assert not pyref.groth16_verify(c, vk, (ar, bs, krs, coms, pok), [(w[1] + 1) % c.r])
+    assert not pyref.groth16_verify(c, vk, (G1.add(ar, c.g1), bs, krs, coms, pok), w[1:cs.nb_public])
+    # two commitments (BSB22)
+    cs = pyref.commit_r1cs()
+    pk, vk, _ = pyref.groth16_setup(c, cs, [rng.field(c.r) for _ in range(8)])
+    w = pyref.commit_solve(c, cs, 5, 7, lambda i, ww: pyref.commitment_hint(pk, cs, i, ww)[1])
+    blob = pyref.proof_bytes(c, *pyref.groth16_prove_bsb22(pk, cs, w, r, s))
+    proof = pyref.proof_read(c, blob)[:5]
+    pacc = pyref.vk_public_and_commitment_committed(cs)
+    assert pacc == [[1], [2]]
+    assert pyref.groth16_verify(c, vk, proof, w[1:cs.nb_public], pacc)
+    assert not pyref.groth16_verify(c, vk, proof, [(w[1] + 1) % c.r], pacc)
+    bad = (proof[0], proof[1], proof[2], [G1.add(proof[3][0], c.g1), proof[3][1]], proof[4])
+    assert not pyref.groth16_verify(c, vk, bad, w[1:cs.nb_public], pacc)
+
+
+# ---- the FFT convention and the remaining encodings, from literals the reference ships ------------------------------------------
+def _fr_be(b):
+    return int.from_bytes(b, "big")
+
+
+@pytest.mark.parametrize("c", [BN254, BLS12_381], ids=lambda c: c.name)
+def test_domain_constants_match_the_reference_literals(c, emu_ctx):
+    """backend/solidity/testdata/blank_plonk_{bn254,bls12381}_nocommit.sol:42-65 (VK_DOMAIN_SIZE, VK_INV_DOMAIN_SIZE, VK_OMEGA,
+    VK_COSET_SHIFT) and the head of the serialized blank_plonk_*.vk (backend/plonk/bn254/marshal.go:177-203: Size, SizeInv,
+    Generator, NbPublicVariables, CosetShift): gnark's root of unity / coset shift as literals, against the oracle's domain
+    AND the library's (a size-8 transform of the unit vector e_1 spells out the powers of the domain generator)."""
+    from gnark_amd import fft
+    k = json.load(open(os.path.join(GOLD, "fft_constants.json")))[c.name]
+    n, ninv, omega, shift = (int(k[x]) for x in ("VK_DOMAIN_SIZE", "VK_INV_DOMAIN_SIZE", "VK_OMEGA", "VK_COSET_SHIFT"))
+    assert int(k["R_MOD"]) == c.r and n == 8
+    assert c.fr_root_of_unity(n) == omega and pow(n, -1, c.r) == ninv and c.fr_gen == shift
+    for name in ("nocommit", "commit"):
+        raw = open(os.path.join(GOLD, "vk_blank_plonk_%s_%s.bin" % (c.name.replace("-", ""), name)), "rb").read()
+        if _fr_be(raw[:8]) == 0:                                      # keyVersionMarker, then the version (marshal.go:233-245, setup.go:32)
+            assert _fr_be(raw[8:16]) == 1
+            raw = raw[16:]
+        size = _fr_be(raw[:8])                                        # (else: the legacy layout starts with Size, marshal.go:262-285)
+        assert size == (n if name == "nocommit" else 2 * n)           # (the circuit with a commitment has a 16-point domain)
+        if name == "nocommit":
+            assert _fr_be(raw[8:40]) == ninv and _fr_be(raw[40:72]) == omega
+        assert _fr_be(raw[8:40]) == pow(size, -1, c.r) and _fr_be(raw[40:72]) == c.fr_root_of_unity(size) and _fr_be(raw[80:112]) == shift
+        nb = c.fp_bytes
+        off = 112
+        G1 = pyref.g1_group(c)
+        for _ in range(8):                                            # S1 S2 S3 Ql Qr Qm Qo Qk: compressed G1 points
+            P = pyref.g1_decompress(c, raw[off:off + nb])
+            assert G1.on_curve(P) and pyref.g1_compress(c, P) == raw[off:off + nb]
+            off += nb
+        nq = int.from_bytes(raw[off:off + 4], "big")                  # Qcp
+        off += 4 + nq * nb
+        assert nq == (1 if name == "commit" else 0)
+        assert pyref.g1_decompress(c, raw[off:off + nb]) == c.g1      # Kzg.G1 = [1]G1
+        off += nb
+        assert pyref.g2_decompress(c, raw[off:off + 2 * nb]) == c.g2  # Kzg.G2[0] = [1]G2
+        tau2 = pyref.g2_decompress(c, raw[off + 2 * nb:off + 4 * nb])  # Kzg.G2[1] = [tau]G2
+        assert pyref.g2_group(c).mul(tau2, c.r) is None
+    # the library's domain of size 8: FFT(e_1)[k] = omega^k (DIT: bit-reversed in, natural out; e_1 sits at bitrev(1) = 4)
+    d = fft.Domain(emu_ctx, c.name, 8)
+    try:
+        e = [0] * 8
+        e[4] = 1
+        got = [pyref.from_mont_limbs(row, c.r) for row in d.FFT(fr_to_arr(c, e), fft.DIT)]
+        assert got == [pow(omega, i, c.r) for i in range(8)]
+        e = [0] * 8
+        e[1] = 1
+        got = [pyref.from_mont_limbs(row, c.r) for row in d.FFT(fr_to_arr(c, e), fft.DIF, True)]      # coset: (shift*omega^k), bit-reversed out
+        assert [got[pyref.bitrev(i, 3)] for i in range(8)] == [shift * pow(omega, i, c.r) % c.r for i in range(8)]
+        got = [pyref.from_mont_limbs(row, c.r) for row in d.FFTInverse(fr_to_arr(c, [1] * 8), fft.DIF)]
+        assert got[0] == 1 and not any(got[1:])                       # 1/n inside the inverse: iFFT(1,...,1) = e_0
+    finally:
+        d.close()
+
+
+@pytest.mark.parametrize("c", [BN254, BLS12_381], ids=lambda c: c.name)
+def test_groth16_commit_vk_fixture_decodes(c):
+    """backend/solidity/testdata/blank_groth16_*_commit.vk per backend/groth16/bn254/marshal.go:151-230: the key of a circuit with
+    one commitment -- K, PublicAndCommitmentCommitted, one pedersen.VerifyingKey (G, GSigmaNeg in G2).  Every byte is consumed and
+    every G2 point is r-torsion."""
+    raw = open(os.path.join(GOLD, "vk_blank_groth16_%s_commit.bin" % c.name.replace("-", "")), "rb").read()
+    vk, pacc, beta1, delta1, used = pyref.vk_read(c, raw)
+    assert used == len(raw) and len(pacc) == 1 and len(vk.commitment_g2_sigma_neg) == 1
+    G2 = pyref.g2_group(c)
+    for Q in (vk.beta2, vk.gamma2, vk.delta2, vk.commitment_g2, vk.commitment_g2_sigma_neg[0]):
+        assert G2.on_curve(Q) and G2.mul(Q, c.r) is None
+    assert len(vk.K) >= 2 and all(pyref.g1_group(c).on_curve(P) for P in vk.K + [vk.alpha1, beta1, delta1])

@@ -6,7 +6,12 @@ exists; the GPU box only sees the committed outputs).
                          (4096 each) and g2_monomial[0..3], decompressed with oracle/pyref.py to gnark memory images
                          (Montgomery limbs) + the compressed bytes of the first 8 entries (decompression KATs)
   vk_*.bin               backend/solidity/testdata/blank_groth16_{bn254,bls12381}_nocommit.vk (serialized VKs, raw)
-  bellman_bls12381.json  the first (vk, proof) tuple of backend/groth16/bellman_test.go:26-40 (base64 as in the file)
+  bellman_bls12381.json  the first (vk, proof, inputs) tuple of backend/groth16/bellman_test.go:26-40 (base64 as in the file) and, under
+                         "tuples", all twelve of :26-84 with their `ok` flags (6 the verifier must accept, 6 it must not)
+  fft_constants.json     the domain constants the reference ships as literals: VK_DOMAIN_SIZE / VK_INV_DOMAIN_SIZE / VK_OMEGA /
+                         VK_COSET_SHIFT of backend/solidity/testdata/blank_plonk_{bn254,bls12381}_nocommit.sol
+  vk_blank_plonk_*.bin, vk_blank_groth16_*_commit.bin   the serialized keys of backend/solidity/testdata (decoded in the tests per
+                         backend/plonk/bn254/marshal.go:177-203 and backend/groth16/bn254/marshal.go:151-230)
   expand_msg_xmd.json    the 16 expand_message_xmd (SHA-256) vectors of std/hash/expand/expand_test.go:44-140 (32, 48 and 128 output bytes)
 """
 import base64
@@ -46,7 +51,24 @@ def main():
         shutil.copyfile(os.path.join(REF, "backend/solidity/testdata", name), os.path.join(OUT, "vk_" + name.replace(".vk", ".bin")))
     src = open(os.path.join(REF, "backend/groth16/bellman_test.go")).read()
     strs = re.findall(r'"([A-Za-z0-9+/=]{40,})"', src)
-    json.dump({"vk": strs[0], "proof": strs[1], "inputs": strs[2] if len(strs) > 2 else ""}, open(os.path.join(OUT, "bellman_bls12381.json"), "w"))
+    body = src[src.index("for _, test := range"):src.index("// decode verifying key")]
+    tuples = re.findall(r'\{\s*"([A-Za-z0-9+/=]+)",\s*"([A-Za-z0-9+/=]+)",\s*"([A-Za-z0-9+/=]*)",\s*(true|false),\s*\}', body)
+    assert len(tuples) == 12 and sum(t[3] == "true" for t in tuples) == 6
+    json.dump({"vk": strs[0], "proof": strs[1], "inputs": strs[2] if len(strs) > 2 else "",
+               "tuples": [{"vk": v, "proof": pr, "inputs": i, "ok": ok == "true"} for v, pr, i, ok in tuples]},
+              open(os.path.join(OUT, "bellman_bls12381.json"), "w"), indent=0)
+    # FFT-convention literals: the solidity templates rendered for the blank PLONK keys
+    consts = {}
+    for curve, fn in (("bn254", "blank_plonk_bn254_nocommit.sol"), ("bls12-381", "blank_plonk_bls12381_nocommit.sol")):
+        sol = open(os.path.join(REF, "backend/solidity/testdata", fn)).read()
+        get = lambda name: int(re.search(r"uint256 private constant %s = (\d+);" % name, sol).group(1))
+        consts[curve] = {k: str(get(k)) for k in ("VK_DOMAIN_SIZE", "VK_INV_DOMAIN_SIZE", "VK_OMEGA", "VK_COSET_SHIFT", "R_MOD")
+                         if re.search(r"uint256 private constant %s = " % k, sol)}
+    json.dump(consts, open(os.path.join(OUT, "fft_constants.json"), "w"), indent=1)
+    for name in ("blank_plonk_bn254_nocommit.vk", "blank_plonk_bls12381_nocommit.vk", "blank_plonk_bn254_commit.vk", "blank_plonk_bls12381_commit.vk",
+                 "blank_groth16_bn254_commit.vk", "blank_groth16_bls12381_commit.vk"):
+        if os.path.exists(os.path.join(REF, "backend/solidity/testdata", name)):
+            shutil.copyfile(os.path.join(REF, "backend/solidity/testdata", name), os.path.join(OUT, "vk_" + name.replace(".vk", ".bin")))
     # expand_message_xmd known answers (std/hash/expand/expand_test.go:44-140, "adapted from gnark-crypto/field/hash"): they pin
     # the hash-to-field used by the BSB22 commitment hint and the PoK fold challenge
     src = open(os.path.join(REF, "std/hash/expand/expand_test.go")).read()
