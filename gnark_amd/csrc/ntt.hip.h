@@ -94,36 +94,24 @@ __device__ __forceinline__ Fe<FrP> ntt_scale_factor(const NttScale& sc, uint64_t
 // For a quad on index bits (s, s+1) the three twiddles are TS[2^s + x], TS[2^(s+1) + x], TS[2^(s+1) + 2^s + x] (DIT) and
 // TB[u], TB[2u], TB[2u+1] with u = i >> (s+2) (natural -> bit-reversed: the last two adjacent, all three shared by every lane
 // with the same upper index bits).
-// LDS tile: [NL][tile] words, one plane per limb.  Unit-stride lanes hit consecutive banks; the quads of the low stages do not (the
-// 32 lanes of a half-wave read slots l00 + {bits of q spread around the two butterfly bits}: for index bits lb < 5 only 8 distinct
-// banks, SQ_LDS_BANK_CONFLICT = 41 % of the LDS cycles in round 2's kernel).  GA_NTT_LDS_SWZ=1 stores slot l at l ^ m(l5, l6) with
-// m = 01010b for bit 5, 10101b for bit 6: a bijection within every aligned block of 128 slots that makes the low five address bits a
-// bijection of the five lowest FREE index bits for every butterfly position lb.
-#ifndef GA_NTT_LDS_SWZ
-#define GA_NTT_LDS_SWZ 0
-#endif
+// LDS tile: [NL][tile] words, one plane per limb.  Unit-stride lanes hit consecutive banks; the quads of the low stages do not
+// (index bits lb < 5 leave a half-wave only 8 distinct banks: SQ_LDS_BANK_CONFLICT = 41 % of the LDS-array cycles).  Measured
+// in round 3: an XOR swizzle of the slot index that makes every butterfly position conflict-free changes nothing (computeH
+// 15.96 vs 15.99 ms, profiles/README.md) -- the LDS array is busy 17 % of the time, the conflicts hide behind the multiplies
+// -- so the plain layout stays.
 template <class FrP>
 struct LdsTile29 {
     uint32_t* base;
     static constexpr int NL = Radix<FrP>::NL, STRIDE = 1 << NTT_LG_TILE;
-    __device__ __forceinline__ static uint32_t slot(uint32_t l) {
-#if GA_NTT_LDS_SWZ
-        return l ^ ((0x1F150A00u >> ((l >> 2) & 0x18u)) & 0x1Fu);
-#else
-        return l;
-#endif
-    }
     __device__ __forceinline__ F29<FrP> get(uint32_t l) const {
         F29<FrP> r;
-        const uint32_t p = slot(l);
 #pragma unroll
-        for (int i = 0; i < NL; i++) r.l[i] = base[i * STRIDE + p];
+        for (int i = 0; i < NL; i++) r.l[i] = base[i * STRIDE + l];
         return r;
     }
     __device__ __forceinline__ void put(uint32_t l, const F29<FrP>& v) const {
-        const uint32_t p = slot(l);
 #pragma unroll
-        for (int i = 0; i < NL; i++) base[i * STRIDE + p] = v.l[i];
+        for (int i = 0; i < NL; i++) base[i * STRIDE + l] = v.l[i];
     }
 };
 

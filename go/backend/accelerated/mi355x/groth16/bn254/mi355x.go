@@ -46,20 +46,63 @@ func kRemoveList(info constraint.Groth16Commitments) []uint64 {
 	return out
 }
 
-// setupDevicePointers pins the key on the configured devices if that has not happened yet (or happened for another
-// device set).  Counterpart of (*ProvingKey).setupDevicePointers, icicle.go:88-264: the Den vector, the coset
-// generator and the NTT domain bookkeeping have no Go-side remains -- the library derives them from the cardinality.
-func (pk *ProvingKey) setupDevicePointers(cfg *mi355x.Config, info constraint.Groth16Commitments) error {
+// effectivePrecompute is the window-table policy a key is pinned with.  A key that is NOT kept on the device between proofs
+// (PinToGPU false, the default -- the ICICLE backend's default too: icicle.go:797-805, provingkey.go:37-42) is uploaded as plain
+// vectors unless the caller asked for tables explicitly: building 72 GiB of tables (2.4 s for a 2^24 BN254 key) to save 50 ms
+// on the one proof that uses them, and freeing them afterwards, would make every default Prove ~17x slower.
+func effectivePrecompute(cfg *mi355x.Config, pinned bool) int32 {
+	if !pinned && cfg.Precompute == mi355x.PrecomputeAuto {
+		return int32(mi355x.PrecomputeNever)
+	}
+	return int32(cfg.Precompute)
+}
+
+// acquire registers a prover on the key and returns the device copy it proves on, pinning the key first if that has not
+// happened yet; release is its counterpart.  Between the two the device copy cannot be freed: FreeGPUResources from another
+// goroutine (or the un-pinned key's own free-after-proof) is deferred to the LAST prover's release.  Two goroutines may
+// therefore prove on one key at the same time (the library runs the second on its own pair of lanes), as the reference's
+// accelerated backend allows under its per-device mutex (icicle.go:821-823).
+func (pk *ProvingKey) acquire(cfg *mi355x.Config, info constraint.Groth16Commitments) (*deviceInfo, error) {
 	pk.setupMu.Lock()
 	defer pk.setupMu.Unlock()
+	pk.PinToGPU = pk.PinToGPU || cfg.PinToGPU
+	if !(pk.deviceInfo != nil && len(pk.InfinityA) == 0) { // a key pinned by PinFromFile has no host copy to (re)pin from
+		if err := pk.setupDevicePointersLocked(cfg, info); err != nil {
+			return nil, err
+		}
+	}
+	pk.users++
+	return pk.deviceInfo, nil
+}
+
+func (pk *ProvingKey) release() {
+	pk.setupMu.Lock()
+	defer pk.setupMu.Unlock()
+	pk.users--
+	if pk.users == 0 && (!pk.PinToGPU || pk.freePending) {
+		pk.freeLocked()
+		pk.freePending = false
+	}
+}
+
+// setupDevicePointersLocked pins the key on the configured devices if that has not happened yet (or happened for another
+// device set or table policy).  Counterpart of (*ProvingKey).setupDevicePointers, icicle.go:88-264: the Den vector, the coset
+// generator and the NTT domain bookkeeping have no Go-side remains -- the library derives them from the cardinality.
+// Caller holds setupMu.
+func (pk *ProvingKey) setupDevicePointersLocked(cfg *mi355x.Config, info constraint.Groth16Commitments) error {
 	devices := cfg.DeviceIDs()
+	precompute := effectivePrecompute(cfg, pk.PinToGPU)
 	if pk.deviceInfo != nil {
-		if slices.Equal(pk.deviceInfo.devices, devices) && pk.deviceInfo.precompute == int32(cfg.Precompute) {
+		if slices.Equal(pk.deviceInfo.devices, devices) && pk.deviceInfo.precompute == precompute {
 			return nil
+		}
+		if pk.users > 0 {
+			return fmt.Errorf("proving key is in use on devices %v (precompute %d); cannot re-pin it for devices %v (precompute %d) now",
+				pk.deviceInfo.devices, pk.deviceInfo.precompute, devices, precompute)
 		}
 		pk.freeLocked()
 	}
-	di := &deviceInfo{devices: slices.Clone(devices), precompute: int32(cfg.Precompute)}
+	di := &deviceInfo{devices: slices.Clone(devices), precompute: precompute}
 	remove := kRemoveList(info)
 	for shard, dev := range devices {
 		ctx, err := ga.ContextFor(dev)
@@ -123,7 +166,7 @@ func (pk *ProvingKey) setupDevicePointers(cfg *mi355x.Config, info constraint.Gr
 			di.free()
 			return err
 		}
-		key, err := b.Finish(int32(cfg.Precompute))
+		key, err := b.Finish(precompute)
 		if err != nil {
 			di.free()
 			return err
@@ -142,9 +185,12 @@ func (pk *ProvingKey) setupDevicePointers(cfg *mi355x.Config, info constraint.Gr
 func (pk *ProvingKey) PinFromFile(path string, cfg *mi355x.Config, info constraint.Groth16Commitments) error {
 	pk.setupMu.Lock()
 	defer pk.setupMu.Unlock()
+	if pk.users > 0 {
+		return fmt.Errorf("proving key is in use by %d prover(s); cannot replace its device copy now", pk.users)
+	}
 	pk.freeLocked()
 	devices := cfg.DeviceIDs()
-	di := &deviceInfo{devices: slices.Clone(devices), precompute: int32(cfg.Precompute)}
+	di := &deviceInfo{devices: slices.Clone(devices), precompute: int32(cfg.Precompute)} // a key read from a file stays pinned: the caller's policy as is
 	remove := kRemoveList(info)
 	for shard, dev := range devices {
 		ctx, err := ga.ContextFor(dev)
@@ -185,10 +231,15 @@ func (pk *ProvingKey) freeLocked() {
 }
 
 // FreeGPUResources releases the device copy of the key (vectors, window tables, commitment keys).  Idempotent; the
-// next Prove pins the key again.  Counterpart of icicle.go:1493-1549.
+// next Prove pins the key again.  While other goroutines are proving on the key the release is deferred to the last of
+// them (the device memory must outlive their proofs).  Counterpart of icicle.go:1493-1549.
 func (pk *ProvingKey) FreeGPUResources() {
 	pk.setupMu.Lock()
 	defer pk.setupMu.Unlock()
+	if pk.users > 0 {
+		pk.freePending = true
+		return
+	}
 	pk.freeLocked()
 }
 
@@ -205,22 +256,16 @@ func Prove(r1cs *cs.R1CS, pk *ProvingKey, fullWitness witness.Witness, cfg *mi35
 	if opt.HashToFieldFn == nil {
 		opt.HashToFieldFn = hash_to_field.New([]byte(constraint.CommitmentDst))
 	}
-	pk.PinToGPU = pk.PinToGPU || cfg.PinToGPU
 	log := logger.Logger().With().Str("curve", r1cs.CurveID().String()).Str("acceleration", "mi355x").Int("nbConstraints", r1cs.GetNbConstraints()).Str("backend", "groth16").Logger()
 
 	commitmentInfo := r1cs.CommitmentInfo.(constraint.Groth16Commitments)
-	if pk.deviceInfo == nil {
-		log.Debug().Msg("pinning proving key in HBM")
+	// pin (if needed) and hold the device copy for the whole proof; an un-pinned key is freed by the last prover's release
+	di, err := pk.acquire(cfg, commitmentInfo)
+	if err != nil {
+		return nil, fmt.Errorf("setup device pointers: %w", err)
 	}
-	if !(pk.deviceInfo != nil && len(pk.InfinityA) == 0) { // a key pinned by PinFromFile has no host copy to (re)pin from
-		if err := pk.setupDevicePointers(cfg, commitmentInfo); err != nil {
-			return nil, fmt.Errorf("setup device pointers: %w", err)
-		}
-	}
-	if !pk.PinToGPU {
-		defer pk.FreeGPUResources()
-	}
-	keys := pk.deviceInfo.keys
+	defer pk.release()
+	keys := di.keys
 
 	proof := &groth16_bn254.Proof{Commitments: make([]curve.G1Affine, len(commitmentInfo))}
 	poks := make([]curve.G1Affine, len(commitmentInfo))
@@ -306,7 +351,7 @@ func Prove(r1cs *cs.R1CS, pk *ProvingKey, fullWitness witness.Witness, cfg *mi35
 	proof.Ar, proof.Bs, proof.Krs = out.Ar, out.Bs, out.Krs
 
 	if cfg.StepProfile {
-		for _, dev := range pk.deviceInfo.devices {
+		for _, dev := range di.devices {
 			if ctx, err := ga.ContextFor(dev); err == nil {
 				if stages, err := ctx.ReadProfile(); err == nil {
 					log.Debug().Int("device", dev).Str("stages_ms", stages).Msg("mi355x step profile")

@@ -24,6 +24,8 @@ type deviceInfo struct {
 type ProvingKey struct {
 	groth16_bn254.ProvingKey
 	*deviceInfo
-	setupMu  sync.Mutex // protects the creation / release of deviceInfo
-	PinToGPU bool       // keep the device copy between proofs (default false, like the ICICLE backend)
+	setupMu     sync.Mutex // protects deviceInfo, users, freePending and PinToGPU
+	users       int        // provers currently inside Prove on this key (acquire / release)
+	freePending bool       // FreeGPUResources was called while provers were active: the last one frees
+	PinToGPU    bool       // keep the device copy between proofs (default false, like the ICICLE backend)
 }

@@ -10,7 +10,9 @@ import (
 type Precompute int32
 
 const (
-	// PrecomputeAuto builds [2^(c*w)]P tables for A, B, K, Z and G2.B when they fit in 85 % of the free HBM.
+	// PrecomputeAuto: for a key kept on the device (WithPinKeysToGPU(true), PinFromFile) build [2^(c*w)]P tables for A, B, K, Z
+	// and G2.B when they fit in 85 % of the free HBM; for a key that is uploaded per proof and freed afterwards (the default,
+	// as in the ICICLE backend) upload the plain vectors only.
 	PrecomputeAuto Precompute = 0
 	// PrecomputeAlways builds them or fails.
 	PrecomputeAlways Precompute = 1
@@ -30,7 +32,7 @@ type Config struct {
 	// PinToGPU keeps the device copy of the proving key between proofs.  Default false, as in the ICICLE backend
 	// (the device memory is released after each proof); long-lived provers want true.
 	PinToGPU bool
-	// Precompute is the window-table policy.
+	// Precompute is the window-table policy (see PrecomputeAuto for what the default means for un-pinned keys).
 	Precompute Precompute
 	// StepProfile logs the per-stage device timings of every proof (ICICLE_STEP_PROFILE of the ICICLE backend).
 	StepProfile bool
