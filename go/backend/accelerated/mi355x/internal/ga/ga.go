@@ -392,6 +392,26 @@ func (t *Table) Free() {
 	}
 }
 
+// LinearCombination is out[i] = sum_j scalars[j] * vecs[j][i] over fr for k <= 16 host vectors of n elements each
+// (ga_fr_linear_combination): the fold of kzg.BatchOpenSinglePoint.  The pointer array lives in C memory, the vectors are pinned.
+func (c *Context) LinearCombination(curve Curve, n uint64, vecs []unsafe.Pointer, scalars, out unsafe.Pointer) error {
+	k := len(vecs)
+	if k == 0 || k > 16 {
+		return fmt.Errorf("ga: linear combination of %d vectors outside [1, 16]", k)
+	}
+	arr := (*[16]unsafe.Pointer)(C.malloc(C.size_t(k) * C.size_t(unsafe.Sizeof(uintptr(0)))))
+	defer C.free(unsafe.Pointer(arr))
+	var pin runtime.Pinner
+	defer pin.Unpin()
+	for i, p := range vecs {
+		pin.Pin(p)
+		arr[i] = p
+	}
+	return call("ga_fr_linear_combination", func() C.int {
+		return C.ga_fr_linear_combination(c.h, C.int(curve), C.uint64_t(n), C.int(k), (*unsafe.Pointer)(unsafe.Pointer(arr)), scalars, out, 0)
+	})
+}
+
 // JacToAffine converts with the library's host arithmetic (the Go callers normally use curve.G1Affine.FromJacobian).
 func JacToAffine(curve Curve, group int, jac, affineOut unsafe.Pointer) error {
 	return call("ga_jac_to_affine", func() C.int { return C.ga_jac_to_affine(C.int(curve), C.int(group), jac, affineOut) })

@@ -97,7 +97,10 @@ static void append_transient(ga_g16_builder* b, int which, const void* src, uint
     free(tmp);
 }
 
-static ga_g16_pk* pin_staged(ga_ctx* ctx, const host_key* k) {
+static ga_g16_pk* pin_staged_pre(ga_ctx* ctx, const host_key* k, int32_t precompute);
+static ga_g16_pk* pin_staged(ga_ctx* ctx, const host_key* k) { return pin_staged_pre(ctx, k, 0); }
+
+static ga_g16_pk* pin_staged_pre(ga_ctx* ctx, const host_key* k, int32_t precompute) {
     ga_g16_builder* b = NULL;
     CHECK(ga_g16_builder_create(ctx, GA_BN254, k->n, k->nw, 0, 1, &b));
     const void* vec[5] = {k->A, k->B, k->Z, k->K, k->B2};
@@ -117,7 +120,7 @@ static ga_g16_pk* pin_staged(ga_ctx* ctx, const host_key* k) {
     CHECK(ga_g16_builder_set_infinity(b, 0, k->inf_a, k->nw));
     CHECK(ga_g16_builder_set_infinity(b, 1, k->inf_b, k->nw));
     ga_g16_pk* pk = NULL;
-    CHECK(ga_g16_builder_finish(b, 0, &pk));
+    CHECK(ga_g16_builder_finish(b, precompute, &pk));
     return pk;
 }
 
@@ -205,6 +208,15 @@ static void* prove_worker(void* p) {
     }
     return NULL;
 }
+/* like prove_worker, but a refused call (the key is being destroyed) is not a failure; a WRONG proof is */
+static void* prove_worker_tolerant(void* p) {
+    worker* w = (worker*)p;
+    uint64_t proof[32];
+    const solution* s = w->sol;   /* ONE call: after the destroy has returned the handle is gone and must not be used again */
+    int rc = ga_g16_prove(w->pk, s->W, s->A, s->B, s->C, s->n, s->nb_public, s->rs, (const char*)s->rs + 32, proof);
+    if (rc != GA_ERR_STATE && (rc != GA_OK || memcmp(proof, w->want, sizeof proof))) w->failures++;
+    return NULL;
+}
 static void* fft_worker(void* p) {
     worker* w = (worker*)p;
     void* buf = malloc(w->n * 32);
@@ -252,6 +264,55 @@ int main(void) {
     if (blen != 164) {
         fprintf(stderr, "proof is %zu bytes, expected 164\n", blen);
         return 1;
+    }
+
+    /* ---- the shim's DEFAULT path: a key that is not kept on the device (PinToGPU false, opts.go) is uploaded as plain vectors
+     * (precompute -1: no window tables are built just to be freed after the proof), proves to the same bytes and gives its memory
+     * back.  On a GPU the free-memory readings bound its footprint: the plain key and nothing like the 12x of the tables. */
+    {
+        uint64_t total = 0, free0 = 0, free1 = 0, free2 = 0;
+        char name[128];
+        CHECK(ga_device_info(ctx, name, sizeof name, &total, &free0));
+        ga_g16_pk* pk_once = pin_staged_pre(ctx, &k, -1);
+        CHECK(ga_device_info(ctx, name, sizeof name, &total, &free1));
+        uint64_t p5[32];
+        prove_transient(pk_once, &s, p5);
+        ga_g16_pk_destroy(pk_once);
+        CHECK(ga_device_info(ctx, name, sizeof name, &total, &free2));
+        const uint64_t plain = (k.len_a + k.len_b + k.len_z + k.len_k) * 64 + k.len_b * 128 + 3 * k.nw * 4;
+        if (memcmp(p5, p1, sizeof p1)) {
+            fprintf(stderr, "the un-pinned (plain vectors) key proves to different bytes\n");
+            return 1;
+        }
+        if (free0 > free1 && free0 - free1 > 3 * plain + (64u << 20)) {
+            fprintf(stderr, "un-pinned key took %llu bytes of HBM for %llu bytes of plain vectors: tables were built\n",
+                    (unsigned long long)(free0 - free1), (unsigned long long)plain);
+            return 1;
+        }
+        printf("un-pinned key: %llu bytes of plain vectors, HBM delta on pin %lld, after destroy %lld\n", (unsigned long long)plain,
+               (long long)(free0 - free1), (long long)(free0 - free2));
+    }
+    /* ---- FreeGPUResources from one thread while another is still proving on the key (a Go `defer pk.FreeGPUResources()` beside a
+     * second goroutine's Prove): ga_g16_pk_destroy waits for the proof in flight; a call that arrives after the key started dying is
+     * refused with GA_ERR_STATE instead of touching freed memory ---- */
+    {
+        ga_g16_pk* pk_tmp = pin_staged(ctx, &k);
+        worker wd;
+        memset(&wd, 0, sizeof wd);
+        wd.pk = pk_tmp; wd.sol = &s; wd.want = p1;
+        pthread_t td;
+        uint64_t st0[6], st1[6];
+        CHECK(ga_g16_lane_stats(ctx, st0));
+        pthread_create(&td, NULL, prove_worker_tolerant, &wd);
+        do {   /* wait until the call is registered on the key (the counters move after the key's use count has been taken) */
+            CHECK(ga_g16_lane_stats(ctx, st1));
+        } while (st1[0] + st1[1] + st1[2] == st0[0] + st0[1] + st0[2]);
+        ga_g16_pk_destroy(pk_tmp);   /* while that proof is in flight */
+        pthread_join(td, NULL);
+        if (wd.failures) {
+            fprintf(stderr, "a proof that overlapped ga_g16_pk_destroy came back wrong\n");
+            return 1;
+        }
     }
 
     /* ---- concurrency ---- */

@@ -92,6 +92,40 @@ def test_cgo_call_pattern_and_concurrency_against_the_emulation_build(tmp_path, 
     assert r.returncode == 0 and "CGO_PATTERN_OK" in r.stdout, r.stdout + r.stderr
 
 
+@pytest.mark.parametrize("curve", ["GA_BN254", "GA_BLS12_381"])
+def test_plonk_call_pattern_against_the_emulation_build(tmp_path, emu_lib, curve):
+    """tests/c_abi/plonk_pattern.c: the device call sequence of the PLONK prover with prove.patch applied (pin both SRS, batched
+    commitment of L, R, O, grand product, pinned + un-pinned quotient, batched commitment of h1..h3, the two openings incl. the fold),
+    every buffer transient and poisoned after its call, replayed twice to identical outputs -- here against the emulation build"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "plonk_pattern_emu")
+    emu_dir = os.path.join(root, "tests", "emu")
+    subprocess.check_call(["gcc", "-std=gnu99", "-O2", "-DPLONK_LOGN=6", "-DPLONK_CURVE=" + curve, "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "c_abi", "plonk_pattern.c"), os.path.join(emu_dir, "libgnark_amd_emu.so"),
+                           "-Wl,-rpath," + emu_dir, "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "PLONK_PATTERN_OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12-381"])
+def test_plonk_prover_patch_applies_to_the_reference(tmp_path, curve):
+    """go/backend/accelerated/mi355x/plonk/<curve>/prove.patch (the Accelerator hooks wired into backend/plonk/<curve>/prove.go)
+    applies cleanly to the reference's file -- the call sites it names exist as quoted"""
+    import shutil
+    import subprocess
+    ref = "/root/reference/backend/plonk/%s/prove.go" % curve
+    if not os.path.exists(ref):
+        pytest.skip("reference tree not present on this box")
+    shutil.copy(ref, tmp_path / "prove.go")
+    patch = os.path.join(ROOT, "go", "backend", "accelerated", "mi355x", "plonk", curve, "prove.patch")
+    r = subprocess.run(["patch", "-p4", "--dry-run", "-i", patch], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0 and "FAILED" not in r.stdout, r.stdout + r.stderr
+    src = open(patch).read()
+    for hook in ("CommitLagrangeBatch", "CommitBatch", "BuildRatioCopyConstraint", "ComputeQuotientRaw", "s.acc.Open(", "LinearCombination"):
+        assert hook in src, hook
+
+
 def test_go_shim_identifiers_resolve():
     """tools/check_go_idents.py: every `pkg.Ident` of go/** is declared in the reference package it is imported from (or, for the
     gnark-crypto dependency that is not in the tree, used by the reference under the same import path), and every `C.ga_*` call

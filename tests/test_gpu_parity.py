@@ -562,6 +562,21 @@ def test_cgo_call_pattern_and_concurrency(tmp_path):
     assert r.returncode == 0 and "CGO_PATTERN_OK" in r.stdout, r.stdout + r.stderr
 
 
+@pytest.mark.parametrize("curve", ["GA_BN254", "GA_BLS12_381"])
+def test_plonk_call_pattern(tmp_path, curve):
+    """tests/c_abi/plonk_pattern.c on the device at n = 2^14: the patched PLONK prover's call order (prove.patch) with transient,
+    poisoned buffers, the struct arguments in C heap, batched == single commitments, pinned == un-pinned quotient, two replays equal"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "plonk_pattern")
+    lib = os.path.join(root, "gnark_amd")
+    subprocess.check_call(["gcc", "-std=gnu99", "-O2", "-DPLONK_LOGN=14", "-DPLONK_CURVE=" + curve, "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "c_abi", "plonk_pattern.c"), "-L", lib, "-lgnark_amd", "-Wl,-rpath," + lib, "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "PLONK_PATTERN_OK" in r.stdout, r.stdout + r.stderr
+
+
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
 @pytest.mark.parametrize("precompute", [1, -1], ids=["tables", "no-tables"])
 def test_groth16_staged_builder(gpu_ctx, c, precompute):
