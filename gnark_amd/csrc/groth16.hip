@@ -7,6 +7,8 @@
 #include <algorithm>
 #include <condition_variable>
 #include <memory>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <thread>
 
@@ -233,6 +235,16 @@ static int stage_finish(G16Stage* st, int precompute, G16Pk** out) {
     }
     if (st->nb_wires >= (1ull << 32)) {
         set_error("proving key: %llu wires exceed the 32-bit wire index space", (unsigned long long)st->nb_wires);
+        return GA_ERR_INVALID;
+    }
+    if (len_a > st->nb_wires || len_b > st->nb_wires || len_k > st->nb_wires || st->k_remove.size() > st->nb_wires ||
+        len_k + st->k_remove.size() > st->nb_wires) {   // (nbWires - len(K) - len(k_remove) = nbPublic >= 0; the wire-indexed layouts rely on it)
+        set_error("proving key: len(A) %llu, len(B) %llu, len(K) %llu + %zu removed wires do not fit %llu wires", (unsigned long long)len_a,
+                  (unsigned long long)len_b, (unsigned long long)len_k, st->k_remove.size(), (unsigned long long)st->nb_wires);
+        return GA_ERR_INVALID;
+    }
+    if (st->inf[0].size() != st->nb_wires || st->inf[1].size() != st->nb_wires) {
+        set_error("proving key: InfinityA / InfinityB must have one entry per wire");
         return GA_ERR_INVALID;
     }
     if (st->win_count > 1 && (st->shard_count > 1 || st->win_index >= st->win_count)) {
@@ -558,13 +570,16 @@ static int decode_stream(Ctx* ctx, Staging& sg, ByteSource& src, uint64_t count,
 }
 
 // a []G1Affine / []G2Affine of the Encoder: u32 BE length, then the points (all compressed or all uncompressed)
+// mode: the encoding of the STREAM (1 compressed, 0 raw), fixed once from [alpha]1 -- which is never infinity -- by pk_read; -1 =
+// unknown, guess from the first byte of the vector (a vector that starts with a point at infinity is then ambiguous on BN254,
+// whose infinity flag is the same in both encodings)
 template <class C, int G>
-static int read_encoded_vector(G16Stage* st, Staging& sg, ByteSource& src, int which, void** d_plain, uint64_t* len_out) {
+static int read_encoded_vector(G16Stage* st, Staging& sg, ByteSource& src, int which, void** d_plain, uint64_t* len_out, int mode = -1) {
     typedef typename GroupField<C, G>::F F;
     uint32_t len = 0;
     GA_CHECK(src.u32be(&len));
-    bool compressed = true;
-    if (len) {
+    bool compressed = mode != 0;
+    if (len && mode < 0) {
         uint8_t b0;
         GA_CHECK(src.peek(&b0, 1));
         PointFlags f;
@@ -719,23 +734,44 @@ static int pk_read(Ctx* ctx, ByteSource& src, int32_t precompute, uint32_t shard
             set_error("key file: %llu wires", (unsigned long long)nb_wires);
             return GA_ERR_INVALID;
         }
+        if (nia > nb_wires || nib > nb_wires) {
+            set_error("key file: %llu / %llu infinity entries for %llu wires", (unsigned long long)nia, (unsigned long long)nib, (unsigned long long)nb_wires);
+            return GA_ERR_INVALID;
+        }
+        if (src.fd < 0 && 2 * nb_wires > src.mem_len - src.mem_pos) {   // (never size a buffer from an untrusted count alone)
+            set_error("key image: unexpected end of input (%llu wires announced, %zu bytes left)", (unsigned long long)nb_wires, src.mem_len - src.mem_pos);
+            return GA_ERR_INVALID;
+        }
         st.nb_wires = nb_wires;
         for (int k = 0; k < 2; k++) {
-            st.inf[k].resize(nb_wires);
-            GA_CHECK(src.read(st.inf[k].data(), nb_wires));
+            st.inf[k].clear();
+            for (uint64_t done = 0; done < nb_wires;) {   // grown as the bytes really arrive
+                const uint64_t cn = nb_wires - done < (1u << 20) ? nb_wires - done : (1u << 20);
+                st.inf[k].resize(done + cn);
+                GA_CHECK(src.read(st.inf[k].data() + done, cn));
+                done += cn;
+            }
             st.have_inf[k] = true;
+            uint64_t ones = 0;
+            for (uint8_t b : st.inf[k]) ones += b != 0;
+            if (ones != (k == 0 ? nia : nib)) {
+                set_error("key file: Infinity%c holds %llu set entries, the header says %llu", k == 0 ? 'A' : 'B', (unsigned long long)ones,
+                          (unsigned long long)(k == 0 ? nia : nib));
+                return GA_ERR_INVALID;
+            }
         }
         return GA_OK;
     };
     uint32_t nb_commitments = 0;
+    int mode = -1;   // compressed (1) or raw (0) stream: taken from [alpha]1, the first point, which is never infinity
     if (!dump) {   // ReadFrom order, marshal.go:316-330
-        GA_CHECK((read_header_point<C, GA_G1>(src, &st.pts[GA_KEY_G1_ALPHA])));
-        GA_CHECK((read_header_point<C, GA_G1>(src, &st.pts[GA_KEY_G1_BETA])));
-        GA_CHECK((read_header_point<C, GA_G1>(src, &st.pts[GA_KEY_G1_DELTA])));
-        for (int w : {GA_KEY_G1_A, GA_KEY_G1_B, GA_KEY_G1_Z, GA_KEY_G1_K}) GA_CHECK((read_encoded_vector<C, GA_G1>(&st, sg, src, w, nullptr, nullptr)));
-        GA_CHECK((read_header_point<C, GA_G2>(src, &st.pts[GA_KEY_G2_BETA])));
-        GA_CHECK((read_header_point<C, GA_G2>(src, &st.pts[GA_KEY_G2_DELTA])));
-        GA_CHECK((read_encoded_vector<C, GA_G2>(&st, sg, src, GA_KEY_G2_B, nullptr, nullptr)));
+        GA_CHECK((read_header_point<C, GA_G1>(src, &st.pts[GA_KEY_G1_ALPHA], &mode)));
+        GA_CHECK((read_header_point<C, GA_G1>(src, &st.pts[GA_KEY_G1_BETA], &mode)));
+        GA_CHECK((read_header_point<C, GA_G1>(src, &st.pts[GA_KEY_G1_DELTA], &mode)));
+        for (int w : {GA_KEY_G1_A, GA_KEY_G1_B, GA_KEY_G1_Z, GA_KEY_G1_K}) GA_CHECK((read_encoded_vector<C, GA_G1>(&st, sg, src, w, nullptr, nullptr, mode)));
+        GA_CHECK((read_header_point<C, GA_G2>(src, &st.pts[GA_KEY_G2_BETA], &mode)));
+        GA_CHECK((read_header_point<C, GA_G2>(src, &st.pts[GA_KEY_G2_DELTA], &mode)));
+        GA_CHECK((read_encoded_vector<C, GA_G2>(&st, sg, src, GA_KEY_G2_B, nullptr, nullptr, mode)));
         GA_CHECK(header_tail());
         GA_CHECK(src.u32be(&nb_commitments));
     } else {       // ReadDump order, marshal.go:459-478
@@ -756,8 +792,8 @@ static int pk_read(Ctx* ctx, ByteSource& src, int32_t precompute, uint32_t shard
     for (uint32_t i = 0; i < nb_commitments; i++) {   // pedersen.ProvingKey: Basis, BasisExpSigma
         void *db = nullptr, *ds = nullptr;
         uint64_t lb = 0, ls = 0;
-        int rc = dump ? read_dumped_vector<C, GA_G1>(&st, sg, src, -1, &db, &lb) : read_encoded_vector<C, GA_G1>(&st, sg, src, -1, &db, &lb);
-        if (rc == GA_OK) rc = dump ? read_dumped_vector<C, GA_G1>(&st, sg, src, -1, &ds, &ls) : read_encoded_vector<C, GA_G1>(&st, sg, src, -1, &ds, &ls);
+        int rc = dump ? read_dumped_vector<C, GA_G1>(&st, sg, src, -1, &db, &lb) : read_encoded_vector<C, GA_G1>(&st, sg, src, -1, &db, &lb, mode);
+        if (rc == GA_OK) rc = dump ? read_dumped_vector<C, GA_G1>(&st, sg, src, -1, &ds, &ls) : read_encoded_vector<C, GA_G1>(&st, sg, src, -1, &ds, &ls, mode);
         if (rc == GA_OK && lb != ls) {
             set_error("key file: commitment key %u has %llu basis points and %llu sigma points", i, (unsigned long long)lb, (unsigned long long)ls);
             rc = GA_ERR_INVALID;
@@ -1747,6 +1783,19 @@ static int prove_multi(G16Pk* const* pks, uint32_t n, const void* w, const void*
 
 using namespace ga;
 
+// no C++ exception may cross the C ABI: host allocations sized from key files / caller arguments are the ones that can throw
+#define GA_NOTHROW_BEGIN try {
+#define GA_NOTHROW_END                                                              \
+    }                                                                               \
+    catch (const std::bad_alloc&) {                                                 \
+        set_error("out of host memory");                                            \
+        return GA_ERR_NOMEM;                                                        \
+    }                                                                               \
+    catch (const std::exception& e) {                                               \
+        set_error("internal error: %s", e.what());                                  \
+        return GA_ERR_STATE;                                                        \
+    }
+
 extern "C" {
 
 int ga_g16_pk_create(ga_ctx* h, const ga_g16_key* key, ga_g16_pk** out) {
@@ -1757,7 +1806,9 @@ int ga_g16_pk_create(ga_ctx* h, const ga_g16_key* key, ga_g16_pk** out) {
     }
     CtxLock g(ctx);
     G16Pk* pk = nullptr;
+    GA_NOTHROW_BEGIN
     GA_CHECK(pk_create_from_struct(ctx, key, &pk));
+    GA_NOTHROW_END
     *out = reinterpret_cast<ga_g16_pk*>(pk);
     return GA_OK;
 }
@@ -1818,7 +1869,9 @@ int ga_g16_builder_set_infinity(ga_g16_builder* b, int which, const uint8_t* mas
         set_error("ga_g16_builder_set_infinity: which must be 0/1 and the mask must have nbWires = %llu entries", (unsigned long long)st->nb_wires);
         return GA_ERR_INVALID;
     }
+    GA_NOTHROW_BEGIN
     st->inf[which].assign(mask, mask + nb_wires);
+    GA_NOTHROW_END
     st->have_inf[which] = true;
     return GA_OK;
 }
@@ -1834,7 +1887,13 @@ int ga_g16_builder_set_k_remove(ga_g16_builder* b, const uint64_t* ids, uint64_t
         set_error("ga_g16_builder_set_k_remove: null pointer");
         return GA_ERR_INVALID;
     }
+    if (len > st->nb_wires) {
+        set_error("ga_g16_builder_set_k_remove: %llu removed wires for %llu wires", (unsigned long long)len, (unsigned long long)st->nb_wires);
+        return GA_ERR_INVALID;
+    }
+    GA_NOTHROW_BEGIN
     st->k_remove.assign(ids, ids + len);
+    GA_NOTHROW_END
     return GA_OK;
 }
 
@@ -1860,8 +1919,13 @@ int ga_g16_builder_finish(ga_g16_builder* b, int32_t precompute, ga_g16_pk** out
         CtxLock g(st->ctx);
         G16Pk* pk = nullptr;
         rc = GA_ERR_INVALID;
-        if (st->curve == GA_BN254) rc = stage_finish<Bn254>(st, precompute, &pk);
-        else if (st->curve == GA_BLS12_381) rc = stage_finish<Bls12381>(st, precompute, &pk);
+        try {
+            if (st->curve == GA_BN254) rc = stage_finish<Bn254>(st, precompute, &pk);
+            else if (st->curve == GA_BLS12_381) rc = stage_finish<Bls12381>(st, precompute, &pk);
+        } catch (const std::exception& e) {   // (host allocations sized by the key: no exception crosses the C ABI)
+            set_error("ga_g16_builder_finish: %s", e.what());
+            rc = GA_ERR_NOMEM;
+        }
         if (rc == GA_OK) *out = reinterpret_cast<ga_g16_pk*>(pk);
     }
     delete st;   // consumed either way: a failed finish leaves nothing half-built behind
@@ -2175,7 +2239,9 @@ static int pk_read_any(ga_ctx* h, int curve, ByteSource& src, int32_t precompute
     }
     CtxLock g(ctx);
     G16Pk* pk = nullptr;
+    GA_NOTHROW_BEGIN
     GA_DISPATCH_CURVE(curve, GA_CHECK(pk_read<C>(ctx, src, precompute, shard_index, shard_count, k_remove, len_k_remove, &pk)));
+    GA_NOTHROW_END
     *out = reinterpret_cast<ga_g16_pk*>(pk);
     if (bytes_read) *bytes_read = src.consumed;
     return GA_OK;

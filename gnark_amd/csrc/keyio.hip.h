@@ -177,6 +177,15 @@ GA_HD bool point_decode(const uint8_t* b, bool compressed, Affine<typename Group
         return true;
     }
     if (f.compressed != compressed) return false;
+    if (!compressed) {   // an uncompressed point of all-zero bytes is accepted as infinity as well (lenient: the flagged form is 0x40 | 0...)
+        bool all_zero = true;
+        for (int i = 0; i < 2 * CB; i++) all_zero = all_zero && b[i] == 0;
+        if (all_zero) {
+            out->x = FieldTraits<F>::zero();
+            out->y = FieldTraits<F>::zero();
+            return true;
+        }
+    }
     F x, y;
     if (!coord_from_bytes(b, f.mask, &x)) return false;
     const F rhs = add(mul(sqr(x), x), CurveB<C, G>::get());

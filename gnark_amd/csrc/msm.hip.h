@@ -1085,6 +1085,15 @@ int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, X
     // once more with the complete lazy loop, then whatever is left with the exact kernel.  A table on which most tasks were flagged
     // (a DummySetup key: every base the same point) is remembered and gets the complete loop directly from then on.
     uint32_t h_redo = 0;
+    // the count of flagged tasks is copied into this stack variable asynchronously: every return path, the early error returns
+    // included, must leave with that copy finished
+    struct PendingRead {
+        hipStream_t st;
+        bool pending = false;
+        ~PendingRead() {
+            if (pending) hipStreamSynchronize(st);
+        }
+    } redo_read{ctx->work_stream()};
     const uint32_t* acc_table = (const uint32_t*)d_bases;
     {
         uint32_t *redo_list, *redo_count, *redo2_list;
@@ -1125,6 +1134,7 @@ int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, X
                            (const uint32_t*)(redo_count + 1), (const uint32_t*)P.task_dest, bsum);
         GA_KERNEL_CHECK();
         GA_HIP_CHECK(hipMemcpyAsync(&h_redo, redo_count, 4, hipMemcpyDeviceToHost, st));   // read after the stream's final sync below
+        redo_read.pending = true;
     }
     auto note_degenerate = [&]() {
         if (P.table && (uint64_t)h_redo * 4 > P.max_tasks) ctx->mark_degenerate(d_bases);

@@ -1172,6 +1172,41 @@ def test_emu_proving_key_files(emu_ctx, c, circuit, tmp_path):
         groth16.ProvingKey.ReadFrom(emu_ctx, c.name, bytes(bad), k_remove=removed)
     with pytest.raises(Exception, match="end of input"):
         groth16.ProvingKey.ReadFrom(emu_ctx, c.name, images[groth16.KEY_FORMAT_RAW][:-7], k_remove=removed)
+    # a vector whose FIRST point is infinity (an unused first private wire): on BN254 the infinity flag is the same byte in the
+    # compressed and the raw encoding, so the stream's mode must come from [alpha]1, not from the vector's first byte
+    if circuit == "cubic":
+        import copy
+        pk0 = copy.copy(pk)
+        pk0.K = [None] + list(pk.K[1:])
+        f0 = _py_key_fields(c, pk0)
+        ref = groth16.ProvingKey(emu_ctx, c.name, **f0)
+        try:
+            want0 = groth16.Prove(ref, sol, cs.nb_public, r, s).raw()
+        finally:
+            ref.FreeGPUResources()
+        assert not np.array_equal(want0, want)
+        for raw in (False, True):
+            dpk = groth16.ProvingKey.ReadFrom(emu_ctx, c.name, pyref.pk_write(pk0, raw=raw))
+            try:
+                assert np.array_equal(groth16.Prove(dpk, sol, cs.nb_public, r, s).raw(), want0), raw
+            finally:
+                dpk.FreeGPUResources()
+        # an all-zero uncompressed point is accepted as infinity too (lenient reading of RawBytes)
+        img = bytearray(pyref.pk_write(pk0, raw=True))
+        nbp = c.fp_bytes
+        k_off = 8 + 160 + 1 + 3 * 2 * nbp + sum(4 + 2 * nbp * len(v) for v in (pk0.A, pk0.B, pk0.Z)) + 4
+        assert img[k_off] == 0x40 and not any(img[k_off + 1:k_off + 2 * nbp])
+        img[k_off] = 0
+        dpk = groth16.ProvingKey.ReadFrom(emu_ctx, c.name, bytes(img))
+        try:
+            assert np.array_equal(groth16.Prove(dpk, sol, cs.nb_public, r, s).raw(), want0)
+        finally:
+            dpk.FreeGPUResources()
+        # a key whose vectors cannot belong to its wire count is refused before anything is laid out by wire id
+        bad_fields = dict(fields)
+        bad_fields["K"] = np.concatenate([fields["K"]] * 4)
+        with pytest.raises(Exception, match="do not fit|inconsistent|len"):
+            groth16.ProvingKey(emu_ctx, c.name, **bad_fields)
 
 
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
