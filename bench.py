@@ -50,6 +50,21 @@ def parse():
     return ap.parse_args()
 
 
+def effective_cores():
+    """CPUs this process can really use: the affinity mask capped by the cgroup CPU quota (the GPU boxes show 256 logical CPUs and
+    a quota of 16: cpu.max = "1600000 100000")."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    eff = n if quota is None else max(1, min(n, int(quota + 0.5)))
+    return eff, n, quota
+
+
 def stage_stats(records):
     agg = {}
     for name, ms in records:
@@ -150,7 +165,8 @@ def main():
     # ---- inputs resident in HBM ---------------------------------------------------------------------------
     bases = ctx.malloc(n * words_aff * 8)
     scalars = ctx.malloc(n * 32)
-    lib.check(lib.ga_gen_bases(ctx.handle, cid, _lib.G1, 0x5EED0002 + 977 * rank, n, bases.ptr, None))
+    base_dlogs = ctx.malloc(n * 32) if (world == 1 and not args.no_check) else None   # k_i of [k_i]G: the timed result is checked against them
+    lib.check(lib.ga_gen_bases(ctx.handle, cid, _lib.G1, 0x5EED0002 + 977 * rank, n, bases.ptr, base_dlogs.ptr if base_dlogs else None))
     lib.check(lib.ga_gen_scalars(ctx.handle, cid, 0x5EED0001 + 977 * rank, n, scalars.ptr))
     # the bases are a pinned key: keep them with their window multiples (ga_msm_table_*, built outside the timed region)
     use_table = os.environ.get("GA_BENCH_TABLE", "1") != "0"
@@ -197,23 +213,37 @@ def main():
 
     ms_per_step = elapsed * 1e3 / args.steps
     value = world * n * args.steps / elapsed / 1e6
+    # is the timed result THE result?  MSM(s, [k_i]G) = [sum s_i k_i]G: the exponent by a dot product on the CPU oracle, the point by
+    # the oracle's fixed-base multiplication -- outside the timed region, N = 1 only (the oracle is the checker, never the thing timed)
+    value_checked = None
+    if base_dlogs is not None:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import oracle
+            e = oracle.fr_dot(cid, scalars.to_host((n, 4)), base_dlogs.to_host((n, 4)))
+            want_pt = oracle.jac_to_affine(cid, 0, oracle.generator_mul(cid, 0, e))
+            value_checked = bool(np.array_equal(ecc.jac_to_affine(cid, _lib.G1, result), want_pt))
+        except Exception as ex:   # a failing checker is reported, it does not hide the measurement
+            value_checked = "checker error: " + repr(ex)[:200]
+        base_dlogs.free()
 
     out = None
     if rank == 0:
         acc = stages.get("msm_accumulate", {"avg_ms": float("nan")})
         alg_bytes = 96.0 * n if cid == 0 else 128.0 * n
         achieved = alg_bytes / (acc["avg_ms"] * 1e-3) / 1e9
-        traffic = None   # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_latest.json), same shape only
+        traffic, traffic_source = None, None   # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_latest.json), same shape only
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))["kernels"]["msm_accumulate_kernel"]
-            ent = pmc.get(args.curve, {}).get(str(args.log_n))
+            pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+            ent = pj["kernels"]["msm_accumulate_kernel"].get(args.curve, {}).get(str(args.log_n))
             if ent and world == 1:
                 traffic = ent["fetch_bytes"] + ent["write_bytes"]
+                traffic_source = "profiles/pmc_latest.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (%s) of this kernel at this shape, not re-measured in this run" % pj.get("source", "round 2")
         except (OSError, KeyError, ValueError):
             pass
         out = {
             "metric": "G1 MSM throughput, %s, 2^%d scalar-muls per GPU (Groth16 proofs/s at 2^%d constraints in 'groth16')" % (args.curve.upper(), args.log_n, args.log_n),
-            "value": round(value, 3), "unit": "Mscalar-mul/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 3), "value_checked": value_checked, "unit": "Mscalar-mul/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64 Montgomery limbs in memory; 29/28-bit limbs, v_mad_u64_u32 (32x32+64) in registers", "data": "emulation" if emu else "synthetic",
             "config": {"workload": "%s G1 Pippenger MSM, 2^%d uniform scalars x distinct known-dlog affine bases per GPU, inputs resident in HBM" % (args.curve.upper(), args.log_n),
@@ -221,7 +251,7 @@ def main():
                        "precompute": ("[2^(c*w)]P tables for all %d windows, %.1f GiB, one shared bucket set" % (nwin, ti["table_bytes"] / 2**30)) if use_table else "none",
                        "parallelism": "1 GPU" if world == 1 else "base-range sharding x%d, RCCL all_gather of Jacobian partials" % world},
             "roofline": {"bound": "hbm", "kernel": "msm_accumulate29_kernel" if use_table else "msm_accumulate_kernel", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(achieved / 8000.0, 6), "traffic": traffic,
+                         "frac": round(achieved / 8000.0, 6), "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": acc["avg_ms"],
                          "note": "MSM is integer-multiplier bound (SURVEY 8d): ~2.4e4 32-bit MADs per scalar-mul vs 96 B",
                          # "report achieved MAD/s fraction": v_mad_u64_u32 per mixed addition from the shipped ISA
@@ -366,81 +396,121 @@ def main():
     # key sharded by base-point range (or by windows), W uploaded per wire range, computeH's chains on ranks 0..2, h slices scattered
     # over xGMI, one all_gather of the partial sums (gnark_amd/multigpu.py)
     if world > 1 and args.groth16_proofs > 0 and os.environ.get("GA_BENCH_SHARDED_G16", "1") != "0":
-        g16 = None
-        try:
-            import psutil
-            need = (12 << 30) * (1 << args.log_n) // (1 << 24) + (2 << 30)   # full synthetic key + solution staged on the host per rank
-            if psutil.virtual_memory().available < need * world:
-                raise RuntimeError("not enough host memory to stage %d synthetic keys" % world)
-            from gnark_amd import groth16, synth
-            if table is None:
-                bases.free()
-                scalars.free()
-            inst = synth.make_instance(ctx, cid, args.log_n, 0x5EED0005, want_dlogs=False)   # same seeds on every rank
-            kw = dict(shard=(rank, world), precompute=1) if args.partition == "range" else dict(window_shard=(rank, world), precompute=1)
-            t_pin = time.perf_counter()
-            pk = inst.proving_key(ctx, **kw)
-            pin_s = time.perf_counter() - t_pin
-            sol, nb_public, r, s = inst.solution, inst.nb_public, inst.r, inst.s
-            multigpu.groth16_prove_sharded(pk, sol, nb_public, r, s, dist, dev)   # warm-up
-            fence()
-            t0 = time.perf_counter()
-            for _ in range(args.groth16_proofs):
-                proof = multigpu.groth16_prove_sharded(pk, sol, nb_public, r, s, dist, dev)
-            fence()
-            el = time.perf_counter() - t0
-            rep_ms = None
-            if os.environ.get("GA_BENCH_REPLICATE_H", "0") == "1":   # the round-1 scheme, for comparison
-                multigpu.groth16_prove_sharded(pk, sol, nb_public, r, s, dist, dev, replicate_h=True)
+        from gnark_amd import groth16, synth
+        if table is None:
+            bases.free()
+            scalars.free()
+
+        def sharded_leg(leg_cid, leg_curve):
+            """one 2^log_n proof over the world's GPUs.  Every rank generates ITS shard of the synthetic key on its own device, chunk
+            by chunk (synth.pin_key_chunked: no 12 GiB key is staged through host memory), and the solution (the prover's real input)."""
+            try:
+                inst = synth.make_instance(ctx, leg_cid, args.log_n, 0x5EED0005, want_dlogs=False, with_key=False)   # same seeds on every rank
+                kw = dict(shard=(rank, world)) if args.partition == "range" else dict(window_shard=(rank, world))
+                t_pin = time.perf_counter()
+                pk = synth.pin_key_chunked(ctx, inst, precompute=1, **kw)
+                pin_s = time.perf_counter() - t_pin
+                sol, nb_public, r, s = inst.solution, inst.nb_public, inst.r, inst.s
+                multigpu.groth16_prove_sharded(pk, sol, nb_public, r, s, dist, dev)   # warm-up
                 fence()
                 t0 = time.perf_counter()
-                multigpu.groth16_prove_sharded(pk, sol, nb_public, r, s, dist, dev, replicate_h=True)
+                for _ in range(args.groth16_proofs):
+                    proof = multigpu.groth16_prove_sharded(pk, sol, nb_public, r, s, dist, dev)
                 fence()
-                rep_ms = round((time.perf_counter() - t0) * 1e3, 2)
-            lay = groth16.ShardLayout(pk)
-            pk.FreeGPUResources()
-            tm = torch.tensor([el], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-            el = float(tm.item())
-            g16 = {"proofs_per_s": round(args.groth16_proofs / el, 4), "ms_per_proof": round(el * 1e3 / args.groth16_proofs, 2),
-                   "proofs": args.groth16_proofs, "constraints": n, "scaling": "strong", "partition": args.partition,
-                   "mode": ("one proof over %d GPUs: key sharded by base-point range (1/%d of the tables per GPU), W uploaded per wire range "
-                            "(%d of %d wires on rank 0), A,B,C uploaded 1/N per rank and gathered on the chain owners (N >= 3), computeH chains on ranks 0-2 beside the witness MSMs, h slices scattered, all_gather of 5 partial points" %
-                            (world, world, lay["w_hi"] - lay["w_lo"], lay["nb_wires"])) if args.partition == "range" else
-                           ("one proof over %d GPUs: whole key on every GPU, windows of every MSM shared out, h broadcast, all_gather of 5 partial points" % world),
-                   "key_pin_s": round(pin_s, 1), "replicate_h_ms_per_proof": rep_ms,
-                   "proof_sha": __import__("hashlib").sha256(proof.WriteTo()).hexdigest()[:16]}
-        except Exception as e:   # never lose the headline line because of the optional leg
-            g16 = {"error": repr(e)[:300]}
+                el = time.perf_counter() - t0
+                rep_ms = None
+                if os.environ.get("GA_BENCH_REPLICATE_H", "0") == "1":   # the round-1 scheme, for comparison
+                    multigpu.groth16_prove_sharded(pk, sol, nb_public, r, s, dist, dev, replicate_h=True)
+                    fence()
+                    t0 = time.perf_counter()
+                    multigpu.groth16_prove_sharded(pk, sol, nb_public, r, s, dist, dev, replicate_h=True)
+                    fence()
+                    rep_ms = round((time.perf_counter() - t0) * 1e3, 2)
+                lay = groth16.ShardLayout(pk)
+                pk.FreeGPUResources()
+                tm = torch.tensor([el], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                el = float(tm.item())
+                return {"curve": leg_curve, "proofs_per_s": round(args.groth16_proofs / el, 4), "ms_per_proof": round(el * 1e3 / args.groth16_proofs, 2),
+                        "proofs": args.groth16_proofs, "constraints": n, "scaling": "strong", "partition": args.partition,
+                        "mode": ("one proof over %d GPUs: key sharded by base-point range (1/%d of the tables per GPU, each rank generates only its shard), W uploaded per wire range "
+                                 "(%d of %d wires on rank 0), A,B,C uploaded 1/N per rank and gathered on the chain owners (N >= 3), computeH chains on ranks 0-2 beside the witness MSMs, h slices scattered, all_gather of 5 partial points" %
+                                 (world, world, lay["w_hi"] - lay["w_lo"], lay["nb_wires"])) if args.partition == "range" else
+                                ("one proof over %d GPUs: whole key on every GPU, windows of every MSM shared out, h broadcast, all_gather of 5 partial points" % world),
+                        "key_pin_s": round(pin_s, 1), "replicate_h_ms_per_proof": rep_ms,
+                        "proof_sha": __import__("hashlib").sha256(proof.WriteTo()).hexdigest()[:16]}
+            except Exception as e:   # never lose the headline line because of the optional leg
+                return {"curve": leg_curve, "error": repr(e)[:300]}
+        g16 = sharded_leg(cid, args.curve)
+        # BASELINE config 4 (Groth16 BLS12-381 at 2^24 over 8 GPUs) appears in the same line once the node has 8 ranks
+        g16_bls = None
+        if cid == 0 and (world >= 8 or os.environ.get("GA_BENCH_CONFIG4", "0") == "1"):
+            g16_bls = sharded_leg(curve_id("bls12-381"), "bls12-381")
         if rank == 0:
             out["groth16"] = g16
+            if g16_bls is not None:
+                out["groth16_bls12_381"] = g16_bls
 
     # ---- CPU baseline: the oracle's Pippenger on a bounded sample (rank 0, N=1) ----------------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle
-        host_cores = os.cpu_count() or 1
+        eff_cores, logical_cpus, quota = effective_cores()
         sample_log = min(args.log_n, 24)
         sn = 1 << sample_log
-        sb = ctx.malloc(sn * words_aff * 8)
-        lib.check(lib.ga_gen_bases(ctx.handle, cid, _lib.G1, 0x5EED0002, sn, sb.ptr, None))
-        P = sb.to_host((sn, words_aff))
-        ss = ctx.malloc(sn * 32)
-        lib.check(lib.ga_gen_scalars(ctx.handle, cid, 0x5EED0001, sn, ss.ptr))
-        S = ss.to_host((sn, 4))
-        t0 = time.perf_counter()
-        ref = oracle.msm(cid, 0, P, S, nthreads=host_cores)
-        cpu_s = time.perf_counter() - t0
-        gpu = ecc.MultiExp(ctx, cid, _lib.G1, sb, ss, n=sn)
-        same = bool(np.array_equal(oracle.jac_to_affine(cid, 0, ref), ecc.jac_to_affine(cid, _lib.G1, gpu)))
-        sb.free()
-        ss.free()
-        threads_used = min(host_cores, oracle.msm_windows(cid, sn))   # the port runs one thread per Pippenger window
+
+        def cpu_vs_gpu(logn):
+            """the oracle's Pippenger and the library's plain (un-pinned bases: no table) MSM on the same 2^logn inputs"""
+            m = 1 << logn
+            sb = ctx.malloc(m * words_aff * 8)
+            lib.check(lib.ga_gen_bases(ctx.handle, cid, _lib.G1, 0x5EED0002, m, sb.ptr, None))
+            P = sb.to_host((m, words_aff))
+            ss = ctx.malloc(m * 32)
+            lib.check(lib.ga_gen_scalars(ctx.handle, cid, 0x5EED0001, m, ss.ptr))
+            S = ss.to_host((m, 4))
+            t0 = time.perf_counter()
+            ref = oracle.msm(cid, 0, P, S, nthreads=eff_cores)
+            cpu = time.perf_counter() - t0
+            gpu_res = ecc.MultiExp(ctx, cid, _lib.G1, sb, ss, n=m)   # (also the warm-up of the timed repetitions below)
+            reps = 5
+            ctx.profile(True)
+            ctx.profile_reset()
+            ctx.sync()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                ecc.MultiExp(ctx, cid, _lib.G1, sb, ss, n=m)
+            ctx.sync()
+            gpu = (time.perf_counter() - t0) / reps
+            st = stage_stats(ctx.profile_read())
+            ctx.profile(False)
+            same = bool(np.array_equal(oracle.jac_to_affine(cid, 0, ref), ecc.jac_to_affine(cid, _lib.G1, gpu_res)))
+            sb.free()
+            ss.free()
+            return cpu, gpu, same, st
+        cpu_s, _, same, _ = cpu_vs_gpu(sample_log)
+        threads_used = min(eff_cores, oracle.msm_windows(cid, sn))   # the port runs one thread per Pippenger window
         out["cpu_baseline"] = {"value": round(sn / cpu_s / 1e6, 4), "unit": "Mscalar-mul/s", "cores": threads_used, "threads_used": threads_used,
-                               "host_cores": host_cores, "kind": "port",
-                               "sample": "%s G1 MSM of 2^%d points, oracle/oracle.c Pippenger (one thread per window), %.1f s" % (args.curve.upper(), sample_log, cpu_s),
+                               "effective_cores": eff_cores, "logical_cpus": logical_cpus, "cgroup_cpu_quota": quota, "host_cores": logical_cpus, "kind": "port",
+                               "sample": "%s G1 MSM of 2^%d points, oracle/oracle.c Pippenger (one thread per window: %d windows, %d usable CPUs), %.1f s" % (args.curve.upper(), sample_log, oracle.msm_windows(cid, sn), eff_cores, cpu_s),
                                "gpu_result_matches_oracle": same,
-                               "note": "a plain-C restatement (64-bit CIOS, no assembly), NOT gnark-crypto: gnark cannot be built here (no Go toolchain)"}
+                               "note": "a plain-C restatement (64-bit CIOS, no assembly), NOT gnark-crypto: gnark cannot be built here (no Go toolchain); the box shows %d logical CPUs but its cgroup grants %s of them" % (logical_cpus, "all" if quota is None else "%.0f" % quota)}
+        # BASELINE config 2: G1 MSM over 2^20 random, UN-PINNED bases (ga_msm: bases converted per call, no table), GPU beside the CPU port
+        if args.log_n >= 20:
+            try:
+                c2_cpu, c2_gpu, c2_same, c2_st = cpu_vs_gpu(20)
+                acc2 = c2_st.get("msm_accumulate", {}).get("avg_ms")
+                alg2 = (96.0 if cid == 0 else 128.0) * (1 << 20)
+                out["config2_msm_2p20_unpinned"] = {
+                    "gpu_ms_per_msm": round(c2_gpu * 1e3, 3), "gpu_Mscalar_mul_per_s": round((1 << 20) / c2_gpu / 1e6, 2),
+                    "cpu_port_Mscalar_mul_per_s": round((1 << 20) / c2_cpu / 1e6, 4), "cpu_threads": min(eff_cores, oracle.msm_windows(cid, 1 << 20)),
+                    "gpu_result_matches_oracle": c2_same,
+                    "roofline": {"bound": "hbm", "kernel": "msm_accumulate29_kernel (raw bases: one bucket set per window)", "avg_launch_ms": acc2,
+                                 "algorithmic_bytes_per_launch": alg2, "achieved": round(alg2 / (acc2 * 1e-3) / 1e9, 3) if acc2 else None, "peak": 8000.0, "unit": "GB/s",
+                                 "frac": round(alg2 / (acc2 * 1e-3) / 8e12, 6) if acc2 else None},
+                    "how": "ga_msm on device-resident raw affine bases and Montgomery scalars, 5 timed calls; the CPU port on the same inputs"}
+            except Exception as e:
+                out["config2_msm_2p20_unpinned"] = {"error": repr(e)[:300]}
+        host_cores = eff_cores
         # proofs/s for the same port: the oracle's Groth16 prover (7 FFTs + 4 G1 + 1 G2 MSM) on a bounded 2^20-constraint sample
         if args.groth16_proofs > 0:
             try:
@@ -456,7 +526,7 @@ def main():
                 gpk.FreeGPUResources()
                 g_same = bool(np.array_equal(gp.Ar, want[0]) and np.array_equal(gp.Bs, want[1]) and np.array_equal(gp.Krs, want[2]))
                 out["cpu_baseline"]["groth16"] = {"proofs_per_s": round(1.0 / g_s, 4), "constraints": 1 << glog, "kind": "port", "threads_used": host_cores,
-                                                  "sample": "oracle/oracle.c Groth16 prover, 2^%d constraints, %.1f s" % (glog, g_s),
+                                                  "sample": "oracle/oracle.c Groth16 prover, 2^%d constraints, %d threads, %.1f s" % (glog, host_cores, g_s),
                                                   "gpu_proof_matches_oracle": g_same}
             except Exception as e:
                 out["cpu_baseline"]["groth16"] = {"error": repr(e)[:300]}

@@ -138,6 +138,7 @@ _PROTOS = {
     "ga_profile_reset": (C.c_int, [_P]),
     "ga_profile_read": (C.c_int, [_P, C.c_char_p, C.c_size_t]),
     "ga_gen_bases": (C.c_int, [_P, C.c_int, C.c_int, C.c_uint64, C.c_size_t, _P, _P]),
+    "ga_gen_bases_at": (C.c_int, [_P, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_size_t, _P, _P]),
     "ga_gen_scalars": (C.c_int, [_P, C.c_int, C.c_uint64, C.c_size_t, _P]),
     "ga_fr_dot": (C.c_int, [_P, C.c_int, _P, _P, C.c_size_t, _P]),
     "ga_generator_mul": (C.c_int, [C.c_int, C.c_int, _P, _P]),

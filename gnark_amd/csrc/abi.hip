@@ -820,6 +820,14 @@ int ga_gen_bases(ga_ctx* h, int curve, int group, uint64_t seed, size_t n, void*
     return GA_OK;
 }
 
+int ga_gen_bases_at(ga_ctx* h, int curve, int group, uint64_t seed, uint64_t first, size_t n, void* bases_dev, void* dlogs_dev) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    Lock l(c);
+    GA_DISPATCH_CURVE(curve, GA_DISPATCH_GROUP(group, GA_CHECK((util_gen_bases<C, G>(c, seed, n, bases_dev, dlogs_dev, first)))));
+    GA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return GA_OK;
+}
+
 int ga_gen_scalars(ga_ctx* h, int curve, uint64_t seed, size_t n, void* scalars_dev) {
     Ctx* c = reinterpret_cast<Ctx*>(h);
     Lock l(c);

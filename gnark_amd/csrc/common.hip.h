@@ -325,7 +325,7 @@ template <class C> int fr_vec_lincomb(Ctx* ctx, uint64_t n, int k, const void* c
 template <class C> int kzg_domain_divide(Ctx* ctx, const void* d_poly, uint64_t n, const void* z_mont, void* d_quot, void* value_out);
 
 // utility kernels (util_*.hip)
-template <class C, int G> int util_gen_bases(Ctx* ctx, uint64_t seed, size_t n, void* d_bases, void* d_dlogs);
+template <class C, int G> int util_gen_bases(Ctx* ctx, uint64_t seed, size_t n, void* d_bases, void* d_dlogs, uint64_t first = 0);
 template <class C> int util_gen_scalars(Ctx* ctx, uint64_t seed, size_t n, void* d_scalars);
 template <class C> int util_fr_dot(Ctx* ctx, const void* d_a, const void* d_b, size_t n, void* h_out);
 template <class C> int util_fr_vec_mul(Ctx* ctx, const void* d_a, const void* d_b, size_t n, void* d_out);

@@ -1852,8 +1852,20 @@ int ga_g16_builder_reserve(ga_g16_builder* b, int which, uint64_t total_len) {
 int ga_g16_builder_append(ga_g16_builder* b, int which, const void* points, uint64_t count) {
     GA_STAGE(b);
     if (count && !points) {
-        set_error("ga_g16_builder_append: null pointer");
-        return GA_ERR_INVALID;
+        // skipping is allowed for points that are none of this shard's business
+        if (which < 0 || which >= GA_KEY_NB_VECTORS || !st->v[which].reserved) {
+            set_error("ga_g16_builder_append: skip on vector %d before ga_g16_builder_reserve", which);
+            return GA_ERR_STATE;
+        }
+        G16Stage::Vec& x = st->v[which];
+        const bool outside = x.seen + count <= x.lo || x.seen >= x.lo + x.cnt;
+        if (!outside || x.seen + count > x.total) {
+            set_error("ga_g16_builder_append: null pointer for points [%llu, %llu) of vector %d, of which this shard keeps [%llu, %llu)",
+                      (unsigned long long)x.seen, (unsigned long long)(x.seen + count), which, (unsigned long long)x.lo, (unsigned long long)(x.lo + x.cnt));
+            return GA_ERR_INVALID;
+        }
+        x.seen += count;
+        return GA_OK;
     }
     return stage_append(st, which, points, count);
 }

@@ -8,11 +8,11 @@ namespace ga {
 // bases[i] = [k_i]G with k_i = splitmix64(seed, i) | 1  (64-bit, odd => never zero); dlogs[i] = k_i as canonical fr
 template <class C, int G>
 __global__ void __launch_bounds__(64)
-gen_bases_kernel(uint64_t seed, uint64_t n, void* __restrict__ bases, uint32_t* __restrict__ dlogs) {
+gen_bases_kernel(uint64_t seed, uint64_t first, uint64_t n, void* __restrict__ bases, uint32_t* __restrict__ dlogs) {
     typedef typename GroupField<C, G>::F F;
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint64_t k = splitmix64(seed ^ splitmix64(i)) | 1ull;
+    uint64_t k = splitmix64(seed ^ splitmix64(first + i)) | 1ull;   // element `first + i` of the seed's sequence
     uint32_t kw[2] = {(uint32_t)k, (uint32_t)(k >> 32)};
     XYZZ<F> p = scalar_mul(to_xyzz(Generator<C, G>::get()), kw, 2);
     Affine<F> a = to_affine(p);
@@ -85,10 +85,10 @@ __global__ void gather_fr_kernel(uint32_t* __restrict__ dst, const uint32_t* __r
 }
 
 template <class C, int G>
-int util_gen_bases(Ctx* ctx, uint64_t seed, size_t n, void* d_bases, void* d_dlogs) {
+int util_gen_bases(Ctx* ctx, uint64_t seed, size_t n, void* d_bases, void* d_dlogs, uint64_t first) {
     if (n == 0) return GA_OK;
     StageTimer tm(ctx, "gen_bases");
-    hipLaunchKernelGGL((gen_bases_kernel<C, G>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->work_stream(), seed, (uint64_t)n,
+    hipLaunchKernelGGL((gen_bases_kernel<C, G>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->work_stream(), seed, first, (uint64_t)n,
                        d_bases, (uint32_t*)d_dlogs);
     GA_KERNEL_CHECK();
     return GA_OK;

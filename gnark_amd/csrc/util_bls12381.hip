@@ -1,8 +1,8 @@
 // Explicit instantiation: synthetic-input / checking kernels, bls12381 (see util.hip.h).
 #include "util.hip.h"
 namespace ga {
-template int util_gen_bases<Bls12381, GA_G1>(Ctx*, uint64_t, size_t, void*, void*);
-template int util_gen_bases<Bls12381, GA_G2>(Ctx*, uint64_t, size_t, void*, void*);
+template int util_gen_bases<Bls12381, GA_G1>(Ctx*, uint64_t, size_t, void*, void*, uint64_t);
+template int util_gen_bases<Bls12381, GA_G2>(Ctx*, uint64_t, size_t, void*, void*, uint64_t);
 template int util_gen_scalars<Bls12381>(Ctx*, uint64_t, size_t, void*);
 template int util_fr_dot<Bls12381>(Ctx*, const void*, const void*, size_t, void*);
 template int util_fr_vec_mul<Bls12381>(Ctx*, const void*, const void*, size_t, void*);

@@ -136,6 +136,14 @@ class ProvingKey:
     """setup.go:25-48 fields, uploaded once ("PinToGPU"); free with FreeGPUResources() (icicle.go:1493)."""
 
     @classmethod
+    def from_handle(cls, ctx: Context, curve, handle, *, nb_wires: int, domain_cardinality: int, shard=(0, 1)):
+        """wrap a key that was built directly through ga_g16_builder_* (gnark_amd/synth.py pin_key_chunked)"""
+        self = cls.__new__(cls)
+        self.ctx, self.curve, self.shard = ctx, curve_id(curve), (int(shard[0]), int(shard[1]))
+        self.handle, self.nb_wires, self.domain_cardinality, self.nb_commitments = handle, int(nb_wires), int(domain_cardinality), 0
+        return self
+
+    @classmethod
     def ReadFrom(cls, ctx: Context, curve, source, *, precompute: int = 0, shard=(0, 1), k_remove=()):
         """ProvingKey.ReadFrom / UnsafeReadFrom / ReadDump (marshal.go:305-373,449-539) straight into HBM: source is bytes or an
         open binary file; the format (compressed / raw points / dump) is recognised from the stream.  k_remove: see __init__."""

@@ -79,10 +79,18 @@ def _gen_scalars(ctx: Context, cid: int, count: int, seed: int) -> np.ndarray:
     return host
 
 
+def _vector_plan(nw: int, n: int, nb_public: int, infA, infB):
+    """(name, group, length, seed offset) of the five base vectors of the synthetic key"""
+    return (("A", 0, nw - int(infA.sum()), 1), ("B", 0, nw - int(infB.sum()), 2), ("Z", 0, n - 1, 3), ("K", 0, nw - nb_public, 4),
+            ("B2", 1, nw - int(infB.sum()), 5))
+
+
 def make_instance(ctx: Context, curve, logn: int, seed: int = 0x5EED0005, *, nb_constraints: int | None = None, nb_public: int = 2,
-                  inf_a=None, inf_b=None, want_dlogs: bool = True, product_c: bool = True) -> Instance:
+                  inf_a=None, inf_b=None, want_dlogs: bool = True, product_c: bool = True, with_key: bool = True) -> Instance:
     """2^logn-constraint instance in the shape of SURVEY 8d config 3: nbWires = n, two infinity entries in A and in B like the
-    squaring-chain circuit of backend/groth16/groth16_test.go:120-132, len(K) = nbWires - nbPublic, len(Z) = n - 1."""
+    squaring-chain circuit of backend/groth16/groth16_test.go:120-132, len(K) = nbWires - nbPublic, len(Z) = n - 1.
+    with_key=False leaves the five base vectors out (12 GiB of host memory at 2^24): pin_key_chunked generates and pins them
+    chunk by chunk, and only the slice a shard keeps."""
     cid = curve_id(curve)
     n = 1 << logn
     nw = n
@@ -94,9 +102,9 @@ def make_instance(ctx: Context, curve, logn: int, seed: int = 0x5EED0005, *, nb_
     infA[inf_a] = 1
     infB[inf_b] = 1
     key, dl = {}, {}
-    for name, group, count, sd in (("A", 0, nw - int(infA.sum()), 1), ("B", 0, nw - int(infB.sum()), 2), ("Z", 0, n - 1, 3),
-                                   ("K", 0, nw - nb_public, 4), ("B2", 1, nw - int(infB.sum()), 5)):
-        key[name], dl[name] = _gen_bases(ctx, cid, group, count, seed + sd, want_dlogs)
+    for name, group, count, sd in _vector_plan(nw, n, nb_public, infA, infB):
+        if with_key:
+            key[name], dl[name] = _gen_bases(ctx, cid, group, count, seed + sd, want_dlogs)
     m1, k1 = _gen_bases(ctx, cid, 0, 3, seed + 6, want_dlogs)
     m2, k2 = _gen_bases(ctx, cid, 1, 2, seed + 7, want_dlogs)
     key.update(alpha1=m1[0:1], beta1=m1[1:2], delta1=m1[2:3], beta2=m2[0:1], delta2=m2[1:2], infinityA=infA, infinityB=infB)
@@ -114,7 +122,51 @@ def make_instance(ctx: Context, curve, logn: int, seed: int = 0x5EED0005, *, nb_
     else:
         c = _gen_scalars(ctx, cid, m, seed + 13)
     rs = _gen_scalars(ctx, cid, 2, seed + 14)
-    return Instance(cid, n, nw, nb_public, key, dl, groth16.Solution(W, a, b, c), rs[0].copy(), rs[1].copy())
+    return Instance(cid, n, nw, nb_public, key, dl, groth16.Solution(W, a, b, c), rs[0].copy(), rs[1].copy(), extra={"seed": seed})
+
+
+def pin_key_chunked(ctx: Context, inst: Instance, *, shard=(0, 1), window_shard=(0, 1), precompute: int = 1, chunk: int = 1 << 19) -> groth16.ProvingKey:
+    """The proving key of make_instance(seed) -- the same bases, point for point -- pinned through the staged builder WITHOUT ever
+    holding a vector on the host: every vector is generated on the device in chunks of `chunk` points (ga_gen_bases_at), pulled,
+    appended and dropped; a base-range shard generates only the slice it keeps and skips the rest (ga_g16_builder_append with a
+    null pointer).  What a rank of a multi-GPU bench run uses: host staging per rank is one chunk, not the 12 GiB key."""
+    import ctypes as C
+    lib, cid, n, nw = ctx.lib, inst.curve, inst.n, inst.nb_wires
+    seed = inst.extra["seed"]
+    infA, infB = inst.key["infinityA"], inst.key["infinityB"]
+    k, N = int(shard[0]), int(shard[1])
+    b = C.c_void_p()
+    lib.check(lib.ga_g16_builder_create(ctx.handle, cid, n, nw, k, N, C.byref(b)))
+    try:
+        for which, (name, group, total, sd) in enumerate(_vector_plan(nw, n, inst.nb_public, infA, infB)):
+            lib.check(lib.ga_g16_builder_reserve(b, which, total))
+            base, rem = divmod(total, N)                      # the split of ga_g16_builder_reserve (= multigpu.shard_range)
+            lo = k * base + min(k, rem)
+            cnt = base + (1 if k < rem else 0)
+            words = affine_words(cid, group)
+            if lo:
+                lib.check(lib.ga_g16_builder_append(b, which, None, lo))
+            buf = ctx.malloc(max(1, min(chunk, cnt)) * words * 8)
+            for c0 in range(lo, lo + cnt, chunk):
+                cn = min(chunk, lo + cnt - c0)
+                lib.check(lib.ga_gen_bases_at(ctx.handle, cid, group, seed + sd, c0, cn, buf.ptr, None))
+                part = buf.to_host((cn, words))
+                lib.check(lib.ga_g16_builder_append(b, which, part.ctypes.data, cn))
+            buf.free()
+            if total - lo - cnt:
+                lib.check(lib.ga_g16_builder_append(b, which, None, total - lo - cnt))
+        for which, name in enumerate(("alpha1", "beta1", "delta1", "beta2", "delta2")):
+            lib.check(lib.ga_g16_builder_set_point(b, which, inst.key[name].ctypes.data))
+        lib.check(lib.ga_g16_builder_set_infinity(b, 0, infA.ctypes.data, nw))
+        lib.check(lib.ga_g16_builder_set_infinity(b, 1, infB.ctypes.data, nw))
+        if int(window_shard[1]) > 1:
+            lib.check(lib.ga_g16_builder_set_window_shard(b, int(window_shard[0]), int(window_shard[1])))
+    except Exception:
+        lib.ga_g16_builder_destroy(b)
+        raise
+    h = C.c_void_p()
+    lib.check(lib.ga_g16_builder_finish(b, int(precompute), C.byref(h)))
+    return groth16.ProvingKey.from_handle(ctx, cid, h, nb_wires=nw, domain_cardinality=n, shard=(k, N))
 
 
 def expected_exponents(inst: Instance, h_bitrev: np.ndarray, dot) -> dict:

@@ -261,6 +261,8 @@ int ga_g16_lane_stats(ga_ctx* ctx, uint64_t* out6);
  * see go/backend/accelerated/mi355x).  It is also what the key-file readers below are built on.
  *   create -> reserve(which, len) -> append(which, chunk, count)* -> set_point x5 -> set_infinity x2
  *          [-> add_commitment_key* -> set_k_remove] -> finish  (finish consumes the builder; destroy abandons it) */
+/* (ga_g16_builder_append with points == NULL skips `count` points that lie wholly OUTSIDE this shard's slice of the vector: a
+ * caller that holds only its own slice -- a file reader seeking past the rest, a rank generating its shard -- need not produce them) */
 #define GA_KEY_G1_A 0
 #define GA_KEY_G1_B 1
 #define GA_KEY_G1_Z 2
@@ -399,6 +401,8 @@ int ga_profile_read(ga_ctx* ctx, char* buf, size_t cap);
  * the same k_i are written (as canonical fr elements, 4 limbs) to dlogs_out (device) so that a test can check
  * MSM(s, P) == [sum s_i k_i] G with a field dot product (SURVEY 8c "known discrete log").  */
 int ga_gen_bases(ga_ctx* ctx, int curve, int group, uint64_t seed, size_t n, void* bases_dev, void* dlogs_dev);
+/* elements [first, first + n) of the same sequence: a rank of a multi-GPU run generates only its shard of a synthetic key */
+int ga_gen_bases_at(ga_ctx* ctx, int curve, int group, uint64_t seed, uint64_t first, size_t n, void* bases_dev, void* dlogs_dev);
 /* out[i] = uniform fr element (Montgomery) from a counter-based generator keyed by seed (device) */
 int ga_gen_scalars(ga_ctx* ctx, int curve, uint64_t seed, size_t n, void* scalars_dev);
 /* dot = sum a_i * b_i over fr; a Montgomery, b canonical (the dlogs above); result canonical LE (32 bytes, host) */
