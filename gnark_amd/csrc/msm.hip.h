@@ -386,18 +386,9 @@ msm_accumulate29_kernel(const uint32_t* __restrict__ table, const uint32_t* __re
 #define GA_ACC_LDS_PAD 0   // experiment: extra LDS words per workgroup, to lower the number of co-resident workgroups
 #endif
     __shared__ uint32_t lds[(LdsAcc29<F>::IN_REGS ? 1 : 4 * NW * Table29<F>::THREADS) + GA_ACC_LDS_PAD];
-#ifndef GA_ACC_G1_WAVES
-#define GA_ACC_G1_WAVES 4   // resident waves per SIMD of the G1 bucket kernel: 4 = whatever fits (it fills 144 of the 160 KB of LDS);
-#endif                      // 3 = capped through its register allocation, so that a kernel of ANOTHER stream finds LDS and registers
-    // The cap: a workgroup is one wave per SIMD, so waves per SIMD = workgroups per CU.  The kernel needs 64 VGPRs; declaring a
-    // high register as clobbered raises its ALLOCATION to 136-168, which limits a SIMD to 3 of its waves and leaves
-    // 160 - 3 * 36 = 52 KB of LDS and ~100 registers per lane for a co-resident sort / transform / reduction wave.  Alone the kernel
-    // runs as fast with 3 waves as with 4 (round 2: 15.18 vs 15.15 ms): it is issue-bound.
-    if constexpr (!Lazy<F>::FP2 && GA_ACC_G1_WAVES == 3) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        asm volatile("" ::: "v140");
-#endif
-    }
+    // (Round 3 measured two ways of making room for kernels of the partner lane beside this one -- which fills 144 of the 160 KB
+    // of LDS of a CU: the accumulator in registers instead of LDS (GA_ACC_REGS below: 15.58 vs 15.04 ms, slower) and a cap of 3
+    // resident waves per SIMD through the register allocation (proof time unchanged, 139.4 vs 139.9 ms).  Neither stays.)
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= max_tasks) return;
     const uint32_t key = task_key_sorted[t];

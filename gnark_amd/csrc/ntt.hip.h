@@ -19,7 +19,11 @@
 #include "common.hip.h"
 #include "field29.hip.h"
 #include <stdlib.h>
+#include <array>
 #include <functional>
+#include <mutex>
+#include <utility>
+#include <vector>
 
 namespace ga {
 
@@ -152,7 +156,8 @@ __device__ __forceinline__ F29<FrP> ntt_twiddle29(const uint32_t* __restrict__ t
 template <class FrP, bool DIT_>
 __global__ void __launch_bounds__(NTT_THREADS)
 ntt_pass29r4_kernel(uint32_t* data, const uint32_t* src, const uint32_t* __restrict__ tw, int logn, int lg_tile, int s_lo, int K,
-                    int lc, NttScale pre, NttScale post) {
+                    int lc, NttScale pre, NttScale post, int unit_ok) {
+    // unit_ok = 0: the table is a coset table (every entry carries its stage's power of the coset generator): no twiddle is 1
     static_assert(FrP::N == 8, "Fr is 4x64-bit limbs on both curves");
     typedef F29<FrP> E;
     __shared__ uint32_t lds[Radix<FrP>::NL << NTT_LG_TILE];
@@ -189,7 +194,7 @@ ntt_pass29r4_kernel(uint32_t* data, const uint32_t* src, const uint32_t* __restr
                 k1 = (1ull << s) + x;
                 k2 = (2ull << s) + x;
                 k3 = k2 + (1ull << s);
-                unit = x == 0;
+                unit = unit_ok && x == 0;
             } else {
                 const uint64_t u = i0 >> (s + 2);
                 k1 = u;
@@ -245,7 +250,7 @@ ntt_pass29r4_kernel(uint32_t* data, const uint32_t* src, const uint32_t* __restr
             if (DIT_) {
                 const uint64_t x = i0 & ((1ull << s) - 1);
                 kk = (1ull << s) + x;
-                unit = x == 0;
+                unit = unit_ok && x == 0;
             } else {
                 kk = i0 >> (s + 1);
                 unit = kk == 0;
@@ -269,14 +274,21 @@ ntt_pass29r4_kernel(uint32_t* data, const uint32_t* src, const uint32_t* __restr
 // One twiddle table (unpacked hat(w^e) entries, NTT_TW_WORDS words each) from the table of w^(2^k):
 //   stacked = 1:  out[2^s + x] = w^(x << (logn-1-s)), x < 2^s, s < logn   (entry 0 unused)      -- n entries
 //   stacked = 0:  out[j] = w^bitrev_{logn-1}(j), j < n/2                                          -- n/2 entries
+//   stage_cst != null (stacked only): entry [2^s + x] is additionally multiplied by stage_cst[s] -- the coset table TSg with
+//   stage_cst[s] = g^(2^(logn-1-s)): a bit-reversed -> natural transform over it evaluates on the coset g*<w> without scaling its
+//   input (A(g w^k) = A_even((g w^k)^2) + g w^k A_odd((g w^k)^2): the twiddle of the stage that merges halves of size 2^s is
+//   g^(n/2^(s+1)) w^(x n/2^(s+1)), and the halves are transforms on the coset of g^2 -- recursively)
 template <class FrP>
-__global__ void ntt_twiddle_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ pow2, uint64_t count, int logn, int stacked) {
+__global__ void ntt_twiddle_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ pow2, uint64_t count, int logn, int stacked,
+                                   const uint32_t* __restrict__ stage_cst) {
     uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= count) return;
     uint64_t e = 0;
+    int stage = 0;
     if (stacked) {
         if (k > 0) {
             int s = 63 - __clzll((long long)k);
+            stage = s;
             e = (k - (1ull << s)) << (logn - 1 - s);
         }
     } else {
@@ -285,21 +297,26 @@ __global__ void ntt_twiddle_kernel(uint32_t* __restrict__ out, const uint32_t* _
     Fe<FrP> r = fe_one<FrP>();
     for (int b = 0; b + 1 < logn; b++)
         if ((e >> b) & 1) r = mul(r, load_fe<FrP>(pow2 + b * 8));
+    if (stage_cst && k > 0) r = mul(r, load_fe<FrP>(stage_cst + stage * 8));
     const F29<FrP> u = f29_unpack(f29_hat_packed(r));   // the pass kernels multiply by hat(w) = w * 2^261
     for (int i = 0; i < NTT_TW_WORDS; i++) out[k * NTT_TW_WORDS + i] = i < Radix<FrP>::NL ? u.l[i] : 0u;
 }
 
-// a[i] = (a[i]*b[i] - c[i]) * den      (prove.go:377-383)
+// a[i] = (a[i]*b[i] - c[i]*cn) * den      (prove.go:377-383; cn = n and den = 1/((g^n - 1) n^2) when a, b, c are the UNSCALED chains
+// n * FFT_coset(iFFT(.)) of ntt_compute_h_chain: (n a)(n b) - n (n c) = n^2 (a b - c))
 template <class FrP>
 __global__ void ntt_pointwise_h_kernel(uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
-                                       const uint32_t* __restrict__ c, uint64_t n, NttScale den) {
+                                       const uint32_t* __restrict__ c, uint64_t n, NttScale den, NttScale cn) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Fe<FrP> d;
+    Fe<FrP> d, e;
 #pragma unroll
-    for (int k = 0; k < 8; k++) d.l[k] = den.cst[k];
+    for (int k = 0; k < 8; k++) {
+        d.l[k] = den.cst[k];
+        e.l[k] = cn.cst[k];
+    }
     Fe<FrP> x = load_fe<FrP>(a + i * 8), y = load_fe<FrP>(b + i * 8), z = load_fe<FrP>(c + i * 8);
-    store_fe(a + i * 8, mul(sub(mul(x, y), z), d));
+    store_fe(a + i * 8, mul(sub(mul(x, y), mul(z, e)), d));
 }
 
 // ---- host side -----------------------------------------------------------------------------------
@@ -310,17 +327,24 @@ struct Domain {
     uint64_t n = 0;
     int logn = 0;
     // twiddle tables of the pass kernels (layouts: ntt_twiddle_kernel): stacked per stage for bit-reversed -> natural transforms,
-    // bit-reversed for natural -> bit-reversed ones; forward (w) and inverse (1/w): 3n entries of 48 bytes in all (2.3 GiB at 2^24)
+    // bit-reversed for natural -> bit-reversed ones; forward (w) and inverse (1/w), plus the forward coset table: 4n entries of
+    // 48 bytes in all (3 GiB at 2^24)
     uint32_t* d_ts = nullptr;       // TS, w
     uint32_t* d_ts_inv = nullptr;   // TS, 1/w
     uint32_t* d_tb = nullptr;       // TB, w
     uint32_t* d_tb_inv = nullptr;   // TB, 1/w
+    uint32_t* d_ts_g = nullptr;     // TS of w with the coset generator folded in (ntt_twiddle_kernel): computeH's coset FFTs scale nothing
+    uint32_t* d_pow2 = nullptr;     // w^(2^k), k < 32, then (1/w)^(2^k): what ntt_twiddle_kernel builds tables from
+    // coset tables built on demand (ntt_coset_table): (shift, table) pairs -- d_ts_g is the first, PLONK's rho cosets follow
+    std::mutex coset_mu;
+    std::vector<std::pair<std::array<uint32_t, 8>, uint32_t*>> coset_tabs;
+    uint32_t den_n2[8];             // (g^n - 1)^-1 / n^2 and n (Montgomery): the point-wise step on the unscaled chains of computeH
+    uint32_t n_mont[8];
     // coset power tables
     uint32_t* d_g_lo = nullptr;     // g^k
     uint32_t* d_g_hi = nullptr;
     uint32_t* d_gi_lo = nullptr;    // g^-k / n
     uint32_t* d_gi_hi = nullptr;
-    uint32_t* d_gn_lo = nullptr;    // g^k / n   (computeH: coset FFT fused with the 1/n of the preceding iFFT)
     static constexpr bool lazy = true;   // twiddle / scale tables are kept in the hat domain (w * 2^261) for the lazy passes
     uint32_t ninv[8];               // 1/n (Montgomery; hat-packed when lazy)
     uint32_t den[8];                // (g^n - 1)^-1 (Montgomery), prove.go:370-373
@@ -399,10 +423,12 @@ inline std::vector<NttPass> ntt_plan(int logn) {
 
 template <class FrP>
 int ntt_run(Domain* d, uint32_t* d_data, bool inverse, bool dit, const NttScale& pre_first, const NttScale& post_last,
-            const uint32_t* d_src = nullptr) {
+            const uint32_t* d_src = nullptr, const uint32_t* coset_table = nullptr) {
+    // coset_table != nullptr: a stacked table with the coset generator folded in (forward, bit-reversed -> natural only)
     // d_src != nullptr: out-of-place transform (the first pass reads d_src, every pass writes d_data; d_src is left untouched)
     Ctx* ctx = d->ctx;
-    const uint32_t* tw = dit ? (inverse ? d->d_ts_inv : d->d_ts) : (inverse ? d->d_tb_inv : d->d_tb);
+    const uint32_t* tw = coset_table ? coset_table : dit ? (inverse ? d->d_ts_inv : d->d_ts) : (inverse ? d->d_tb_inv : d->d_tb);
+    const int unit_ok = coset_table ? 0 : 1;
     NttScale none;
     memset(&none, 0, sizeof(none));
     int np = (int)d->passes.size();
@@ -416,10 +442,10 @@ int ntt_run(Domain* d, uint32_t* d_data, bool inverse, bool dit, const NttScale&
         StageTimer st(ctx, dit ? "ntt_pass_dit" : "ntt_pass_dif");
         if (dit)
             hipLaunchKernelGGL((ntt_pass29r4_kernel<FrP, true>), dim3((unsigned)tiles), dim3(NTT_THREADS), 0, ctx->work_stream(),
-                               d_data, src, tw, d->logn, lg_tile, ps.s_lo, ps.K, ps.lc, pre, post);
+                               d_data, src, tw, d->logn, lg_tile, ps.s_lo, ps.K, ps.lc, pre, post, unit_ok);
         else
             hipLaunchKernelGGL((ntt_pass29r4_kernel<FrP, false>), dim3((unsigned)tiles), dim3(NTT_THREADS), 0, ctx->work_stream(),
-                               d_data, src, tw, d->logn, lg_tile, ps.s_lo, ps.K, ps.lc, pre, post);
+                               d_data, src, tw, d->logn, lg_tile, ps.s_lo, ps.K, ps.lc, pre, post, unit_ok);
         GA_KERNEL_CHECK();
     }
     return GA_OK;
@@ -469,10 +495,10 @@ int ntt_fft(Domain* d, uint32_t* d_data, int direction, int decimation, int on_c
 template <class FrP>
 int ntt_compute_h_chain(Domain* d, uint32_t* d_v) {
     if (d->logn == 0) return GA_OK;   // n = 1: iFFT and coset FFT are identities
-    // iFFT (DIF) without its 1/n ...
+    // n * FFT_coset(iFFT(v)) without a single scaling multiplication: the inverse transform leaves its 1/n out (the point-wise step
+    // of ntt_compute_h_combine absorbs it: the chains are only ever consumed there) and the forward one runs over the coset table
     GA_CHECK(ntt_run<FrP>(d, d_v, /*inverse=*/true, /*dit=*/false, scale_none(), scale_none()));
-    // ... which is folded into the coset pre-scale of the forward DIT: factor g^bitrev(i) / n
-    return ntt_run<FrP>(d, d_v, /*inverse=*/false, /*dit=*/true, scale_pow(d->d_gn_lo, d->d_g_hi, true), scale_none());
+    return ntt_run<FrP>(d, d_v, /*inverse=*/false, /*dit=*/true, scale_none(), scale_none(), nullptr, d->d_ts_g);
 }
 
 template <class FrP>
@@ -480,9 +506,9 @@ int ntt_compute_h_combine(Domain* d, uint32_t* d_a, const uint32_t* d_b, const u
     Ctx* ctx = d->ctx;
     {
         StageTimer st(ctx, "h_pointwise");
-        NttScale den = scale_const(d->den);
+        NttScale den = scale_const(d->den_n2), cn = scale_const(d->n_mont);   // a, b, c are n * (the reference's vectors)
         unsigned blocks = d->logn == 0 ? 1u : (unsigned)((d->n + 255) / 256);
-        hipLaunchKernelGGL((ntt_pointwise_h_kernel<FrP>), dim3(blocks), dim3(d->logn == 0 ? 64 : 256), 0, ctx->work_stream(), d_a, d_b, d_c, d->n, den);
+        hipLaunchKernelGGL((ntt_pointwise_h_kernel<FrP>), dim3(blocks), dim3(d->logn == 0 ? 64 : 256), 0, ctx->work_stream(), d_a, d_b, d_c, d->n, den, cn);
         GA_KERNEL_CHECK();
     }
     if (d->logn == 0) return GA_OK;
@@ -495,6 +521,49 @@ int ntt_compute_h(Domain* d, uint32_t* d_a, uint32_t* d_b, uint32_t* d_c) {
     uint32_t* v[3] = {d_a, d_b, d_c};
     for (int k = 0; k < 3; k++) GA_CHECK(ntt_compute_h_chain<FrP>(d, v[k]));
     return ntt_compute_h_combine<FrP>(d, d_a, d_b, d_c);
+}
+
+// The stacked forward table of the domain with the coset `shift` folded in (layout and derivation: ntt_twiddle_kernel): a
+// bit-reversed -> natural transform over it evaluates on shift*<w> with no scaling pass.  Built once per (domain, shift) and kept:
+// computeH's g, the rho cosets g*w_{rho n}^i of the PLONK quotient (n * 48 bytes each).
+template <class FrP>
+int ntt_coset_table(Domain* d, const Fe<FrP>& shift, const uint32_t** out) {
+    typedef Fe<FrP> F;
+    std::array<uint32_t, 8> key;
+    memcpy(key.data(), shift.l, 32);
+    std::lock_guard<std::mutex> g(d->coset_mu);
+    for (auto& kv : d->coset_tabs)
+        if (kv.first == key) {
+            *out = kv.second;
+            return GA_OK;
+        }
+    Ctx* ctx = d->ctx;
+    std::vector<uint32_t> cs(64 * 8, 0);   // cs[s] = shift^(2^(logn-1-s))
+    F c = shift;
+    for (int sidx = d->logn - 1; sidx >= 0; sidx--) {
+        memcpy(&cs[sidx * 8], c.l, 32);
+        c = sqr(c);
+    }
+    struct DevTmp {
+        void* p = nullptr;
+        ~DevTmp() { hipFree(p); }
+    } tmp;
+    GA_HIP_CHECK(hipMalloc(&tmp.p, cs.size() * 4));
+    GA_HIP_CHECK(hipMemcpy(tmp.p, cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
+    uint32_t* tab = nullptr;
+    GA_HIP_CHECK(hipMalloc((void**)&tab, d->n * NTT_TW_WORDS * 4));
+    hipLaunchKernelGGL((ntt_twiddle_kernel<FrP>), dim3((unsigned)((d->n + 255) / 256)), dim3(256), 0, ctx->work_stream(), tab,
+                       (const uint32_t*)d->d_pow2, d->n, d->logn, 1, (const uint32_t*)tmp.p);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->work_stream());
+    if (e != hipSuccess) {
+        hipFree(tab);
+        set_error("coset twiddle table: %s", hipGetErrorString(e));
+        return GA_ERR_HIP;
+    }
+    d->coset_tabs.emplace_back(key, tab);
+    *out = tab;
+    return GA_OK;
 }
 
 template <class FrP>
@@ -530,6 +599,13 @@ int domain_init(Ctx* ctx, Domain* d, int curve, uint64_t n) {
     for (int k = 0; k < d->logn; k++) gn = sqr(gn);
     F den = inv(sub(gn, fe_one<FrP>()));
     memcpy(d->den, den.l, 32);
+    {
+        F nm = fe_one<FrP>();                       // n = 2^logn (Montgomery)
+        for (int k = 0; k < d->logn; k++) nm = add(nm, nm);
+        memcpy(d->n_mont, nm.l, 32);
+        F dn2 = mul(den, mul(ninv, ninv));
+        memcpy(d->den_n2, dn2.l, 32);
+    }
 
     uint64_t half_n = n / 2;
     if (half_n > 0) {
@@ -541,23 +617,21 @@ int domain_init(Ctx* ctx, Domain* d, int curve, uint64_t n) {
             a = sqr(a);
             b = sqr(b);
         }
-        struct DevTmp {   // released on every return path (the domain's own tables are released by domain_free in the caller)
-            void* p = nullptr;
-            ~DevTmp() { hipFree(p); }
-        } tmp_p2;
-        GA_HIP_CHECK(hipMalloc(&tmp_p2.p, p2.size() * 4));
-        void* const d_p2 = tmp_p2.p;
-        GA_HIP_CHECK(hipMemcpy(d_p2, p2.data(), p2.size() * 4, hipMemcpyHostToDevice));
+        GA_HIP_CHECK(hipMalloc((void**)&d->d_pow2, p2.size() * 4));
+        GA_HIP_CHECK(hipMemcpy(d->d_pow2, p2.data(), p2.size() * 4, hipMemcpyHostToDevice));
         uint32_t** tabs[4] = {&d->d_ts, &d->d_ts_inv, &d->d_tb, &d->d_tb_inv};
         for (int t = 0; t < 4; t++) {
             const bool stacked = t < 2;
             const uint64_t count = stacked ? n : half_n;
             GA_HIP_CHECK(hipMalloc((void**)tabs[t], count * NTT_TW_WORDS * 4));
             hipLaunchKernelGGL((ntt_twiddle_kernel<FrP>), dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->work_stream(), *tabs[t],
-                               (const uint32_t*)d_p2 + (t & 1) * 32 * 8, count, d->logn, stacked ? 1 : 0);
+                               (const uint32_t*)d->d_pow2 + (t & 1) * 32 * 8, count, d->logn, stacked ? 1 : 0, (const uint32_t*)nullptr);
         }
         GA_KERNEL_CHECK();
         GA_HIP_CHECK(hipStreamSynchronize(ctx->work_stream()));
+        const uint32_t* tg = nullptr;
+        GA_CHECK(ntt_coset_table<FrP>(d, g, &tg));
+        d->d_ts_g = const_cast<uint32_t*>(tg);
     }
     // coset power tables (host-computed: <= 2^12 + n/2^12 entries each)
     uint64_t nlo = 1ull << NTT_POW_LO_BITS;
@@ -588,7 +662,6 @@ int domain_init(Ctx* ctx, Domain* d, int curve, uint64_t n) {
     };
     GA_CHECK(build(g, fe_one<FrP>(), &d->d_g_lo, &d->d_g_hi));
     GA_CHECK(build(gi, ninv, &d->d_gi_lo, &d->d_gi_hi));
-    GA_CHECK(build(g, ninv, &d->d_gn_lo, nullptr));
     return GA_OK;
 }
 
@@ -597,11 +670,13 @@ inline void domain_free(Domain* d) {
     hipFree(d->d_ts_inv);
     hipFree(d->d_tb);
     hipFree(d->d_tb_inv);
+    hipFree(d->d_pow2);
+    for (auto& kv : d->coset_tabs) hipFree(kv.second);   // (d_ts_g is one of them)
+    d->coset_tabs.clear();
     hipFree(d->d_g_lo);
     hipFree(d->d_g_hi);
     hipFree(d->d_gi_lo);
     hipFree(d->d_gi_hi);
-    hipFree(d->d_gn_lo);
 }
 
 }  // namespace ga

@@ -988,8 +988,8 @@ def test_emu_groth16_split_schedule_and_late_free(emu_ctx, c, precompute, monkey
 # ---- one proof over several devices from one process (ga_g16_prove_multi) ------------------------------------------------------
 # (under the emulation a subset of the curve x shard-count x key-mode grid, sized for the CPU suite; the GPU suite runs both curves
 # with 2 and 3 shards and both key modes at 2^12 constraints)
-@pytest.mark.parametrize("c,nshards,precompute", [(BN254, 2, 1), (BN254, 3, 1), (BN254, 3, -1), (BLS12_381, 3, 1), (BLS12_381, 2, -1), (BLS12_381, 5, -1)],
-                         ids=["bn254-2-tables", "bn254-3-tables", "bn254-3-no-tables", "bls12-381-3-tables", "bls12-381-2-no-tables", "bls12-381-5-no-tables"])
+@pytest.mark.parametrize("c,nshards,precompute", [(BN254, 2, 1), (BN254, 3, -1), (BLS12_381, 3, 1), (BLS12_381, 5, -1)],
+                         ids=["bn254-2-tables", "bn254-3-no-tables", "bls12-381-3-tables", "bls12-381-5-no-tables"])
 def test_emu_groth16_prove_multi(emu_ctx, c, nshards, precompute, logn=7):
     """shard i of N in its own context (one context per device; here all on device 0): the native multi-device prover -- one
     host thread per shard, computeH's chains on the first three, peer copies of b, c and of the h slices -- returns the proof of
