@@ -79,6 +79,7 @@ void Tunables::read_env() {
     put(g16_share_min_pct, (int)num("GA_G16_SHARE_MIN_PCT", 90));
     put(g16_lanes, (int)num("GA_G16_LANES", 2));
     put(g16_split, (int)num("GA_G16_SPLIT", 1));
+    put(ntt_coset_fold, (int)num("GA_NTT_COSET_FOLD", 1));
     put(table_c, (int)num("GA_TABLE_C", 0));
     put(msm_exact_redo, (int)num("GA_MSM_EXACT_REDO", 0));
     const uint64_t seg = num("GA_MSM_MIN_SEG", 256);

@@ -89,6 +89,7 @@ struct StageRec {
 //   GA_TABLE_C            force the window width of precomputed tables built from now on (experiments; 0 = planned)
 //   GA_G16_LANES          1: a second concurrent ga_g16_prove caller queues for the device instead of proving on its own lanes
 //   GA_G16_SPLIT          0: a proof keeps its H side (computeH, Z MSM) on the lane of its witness MSMs instead of a partner lane
+//   GA_NTT_COSET_FOLD     0: coset FFTs scale their input by the coset powers (round 2) instead of running over a coset twiddle table
 // The fields are relaxed atomics: the entry point that holds lane 0 refreshes them while provers on the other lanes read them.
 struct Tunables {
     std::atomic<uint64_t> msm_max_chunk{0};          // 0 = only the 2^31 pair-space limit
@@ -96,6 +97,7 @@ struct Tunables {
     std::atomic<int> g16_share_min_pct{90};
     std::atomic<int> g16_lanes{2};
     std::atomic<int> g16_split{1};
+    std::atomic<int> ntt_coset_fold{1};
     std::atomic<int> table_c{0};
     std::atomic<uint64_t> msm_min_seg{256};
     std::atomic<int> msm_exact_redo{0};

@@ -480,6 +480,8 @@ int ntt_fft(Domain* d, uint32_t* d_data, int direction, int decimation, int on_c
     bool dit = decimation == GA_DIT;
     NttScale pre = scale_none(), post = scale_none();
     if (!inverse) {
+        if (on_coset && dit && d->d_ts_g && d->ctx->tun.ntt_coset_fold)   // the coset lives in the twiddle table: no scaling pass
+            return ntt_run<FrP>(d, d_data, false, true, pre, post, nullptr, d->d_ts_g);
         if (on_coset) pre = scale_pow(d->d_g_lo, d->d_g_hi, /*bitrev=*/dit);
     } else {
         if (on_coset) post = scale_pow(d->d_gi_lo, d->d_gi_hi, /*bitrev=*/!dit);
@@ -498,6 +500,8 @@ int ntt_compute_h_chain(Domain* d, uint32_t* d_v) {
     // n * FFT_coset(iFFT(v)) without a single scaling multiplication: the inverse transform leaves its 1/n out (the point-wise step
     // of ntt_compute_h_combine absorbs it: the chains are only ever consumed there) and the forward one runs over the coset table
     GA_CHECK(ntt_run<FrP>(d, d_v, /*inverse=*/true, /*dit=*/false, scale_none(), scale_none()));
+    if (!d->ctx->tun.ntt_coset_fold)   // (A/B: the round-2 form, coset powers and 1/n applied to the input of the forward transform; x n to match)
+        return ntt_run<FrP>(d, d_v, /*inverse=*/false, /*dit=*/true, scale_pow(d->d_g_lo, d->d_g_hi, true), scale_none());
     return ntt_run<FrP>(d, d_v, /*inverse=*/false, /*dit=*/true, scale_none(), scale_none(), nullptr, d->d_ts_g);
 }
 

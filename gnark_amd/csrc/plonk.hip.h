@@ -382,14 +382,17 @@ int plonk_quotient(Domain* d0, Domain* d1, const PlonkQuotientArgs& A, void* h_o
         // evaluations on coset*H: forward DIT with the coset powers fused into the first pass (prove.go:1033-1058)
         // (round 3: the coset lives in the twiddle table -- ntt_coset_table, built once per domain and coset and kept -- instead of
         // a scaling of the input by coset^i: two products per element and transform less)
-        uint32_t *x_lo, *x_hi;
+        uint32_t *x_lo, *x_hi, *s_lo = nullptr, *s_hi = nullptr;
         const uint32_t* coset_tw = nullptr;
-        GA_CHECK(ntt_coset_table<FrP>(d0, coset, &coset_tw));
+        const bool fold = ctx->tun.ntt_coset_fold != 0;
+        if (fold) GA_CHECK(ntt_coset_table<FrP>(d0, coset, &coset_tw));
+        else GA_CHECK(plonk_pow_tables<FrP>(ctx, "plonk_scale_tab", coset, fe_one<FrP>(), n, d0->lazy, &s_lo, &s_hi));
         GA_CHECK(plonk_pow_tables<FrP>(ctx, "plonk_x_tab", w0, coset, n, false, &x_lo, &x_hi));
         for (int p = 0; p < np; p++) {
             if (skip(p)) continue;
             uint32_t* dst = mode == 1 ? fx->evals + ((size_t)(i * fx->nslots + fx->slot[p])) * n * 8 : work + (size_t)p * n * 8;
-            GA_CHECK(ntt_run<FrP>(d0, dst, /*inverse=*/false, /*dit=*/true, scale_none(), scale_none(), canon + (size_t)p * n * 8, coset_tw));
+            if (fold) GA_CHECK(ntt_run<FrP>(d0, dst, /*inverse=*/false, /*dit=*/true, scale_none(), scale_none(), canon + (size_t)p * n * 8, coset_tw));
+            else GA_CHECK(ntt_run<FrP>(d0, dst, /*inverse=*/false, /*dit=*/true, scale_pow(s_lo, s_hi, /*bitrev=*/true), scale_none(), canon + (size_t)p * n * 8));
         }
         uint32_t* inv_i = mode == 0 ? invb : fx->inv_xm1 + (size_t)i * n * 8;
         if (mode != 2) {
