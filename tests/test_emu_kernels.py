@@ -1284,3 +1284,37 @@ def test_emu_plonk_build_z_rejects_bad_device_permutation(emu_ctx):
             b.free()
     finally:
         d0.close()
+
+
+def test_emu_chunked_sharded_key_generation(emu_ctx):
+    """synth.pin_key_chunked (what every rank of `bench.py --gpus N` uses): the key of make_instance generated on the device chunk by
+    chunk, only the slice a shard keeps (ga_gen_bases_at + ga_g16_builder_append(NULL) for the rest), proves like the key uploaded from
+    host arrays -- whole, and as three base-range shards whose partial sums are added; a null-pointer append INSIDE the shard's slice is
+    refused"""
+    import ctypes as C
+    from gnark_amd import synth
+    c = BN254
+    inst = synth.make_instance(emu_ctx, c.name, 7, 0x77, want_dlogs=False)
+    pk = inst.proving_key(emu_ctx, precompute=1)
+    want = groth16.Prove(pk, inst.solution, inst.nb_public, inst.r, inst.s).raw()
+    pk.FreeGPUResources()
+    lean = synth.make_instance(emu_ctx, c.name, 7, 0x77, want_dlogs=False, with_key=False)
+    assert "A" not in lean.key and np.array_equal(lean.solution.W, inst.solution.W)
+    pk2 = synth.pin_key_chunked(emu_ctx, lean, precompute=1, chunk=50)
+    assert np.array_equal(groth16.Prove(pk2, lean.solution, lean.nb_public, lean.r, lean.s).raw(), want)
+    pk2.FreeGPUResources()
+    parts = []
+    for k in range(3):
+        spk = synth.pin_key_chunked(emu_ctx, lean, shard=(k, 3), precompute=-1, chunk=20)
+        parts.append(groth16.ProvePartial(spk, lean.solution, lean.nb_public))
+        if k == 2:
+            fin = groth16.Finish(spk, groth16.SumPartials(c.name, parts, lib=emu_ctx.lib), lean.r, lean.s)
+        spk.FreeGPUResources()
+    assert np.array_equal(fin.raw(), want)
+    lib = emu_ctx.lib
+    b = C.c_void_p()
+    lib.check(lib.ga_g16_builder_create(emu_ctx.handle, c.cid, 128, 128, 1, 2, C.byref(b)))
+    lib.check(lib.ga_g16_builder_reserve(b, 0, 100))
+    lib.check(lib.ga_g16_builder_append(b, 0, None, 50))            # points [0, 50): shard 1 of 2 keeps [50, 100)
+    assert lib.ga_g16_builder_append(b, 0, None, 10) != 0 and b"null pointer" in lib.ga_last_error()
+    lib.ga_g16_builder_destroy(b)
