@@ -200,6 +200,8 @@ int ga_ctx_create(int device, ga_ctx** out) {
     c->device = device;
     hipStream_t* slots[3 + GA_NUM_LANES] = {&c->lane_stream[0], &c->lane_stream[1], &c->lane_stream[2], &c->lane_stream[3],
                                             &c->copy_stream, &c->slot_stream[0], &c->slot_stream[1]};
+    // (measured and dropped, profiles/README.md round 3 batch H: creating the partner lanes -- or the witness lanes -- with the highest
+    // stream priority changes nothing: 140.3 / 140.9 ms per proof without, 141.1 / 141.9 / 141.0 with)
     for (int k = 0; k < 3 + GA_NUM_LANES; k++) {
         hipError_t se = hipStreamCreateWithFlags(slots[k], hipStreamNonBlocking);
         if (se != hipSuccess) {

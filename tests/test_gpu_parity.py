@@ -701,6 +701,14 @@ def test_groth16_2_24_known_dlogs(gpu_ctx, c):
     cases.check_groth16_known_dlogs(gpu_ctx, c, 24, nthreads=_NT, proofs=2)
 
 
+def test_groth16_2_26_known_dlogs_beyond_the_table_budget(gpu_ctx):
+    """four times the headline size: 2^26 constraints, BN254.  The window tables no longer fit HBM (precompute = 0 decides that by
+    itself), so the proof runs on the plain base vectors (per-window bucket sets, c = 22 plans over 2^26 points, 2^26-point
+    transforms: 4-pass plans) and must still equal the closed form from the key's discrete logs; h satisfies the identity.
+    (`tools/size_sweep.py` ran the same check at 2^27 -- 230 GiB of HBM -- profiles/README.md, round 3 batch M.)"""
+    cases.check_groth16_known_dlogs(gpu_ctx, BN254, 26, nthreads=_NT, proofs=1, precompute=0)
+
+
 @pytest.mark.parametrize("c,group", [(BN254, 1), (BLS12_381, 0), (BLS12_381, 1)], ids=["bn254-G2", "bls12-381-G1", "bls12-381-G2"])
 def test_msm_2_24_other_shapes_dlog(gpu_ctx, c, group):
     """the MSM shapes of configs 3/4 besides BN254 G1, 2^24 points each, raw bases (ga_msm) and pinned table (ga_msm_table_run)"""

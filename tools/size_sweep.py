@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Groth16 proof time against the number of constraints (one GPU, synthetic known-dlog key, W/A/B/C on the host, proof on the host;
+precompute = 0: the library decides whether the window tables fit HBM).  One JSON object per size on stdout.
+
+  python tools/size_sweep.py --curve bn254 --logs 16,18,20,22,24,25,26 [--check-max 26]
+
+--check-max L: sizes up to 2^L are also CHECKED against the closed form from the key's discrete logs (oracle/checkers.py; CPU
+time grows with n) -- the checker is test infrastructure, outside every timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--curve", default="bn254")
+    ap.add_argument("--logs", default="16,18,20,22,24")
+    ap.add_argument("--proofs", type=int, default=3)
+    ap.add_argument("--precompute", type=int, default=0)
+    ap.add_argument("--check-max", type=int, default=0)
+    args = ap.parse_args()
+    from gnark_amd import groth16, synth
+    from gnark_amd.device import Context
+    ctx = Context(0)
+    for logn in [int(x) for x in args.logs.split(",")]:
+        info0 = ctx.info()
+        t0 = time.perf_counter()
+        checked = None
+        if logn <= args.check_max:
+            import checkers
+            import pyref
+            t0 = time.perf_counter()
+            checkers.check_groth16_known_dlogs(ctx, pyref.CURVES[args.curve], logn, nthreads=min(64, os.cpu_count() or 1), proofs=1, precompute=args.precompute)
+            checked = round(time.perf_counter() - t0, 1)
+        inst = synth.make_instance(ctx, args.curve, logn, 0x5EED0005, want_dlogs=False)
+        t1 = time.perf_counter()
+        pk = inst.proving_key(ctx, precompute=args.precompute)
+        ctx.sync()
+        t2 = time.perf_counter()
+        sol, nbp, r, s = inst.solution, inst.nb_public, inst.r, inst.s
+        for _ in range(2):
+            groth16.Prove(pk, sol, nbp, r, s)
+        ctx.sync()
+        t3 = time.perf_counter()
+        for _ in range(args.proofs):
+            groth16.Prove(pk, sol, nbp, r, s)
+        ctx.sync()
+        ms = (time.perf_counter() - t3) * 1e3 / args.proofs
+        info1 = ctx.info()
+        pk.FreeGPUResources()
+        print(json.dumps({"curve": args.curve, "log_n": logn, "ms_per_proof": round(ms, 3), "proofs_per_s": round(1e3 / ms, 3),
+                          "constraints_per_s": round((1 << logn) / ms * 1e3), "key_pin_s": round(t2 - t1, 2),
+                          "hbm_used_gib": round((info0["free_bytes"] - info1["free_bytes"]) / 2**30, 2),
+                          "checked_known_dlogs_s": checked}), flush=True)
+        del inst, sol
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
