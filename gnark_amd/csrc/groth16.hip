@@ -1409,8 +1409,7 @@ static int finish(G16Pk* pk, XYZZ<Fe<typename C::FpP>> ar, XYZZ<Fe<typename C::F
     bs1 = add(add(bs1, host_load_affine<F1>(pk->beta1.data())), d_s);
     ar = add(add(ar, host_load_affine<F1>(pk->alpha1.data())), d_r);
     krs = add(krs, d_kr);
-    krs = add(krs, scalar_mul(ar, sc.l, 8));
-    krs = add(krs, scalar_mul(bs1, rc.l, 8));
+    krs = add(krs, scalar_mul2(ar, sc.l, bs1, rc.l, 8));   // s*Ar + r*Bs1 on one doubling chain
     bs2 = add(add(bs2, fixed_base_mul<F2>(pk->delta2_tab, sc.l)), host_load_affine<F2>(pk->beta2.data()));
     char* o = reinterpret_cast<char*>(proof_out);
     host_store_affine<F1>(o, ar);

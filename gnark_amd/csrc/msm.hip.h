@@ -1160,7 +1160,11 @@ int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, X
     // the lazy formulas cannot add to themselves) are the rule there and every group would be redone.
     // buckets from which the lazy pass pays (measured: 2^20 points / 2^16 buckets 2.82 -> 2.53 ms); ctx->tun is read from the
     // environment once per entry point (GA_REDUCE_LAZY_MIN: tests force the lazy path on sparse bucket sets with 0)
-    const bool lazy_reduce = (uint64_t)half * nsets >= ctx->tun.reduce_lazy_min;
+    // ... unless the set is DENSE (a table's shared set: windows x n entries over 2^(c-1) buckets; >= 16 entries per bucket leave
+    // e^-16 of them empty): a 2^14-constraint proof spent 1.1 ms per MSM in the exact kernel's per-lane scalar multiplications
+    // (6.3 ms per proof against 3.2 ms at 2^16, profiles/README.md round 3 batch N)
+    const bool dense_set = P.m >= 16ull * (uint64_t)half * (uint64_t)nsets;
+    const bool lazy_reduce = (uint64_t)half * nsets >= ctx->tun.reduce_lazy_min || dense_set;
     if (!lazy_reduce) {
         StageTimer tm(ctx, "msm_reduce");
         hipLaunchKernelGGL((msm_reduce_groups_kernel<F>), dim3((total_groups + 63) / 64), dim3(64), 0, st, (const XYZZ<F>*)bsum,
@@ -1183,7 +1187,12 @@ int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, X
     }
     int nbits = 0;
     while ((1u << nbits) < groups_per_win) nbits++;
-    const uint32_t sg = 1024;   // (256 / 128 measured: msm_reduce 1.05 -> 1.13 / 1.34 ms, the second-level sums grow)
+    // chunk of groups per wave of the per-bit sums: 1024 where the grid fills the device anyway (2^24: 128 chunks x 18 rows; 256 / 128
+    // measured there: msm_reduce 1.05 -> 1.13 / 1.34 ms, the second-level sums grow).  Smaller bucket sets are latency-bound -- a
+    // lane's 16 dependent additions + 6 tree levels at ~9 us each made this kernel as expensive as the bucket accumulation of a
+    // 2^16 MSM (profiles/README.md round 3, batches K / L) -- so the chunk shrinks until the grid has ~2 waves per SIMD
+    uint32_t sg = 1024;
+    while (sg > 64 && (uint64_t)(groups_per_win / sg) * (uint64_t)(nbits + 1) * (uint64_t)nsets < 2048) sg >>= 1;
     const uint32_t chunk_len = groups_per_win > sg ? sg : groups_per_win;   // powers of two
     const uint32_t chunks = groups_per_win / chunk_len;
     int log_chunk = 0;
