@@ -12,7 +12,9 @@ Workload (BASELINE.json `metric`: "G1 MSM Mscalar-mul/s + Groth16 proofs/s, BN25
     5 single-caller proofs (every one checked against the closed form from the key's known discrete logs + the polynomial
     identity of h, outside the timed region: "matches_dlog", "check"), then 10 proofs from two host threads on one key (two
     proofs in flight on the context's two lanes: "pipelined"; `--no-pipelined` leaves that leg out of profiler passes).
-    With N > 1 ranks the "groth16" object is ONE proof sharded over the N GPUs (strong scaling; gnark_amd/multigpu.py).
+    With N > 1 ranks the "groth16" object is ONE proof sharded over the N GPUs (strong scaling; gnark_amd/multigpu.py): every rank
+    generates only its shard of the key, rank 0 checks the sharded proof against the same closed form afterwards ("matches_dlog");
+    its "proof_sha" equals the N = 1 line's.  With 8 ranks (or GA_BENCH_CONFIG4=1) "groth16_bls12_381" is BASELINE config 4.
   * the PLONK leg (BASELINE config 5: kernel work of one BN254 proof at 2^22 gates -- 10 KZG-commit MSMs over a pinned SRS,
     grand product, quotient) is reported in the "plonk" object (N = 1, BN254; `--plonk-log-n 0` disables it).
   * "roofline": dominant kernel (msm_accumulate) vs the 8 TB/s HBM peak using the ALGORITHMIC 96 B per scalar-mul
@@ -405,7 +407,8 @@ def main():
             """one 2^log_n proof over the world's GPUs.  Every rank generates ITS shard of the synthetic key on its own device, chunk
             by chunk (synth.pin_key_chunked: no 12 GiB key is staged through host memory), and the solution (the prover's real input)."""
             try:
-                inst = synth.make_instance(ctx, leg_cid, args.log_n, 0x5EED0005, want_dlogs=False, with_key=False)   # same seeds on every rank
+                check_here = rank == 0 and not args.no_check   # rank 0 checks the sharded proof against the key's known discrete logs
+                inst = synth.make_instance(ctx, leg_cid, args.log_n, 0x5EED0005, want_dlogs=check_here, with_key=False)   # same seeds on every rank
                 kw = dict(shard=(rank, world)) if args.partition == "range" else dict(window_shard=(rank, world))
                 t_pin = time.perf_counter()
                 pk = synth.pin_key_chunked(ctx, inst, precompute=1, **kw)
@@ -431,7 +434,15 @@ def main():
                 tm = torch.tensor([el], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
                 dist.all_reduce(tm, op=dist.ReduceOp.MAX)
                 el = float(tm.item())
+                chk = None
+                if check_here:   # outside the timed region, after the key has been freed: the closed form of the N = 1 leg
+                    try:
+                        synth.attach_vector_dlogs(ctx, inst)
+                        chk = check_groth16(ctx, inst, proof, os.cpu_count() or 1)
+                    except Exception as e:   # a failing CHECKER must not lose the measurement; the line says so
+                        chk = {"matches_dlog": None, "checker_error": repr(e)[:300]}
                 return {"curve": leg_curve, "proofs_per_s": round(args.groth16_proofs / el, 4), "ms_per_proof": round(el * 1e3 / args.groth16_proofs, 2),
+                        "matches_dlog": chk["matches_dlog"] if chk else None, "check": chk,
                         "proofs": args.groth16_proofs, "constraints": n, "scaling": "strong", "partition": args.partition,
                         "mode": ("one proof over %d GPUs: key sharded by base-point range (1/%d of the tables per GPU, each rank generates only its shard), W uploaded per wire range "
                                  "(%d of %d wires on rank 0), A,B,C uploaded 1/N per rank and gathered on the chain owners (N >= 3), computeH chains on ranks 0-2 beside the witness MSMs, h slices scattered, all_gather of 5 partial points" %

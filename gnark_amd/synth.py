@@ -169,6 +169,27 @@ def pin_key_chunked(ctx: Context, inst: Instance, *, shard=(0, 1), window_shard=
     return groth16.ProvingKey.from_handle(ctx, cid, h, nb_wires=nw, domain_cardinality=n, shard=(k, N))
 
 
+def attach_vector_dlogs(ctx: Context, inst: Instance) -> None:
+    """The exponents of the five base vectors of an instance made with with_key=False, want_dlogs=True (the vectors themselves are
+    what pin_key_chunked generates shard by shard, same seeds): ga_gen_bases once per vector for its dlog output; the points are
+    dropped on the device.  Lets rank 0 of a multi-GPU run check the sharded proof against the closed form (bench.py)."""
+    seed = inst.extra["seed"]
+    for name, group, count, sd in _vector_plan(inst.nb_wires, inst.n, inst.nb_public, inst.key["infinityA"], inst.key["infinityB"]):
+        _, inst.dlogs[name] = _dlogs_only(ctx, inst.curve, group, count, seed + sd)
+
+
+def _dlogs_only(ctx: Context, cid: int, group: int, count: int, seed: int):
+    words = affine_words(cid, group)
+    buf = ctx.malloc(max(count, 1) * words * 8)
+    dl = ctx.malloc(max(count, 1) * 32)
+    try:
+        ctx.lib.check(ctx.lib.ga_gen_bases(ctx.handle, cid, group, seed, count, buf.ptr, dl.ptr))
+        return None, dl.to_host((count, 4))
+    finally:
+        buf.free()
+        dl.free()
+
+
 def expected_exponents(inst: Instance, h_bitrev: np.ndarray, dot) -> dict:
     """Discrete logs of Ar, Bs (G2), Krs and of the pre-randomisation sums, from the instance's exponents.
     dot(a_mont, b_canonical) -> int must return sum a_i * b_i mod r with a in Montgomery form and b canonical (the oracle's

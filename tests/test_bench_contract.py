@@ -55,3 +55,4 @@ def test_two_ranks_line(env):
     g = d["groth16"]
     assert "error" not in g, g
     assert g["scaling"] == "strong" and g["constraints"] == 512 and len(g["proof_sha"]) == 16
+    assert g["matches_dlog"] is True and g["check"]["h_identity_ok"] is True   # rank 0 checked the sharded proof by the key's known dlogs
