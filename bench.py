@@ -167,7 +167,7 @@ def main():
     # ---- inputs resident in HBM ---------------------------------------------------------------------------
     bases = ctx.malloc(n * words_aff * 8)
     scalars = ctx.malloc(n * 32)
-    base_dlogs = ctx.malloc(n * 32) if (world == 1 and not args.no_check) else None   # k_i of [k_i]G: the timed result is checked against them
+    base_dlogs = ctx.malloc(n * 32) if not args.no_check else None   # k_i of [k_i]G: the timed result is checked against them
     lib.check(lib.ga_gen_bases(ctx.handle, cid, _lib.G1, 0x5EED0002 + 977 * rank, n, bases.ptr, base_dlogs.ptr if base_dlogs else None))
     lib.check(lib.ga_gen_scalars(ctx.handle, cid, 0x5EED0001 + 977 * rank, n, scalars.ptr))
     # the bases are a pinned key: keep them with their window multiples (ga_msm_table_*, built outside the timed region)
@@ -216,17 +216,36 @@ def main():
     ms_per_step = elapsed * 1e3 / args.steps
     value = world * n * args.steps / elapsed / 1e6
     # is the timed result THE result?  MSM(s, [k_i]G) = [sum s_i k_i]G: the exponent by a dot product on the CPU oracle, the point by
-    # the oracle's fixed-base multiplication -- outside the timed region, N = 1 only (the oracle is the checker, never the thing timed)
+    # the oracle's fixed-base multiplication -- outside the timed region (the oracle is the checker, never the thing timed)
     value_checked = None
     if base_dlogs is not None:
+        e, err = None, None
         try:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import oracle
             e = oracle.fr_dot(cid, scalars.to_host((n, 4)), base_dlogs.to_host((n, 4)))
-            want_pt = oracle.jac_to_affine(cid, 0, oracle.generator_mul(cid, 0, e))
-            value_checked = bool(np.array_equal(ecc.jac_to_affine(cid, _lib.G1, result), want_pt))
         except Exception as ex:   # a failing checker is reported, it does not hide the measurement
-            value_checked = "checker error: " + repr(ex)[:200]
+            err = "checker error: " + repr(ex)[:200]
+        if world > 1:   # the gathered sum is [sum over ranks of <s, k>]G: every rank contributes its exponent (8 x 32 bits + an ok flag);
+            # every rank takes part in the collective whatever happened to its checker
+            mine = torch.tensor([((e or 0) >> (32 * i)) & 0xFFFFFFFF for i in range(8)] + [0 if e is None else 1], dtype=torch.int64,
+                                device="cuda" if backend == "nccl" else "cpu")
+            parts = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(parts, mine)
+            parts = [p.tolist() for p in parts]
+            if all(p[8] == 1 for p in parts):
+                from gnark_amd import synth
+                e = sum(sum(int(v) << (32 * i) for i, v in enumerate(p[:8])) for p in parts) % synth.FR_MODULUS[cid]
+            else:
+                e, err = None, err or "checker error on another rank"
+        if e is not None:
+            try:
+                want_pt = oracle.jac_to_affine(cid, 0, oracle.generator_mul(cid, 0, e))
+                value_checked = bool(np.array_equal(ecc.jac_to_affine(cid, _lib.G1, result), want_pt))
+            except Exception as ex:
+                value_checked = "checker error: " + repr(ex)[:200]
+        else:
+            value_checked = err
         base_dlogs.free()
 
     out = None

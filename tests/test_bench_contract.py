@@ -51,7 +51,7 @@ def test_two_ranks_line(env):
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _line(r.stdout)
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["value_checked"] is True
     g = d["groth16"]
     assert "error" not in g, g
     assert g["scaling"] == "strong" and g["constraints"] == 512 and len(g["proof_sha"]) == 16
