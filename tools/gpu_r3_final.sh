@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-3 closing run on one box: full GPU suite, smoke(), the bench lines (both curves), the PLONK leg, kernel stats, FETCH/WRITE and
 # SQ passes of the final code.  TAG names the output files (copied into profiles/ afterwards).
-TAG=${TAG:-r03_g}
+TAG=${TAG:-r03_p}
 OUT=gpurun_out/final3
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -39,3 +39,10 @@ for c in ("bn254", "bls12381"):
 P
 grep -E "accumulate29_kernel|radix_sort|ntt_pass" $OUT/${TAG}_bench24_bn254_kernel_stats.txt | head -8 | cut -c1-170
 grep -E "ntt_pass|accumulate29" $OUT/${TAG}_bench24_bn254_pmc_FETCH_SIZE.txt | head -4 | cut -c1-170
+# the --gpus N code path on this 1-GPU box: two ranks share the GPU, collectives over gloo (control flow + self-checks; timings mean nothing)
+GA_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 2 --steps 3 --warmup 1 > $OUT/${TAG}_bench_2ranks_one_gpu_gloo.json 2> $OUT/bench_2ranks.err
+python - <<P
+import json
+d = json.loads(open("gpurun_out/final3/${TAG}_bench_2ranks_one_gpu_gloo.json").read().strip().splitlines()[-1])
+print("2 ranks: value_checked", d.get("value_checked"), "groth16", {k: d["groth16"].get(k) for k in ("ms_per_proof", "matches_dlog", "proof_sha", "error")})
+P
