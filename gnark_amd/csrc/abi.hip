@@ -28,6 +28,27 @@ int current_lane() { return g_lane; }
 LaneScope::LaneScope(int lane) : prev(g_lane) { g_lane = lane; }
 LaneScope::~LaneScope() { g_lane = prev; }
 
+hipError_t device_malloc_bytes(void** p, size_t bytes) {
+    static const size_t reserve = []() {
+        const char* e = getenv("GA_HBM_RESERVE_MB");
+        return (size_t)(e ? strtoull(e, nullptr, 10) : 1024ull) << 20;
+    }();
+    *p = nullptr;
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();   // clear the sticky error: the caller reports this failure itself
+        *p = nullptr;
+        return e;
+    }
+    size_t free_b = 0, total_b = 0;
+    if (reserve && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < reserve) {
+        hipFree(*p);
+        *p = nullptr;
+        return hipErrorOutOfMemory;
+    }
+    return hipSuccess;
+}
+
 int Ctx::scratch_get(const char* base_key, size_t bytes, void** out) {
     // every lane has its own namespace: a lane-1 proof never shares a buffer with the lane-0 work running beside it
     const int lane = current_lane();
@@ -45,9 +66,9 @@ int Ctx::scratch_get(const char* base_key, size_t bytes, void** out) {
     }
     void* p = nullptr;
     size_t want = bytes + bytes / 8 + 256;
-    hipError_t e = hipMalloc(&p, want);
+    hipError_t e = device_malloc(&p, want);
     if (e != hipSuccess) {
-        set_error("device scratch '%s': hipMalloc(%zu) failed: %s", key, want, hipGetErrorString(e));
+        set_error("device scratch '%s': device_malloc(%zu) failed: %s", key, want, hipGetErrorString(e));
         return GA_ERR_NOMEM;
     }
     scratch[key] = std::make_pair(p, want);
@@ -99,9 +120,9 @@ struct Staged {
             dev = p;
             return GA_OK;
         }
-        hipError_t e = hipMalloc(&owned, bytes);
+        hipError_t e = device_malloc(&owned, bytes);
         if (e != hipSuccess) {
-            set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+            set_error("device_malloc(%zu) failed: %s", bytes, hipGetErrorString(e));
             return GA_ERR_NOMEM;
         }
         GA_HIP_CHECK(hipMemcpyAsync(owned, p, bytes, hipMemcpyHostToDevice, ctx->work_stream()));
@@ -250,9 +271,9 @@ int ga_device_info(ga_ctx* h, char* name, size_t name_len, uint64_t* total_bytes
 int ga_malloc(ga_ctx* h, size_t bytes, void** dptr) {
     Ctx* c = reinterpret_cast<Ctx*>(h);
     Lock l(c);
-    hipError_t e = hipMalloc(dptr, bytes ? bytes : 16);
+    hipError_t e = device_malloc(dptr, bytes ? bytes : 16);
     if (e != hipSuccess) {
-        set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        set_error("device_malloc(%zu) failed: %s", bytes, hipGetErrorString(e));
         return GA_ERR_NOMEM;
     }
     return GA_OK;
@@ -358,8 +379,8 @@ int ga_msm_table_create(ga_ctx* h, int curve, int group, const void* bases, size
                           t->bytes = (uint64_t)t->nwin * n * msm_table_point_bytes<C, G>();
                           Staged sb{c};
                           if (rc == GA_OK) rc = sb.stage(bases, n * sizeof(Affine<F>), flags & GA_BASES_ON_DEVICE);
-                          if (rc == GA_OK && hipMalloc(&t->d_table, t->bytes) != hipSuccess) {
-                              set_error("ga_msm_table_create: hipMalloc(%llu) failed", (unsigned long long)t->bytes);
+                          if (rc == GA_OK && device_malloc(&t->d_table, t->bytes) != hipSuccess) {
+                              set_error("ga_msm_table_create: device_malloc(%llu) failed", (unsigned long long)t->bytes);
                               rc = GA_ERR_NOMEM;
                           }
                           if (rc == GA_OK) rc = msm_table_build<C, G>(c, sb.dev, n, t->c, t->d_table);

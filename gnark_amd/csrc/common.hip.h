@@ -32,6 +32,18 @@ const char* get_error();
         }                                                                                               \
     } while (0)
 
+// Every device allocation of the library goes through here.  Two things hipMalloc does not do for a long-lived server process:
+//  * the ROCm runtime allocates the private-segment ("scratch") memory of a kernel at dispatch time and ABORTS THE PROCESS when it
+//    cannot (rocdevice.cpp "Aborting with error : HSA_STATUS_ERROR_OUT_OF_RESOURCES", reproduced in round 3 with
+//    tools/exp/oom_repro.py: a key pinned into the last 96 MiB of HBM, then the table kernel's 896 B of scratch per lane) -- so an
+//    allocation that would leave less than GA_HBM_RESERVE_MB (default 1024) free is refused as out-of-memory instead;
+//  * a failed hipMalloc leaves its error in the thread's sticky last-error slot, where the next kernel-launch check would find it.
+hipError_t device_malloc_bytes(void** p, size_t bytes);
+template <class T>
+inline hipError_t device_malloc(T** p, size_t bytes) {
+    return device_malloc_bytes(reinterpret_cast<void**>(p), bytes);
+}
+
 #define GA_CHECK(expr)               \
     do {                             \
         int _r = (expr);             \
@@ -90,6 +102,7 @@ struct StageRec {
 //   GA_G16_LANES          1: a second concurrent ga_g16_prove caller queues for the device instead of proving on its own lanes
 //   GA_G16_SPLIT          0: a proof keeps its H side (computeH, Z MSM) on the lane of its witness MSMs instead of a partner lane
 //   GA_NTT_COSET_FOLD     0: coset FFTs scale their input by the coset powers (round 2) instead of running over a coset twiddle table
+// (GA_HBM_RESERVE_MB is read once per process by device_malloc: see there.)
 // The fields are relaxed atomics: the entry point that holds lane 0 refreshes them while provers on the other lanes read them.
 struct Tunables {
     std::atomic<uint64_t> msm_max_chunk{0};          // 0 = only the 2^31 pair-space limit

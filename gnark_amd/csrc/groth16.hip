@@ -95,9 +95,9 @@ struct PkUse {
 
 static int upload(Ctx* ctx, const void* src, size_t bytes, void** dst) {
     *dst = nullptr;
-    hipError_t e = hipMalloc(dst, bytes ? bytes : 16);
+    hipError_t e = device_malloc(dst, bytes ? bytes : 16);
     if (e != hipSuccess) {
-        set_error("proving key upload: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        set_error("proving key upload: device_malloc(%zu) failed: %s", bytes, hipGetErrorString(e));
         return GA_ERR_NOMEM;
     }
     if (bytes) GA_HIP_CHECK(hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -171,9 +171,9 @@ static int stage_reserve(G16Stage* st, int which, uint64_t total) {
     x.lo = k * base + (k < rem ? k : rem);
     x.cnt = base + (k < rem ? 1 : 0);
     const size_t bytes = x.cnt * stage_point_bytes(st->curve, which);
-    hipError_t e = hipMalloc(&x.d, bytes ? bytes : 16);
+    hipError_t e = device_malloc(&x.d, bytes ? bytes : 16);
     if (e != hipSuccess) {
-        set_error("proving key upload: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        set_error("proving key upload: device_malloc(%zu) failed: %s", bytes, hipGetErrorString(e));
         return GA_ERR_NOMEM;
     }
     x.reserved = true;
@@ -371,7 +371,7 @@ static int stage_finish(G16Stage* st, int precompute, G16Pk** out) {
                 if (len == 0) return GA_OK;
                 const int nwin = C::FrP::BITS / c + 1;
                 void* t = nullptr;
-                if (hipMalloc(&t, (uint64_t)nwin * len * psz) != hipSuccess) {
+                if (device_malloc(&t, (uint64_t)nwin * len * psz) != hipSuccess) {
                     set_error("proving key: hipMalloc of a %llu-byte window table failed", (unsigned long long)((uint64_t)nwin * len * psz));
                     return GA_ERR_NOMEM;
                 }
@@ -386,7 +386,7 @@ static int stage_finish(G16Stage* st, int precompute, G16Pk** out) {
             // compact base array -> wire-indexed array with (0,0) at the missing wires
             auto widen = [&](void** slot, uint64_t len, const uint32_t* d_idx, size_t psz) -> int {
                 void* wide_arr = nullptr;
-                if (hipMalloc(&wide_arr, pk->nb_wires * psz) != hipSuccess) {
+                if (device_malloc(&wide_arr, pk->nb_wires * psz) != hipSuccess) {
                     set_error("proving key: hipMalloc of a wire-indexed base array failed");
                     return GA_ERR_NOMEM;
                 }
@@ -598,7 +598,7 @@ static int read_encoded_vector(G16Stage* st, Staging& sg, ByteSource& src, int w
         return GA_OK;
     }
     *d_plain = nullptr;   // a commitment basis: kept whole
-    hipError_t e = hipMalloc(d_plain, len ? (size_t)len * sizeof(Affine<F>) : 16);
+    hipError_t e = device_malloc(d_plain, len ? (size_t)len * sizeof(Affine<F>) : 16);
     if (e != hipSuccess) {
         set_error("key file: hipMalloc of a commitment basis failed: %s", hipGetErrorString(e));
         return GA_ERR_NOMEM;
@@ -621,7 +621,7 @@ static int read_dumped_vector(G16Stage* st, Staging& sg, ByteSource& src, int wh
     char* plain = nullptr;
     if (which >= 0) GA_CHECK(stage_reserve(st, which, len));
     else {
-        hipError_t e = hipMalloc((void**)&plain, len ? len * psz : 16);
+        hipError_t e = device_malloc((void**)&plain, len ? len * psz : 16);
         if (e != hipSuccess) {
             set_error("key dump: hipMalloc of a commitment basis failed: %s", hipGetErrorString(e));
             return GA_ERR_NOMEM;

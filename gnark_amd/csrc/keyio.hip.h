@@ -381,9 +381,9 @@ struct Staging {
             GA_HIP_CHECK(hipHostMalloc((void**)&h[k], BYTES, 0));
             GA_HIP_CHECK(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
         }
-        GA_HIP_CHECK(hipMalloc((void**)&d_bytes, BYTES));
-        GA_HIP_CHECK(hipMalloc(&d_points, 2 * BYTES));   // a compressed point doubles when decoded
-        GA_HIP_CHECK(hipMalloc((void**)&d_bad, 256));
+        GA_HIP_CHECK(device_malloc((void**)&d_bytes, BYTES));
+        GA_HIP_CHECK(device_malloc(&d_points, 2 * BYTES));   // a compressed point doubles when decoded
+        GA_HIP_CHECK(device_malloc((void**)&d_bad, 256));
         return GA_OK;
     }
     ~Staging() {

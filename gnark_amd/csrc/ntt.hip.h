@@ -552,10 +552,10 @@ int ntt_coset_table(Domain* d, const Fe<FrP>& shift, const uint32_t** out) {
         void* p = nullptr;
         ~DevTmp() { hipFree(p); }
     } tmp;
-    GA_HIP_CHECK(hipMalloc(&tmp.p, cs.size() * 4));
+    GA_HIP_CHECK(device_malloc(&tmp.p, cs.size() * 4));
     GA_HIP_CHECK(hipMemcpy(tmp.p, cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
     uint32_t* tab = nullptr;
-    GA_HIP_CHECK(hipMalloc((void**)&tab, d->n * NTT_TW_WORDS * 4));
+    GA_HIP_CHECK(device_malloc((void**)&tab, d->n * NTT_TW_WORDS * 4));
     hipLaunchKernelGGL((ntt_twiddle_kernel<FrP>), dim3((unsigned)((d->n + 255) / 256)), dim3(256), 0, ctx->work_stream(), tab,
                        (const uint32_t*)d->d_pow2, d->n, d->logn, 1, (const uint32_t*)tmp.p);
     hipError_t e = hipGetLastError();
@@ -621,13 +621,13 @@ int domain_init(Ctx* ctx, Domain* d, int curve, uint64_t n) {
             a = sqr(a);
             b = sqr(b);
         }
-        GA_HIP_CHECK(hipMalloc((void**)&d->d_pow2, p2.size() * 4));
+        GA_HIP_CHECK(device_malloc((void**)&d->d_pow2, p2.size() * 4));
         GA_HIP_CHECK(hipMemcpy(d->d_pow2, p2.data(), p2.size() * 4, hipMemcpyHostToDevice));
         uint32_t** tabs[4] = {&d->d_ts, &d->d_ts_inv, &d->d_tb, &d->d_tb_inv};
         for (int t = 0; t < 4; t++) {
             const bool stacked = t < 2;
             const uint64_t count = stacked ? n : half_n;
-            GA_HIP_CHECK(hipMalloc((void**)tabs[t], count * NTT_TW_WORDS * 4));
+            GA_HIP_CHECK(device_malloc((void**)tabs[t], count * NTT_TW_WORDS * 4));
             hipLaunchKernelGGL((ntt_twiddle_kernel<FrP>), dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->work_stream(), *tabs[t],
                                (const uint32_t*)d->d_pow2 + (t & 1) * 32 * 8, count, d->logn, stacked ? 1 : 0, (const uint32_t*)nullptr);
         }
@@ -656,10 +656,10 @@ int domain_init(Ctx* ctx, Domain* d, int curve, uint64_t n) {
             memcpy(&hi[k * 8], st.l, 32);
             acc = mul(acc, step);
         }
-        GA_HIP_CHECK(hipMalloc((void**)dlo, nlo * 32));
+        GA_HIP_CHECK(device_malloc((void**)dlo, nlo * 32));
         GA_HIP_CHECK(hipMemcpy(*dlo, lo.data(), nlo * 32, hipMemcpyHostToDevice));
         if (dhi) {
-            GA_HIP_CHECK(hipMalloc((void**)dhi, nhi * 32));
+            GA_HIP_CHECK(device_malloc((void**)dhi, nhi * 32));
             GA_HIP_CHECK(hipMemcpy(*dhi, hi.data(), nhi * 32, hipMemcpyHostToDevice));
         }
         return GA_OK;

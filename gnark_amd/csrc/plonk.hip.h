@@ -441,7 +441,7 @@ int plonk_fixed_create(Domain* d0, Domain* d1, const PlonkQuotientArgs& A, Plonk
     const int np = PLONK_NB_FIXED + 2 * (int)A.nb_bsb;
     for (int p = 0; p < PLONK_NB_FIXED + 2 * PLONK_MAX_BSB; p++) fx->slot[p] = (p < np && plonk_is_fixed(p)) ? fx->nslots++ : -1;
     const size_t ev = (size_t)rho * fx->nslots * n * 32, iv = (size_t)rho * n * 32;
-    if (hipMalloc((void**)&fx->evals, ev) != hipSuccess || hipMalloc((void**)&fx->inv_xm1, iv) != hipSuccess) {
+    if (device_malloc((void**)&fx->evals, ev) != hipSuccess || device_malloc((void**)&fx->inv_xm1, iv) != hipSuccess) {
         set_error("plonk key: hipMalloc of %zu bytes failed", ev + iv);
         hipFree(fx->evals);
         delete fx;

@@ -40,7 +40,10 @@ extern "C" {
 #define GA_OK 0
 #define GA_ERR_INVALID (-1)   /* bad argument */
 #define GA_ERR_HIP (-2)       /* HIP runtime error (message in ga_last_error) */
-#define GA_ERR_NOMEM (-3)     /* device allocation failed */
+#define GA_ERR_NOMEM (-3)     /* device allocation failed -- or would have left less than GA_HBM_RESERVE_MB (environment, default
+                                 1024) MiB of HBM free: the ROCm runtime allocates the kernels' private segments at dispatch time
+                                 and aborts the PROCESS when it cannot, so the library never takes the last gigabyte.  After this
+                                 error the context and its keys stay usable. */
 #define GA_ERR_STATE (-4)     /* object used in the wrong state */
 
 /* curve ids (ecc.ID analogue; only the two curves of BASELINE.json are built) */

@@ -591,6 +591,86 @@ def test_groth16_two_callers_distinct_solutions(gpu_ctx, c, precompute):
     cases.test_emu_groth16_two_callers_distinct_solutions(gpu_ctx, c, precompute, logn=16, rounds=6)
 
 
+def test_groth16_soak_no_device_memory_growth(gpu_ctx):
+    """600 small proofs from three host threads on one key (every lane pair, slot hand-offs, helper threads, per-proof events):
+    all byte-equal to the first proof, and the device's free memory after the run is what it was after the warm-up -- nothing a
+    proof allocates (scratch is reused, events / streams are released) accumulates."""
+    import threading
+    from gnark_amd import synth
+    inst = synth.make_instance(gpu_ctx, "bn254", 12, 0x50AC, want_dlogs=False)
+    pk = inst.proving_key(gpu_ctx, precompute=1)
+    sol, nbp, r, s = inst.solution, inst.nb_public, inst.r, inst.s
+    try:
+        want = groth16.Prove(pk, sol, nbp, r, s).raw()
+        bad = []
+
+        def prover(count):
+            for _ in range(count):
+                if not np.array_equal(groth16.Prove(pk, sol, nbp, r, s).raw(), want):
+                    bad.append(1)
+
+        def run(count):
+            th = [threading.Thread(target=prover, args=(count,)) for _ in range(3)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            gpu_ctx.sync()
+
+        run(5)                                   # warm-up: every lane's scratch exists now
+        free0 = gpu_ctx.info()["free_bytes"]
+        run(200)
+        free1 = gpu_ctx.info()["free_bytes"]
+        assert not bad
+        assert free1 >= free0 - (8 << 20), (free0, free1)
+    finally:
+        pk.FreeGPUResources()
+
+
+def test_out_of_device_memory_is_an_error_not_a_crash(gpu_ctx):
+    """HBM exhausted (down to the reserve the library keeps for the runtime): pinning a key (tables asked for explicitly) and
+    proving on a key pinned earlier must come back as library errors -- no crash, no leaked lock, no poisoned context, no stale
+    HIP error picked up by the next launch -- and once the memory is back the same calls succeed with the same proof bytes."""
+    from gnark_amd import synth
+    from gnark_amd._lib import GnarkAmdError
+    from gnark_amd.device import Context
+    inst = synth.make_instance(gpu_ctx, "bn254", 16, 0x00D1, want_dlogs=False)
+    sol, nbp, r, s = inst.solution, inst.nb_public, inst.r, inst.s
+    shared_ctx, gpu_ctx = gpu_ctx, Context(0)           # a context of its own: no scratch left over from earlier tests
+    pk = inst.proving_key(gpu_ctx, precompute=-1)      # plain vectors; no proof yet, so its scratch does not exist
+    ballast = []
+    try:
+        # fill the device down to the library's reserve (GA_HBM_RESERVE_MB, 1 GiB: what the ROCm runtime needs for the kernels'
+        # private segments -- it aborts the process when it cannot get it, tools/exp/oom_repro.py): ever smaller pieces until an
+        # 8 MiB one is refused, so that less than a 2^16 proof's scratch and far less than a key with tables is left
+        step = 64 << 30
+        while step >= (8 << 20):
+            try:
+                ballast.append(gpu_ctx.malloc(step))
+            except GnarkAmdError:
+                step //= 2
+        assert gpu_ctx.info()["free_bytes"] >= (1 << 30) - (64 << 20)      # the reserve itself stays free
+        with pytest.raises(GnarkAmdError):
+            inst.proving_key(gpu_ctx, precompute=1)
+        with pytest.raises(GnarkAmdError):
+            groth16.Prove(pk, sol, nbp, r, s)
+        with pytest.raises(GnarkAmdError):               # a second failure: the first one left no lock or lane behind
+            groth16.Prove(pk, sol, nbp, r, s)
+    finally:
+        for b in ballast:
+            b.free()
+    try:
+        got = groth16.Prove(pk, sol, nbp, r, s).raw()
+        pk2 = inst.proving_key(gpu_ctx, precompute=1)
+        try:
+            assert np.array_equal(groth16.Prove(pk2, sol, nbp, r, s).raw(), got)
+        finally:
+            pk2.FreeGPUResources()
+    finally:
+        pk.FreeGPUResources()
+        gpu_ctx.close()
+
+
 def test_groth16_builder_errors(gpu_ctx):
     cases.test_emu_groth16_builder_errors(gpu_ctx)
 
