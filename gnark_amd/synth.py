@@ -95,8 +95,8 @@ def make_instance(ctx: Context, curve, logn: int, seed: int = 0x5EED0005, *, nb_
     n = 1 << logn
     nw = n
     m = n if nb_constraints is None else int(nb_constraints)
-    inf_a = [1, nw - 1] if inf_a is None else list(inf_a)
-    inf_b = [0, nw - 2] if inf_b is None else list(inf_b)
+    inf_a = np.asarray([1, nw - 1] if inf_a is None else inf_a, dtype=np.int64)
+    inf_b = np.asarray([0, nw - 2] if inf_b is None else inf_b, dtype=np.int64)
     infA = np.zeros(nw, dtype=np.uint8)
     infB = np.zeros(nw, dtype=np.uint8)
     infA[inf_a] = 1

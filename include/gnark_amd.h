@@ -75,6 +75,9 @@ typedef struct ga_g16_pk ga_g16_pk;   /* device-resident Groth16 proving key ("P
  * replaces: icicle runtime LoadBackend / CreateDevice / WarmUpDevice (groth16_icicle.go:38-72). */
 int ga_device_count(int* count);
 int ga_ctx_create(int device, ga_ctx** out);
+/* ga_ctx_destroy: every object created on the context (proving keys, builders, domains, tables, PLONK keys) must have been destroyed
+ * first and no entry point may be running on it -- the objects keep a plain pointer to their context.  The Go package creates one
+ * context per device for the life of the process (internal/ga) and never calls this. */
 void ga_ctx_destroy(ga_ctx* ctx);
 const char* ga_last_error(void);
 const char* ga_version(void);

@@ -38,11 +38,11 @@ def check_compute_h_identity(c, A, B, Cc, h_bitrev, n, nthreads=1, xv=0x12345678
     assert (ea * eb - ec) % c.r == hx * (pow(xv, n, c.r) - 1) % c.r
 
 
-def check_groth16_known_dlogs(ctx, c, logn, nthreads=1, seed=0x5EED0005, also_oracle_prover=False, proofs=1, **pk_kw):
+def check_groth16_known_dlogs(ctx, c, logn, nthreads=1, seed=0x5EED0005, also_oracle_prover=False, proofs=1, inst_kw=None, **pk_kw):
     """Groth16 Prove on the synthetic known-dlog instance: the three proof points must equal [ar]G1, [bs]G2, [krs]G1 with the
     exponents computed by the CPU oracle's dot products (gnark_amd/synth.py), and h must satisfy the polynomial identity."""
     from gnark_amd import synth
-    inst = synth.make_instance(ctx, c.name, logn, seed)
+    inst = synth.make_instance(ctx, c.name, logn, seed, **(inst_kw or {}))   # inst_kw: e.g. inf_b = the wires that do not appear in B
     n = inst.n
     sol = inst.solution
     assert np.array_equal(sol.C[:64], oracle.fr_mul(c.cid, sol.A[:64], sol.B[:64]))   # ga_fr_vec_mul really multiplied
