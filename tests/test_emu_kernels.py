@@ -901,6 +901,38 @@ def test_emu_groth16_builder_errors(emu_ctx):
     lib.ga_g16_builder_destroy(b2)                                                               # abandon: frees the staged buffers
 
 
+def test_emu_groth16_two_keys_two_curves_interleaved(emu_ctx, logn_a=6, logn_b=8, rounds=3):
+    """Two pinned keys of different sizes AND different curves on one context, proved alternately from two host threads (each
+    thread switches key every proof): the context's scratch is shared by name across keys and grows / is reused across element
+    sizes, the lanes are taken by whichever caller comes first -- every proof must equal the proof of its key computed alone."""
+    import threading
+    from gnark_amd import synth
+    ia = synth.make_instance(emu_ctx, BN254.name, logn_a, 0x2B01, want_dlogs=False)
+    ib = synth.make_instance(emu_ctx, BLS12_381.name, logn_b, 0x2B02, want_dlogs=False)
+    pka, pkb = ia.proving_key(emu_ctx, precompute=1), ib.proving_key(emu_ctx, precompute=-1)
+    try:
+        jobs = [(pka, ia), (pkb, ib)]
+        want = [groth16.Prove(pk, i.solution, i.nb_public, i.r, i.s).raw() for pk, i in jobs]
+        bad = []
+
+        def prover(tid):
+            for k in range(rounds):
+                j = (tid + k) % 2
+                pk, i = jobs[j]
+                if not np.array_equal(groth16.Prove(pk, i.solution, i.nb_public, i.r, i.s).raw(), want[j]):
+                    bad.append((tid, k, j))
+
+        th = [threading.Thread(target=prover, args=(t,)) for t in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not bad, bad
+    finally:
+        pka.FreeGPUResources()
+        pkb.FreeGPUResources()
+
+
 # ---- two proofs in flight on one context (lanes) with DIFFERENT solutions ---------------------------------------------------------
 @pytest.mark.parametrize("c,precompute", [(BN254, 1), (BLS12_381, -1)], ids=["bn254-tables", "bls12-381-no-tables"])
 def test_emu_groth16_two_callers_distinct_solutions(emu_ctx, c, precompute, logn=7, rounds=2):

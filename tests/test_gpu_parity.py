@@ -591,6 +591,12 @@ def test_groth16_two_callers_distinct_solutions(gpu_ctx, c, precompute):
     cases.test_emu_groth16_two_callers_distinct_solutions(gpu_ctx, c, precompute, logn=16, rounds=6)
 
 
+def test_groth16_two_keys_two_curves_interleaved(gpu_ctx):
+    """a 2^16 BN254 key (tables) and a 2^18 BLS12-381 key (plain vectors) pinned on one context, proved alternately from two host
+    threads: shared scratch names across keys, element sizes and lanes"""
+    cases.test_emu_groth16_two_keys_two_curves_interleaved(gpu_ctx, logn_a=16, logn_b=18, rounds=6)
+
+
 def test_groth16_soak_no_device_memory_growth(gpu_ctx):
     """600 small proofs from three host threads on one key (every lane pair, slot hand-offs, helper threads, per-proof events):
     all byte-equal to the first proof, and the device's free memory after the run is what it was after the warm-up -- nothing a
