@@ -1269,6 +1269,7 @@ static int prove_partial(G16Pk* pk, const SlotLease& slot, bool preloaded, const
     std::thread helper;
     if (!preloaded || may_split)
         helper = std::thread([&]() {
+          try {   // (an exception leaving a thread function terminates the process: host allocations below can throw)
             auto fail = [&](int rc, const char* what) {
                 h_rc = rc;
                 h_err = std::string(what) + ": " + get_error();
@@ -1333,6 +1334,10 @@ static int prove_partial(G16Pk* pk, const SlotLease& slot, bool preloaded, const
                 if (rc != GA_OK) return fail(rc, "K MSM");
                 h_did_k = true;
             }
+          } catch (...) {
+              h_rc = GA_ERR_STATE;
+              h_err = "exception on the helper thread (out of host memory?)";
+          }
         });
     ThreadJoiner joiner{helper};
     bool did_k = false;
