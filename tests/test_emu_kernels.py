@@ -1242,6 +1242,64 @@ def test_emu_proving_key_files(emu_ctx, c, circuit, tmp_path):
 
 
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_emu_proving_key_file_fuzz(emu_ctx, c):
+    """The key reader on damaged input (marshal.go:305-373,449-539 read untrusted files): every truncation point class and 24
+    random mutations (byte flips, overwritten length words, spliced garbage) of each of the three layouts must come back as an
+    error -- or as a key, when the damage happens to decode -- without crashing, hanging or allocating by an untrusted length;
+    a key that does load must survive a proof call (error or proof)."""
+    rng = pyref.Xoshiro(0xF022)
+    cs = pyref.commit_r1cs()
+    pk, _, _ = pyref.groth16_setup(c, cs, [rng.field(c.r) for _ in range(5 + len(cs.commitments) + 1)])
+    w = pyref.commit_solve(c, cs, 4, 9, lambda i, ww: pyref.commitment_hint(pk, cs, i, ww)[1])
+    removed = sorted({j for cm in cs.commitments for j in cm.private_committed} | {cm.commitment_index for cm in cs.commitments})
+    A, B, Cc = pyref.r1cs_solve(c, cs, w)
+    sol = groth16.Solution(W=fr_to_arr(c, w), A=fr_to_arr(c, A), B=fr_to_arr(c, B), C=fr_to_arr(c, Cc))
+    r, s = fr_to_arr(c, [rng.field(c.r)]), fr_to_arr(c, [rng.field(c.r)])
+    images = [pyref.pk_write(pk, raw=False), pyref.pk_write(pk, raw=True), pyref.pk_write_dump(pk)]
+    prng = np.random.default_rng(20260924)
+    loaded = errors = 0
+
+    def attempt(data):
+        nonlocal loaded, errors
+        try:
+            dpk = groth16.ProvingKey.ReadFrom(emu_ctx, c.name, bytes(data), k_remove=removed)
+        except Exception:
+            errors += 1
+            return
+        loaded += 1
+        try:
+            groth16.Prove(dpk, sol, cs.nb_public, r, s)
+        except Exception:
+            pass
+        finally:
+            dpk.FreeGPUResources()
+
+    for img in images:
+        n = len(img)
+        for cut in sorted({0, 1, 7, 8, 9, 100, 167, 168, 169, 170, n // 3, n // 2, n - 33, n - 4, n - 1} & set(range(n))):
+            attempt(img[:cut])
+        for _ in range(24):
+            d = bytearray(img)
+            kind = int(prng.integers(0, 4))
+            pos = int(prng.integers(0, n))
+            if kind == 0:                                   # a flipped byte anywhere
+                d[pos] ^= int(prng.integers(1, 256))
+            elif kind == 1:                                 # a huge big-endian length / count word somewhere
+                d[pos:pos + 8] = (int(prng.integers(1 << 20, 1 << 62))).to_bytes(8, "big")[: max(0, min(8, n - pos))]
+            elif kind == 2:                                 # random garbage spliced in
+                d[pos:pos] = bytes(prng.integers(0, 256, size=int(prng.integers(1, 64)), dtype=np.uint8))
+            else:                                           # a run of 0xFF
+                d[pos:pos + 16] = b"\xff" * min(16, n - pos)
+            attempt(d)
+    assert errors > 40          # most damage is detected (points off the curve, lengths that do not fit, short input)
+    whole = groth16.ProvingKey.ReadFrom(emu_ctx, c.name, images[0], k_remove=removed)   # and the reader is still usable afterwards
+    try:
+        assert whole.bytes_read == len(images[0])
+    finally:
+        whole.FreeGPUResources()
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
 def test_emu_proof_unmarshal(emu_ctx, c):
     """Proof.ReadFrom (marshal.go:62-86) on the oracle's WriteTo and WriteRawTo bytes, with and without commitments; the single
     point decoder on the reference's serialized verifying keys (backend/solidity/testdata/*.vk)"""
