@@ -1342,6 +1342,41 @@ def test_emu_proof_unmarshal(emu_ctx, c):
         off += ln
 
 
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_emu_proof_unmarshal_fuzz(emu_ctx, c):
+    """Proof.ReadFrom on damaged bytes (proofs arrive over the network): truncations at every length and random mutations of a
+    compressed and a raw proof with commitments -- an error or a proof, never a crash; an absurd commitment count is refused
+    before anything is allocated for it."""
+    lib = emu_ctx.lib
+    rng = pyref.Xoshiro(1234)
+    G1, G2 = group_of(c, 0), group_of(c, 1)
+    pt1 = lambda: G1.mul(c.g1, rng.field(c.r))
+    ar, bs, krs, coms, pok = pt1(), G2.mul(c.g2, rng.field(c.r)), pt1(), [pt1(), pt1()], pt1()
+    prng = np.random.default_rng(7)
+    ok = bad = 0
+    for data in (pyref.proof_bytes(c, ar, bs, krs, coms, pok), pyref.proof_bytes_raw(c, ar, bs, krs, coms, pok)):
+        cases_ = [data[:k] for k in range(len(data))]
+        for _ in range(150):
+            d = bytearray(data)
+            for _ in range(int(prng.integers(1, 4))):
+                d[int(prng.integers(0, len(d)))] = int(prng.integers(0, 256))
+            cases_.append(bytes(d))
+        for blob in cases_:
+            try:
+                p = groth16.ParseProof(c.name, blob, lib=lib)
+                assert p.bytes_read <= len(blob)
+                ok += 1
+            except Exception:
+                bad += 1
+    # the commitment count sits right after Ar | Bs | Krs: 0xFFFFFFFF commitments must be an error, not an allocation
+    comp = pyref.proof_bytes(c, ar, bs, krs, [], None)
+    head = 4 * c.fp_bytes
+    assert comp[head:head + 4] == b"\x00\x00\x00\x00"
+    with pytest.raises(Exception):
+        groth16.ParseProof(c.name, comp[:head] + b"\xff\xff\xff\xff" + comp[head + 4:], lib=lib)
+    assert bad > 200 and ok >= 0
+
+
 def test_emu_msm_unreduced_canonical_scalars(emu_ctx):
     """canonical (non-Montgomery) scalars need not be below r -- r itself, 2r+5 and 2^256-1 give the same point as
     their residues"""
