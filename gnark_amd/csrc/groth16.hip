@@ -590,6 +590,7 @@ static int read_encoded_vector(G16Stage* st, Staging& sg, ByteSource& src, int w
         compressed = f.compressed || (f.infinity && C::ID == GA_BLS12_381 && (b0 & 0x80));
     }
     if (len_out) *len_out = len;
+    GA_CHECK(src.expect(len, compressed ? sizeof(Affine<F>) / 2 : sizeof(Affine<F>), "a point vector"));   // before any allocation
     if (which >= 0) {
         GA_CHECK(stage_reserve(st, which, len));
         G16Stage::Vec& x = st->v[which];
@@ -618,6 +619,7 @@ static int read_dumped_vector(G16Stage* st, Staging& sg, ByteSource& src, int wh
         return GA_ERR_INVALID;
     }
     if (len_out) *len_out = len;
+    GA_CHECK(src.expect(len, psz, "a dumped slice"));   // before any allocation
     char* plain = nullptr;
     if (which >= 0) GA_CHECK(stage_reserve(st, which, len));
     else {

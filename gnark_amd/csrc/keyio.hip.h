@@ -24,6 +24,7 @@
 // the key-level framing has no fixture in the reference tree, so the test-side big-integer restatement writes the same layouts
 // from marshal.go and the tests compare bytes both ways (library-written == checker-written, and each reads the other's).
 #pragma once
+#include <sys/stat.h>
 #include <errno.h>
 #include <unistd.h>
 
@@ -262,6 +263,25 @@ struct ByteSource {
                 return GA_ERR_INVALID;
             }
             ahead.insert(ahead.end(), tmp, tmp + r);
+        }
+        return GA_OK;
+    }
+    // bytes left in the input, when that can be known (memory image; regular file): a length word read from the input is checked
+    // against it BEFORE anything is allocated for it (the reader's fuzz test under ASAN: a damaged 32-bit length asked for 72 GB)
+    uint64_t remaining() const {
+        if (fd < 0) return mem_len - mem_pos;
+        struct stat sb;
+        if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) return UINT64_MAX;
+        const off_t at = lseek(fd, 0, SEEK_CUR);
+        if (at < 0 || sb.st_size < at) return UINT64_MAX;
+        return (uint64_t)(sb.st_size - at) + ahead.size();
+    }
+    int expect(uint64_t count, uint64_t bytes_each, const char* what) const {
+        const uint64_t left = remaining();
+        if (left != UINT64_MAX && (bytes_each == 0 || count > left / bytes_each)) {
+            set_error("key file: unexpected end of input (%s announces %llu elements of at least %llu bytes, %llu bytes are left)", what, (unsigned long long)count,
+                      (unsigned long long)bytes_each, (unsigned long long)left);
+            return GA_ERR_INVALID;
         }
         return GA_OK;
     }

@@ -19,6 +19,9 @@ def pytest_configure(config):
 def emu_lib():
     """The product sources compiled against the functional HIP emulation (tests/emu) -- kernel-logic checks only."""
     from gnark_amd import _lib
+    alt = os.environ.get("GA_EMU_LIB_PATH")   # another build of the same emulation library (sanitizer builds, tools/emu_sanitize.sh)
+    if alt:
+        return _lib.Library(alt)
     so = os.path.join(ROOT, "tests", "emu", "libgnark_amd_emu.so")
     r = subprocess.run([os.path.join(ROOT, "tests", "emu", "build_emu.sh")], capture_output=True, text=True)
     if r.returncode != 0 or not os.path.exists(so):
