@@ -195,7 +195,15 @@ struct Table29 {
     // limbs unpacked (80 B for BN254 G1) made every third gather touch two lines: FETCH_SIZE 41 GB per 2^24 MSM.
     static constexpr int WORDS = sizeof(Affine<F>) / 4;
     // workgroup size: the LDS-resident accumulators (4*NW words per lane) must leave room for 2 workgroups per CU
+    // (GA_ACC_THREADS_WIDE: A/B builds -- the workgroup size of the 14-limb fields, whose 224 / 448 bytes of LDS per lane allow more
+    // waves per CU with smaller workgroups: 8 -> 10 -> 11 for BLS12-381 G1 at 256 / 128 / 64 lanes, 4 -> 5 for G2 at 128 / 64.
+    // Measured in round 3 (profiles/r03_v_bls_workgroup_size_ab.txt): G1 30.41 / 30.92 / 30.44 ms per 2^24 launch, G2 95.6 (128 lanes)
+    // / 108.6 (64 lanes): the kernels are issue-bound at two waves per SIMD already; the defaults stay)
+#ifdef GA_ACC_THREADS_WIDE
+    static constexpr int THREADS = NW >= 14 ? GA_ACC_THREADS_WIDE : ((4 * NW * 4 * 256 <= 72 * 1024) ? 256 : 128);
+#else
     static constexpr int THREADS = (4 * NW * 4 * 256 <= 72 * 1024) ? 256 : 128;
+#endif
     static constexpr int MIN_WAVES = Lazy<F>::FP2 ? 2 : GA_ACC29_MINW;
 };
 
