@@ -293,6 +293,17 @@ def main():
             ecc.MultiExp(ctx, cid, _lib.G1, bases, scalars, n=n)
         out["plain_msm_no_tables"] = {"ms_per_msm": round((time.perf_counter() - t0) * 500, 3),
                                       "Mscalar_mul_per_s": round(n / ((time.perf_counter() - t0) / 2) / 1e6, 2)}
+        # SURVEY 8d metric (i), second figure: the headline MSM with the SCALARS in host memory (PCIe-inclusive; never `value`)
+        s_host = scalars.to_host((n, 4))
+        r_host = table.MultiExp(s_host)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            r_host = table.MultiExp(s_host)
+        el_h = (time.perf_counter() - t0) / 3
+        out["msm_with_scalar_h2d"] = {"ms_per_msm": round(el_h * 1e3, 3), "Mscalar_mul_per_s": round(n / el_h / 1e6, 2),
+                                      "same_result": bool(np.array_equal(r_host, result)),
+                                      "how": "the timed table MSM with its 2^%d x 32 B of scalars uploaded from pageable host memory inside the call" % args.log_n}
+        del s_host
     if table is not None:
         table.free()
         if world > 1:

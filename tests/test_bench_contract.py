@@ -43,6 +43,7 @@ def test_single_rank_line(env):
     assert g["matches_dlog"] is True and g["check"]["h_identity_ok"] is True and g["proofs"] == 2
     assert g["pipelined"]["same_proof_bytes"] is True and g["pipelined"]["host_threads"] == 2
     assert d["plonk"]["identity_ok"] is True
+    assert d["msm_with_scalar_h2d"]["same_result"] is True and d["msm_with_scalar_h2d"]["ms_per_msm"] > 0
 
 
 def test_two_ranks_line(env):
