@@ -901,6 +901,25 @@ def test_emu_groth16_builder_errors(emu_ctx):
     lib.ga_g16_builder_destroy(b2)                                                               # abandon: frees the staged buffers
 
 
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_emu_groth16_tiny_domains_vs_oracle(emu_ctx, c):
+    """the smallest circuits (domain 2, 4, 8; one public wire; duplicate infinity positions): window plans with a single point,
+    transforms of one and two stages, empty K slices -- with and without tables, against the C oracle's prover"""
+    from gnark_amd import synth
+    for logn in (1, 2, 3):
+        inst = synth.make_instance(emu_ctx, c.name, logn, 0x77, want_dlogs=False, nb_public=1)
+        key = dict(inst.key, n=inst.n)
+        sol = inst.solution
+        want = oracle.groth16_prove(c.cid, key, sol.W, sol.A, sol.B, sol.C, inst.nb_public, inst.r, inst.s, nthreads=1)
+        want = np.concatenate([np.asarray(w).reshape(-1) for w in want])
+        for pre in (1, -1):
+            pk = inst.proving_key(emu_ctx, precompute=pre)
+            try:
+                assert np.array_equal(groth16.Prove(pk, sol, inst.nb_public, inst.r, inst.s).raw(), want), (logn, pre)
+            finally:
+                pk.FreeGPUResources()
+
+
 def test_emu_groth16_two_keys_two_curves_interleaved(emu_ctx, logn_a=6, logn_b=8, rounds=3):
     """Two pinned keys of different sizes AND different curves on one context, proved alternately from two host threads (each
     thread switches key every proof): the context's scratch is shared by name across keys and grows / is reused across element
