@@ -175,12 +175,84 @@ ntt_pass29r4_kernel(uint32_t* data, const uint32_t* src, const uint32_t* __restr
     }
     __syncthreads();
 
-    int k = 0;
-    for (; k + 1 < K; k += 2) {
-        // stage order: DIT ascending (t, t+1); natural -> bit-reversed descending (t+1, t) with t = K-2-k
-        const int t = DIT_ ? k : (K - 2 - k);
+    // rounds of r stages in registers per LDS round trip: r = 2 (radix-4 blocks), a last r = 1 for an odd stage count; with
+    // GA_NTT_RADIX8 (A/B builds) r = 3 wherever that leaves no single stage over (10 = 3+3+2+2, 7 = 3+2+2).  Bit-reversed -> natural
+    // runs the groups ascending, natural -> bit-reversed descending (the stages INSIDE a group likewise).
+    for (int done = 0; done < K;) {
+        const int rem = K - done;
+#ifdef GA_NTT_RADIX8
+        const int r = (rem >= 5 || rem == 3) ? 3 : (rem >= 2 ? 2 : 1);
+#else
+        const int r = rem >= 2 ? 2 : 1;
+#endif
+        const int t = DIT_ ? done : (K - done - r);
         const int lb = lc + t;
         const int s = s_lo + t;
+#ifdef GA_NTT_RADIX8
+        if (r == 3) {
+            for (uint32_t q = tid; q < tile_elems / 8; q += NTT_THREADS) {
+                const uint32_t l0 = ((q >> lb) << (lb + 3)) | (q & ((1u << lb) - 1));
+                const uint64_t i0 = ntt_gidx(l0, tile, lg_tile, s_lo, K, lc);
+                E a[8];   // a[b2 b1 b0]: index bit lb + j of the element is b_j
+#pragma unroll
+                for (int j = 0; j < 8; j++) a[j] = T.get(l0 | ((uint32_t)j << lb));
+                // butterfly on elements (lo, hi) with twiddle entry kk: (lo, hi) <- (lo + hi*w, lo - hi*w); products < 3p
+                auto bf = [&](int lo, int hi, const E& w) {
+                    const E m = f29_mul(a[hi], w);
+                    const E x = a[lo];
+                    a[lo] = f29_add_raw(x, m);
+                    a[hi] = f29_sub_raw<4>(x, m);
+                };
+                if (DIT_) {
+                    const uint64_t x = i0 & ((1ull << s) - 1);
+                    {   // stage s on bit 0: one twiddle
+                        const E w = twid((1ull << s) + x);
+#pragma unroll
+                        for (int h = 0; h < 4; h++) bf(2 * h, 2 * h + 1, w);
+                    }
+#pragma unroll
+                    for (int b0 = 0; b0 < 2; b0++) {   // stage s+1 on bit 1: position x + b0*2^s inside the block
+                        const E w = twid((2ull << s) + ((uint64_t)b0 << s) + x);
+                        bf(b0, b0 | 2, w);
+                        bf(b0 | 4, b0 | 6, w);
+                    }
+#pragma unroll
+                    for (int j = 4; j < 8; j++) f29_normalize(a[j]);   // third-stage multiplicands: limbs back below 2^29 (+ top)
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {      // stage s+2 on bit 2: position x + (b0 + 2 b1)*2^s
+                        const E w = twid((4ull << s) + ((uint64_t)b << s) + x);
+                        bf(b, b | 4, w);
+                    }
+                } else {
+                    const uint64_t u = i0 >> (s + 3);
+                    {   // stage s+2 on bit 2: the block's twiddle
+                        const E w = twid(u);
+#pragma unroll
+                        for (int b = 0; b < 4; b++) bf(b, b | 4, w);
+                    }
+#pragma unroll
+                    for (int b2 = 0; b2 < 2; b2++) {   // stage s+1 on bit 1: block 2u + b2
+                        const E w = twid(2 * u + b2);
+                        bf(4 * b2, 4 * b2 | 2, w);
+                        bf(4 * b2 | 1, 4 * b2 | 3, w);
+                    }
+#pragma unroll
+                    for (int h = 0; h < 4; h++) f29_normalize(a[2 * h + 1]);
+#pragma unroll
+                    for (int h = 0; h < 4; h++) {      // stage s on bit 0: block 4u + 2 b2 + b1 = 4u + h
+                        const E w = twid(4 * u + h);
+                        bf(2 * h, 2 * h + 1, w);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    f29_normalize(a[j]);
+                    T.put(l0 | ((uint32_t)j << lb), a[j]);
+                }
+            }
+        } else
+#endif
+        if (r == 2) {
         for (uint32_t q = tid; q < tile_elems / 4; q += NTT_THREADS) {
             const uint32_t l00 = ((q >> lb) << (lb + 2)) | (q & ((1u << lb) - 1));
             // (DIT: first stage on bit lb, second on bit lb+1; natural -> bit-reversed: the other way round, which is the same
@@ -235,12 +307,7 @@ ntt_pass29r4_kernel(uint32_t* data, const uint32_t* src, const uint32_t* __restr
             T.put(l10, c10);
             T.put(l11, c11);
         }
-        __syncthreads();
-    }
-    if (k < K) {   // odd stage count: the last stage as a plain radix-2 stage (DIT: t = K-1, natural -> bit-reversed: t = 0)
-        const int t = DIT_ ? k : 0;
-        const int lb = lc + t;
-        const int s = s_lo + t;
+        } else {   // a single stage (odd stage count: the last round; DIT: t = K-1, natural -> bit-reversed: t = 0)
         for (uint32_t q = tid; q < tile_elems / 2; q += NTT_THREADS) {
             uint32_t l0 = ((q >> lb) << (lb + 1)) | (q & ((1u << lb) - 1));
             uint32_t l1 = l0 | (1u << lb);
@@ -260,7 +327,9 @@ ntt_pass29r4_kernel(uint32_t* data, const uint32_t* src, const uint32_t* __restr
             T.put(l0, f29_add(x, m));
             T.put(l1, f29_sub<4>(x, m));
         }
+        }
         __syncthreads();
+        done += r;
     }
 
     for (uint32_t l = tid; l < tile_elems; l += NTT_THREADS) {
