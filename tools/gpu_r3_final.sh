@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-3 closing run on one box: full GPU suite, smoke(), the bench lines (both curves), the PLONK leg, kernel stats, FETCH/WRITE and
 # SQ passes of the final code.  TAG names the output files (copied into profiles/ afterwards).
-TAG=${TAG:-r03_z}
+TAG=${TAG:-r03_final}
 OUT=gpurun_out/final3
 mkdir -p $OUT
 export TMPDIR=/tmp
