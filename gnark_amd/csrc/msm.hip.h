@@ -1069,7 +1069,8 @@ int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, X
     const int nsets = P.nsets;
     // buckets per running-sum group: MSM_GROUP when there are plenty of buckets, smaller (down to 2) when a set has few so
     // that the reduction still spreads over >= 2^15 lanes (small n, or table mode's single bucket set)
-    uint32_t m_groups = (uint32_t)MSM_GROUP;
+    const int tuned_group = ctx->tun.msm_group.load(std::memory_order_relaxed);
+    uint32_t m_groups = tuned_group ? (uint32_t)tuned_group : (uint32_t)MSM_GROUP;
     const uint64_t min_lanes = 32768;   // (65536 / 131072 measured in round 2: no change / slower)
     while (m_groups > 2 && (uint64_t)half * nsets / m_groups < min_lanes) m_groups >>= 1;
     if (m_groups > half) m_groups = half;
