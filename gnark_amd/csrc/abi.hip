@@ -103,6 +103,7 @@ void Tunables::read_env() {
     put(ntt_coset_fold, (int)num("GA_NTT_COSET_FOLD", 1));
     put(table_c, (int)num("GA_TABLE_C", 0));
     put(msm_exact_redo, (int)num("GA_MSM_EXACT_REDO", 0));
+    put64(msm_fuse_min, num("GA_MSM_FUSE_MIN", 1ull << 25));
     const int grp = (int)num("GA_MSM_GROUP", 0);
     put(msm_group, (grp >= 2 && grp <= 256 && (grp & (grp - 1)) == 0) ? grp : 0);
     const uint64_t seg = num("GA_MSM_MIN_SEG", 256);

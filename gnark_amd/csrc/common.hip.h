@@ -114,6 +114,7 @@ struct Tunables {
     std::atomic<int> table_c{0};
     std::atomic<uint64_t> msm_min_seg{256};
     std::atomic<int> msm_exact_redo{0};
+    std::atomic<uint64_t> msm_fuse_min{1ull << 25};   // pairs from which the digits are fused with the first sort pass (msm.hip.h 1b)
     std::atomic<int> msm_group{0};                   // buckets per running-sum group of the window reduction (0 = MSM_GROUP)
     void read_env();
 };

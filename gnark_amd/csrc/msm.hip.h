@@ -47,19 +47,21 @@ typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_con
                                                                        rocprim::block_radix_rank_algorithm::match>>
     MsmSortWide;
 
-// Sort (key, value) pairs on the low `end_bit` key bits, ping-ponging between the two buffer pairs (no third copy of the data);
-// on return keys2/vals2 point at the sorted arrays and keys/vals at the other pair.
+// Sort (key, value) pairs on key bits [begin_bit, end_bit), ping-ponging between the two buffer pairs (no third copy of the data);
+// on return keys2/vals2 point at the sorted arrays and keys/vals at the other pair.  (The sort is stable: with begin_bit > 0 it is
+// the last pass of an LSD sort whose first pass the caller has made itself, msm_digits_pass1_kernel.)
 inline int msm_sort_pairs(Ctx* ctx, const std::string& tmp_name, uint32_t*& keys, uint32_t*& keys2, uint32_t*& vals, uint32_t*& vals2, size_t m,
-                          int end_bit, hipStream_t st) {
+                          int end_bit, hipStream_t st, int begin_bit = 0) {
     rocprim::double_buffer<uint32_t> dk(keys, keys2), dv(vals, vals2);
-    const bool wide = (end_bit + 10) / 11 < (end_bit + 7) / 8;   // fewer passes with 11-bit digits than with 8-bit ones
+    const int bits = end_bit - begin_bit;
+    const bool wide = (bits + 10) / 11 < (bits + 7) / 8;   // fewer passes with 11-bit digits than with 8-bit ones
     size_t tmp_bytes = 0;
     void* tmp = nullptr;
-    if (wide) GA_HIP_CHECK((rocprim::radix_sort_pairs<MsmSortWide>(nullptr, tmp_bytes, dk, dv, m, 0, (unsigned)end_bit, st)));
-    else GA_HIP_CHECK((rocprim::radix_sort_pairs(nullptr, tmp_bytes, dk, dv, m, 0, (unsigned)end_bit, st)));
+    if (wide) GA_HIP_CHECK((rocprim::radix_sort_pairs<MsmSortWide>(nullptr, tmp_bytes, dk, dv, m, (unsigned)begin_bit, (unsigned)end_bit, st)));
+    else GA_HIP_CHECK((rocprim::radix_sort_pairs(nullptr, tmp_bytes, dk, dv, m, (unsigned)begin_bit, (unsigned)end_bit, st)));
     GA_CHECK(ctx->scratch_get(tmp_name.c_str(), tmp_bytes + 256, &tmp));
-    if (wide) GA_HIP_CHECK((rocprim::radix_sort_pairs<MsmSortWide>(tmp, tmp_bytes, dk, dv, m, 0, (unsigned)end_bit, st)));
-    else GA_HIP_CHECK((rocprim::radix_sort_pairs(tmp, tmp_bytes, dk, dv, m, 0, (unsigned)end_bit, st)));
+    if (wide) GA_HIP_CHECK((rocprim::radix_sort_pairs<MsmSortWide>(tmp, tmp_bytes, dk, dv, m, (unsigned)begin_bit, (unsigned)end_bit, st)));
+    else GA_HIP_CHECK((rocprim::radix_sort_pairs(tmp, tmp_bytes, dk, dv, m, (unsigned)begin_bit, (unsigned)end_bit, st)));
     keys2 = dk.current();
     keys = dk.alternate();
     vals2 = dv.current();
@@ -68,26 +70,27 @@ inline int msm_sort_pairs(Ctx* ctx, const std::string& tmp_name, uint32_t*& keys
 }
 
 // ---- 1. digits ------------------------------------------------------------------------------------
+// The signed c-bit digits of one scalar, least significant window first: (key, value) of window w.
+// table mode: every window shares ONE bucket set (bucket set `key_base / half` of a batch of scalar vectors over the same
+// table) and the value indexes the precomputed table [window][point]; skip = total bucket count (sorts last)
 template <class FrP>
-__global__ void msm_digits_kernel(const uint32_t* __restrict__ scalars, uint64_t n, int mont, int c, int nwin, int win_lo,
-                                  int win_hi, int table, uint32_t key_base, uint32_t skip, uint32_t* __restrict__ keys,
-                                  uint32_t* __restrict__ vals) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Fe<FrP> s = load_fe<FrP>(scalars + i * 8);
-    if (mont) s = from_mont(s);
-    else {
-        // canonical input may be any 256-bit integer (a caller's big.Int bytes): bring it below r, at most 2^256 / r < 6 steps,
-        // so that only (BITS mod c) bits are live in the top window as the digit loop assumes
-#pragma unroll 1
-        for (int k = 0; k < 6; k++) reduce_once<FrP>(s.l);
-    }
-    const uint32_t half = 1u << (c - 1);
-    const uint32_t mask = (1u << c) - 1;
-    // table mode: every window shares ONE bucket set (bucket set `key_base / half` of a batch of scalar vectors over the same
-    // table) and the value indexes the precomputed table [window][point]; skip = total bucket count (sorts last)
+struct DigitWalk {
+    Fe<FrP> s;
     uint32_t carry = 0;
-    for (int w = 0; w < nwin; w++) {
+    __device__ __forceinline__ void load(const uint32_t* __restrict__ scalars, uint64_t i, int mont) {
+        s = load_fe<FrP>(scalars + i * 8);
+        if (mont) s = from_mont(s);
+        else {
+            // canonical input may be any 256-bit integer (a caller's big.Int bytes): bring it below r, at most 2^256 / r < 6 steps,
+            // so that only (BITS mod c) bits are live in the top window as the digit loop assumes
+#pragma unroll 1
+            for (int k = 0; k < 6; k++) reduce_once<FrP>(s.l);
+        }
+    }
+    __device__ __forceinline__ void next(int c, int w, int win_lo, uint64_t n, uint64_t i, int table, uint32_t key_base, uint32_t skip,
+                                         uint32_t& key, uint32_t& val) {
+        const uint32_t half = 1u << (c - 1);
+        const uint32_t mask = (1u << c) - 1;
         uint32_t d = (s.l[0] & mask) + carry;
         // s >>= c  (c < 32)
 #pragma unroll
@@ -101,11 +104,140 @@ __global__ void msm_digits_kernel(const uint32_t* __restrict__ scalars, uint64_t
         } else {
             carry = 0;
         }
+        key = d == 0 ? skip : key_base + (table ? 0u : (uint32_t)(w - win_lo) * half) + (d - 1);
+        val = (table ? (uint32_t)((uint64_t)w * n + i) : (uint32_t)i) | neg;
+    }
+};
+
+template <class FrP>
+__global__ void msm_digits_kernel(const uint32_t* __restrict__ scalars, uint64_t n, int mont, int c, int nwin, int win_lo,
+                                  int win_hi, int table, uint32_t key_base, uint32_t skip, uint32_t* __restrict__ keys,
+                                  uint32_t* __restrict__ vals) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    DigitWalk<FrP> D;
+    D.load(scalars, i, mont);
+    for (int w = 0; w < nwin; w++) {
+        uint32_t k, v;
+        D.next(c, w, win_lo, n, i, table, key_base, skip, k, v);
         if (w >= win_lo && w < win_hi) {
             uint64_t idx = (uint64_t)(w - win_lo) * n + i;
-            keys[idx] = d == 0 ? skip : key_base + (table ? 0u : (uint32_t)(w - win_lo) * half) + (d - 1);
-            vals[idx] = (table ? (uint32_t)((uint64_t)w * n + i) : (uint32_t)i) | neg;
+            keys[idx] = k;
+            vals[idx] = v;
         }
+    }
+}
+
+// ---- 1b. digits fused with the first pass of the radix sort (large shared bucket sets) ----------------------------------------
+// The plain sequence writes the (key, value) pairs in scalar order (1.6 GB at 12 x 2^24), reads the keys for the histograms and
+// reads / scatters the pairs twice (two 11-bit onesweep passes).  Here the FIRST LSD pass -- a partition by the low MSM_P1_BITS key
+// bits -- is made by the kernel that extracts the digits: a histogram of the low key bits straight from the scalars (digits are
+// cheap to recompute: nothing is written), then a tile of <= 1024 scalars x windows is partitioned in LDS and leaves the CU as one
+// run per (tile, bin); the library then sorts bits [MSM_P1_BITS, end) in ONE stable pass, which yields the fully sorted list.
+// The order inside a bin is not the input order (ranks come from LDS atomics) -- irrelevant for a first pass.  Any key distribution
+// works: a bin's slice of the output is reserved with one global atomic per (tile, bin).
+// Measured at 12 x 2^24 pairs (tools/exp/partbench.hip, profiles/README.md round 3 batch ZZ): digits 0.37 + sort 3.62 ms ->
+// histogram 0.19 + digits/first pass 1.38 + second pass 1.87 ms.
+constexpr int MSM_P1_BITS = 11;
+constexpr uint32_t MSM_P1_BINS = 1u << MSM_P1_BITS;
+constexpr int MSM_P1_THREADS = 1024;
+constexpr int MSM_P1_MAXW = 16;                       // windows a thread keeps in registers
+constexpr uint32_t MSM_P1_ENTRIES = 1024 * 13;        // pairs staged per tile: 104 KB of LDS (+ 32 KB of counters)
+static inline uint32_t msm_p1_tile_scalars(int nwl) {
+    const uint32_t t = MSM_P1_ENTRIES / (uint32_t)nwl;
+    return t < (uint32_t)MSM_P1_THREADS ? t : (uint32_t)MSM_P1_THREADS;
+}
+
+template <class FrP>
+__global__ void __launch_bounds__(256)
+msm_digit_hist_kernel(const uint32_t* __restrict__ scalars, uint64_t n, int mont, int c, int nwin, int win_lo, int win_hi, int table,
+                      uint32_t key_base, uint32_t skip, uint32_t* __restrict__ ghist) {
+    __shared__ uint32_t h[MSM_P1_BINS];
+    for (uint32_t b = threadIdx.x; b < MSM_P1_BINS; b += blockDim.x) h[b] = 0;
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        DigitWalk<FrP> D;
+        D.load(scalars, i, mont);
+        for (int w = 0; w < win_hi; w++) {
+            uint32_t k, v;
+            D.next(c, w, win_lo, n, i, table, key_base, skip, k, v);
+            if (w >= win_lo) atomicAdd(&h[k & (MSM_P1_BINS - 1)], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < MSM_P1_BINS; b += blockDim.x)
+        if (h[b]) atomicAdd(&ghist[b], h[b]);
+}
+
+// exclusive scan of the MSM_P1_BINS bin counts (one block): where each bin's slice of the partitioned arrays starts
+static __global__ void __launch_bounds__(1024) msm_p1_scan_kernel(const uint32_t* __restrict__ ghist, uint32_t* __restrict__ cursor) {
+    __shared__ uint32_t a[2][MSM_P1_BINS];
+    for (uint32_t b = threadIdx.x; b < MSM_P1_BINS; b += blockDim.x) a[0][b] = ghist[b];
+    __syncthreads();
+    int cur = 0;
+    for (uint32_t d = 1; d < MSM_P1_BINS; d <<= 1) {
+        for (uint32_t b = threadIdx.x; b < MSM_P1_BINS; b += blockDim.x) a[cur ^ 1][b] = a[cur][b] + (b >= d ? a[cur][b - d] : 0);
+        __syncthreads();
+        cur ^= 1;
+    }
+    for (uint32_t b = threadIdx.x; b < MSM_P1_BINS; b += blockDim.x) cursor[b] = b ? a[cur][b - 1] : 0;
+}
+
+template <class FrP>
+__global__ void __launch_bounds__(MSM_P1_THREADS)
+msm_digits_pass1_kernel(const uint32_t* __restrict__ scalars, uint64_t n, int mont, int c, int nwin, int win_lo, int win_hi, int table,
+                        uint32_t key_base, uint32_t skip, uint32_t tile_scalars, uint32_t* __restrict__ cursor,
+                        uint32_t* __restrict__ out_keys, uint32_t* __restrict__ out_vals) {
+    __shared__ uint32_t stage_k[MSM_P1_ENTRIES], stage_v[MSM_P1_ENTRIES];
+    __shared__ uint32_t cnt[MSM_P1_BINS], incl[2][MSM_P1_BINS], gbase[MSM_P1_BINS];
+    const uint32_t t = threadIdx.x;
+    for (uint32_t b = t; b < MSM_P1_BINS; b += blockDim.x) cnt[b] = 0;
+    __syncthreads();
+    const uint64_t i = (uint64_t)blockIdx.x * tile_scalars + t;
+    const bool live = t < tile_scalars && i < n;
+    uint32_t key[MSM_P1_MAXW], val[MSM_P1_MAXW], rank[MSM_P1_MAXW];
+    if (live) {
+        DigitWalk<FrP> D;
+        D.load(scalars, i, mont);
+        for (int w = 0; w < win_lo; w++) {   // (windows below this device's share: only their carries matter)
+            uint32_t k, v;
+            D.next(c, w, win_lo, n, i, table, key_base, skip, k, v);
+        }
+#pragma unroll
+        for (int q = 0; q < MSM_P1_MAXW; q++)
+            if (win_lo + q < win_hi) {
+                D.next(c, win_lo + q, win_lo, n, i, table, key_base, skip, key[q], val[q]);
+                rank[q] = atomicAdd(&cnt[key[q] & (MSM_P1_BINS - 1)], 1u);
+            }
+    }
+    __syncthreads();
+    // inclusive scan of the bin counts of this tile; a bin's run starts at incl[b] - cnt[b] in the staging arrays
+    for (uint32_t b = t; b < MSM_P1_BINS; b += blockDim.x) incl[0][b] = cnt[b];
+    __syncthreads();
+    int cur = 0;
+    for (uint32_t d = 1; d < MSM_P1_BINS; d <<= 1) {
+        for (uint32_t b = t; b < MSM_P1_BINS; b += blockDim.x) incl[cur ^ 1][b] = incl[cur][b] + (b >= d ? incl[cur][b - d] : 0);
+        __syncthreads();
+        cur ^= 1;
+    }
+    const uint32_t total = incl[cur][MSM_P1_BINS - 1];
+    for (uint32_t b = t; b < MSM_P1_BINS; b += blockDim.x) gbase[b] = cnt[b] ? atomicAdd(&cursor[b], cnt[b]) : 0;
+    if (live) {
+#pragma unroll
+        for (int q = 0; q < MSM_P1_MAXW; q++)
+            if (win_lo + q < win_hi) {
+                const uint32_t b = key[q] & (MSM_P1_BINS - 1), at = incl[cur][b] - cnt[b] + rank[q];
+                stage_k[at] = key[q];
+                stage_v[at] = val[q];
+            }
+    }
+    __syncthreads();
+    for (uint32_t p = t; p < total; p += blockDim.x) {   // consecutive lanes write consecutive addresses inside a run
+        const uint32_t k = stage_k[p];
+        const uint32_t b = k & (MSM_P1_BINS - 1);
+        const uint64_t dst = (uint64_t)gbase[b] + (p - (incl[cur][b] - cnt[b]));
+        out_keys[dst] = k;
+        out_vals[dst] = stage_v[p];
     }
 }
 
@@ -993,20 +1125,44 @@ int msm_prepare(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, in
     uint32_t* task_dest;
     GA_CHECK(ctx->scratch_get(key("msm_task_dest").c_str(), max_tasks * 4, (void**)&task_dest));
 
-    {
-        StageTimer tm(ctx, "msm_digits", st);
-        for (int b = 0; b < batch; b++) {
-            const uint32_t* sc = batch == 1 ? (const uint32_t*)d_scalars : reinterpret_cast<const uint32_t* const*>(d_scalars)[b];
-            hipLaunchKernelGGL((msm_digits_kernel<FrP>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sc, (uint64_t)n,
-                               scalars_mont ? 1 : 0, c, nwin, win_lo, win_hi, table ? 1 : 0, (uint32_t)b * half, (uint32_t)nb64,
-                               keys + (uint64_t)b * nwl * n, vals + (uint64_t)b * nwl * n);
+    int end_bit = 1;
+    while ((1ull << end_bit) <= nb64) end_bit++;   // keys take values 0..nb (nb = SKIP)
+    // digits fused with the first sort pass: one vector of scalars, a key range that leaves ONE library pass above the low
+    // MSM_P1_BITS bits, at most MSM_P1_MAXW windows per scalar, enough pairs for the saved traffic to matter (GA_MSM_FUSE_MIN)
+    const bool fused = batch == 1 && end_bit > MSM_P1_BITS && end_bit <= 2 * MSM_P1_BITS && nwl <= MSM_P1_MAXW &&
+                       m >= ctx->tun.msm_fuse_min.load(std::memory_order_relaxed);
+    if (fused) {
+        uint32_t *ghist, *cursor;
+        GA_CHECK(ctx->scratch_get(key("msm_p1_hist").c_str(), MSM_P1_BINS * 4, (void**)&ghist));
+        GA_CHECK(ctx->scratch_get(key("msm_p1_cursor").c_str(), MSM_P1_BINS * 4, (void**)&cursor));
+        {
+            StageTimer tm(ctx, "msm_digits_pass1", st);
+            const uint32_t tile = msm_p1_tile_scalars(nwl);
+            uint64_t hist_blocks = (n + 255) / 256;
+            if (hist_blocks > 2048) hist_blocks = 2048;
+            GA_HIP_CHECK(hipMemsetAsync(ghist, 0, MSM_P1_BINS * 4, st));
+            hipLaunchKernelGGL((msm_digit_hist_kernel<FrP>), dim3((unsigned)hist_blocks), dim3(256), 0, st, (const uint32_t*)d_scalars, (uint64_t)n,
+                               scalars_mont ? 1 : 0, c, nwin, win_lo, win_hi, table ? 1 : 0, 0u, (uint32_t)nb64, ghist);
+            hipLaunchKernelGGL(msm_p1_scan_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t*)ghist, cursor);
+            hipLaunchKernelGGL((msm_digits_pass1_kernel<FrP>), dim3((unsigned)((n + tile - 1) / tile)), dim3(MSM_P1_THREADS), 0, st,
+                               (const uint32_t*)d_scalars, (uint64_t)n, scalars_mont ? 1 : 0, c, nwin, win_lo, win_hi, table ? 1 : 0, 0u,
+                               (uint32_t)nb64, tile, cursor, keys, vals);
+            GA_KERNEL_CHECK();
         }
-        GA_KERNEL_CHECK();
-    }
-    {
         StageTimer tm(ctx, "msm_sort", st);
-        int end_bit = 1;
-        while ((1ull << end_bit) <= nb64) end_bit++;   // keys take values 0..nb (nb = SKIP)
+        GA_CHECK(msm_sort_pairs(ctx, key("msm_sort_tmp"), keys, keys2, vals, vals2, (size_t)m, end_bit, st, MSM_P1_BITS));
+    } else {
+        {
+            StageTimer tm(ctx, "msm_digits", st);
+            for (int b = 0; b < batch; b++) {
+                const uint32_t* sc = batch == 1 ? (const uint32_t*)d_scalars : reinterpret_cast<const uint32_t* const*>(d_scalars)[b];
+                hipLaunchKernelGGL((msm_digits_kernel<FrP>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sc, (uint64_t)n,
+                                   scalars_mont ? 1 : 0, c, nwin, win_lo, win_hi, table ? 1 : 0, (uint32_t)b * half, (uint32_t)nb64,
+                                   keys + (uint64_t)b * nwl * n, vals + (uint64_t)b * nwl * n);
+            }
+            GA_KERNEL_CHECK();
+        }
+        StageTimer tm(ctx, "msm_sort", st);
         GA_CHECK(msm_sort_pairs(ctx, key("msm_sort_tmp"), keys, keys2, vals, vals2, (size_t)m, end_bit, st));
     }
     {

@@ -693,6 +693,57 @@ def test_emu_msm_very_hot_bucket(emu_ctx, c, group, table, n=36000):
             b.free()
 
 
+@pytest.mark.parametrize("c,group", [(BN254, 0), (BLS12_381, 1)], ids=["bn254-G1", "bls12-381-G2"])
+def test_emu_msm_fused_first_sort_pass(emu_ctx, c, group, monkeypatch, n=2500, table_c=16):
+    """msm.hip.h 1b -- the digit extraction fused with the first radix-sort pass (histogram of the low key bits from the scalars,
+    LDS-partitioned tiles, one library pass for the high bits) -- forced on a small table MSM (GA_MSM_FUSE_MIN=0; GA_TABLE_C=16:
+    16 windows, 2^15 buckets, partial tiles of 832 scalars) and compared with the same MSM through the plain digits + sort
+    sequence and with [sum s_i k_i]G.  Scalars: uniform, 0, 1, r-1, a hot value, canonical and Montgomery inputs, window ranges."""
+    ctx = emu_ctx
+    monkeypatch.setenv("GA_TABLE_C", str(table_c))
+    bases, dlogs, scal = _device_inputs(ctx, c, group, n, 0xF05E + group)
+    S = scal.to_host((n, 4))
+    K = dlogs.to_host((n, 4))
+    mont = lambda v: np.array(pyref.to_mont_limbs(v, c.r, 4), dtype=np.uint64)
+    S[0], S[1], S[2] = mont(0), mont(1), mont(c.r - 1)
+    S[100:700] = mont(1)          # a hot bucket (window 0, digit 1) and many zero digits above it
+    S[700:900] = mont(0)
+    sdev = ctx.to_device(S)
+    t = ecc.PrecomputedBases(ctx, c.name, group, bases, n=n)
+    try:
+        info = t.info()
+        assert info["window_bits"] == table_c and info["windows"] <= 16
+        want = _expect_from_dlogs(c, group, S, K)
+        monkeypatch.setenv("GA_MSM_FUSE_MIN", str(1 << 40))
+        plain = t.MultiExp(sdev)
+        monkeypatch.setenv("GA_MSM_FUSE_MIN", "0")
+        ctx.profile(True)
+        ctx.profile_reset()
+        fused = t.MultiExp(sdev)
+        ctx.sync()
+        stages = [name for name, _ in ctx.profile_read()]
+        ctx.profile(False)
+        assert "msm_digits_pass1" in stages and "msm_digits" not in stages   # the fused path is what ran
+        assert np.array_equal(oracle.jac_to_affine(c.cid, group, plain), want)
+        assert np.array_equal(oracle.jac_to_affine(c.cid, group, fused), want)
+        # canonical scalars, and the window ranges of a window-sharded key (carries below the range, partial results add up)
+        rinv, m64 = pow(1 << 256, -1, c.r), (1 << 64) - 1
+        ints = [(int(a) | int(b) << 64 | int(d) << 128 | int(e) << 192) * rinv % c.r for a, b, d, e in S.tolist()]
+        canon = np.array([[v & m64, v >> 64 & m64, v >> 128 & m64, v >> 192] for v in ints], dtype=np.uint64)
+        got = t.MultiExp(ctx.to_device(canon), montgomery=False)
+        assert np.array_equal(oracle.jac_to_affine(c.cid, group, got), want)
+        nw = info["windows"]
+        parts = [t.MultiExpWindows(sdev, lo, hi) for lo, hi in ((0, 5), (5, nw - 1), (nw - 1, nw))]
+        acc = parts[0]
+        for q in parts[1:]:
+            acc = ecc.jac_add(c.name, group, acc, q, lib=ctx.lib)
+        assert np.array_equal(oracle.jac_to_affine(c.cid, group, acc), want)
+    finally:
+        t.free()
+        for b in (bases, dlogs, scal, sdev):
+            b.free()
+
+
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
 @pytest.mark.parametrize("group", [0, 1], ids=["G1", "G2"])
 def test_emu_msm_vs_c_oracle_and_dlogs(emu_ctx, c, group, logn=11):

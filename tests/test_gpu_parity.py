@@ -149,6 +149,15 @@ def test_msm_degenerate_bases_exact_kernel(gpu_ctx, monkeypatch):
     cases.test_emu_msm_degenerate_bases_exact_kernel(gpu_ctx, monkeypatch, n=1 << 14)
 
 
+@pytest.mark.parametrize("c,group,n,table_c", [(BN254, 0, 1 << 20, 22), (BLS12_381, 1, 1 << 18, 20), (BN254, 1, (1 << 16) + 77, 16)],
+                         ids=["bn254-G1-2^20-c22", "bls12-381-G2-2^18-c20", "bn254-G2-ragged-c16"])
+def test_msm_fused_first_sort_pass(gpu_ctx, monkeypatch, c, group, n, table_c):
+    """the digit extraction fused with the first radix-sort pass (msm.hip.h 1b; the default from 2^25 pairs, forced here on smaller
+    inputs) == the plain digits + two-pass sort sequence == [sum s_i k_i]G: production shape (c = 22, 12 windows), 13 windows,
+    16 windows with partial tiles and a ragged length; hot / zero / canonical scalars, window ranges"""
+    cases.test_emu_msm_fused_first_sort_pass(gpu_ctx, c, group, monkeypatch, n=n, table_c=table_c)
+
+
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
 @pytest.mark.parametrize("group", [0, 1], ids=["G1", "G2"])
 def test_msm_table_batch_2_18(gpu_ctx, c, group):
