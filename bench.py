@@ -301,7 +301,10 @@ def main():
             r_host = table.MultiExp(s_host)
         el_h = (time.perf_counter() - t0) / 3
         out["msm_with_scalar_h2d"] = {"ms_per_msm": round(el_h * 1e3, 3), "Mscalar_mul_per_s": round(n / el_h / 1e6, 2),
-                                      "same_result": bool(np.array_equal(r_host, result)),
+                                      # (the same group element: since the digits are fused with the first sort pass the order inside a bucket -- and with
+                                      # it the Jacobian representative of the sum -- differs from run to run; the affine point does not)
+                                      "same_result": bool(np.array_equal(ecc.jac_to_affine(cid, _lib.G1, r_host, lib=ctx.lib),
+                                                                         ecc.jac_to_affine(cid, _lib.G1, result, lib=ctx.lib))),
                                       "how": "the timed table MSM with its 2^%d x 32 B of scalars uploaded from pageable host memory inside the call" % args.log_n}
         del s_host
     if table is not None:

@@ -97,7 +97,12 @@ int ga_sync(ga_ctx* ctx);
  *   bases   : n affine points (Montgomery), host or device pointer per flags
  *   scalars : n fr elements, Montgomery if GA_SCALARS_MONTGOMERY
  *   out_jac : HOST buffer for one Jacobian point {X,Y,Z} (Montgomery) -- castable to curve.G1Jac / G2Jac.
- * (0,0) bases are treated as infinity and zero scalars are skipped, as gnark-crypto does. */
+ * (0,0) bases are treated as infinity and zero scalars are skipped, as gnark-crypto does.
+ * Jacobian results (here and in every entry point below that returns Jacobian points or partial sums) are group elements: two
+ * calls on the same inputs return the same point, but not necessarily the same representative {X,Y,Z} -- from 2^25 (bucket,
+ * point) pairs the order in which a bucket's points are added is not fixed (the first sort pass ranks with atomics, msm.hip.h 1b),
+ * exactly as gnark-crypto's MultiExp returns a different representative for a different NbTasks.  Affine outputs (proofs,
+ * commitments, ga_jac_to_affine of any result) are bit-identical from call to call and from device to device. */
 int ga_msm(ga_ctx* ctx, int curve, int group, const void* bases, const void* scalars, size_t n, unsigned flags,
            void* out_jac);
 

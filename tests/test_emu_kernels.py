@@ -694,7 +694,7 @@ def test_emu_msm_very_hot_bucket(emu_ctx, c, group, table, n=36000):
 
 
 @pytest.mark.parametrize("c,group", [(BN254, 0), (BLS12_381, 1)], ids=["bn254-G1", "bls12-381-G2"])
-def test_emu_msm_fused_first_sort_pass(emu_ctx, c, group, monkeypatch, n=2500, table_c=16):
+def test_emu_msm_fused_first_sort_pass(emu_ctx, c, group, monkeypatch, n=1300, table_c=16):
     """msm.hip.h 1b -- the digit extraction fused with the first radix-sort pass (histogram of the low key bits from the scalars,
     LDS-partitioned tiles, one library pass for the high bits) -- forced on a small table MSM (GA_MSM_FUSE_MIN=0; GA_TABLE_C=16:
     16 windows, 2^15 buckets, partial tiles of 832 scalars) and compared with the same MSM through the plain digits + sort
