@@ -738,6 +738,21 @@ def test_emu_msm_fused_first_sort_pass(emu_ctx, c, group, monkeypatch, n=1300, t
         for q in parts[1:]:
             acc = ecc.jac_add(c.name, group, acc, q, lib=ctx.lib)
         assert np.array_equal(oracle.jac_to_affine(c.cid, group, acc), want)
+        # raw (un-pinned) bases: one bucket set per window, keys = window * 2^(c-1) + digit - 1.  The fused pass applies to window
+        # ranges of at most 16 windows whose bucket sets fit 22 key bits: the two halves of a window-sharded MSM recombine to the point
+        monkeypatch.delenv("GA_TABLE_C")
+        cbits, nwin = ecc.plan(c.name, group, n, lib=ctx.lib)
+        cuts = list(range(0, nwin, 16)) + [nwin]
+        ctx.profile(True)
+        ctx.profile_reset()
+        wins = [ecc.MultiExpWindows(ctx, c.name, group, bases, sdev, n, lo, hi)[0] for lo, hi in zip(cuts[:-1], cuts[1:])]
+        ctx.sync()
+        stages = [name for name, _ in ctx.profile_read()]
+        ctx.profile(False)
+        if 8 <= cbits <= 18:   # 16 windows x 2^(c-1) buckets: 12..22 key bits
+            assert "msm_digits_pass1" in stages
+        comb = ecc.combine_windows(c.name, group, np.concatenate(wins), cbits, lib=ctx.lib)
+        assert np.array_equal(oracle.jac_to_affine(c.cid, group, comb), want)
     finally:
         t.free()
         for b in (bases, dlogs, scal, sdev):

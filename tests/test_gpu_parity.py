@@ -154,7 +154,8 @@ def test_msm_degenerate_bases_exact_kernel(gpu_ctx, monkeypatch):
 def test_msm_fused_first_sort_pass(gpu_ctx, monkeypatch, c, group, n, table_c):
     """the digit extraction fused with the first radix-sort pass (msm.hip.h 1b; the default from 2^25 pairs, forced here on smaller
     inputs) == the plain digits + two-pass sort sequence == [sum s_i k_i]G: production shape (c = 22, 12 windows), 13 windows,
-    16 windows with partial tiles and a ragged length; hot / zero / canonical scalars, window ranges"""
+    16 windows with partial tiles and a ragged length; hot / zero / canonical scalars, window ranges; the same inputs as a raw-bases
+    MSM in ranges of 16 windows (one bucket set per window)"""
     cases.test_emu_msm_fused_first_sort_pass(gpu_ctx, c, group, monkeypatch, n=n, table_c=table_c)
 
 
@@ -185,6 +186,23 @@ def test_msm_2_24_bn254_g1_dlog(gpu_ctx):
     parts = [ecc.MultiExpWindows(gpu_ctx, c.name, group, bases, scal, n, lo, hi)[0] for lo, hi in ((0, nwin // 2), (nwin // 2, nwin))]
     comb = oracle.jac_to_affine(c.cid, group, ecc.combine_windows(c.name, group, np.concatenate(parts), cbits))
     assert np.array_equal(comb, got)
+    for b in (bases, dlogs, scal):
+        b.free()
+
+
+def test_msm_2_22_raw_bases_take_the_fused_sort_pass_by_default(gpu_ctx):
+    """2^22 un-pinned bases (c = 17: 15 bucket sets, 21 key bits, 63 M pairs): the library fuses the digit extraction with the
+    first sort pass on its own (no knob) and the result equals [sum s_i k_i]G"""
+    c, group, n = BN254, 0, 1 << 22
+    bases, dlogs, scal = _device_inputs(gpu_ctx, c, group, n, 0x5EED0022)
+    gpu_ctx.profile(True)
+    gpu_ctx.profile_reset()
+    got = oracle.jac_to_affine(c.cid, group, ecc.MultiExp(gpu_ctx, c.name, group, bases, scal, n=n))
+    gpu_ctx.sync()
+    stages = [name for name, _ in gpu_ctx.profile_read()]
+    gpu_ctx.profile(False)
+    assert "msm_digits_pass1" in stages and "msm_digits" not in stages
+    assert np.array_equal(got, _expect_from_dlogs(c, group, scal.to_host((n, 4)), dlogs.to_host((n, 4))))
     for b in (bases, dlogs, scal):
         b.free()
 
