@@ -169,18 +169,32 @@ msm_digit_hist_kernel(const uint32_t* __restrict__ scalars, uint64_t n, int mont
         if (h[b]) atomicAdd(&ghist[b], h[b]);
 }
 
-// exclusive scan of the MSM_P1_BINS bin counts (one block): where each bin's slice of the partitioned arrays starts
-static __global__ void __launch_bounds__(1024) msm_p1_scan_kernel(const uint32_t* __restrict__ ghist, uint32_t* __restrict__ cursor) {
-    __shared__ uint32_t a[2][MSM_P1_BINS];
-    for (uint32_t b = threadIdx.x; b < MSM_P1_BINS; b += blockDim.x) a[0][b] = ghist[b];
+// exclusive scans of the MSM_P1_BINS bin counts (one block): where each bin's slice of the partitioned arrays starts (cursor: consumed
+// by the first pass; bin_off: kept, MSM_P1_BINS + 1 entries) and the number of MSM_P2_SEG-pair segments before each bin (seg_off)
+constexpr uint32_t MSM_P2_SEG = 16384;
+static __global__ void __launch_bounds__(1024) msm_p1_scan_kernel(const uint32_t* __restrict__ ghist, uint32_t* __restrict__ cursor,
+                                                                  uint32_t* __restrict__ bin_off, uint32_t* __restrict__ seg_off) {
+    __shared__ uint32_t a[2][MSM_P1_BINS], g[2][MSM_P1_BINS];
+    for (uint32_t b = threadIdx.x; b < MSM_P1_BINS; b += blockDim.x) {
+        a[0][b] = ghist[b];
+        g[0][b] = (ghist[b] + MSM_P2_SEG - 1) / MSM_P2_SEG;
+    }
     __syncthreads();
     int cur = 0;
     for (uint32_t d = 1; d < MSM_P1_BINS; d <<= 1) {
-        for (uint32_t b = threadIdx.x; b < MSM_P1_BINS; b += blockDim.x) a[cur ^ 1][b] = a[cur][b] + (b >= d ? a[cur][b - d] : 0);
+        for (uint32_t b = threadIdx.x; b < MSM_P1_BINS; b += blockDim.x) {
+            a[cur ^ 1][b] = a[cur][b] + (b >= d ? a[cur][b - d] : 0);
+            g[cur ^ 1][b] = g[cur][b] + (b >= d ? g[cur][b - d] : 0);
+        }
         __syncthreads();
         cur ^= 1;
     }
-    for (uint32_t b = threadIdx.x; b < MSM_P1_BINS; b += blockDim.x) cursor[b] = b ? a[cur][b - 1] : 0;
+    for (uint32_t b = threadIdx.x; b <= MSM_P1_BINS; b += blockDim.x) {
+        const uint32_t ex = b ? a[cur][b - 1] : 0;
+        if (b < MSM_P1_BINS) cursor[b] = ex;
+        bin_off[b] = ex;
+        seg_off[b] = b ? g[cur][b - 1] : 0;
+    }
 }
 
 template <class FrP>
@@ -238,6 +252,101 @@ msm_digits_pass1_kernel(const uint32_t* __restrict__ scalars, uint64_t n, int mo
         const uint64_t dst = (uint64_t)gbase[b] + (p - (incl[cur][b] - cnt[b]));
         out_keys[dst] = k;
         out_vals[dst] = stage_v[p];
+    }
+}
+
+// ---- 1c. the second level of the fused sort, in place of the library pass and the binary-search offsets ------------------------
+// After the first pass the pairs are grouped by their low MSM_P1_BITS key bits; inside a group a pair's final place is
+// off[key] + (any rank among the pairs with the same key): no stability is needed, only the per-key counts.  Segments of at most
+// MSM_P2_SEG pairs of ONE group count the high key parts in LDS and add them to a global per-key histogram (gcount[key]: the low
+// part is the group); an exclusive scan of that histogram IS the bucket-offset array `off`; then the same segments reserve one run
+// per (segment, key) behind a global atomic and write the VALUES (the sorted keys are never materialised), LDS-staged so that a
+// run leaves the CU as consecutive addresses.  Any key distribution works (a group of any size is just more segments).
+// Measured at 12 x 2^24 pairs (tools/exp/partbench.hip variant C): 1.41 ms against the library pass + offsets kernel's 2.0 ms.
+constexpr uint32_t MSM_P2_HB = 2056;   // capacity for the high key parts: keys <= nb < 2^22 (the fused path's condition) -> at most 2048;
+                                        // the kernels loop over hb = (nb >> MSM_P1_BITS) + 1 of them (1025 for a table's 2^21 buckets)
+__device__ __forceinline__ bool msm_p2_segment(const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ bin_off, uint32_t& bin,
+                                               uint32_t& lo, uint32_t& hi) {
+    const uint32_t sidx = blockIdx.x;
+    if (sidx >= seg_off[MSM_P1_BINS]) return false;
+    uint32_t l = 0, r = MSM_P1_BINS;   // the last bin with seg_off[bin] <= sidx
+    while (r - l > 1) {
+        const uint32_t mid = (l + r) >> 1;
+        if (seg_off[mid] <= sidx) l = mid;
+        else r = mid;
+    }
+    bin = l;
+    lo = bin_off[bin] + (sidx - seg_off[bin]) * MSM_P2_SEG;
+    hi = bin_off[bin + 1];
+    if (hi - lo > MSM_P2_SEG) hi = lo + MSM_P2_SEG;
+    return true;
+}
+static __global__ void __launch_bounds__(1024)
+msm_p2_count_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ bin_off,
+                    uint32_t hb, uint32_t* __restrict__ gcount) {
+    __shared__ uint32_t cnt[MSM_P2_HB];
+    uint32_t bin, lo, hi;
+    if (!msm_p2_segment(seg_off, bin_off, bin, lo, hi)) return;   // (uniform per block)
+    for (uint32_t h = threadIdx.x; h < hb; h += blockDim.x) cnt[h] = 0;
+    __syncthreads();
+    constexpr int U = MSM_P2_SEG / 1024;
+    uint32_t kk[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const uint32_t p = lo + u * 1024 + threadIdx.x;
+        kk[u] = p < hi ? keys[p] : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++)
+        if (kk[u] != 0xFFFFFFFFu) atomicAdd(&cnt[kk[u] >> MSM_P1_BITS], 1u);
+    __syncthreads();
+    for (uint32_t h = threadIdx.x; h < hb; h += blockDim.x)
+        if (cnt[h]) atomicAdd(&gcount[(h << MSM_P1_BITS) | bin], cnt[h]);
+}
+static __global__ void __launch_bounds__(1024)
+msm_p2_scatter_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ seg_off,
+                      const uint32_t* __restrict__ bin_off, uint32_t hb, uint32_t* __restrict__ cursor, uint32_t* __restrict__ out_vals) {
+    __shared__ uint32_t stage_v[MSM_P2_SEG];
+    __shared__ uint16_t stage_h[MSM_P2_SEG];
+    __shared__ uint32_t cnt[MSM_P2_HB], incl[2][MSM_P2_HB], gb[MSM_P2_HB];
+    uint32_t bin, lo, hi;
+    if (!msm_p2_segment(seg_off, bin_off, bin, lo, hi)) return;
+    const uint32_t t = threadIdx.x;
+    for (uint32_t h = t; h < hb; h += blockDim.x) cnt[h] = 0;
+    __syncthreads();
+    constexpr int U = MSM_P2_SEG / 1024;
+    uint32_t kk[U], vv[U], rk[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const uint32_t p = lo + u * 1024 + t;
+        kk[u] = p < hi ? keys[p] : 0xFFFFFFFFu;
+        vv[u] = p < hi ? vals[p] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++)
+        if (kk[u] != 0xFFFFFFFFu) rk[u] = atomicAdd(&cnt[kk[u] >> MSM_P1_BITS], 1u);
+    __syncthreads();
+    for (uint32_t h = t; h < hb; h += blockDim.x) incl[0][h] = cnt[h];
+    __syncthreads();
+    int cur = 0;
+    for (uint32_t d = 1; d < hb; d <<= 1) {
+        for (uint32_t h = t; h < hb; h += blockDim.x) incl[cur ^ 1][h] = incl[cur][h] + (h >= d ? incl[cur][h - d] : 0);
+        __syncthreads();
+        cur ^= 1;
+    }
+    for (uint32_t h = t; h < hb; h += blockDim.x) gb[h] = cnt[h] ? atomicAdd(&cursor[(h << MSM_P1_BITS) | bin], cnt[h]) : 0;
+#pragma unroll
+    for (int u = 0; u < U; u++)
+        if (kk[u] != 0xFFFFFFFFu) {
+            const uint32_t h = kk[u] >> MSM_P1_BITS, at = incl[cur][h] - cnt[h] + rk[u];
+            stage_v[at] = vv[u];
+            stage_h[at] = (uint16_t)h;
+        }
+    __syncthreads();
+    const uint32_t total = hi - lo;
+    for (uint32_t p = t; p < total; p += blockDim.x) {
+        const uint32_t h = stage_h[p];
+        out_vals[(uint64_t)gb[h] + (p - (incl[cur][h] - cnt[h]))] = stage_v[p];
     }
 }
 
@@ -1132,9 +1241,14 @@ int msm_prepare(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, in
     const bool fused = batch == 1 && end_bit > MSM_P1_BITS && end_bit <= 2 * MSM_P1_BITS && nwl <= MSM_P1_MAXW &&
                        m >= ctx->tun.msm_fuse_min.load(std::memory_order_relaxed);
     if (fused) {
-        uint32_t *ghist, *cursor;
+        uint32_t *ghist, *cursor, *bin_off, *seg_off, *gcount, *kcursor;
         GA_CHECK(ctx->scratch_get(key("msm_p1_hist").c_str(), MSM_P1_BINS * 4, (void**)&ghist));
         GA_CHECK(ctx->scratch_get(key("msm_p1_cursor").c_str(), MSM_P1_BINS * 4, (void**)&cursor));
+        GA_CHECK(ctx->scratch_get(key("msm_p1_bin_off").c_str(), (MSM_P1_BINS + 1) * 4, (void**)&bin_off));
+        GA_CHECK(ctx->scratch_get(key("msm_p2_seg_off").c_str(), (MSM_P1_BINS + 1) * 4, (void**)&seg_off));
+        const uint64_t nkeys = (((uint64_t)nb >> MSM_P1_BITS) + 1) << MSM_P1_BITS;   // >= nb + 1: every (high part, group) pair a key 0..nb can form
+        GA_CHECK(ctx->scratch_get(key("msm_p2_count").c_str(), nkeys * 4, (void**)&gcount));
+        GA_CHECK(ctx->scratch_get(key("msm_p2_cursor").c_str(), nkeys * 4, (void**)&kcursor));
         {
             StageTimer tm(ctx, "msm_digits_pass1", st);
             const uint32_t tile = msm_p1_tile_scalars(nwl);
@@ -1143,14 +1257,30 @@ int msm_prepare(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, in
             GA_HIP_CHECK(hipMemsetAsync(ghist, 0, MSM_P1_BINS * 4, st));
             hipLaunchKernelGGL((msm_digit_hist_kernel<FrP>), dim3((unsigned)hist_blocks), dim3(256), 0, st, (const uint32_t*)d_scalars, (uint64_t)n,
                                scalars_mont ? 1 : 0, c, nwin, win_lo, win_hi, table ? 1 : 0, 0u, (uint32_t)nb64, ghist);
-            hipLaunchKernelGGL(msm_p1_scan_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t*)ghist, cursor);
+            hipLaunchKernelGGL(msm_p1_scan_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t*)ghist, cursor, bin_off, seg_off);
             hipLaunchKernelGGL((msm_digits_pass1_kernel<FrP>), dim3((unsigned)((n + tile - 1) / tile)), dim3(MSM_P1_THREADS), 0, st,
                                (const uint32_t*)d_scalars, (uint64_t)n, scalars_mont ? 1 : 0, c, nwin, win_lo, win_hi, table ? 1 : 0, 0u,
                                (uint32_t)nb64, tile, cursor, keys, vals);
             GA_KERNEL_CHECK();
         }
-        StageTimer tm(ctx, "msm_sort", st);
-        GA_CHECK(msm_sort_pairs(ctx, key("msm_sort_tmp"), keys, keys2, vals, vals2, (size_t)m, end_bit, st, MSM_P1_BITS));
+        {
+            StageTimer tm(ctx, "msm_sort", st);
+            const unsigned max_seg = (unsigned)(m / MSM_P2_SEG + MSM_P1_BINS);
+            const uint32_t hb = (nb >> MSM_P1_BITS) + 1;   // high parts of the keys 0..nb
+            GA_HIP_CHECK(hipMemsetAsync(gcount, 0, nkeys * 4, st));
+            hipLaunchKernelGGL(msm_p2_count_kernel, dim3(max_seg), dim3(1024), 0, st, (const uint32_t*)keys, (const uint32_t*)seg_off,
+                               (const uint32_t*)bin_off, hb, gcount);
+            GA_KERNEL_CHECK();
+            size_t sb = 0;
+            void* stmp;
+            GA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, sb, gcount, off, (int)(nb + 1), st));
+            GA_CHECK(ctx->scratch_get(key("msm_p2_scan_tmp").c_str(), sb + 256, &stmp));
+            GA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(stmp, sb, gcount, off, (int)(nb + 1), st));   // off[b], b = 0..nb (nb = SKIP)
+            GA_HIP_CHECK(hipMemcpyAsync(kcursor, off, ((uint64_t)nb + 1) * 4, hipMemcpyDeviceToDevice, st));
+            hipLaunchKernelGGL(msm_p2_scatter_kernel, dim3(max_seg), dim3(1024), 0, st, (const uint32_t*)keys, (const uint32_t*)vals,
+                               (const uint32_t*)seg_off, (const uint32_t*)bin_off, hb, kcursor, vals2);
+            GA_KERNEL_CHECK();
+        }
     } else {
         {
             StageTimer tm(ctx, "msm_digits", st);
@@ -1167,7 +1297,8 @@ int msm_prepare(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, in
     }
     {
         StageTimer tm(ctx, "msm_tasks", st);
-        hipLaunchKernelGGL(msm_offsets_kernel, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, (const uint32_t*)keys2, m, nb, off);
+        if (!fused)   // (the fused sort produced `off` itself)
+            hipLaunchKernelGGL(msm_offsets_kernel, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, (const uint32_t*)keys2, m, nb, off);
         hipLaunchKernelGGL(msm_tasks_kernel, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, (const uint32_t*)off, nb, seg, ntask);
         GA_KERNEL_CHECK();
         size_t tmp_bytes = 0;

@@ -8,6 +8,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -w tools/exp/partbench.hip -o partbench && ./partbench
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <hipcub/hipcub.hpp>
 #include <cstdio>
 #include <cstdint>
 #include <vector>
@@ -168,6 +169,94 @@ __global__ void __launch_bounds__(TILE) part_scatter_kernel(const uint32_t* __re
     }
 }
 
+
+// ---- variant C: own second level in the NATURAL layout.  The pass-1 output is grouped by the low CB key bits; inside a group all
+// pairs share them, so a pair's final place is off[key] + (any rank among the pairs of the same key): no stability needed.
+// Segments of at most SEG pairs of ONE group: count the high key parts (LDS), add them into a global per-key histogram; an exclusive
+// scan of that histogram IS the bucket-offset array; then the same segments reserve a run per (segment, key) and write the values.
+constexpr uint32_t SEG = 16384, HB = 1032;   // HB >= 1025 high parts (skip key included)
+__global__ void __launch_bounds__(1024) seg_plan_kernel(const uint32_t* __restrict__ ghist, uint32_t* __restrict__ seg_off) {
+    __shared__ uint32_t a[2][2048];
+    for (uint32_t b = threadIdx.x; b < 2048; b += 1024) a[0][b] = (ghist[b] + SEG - 1) / SEG;
+    __syncthreads();
+    int cur = 0;
+    for (uint32_t d = 1; d < 2048; d <<= 1) {
+        for (uint32_t b = threadIdx.x; b < 2048; b += 1024) a[cur ^ 1][b] = a[cur][b] + (b >= d ? a[cur][b - d] : 0);
+        __syncthreads();
+        cur ^= 1;
+    }
+    for (uint32_t b = threadIdx.x; b <= 2048; b += 1024) seg_off[b] = b ? a[cur][b - 1] : 0;
+}
+__device__ __forceinline__ bool seg_range(const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ coff, uint32_t& bin, uint32_t& lo, uint32_t& hi) {
+    const uint32_t sidx = blockIdx.x;
+    if (sidx >= seg_off[2048]) return false;
+    uint32_t l = 0, r = 2048;                // last bin with seg_off[bin] <= sidx
+    while (r - l > 1) { const uint32_t mid = (l + r) >> 1; if (seg_off[mid] <= sidx) l = mid; else r = mid; }
+    bin = l;
+    lo = coff[bin] + (sidx - seg_off[bin]) * SEG;
+    hi = coff[bin + 1];
+    if (hi - lo > SEG) hi = lo + SEG;
+    return true;
+}
+__global__ void __launch_bounds__(1024) seg_count_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ coff,
+                                                          uint32_t* __restrict__ gcount) {
+    __shared__ uint32_t cnt[HB];
+    uint32_t bin, lo, hi;
+    if (!seg_range(seg_off, coff, bin, lo, hi)) return;
+    for (uint32_t h = threadIdx.x; h < HB; h += 1024) cnt[h] = 0;
+    __syncthreads();
+    uint32_t kk[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) { const uint32_t p = lo + u * 1024 + threadIdx.x; kk[u] = p < hi ? keys[p] : 0xFFFFFFFFu; }
+#pragma unroll
+    for (int u = 0; u < 16; u++) if (kk[u] != 0xFFFFFFFFu) atomicAdd(&cnt[kk[u] >> CB], 1u);
+    __syncthreads();
+    for (uint32_t h = threadIdx.x; h < HB; h += 1024) if (cnt[h]) atomicAdd(&gcount[(h << CB) | bin], cnt[h]);
+}
+__global__ void __launch_bounds__(1024) seg_scatter_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ seg_off,
+                                                            const uint32_t* __restrict__ coff, uint32_t* __restrict__ cursor, uint32_t* __restrict__ out_vals) {
+    __shared__ uint32_t stage_v[SEG];
+    __shared__ uint16_t stage_h[SEG];
+    __shared__ uint32_t cnt[HB], incl[2][HB], gb[HB];
+    uint32_t bin, lo, hi;
+    if (!seg_range(seg_off, coff, bin, lo, hi)) return;
+    const uint32_t t = threadIdx.x;
+    for (uint32_t h = t; h < HB; h += 1024) cnt[h] = 0;
+    __syncthreads();
+    uint32_t kk[16], vv[16], rk[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+        const uint32_t p = lo + u * 1024 + t;
+        kk[u] = p < hi ? keys[p] : 0xFFFFFFFFu;
+        vv[u] = p < hi ? vals[p] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; u++) if (kk[u] != 0xFFFFFFFFu) rk[u] = atomicAdd(&cnt[kk[u] >> CB], 1u);
+    __syncthreads();
+    for (uint32_t h = t; h < HB; h += 1024) incl[0][h] = cnt[h];
+    __syncthreads();
+    int cur = 0;
+    for (uint32_t d = 1; d < HB; d <<= 1) {
+        for (uint32_t h = t; h < HB; h += 1024) incl[cur ^ 1][h] = incl[cur][h] + (h >= d ? incl[cur][h - d] : 0);
+        __syncthreads();
+        cur ^= 1;
+    }
+    for (uint32_t h = t; h < HB; h += 1024) gb[h] = cnt[h] ? atomicAdd(&cursor[(h << CB) | bin], cnt[h]) : 0;
+#pragma unroll
+    for (int u = 0; u < 16; u++)
+        if (kk[u] != 0xFFFFFFFFu) {
+            const uint32_t h = kk[u] >> CB, at = incl[cur][h] - cnt[h] + rk[u];
+            stage_v[at] = vv[u];
+            stage_h[at] = (uint16_t)h;
+        }
+    __syncthreads();
+    const uint32_t total = hi - lo;
+    for (uint32_t p = t; p < total; p += 1024) {
+        const uint32_t h = stage_h[p];
+        out_vals[(uint64_t)gb[h] + (p - (incl[cur][h] - cnt[h]))] = stage_v[p];
+    }
+}
+
 // per-bucket checksum of the values (order inside a bucket is free)
 __global__ void bucket_sum_kernel(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ off, const uint32_t* __restrict__ off_end, uint32_t nb, uint64_t* __restrict__ sums) {
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -188,13 +277,13 @@ int main(int argc, char** argv) {
     hipStream_t st; hipStreamCreate(&st);
     uint32_t *s, *k, *k2, *v, *v2, *off_a, *off_b, *end_b, *vals_b = nullptr, *ghist, *coff, *cursor, *stat;
     uint64_t *sum_a, *sum_b;
-    uint32_t *pk, *pk2, *pv, *pv2;
+    uint32_t *pk, *pk2, *pv, *pv2, *seg_off, *gcount, *cur2, *off_c, *vals_c;
     CK(hipMalloc(&s, n * 32)); CK(hipMalloc(&k, m * 4)); CK(hipMalloc(&k2, m * 4)); CK(hipMalloc(&v, m * 4)); CK(hipMalloc(&v2, m * 4));
     CK(hipMalloc(&off_a, (nb + 2) * 4ull)); CK(hipMalloc(&off_b, (nb + 2) * 4ull)); CK(hipMalloc(&end_b, (nb + 2) * 4ull)); CK(hipMalloc(&ghist, 4096 * 4)); CK(hipMalloc(&coff, 4096 * 4));
-    CK(hipMalloc(&cursor, 4096 * 4)); CK(hipMalloc(&stat, 256)); CK(hipMalloc(&pk, m * 4)); CK(hipMalloc(&pk2, m * 4)); CK(hipMalloc(&pv, m * 4)); CK(hipMalloc(&pv2, m * 4));
+    CK(hipMalloc(&cursor, 4096 * 4)); CK(hipMalloc(&stat, 256)); CK(hipMalloc(&pk, m * 4)); CK(hipMalloc(&pk2, m * 4)); CK(hipMalloc(&pv, m * 4)); CK(hipMalloc(&pv2, m * 4)); CK(hipMalloc(&seg_off, 4096 * 4)); CK(hipMalloc(&gcount, (HB << CB) * 4ull)); CK(hipMalloc(&cur2, (HB << CB) * 4ull)); CK(hipMalloc(&off_c, (HB << CB) * 4ull + 64)); CK(hipMalloc(&vals_c, m * 4));
     CK(hipMalloc(&sum_a, nb * 8ull)); CK(hipMalloc(&sum_b, nb * 8ull));
     gen_scalars<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(s, n, mode);
-    hipEvent_t e[8]; for (auto& x : e) hipEventCreate(&x);
+    hipEvent_t e[10]; for (auto& x : e) hipEventCreate(&x);
     size_t tb = 0;
     rocprim::double_buffer<uint32_t> dk(k, k2), dv(v, v2);
     CK((rocprim::radix_sort_pairs<SortWide>(nullptr, tb, dk, dv, m, 0, 22, st)));
@@ -206,7 +295,9 @@ int main(int argc, char** argv) {
     CK(hipFuncSetAttribute((const void*)part_scatter_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 1024 * nwin * 8));
     CK(hipFuncSetAttribute((const void*)part_scatter_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 512 * nwin * 8));
     CK(hipFuncSetAttribute((const void*)part_scatter_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * nwin * 8));
-    float t_dig = 0, t_sort = 0, t_off = 0, t_h = 0, t_sc = 0, t_f = 0, t_o2 = 0;
+    float t_dig = 0, t_sort = 0, t_off = 0, t_h = 0, t_sc = 0, t_f = 0, t_o2 = 0, t_c = 0;
+    size_t scan_bytes = 0; CK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, gcount, off_c, (int)(nb + 1), st));
+    void* scan_tmp; CK(hipMalloc(&scan_tmp, scan_bytes + 256));
     const int reps = 5;
     uint32_t *sk = nullptr, *sv = nullptr;
     for (int r = 0; r < reps + 1; r++) {
@@ -235,8 +326,20 @@ int main(int argc, char** argv) {
         vals_b = fv.current();
         offsets_kernel<<<(nb + 1 + 255) / 256, 256, 0, st>>>(fk.current(), m, nb, off_b);
         hipEventRecord(e[7], st);
+        // variant C on the same pass-1 output (pk / pv were consumed by the library pass as `current`; they are unchanged: double buffers)
+        hipEventRecord(e[8], st);
+        const uint32_t nkeys = HB << CB;
+        hipMemsetAsync(gcount, 0, nkeys * 4ull, st);
+        seg_plan_kernel<<<1, 1024, 0, st>>>(ghist, seg_off);
+        const unsigned max_seg = (unsigned)(m / SEG + 2048);
+        seg_count_kernel<<<max_seg, 1024, 0, st>>>(pk, seg_off, coff, gcount);
+        CK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, gcount, off_c, (int)(nb + 1), st));
+        hipMemcpyAsync(cur2, off_c, (nb + 1) * 4ull, hipMemcpyDeviceToDevice, st);
+        seg_scatter_kernel<<<max_seg, 1024, 0, st>>>(pk, pv, seg_off, coff, cur2, vals_c);
+        hipEventRecord(e[9], st);
         CK(hipStreamSynchronize(st));
         CK(hipGetLastError());
+        if (r) { float ms; hipEventElapsedTime(&ms, e[8], e[9]); t_c += ms; }
         if (r) {
             float ms;
             hipEventElapsedTime(&ms, e[0], e[1]); t_dig += ms; hipEventElapsedTime(&ms, e[1], e[2]); t_sort += ms; hipEventElapsedTime(&ms, e[2], e[3]); t_off += ms;
@@ -245,6 +348,19 @@ int main(int argc, char** argv) {
     }
     printf("tile=%d ", TILE); printf("n=2^%d mode=%d  shipped: digits %.3f + sort %.3f + offsets %.3f = %.3f ms   fused: hist+scan %.3f + digits/first pass %.3f + second pass %.3f + offsets %.3f = %.3f ms\n", logn, mode,
            t_dig / reps, t_sort / reps, t_off / reps, (t_dig + t_sort + t_off) / reps, t_h / reps, t_sc / reps, t_f / reps, t_o2 / reps, (t_h + t_sc + t_f + t_o2) / reps);
+    printf("variant C (own second level: count + scan + scatter, offsets as a by-product): %.3f ms  -> fused total %.3f ms\n", t_c / reps, (t_h + t_sc + t_c) / reps);
+    {
+        uint64_t* sum_c; CK(hipMalloc(&sum_c, nb * 8ull));
+        bucket_sum_kernel<<<(nb + 255) / 256, 256, 0, st>>>(vals_c, off_c, off_c + 1, nb, sum_c);
+        std::vector<uint32_t> hc(nb + 1), h0(nb + 1); std::vector<uint64_t> sc_(nb), s0(nb);
+        bucket_sum_kernel<<<(nb + 255) / 256, 256, 0, st>>>(sv, off_a, off_a + 1, nb, sum_a);
+        CK(hipMemcpy(hc.data(), off_c, (nb + 1) * 4ull, hipMemcpyDeviceToHost)); CK(hipMemcpy(h0.data(), off_a, (nb + 1) * 4ull, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(sc_.data(), sum_c, nb * 8ull, hipMemcpyDeviceToHost)); CK(hipMemcpy(s0.data(), sum_a, nb * 8ull, hipMemcpyDeviceToHost));
+        uint64_t bo = 0, bs = 0;
+        for (uint32_t b = 0; b <= nb; b++) bo += hc[b] != h0[b];
+        for (uint32_t b = 0; b < nb; b++) bs += sc_[b] != s0[b];
+        printf("variant C: offsets differing %llu, bucket checksums differing %llu\n", (unsigned long long)bo, (unsigned long long)bs);
+    }
     // equality: offsets identical, per-bucket checksums of the values identical
     bucket_sum_kernel<<<(nb + 255) / 256, 256, 0, st>>>(sv, off_a, off_a + 1, nb, sum_a);
     bucket_sum_kernel<<<(nb + 255) / 256, 256, 0, st>>>(vals_b, off_b, off_b + 1, nb, sum_b);

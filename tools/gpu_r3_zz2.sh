@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-3 batch ZZ2: digits fused with the first radix-sort pass (msm.hip.h 1b) -- parity tests, then A/B against the plain
 # digits + two-pass sort sequence (GA_MSM_FUSE_MIN above every size) on one box
-OUT=gpurun_out/r3zz2
+OUT=gpurun_out/${OUTDIR:-r3zz2}
 mkdir -p $OUT
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "msm" > $OUT/pytest_msm.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_msm.log
@@ -16,7 +16,7 @@ run g16fused $AB --parts g16 --tag g16fused
 run g16plain GA_MSM_FUSE_MIN=1099511627776 $AB --parts g16 --tag g16plain
 python - <<'P'
 import json, glob
-for f in sorted(glob.glob("gpurun_out/r3zz2/ab_*.json")):
+for f in sorted(glob.glob("gpurun_out/" + __import__("os").environ.get("OUTDIR", "r3zz2") + "/ab_*.json")):
     try:
         d = json.loads(open(f).read().strip().splitlines()[-1])
     except Exception as e:
