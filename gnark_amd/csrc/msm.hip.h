@@ -133,11 +133,11 @@ __global__ void msm_digits_kernel(const uint32_t* __restrict__ scalars, uint64_t
 // reads / scatters the pairs twice (two 11-bit onesweep passes).  Here the FIRST LSD pass -- a partition by the low MSM_P1_BITS key
 // bits -- is made by the kernel that extracts the digits: a histogram of the low key bits straight from the scalars (digits are
 // cheap to recompute: nothing is written), then a tile of <= 1024 scalars x windows is partitioned in LDS and leaves the CU as one
-// run per (tile, bin); the library then sorts bits [MSM_P1_BITS, end) in ONE stable pass, which yields the fully sorted list.
+// run per (tile, bin); the second level (1c below) finishes the grouping without the library.
 // The order inside a bin is not the input order (ranks come from LDS atomics) -- irrelevant for a first pass.  Any key distribution
 // works: a bin's slice of the output is reserved with one global atomic per (tile, bin).
-// Measured at 12 x 2^24 pairs (tools/exp/partbench.hip, profiles/README.md round 3 batch ZZ): digits 0.37 + sort 3.62 ms ->
-// histogram 0.19 + digits/first pass 1.38 + second pass 1.87 ms.
+// Measured at 12 x 2^24 pairs (tools/exp/partbench.hip, profiles/README.md round 3 batch ZZ2): digits 0.37 + sort 3.62 ms ->
+// histogram 0.19 + digits/first pass 1.38 + one library pass for the high bits 1.87 ms (1c replaces that pass: 1.41 ms).
 constexpr int MSM_P1_BITS = 11;
 constexpr uint32_t MSM_P1_BINS = 1u << MSM_P1_BITS;
 constexpr int MSM_P1_THREADS = 1024;
