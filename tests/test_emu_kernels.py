@@ -641,13 +641,16 @@ def test_emu_msm_table_two_callers(emu_ctx, c=BN254, group=0, n=2000, rounds=3):
         b.free()
     t = ecc.PrecomputedBases(ctx, c.name, group, bases, n=n)
     try:
+        # (compared as affine points: from 2^25 pairs the Jacobian representative of a result is not fixed, gnark_amd.h ga_msm)
+        aff = lambda p: oracle.jac_to_affine(c.cid, group, p)
         want = [t.MultiExp(v) for v in vecs]
+        want_aff = [aff(p) for p in want]
         bad = []
 
         def worker(tid):
             for k in range(rounds):
                 j = (tid + k) % 3
-                if not np.array_equal(t.MultiExp(vecs[j]), want[j]):
+                if not np.array_equal(aff(t.MultiExp(vecs[j])), want_aff[j]):
                     bad.append((tid, k, j))
 
         th = [threading.Thread(target=worker, args=(i,)) for i in range(3)]

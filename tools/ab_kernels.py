@@ -125,7 +125,9 @@ def main():
             ctx.profile(False)
             res[gname] = {"msm_ms": round(el, 3), "accumulate_ms": st.get("msm_accumulate", {}).get("avg_ms"),
                           "reduce_ms": st.get("msm_reduce", {}).get("avg_ms"), "sort_ms": st.get("msm_sort", {}).get("avg_ms"),
-                          "sha": sha(ecc.jac_to_affine(cid, group, r)), "stable": bool(np.array_equal(r, r0))}
+                          "sha": sha(ecc.jac_to_affine(cid, group, r)),
+                          # (as affine points: the Jacobian representative is not fixed from call to call, include/gnark_amd.h ga_msm)
+                          "stable": bool(np.array_equal(ecc.jac_to_affine(cid, group, r), ecc.jac_to_affine(cid, group, r0)))}
             table.free()
             scal.free()
         out["msm"] = res
