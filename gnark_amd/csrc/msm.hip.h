@@ -48,8 +48,9 @@ typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_con
     MsmSortWide;
 
 // Sort (key, value) pairs on key bits [begin_bit, end_bit), ping-ponging between the two buffer pairs (no third copy of the data);
-// on return keys2/vals2 point at the sorted arrays and keys/vals at the other pair.  (The sort is stable: with begin_bit > 0 it is
-// the last pass of an LSD sort whose first pass the caller has made itself, msm_digits_pass1_kernel.)
+// on return keys2/vals2 point at the sorted arrays and keys/vals at the other pair.  (The sort is stable: with begin_bit > 0 it can
+// be the last pass of an LSD sort whose first pass the caller has made itself -- the intermediate version of the fused path, 1b below,
+// did that before its second level, 1c, replaced the library pass; the product calls it with begin_bit = 0 only.)
 inline int msm_sort_pairs(Ctx* ctx, const std::string& tmp_name, uint32_t*& keys, uint32_t*& keys2, uint32_t*& vals, uint32_t*& vals2, size_t m,
                           int end_bit, hipStream_t st, int begin_bit = 0) {
     rocprim::double_buffer<uint32_t> dk(keys, keys2), dv(vals, vals2);
