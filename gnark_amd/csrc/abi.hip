@@ -28,23 +28,37 @@ int current_lane() { return g_lane; }
 LaneScope::LaneScope(int lane) : prev(g_lane) { g_lane = lane; }
 LaneScope::~LaneScope() { g_lane = prev; }
 
+static thread_local char g_alloc_why[160] = {0};
+const char* device_malloc_error(hipError_t e) { return g_alloc_why[0] ? g_alloc_why : hipGetErrorString(e); }
+
 hipError_t device_malloc_bytes(void** p, size_t bytes) {
+    // The last GA_HBM_RESERVE_MB (default 1024) MiB of the device stay free for the runtime's own dispatch-time allocations.
+    // The reserve is a rule about what THIS allocation leaves behind, so it is checked before the hipMalloc, under a process-wide
+    // mutex (two lanes cannot both pass on the same free bytes).  Allocations below 16 MiB may use the upper half of the reserve: a
+    // few-KB buffer is not refused because another process or rank sharing the device has eaten a little into it.
     static const size_t reserve = []() {
         const char* e = getenv("GA_HBM_RESERVE_MB");
         return (size_t)(e ? strtoull(e, nullptr, 10) : 1024ull) << 20;
     }();
+    static const size_t small = 16ull << 20;
+    static std::mutex alloc_mu;
     *p = nullptr;
+    g_alloc_why[0] = 0;
+    std::lock_guard<std::mutex> g(alloc_mu);
+    if (reserve) {
+        size_t free_b = 0, total_b = 0;
+        const size_t floor_b = bytes >= small ? reserve : reserve / 2;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (free_b < bytes || free_b - bytes < floor_b)) {
+            snprintf(g_alloc_why, sizeof(g_alloc_why), "refused: %zu MiB free, the allocation would leave less than the %zu MiB reserve (GA_HBM_RESERVE_MB)",
+                     free_b >> 20, reserve >> 20);
+            return hipErrorOutOfMemory;
+        }
+    }
     hipError_t e = hipMalloc(p, bytes);
     if (e != hipSuccess) {
         (void)hipGetLastError();   // clear the sticky error: the caller reports this failure itself
         *p = nullptr;
         return e;
-    }
-    size_t free_b = 0, total_b = 0;
-    if (reserve && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < reserve) {
-        hipFree(*p);
-        *p = nullptr;
-        return hipErrorOutOfMemory;
     }
     return hipSuccess;
 }
@@ -68,7 +82,7 @@ int Ctx::scratch_get(const char* base_key, size_t bytes, void** out) {
     size_t want = bytes + bytes / 8 + 256;
     hipError_t e = device_malloc(&p, want);
     if (e != hipSuccess) {
-        set_error("device scratch '%s': device_malloc(%zu) failed: %s", key, want, hipGetErrorString(e));
+        set_error("device scratch '%s': device_malloc(%zu) failed: %s", key, want, device_malloc_error(e));
         return GA_ERR_NOMEM;
     }
     scratch[key] = std::make_pair(p, want);
@@ -125,7 +139,7 @@ struct Staged {
         }
         hipError_t e = device_malloc(&owned, bytes);
         if (e != hipSuccess) {
-            set_error("device_malloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+            set_error("device_malloc(%zu) failed: %s", bytes, device_malloc_error(e));
             return GA_ERR_NOMEM;
         }
         GA_HIP_CHECK(hipMemcpyAsync(owned, p, bytes, hipMemcpyHostToDevice, ctx->work_stream()));
@@ -276,7 +290,7 @@ int ga_malloc(ga_ctx* h, size_t bytes, void** dptr) {
     Lock l(c);
     hipError_t e = device_malloc(dptr, bytes ? bytes : 16);
     if (e != hipSuccess) {
-        set_error("device_malloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        set_error("device_malloc(%zu) failed: %s", bytes, device_malloc_error(e));
         return GA_ERR_NOMEM;
     }
     return GA_OK;

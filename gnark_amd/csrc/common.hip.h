@@ -39,6 +39,7 @@ const char* get_error();
 //    allocation that would leave less than GA_HBM_RESERVE_MB (default 1024) free is refused as out-of-memory instead;
 //  * a failed hipMalloc leaves its error in the thread's sticky last-error slot, where the next kernel-launch check would find it.
 hipError_t device_malloc_bytes(void** p, size_t bytes);
+const char* device_malloc_error(hipError_t e);   // why the last device_malloc of this thread failed (names the HBM reserve when that was the cause)
 template <class T>
 inline hipError_t device_malloc(T** p, size_t bytes) {
     return device_malloc_bytes(reinterpret_cast<void**>(p), bytes);
@@ -176,6 +177,22 @@ struct Ctx {
     void forget_table(const void* table) {
         std::lock_guard<std::mutex> g(degenerate_mu);
         degenerate.erase(table);
+        sparse_sets.erase(table);
+    }
+    // tables whose SMALL shared bucket set turned out mostly empty on the previous call (a witness of zeros and ones puts nearly
+    // every (scalar, window) pair into the skip bucket): the lazy window reduction flags most groups there, so the next call takes
+    // the exact kernel again (msm.hip.h, dense_set)
+    std::set<const void*> sparse_sets;
+    bool is_sparse_set(const void* table) {
+        std::lock_guard<std::mutex> g(degenerate_mu);
+        return sparse_sets.count(table) != 0;
+    }
+    void note_sparse_set(const void* table, bool sparse) {
+        std::lock_guard<std::mutex> g(degenerate_mu);
+        if (sparse)
+            sparse_sets.insert(table);
+        else
+            sparse_sets.erase(table);
     }
 
     int scratch_get(const char* key, size_t bytes, void** out);

@@ -97,7 +97,7 @@ static int upload(Ctx* ctx, const void* src, size_t bytes, void** dst) {
     *dst = nullptr;
     hipError_t e = device_malloc(dst, bytes ? bytes : 16);
     if (e != hipSuccess) {
-        set_error("proving key upload: device_malloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        set_error("proving key upload: device_malloc(%zu) failed: %s", bytes, device_malloc_error(e));
         return GA_ERR_NOMEM;
     }
     if (bytes) GA_HIP_CHECK(hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -173,7 +173,7 @@ static int stage_reserve(G16Stage* st, int which, uint64_t total) {
     const size_t bytes = x.cnt * stage_point_bytes(st->curve, which);
     hipError_t e = device_malloc(&x.d, bytes ? bytes : 16);
     if (e != hipSuccess) {
-        set_error("proving key upload: device_malloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        set_error("proving key upload: device_malloc(%zu) failed: %s", bytes, device_malloc_error(e));
         return GA_ERR_NOMEM;
     }
     x.reserved = true;
@@ -1802,6 +1802,19 @@ using namespace ga;
         return GA_ERR_STATE;                                                        \
     }
 
+// The proving entry points construct std::thread helpers and host vectors: a std::system_error / std::bad_alloc must not unwind
+// through the C ABI into cgo (the RAII guards inside release the locks, lanes and slot leases and join the helper on the way out).
+template <class F>
+static int g16_nothrow(F&& body) {
+    GA_NOTHROW_BEGIN
+    return body();
+    GA_NOTHROW_END
+    catch (...) {
+        set_error("internal error: unknown exception");
+        return GA_ERR_STATE;
+    }
+}
+
 extern "C" {
 
 int ga_g16_pk_create(ga_ctx* h, const ga_g16_key* key, ga_g16_pk** out) {
@@ -1972,7 +1985,7 @@ void ga_g16_pk_destroy(ga_g16_pk* p) {
     pk_free(pk);
 }
 
-int ga_g16_prove(ga_g16_pk* p, const void* w, const void* a, const void* b, const void* c, uint64_t n_constraints,
+static int g16_prove_impl(ga_g16_pk* p, const void* w, const void* a, const void* b, const void* c, uint64_t n_constraints,
                  uint64_t nb_public, const void* r, const void* s, void* proof_out) {
     G16Pk* pk = reinterpret_cast<G16Pk*>(p);
     if (!pk || !w || !a || !b || !c || !r || !s || !proof_out) {
@@ -2047,7 +2060,7 @@ int ga_g16_lane_stats(ga_ctx* h, uint64_t* out6) {
     return GA_OK;
 }
 
-int ga_g16_prove_partial(ga_g16_pk* p, const void* w, const void* a, const void* b, const void* c, uint64_t n_constraints,
+static int g16_prove_partial_impl(ga_g16_pk* p, const void* w, const void* a, const void* b, const void* c, uint64_t n_constraints,
                          uint64_t nb_public, void* partials_out) {
     G16Pk* pk = reinterpret_cast<G16Pk*>(p);
     if (!pk || !w || !a || !b || !c || !partials_out) {
@@ -2108,7 +2121,7 @@ int ga_g16_shard_layout(ga_g16_pk* p, uint64_t* out6) {
     return GA_OK;
 }
 
-int ga_g16_witness_partial(ga_g16_pk* p, const void* w, uint64_t nb_public, void* partials_out) {
+static int g16_witness_partial_impl(ga_g16_pk* p, const void* w, uint64_t nb_public, void* partials_out) {
     G16Pk* pk = reinterpret_cast<G16Pk*>(p);
     if (!pk || !w || !partials_out) {
         set_error("ga_g16_witness_partial: null argument");
@@ -2201,7 +2214,7 @@ int ga_g16_z_partial(ga_g16_pk* p, const void* h_slice_dev, void* partial_out) {
     return GA_OK;
 }
 
-int ga_g16_prove_multi(ga_g16_pk* const* keys, uint32_t n, const void* w, const void* a, const void* b, const void* c,
+static int g16_prove_multi_impl(ga_g16_pk* const* keys, uint32_t n, const void* w, const void* a, const void* b, const void* c,
                        uint64_t n_constraints, uint64_t nb_public, const void* r, const void* s, void* proof_out) {
     if (!keys || n == 0 || n > 64 || !w || !a || !b || !c || !r || !s || !proof_out) {
         set_error("ga_g16_prove_multi: null argument or unsupported device count");
@@ -2416,4 +2429,20 @@ int ga_g16_fold_pok(int curve, const void* poks, uint64_t n, const void* challen
     return GA_OK;
 }
 
+
+int ga_g16_prove(ga_g16_pk* p, const void* w, const void* a, const void* b, const void* c, uint64_t n_constraints,
+                 uint64_t nb_public, const void* r, const void* s, void* proof_out) {
+    return g16_nothrow([&]() { return g16_prove_impl(p, w, a, b, c, n_constraints, nb_public, r, s, proof_out); });
+}
+int ga_g16_prove_partial(ga_g16_pk* p, const void* w, const void* a, const void* b, const void* c, uint64_t n_constraints,
+                         uint64_t nb_public, void* partials_out) {
+    return g16_nothrow([&]() { return g16_prove_partial_impl(p, w, a, b, c, n_constraints, nb_public, partials_out); });
+}
+int ga_g16_witness_partial(ga_g16_pk* p, const void* w, uint64_t nb_public, void* partials_out) {
+    return g16_nothrow([&]() { return g16_witness_partial_impl(p, w, nb_public, partials_out); });
+}
+int ga_g16_prove_multi(ga_g16_pk* const* keys, uint32_t n, const void* w, const void* a, const void* b, const void* c,
+                       uint64_t n_constraints, uint64_t nb_public, const void* r, const void* s, void* proof_out) {
+    return g16_nothrow([&]() { return g16_prove_multi_impl(keys, n, w, a, b, c, n_constraints, nb_public, r, s, proof_out); });
+}
 }  // extern "C"

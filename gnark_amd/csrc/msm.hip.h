@@ -1460,8 +1460,13 @@ int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, X
     // ... unless the set is DENSE (a table's shared set: windows x n entries over 2^(c-1) buckets; >= 16 entries per bucket leave
     // e^-16 of them empty): a 2^14-constraint proof spent 1.1 ms per MSM in the exact kernel's per-lane scalar multiplications
     // (6.3 ms per proof against 3.2 ms at 2^16, profiles/README.md round 3 batch N)
-    const bool dense_set = P.m >= 16ull * (uint64_t)half * (uint64_t)nsets;
-    const bool lazy_reduce = (uint64_t)half * nsets >= ctx->tun.reduce_lazy_min || dense_set;
+    // P.m counts every (scalar, window) pair, the zero digits in the skip bucket included: a table over which a 0/1-heavy witness
+    // runs looks dense by that count while most of its buckets are empty.  The pair count of the skip bucket is only known on the
+    // device at this point, so the verdict comes from the previous call on the same table: when the lazy pass flagged more than a
+    // quarter of the groups, the set is remembered as sparse and small sets take the exact kernel again.
+    const bool big_set = (uint64_t)half * nsets >= ctx->tun.reduce_lazy_min;
+    const bool dense_set = P.m >= 16ull * (uint64_t)half * (uint64_t)nsets && !(P.table && ctx->is_sparse_set(d_bases));
+    const bool lazy_reduce = big_set || dense_set;
     if (!lazy_reduce) {
         StageTimer tm(ctx, "msm_reduce");
         hipLaunchKernelGGL((msm_reduce_groups_kernel<F>), dim3((total_groups + 63) / 64), dim3(64), 0, st, (const XYZZ<F>*)bsum,
@@ -1517,9 +1522,12 @@ int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, X
     }
     const int rows = nbits + 1;
     std::vector<XYZZ<F>> hb((size_t)nsets * rows);
+    uint32_t h_redo_groups = 0;
     GA_HIP_CHECK(hipMemcpyAsync(hb.data(), bits, (size_t)nsets * rows * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
+    GA_HIP_CHECK(hipMemcpyAsync(&h_redo_groups, rg_count, 4, hipMemcpyDeviceToHost, st));
     GA_HIP_CHECK(hipStreamSynchronize(st));
     note_degenerate();
+    if (P.table && !big_set) ctx->note_sparse_set(d_bases, (uint64_t)h_redo_groups * 4 > total_groups);
     int log_m = 0;
     while ((1u << log_m) < m_groups) log_m++;
     for (int w = 0; w < nsets; w++) {   // host: ~nbits + log2(m) doublings and nbits additions per set

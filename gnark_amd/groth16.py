@@ -325,13 +325,15 @@ def WitnessPartial(pk: ProvingKey, W, nb_public: int) -> np.ndarray:
 
 
 def HChain(pk: ProvingKey, v, out_dev_ptr: int):
-    """out_dev <- FFT_coset(iFFT(v)) for one of the solver's A, B, C (ga_g16_h_chain); out_dev: n fr elements on pk's device"""
+    """out_dev <- n * FFT_coset(iFFT(v)) for one of the solver's A, B, C (ga_g16_h_chain); out_dev: n fr elements on pk's device.
+    The chain is unscaled (the 1/n lives in HCombine's point-wise step): valid only as an input of HCombine."""
     v = as_u64(v, 4)
     pk.ctx.lib.check(pk.ctx.lib.ga_g16_h_chain(pk.handle, _ptr(v), v.shape[0], C.c_void_p(out_dev_ptr)))
 
 
 def HChainDevice(pk: ProvingKey, buf_dev_ptr: int, n_constraints: int):
-    """buf_dev (n fr elements of room, the first n_constraints filled) <- FFT_coset(iFFT(.)) in place (ga_g16_h_chain_dev)"""
+    """buf_dev (n fr elements of room, the first n_constraints filled) <- n * FFT_coset(iFFT(.)) in place (ga_g16_h_chain_dev);
+    unscaled like HChain: valid only as an input of HCombine"""
     pk.ctx.lib.check(pk.ctx.lib.ga_g16_h_chain_dev(pk.handle, C.c_void_p(buf_dev_ptr), int(n_constraints)))
 
 

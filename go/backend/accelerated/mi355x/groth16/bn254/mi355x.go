@@ -65,12 +65,16 @@ func effectivePrecompute(cfg *mi355x.Config, pinned bool) int32 {
 func (pk *ProvingKey) acquire(cfg *mi355x.Config, info constraint.Groth16Commitments) (*deviceInfo, error) {
 	pk.setupMu.Lock()
 	defer pk.setupMu.Unlock()
-	pk.PinToGPU = pk.PinToGPU || cfg.PinToGPU
+	// the sticky pin flag is committed only once the key really is set up under it: a caller that asks for a pinned key while
+	// another goroutine is proving on the un-pinned copy gets the "in use" error below and must leave pk.PinToGPU as it was, or the
+	// first prover's release() would no longer free its un-pinned device copy
+	pin := pk.PinToGPU || cfg.PinToGPU
 	if !(pk.deviceInfo != nil && len(pk.InfinityA) == 0) { // a key pinned by PinFromFile has no host copy to (re)pin from
-		if err := pk.setupDevicePointersLocked(cfg, info); err != nil {
+		if err := pk.setupDevicePointersLocked(cfg, info, pin); err != nil {
 			return nil, err
 		}
 	}
+	pk.PinToGPU = pin
 	pk.users++
 	return pk.deviceInfo, nil
 }
@@ -89,9 +93,9 @@ func (pk *ProvingKey) release() {
 // device set or table policy).  Counterpart of (*ProvingKey).setupDevicePointers, icicle.go:88-264: the Den vector, the coset
 // generator and the NTT domain bookkeeping have no Go-side remains -- the library derives them from the cardinality.
 // Caller holds setupMu.
-func (pk *ProvingKey) setupDevicePointersLocked(cfg *mi355x.Config, info constraint.Groth16Commitments) error {
+func (pk *ProvingKey) setupDevicePointersLocked(cfg *mi355x.Config, info constraint.Groth16Commitments, pin bool) error {
 	devices := cfg.DeviceIDs()
-	precompute := effectivePrecompute(cfg, pk.PinToGPU)
+	precompute := effectivePrecompute(cfg, pin)
 	if pk.deviceInfo != nil {
 		if slices.Equal(pk.deviceInfo.devices, devices) && pk.deviceInfo.precompute == precompute {
 			return nil

@@ -323,7 +323,10 @@ int ga_g16_finish(ga_g16_pk* pk, const void* partials_sum, const void* r, const 
 /* The same proof in pieces, for callers that orchestrate several devices themselves (gnark_amd/multigpu.py does it with one
  * process per GPU and RCCL): the witness MSMs of this shard (A | B1 | K as G1Jac, B2 as G2Jac -- W is uploaded only over the wire
  * range the shard's bases cover), one chain of computeH per call (v = the solver's A, B or C on the host; out_dev = n fr elements
- * on this key's device, holding FFT_coset(iFFT(v)) afterwards), the combination h = iFFT_coset((a*b - c)/(g^n - 1)) in a_dev
+ * on this key's device, holding n * FFT_coset(iFFT(v)) afterwards -- the chain is UNSCALED: the 1/n of the inverse transform is
+ * not applied here, ga_g16_h_combine divides by n^2 in its point-wise step; a chain buffer is therefore only meaningful as an input
+ * of ga_g16_h_combine of the SAME library build, never as the coset evaluations themselves), the combination
+ * h = iFFT_coset((a*b - c)/(g^n - 1)) in a_dev from three such chains
  * (bit-reversed), and the MSM of this shard's slice of pk.G1.Z with the matching slice of h (h_slice_dev points at element off_z).
  * ga_g16_shard_layout: out8 = {off_z, len_z, w_lo, w_hi, domain cardinality, nb_wires, window_shard_index, window_shard_count}
  * (a window-sharded key covers all of h and W: off_z = 0, len_z = n - 1). */

@@ -75,6 +75,30 @@ def main():
     want = oracle.groth16_prove(c.cid, dict(inst.key, n=inst.n), inst.solution.W, inst.solution.A, inst.solution.B, inst.solution.C,
                                 inst.nb_public, inst.r, inst.s, nthreads=2)
     assert np.array_equal(sproof.Ar, want[0]) and np.array_equal(sproof.Bs, want[1]) and np.array_equal(sproof.Krs, want[2]), "sharded 2^8"
+    # ---- every collective the module uses, with checkable contents (the RCCL self-test of bench.py, here over gloo) -----------
+    st = multigpu.collective_selftest(dist)
+    assert st["ok"] and st.get("send_recv") is not False, st
+    # ---- a rank that fails INSIDE a sharded proof: the fixed collective schedule carries the error to every rank, nobody hangs,
+    # and the process group is usable afterwards (the next proof is the right proof)
+    spk = inst.proving_key(ctx, shard=(rank, world), staged_chunk=64)
+    try:
+        for point in ("witness", "h_side", "z"):
+            os.environ["GA_MGPU_FAULT"] = "%d:%s" % (world - 1 if point != "h_side" else 0, point)
+            try:
+                multigpu.groth16_prove_sharded(spk, inst.solution, inst.nb_public, inst.r, inst.s, dist)
+                raise AssertionError("the injected fault at %s went unnoticed on rank %d" % (point, rank))
+            except multigpu.ShardedProofError as e:
+                assert str(world - 1 if point != "h_side" else 0) in str(e)
+            finally:
+                del os.environ["GA_MGPU_FAULT"]
+        again = multigpu.groth16_prove_sharded(spk, inst.solution, inst.nb_public, inst.r, inst.s, dist)
+        assert np.array_equal(again.raw(), sproof.raw()), "proof after a failed proof differs"
+        ok, why = multigpu.agree(dist, rank != 0, "rank 0 says no")
+        assert ok is False and "rank 0: rank 0 says no" in why
+        ok, why = multigpu.agree(dist, True)
+        assert ok is True and why is None
+    finally:
+        spk.FreeGPUResources()
     dist.barrier()
     if rank == 0:
         print("MGPU_OK world=%d" % world)

@@ -674,10 +674,11 @@ def test_out_of_device_memory_is_an_error_not_a_crash(gpu_ctx):
     ballast = []
     try:
         # fill the device down to the library's reserve (GA_HBM_RESERVE_MB, 1 GiB: what the ROCm runtime needs for the kernels'
-        # private segments -- it aborts the process when it cannot get it, tools/exp/oom_repro.py): ever smaller pieces until an
-        # 8 MiB one is refused, so that less than a 2^16 proof's scratch and far less than a key with tables is left
+        # private segments -- it aborts the process when it cannot get it, tools/exp/oom_repro.py): ever smaller pieces until a
+        # 16 MiB one is refused (smaller ones may use half of the reserve), so that less than a 2^16 proof's scratch and far less
+        # than a key with tables is left
         step = 64 << 30
-        while step >= (8 << 20):
+        while step >= (16 << 20):
             try:
                 ballast.append(gpu_ctx.malloc(step))
             except GnarkAmdError:
@@ -867,3 +868,27 @@ def test_plonk_quotient_2_22_identity(gpu_ctx, pinned):
     """config 5 at its stated size (n = 2^22 gates, 4n = 2^24): grand product + quotient on the device, identity at a random
     point with every polynomial evaluated by the CPU oracle from its values"""
     cases.check_plonk_quotient_identity(gpu_ctx, BN254, 22, nthreads=_NT, pinned=pinned)
+
+
+def test_rccl_collectives_and_sharded_proof_on_one_gpu():
+    """The multi-GPU prover's RCCL path on a 1-GPU box: a ONE-rank process group over the nccl (= RCCL) backend, every collective
+    gnark_amd/multigpu.py uses on DEVICE tensors, one sharded MSM exchange, and a 2^16 sharded proof walked through the full
+    collective schedule (sliced uploads gathered on the chain owner, scatter of h, all_gather of the partial sums) whose bytes
+    must equal the plain single-GPU proof.  Runs in a child process (bench.py --nccl-selftest-worker: the same code the N = 1 bench
+    line reports as "nccl_selftest")."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GA_SELFTEST_BACKEND="nccl", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--nccl-selftest-worker"], capture_output=True, text=True, env=env, cwd=root, timeout=600)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("NCCL_SELFTEST ")]
+    assert lines, (r.returncode, r.stdout[-1000:], r.stderr[-3000:])
+    d = json.loads(lines[-1][len("NCCL_SELFTEST "):])
+    assert d.get("ok") is True, d
+    assert d["collectives"]["backend"] == "nccl" and d["collectives"]["device_tensors"] is True
+    assert all(d["collectives"][k] is True for k in ("all_gather", "gather", "scatter", "broadcast", "all_reduce"))
+    assert d["sharded_proof_same_bytes"] is True and d["msm_all_gather"] is True and d["constraints"] == 1 << 16
