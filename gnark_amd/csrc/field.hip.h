@@ -375,6 +375,21 @@ GA_HD void load16n(const void* p, ga_v4u (&v)[NV]) {
     for (int i = 0; i < NV; i++) asm volatile("" : "+v"(v[i]));
 #endif
 }
+// the two halves of load16n for software-pipelined loops: issue the loads now, make the values opaque (= wait for them) at the point
+// of use an iteration later -- the asm still separates the loads from the limb extraction, so they stay 16-byte loads
+template <int NV>
+GA_HD void load16n_issue(const void* p, ga_v4u (&v)[NV]) {
+    const ga_v4u* q = reinterpret_cast<const ga_v4u*>(p);
+#pragma unroll
+    for (int i = 0; i < NV; i++) v[i] = q[i];
+}
+template <int NV>
+GA_HD void load16n_arrive(ga_v4u (&v)[NV]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int i = 0; i < NV; i++) asm volatile("" : "+v"(v[i]));
+#endif
+}
 GA_HD u32x4 load16(const void* p) {
     ga_v4u v[1];
     load16n<1>(p, v);

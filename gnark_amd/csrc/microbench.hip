@@ -52,6 +52,28 @@ MB_KERNEL(mb_fma_f64, MB_F64_DECL, REP8(OP_FMA64) REP8(OP_FMA64))
 #define OP_FMA32(a) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a) : "v"(x), "v"(y));
 MB_KERNEL(mb_fma_f32, MB_F32_DECL, REP8(OP_FMA32) REP8(OP_FMA32))
 
+// dependency distance and occupancy: DIST accumulators take the 16 multiply-adds of an iteration in turn (DIST = 1: every
+// instruction waits for the previous one's result -- the shape of a product column, which accumulates in place); LDSPAD > 0 leaves
+// room for ONE workgroup of 256 lanes per CU, i.e. one wave per SIMD (the occupancy of the BLS12-381 G2 bucket kernel)
+template <int DIST, int LDSPAD>
+__global__ void __launch_bounds__(256) mb_mad_chain(uint32_t* out, uint32_t seed) {
+    __shared__ uint32_t pad[LDSPAD > 0 ? LDSPAD : 1];
+    if (LDSPAD > 0) pad[threadIdx.x] = seed;
+    uint64_t a[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) a[k] = seed + threadIdx.x + k;
+    uint32_t x = seed | 1u, y = (seed >> 3) | 1u;
+    for (int it = 0; it < MB_ITERS; it++) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(a[k % DIST]) : "v"(x), "v"(y) : "vcc");
+    }
+    uint32_t r = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) r += (uint32_t)a[k];
+    if (LDSPAD > 0) r += pad[(threadIdx.x + 1) & 255];
+    if (r == 0x12345u) out[threadIdx.x] = r;
+}
+
 template <class P>
 __global__ void __launch_bounds__(256) mb_field_mul(uint32_t* out, uint32_t seed) {
     Fe<P> a = fe_const<P>(P::R2), b = fe_one<P>();
@@ -98,20 +120,22 @@ __global__ void __launch_bounds__(256) mb_fe_addsub(uint32_t* out, uint32_t seed
     if (a.l[0] == 0x12345u && b.l[0] == 7) out[threadIdx.x] = a.l[1];
 }
 
+// launches = 3: a burst of a few milliseconds (the boost clock); launches in the hundreds: the SUSTAINED rate of a kernel that runs
+// for 0.1 s or more, which is what the bucket kernels see (round 4: the integer pipes at full load do not hold the burst clock)
 template <class K>
-static int run_one(Ctx* ctx, const char* name, K kernel, double ops_per_thread, std::string& out, uint32_t* d_out) {
+static int run_one(Ctx* ctx, const char* name, K kernel, double ops_per_thread, std::string& out, uint32_t* d_out, int launches = 3) {
     const unsigned blocks = 256 * 8, threads = 256;
     hipEvent_t a, b;
     GA_HIP_CHECK(hipEventCreate(&a));
     GA_HIP_CHECK(hipEventCreate(&b));
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), 0, ctx->stream, d_out, 12345u);   // warm-up
     GA_HIP_CHECK(hipEventRecord(a, ctx->stream));
-    for (int r = 0; r < 3; r++) hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), 0, ctx->stream, d_out, 12345u + r);
+    for (int r = 0; r < launches; r++) hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), 0, ctx->stream, d_out, 12345u + r);
     GA_HIP_CHECK(hipEventRecord(b, ctx->stream));
     GA_HIP_CHECK(hipEventSynchronize(b));
     float ms = 0;
     GA_HIP_CHECK(hipEventElapsedTime(&ms, a, b));
-    double gops = 3.0 * ops_per_thread * blocks * threads / (ms * 1e-3) / 1e9;
+    double gops = (double)launches * ops_per_thread * blocks * threads / (ms * 1e-3) / 1e9;
     char tmp[128];
     snprintf(tmp, sizeof(tmp), "%s=%.1f;", name, gops);
     out += tmp;
@@ -140,6 +164,19 @@ int util_microbench(Ctx* ctx, char* buf, size_t cap) {
     GA_CHECK(run_one(ctx, "f29mul_bls12381_fp_Gmul", mb_f29_mul<BLS12_381_Fp>, 2.0 * (MB_ITERS / 8), out, d_out));
     GA_CHECK(run_one(ctx, "f29addsub_bn254_Gop", mb_f29_addsub<BN254_Fp>, 4.0 * (MB_ITERS / 8), out, d_out));
     GA_CHECK(run_one(ctx, "fe_addsub_bn254_Gop", mb_fe_addsub<BN254_Fp>, 4.0 * (MB_ITERS / 8), out, d_out));
+    constexpr int ONE_WG = 22 * 1024;   // 88 KB of LDS per workgroup: one workgroup (4 waves) per CU
+    GA_CHECK(run_one(ctx, "mad_dist1_Gops", mb_mad_chain<1, 0>, n16, out, d_out));
+    GA_CHECK(run_one(ctx, "mad_dist2_Gops", mb_mad_chain<2, 0>, n16, out, d_out));
+    GA_CHECK(run_one(ctx, "mad_dist4_Gops", mb_mad_chain<4, 0>, n16, out, d_out));
+    GA_CHECK(run_one(ctx, "mad_dist8_Gops", mb_mad_chain<8, 0>, n16, out, d_out));
+    GA_CHECK(run_one(ctx, "mad_dist1_one_wave_per_simd_Gops", mb_mad_chain<1, ONE_WG>, n16, out, d_out));
+    GA_CHECK(run_one(ctx, "mad_dist2_one_wave_per_simd_Gops", mb_mad_chain<2, ONE_WG>, n16, out, d_out));
+    GA_CHECK(run_one(ctx, "mad_dist8_one_wave_per_simd_Gops", mb_mad_chain<8, ONE_WG>, n16, out, d_out));
+    // the same instruction streams held for ~0.2 s each
+    GA_CHECK(run_one(ctx, "v_mad_u64_u32_sustained_Gops", mb_mad_u64_u32, n16, out, d_out, 400));
+    GA_CHECK(run_one(ctx, "v_mov_b32_sustained_Gops", mb_mov_b32, n16, out, d_out, 800));
+    GA_CHECK(run_one(ctx, "f29mul_bn254_sustained_Gmul", mb_f29_mul<BN254_Fp>, 2.0 * (MB_ITERS / 8), out, d_out, 100));
+    GA_CHECK(run_one(ctx, "v_mad_u64_u32_after_Gops", mb_mad_u64_u32, n16, out, d_out));
     snprintf(buf, cap, "%s", out.c_str());
     return GA_OK;
 }

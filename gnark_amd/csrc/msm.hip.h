@@ -47,22 +47,20 @@ typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_con
                                                                        rocprim::block_radix_rank_algorithm::match>>
     MsmSortWide;
 
-// Sort (key, value) pairs on key bits [begin_bit, end_bit), ping-ponging between the two buffer pairs (no third copy of the data);
-// on return keys2/vals2 point at the sorted arrays and keys/vals at the other pair.  (The sort is stable: with begin_bit > 0 it can
-// be the last pass of an LSD sort whose first pass the caller has made itself -- the intermediate version of the fused path, 1b below,
-// did that before its second level, 1c, replaced the library pass; the product calls it with begin_bit = 0 only.)
+// Sort (key, value) pairs on the low end_bit key bits, ping-ponging between the two buffer pairs (no third copy of the data); on
+// return keys2/vals2 point at the sorted arrays and keys/vals at the other pair.  The library sort: small MSMs, and whatever the
+// fused path (1b / 1c below) does not take.
 inline int msm_sort_pairs(Ctx* ctx, const std::string& tmp_name, uint32_t*& keys, uint32_t*& keys2, uint32_t*& vals, uint32_t*& vals2, size_t m,
-                          int end_bit, hipStream_t st, int begin_bit = 0) {
+                          int end_bit, hipStream_t st) {
     rocprim::double_buffer<uint32_t> dk(keys, keys2), dv(vals, vals2);
-    const int bits = end_bit - begin_bit;
-    const bool wide = (bits + 10) / 11 < (bits + 7) / 8;   // fewer passes with 11-bit digits than with 8-bit ones
+    const bool wide = (end_bit + 10) / 11 < (end_bit + 7) / 8;   // fewer passes with 11-bit digits than with 8-bit ones
     size_t tmp_bytes = 0;
     void* tmp = nullptr;
-    if (wide) GA_HIP_CHECK((rocprim::radix_sort_pairs<MsmSortWide>(nullptr, tmp_bytes, dk, dv, m, (unsigned)begin_bit, (unsigned)end_bit, st)));
-    else GA_HIP_CHECK((rocprim::radix_sort_pairs(nullptr, tmp_bytes, dk, dv, m, (unsigned)begin_bit, (unsigned)end_bit, st)));
+    if (wide) GA_HIP_CHECK((rocprim::radix_sort_pairs<MsmSortWide>(nullptr, tmp_bytes, dk, dv, m, 0u, (unsigned)end_bit, st)));
+    else GA_HIP_CHECK((rocprim::radix_sort_pairs(nullptr, tmp_bytes, dk, dv, m, 0u, (unsigned)end_bit, st)));
     GA_CHECK(ctx->scratch_get(tmp_name.c_str(), tmp_bytes + 256, &tmp));
-    if (wide) GA_HIP_CHECK((rocprim::radix_sort_pairs<MsmSortWide>(tmp, tmp_bytes, dk, dv, m, (unsigned)begin_bit, (unsigned)end_bit, st)));
-    else GA_HIP_CHECK((rocprim::radix_sort_pairs(tmp, tmp_bytes, dk, dv, m, (unsigned)begin_bit, (unsigned)end_bit, st)));
+    if (wide) GA_HIP_CHECK((rocprim::radix_sort_pairs<MsmSortWide>(tmp, tmp_bytes, dk, dv, m, 0u, (unsigned)end_bit, st)));
+    else GA_HIP_CHECK((rocprim::radix_sort_pairs(tmp, tmp_bytes, dk, dv, m, 0u, (unsigned)end_bit, st)));
     keys2 = dk.current();
     keys = dk.alternate();
     vals2 = dv.current();
@@ -131,7 +129,7 @@ __global__ void msm_digits_kernel(const uint32_t* __restrict__ scalars, uint64_t
 
 // ---- 1b. digits fused with the first pass of the radix sort (large shared bucket sets) ----------------------------------------
 // The plain sequence writes the (key, value) pairs in scalar order (1.6 GB at 12 x 2^24), reads the keys for the histograms and
-// reads / scatters the pairs twice (two 11-bit onesweep passes).  Here the FIRST LSD pass -- a partition by the low MSM_P1_BITS key
+// reads / scatters the pairs twice (two 11-bit onesweep passes).  Here the FIRST LSD pass -- a partition by the low BITS (11 or 12) key
 // bits -- is made by the kernel that extracts the digits: a histogram of the low key bits straight from the scalars (digits are
 // cheap to recompute: nothing is written), then a tile of <= 1024 scalars x windows is partitioned in LDS and leaves the CU as one
 // run per (tile, bin); the second level (1c below) finishes the grouping without the library.
@@ -139,22 +137,72 @@ __global__ void msm_digits_kernel(const uint32_t* __restrict__ scalars, uint64_t
 // works: a bin's slice of the output is reserved with one global atomic per (tile, bin).
 // Measured at 12 x 2^24 pairs (tools/exp/partbench.hip, profiles/README.md round 3 batch ZZ2): digits 0.37 + sort 3.62 ms ->
 // histogram 0.19 + digits/first pass 1.38 + one library pass for the high bits 1.87 ms (1c replaces that pass: 1.41 ms).
-constexpr int MSM_P1_BITS = 11;
-constexpr uint32_t MSM_P1_BINS = 1u << MSM_P1_BITS;
 constexpr int MSM_P1_THREADS = 1024;
 constexpr int MSM_P1_MAXW = 16;                       // windows a thread keeps in registers
-constexpr uint32_t MSM_P1_ENTRIES = 1024 * 13;        // pairs staged per tile: 104 KB of LDS (+ 32 KB of counters)
+constexpr uint32_t MSM_P1_ENTRIES = 1024 * 13;        // pairs staged per tile: 104 KB of LDS (+ 16 / 32 KB of bin tables)
+constexpr uint32_t MSM_P2_SEG = 16384;                // pairs per second-level segment
+constexpr uint32_t MSM_P2_HB = 4104;                  // capacity for the high key parts of the second level
+// Key width.  The first level splits off the low BITS key bits, the second level handles hb = (nb >> BITS) + 1 high parts in LDS.
+// BITS = 11 while those fit (key spaces below 2^23: a table's 2^21 shared buckets -> hb = 1025, PLONK's three bucket sets of a
+// batched commitment -> 3073, the 13 x 2^19 buckets of a raw 2^24 MSM -> 3329), BITS = 12 up to 2^24 keys (round 4; round 3
+// stopped at 22 key bits and one scalar vector, and those two callers fell back to the library sort).
+static inline int msm_p1_bits(uint64_t nb) { return (nb >> 11) + 1 <= MSM_P2_HB ? 11 : 12; }
+static inline bool msm_fused_fits(uint64_t nb) {
+    const int b = msm_p1_bits(nb);
+    return nb >= (1ull << b) && (nb >> b) + 1 <= MSM_P2_HB;
+}
 static inline uint32_t msm_p1_tile_scalars(int nwl) {
     const uint32_t t = MSM_P1_ENTRIES / (uint32_t)nwl;
     return t < (uint32_t)MSM_P1_THREADS ? t : (uint32_t)MSM_P1_THREADS;
 }
 
-template <class FrP>
+// In-place exclusive prefix sums of a[0, count) in LDS by a block of exactly 1024 threads (count <= 5 * 1024); a[count] receives the
+// total, which is also returned.  wtot: 16 words of LDS.  The caller has synchronised the block on a[]; the block is synchronised on
+// return.  (Round 3 scanned with two ping-pong arrays: 3 x 4 bytes per bin instead of 1 -- what kept 12-bit levels out of 160 KB.)
+__device__ __forceinline__ uint32_t msm_block_excl_scan_1024(uint32_t* __restrict__ a, uint32_t count, uint32_t* __restrict__ wtot) {
+    constexpr int PER = 5;
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    uint32_t v[PER], s = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const uint32_t idx = t * PER + k;
+        const uint32_t x = idx < count ? a[idx] : 0;
+        v[k] = s;
+        s += x;
+    }
+    uint32_t inc = s;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 16; w++) {
+        const uint32_t x = wtot[w];
+        if (w < wave) base += x;
+        total += x;
+    }
+    base += inc - s;
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const uint32_t idx = t * PER + k;
+        if (idx < count) a[idx] = base + v[k];
+    }
+    if (t == 0) a[count] = total;
+    __syncthreads();
+    return total;
+}
+
+template <class FrP, int BITS>
 __global__ void __launch_bounds__(256)
 msm_digit_hist_kernel(const uint32_t* __restrict__ scalars, uint64_t n, int mont, int c, int nwin, int win_lo, int win_hi, int table,
                       uint32_t key_base, uint32_t skip, uint32_t* __restrict__ ghist) {
-    __shared__ uint32_t h[MSM_P1_BINS];
-    for (uint32_t b = threadIdx.x; b < MSM_P1_BINS; b += blockDim.x) h[b] = 0;
+    constexpr uint32_t BINS = 1u << BITS;
+    __shared__ uint32_t h[BINS];
+    for (uint32_t b = threadIdx.x; b < BINS; b += blockDim.x) h[b] = 0;
     __syncthreads();
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         DigitWalk<FrP> D;
@@ -162,51 +210,45 @@ msm_digit_hist_kernel(const uint32_t* __restrict__ scalars, uint64_t n, int mont
         for (int w = 0; w < win_hi; w++) {
             uint32_t k, v;
             D.next(c, w, win_lo, n, i, table, key_base, skip, k, v);
-            if (w >= win_lo) atomicAdd(&h[k & (MSM_P1_BINS - 1)], 1u);
+            if (w >= win_lo) atomicAdd(&h[k & (BINS - 1)], 1u);
         }
     }
     __syncthreads();
-    for (uint32_t b = threadIdx.x; b < MSM_P1_BINS; b += blockDim.x)
+    for (uint32_t b = threadIdx.x; b < BINS; b += blockDim.x)
         if (h[b]) atomicAdd(&ghist[b], h[b]);
 }
 
-// exclusive scans of the MSM_P1_BINS bin counts (one block): where each bin's slice of the partitioned arrays starts (cursor: consumed
-// by the first pass; bin_off: kept, MSM_P1_BINS + 1 entries) and the number of MSM_P2_SEG-pair segments before each bin (seg_off)
-constexpr uint32_t MSM_P2_SEG = 16384;
+// exclusive scans of the bin counts (one block): where each bin's slice of the partitioned arrays starts (cursor: consumed by the
+// first pass; bin_off: kept, BINS + 1 entries) and the number of MSM_P2_SEG-pair segments before each bin (seg_off)
+template <int BITS>
 static __global__ void __launch_bounds__(1024) msm_p1_scan_kernel(const uint32_t* __restrict__ ghist, uint32_t* __restrict__ cursor,
                                                                   uint32_t* __restrict__ bin_off, uint32_t* __restrict__ seg_off) {
-    __shared__ uint32_t a[2][MSM_P1_BINS], g[2][MSM_P1_BINS];
-    for (uint32_t b = threadIdx.x; b < MSM_P1_BINS; b += blockDim.x) {
-        a[0][b] = ghist[b];
-        g[0][b] = (ghist[b] + MSM_P2_SEG - 1) / MSM_P2_SEG;
+    constexpr uint32_t BINS = 1u << BITS;
+    __shared__ uint32_t a[BINS + 1], g[BINS + 1], wtot[16];
+    for (uint32_t b = threadIdx.x; b < BINS; b += blockDim.x) {
+        a[b] = ghist[b];
+        g[b] = (ghist[b] + MSM_P2_SEG - 1) / MSM_P2_SEG;
     }
     __syncthreads();
-    int cur = 0;
-    for (uint32_t d = 1; d < MSM_P1_BINS; d <<= 1) {
-        for (uint32_t b = threadIdx.x; b < MSM_P1_BINS; b += blockDim.x) {
-            a[cur ^ 1][b] = a[cur][b] + (b >= d ? a[cur][b - d] : 0);
-            g[cur ^ 1][b] = g[cur][b] + (b >= d ? g[cur][b - d] : 0);
-        }
-        __syncthreads();
-        cur ^= 1;
-    }
-    for (uint32_t b = threadIdx.x; b <= MSM_P1_BINS; b += blockDim.x) {
-        const uint32_t ex = b ? a[cur][b - 1] : 0;
-        if (b < MSM_P1_BINS) cursor[b] = ex;
-        bin_off[b] = ex;
-        seg_off[b] = b ? g[cur][b - 1] : 0;
+    msm_block_excl_scan_1024(a, BINS, wtot);
+    msm_block_excl_scan_1024(g, BINS, wtot);
+    for (uint32_t b = threadIdx.x; b <= BINS; b += blockDim.x) {
+        if (b < BINS) cursor[b] = a[b];
+        bin_off[b] = a[b];
+        seg_off[b] = g[b];
     }
 }
 
-template <class FrP>
+template <class FrP, int BITS>
 __global__ void __launch_bounds__(MSM_P1_THREADS)
 msm_digits_pass1_kernel(const uint32_t* __restrict__ scalars, uint64_t n, int mont, int c, int nwin, int win_lo, int win_hi, int table,
                         uint32_t key_base, uint32_t skip, uint32_t tile_scalars, uint32_t* __restrict__ cursor,
                         uint32_t* __restrict__ out_keys, uint32_t* __restrict__ out_vals) {
+    constexpr uint32_t BINS = 1u << BITS;
     __shared__ uint32_t stage_k[MSM_P1_ENTRIES], stage_v[MSM_P1_ENTRIES];
-    __shared__ uint32_t cnt[MSM_P1_BINS], incl[2][MSM_P1_BINS], gbase[MSM_P1_BINS];
+    __shared__ uint32_t start[BINS + 1], delta[BINS], wtot[16];   // start: counts, then (scanned in place) where a bin's run starts in the staging arrays
     const uint32_t t = threadIdx.x;
-    for (uint32_t b = t; b < MSM_P1_BINS; b += blockDim.x) cnt[b] = 0;
+    for (uint32_t b = t; b < BINS; b += blockDim.x) start[b] = 0;
     __syncthreads();
     const uint64_t i = (uint64_t)blockIdx.x * tile_scalars + t;
     const bool live = t < tile_scalars && i < n;
@@ -222,26 +264,21 @@ msm_digits_pass1_kernel(const uint32_t* __restrict__ scalars, uint64_t n, int mo
         for (int q = 0; q < MSM_P1_MAXW; q++)
             if (win_lo + q < win_hi) {
                 D.next(c, win_lo + q, win_lo, n, i, table, key_base, skip, key[q], val[q]);
-                rank[q] = atomicAdd(&cnt[key[q] & (MSM_P1_BINS - 1)], 1u);
+                rank[q] = atomicAdd(&start[key[q] & (BINS - 1)], 1u);
             }
     }
     __syncthreads();
-    // inclusive scan of the bin counts of this tile; a bin's run starts at incl[b] - cnt[b] in the staging arrays
-    for (uint32_t b = t; b < MSM_P1_BINS; b += blockDim.x) incl[0][b] = cnt[b];
-    __syncthreads();
-    int cur = 0;
-    for (uint32_t d = 1; d < MSM_P1_BINS; d <<= 1) {
-        for (uint32_t b = t; b < MSM_P1_BINS; b += blockDim.x) incl[cur ^ 1][b] = incl[cur][b] + (b >= d ? incl[cur][b - d] : 0);
-        __syncthreads();
-        cur ^= 1;
+    const uint32_t total = msm_block_excl_scan_1024(start, BINS, wtot);
+    // a bin's slice of the output is reserved with one global atomic per (tile, bin); delta = where the run goes - where it is staged
+    for (uint32_t b = t; b < BINS; b += blockDim.x) {
+        const uint32_t cnt = start[b + 1] - start[b];
+        delta[b] = cnt ? atomicAdd(&cursor[b], cnt) - start[b] : 0;
     }
-    const uint32_t total = incl[cur][MSM_P1_BINS - 1];
-    for (uint32_t b = t; b < MSM_P1_BINS; b += blockDim.x) gbase[b] = cnt[b] ? atomicAdd(&cursor[b], cnt[b]) : 0;
     if (live) {
 #pragma unroll
         for (int q = 0; q < MSM_P1_MAXW; q++)
             if (win_lo + q < win_hi) {
-                const uint32_t b = key[q] & (MSM_P1_BINS - 1), at = incl[cur][b] - cnt[b] + rank[q];
+                const uint32_t at = start[key[q] & (BINS - 1)] + rank[q];
                 stage_k[at] = key[q];
                 stage_v[at] = val[q];
             }
@@ -249,28 +286,27 @@ msm_digits_pass1_kernel(const uint32_t* __restrict__ scalars, uint64_t n, int mo
     __syncthreads();
     for (uint32_t p = t; p < total; p += blockDim.x) {   // consecutive lanes write consecutive addresses inside a run
         const uint32_t k = stage_k[p];
-        const uint32_t b = k & (MSM_P1_BINS - 1);
-        const uint64_t dst = (uint64_t)gbase[b] + (p - (incl[cur][b] - cnt[b]));
+        const uint32_t dst = p + delta[k & (BINS - 1)];
         out_keys[dst] = k;
         out_vals[dst] = stage_v[p];
     }
 }
 
 // ---- 1c. the second level of the fused sort, in place of the library pass and the binary-search offsets ------------------------
-// After the first pass the pairs are grouped by their low MSM_P1_BITS key bits; inside a group a pair's final place is
+// After the first pass the pairs are grouped by their low BITS key bits; inside a group a pair's final place is
 // off[key] + (any rank among the pairs with the same key): no stability is needed, only the per-key counts.  Segments of at most
 // MSM_P2_SEG pairs of ONE group count the high key parts in LDS and add them to a global per-key histogram (gcount[key]: the low
 // part is the group); an exclusive scan of that histogram IS the bucket-offset array `off`; then the same segments reserve one run
 // per (segment, key) behind a global atomic and write the VALUES (the sorted keys are never materialised), LDS-staged so that a
 // run leaves the CU as consecutive addresses.  Any key distribution works (a group of any size is just more segments).
 // Measured at 12 x 2^24 pairs (tools/exp/partbench.hip variant C): 1.41 ms against the library pass + offsets kernel's 2.0 ms.
-constexpr uint32_t MSM_P2_HB = 2056;   // capacity for the high key parts: keys <= nb < 2^22 (the fused path's condition) -> at most 2048;
-                                        // the kernels loop over hb = (nb >> MSM_P1_BITS) + 1 of them (1025 for a table's 2^21 buckets)
+template <int BITS>
 __device__ __forceinline__ bool msm_p2_segment(const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ bin_off, uint32_t& bin,
                                                uint32_t& lo, uint32_t& hi) {
+    constexpr uint32_t BINS = 1u << BITS;
     const uint32_t sidx = blockIdx.x;
-    if (sidx >= seg_off[MSM_P1_BINS]) return false;
-    uint32_t l = 0, r = MSM_P1_BINS;   // the last bin with seg_off[bin] <= sidx
+    if (sidx >= seg_off[BINS]) return false;
+    uint32_t l = 0, r = BINS;   // the last bin with seg_off[bin] <= sidx
     while (r - l > 1) {
         const uint32_t mid = (l + r) >> 1;
         if (seg_off[mid] <= sidx) l = mid;
@@ -282,12 +318,13 @@ __device__ __forceinline__ bool msm_p2_segment(const uint32_t* __restrict__ seg_
     if (hi - lo > MSM_P2_SEG) hi = lo + MSM_P2_SEG;
     return true;
 }
+template <int BITS>
 static __global__ void __launch_bounds__(1024)
 msm_p2_count_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ bin_off,
                     uint32_t hb, uint32_t* __restrict__ gcount) {
     __shared__ uint32_t cnt[MSM_P2_HB];
     uint32_t bin, lo, hi;
-    if (!msm_p2_segment(seg_off, bin_off, bin, lo, hi)) return;   // (uniform per block)
+    if (!msm_p2_segment<BITS>(seg_off, bin_off, bin, lo, hi)) return;   // (uniform per block)
     for (uint32_t h = threadIdx.x; h < hb; h += blockDim.x) cnt[h] = 0;
     __syncthreads();
     constexpr int U = MSM_P2_SEG / 1024;
@@ -299,21 +336,22 @@ msm_p2_count_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restric
     }
 #pragma unroll
     for (int u = 0; u < U; u++)
-        if (kk[u] != 0xFFFFFFFFu) atomicAdd(&cnt[kk[u] >> MSM_P1_BITS], 1u);
+        if (kk[u] != 0xFFFFFFFFu) atomicAdd(&cnt[kk[u] >> BITS], 1u);
     __syncthreads();
     for (uint32_t h = threadIdx.x; h < hb; h += blockDim.x)
-        if (cnt[h]) atomicAdd(&gcount[(h << MSM_P1_BITS) | bin], cnt[h]);
+        if (cnt[h]) atomicAdd(&gcount[(h << BITS) | bin], cnt[h]);
 }
+template <int BITS>
 static __global__ void __launch_bounds__(1024)
 msm_p2_scatter_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ seg_off,
                       const uint32_t* __restrict__ bin_off, uint32_t hb, uint32_t* __restrict__ cursor, uint32_t* __restrict__ out_vals) {
     __shared__ uint32_t stage_v[MSM_P2_SEG];
     __shared__ uint16_t stage_h[MSM_P2_SEG];
-    __shared__ uint32_t cnt[MSM_P2_HB], incl[2][MSM_P2_HB], gb[MSM_P2_HB];
+    __shared__ uint32_t start[MSM_P2_HB + 1], delta[MSM_P2_HB], wtot[16];
     uint32_t bin, lo, hi;
-    if (!msm_p2_segment(seg_off, bin_off, bin, lo, hi)) return;
+    if (!msm_p2_segment<BITS>(seg_off, bin_off, bin, lo, hi)) return;
     const uint32_t t = threadIdx.x;
-    for (uint32_t h = t; h < hb; h += blockDim.x) cnt[h] = 0;
+    for (uint32_t h = t; h < hb; h += blockDim.x) start[h] = 0;
     __syncthreads();
     constexpr int U = MSM_P2_SEG / 1024;
     uint32_t kk[U], vv[U], rk[U];
@@ -325,30 +363,78 @@ msm_p2_scatter_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restr
     }
 #pragma unroll
     for (int u = 0; u < U; u++)
-        if (kk[u] != 0xFFFFFFFFu) rk[u] = atomicAdd(&cnt[kk[u] >> MSM_P1_BITS], 1u);
+        if (kk[u] != 0xFFFFFFFFu) rk[u] = atomicAdd(&start[kk[u] >> BITS], 1u);
     __syncthreads();
-    for (uint32_t h = t; h < hb; h += blockDim.x) incl[0][h] = cnt[h];
-    __syncthreads();
-    int cur = 0;
-    for (uint32_t d = 1; d < hb; d <<= 1) {
-        for (uint32_t h = t; h < hb; h += blockDim.x) incl[cur ^ 1][h] = incl[cur][h] + (h >= d ? incl[cur][h - d] : 0);
-        __syncthreads();
-        cur ^= 1;
+    msm_block_excl_scan_1024(start, hb, wtot);
+    for (uint32_t h = t; h < hb; h += blockDim.x) {
+        const uint32_t cnt = start[h + 1] - start[h];
+        delta[h] = cnt ? atomicAdd(&cursor[(h << BITS) | bin], cnt) - start[h] : 0;
     }
-    for (uint32_t h = t; h < hb; h += blockDim.x) gb[h] = cnt[h] ? atomicAdd(&cursor[(h << MSM_P1_BITS) | bin], cnt[h]) : 0;
 #pragma unroll
     for (int u = 0; u < U; u++)
         if (kk[u] != 0xFFFFFFFFu) {
-            const uint32_t h = kk[u] >> MSM_P1_BITS, at = incl[cur][h] - cnt[h] + rk[u];
+            const uint32_t h = kk[u] >> BITS, at = start[h] + rk[u];
             stage_v[at] = vv[u];
             stage_h[at] = (uint16_t)h;
         }
     __syncthreads();
     const uint32_t total = hi - lo;
-    for (uint32_t p = t; p < total; p += blockDim.x) {
-        const uint32_t h = stage_h[p];
-        out_vals[(uint64_t)gb[h] + (p - (incl[cur][h] - cnt[h]))] = stage_v[p];
+    for (uint32_t p = t; p < total; p += blockDim.x) out_vals[p + delta[stage_h[p]]] = stage_v[p];
+}
+
+// The fused sort of `batch` scalar vectors' (key, value) pairs: on return `off` holds the bucket offsets (nb + 2 entries) and vals2
+// the values grouped by key.  keys / vals: the first level's output (scratch).
+template <class FrP, int BITS>
+int msm_fused_sort(Ctx* ctx, const std::string& sfx, hipStream_t st, const void* d_scalars, size_t n, bool scalars_mont, int c, int nwin,
+                   int win_lo, int win_hi, bool table, int batch, uint32_t half, uint32_t nb, uint64_t m, uint32_t* keys, uint32_t* vals,
+                   uint32_t* vals2, uint32_t* off) {
+    constexpr uint32_t BINS = 1u << BITS;
+    auto key = [&](const char* k) { return std::string(k) + sfx; };
+    const int nwl = win_hi - win_lo;
+    uint32_t *ghist, *cursor, *bin_off, *seg_off, *gcount, *kcursor;
+    GA_CHECK(ctx->scratch_get(key("msm_p1_hist").c_str(), BINS * 4, (void**)&ghist));
+    GA_CHECK(ctx->scratch_get(key("msm_p1_cursor").c_str(), BINS * 4, (void**)&cursor));
+    GA_CHECK(ctx->scratch_get(key("msm_p1_bin_off").c_str(), (BINS + 1) * 4, (void**)&bin_off));
+    GA_CHECK(ctx->scratch_get(key("msm_p2_seg_off").c_str(), (BINS + 1) * 4, (void**)&seg_off));
+    const uint64_t nkeys = (((uint64_t)nb >> BITS) + 1) << BITS;   // >= nb + 1: every (high part, group) pair a key 0..nb can form
+    GA_CHECK(ctx->scratch_get(key("msm_p2_count").c_str(), nkeys * 4, (void**)&gcount));
+    GA_CHECK(ctx->scratch_get(key("msm_p2_cursor").c_str(), nkeys * 4, (void**)&kcursor));
+    auto vec = [&](int b) { return batch == 1 ? (const uint32_t*)d_scalars : reinterpret_cast<const uint32_t* const*>(d_scalars)[b]; };
+    {
+        StageTimer tm(ctx, "msm_digits_pass1", st);
+        const uint32_t tile = msm_p1_tile_scalars(nwl);
+        uint64_t hist_blocks = (n + 255) / 256;
+        if (hist_blocks > 2048) hist_blocks = 2048;
+        GA_HIP_CHECK(hipMemsetAsync(ghist, 0, BINS * 4, st));
+        for (int b = 0; b < batch; b++)   // (a batch: the vectors' bucket sets are stacked in ONE key space, key_base = b * 2^(c-1))
+            hipLaunchKernelGGL((msm_digit_hist_kernel<FrP, BITS>), dim3((unsigned)hist_blocks), dim3(256), 0, st, vec(b), (uint64_t)n,
+                               scalars_mont ? 1 : 0, c, nwin, win_lo, win_hi, table ? 1 : 0, (uint32_t)b * half, nb, ghist);
+        hipLaunchKernelGGL(msm_p1_scan_kernel<BITS>, dim3(1), dim3(1024), 0, st, (const uint32_t*)ghist, cursor, bin_off, seg_off);
+        for (int b = 0; b < batch; b++)
+            hipLaunchKernelGGL((msm_digits_pass1_kernel<FrP, BITS>), dim3((unsigned)((n + tile - 1) / tile)), dim3(MSM_P1_THREADS), 0, st, vec(b),
+                               (uint64_t)n, scalars_mont ? 1 : 0, c, nwin, win_lo, win_hi, table ? 1 : 0, (uint32_t)b * half, nb, tile, cursor, keys,
+                               vals);
+        GA_KERNEL_CHECK();
     }
+    {
+        StageTimer tm(ctx, "msm_sort", st);
+        const unsigned max_seg = (unsigned)(m / MSM_P2_SEG + BINS);
+        const uint32_t hb = (nb >> BITS) + 1;   // high parts of the keys 0..nb
+        GA_HIP_CHECK(hipMemsetAsync(gcount, 0, nkeys * 4, st));
+        hipLaunchKernelGGL(msm_p2_count_kernel<BITS>, dim3(max_seg), dim3(1024), 0, st, (const uint32_t*)keys, (const uint32_t*)seg_off,
+                           (const uint32_t*)bin_off, hb, gcount);
+        GA_KERNEL_CHECK();
+        size_t sb = 0;
+        void* stmp;
+        GA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, sb, gcount, off, (int)(nb + 1), st));
+        GA_CHECK(ctx->scratch_get(key("msm_p2_scan_tmp").c_str(), sb + 256, &stmp));
+        GA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(stmp, sb, gcount, off, (int)(nb + 1), st));   // off[b], b = 0..nb (nb = SKIP)
+        GA_HIP_CHECK(hipMemcpyAsync(kcursor, off, ((uint64_t)nb + 1) * 4, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(msm_p2_scatter_kernel<BITS>, dim3(max_seg), dim3(1024), 0, st, (const uint32_t*)keys, (const uint32_t*)vals,
+                           (const uint32_t*)seg_off, (const uint32_t*)bin_off, hb, kcursor, vals2);
+        GA_KERNEL_CHECK();
+    }
+    return GA_OK;
 }
 
 // ---- 3. bucket boundaries and tasks ---------------------------------------------------------------
@@ -447,6 +533,12 @@ struct Table29 {
     static constexpr int THREADS = (4 * NW * 4 * 256 <= 72 * 1024) ? 256 : 128;
 #endif
     static constexpr int MIN_WAVES = Lazy<F>::FP2 ? 2 : GA_ACC29_MINW;
+    // the next table entry is requested one addition ahead and parked in registers (accumulate_task29): for the kernels that run
+    // one or two waves per SIMD, where nothing else hides the gather's latency
+#ifndef GA_ACC_PREFETCH
+#define GA_ACC_PREFETCH 0   // A/B: 0 none, 1 the 14-limb fields (BLS12-381 G1, G2), 2 those and BN254 G2, 3 all
+#endif
+    static constexpr bool PREFETCH = GA_ACC_PREFETCH >= 3 || (GA_ACC_PREFETCH == 2 && (NW >= 14 || Lazy<F>::FP2)) || (GA_ACC_PREFETCH == 1 && NW >= 14);
 };
 
 // GA_ACC_REGS (A/B builds): 1 keeps the G1 accumulator in registers instead of LDS, 2 the Fp2 one as well -- measured in round 3
@@ -583,9 +675,45 @@ __device__ __forceinline__ bool accumulate_task29(const LdsAcc29<F>& A, const ui
     const T one = Lazy<F>::from_mem(FieldTraits<F>::one());
     bool have = false;
     uint32_t v = vals[start];
+    constexpr int NV = (int)(sizeof(Affine<F>) / 16);
+    ga_v4u ahead[Table29<F>::PREFETCH ? NV : 1];
+    uint32_t vn = v;
+    if constexpr (Table29<F>::PREFETCH) {
+        load16n_issue<NV>(table + (uint64_t)(v & ~MSM_SIGN) * Table29<F>::WORDS, ahead);
+        vn = start + 1 < end ? vals[start + 1] : v;
+    }
     for (uint32_t p = start; p < end; p++) {
-        const uint32_t vn = p + 1 < end ? vals[p + 1] : v;
         T qx, qy;
+        if constexpr (Table29<F>::PREFETCH) {
+            // entry p arrives (requested an addition ago), entry p + 1 is requested, index p + 2 is read
+            load16n_arrive<NV>(ahead);
+            Affine<F> a;
+#pragma unroll
+            for (int i = 0; i < NV; i++) memcpy(reinterpret_cast<char*>(&a) + 16 * i, &ahead[i], 16);
+            const uint32_t vnn = p + 2 < end ? vals[p + 2] : vn;
+            if (p + 1 < end) load16n_issue<NV>(table + (uint64_t)(vn & ~MSM_SIGN) * Table29<F>::WORDS, ahead);
+            qx = Lazy<F>::unpack(a.x);
+            qy = Lazy<F>::unpack(a.y);
+            const uint32_t vcur = v;
+            v = vn;
+            vn = vnn;
+            if (!(f29_is_zero_limbs(qx) & f29_is_zero_limbs(qy))) {
+                if (vcur & MSM_SIGN) qy = f29_sub<2>(Lazy<F>::from_mem(FieldTraits<F>::zero()), qy);   // 2p - y
+                if (!have) {
+                    A.put(0, qx);
+                    A.put(1, qy);
+                    A.put(2, one);
+                    A.put(3, one);
+                    have = true;
+                } else if constexpr (COMPLETE) {
+                    have = madd29_complete<F>(A, qx, qy);
+                } else {
+                    madd29<P>(A, qx, qy);
+                }
+            }
+            continue;
+        }
+        vn = p + 1 < end ? vals[p + 1] : v;
         load_point29<F>(table, v & ~MSM_SIGN, qx, qy);
         if (!(f29_is_zero_limbs(qx) & f29_is_zero_limbs(qy))) {   // (0,0) = infinity: skip
             if (v & MSM_SIGN) qy = f29_sub<2>(Lazy<F>::from_mem(FieldTraits<F>::zero()), qy);   // 2p - y
@@ -1237,51 +1365,14 @@ int msm_prepare(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, in
 
     int end_bit = 1;
     while ((1ull << end_bit) <= nb64) end_bit++;   // keys take values 0..nb (nb = SKIP)
-    // digits fused with the first sort pass: one vector of scalars, a key range that leaves ONE library pass above the low
-    // MSM_P1_BITS bits, at most MSM_P1_MAXW windows per scalar, enough pairs for the saved traffic to matter (GA_MSM_FUSE_MIN)
-    const bool fused = batch == 1 && end_bit > MSM_P1_BITS && end_bit <= 2 * MSM_P1_BITS && nwl <= MSM_P1_MAXW &&
-                       m >= ctx->tun.msm_fuse_min.load(std::memory_order_relaxed);
+    // digits fused with the first sort pass (1b / 1c): key spaces of 2^11 .. 2^24 keys, at most MSM_P1_MAXW windows per scalar, any
+    // number of scalar vectors over one table, enough pairs for the saved traffic to matter (GA_MSM_FUSE_MIN)
+    const bool fused = msm_fused_fits(nb64) && nwl <= MSM_P1_MAXW && m >= ctx->tun.msm_fuse_min.load(std::memory_order_relaxed);
     if (fused) {
-        uint32_t *ghist, *cursor, *bin_off, *seg_off, *gcount, *kcursor;
-        GA_CHECK(ctx->scratch_get(key("msm_p1_hist").c_str(), MSM_P1_BINS * 4, (void**)&ghist));
-        GA_CHECK(ctx->scratch_get(key("msm_p1_cursor").c_str(), MSM_P1_BINS * 4, (void**)&cursor));
-        GA_CHECK(ctx->scratch_get(key("msm_p1_bin_off").c_str(), (MSM_P1_BINS + 1) * 4, (void**)&bin_off));
-        GA_CHECK(ctx->scratch_get(key("msm_p2_seg_off").c_str(), (MSM_P1_BINS + 1) * 4, (void**)&seg_off));
-        const uint64_t nkeys = (((uint64_t)nb >> MSM_P1_BITS) + 1) << MSM_P1_BITS;   // >= nb + 1: every (high part, group) pair a key 0..nb can form
-        GA_CHECK(ctx->scratch_get(key("msm_p2_count").c_str(), nkeys * 4, (void**)&gcount));
-        GA_CHECK(ctx->scratch_get(key("msm_p2_cursor").c_str(), nkeys * 4, (void**)&kcursor));
-        {
-            StageTimer tm(ctx, "msm_digits_pass1", st);
-            const uint32_t tile = msm_p1_tile_scalars(nwl);
-            uint64_t hist_blocks = (n + 255) / 256;
-            if (hist_blocks > 2048) hist_blocks = 2048;
-            GA_HIP_CHECK(hipMemsetAsync(ghist, 0, MSM_P1_BINS * 4, st));
-            hipLaunchKernelGGL((msm_digit_hist_kernel<FrP>), dim3((unsigned)hist_blocks), dim3(256), 0, st, (const uint32_t*)d_scalars, (uint64_t)n,
-                               scalars_mont ? 1 : 0, c, nwin, win_lo, win_hi, table ? 1 : 0, 0u, (uint32_t)nb64, ghist);
-            hipLaunchKernelGGL(msm_p1_scan_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t*)ghist, cursor, bin_off, seg_off);
-            hipLaunchKernelGGL((msm_digits_pass1_kernel<FrP>), dim3((unsigned)((n + tile - 1) / tile)), dim3(MSM_P1_THREADS), 0, st,
-                               (const uint32_t*)d_scalars, (uint64_t)n, scalars_mont ? 1 : 0, c, nwin, win_lo, win_hi, table ? 1 : 0, 0u,
-                               (uint32_t)nb64, tile, cursor, keys, vals);
-            GA_KERNEL_CHECK();
-        }
-        {
-            StageTimer tm(ctx, "msm_sort", st);
-            const unsigned max_seg = (unsigned)(m / MSM_P2_SEG + MSM_P1_BINS);
-            const uint32_t hb = (nb >> MSM_P1_BITS) + 1;   // high parts of the keys 0..nb
-            GA_HIP_CHECK(hipMemsetAsync(gcount, 0, nkeys * 4, st));
-            hipLaunchKernelGGL(msm_p2_count_kernel, dim3(max_seg), dim3(1024), 0, st, (const uint32_t*)keys, (const uint32_t*)seg_off,
-                               (const uint32_t*)bin_off, hb, gcount);
-            GA_KERNEL_CHECK();
-            size_t sb = 0;
-            void* stmp;
-            GA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, sb, gcount, off, (int)(nb + 1), st));
-            GA_CHECK(ctx->scratch_get(key("msm_p2_scan_tmp").c_str(), sb + 256, &stmp));
-            GA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(stmp, sb, gcount, off, (int)(nb + 1), st));   // off[b], b = 0..nb (nb = SKIP)
-            GA_HIP_CHECK(hipMemcpyAsync(kcursor, off, ((uint64_t)nb + 1) * 4, hipMemcpyDeviceToDevice, st));
-            hipLaunchKernelGGL(msm_p2_scatter_kernel, dim3(max_seg), dim3(1024), 0, st, (const uint32_t*)keys, (const uint32_t*)vals,
-                               (const uint32_t*)seg_off, (const uint32_t*)bin_off, hb, kcursor, vals2);
-            GA_KERNEL_CHECK();
-        }
+        if (msm_p1_bits(nb64) == 11)
+            GA_CHECK((msm_fused_sort<FrP, 11>(ctx, sfx, st, d_scalars, n, scalars_mont, c, nwin, win_lo, win_hi, table, batch, half, nb, m, keys, vals, vals2, off)));
+        else
+            GA_CHECK((msm_fused_sort<FrP, 12>(ctx, sfx, st, d_scalars, n, scalars_mont, c, nwin, win_lo, win_hi, table, batch, half, nb, m, keys, vals, vals2, off)));
     } else {
         {
             StageTimer tm(ctx, "msm_digits", st);

@@ -226,8 +226,8 @@ inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     return hipSuccess;
 }
 inline hipError_t hipMemGetInfo(size_t* f, size_t* t) {
-    *f = 4ull << 30;
-    *t = 8ull << 30;
+    *f = 16ull << 30;
+    *t = 32ull << 30;
     return hipSuccess;
 }
 inline hipError_t hipMalloc(void** p, size_t n) {

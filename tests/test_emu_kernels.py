@@ -762,6 +762,49 @@ def test_emu_msm_fused_first_sort_pass(emu_ctx, c, group, monkeypatch, n=1300, t
             b.free()
 
 
+@pytest.mark.parametrize("table_c,batch", [(22, 3), (23, 3)], ids=["23-bit-keys-11-bit-level", "24-bit-keys-12-bit-level"])
+def test_emu_msm_fused_sort_wide_keys(emu_ctx, monkeypatch, table_c, batch, c=BN254, group=0, n=257):
+    """msm.hip.h 1b / 1c beyond 22 key bits and beyond one scalar vector (round 4): a batch of `batch` scalar vectors over one table
+    stacks its bucket sets in ONE key space -- 3 x 2^21 keys (PLONK's batched commitments: 23 key bits, 11-bit first level with 3073
+    high parts in the second) and 3 x 2^22 keys (24 key bits: the 12-bit first level).  Vectors: uniform; every scalar the same (all
+    pairs of a window share ONE key: one bin, one run, segments of a single key); zeros and ones (skip bucket + a hot bucket); r - 1.
+    The top window of a 254-bit scalar has 12 live bits at c = 22 (2^24 of 12 x 2^24 pairs in buckets 0..4095 at full size) -- inherent
+    in every vector here.  Fused == the library sort == [sum s_i k_i]G."""
+    ctx = emu_ctx
+    monkeypatch.setenv("GA_TABLE_C", str(table_c))
+    bases, dlogs, scal = _device_inputs(ctx, c, group, n, 0x57DE + table_c)
+    K = dlogs.to_host((n, 4))
+    mont = lambda v: np.array(pyref.to_mont_limbs(v, c.r, 4), dtype=np.uint64)
+    U = scal.to_host((n, 4))
+    same = np.tile(mont(0x1234567890ABCDEF1234567890ABCDEF % c.r), (n, 1))
+    zo = np.tile(mont(1), (n, 1))
+    zo[::3] = mont(0)
+    zo[5] = mont(c.r - 1)
+    vecs = [U, same, zo][:batch]
+    devs = [ctx.to_device(v) for v in vecs]
+    t = ecc.PrecomputedBases(ctx, c.name, group, bases, n=n)
+    try:
+        assert t.info()["window_bits"] == table_c
+        want = [_expect_from_dlogs(c, group, v, K) for v in vecs]
+        monkeypatch.setenv("GA_MSM_FUSE_MIN", str(1 << 40))
+        plain = t.MultiExpBatch(devs)
+        monkeypatch.setenv("GA_MSM_FUSE_MIN", "0")
+        ctx.profile(True)
+        ctx.profile_reset()
+        fused = t.MultiExpBatch(devs)
+        ctx.sync()
+        stages = [name for name, _ in ctx.profile_read()]
+        ctx.profile(False)
+        assert "msm_digits_pass1" in stages and "msm_digits" not in stages   # the fused path took the batch
+        for j in range(batch):
+            assert np.array_equal(oracle.jac_to_affine(c.cid, group, plain[j]), want[j]), j
+            assert np.array_equal(oracle.jac_to_affine(c.cid, group, fused[j]), want[j]), j
+    finally:
+        t.free()
+        for b in [bases, dlogs, scal] + devs:
+            b.free()
+
+
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
 @pytest.mark.parametrize("group", [0, 1], ids=["G1", "G2"])
 def test_emu_msm_vs_c_oracle_and_dlogs(emu_ctx, c, group, logn=11):

@@ -159,6 +159,33 @@ def test_msm_fused_first_sort_pass(gpu_ctx, monkeypatch, c, group, n, table_c):
     cases.test_emu_msm_fused_first_sort_pass(gpu_ctx, c, group, monkeypatch, n=n, table_c=table_c)
 
 
+@pytest.mark.parametrize("table_c,batch,n", [(22, 3, 1 << 20), (23, 3, (1 << 18) + 5)], ids=["23-bit-keys-2^20", "24-bit-keys-ragged"])
+def test_msm_fused_sort_wide_keys(gpu_ctx, monkeypatch, table_c, batch, n):
+    """the fused sort on 23- and 24-bit key spaces and batches of scalar vectors (PLONK's grouped commitments; the 12-bit first level):
+    uniform / all-equal / zero-one vectors, fused == library sort == known discrete logs"""
+    cases.test_emu_msm_fused_sort_wide_keys(gpu_ctx, monkeypatch, table_c, batch, n=n)
+
+
+def test_raw_msm_2_24_takes_the_fused_sort(gpu_ctx):
+    """a raw-bases (no table) BN254 G1 MSM of 2^24 points -- 13 windows x 2^19 buckets, 23 key bits -- runs on the fused sort since
+    round 4 (no library sort on any BASELINE path) and equals [sum s_i k_i]G"""
+    c, n = BN254, 1 << 24
+    bases, dlogs, scal = cases._device_inputs(gpu_ctx, c, 0, n, 0x24F5)
+    try:
+        gpu_ctx.profile(True)
+        gpu_ctx.profile_reset()
+        got = ecc.MultiExp(gpu_ctx, c.name, 0, bases, scal, n=n)
+        gpu_ctx.sync()
+        stages = [name for name, _ in gpu_ctx.profile_read()]
+        gpu_ctx.profile(False)
+        assert "msm_digits_pass1" in stages and "msm_digits" not in stages, stages
+        want = cases._expect_from_dlogs(c, 0, scal.to_host((n, 4)), dlogs.to_host((n, 4)))
+        assert np.array_equal(oracle.jac_to_affine(c.cid, 0, got), want)
+    finally:
+        for b in (bases, dlogs, scal):
+            b.free()
+
+
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
 @pytest.mark.parametrize("group", [0, 1], ids=["G1", "G2"])
 def test_msm_table_batch_2_18(gpu_ctx, c, group):

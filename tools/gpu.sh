@@ -1,0 +1,101 @@
+#!/bin/bash
+# One parameterised driver for everything that runs on the GPU box (replaces the per-batch gpu_r2_* / gpu_r3_* scripts).
+#   TAG=r04_a tools/gpu.sh <step> [<step> ...]        steps run in order; outputs go to gpurun_out/${TAG}_*
+# steps:
+#   tests[:<pytest -k expression>]   the -m gpu suite (or a selection)
+#   smoke                            __graft_entry__.smoke()
+#   bench[:<extra bench.py args>]    python bench.py -> ${TAG}_bench.json  (":--curve bls12-381" etc.; spaces as '+')
+#   bench2                           the --gpus 2 code path: two ranks share this box's GPU, collectives over gloo
+#   stats[:<bench args>]             rocprofv3 --kernel-trace --stats of a short bench -> ${TAG}_kernel_stats.txt
+#   hbm[:<bench args>]               FETCH_SIZE / WRITE_SIZE passes (separate, kernel-trace only) -> ${TAG}_pmc_{FETCH,WRITE}_SIZE.txt
+#   sq:<name>:<driver>               the SQ issue accounting + the wait split (LDS / VMEM / instruction cache) of <driver>:
+#                                    bench | bls (BLS12-381 G1+G2 table MSMs) | bn (BN254 ones) | ntt  -> ${TAG}_sq_<name>_{counters,summary}.txt
+#   ab:<name>:<parts>[:<curve>[:<variant>]]   tools/ab_kernels.py --parts <parts>, on gnark_amd/variants/libgnark_amd_<variant>.so when given
+#                                    (run-time knobs from the environment) -> ${TAG}_ab_<name>.json
+# Counter passes never combine --pmc with anything but --kernel-trace.
+TAG=${TAG:-r04}
+OUT=gpurun_out
+mkdir -p $OUT
+export TMPDIR=/tmp
+SHORT_BENCH="--steps 3 --warmup 1 --no-cpu-baseline --no-check --groth16-proofs 1 --no-pipelined --plonk-log-n 0 --no-bls --no-selftest"
+
+driver_cmd() {
+  case "$1" in
+    bench) echo "python bench.py $SHORT_BENCH" ;;
+    bls) echo "python tools/ab_kernels.py --parts msm --curve bls12-381 --reps 2" ;;
+    bn) echo "python tools/ab_kernels.py --parts msm --curve bn254 --reps 2" ;;
+    ntt) echo "python tools/ab_kernels.py --parts ntt --reps 2" ;;
+    *) echo "$1" ;;
+  esac
+}
+
+pmc_pass() {   # pmc_pass <outfile> <counters...> -- <cmd>
+  local outfile=$1; shift
+  local ctrs=()
+  while [ "$1" != "--" ]; do ctrs+=("$1"); shift; done
+  shift
+  local d=$OUT/pmc_tmp_$$
+  rm -rf $d
+  timeout 900 rocprofv3 --pmc "${ctrs[@]}" --kernel-trace -d $d -o p -- "$@" > $OUT/pmc_last.log 2>&1 || echo "rocprofv3 ${ctrs[*]} failed (see $OUT/pmc_last.log)"
+  python tools/prof_summary.py --pmc $d/p_results.db 2>/dev/null | grep -E "counter|accumulate29_kernel|reduce_groups29|ntt_pass29r4|msm_p2_|msm_digits_pass1|plonk_" | cut -c1-230 >> $outfile
+  rm -rf $d
+}
+
+for step in "$@"; do
+  name=${step%%:*}
+  arg=""; [ "$step" != "$name" ] && arg=${step#*:}
+  arg=${arg//+/ }
+  echo "=== $step"
+  case "$name" in
+    tests)
+      if [ -n "$arg" ]; then
+        (time timeout 2400 python -m pytest tests -q -m gpu -p no:cacheprovider -k "$arg" --durations=5) > $OUT/${TAG}_gpu_tests_selected.log 2>&1
+        tail -5 $OUT/${TAG}_gpu_tests_selected.log
+      else
+        (time timeout 3000 python -m pytest tests -q -m gpu -p no:cacheprovider --durations=8) > $OUT/${TAG}_full_gpu_suite.log 2>&1
+        tail -5 $OUT/${TAG}_full_gpu_suite.log
+      fi ;;
+    smoke)
+      python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE_OK')" 2>&1 | tail -2 ;;
+    bench)
+      sfx=$(echo "$arg" | tr -cd 'a-z0-9' | cut -c1-24)
+      (time timeout 2400 python bench.py $arg) > $OUT/${TAG}_bench${sfx:+_$sfx}.json 2> $OUT/${TAG}_bench${sfx:+_$sfx}.err
+      tail -4 $OUT/${TAG}_bench${sfx:+_$sfx}.err
+      python tools/bench_digest.py $OUT/${TAG}_bench${sfx:+_$sfx}.json ;;
+    bench2)
+      GA_BENCH_BACKEND=gloo timeout 1500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 \
+        bench.py --gpus 2 --steps 3 --warmup 1 $arg > $OUT/${TAG}_bench_2ranks_one_gpu_gloo.json 2> $OUT/${TAG}_bench_2ranks.err
+      tail -3 $OUT/${TAG}_bench_2ranks.err
+      python tools/bench_digest.py $OUT/${TAG}_bench_2ranks_one_gpu_gloo.json ;;
+    stats)
+      d=$OUT/stats_tmp_$$
+      timeout 900 rocprofv3 --kernel-trace --stats -d $d -o k -- python bench.py $SHORT_BENCH $arg > $OUT/${TAG}_stats.log 2>&1
+      python tools/prof_summary.py $d/k_results.db > $OUT/${TAG}_kernel_stats.txt 2>/dev/null
+      rm -rf $d
+      head -12 $OUT/${TAG}_kernel_stats.txt | cut -c1-200 ;;
+    hbm)
+      for ctr in FETCH_SIZE WRITE_SIZE; do
+        rm -f $OUT/${TAG}_pmc_${ctr}.txt
+        pmc_pass $OUT/${TAG}_pmc_${ctr}.txt $ctr -- python bench.py $SHORT_BENCH $arg
+        head -5 $OUT/${TAG}_pmc_${ctr}.txt | cut -c1-170
+      done ;;
+    sq)
+      nm=${arg%%:*}; drv=${arg#*:}
+      cmd=$(driver_cmd "$drv")
+      f=$OUT/${TAG}_sq_${nm}_counters.txt
+      rm -f $f
+      for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
+                 "SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" "SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_INST_LEVEL_VMEM" \
+                 "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH" "TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum"; do
+        pmc_pass $f $set -- $cmd
+      done
+      python tools/sq_summary.py $f > $OUT/${TAG}_sq_${nm}_summary.txt 2>&1
+      cat $OUT/${TAG}_sq_${nm}_summary.txt ;;
+    ab)
+      IFS=: read -r nm parts curve variant <<< "$arg"
+      libenv=""; [ -n "$variant" ] && libenv="GA_LIB_PATH=$PWD/gnark_amd/variants/libgnark_amd_${variant}.so"
+      env $libenv timeout 1200 python tools/ab_kernels.py --parts $parts --curve ${curve:-bn254} --tag $nm > $OUT/${TAG}_ab_${nm}.json 2> $OUT/${TAG}_ab_${nm}.err
+      tail -2 $OUT/${TAG}_ab_${nm}.err; cut -c1-1500 $OUT/${TAG}_ab_${nm}.json ;;
+    *) echo "unknown step $step" ;;
+  esac
+done
