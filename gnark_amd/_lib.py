@@ -143,6 +143,7 @@ _PROTOS = {
     "ga_fr_dot": (C.c_int, [_P, C.c_int, _P, _P, C.c_size_t, _P]),
     "ga_generator_mul": (C.c_int, [C.c_int, C.c_int, _P, _P]),
     "ga_microbench": (C.c_int, [_P, C.c_char_p, C.c_size_t]),
+    "ga_clock_probe": (C.c_int, [_P, C.c_uint32, C.POINTER(C.c_double)]),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOS)

@@ -913,6 +913,15 @@ int ga_generator_mul(int curve, int group, const void* k, void* out_jac) {
     return GA_OK;
 }
 
+int ga_clock_probe(ga_ctx* h, uint32_t micros, double* mhz_out) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    if (!c || !mhz_out || micros == 0) {
+        set_error("ga_clock_probe: bad argument");
+        return GA_ERR_INVALID;
+    }
+    return util_clock_probe(c, micros, mhz_out);   // (no context lock: it is meant to run BESIDE whatever holds it)
+}
+
 int ga_microbench(ga_ctx* h, char* buf, size_t cap) {
     Ctx* c = reinterpret_cast<Ctx*>(h);
     Lock l(c);

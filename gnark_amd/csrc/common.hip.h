@@ -365,6 +365,7 @@ template <class C> int util_fr_dot(Ctx* ctx, const void* d_a, const void* d_b, s
 template <class C> int util_fr_vec_mul(Ctx* ctx, const void* d_a, const void* d_b, size_t n, void* d_out);
 template <class C> int util_gather_fr(Ctx* ctx, void* d_dst, const void* d_src, const uint32_t* d_idx, size_t n);
 int util_microbench(Ctx* ctx, char* buf, size_t cap);
+int util_clock_probe(Ctx* ctx, uint32_t micros, double* mhz_out);
 
 #define GA_DISPATCH_CURVE(curve, ...)                                \
     switch (curve) {                                                 \

@@ -144,6 +144,48 @@ static int run_one(Ctx* ctx, const char* name, K kernel, double ops_per_thread, 
     return GA_OK;
 }
 
+// One wave that watches the clocks for `ticks` ticks of the constant-rate counter (wall_clock64: 100 MHz): how many shader cycles
+// (clock64 = s_memtime) went by.  Launched on a stream of its own beside whatever else the device is running, it reports the clock the
+// chip HOLDS under that load -- the bucket kernels run for seconds of a proof stream, not for the milliseconds of a microbenchmark.
+__global__ void __launch_bounds__(64) mb_clock_probe(uint64_t ticks, uint64_t* out) {
+    const uint64_t w0 = wall_clock64(), c0 = clock64();
+    uint64_t w = w0;
+    while (w - w0 < ticks) {
+        __builtin_amdgcn_s_sleep(32);
+        w = wall_clock64();
+    }
+    if (threadIdx.x == 0) {
+        out[0] = clock64() - c0;
+        out[1] = w - w0;
+    }
+}
+
+int util_clock_probe(Ctx* ctx, uint32_t micros, double* mhz_out) {
+    hipSetDevice(ctx->device);
+    hipStream_t st;
+    GA_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    uint64_t *d_out = nullptr, h_out[2] = {0, 0};
+    hipError_t e = hipMalloc(&d_out, 16);
+    if (e != hipSuccess) {
+        hipStreamDestroy(st);
+        set_error("ga_clock_probe: hipMalloc failed");
+        return GA_ERR_NOMEM;
+    }
+    int wall_khz = 100000;
+    (void)hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, ctx->device);
+    hipLaunchKernelGGL(mb_clock_probe, dim3(1), dim3(64), 0, st, (uint64_t)micros * (uint64_t)wall_khz / 1000ull, d_out);
+    e = hipMemcpyAsync(h_out, d_out, 16, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    hipFree(d_out);
+    hipStreamDestroy(st);
+    if (e != hipSuccess || h_out[1] == 0) {
+        set_error("ga_clock_probe failed: %s", hipGetErrorString(e));
+        return GA_ERR_HIP;
+    }
+    *mhz_out = (double)h_out[0] / (double)h_out[1] * (double)wall_khz / 1000.0;
+    return GA_OK;
+}
+
 int util_microbench(Ctx* ctx, char* buf, size_t cap) {
     uint32_t* d_out;
     GA_CHECK(ctx->scratch_get("microbench", 4096, (void**)&d_out));

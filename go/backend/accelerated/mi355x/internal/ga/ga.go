@@ -325,6 +325,13 @@ func (pk *ProvingKey) Free() {
 }
 
 // ---- MSM / NTT (PLONK) -------------------------------------------------------------------------------------------
+//
+// Every MSM entry point returns A Jacobian representative of the sum, not a canonical one: the order in which a bucket's points
+// are added comes from atomics in the fused sort, so X, Y, Z of two calls on the same inputs may differ by a common scaling while
+// the point is the same (include/gnark_amd.h, ga_msm).  gnark-crypto's MultiExp is deterministic for a fixed NbTasks; code on this
+// side must therefore never compare, hash or serialise the Jacobian limbs of a result -- convert with FromJacobian (or compare with
+// G1Jac.Equal / G2Jac.Equal) first, as the provers in ../../groth16 and ../../plonk do.  tests/test_abi_surface.py checks the shim
+// for `==` / `!=` on Jacobian values.
 
 // MSM computes sum scalars[i]*bases[i] into a Jacobian point (G1Jac / G2Jac image).
 func (c *Context) MSM(curve Curve, group int, bases, scalars unsafe.Pointer, n uint64, flags uint, outJac unsafe.Pointer) error {

@@ -427,6 +427,10 @@ int ga_generator_mul(int curve, int group, const void* k_canonical_le32, void* o
 /* integer-multiplier / FMA issue-rate microbenchmarks (SURVEY 8d asks for the v_mad_u64_u32 rate);
  * writes "name=Gops;..." */
 int ga_microbench(ga_ctx* ctx, char* buf, size_t cap);
+/* the shader clock the device holds right now, in MHz: one wave on a stream of its own compares the shader cycle counter with the
+ * constant-rate one for `micros` microseconds.  Takes no context lock -- call it from a second thread while the load of interest runs
+ * (tools/clock_probe.py: the bucket kernels run below the clock short microbenchmarks see). */
+int ga_clock_probe(ga_ctx* ctx, uint32_t micros, double* mhz_out);
 
 #ifdef __cplusplus
 }

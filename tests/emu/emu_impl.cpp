@@ -192,4 +192,8 @@ int util_microbench(Ctx*, char* buf, size_t cap) {
     snprintf(buf, cap, "emulation=1;");
     return 0;
 }
+int util_clock_probe(Ctx*, uint32_t, double* mhz_out) {
+    *mhz_out = 0.0;   // no shader clock under the emulation
+    return 0;
+}
 }  // namespace ga

@@ -144,3 +144,54 @@ def test_go_shim_identifiers_resolve():
     assert r.returncode == 0, r.stdout[-3000:]
     fresh = json.load(open(out))
     assert fresh["resolved"] == table["resolved"], "go/IDENTS.json is stale: run python tools/check_go_idents.py --json go/IDENTS.json"
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12-381"])
+def test_groth16_randomness_hook_patch_applies_to_the_reference(tmp_path, curve):
+    """go/backend/accelerated/mi355x/internal/fixtures/groth16_rs_<curve>.patch -- the test-only hook that lets gnark's own CPU prover
+    take (r, s) and show its solution, so that gen_fixtures_test.go can write golden directories (tests/gnark_fixture.py) -- applies
+    cleanly to backend/groth16/<curve>/prove.go: the lines it names (prove.go:105,171-177) exist as quoted"""
+    import shutil
+    import subprocess
+    ref = "/root/reference/backend/groth16/%s/prove.go" % curve
+    if not os.path.exists(ref):
+        pytest.skip("reference tree not present on this box")
+    dst = tmp_path / "backend" / "groth16" / curve
+    dst.mkdir(parents=True)
+    shutil.copy(ref, dst / "prove.go")
+    fx = os.path.join(ROOT, "go", "backend", "accelerated", "mi355x", "internal", "fixtures")
+    patch = os.path.join(fx, "groth16_rs_%s.patch" % curve)
+    r = subprocess.run(["patch", "-p1", "--dry-run", "-i", patch], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0 and "FAILED" not in r.stdout, r.stdout + r.stderr
+    src = open(patch).read()
+    assert "TestingHooks.Randomness" in src and "TestingHooks.Solution(solution)" in src and "SetRandom" in src
+    gen = open(os.path.join(fx, "gen_fixtures_test.go")).read()
+    for name in ("meta.json", "pk.bin", "solution.bin", "r.bin", "s.bin", "proof.bin", "proof.raw"):   # the layout tests/gnark_fixture.py reads
+        assert '"%s"' % name in gen, name
+    import gnark_fixture
+    assert all(k in gen for k in ("private_committed", "public_and_commitment_committed", "commitment_index", "nb_public", "curve"))
+    assert gnark_fixture.run_case.__doc__
+
+
+def test_go_shim_never_compares_jacobian_limbs():
+    """ga_msm* return A Jacobian representative of the sum (include/gnark_amd.h): nothing in the Go shim may compare two Jacobian
+    values with == / != (or use them as map keys): results go through FromJacobian / Equal.  Textual check of go/**: every identifier
+    declared with a G1Jac / G2Jac type, and no comparison operator next to it."""
+    import re
+    bad = []
+    for d, _, fs in os.walk(os.path.join(ROOT, "go")):
+        for f in fs:
+            if not f.endswith(".go"):
+                continue
+            src = open(os.path.join(d, f)).read()
+            code = re.sub(r"//[^\n]*", "", src)
+            names = set(re.findall(r"\bvar\s+(\w+)(?:\s*,\s*\w+)*\s+\w*\.?G[12]Jac\b", code)) | set(re.findall(r"\b(\w+)\s*:=\s*\w*\.?G[12]Jac\{", code))
+            for m in re.finditer(r"\bvar\s+((?:\w+\s*,\s*)+\w+)\s+\w*\.?G[12]Jac\b", code):
+                names |= set(x.strip() for x in m.group(1).split(","))
+            for nm in names:
+                if re.search(r"\b%s\s*(==|!=)|(==|!=)\s*&?%s\b" % (nm, nm), code):
+                    bad.append((f, nm))
+            assert not re.search(r"map\[\w*\.?G[12]Jac\]", code), f
+    assert not bad, bad
+    ga = open(os.path.join(ROOT, "go", "backend", "accelerated", "mi355x", "internal", "ga", "ga.go")).read()
+    assert "never compare, hash or serialise the Jacobian limbs" in ga

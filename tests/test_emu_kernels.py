@@ -1,5 +1,7 @@
 """Kernel-logic checks of the product sources under the functional HIP emulation (tests/emu), against the
 big-integer oracle.  These run on CPU (`-m "not gpu"`); the same cases run on the real GPU in test_gpu_*.py."""
+import os
+
 import numpy as np
 import pytest
 
@@ -1574,3 +1576,26 @@ def test_emu_chunked_sharded_key_generation(emu_ctx):
     lib.check(lib.ga_g16_builder_append(b, 0, None, 50))            # points [0, 50): shard 1 of 2 keeps [50, 100)
     assert lib.ga_g16_builder_append(b, 0, None, 10) != 0 and b"null pointer" in lib.ga_last_error()
     lib.ga_g16_builder_destroy(b)
+
+
+def test_emu_gnark_fixture_directories(emu_ctx, tmp_path):
+    """tests/gnark_fixture.py: case directories in the layout gen_fixtures_test.go writes from a gnark checkout (pk.WriteRawTo bytes,
+    R1CSSolution.WriteTo bytes, r, s, gnark's proof bytes) proved through ga_g16_pk_read_mem -> ga_g16_prove (+ ga_g16_commit /
+    ga_g16_fold_pok) and compared byte for byte.  No Go toolchain exists here, so the directories of this test come from the oracle in
+    the same layout (examples/cubic and the two-commitment circuit, both curves); directories under tests/golden/gnark/ -- the real
+    thing, once a box with Go has produced them -- are consumed the same way."""
+    import gnark_fixture
+    ctx = emu_ctx
+    cases_ = gnark_fixture.oracle_cases(str(tmp_path)) + gnark_fixture.case_dirs(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gnark"))
+    assert len(cases_) >= 4
+    for d in cases_:
+        for precompute in (-1, 1):
+            got, got_raw, want, want_raw = gnark_fixture.run_case(ctx, d, precompute=precompute)
+            assert got == want, d
+            assert want_raw is None or got_raw == want_raw, d
+    # the parsers refuse damaged inputs instead of proving something else
+    c = pyref.BN254
+    good = open(os.path.join(cases_[0], "solution.bin"), "rb").read()
+    for bad in (good[:-1], good + b"\0", good[:4] + b"\xff" * 32 + good[36:]):
+        with pytest.raises(ValueError):
+            gnark_fixture.parse_solution(c, bad)

@@ -919,3 +919,10 @@ def test_rccl_collectives_and_sharded_proof_on_one_gpu():
     assert d["collectives"]["backend"] == "nccl" and d["collectives"]["device_tensors"] is True
     assert all(d["collectives"][k] is True for k in ("all_gather", "gather", "scatter", "broadcast", "all_reduce"))
     assert d["sharded_proof_same_bytes"] is True and d["msm_all_gather"] is True and d["constraints"] == 1 << 16
+
+
+def test_gnark_fixture_directories(gpu_ctx, tmp_path):
+    """golden directories in gnark's own formats (tests/gnark_fixture.py; go/.../internal/fixtures/gen_fixtures_test.go writes them from a
+    gnark checkout with the groth16_rs.patch hook): key bytes -> HBM, solution -> proof, proof BYTES == the directory's.  Consumes
+    tests/golden/gnark/* when present (none yet: no Go toolchain) and the same layout written by the oracle."""
+    cases.test_emu_gnark_fixture_directories(gpu_ctx, tmp_path)

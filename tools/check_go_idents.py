@@ -30,11 +30,12 @@ SHIM_PREFIX = "backend/accelerated/mi355x"
 
 STDLIB = {
     "fmt": {"Errorf", "Sprintf", "Println", "Printf", "Sprint", "Fprintf"}, "errors": {"New", "Is", "As"},
-    "os": {"Open", "File", "Getenv", "Create", "Remove", "CreateTemp", "ReadFile", "WriteFile"}, "slices": {"Equal", "Clone", "Concat", "Sort", "Compact", "Contains"},
+    "os": {"Open", "File", "Getenv", "Create", "Remove", "CreateTemp", "ReadFile", "WriteFile", "MkdirAll"}, "slices": {"Equal", "Clone", "Concat", "Sort", "Compact", "Contains"},
     "sync": {"Mutex", "RWMutex", "Once", "WaitGroup"}, "time": {"Now", "Since", "Duration"}, "unsafe": {"Pointer", "Sizeof", "SliceData", "Slice", "Add"},
     "runtime": {"Pinner", "KeepAlive", "LockOSThread", "UnlockOSThread", "NumCPU"}, "math/big": {"Int", "NewInt"}, "io": {"Reader", "Writer", "ReaderFrom", "WriterTo"},
     "bytes": {"Buffer", "NewReader", "Equal"}, "testing": {"T", "B", "Short"}, "math/bits": {"Len64", "TrailingZeros64"}, "hash": {"Hash"},
     "context": {"Context", "Background"}, "strings": {"Join", "Split", "HasPrefix"}, "sort": {"Slice", "Ints"}, "path/filepath": {"Join"},
+    "encoding/json": {"MarshalIndent", "Marshal"},
     "crypto/sha256": {"New", "Sum256"}, "encoding/binary": {"BigEndian", "LittleEndian", "Write", "Read"},
 }
 CGO_BUILTINS = {"int", "uint", "uint32_t", "uint64_t", "int32_t", "size_t", "char", "uchar", "GoString", "CString", "free", "malloc", "calloc", "GoBytes",
@@ -119,6 +120,26 @@ def declared_in(dirpath):
     return names
 
 
+def declared_by_patches():
+    """exported identifiers ADDED to a reference package by a patch shipped under go/** (prove.patch: the PLONK Accelerator hooks;
+    internal/fixtures/groth16_rs_*.patch: the test-only TestingHooks of the Groth16 prover): package dir -> {ident: patch}"""
+    out = {}
+    for d, _, fs in os.walk(os.path.join(ROOT, "go")):
+        for f in fs:
+            if not f.endswith(".patch"):
+                continue
+            pkg = None
+            for line in open(os.path.join(d, f)):
+                if line.startswith("+++ "):
+                    m = re.match(r"\+\+\+ [ab]/(\S+)", line)
+                    pkg = os.path.dirname(m.group(1)) if m else None
+                elif pkg and line.startswith("+") and not line.startswith("+++"):
+                    m = re.match(r"\+(?:func|type|var|const)\s+([A-Z]\w*)\b", line)
+                    if m:
+                        out.setdefault(pkg, {})[m.group(1)] = os.path.relpath(os.path.join(d, f), ROOT)
+    return out
+
+
 _REF_USE_CACHE = {}
 
 
@@ -185,6 +206,7 @@ def main():
         print("reference tree not present at %s: nothing to resolve against" % REF)
         return 2
     protos, defines, ctypes = header_symbols()
+    patched = declared_by_patches()
     table, bad = [], []
     for f in sorted(go_files(os.path.join(ROOT, "go"))):
         raw = open(f).read()
@@ -219,6 +241,8 @@ def main():
                     d = os.path.join(ROOT, "go", pkg) if pkg.startswith(SHIM_PREFIX) else os.path.join(REF, pkg)
                     if ident in declared_in(d):
                         table.append((rel, "%s.%s" % (alias, ident), "declared in %s" % os.path.relpath(d, "/")))
+                    elif ident in patched.get(pkg, {}):
+                        table.append((rel, "%s.%s" % (alias, ident), "added to %s by %s" % (pkg, patched[pkg][ident])))
                     else:
                         bad.append((rel, "%s.%s" % (alias, ident), "not declared in %s" % d))
                 elif path.startswith(CRYPTO):

@@ -4,6 +4,7 @@
 # steps:
 #   tests[:<pytest -k expression>]   the -m gpu suite (or a selection)
 #   smoke                            __graft_entry__.smoke()
+#   micro                            ga_microbench: instruction issue rates (burst and sustained), dependency distance x occupancy
 #   bench[:<extra bench.py args>]    python bench.py -> ${TAG}_bench.json  (":--curve bls12-381" etc.; spaces as '+')
 #   bench2                           the --gpus 2 code path: two ranks share this box's GPU, collectives over gloo
 #   stats[:<bench args>]             rocprofv3 --kernel-trace --stats of a short bench -> ${TAG}_kernel_stats.txt
@@ -57,6 +58,9 @@ for step in "$@"; do
       fi ;;
     smoke)
       python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE_OK')" 2>&1 | tail -2 ;;
+    micro)
+      python -c "import gnark_amd, json; ctx = gnark_amd.Context(0); print(json.dumps(ctx.microbench()))" > $OUT/${TAG}_microbench.json 2> $OUT/${TAG}_microbench.err
+      tail -2 $OUT/${TAG}_microbench.err; cat $OUT/${TAG}_microbench.json ;;
     bench)
       sfx=$(echo "$arg" | tr -cd 'a-z0-9' | cut -c1-24)
       (time timeout 2400 python bench.py $arg) > $OUT/${TAG}_bench${sfx:+_$sfx}.json 2> $OUT/${TAG}_bench${sfx:+_$sfx}.err
