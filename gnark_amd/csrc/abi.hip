@@ -115,6 +115,8 @@ void Tunables::read_env() {
     put(g16_lanes, (int)num("GA_G16_LANES", 2));
     put(g16_split, (int)num("GA_G16_SPLIT", 1));
     put(ntt_coset_fold, (int)num("GA_NTT_COSET_FOLD", 1));
+    put(ntt_wave_local, (int)num("GA_NTT_WAVE_LOCAL", 1));
+    put(ntt_direct, (int)num("GA_NTT_DIRECT", 1));
     put(table_c, (int)num("GA_TABLE_C", 0));
     put(msm_exact_redo, (int)num("GA_MSM_EXACT_REDO", 0));
     put64(msm_fuse_min, num("GA_MSM_FUSE_MIN", 1ull << 25));

@@ -19,6 +19,20 @@
 
 namespace ga {
 
+// Rendezvous of the lanes of ONE wave around LDS traffic among themselves: a wave's LDS instructions are served in issue order, so
+// a ds_write by one lane is visible to a later ds_read of another lane of the same wave without an s_barrier; what is needed is
+// that the compiler keeps the two sides in program order (the fences emit no instruction).  The functional emulation runs lanes as
+// fibers and has them meet for real.
+__device__ __forceinline__ void wave_lds_sync() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#elif defined(GA_HIP_EMULATION)
+    hipemu::wave_barrier();
+#endif
+}
+
 // ---- errors --------------------------------------------------------------------------------------
 void set_error(const char* fmt, ...);
 const char* get_error();
@@ -103,6 +117,8 @@ struct StageRec {
 //   GA_G16_LANES          1: a second concurrent ga_g16_prove caller queues for the device instead of proving on its own lanes
 //   GA_G16_SPLIT          0: a proof keeps its H side (computeH, Z MSM) on the lane of its witness MSMs instead of a partner lane
 //   GA_NTT_COSET_FOLD     0: coset FFTs scale their input by the coset powers (round 2) instead of running over a coset twiddle table
+//   GA_NTT_WAVE_LOCAL     0: every round of an NTT pass ends in a workgroup barrier (round 3) instead of wave-local exchanges
+//   GA_NTT_DIRECT         0: the first / last round of an NTT pass goes through LDS instead of moving its quads to / from HBM itself
 // (GA_HBM_RESERVE_MB is read once per process by device_malloc: see there.)
 // The fields are relaxed atomics: the entry point that holds lane 0 refreshes them while provers on the other lanes read them.
 struct Tunables {
@@ -112,6 +128,8 @@ struct Tunables {
     std::atomic<int> g16_lanes{2};
     std::atomic<int> g16_split{1};
     std::atomic<int> ntt_coset_fold{1};
+    std::atomic<int> ntt_wave_local{1};
+    std::atomic<int> ntt_direct{1};
     std::atomic<int> table_c{0};
     std::atomic<uint64_t> msm_min_seg{256};
     std::atomic<int> msm_exact_redo{0};

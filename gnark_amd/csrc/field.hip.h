@@ -268,19 +268,13 @@ GA_HD_BIG Fe<P> mul_body(const Fe<P>& a, const Fe<P>& b) {
 template <class P>
 GA_HD_CALL Fe<P> mul_call(const Fe<P>& a, const Fe<P>& b) { return mul_body(a, b); }
 
-// by-value variant: operands and result travel in VGPRs (AMDGPU calling convention), no memory traffic.  Used by the
-// 12-limb field inside hot loops when enabled: a fully inlined BLS12-381 point addition is ~200 KB of code, beyond
-// the 64 KB instruction cache.
-#ifndef GA_BIGFIELD_CALLS
-#define GA_BIGFIELD_CALLS 0   // measured on MI355X: calls cost 20-25 % (BLS12-381 G1 accumulate 42 -> 51 ms); kept for experiments
-#endif
+// by-value variant: operands and result travel in VGPRs (AMDGPU calling convention), no memory traffic: the cold PLONK passes
+// call it (one shared copy per field).  The hot loops inline their products (out-of-line products for the 12-limb field there
+// measured -20..25 %, BLS12-381 G1 accumulate 42 -> 51 ms, round 1).
 template <class P>
 GA_HD_CALL Fe<P> mul_val(Fe<P> a, Fe<P> b) { return mul_body(a, b); }
 template <class P>
-GA_HD Fe<P> mul_hot(const Fe<P>& a, const Fe<P>& b) {
-    if constexpr (P::N > 8 && GA_BIGFIELD_CALLS) return mul_val(a, b);
-    else return mul_body(a, b);
-}
+GA_HD Fe<P> mul_hot(const Fe<P>& a, const Fe<P>& b) { return mul_body(a, b); }
 
 // 8-limb fields (BN254 Fp/Fr, BLS12-381 Fr): inlined.  12-limb BLS12-381 Fp: one shared out-of-line copy.
 template <class P>
@@ -370,21 +364,6 @@ GA_HD void load16n(const void* p, ga_v4u (&v)[NV]) {
     const ga_v4u* q = reinterpret_cast<const ga_v4u*>(p);
 #pragma unroll
     for (int i = 0; i < NV; i++) v[i] = q[i];
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-    for (int i = 0; i < NV; i++) asm volatile("" : "+v"(v[i]));
-#endif
-}
-// the two halves of load16n for software-pipelined loops: issue the loads now, make the values opaque (= wait for them) at the point
-// of use an iteration later -- the asm still separates the loads from the limb extraction, so they stay 16-byte loads
-template <int NV>
-GA_HD void load16n_issue(const void* p, ga_v4u (&v)[NV]) {
-    const ga_v4u* q = reinterpret_cast<const ga_v4u*>(p);
-#pragma unroll
-    for (int i = 0; i < NV; i++) v[i] = q[i];
-}
-template <int NV>
-GA_HD void load16n_arrive(ga_v4u (&v)[NV]) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
     for (int i = 0; i < NV; i++) asm volatile("" : "+v"(v[i]));

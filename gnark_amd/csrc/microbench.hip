@@ -74,6 +74,71 @@ __global__ void __launch_bounds__(256) mb_mad_chain(uint32_t* out, uint32_t seed
     if (r == 0x12345u) out[threadIdx.x] = r;
 }
 
+// Round 4: what a multiply-add costs INSIDE a product.  64 multiply-adds per loop trip (the branch of the 16-per-trip kernels above is
+// ~5 % of their time), eight independent accumulators, in the variants a Montgomery product is made of:
+//   0 all operands in VGPRs, carry-out to vcc            1 carry-out alternating between two SGPR pairs
+//   2 one multiplicand in an SGPR (a modulus limb)        3 as 0 with a 64-bit shift + 64-bit add after every 8 multiply-adds (a column's carry)
+//   4 as 3 with v_mul_lo_u32 + v_and_b32 as well (a whole reduction row: 9 MAD + mul_lo + and + shift + add)
+template <int VARIANT>
+__global__ void __launch_bounds__(256) mb_mad_mix(uint32_t* out, uint32_t seed) {
+    uint64_t a[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) a[k] = seed + threadIdx.x + k;
+    uint32_t x = seed | 1u, y = (seed >> 3) | 1u, m = seed ^ 0x5555u;
+    const uint32_t sy = __builtin_amdgcn_readfirstlane(y);
+    for (int it = 0; it < MB_ITERS / 4; it++) {
+#pragma unroll
+        for (int k = 0; k < 64; k++) {
+            if (VARIANT == 1) {
+                if (k & 1) asm volatile("v_mad_u64_u32 %0, s[10:11], %1, %2, %0" : "+v"(a[k % 8]) : "v"(x), "v"(y) : "s10", "s11");
+                else asm volatile("v_mad_u64_u32 %0, s[12:13], %1, %2, %0" : "+v"(a[k % 8]) : "v"(x), "v"(y) : "s12", "s13");
+            } else if (VARIANT == 2) {
+                asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(a[k % 8]) : "v"(x), "s"(sy) : "vcc");
+            } else {
+                asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(a[k % 8]) : "v"(m), "v"(y) : "vcc");
+                if (VARIANT >= 3 && (k % 8) == 7) {
+                    const int j = (k / 8) % 8;
+                    if (VARIANT == 4) {
+                        asm volatile("v_mul_lo_u32 %0, %1, %2" : "=v"(m) : "v"((uint32_t)a[j]), "v"(x));
+                        asm volatile("v_and_b32 %0, 0x1fffffff, %0" : "+v"(m));
+                    }
+                    uint64_t c;
+                    asm volatile("v_lshrrev_b64 %0, 29, %1" : "=v"(c) : "v"(a[j]));
+                    asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(a[(j + 1) % 8]) : "v"(c));
+                }
+            }
+        }
+    }
+    uint32_t r = m;
+#pragma unroll
+    for (int k = 0; k < 8; k++) r += (uint32_t)a[k];
+    if (r == 0x12345u) out[threadIdx.x] = r;
+}
+
+// K independent Montgomery products per lane and trip (K = 1: the dependent chain of mb_f29_mul): how much of a product's cost
+// is waiting for its own carries
+template <class P, int K>
+__global__ void __launch_bounds__(256) mb_f29_mul_ilp(uint32_t* out, uint32_t seed) {
+    F29<P> a[K], b[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        a[k] = f29_from_mem(fe_const<P>(P::R2));
+        b[k] = f29_from_mem(fe_one<P>());
+        a[k].l[0] ^= (seed + threadIdx.x + k) & 0xFFFF;
+        b[k].l[1] ^= (seed + 3 * k) & 0xFFFF;
+    }
+    for (int it = 0; it < MB_ITERS / 8; it++) {
+#pragma unroll
+        for (int k = 0; k < K; k++) a[k] = f29_mul(a[k], b[k]);
+#pragma unroll
+        for (int k = 0; k < K; k++) b[k] = f29_mul(b[k], a[k]);
+    }
+    uint32_t r = 0;
+#pragma unroll
+    for (int k = 0; k < K; k++) r += a[k].l[0] + b[k].l[0];
+    if (r == 0x12345u) out[threadIdx.x] = r;
+}
+
 template <class P>
 __global__ void __launch_bounds__(256) mb_field_mul(uint32_t* out, uint32_t seed) {
     Fe<P> a = fe_const<P>(P::R2), b = fe_one<P>();
@@ -214,6 +279,15 @@ int util_microbench(Ctx* ctx, char* buf, size_t cap) {
     GA_CHECK(run_one(ctx, "mad_dist1_one_wave_per_simd_Gops", mb_mad_chain<1, ONE_WG>, n16, out, d_out));
     GA_CHECK(run_one(ctx, "mad_dist2_one_wave_per_simd_Gops", mb_mad_chain<2, ONE_WG>, n16, out, d_out));
     GA_CHECK(run_one(ctx, "mad_dist8_one_wave_per_simd_Gops", mb_mad_chain<8, ONE_WG>, n16, out, d_out));
+    const double n64 = 64.0 * (MB_ITERS / 4);
+    GA_CHECK(run_one(ctx, "mad64_unroll64_Gops", mb_mad_mix<0>, n64, out, d_out, 20));
+    GA_CHECK(run_one(ctx, "mad64_two_sdst_Gops", mb_mad_mix<1>, n64, out, d_out, 20));
+    GA_CHECK(run_one(ctx, "mad64_sgpr_operand_Gops", mb_mad_mix<2>, n64, out, d_out, 20));
+    GA_CHECK(run_one(ctx, "mad64_with_carry_per8_Gmad", mb_mad_mix<3>, n64, out, d_out, 20));
+    GA_CHECK(run_one(ctx, "mad64_reduction_row_Gmad", mb_mad_mix<4>, n64, out, d_out, 20));
+    GA_CHECK(run_one(ctx, "f29mul_bn254_ilp1_Gmul", (mb_f29_mul_ilp<BN254_Fp, 1>), 2.0 * (MB_ITERS / 8), out, d_out, 20));
+    GA_CHECK(run_one(ctx, "f29mul_bn254_ilp2_Gmul", (mb_f29_mul_ilp<BN254_Fp, 2>), 4.0 * (MB_ITERS / 8), out, d_out, 20));
+    GA_CHECK(run_one(ctx, "f29mul_bn254_ilp3_Gmul", (mb_f29_mul_ilp<BN254_Fp, 3>), 6.0 * (MB_ITERS / 8), out, d_out, 20));
     // the same instruction streams held for ~0.2 s each
     GA_CHECK(run_one(ctx, "v_mad_u64_u32_sustained_Gops", mb_mad_u64_u32, n16, out, d_out, 400));
     GA_CHECK(run_one(ctx, "v_mov_b32_sustained_Gops", mb_mov_b32, n16, out, d_out, 800));

@@ -522,50 +522,33 @@ struct Table29 {
     // (BN254 G1, half a cache line, never straddling), 128 B (BN254 G2, one line), 96 / 192 B for BLS12-381.  Storing the
     // limbs unpacked (80 B for BN254 G1) made every third gather touch two lines: FETCH_SIZE 41 GB per 2^24 MSM.
     static constexpr int WORDS = sizeof(Affine<F>) / 4;
-    // workgroup size: the LDS-resident accumulators (4*NW words per lane) must leave room for 2 workgroups per CU
-    // (GA_ACC_THREADS_WIDE: A/B builds -- the workgroup size of the 14-limb fields, whose 224 / 448 bytes of LDS per lane allow more
-    // waves per CU with smaller workgroups: 8 -> 10 -> 11 for BLS12-381 G1 at 256 / 128 / 64 lanes, 4 -> 5 for G2 at 128 / 64.
-    // Measured in round 3 (profiles/r03_v_bls_workgroup_size_ab.txt): G1 30.41 / 30.92 / 30.44 ms per 2^24 launch, G2 95.6 (128 lanes)
-    // / 108.6 (64 lanes): the kernels are issue-bound at two waves per SIMD already; the defaults stay)
-#ifdef GA_ACC_THREADS_WIDE
-    static constexpr int THREADS = NW >= 14 ? GA_ACC_THREADS_WIDE : ((4 * NW * 4 * 256 <= 72 * 1024) ? 256 : 128);
-#else
+    // workgroup size: the LDS-resident accumulators (4*NW words per lane) must leave room for 2 workgroups per CU.  (Measured and
+    // removed -- tools/exp/r04_pruned_knobs.patch brings the build knobs back: 128- / 64-lane workgroups for the 14-limb fields,
+    // G1 30.41 / 30.92 / 30.44 ms per 2^24 launch, G2 95.6 at 128 lanes / 108.6 at 64, profiles/r03_v_bls_workgroup_size_ab.txt;
+    // the next table entry requested one addition ahead and parked in registers: G2 97.1 -> 95.9 ms on BLS12-381, nothing on the
+    // other three kernels, profiles/r04_a_prefetch_ab.txt.)
     static constexpr int THREADS = (4 * NW * 4 * 256 <= 72 * 1024) ? 256 : 128;
-#endif
     static constexpr int MIN_WAVES = Lazy<F>::FP2 ? 2 : GA_ACC29_MINW;
-    // the next table entry is requested one addition ahead and parked in registers (accumulate_task29): for the kernels that run
-    // one or two waves per SIMD, where nothing else hides the gather's latency
-#ifndef GA_ACC_PREFETCH
-#define GA_ACC_PREFETCH 0   // A/B: 0 none, 1 the 14-limb fields (BLS12-381 G1, G2), 2 those and BN254 G2, 3 all
+#ifdef GA_ACC_TOUCH
+    static constexpr bool TOUCH = GA_ACC_TOUCH >= 3 || (GA_ACC_TOUCH == 2 && (NW >= 14 || Lazy<F>::FP2)) || (GA_ACC_TOUCH == 1 && NW >= 28);
 #endif
-    static constexpr bool PREFETCH = GA_ACC_PREFETCH >= 3 || (GA_ACC_PREFETCH == 2 && (NW >= 14 || Lazy<F>::FP2)) || (GA_ACC_PREFETCH == 1 && NW >= 14);
 };
 
-// GA_ACC_REGS (A/B builds): 1 keeps the G1 accumulator in registers instead of LDS, 2 the Fp2 one as well -- measured in round 3
-// (profiles/README.md): the LDS-resident accumulator stays.
-#ifndef GA_ACC_REGS
-#define GA_ACC_REGS 0
-#endif
+// The lane's XYZZ accumulator lives in LDS, word-major (conflict-free): that is what keeps the G1 kernel at 128 VGPRs and four waves
+// per SIMD (the accumulator in registers measured slower in round 3: 15.58 vs 15.04 ms per 2^24 launch, profiles/README.md).
 template <class F>
 struct LdsAcc29 {
     typedef typename Lazy<F>::T T;
-    static constexpr bool IN_REGS = GA_ACC_REGS >= (Lazy<F>::FP2 ? 2 : 1);
     uint32_t* base;
-    mutable T regs[IN_REGS ? 4 : 1];
     __device__ __forceinline__ explicit LdsAcc29(uint32_t* b) : base(b) {}
     static constexpr int NW = Lazy<F>::NW, STRIDE = Table29<F>::THREADS;
     __device__ __forceinline__ T get(int field) const {
-        if constexpr (IN_REGS) return regs[field];
         T r;
 #pragma unroll
         for (int i = 0; i < NW; i++) Lazy<F>::set_word(r, i, base[(field * NW + i) * STRIDE]);
         return r;
     }
     __device__ __forceinline__ void put(int field, const T& v) const {
-        if constexpr (IN_REGS) {
-            regs[field] = v;
-            return;
-        }
 #pragma unroll
         for (int i = 0; i < NW; i++) base[(field * NW + i) * STRIDE] = Lazy<F>::word(v, i);
     }
@@ -675,46 +658,21 @@ __device__ __forceinline__ bool accumulate_task29(const LdsAcc29<F>& A, const ui
     const T one = Lazy<F>::from_mem(FieldTraits<F>::one());
     bool have = false;
     uint32_t v = vals[start];
-    constexpr int NV = (int)(sizeof(Affine<F>) / 16);
-    ga_v4u ahead[Table29<F>::PREFETCH ? NV : 1];
     uint32_t vn = v;
-    if constexpr (Table29<F>::PREFETCH) {
-        load16n_issue<NV>(table + (uint64_t)(v & ~MSM_SIGN) * Table29<F>::WORDS, ahead);
-        vn = start + 1 < end ? vals[start + 1] : v;
-    }
     for (uint32_t p = start; p < end; p++) {
         T qx, qy;
-        if constexpr (Table29<F>::PREFETCH) {
-            // entry p arrives (requested an addition ago), entry p + 1 is requested, index p + 2 is read
-            load16n_arrive<NV>(ahead);
-            Affine<F> a;
-#pragma unroll
-            for (int i = 0; i < NV; i++) memcpy(reinterpret_cast<char*>(&a) + 16 * i, &ahead[i], 16);
-            const uint32_t vnn = p + 2 < end ? vals[p + 2] : vn;
-            if (p + 1 < end) load16n_issue<NV>(table + (uint64_t)(vn & ~MSM_SIGN) * Table29<F>::WORDS, ahead);
-            qx = Lazy<F>::unpack(a.x);
-            qy = Lazy<F>::unpack(a.y);
-            const uint32_t vcur = v;
-            v = vn;
-            vn = vnn;
-            if (!(f29_is_zero_limbs(qx) & f29_is_zero_limbs(qy))) {
-                if (vcur & MSM_SIGN) qy = f29_sub<2>(Lazy<F>::from_mem(FieldTraits<F>::zero()), qy);   // 2p - y
-                if (!have) {
-                    A.put(0, qx);
-                    A.put(1, qy);
-                    A.put(2, one);
-                    A.put(3, one);
-                    have = true;
-                } else if constexpr (COMPLETE) {
-                    have = madd29_complete<F>(A, qx, qy);
-                } else {
-                    madd29<P>(A, qx, qy);
-                }
-            }
-            continue;
-        }
         vn = p + 1 < end ? vals[p + 1] : v;
         load_point29<F>(table, v & ~MSM_SIGN, qx, qy);
+#ifdef GA_ACC_TOUCH
+        // A/B (round 4): one word of each cache line of the NEXT entry is requested behind this entry's loads and dropped at the end of
+        // the addition -- the gather of the next iteration then finds its lines (and the page's translation) in L2
+        uint32_t touch0 = 0, touch1 = 0;
+        if constexpr (Table29<F>::TOUCH) {
+            const uint32_t* nx = table + (uint64_t)(vn & ~MSM_SIGN) * Table29<F>::WORDS;
+            touch0 = *reinterpret_cast<const volatile uint32_t*>(nx);
+            if constexpr (sizeof(Affine<F>) > 128) touch1 = *reinterpret_cast<const volatile uint32_t*>(nx + Table29<F>::WORDS - 1);
+        }
+#endif
         if (!(f29_is_zero_limbs(qx) & f29_is_zero_limbs(qy))) {   // (0,0) = infinity: skip
             if (v & MSM_SIGN) qy = f29_sub<2>(Lazy<F>::from_mem(FieldTraits<F>::zero()), qy);   // 2p - y
             if (!have) {
@@ -729,6 +687,12 @@ __device__ __forceinline__ bool accumulate_task29(const LdsAcc29<F>& A, const ui
                 madd29<P>(A, qx, qy);
             }
         }
+#ifdef GA_ACC_TOUCH
+        if constexpr (Table29<F>::TOUCH) {
+            GA_KEEP_LIVE(touch0);
+            GA_KEEP_LIVE(touch1);
+        }
+#endif
         v = vn;
     }
     return have;
@@ -760,20 +724,19 @@ msm_accumulate29_kernel(const uint32_t* __restrict__ table, const uint32_t* __re
                         const uint32_t* __restrict__ task_dest, XYZZ<F>* __restrict__ sums, uint32_t* __restrict__ redo_list,
                         uint32_t* __restrict__ redo_count) {
     constexpr int NW = Lazy<F>::NW;
-#ifndef GA_ACC_LDS_PAD
-#define GA_ACC_LDS_PAD 0   // experiment: extra LDS words per workgroup, to lower the number of co-resident workgroups
-#endif
-    __shared__ uint32_t lds[(LdsAcc29<F>::IN_REGS ? 1 : 4 * NW * Table29<F>::THREADS) + GA_ACC_LDS_PAD];
+    __shared__ uint32_t lds[4 * NW * Table29<F>::THREADS];
     // (Round 3 measured two ways of making room for kernels of the partner lane beside this one -- which fills 144 of the 160 KB
-    // of LDS of a CU: the accumulator in registers instead of LDS (GA_ACC_REGS below: 15.58 vs 15.04 ms, slower) and a cap of 3
-    // resident waves per SIMD through the register allocation (proof time unchanged, 139.4 vs 139.9 ms).  Neither stays.)
+    // of LDS of a CU: the accumulator in registers instead of LDS (15.58 vs 15.04 ms, slower) and a cap of 3 resident waves per
+    // SIMD through the register allocation (proof time unchanged, 139.4 vs 139.9 ms).  Neither stays.  Round 4: a resident grid
+    // striding over the task list instead of one task per lane is slower on all four kernels, tools/exp/r04_resident_bucket_grid.patch,
+    // profiles/r04_e_resident_bucket_grid_ab.txt.)
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= max_tasks) return;
     const uint32_t key = task_key_sorted[t];
     if (key >= seg) return;
     const uint32_t tid = task_perm[t];
     const uint32_t start = task_start[tid];
-    LdsAcc29<F> A(lds + (LdsAcc29<F>::IN_REGS ? 0 : threadIdx.x));
+    LdsAcc29<F> A(lds + threadIdx.x);
     const bool have = accumulate_task29<F, COMPLETE>(A, table, vals, start, start + (seg - key));
     if (!store_task29<F>(A, have, &sums[task_dest[tid]])) redo_list[atomicAdd(redo_count, 1u)] = tid;   // redo it
 }

@@ -150,115 +150,115 @@ __device__ __forceinline__ F29<FrP> ntt_twiddle29(const uint32_t* __restrict__ t
 }
 
 // Two stages per LDS round trip (radix-4 in registers): a thread keeps a quad (index bits t and t+1) in registers across two
-// stages, so there is one LDS read + write, one index computation and one barrier per TWO stages, and the intermediate values are
-// not carry-normalised: limb-wise sums stay below 2^32 and a 2^31-limb multiplicand still keeps the product columns below 2^64.
-// An odd stage count ends with one plain radix-2 stage (ntt_plan avoids odd counts where it can).
+// stages, so there is one LDS read + write and one index computation per TWO stages, and the intermediate values are not
+// carry-normalised: limb-wise sums stay below 2^32 and a 2^31-limb multiplicand still keeps the product columns below 2^64.
+//
+// Round 4: which rounds need the workgroup at all.  With a full tile (1024 slots, 256 threads) thread q of a round on slot bits
+// (lb, lb+1) owns the quad whose other eight slot bits are q -- so as long as the round's bits lie below bit 8, the four waves
+// work on the slots whose top two bits are their own number, round after round: the exchange between such rounds is traffic
+// among the lanes of ONE wave, which the LDS serves in issue order -- no s_barrier, only a compiler fence (wave_lds_sync).
+// The stage list is cut so that everything below slot bit 8 comes in such wave-local rounds (an odd count puts its single stage
+// at the top of that part, bit 7) and bits 8, 9 form one radix-4 round of their own behind the only __syncthreads of the pass
+// (two when the tile is also loaded / stored through LDS).  The first and the last round move their quads straight between
+// registers and HBM when eight consecutive lanes still cover a 256-byte row (lb >= 3): bit-reversed -> natural upper passes
+// (7 stages: bits 3..9) run  HBM -> (3,4) ~ (5,6) ~ (7) | (8,9) -> HBM  with ONE barrier (|) and three LDS exchanges instead
+// of five barriers and five exchanges; the 10-stage pass  LDS <- HBM ~ (0,1) ~ (2,3) ~ (4,5) ~ (6,7) | (8,9) -> HBM.
+// flags: bit 0 = the table may hold unit twiddles (not a coset table), bit 1 = wave-local rounds, bit 2 = direct first load /
+// last store (GA_NTT_WAVE_LOCAL / GA_NTT_DIRECT, A/B knobs of round 4).
+constexpr int NTT_F_UNIT = 1, NTT_F_WAVE_LOCAL = 2, NTT_F_DIRECT = 4;
+
 template <class FrP, bool DIT_>
-__global__ void __launch_bounds__(NTT_THREADS)
+__global__ void __launch_bounds__(NTT_THREADS, 4)
 ntt_pass29r4_kernel(uint32_t* data, const uint32_t* src, const uint32_t* __restrict__ tw, int logn, int lg_tile, int s_lo, int K,
-                    int lc, NttScale pre, NttScale post, int unit_ok) {
-    // unit_ok = 0: the table is a coset table (every entry carries its stage's power of the coset generator): no twiddle is 1
+                    int lc, NttScale pre, NttScale post, int flags) {
+    // NTT_F_UNIT clear: the table is a coset table (every entry carries its stage's power of the coset generator): no twiddle is 1
     static_assert(FrP::N == 8, "Fr is 4x64-bit limbs on both curves");
+    static_assert(NTT_THREADS == 256 && NTT_LG_TILE == 10, "the wave-local slot mapping below is written for 4 waves x 256 slots");
     typedef F29<FrP> E;
     __shared__ uint32_t lds[Radix<FrP>::NL << NTT_LG_TILE];
     LdsTile29<FrP> T{lds};
     const uint32_t tile_elems = 1u << lg_tile;
     const uint64_t tile = blockIdx.x;
-    const uint32_t tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const bool unit_ok = (flags & NTT_F_UNIT) != 0;
+    const bool wl = lg_tile == NTT_LG_TILE && (flags & NTT_F_WAVE_LOCAL) != 0;
+    const bool direct = lg_tile == NTT_LG_TILE && (flags & NTT_F_DIRECT) != 0;
     auto twid = [&](uint64_t k) { return ntt_twiddle29<FrP>(tw, k); };
-
-    for (uint32_t l = tid; l < tile_elems; l += NTT_THREADS) {
-        uint64_t i = ntt_gidx(l, tile, lg_tile, s_lo, K, lc);
+    auto gidx = [&](uint32_t l) { return ntt_gidx(l, tile, lg_tile, s_lo, K, lc); };
+    auto ld = [&](uint64_t i) {
         E v = f29_unpack(load_fe<FrP>(src + i * 8));   // src == data for an in-place pass
         if (pre.mode != 0) v = f29_mul(v, ntt_scale_factor29<FrP>(pre, i, logn));
-        T.put(l, v);
-    }
-    __syncthreads();
+        return v;
+    };
+    auto st = [&](uint64_t i, E v) {                   // v normalized
+        if (post.mode != 0) v = f29_mul(v, ntt_scale_factor29<FrP>(post, i, logn));
+        store_fe(data + i * 8, f29_pack_canonical(f29_reduce_3p(v)));
+    };
+    // slot of a thread's j-th element in the load / store phases: the wave's own quarter of the tile when rounds are wave-local
+    auto own_slot = [&](uint32_t j) { return wl ? ((wv << 8) | (j << 6) | lane) : tid + j * NTT_THREADS; };
+    // between two phases that exchange through LDS: inside the wave when both are wave-local, through the workgroup otherwise
+    auto sync = [&](bool both_local) {
+        if (both_local) wave_lds_sync();
+        else __syncthreads();
+    };
 
-    // rounds of r stages in registers per LDS round trip: r = 2 (radix-4 blocks), a last r = 1 for an odd stage count; with
-    // GA_NTT_RADIX8 (A/B builds) r = 3 wherever that leaves no single stage over (10 = 3+3+2+2, 7 = 3+2+2).  Bit-reversed -> natural
-    // runs the groups ascending, natural -> bit-reversed descending (the stages INSIDE a group likewise).
-    for (int done = 0; done < K;) {
-        const int rem = K - done;
-#ifdef GA_NTT_RADIX8
-        const int r = (rem >= 5 || rem == 3) ? 3 : (rem >= 2 ? 2 : 1);
-#else
-        const int r = rem >= 2 ? 2 : 1;
-#endif
-        const int t = DIT_ ? done : (K - done - r);
+    // the rounds in ascending stage order, five bits each: first stage t | (stages - 1) << 4
+    uint32_t plan = 0;
+    int nr = 0;
+    {
+        const int below8 = 8 - lc < 0 ? 0 : 8 - lc;
+        const int nlow = wl ? (K < below8 ? K : below8) : K;
+        int t = 0;
+        auto push = [&](int r) {
+            plan |= (uint32_t)(t | ((r - 1) << 4)) << (5 * nr);
+            nr++;
+            t += r;
+        };
+        while (t + 2 <= nlow) push(2);
+        if (t < nlow) push(1);
+        while (t + 2 <= K) push(2);
+        if (t < K) push(1);
+    }
+    auto round_of = [&](int k, int& t, int& r) {     // k-th round in execution order
+        const uint32_t code = (plan >> (5 * (DIT_ ? k : nr - 1 - k))) & 31u;
+        t = (int)(code & 15u);
+        r = (int)(code >> 4) + 1;
+    };
+    auto direct_ok = [&](int t, int r) { return direct && r == 2 && lc + t >= 3; };
+    int t0, r0, t9, r9;
+    round_of(0, t0, r0);
+    round_of(nr - 1, t9, r9);
+    // (a pass that scales its input or output keeps the LDS phases, where the scale factors are applied: the register-resident
+    // rounds stay lean -- with the factor tables in them the kernel needed 158 VGPRs, three waves per SIMD)
+    const bool dload = nr > 0 && pre.mode == 0 && direct_ok(t0, r0), dstore = nr > 0 && post.mode == 0 && direct_ok(t9, r9);
+
+    bool lds_live = false, prev_local = false;       // a previous phase left its results in LDS / it was wave-local
+    if (!dload) {
+        for (uint32_t j = 0; j * NTT_THREADS < tile_elems; j++) {
+            const uint32_t l = own_slot(j);
+            if (l < tile_elems) T.put(l, ld(gidx(l)));
+        }
+        lds_live = true;
+        prev_local = wl;
+    }
+
+    for (int k = 0; k < nr; k++) {
+        int t, r;
+        round_of(k, t, r);
         const int lb = lc + t;
         const int s = s_lo + t;
-#ifdef GA_NTT_RADIX8
-        if (r == 3) {
-            for (uint32_t q = tid; q < tile_elems / 8; q += NTT_THREADS) {
-                const uint32_t l0 = ((q >> lb) << (lb + 3)) | (q & ((1u << lb) - 1));
-                const uint64_t i0 = ntt_gidx(l0, tile, lg_tile, s_lo, K, lc);
-                E a[8];   // a[b2 b1 b0]: index bit lb + j of the element is b_j
-#pragma unroll
-                for (int j = 0; j < 8; j++) a[j] = T.get(l0 | ((uint32_t)j << lb));
-                // butterfly on elements (lo, hi) with twiddle entry kk: (lo, hi) <- (lo + hi*w, lo - hi*w); products < 3p
-                auto bf = [&](int lo, int hi, const E& w) {
-                    const E m = f29_mul(a[hi], w);
-                    const E x = a[lo];
-                    a[lo] = f29_add_raw(x, m);
-                    a[hi] = f29_sub_raw<4>(x, m);
-                };
-                if (DIT_) {
-                    const uint64_t x = i0 & ((1ull << s) - 1);
-                    {   // stage s on bit 0: one twiddle
-                        const E w = twid((1ull << s) + x);
-#pragma unroll
-                        for (int h = 0; h < 4; h++) bf(2 * h, 2 * h + 1, w);
-                    }
-#pragma unroll
-                    for (int b0 = 0; b0 < 2; b0++) {   // stage s+1 on bit 1: position x + b0*2^s inside the block
-                        const E w = twid((2ull << s) + ((uint64_t)b0 << s) + x);
-                        bf(b0, b0 | 2, w);
-                        bf(b0 | 4, b0 | 6, w);
-                    }
-#pragma unroll
-                    for (int j = 4; j < 8; j++) f29_normalize(a[j]);   // third-stage multiplicands: limbs back below 2^29 (+ top)
-#pragma unroll
-                    for (int b = 0; b < 4; b++) {      // stage s+2 on bit 2: position x + (b0 + 2 b1)*2^s
-                        const E w = twid((4ull << s) + ((uint64_t)b << s) + x);
-                        bf(b, b | 4, w);
-                    }
-                } else {
-                    const uint64_t u = i0 >> (s + 3);
-                    {   // stage s+2 on bit 2: the block's twiddle
-                        const E w = twid(u);
-#pragma unroll
-                        for (int b = 0; b < 4; b++) bf(b, b | 4, w);
-                    }
-#pragma unroll
-                    for (int b2 = 0; b2 < 2; b2++) {   // stage s+1 on bit 1: block 2u + b2
-                        const E w = twid(2 * u + b2);
-                        bf(4 * b2, 4 * b2 | 2, w);
-                        bf(4 * b2 | 1, 4 * b2 | 3, w);
-                    }
-#pragma unroll
-                    for (int h = 0; h < 4; h++) f29_normalize(a[2 * h + 1]);
-#pragma unroll
-                    for (int h = 0; h < 4; h++) {      // stage s on bit 0: block 4u + 2 b2 + b1 = 4u + h
-                        const E w = twid(4 * u + h);
-                        bf(2 * h, 2 * h + 1, w);
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    f29_normalize(a[j]);
-                    T.put(l0 | ((uint32_t)j << lb), a[j]);
-                }
-            }
-        } else
-#endif
+        const bool local = wl && lb + r <= 8;
+        const bool from_hbm = dload && k == 0, to_hbm = dstore && k == nr - 1;
+        if (lds_live && !from_hbm) sync(prev_local && local);
         if (r == 2) {
         for (uint32_t q = tid; q < tile_elems / 4; q += NTT_THREADS) {
             const uint32_t l00 = ((q >> lb) << (lb + 2)) | (q & ((1u << lb) - 1));
             // (DIT: first stage on bit lb, second on bit lb+1; natural -> bit-reversed: the other way round, which is the same
             // code with the two middle elements of the quad exchanged)
             const uint32_t l01 = l00 | ((DIT_ ? 1u : 2u) << lb), l10 = l00 | ((DIT_ ? 2u : 1u) << lb), l11 = l00 | (3u << lb);
-            const uint64_t i0 = ntt_gidx(l00, tile, lg_tile, s_lo, K, lc);
+            const uint64_t i0 = gidx(l00);
+            // (global neighbours of the quad: slot bit lb is element-index bit s)
+            const uint64_t d01 = (DIT_ ? 1ull : 2ull) << s, d10 = (DIT_ ? 2ull : 1ull) << s, d11 = 3ull << s;
             uint64_t k1, k2, k3;      // table entries: first stage (both butterflies), second stage (.0) and (.1)
             bool unit;                // first-stage twiddle and the (.0) second-stage twiddle are 1
             if (DIT_) {
@@ -274,7 +274,19 @@ ntt_pass29r4_kernel(uint32_t* data, const uint32_t* src, const uint32_t* __restr
                 k3 = 2 * u + 1;
                 unit = u == 0;
             }
-            E a00 = T.get(l00), a01 = T.get(l01), a10 = T.get(l10), a11 = T.get(l11);
+            E a00, a01, a10, a11;
+            if (from_hbm) {
+                const uint32_t* p0 = src + i0 * 8;
+                a00 = f29_unpack(load_fe<FrP>(p0));
+                a01 = f29_unpack(load_fe<FrP>(p0 + d01 * 8));
+                a10 = f29_unpack(load_fe<FrP>(p0 + d10 * 8));
+                a11 = f29_unpack(load_fe<FrP>(p0 + d11 * 8));
+            } else {
+                a00 = T.get(l00);
+                a01 = T.get(l01);
+                a10 = T.get(l10);
+                a11 = T.get(l11);
+            }
             // first stage: (a00, a01) and (a10, a11); products (or, for w = 1, the operand itself) are brought below 3p
             E m0, m1;
             if (!unit) {
@@ -302,16 +314,27 @@ ntt_pass29r4_kernel(uint32_t* data, const uint32_t* src, const uint32_t* __restr
             f29_normalize(c01);
             f29_normalize(c10);
             f29_normalize(c11);
-            T.put(l00, c00);
-            T.put(l01, c01);
-            T.put(l10, c10);
-            T.put(l11, c11);
+            if (to_hbm) {
+                uint32_t* p0 = data + gidx(l00) * 8;
+                store_fe(p0, f29_pack_canonical(f29_reduce_3p(c00)));
+                store_fe(p0 + d01 * 8, f29_pack_canonical(f29_reduce_3p(c01)));
+                store_fe(p0 + d10 * 8, f29_pack_canonical(f29_reduce_3p(c10)));
+                store_fe(p0 + d11 * 8, f29_pack_canonical(f29_reduce_3p(c11)));
+            } else {
+                T.put(l00, c00);
+                T.put(l01, c01);
+                T.put(l10, c10);
+                T.put(l11, c11);
+            }
         }
-        } else {   // a single stage (odd stage count: the last round; DIT: t = K-1, natural -> bit-reversed: t = 0)
-        for (uint32_t q = tid; q < tile_elems / 2; q += NTT_THREADS) {
+        } else {   // a single stage (odd stage count)
+        for (uint32_t j = 0; j * NTT_THREADS < tile_elems / 2; j++) {
+            // wave-local: the wave's number goes to slot bits 8, 9 (lb <= 7), the iteration to the bit below
+            const uint32_t q = wl ? (lane | (j << 6) | (wv << 7)) : tid + j * NTT_THREADS;
+            if (q >= tile_elems / 2) continue;
             uint32_t l0 = ((q >> lb) << (lb + 1)) | (q & ((1u << lb) - 1));
             uint32_t l1 = l0 | (1u << lb);
-            uint64_t i0 = ntt_gidx(l0, tile, lg_tile, s_lo, K, lc);
+            uint64_t i0 = gidx(l0);
             uint64_t kk;
             bool unit;
             if (DIT_) {
@@ -328,15 +351,16 @@ ntt_pass29r4_kernel(uint32_t* data, const uint32_t* src, const uint32_t* __restr
             T.put(l1, f29_sub<4>(x, m));
         }
         }
-        __syncthreads();
-        done += r;
+        lds_live = !to_hbm;
+        prev_local = local;
     }
 
-    for (uint32_t l = tid; l < tile_elems; l += NTT_THREADS) {
-        uint64_t i = ntt_gidx(l, tile, lg_tile, s_lo, K, lc);
-        E v = T.get(l);
-        if (post.mode != 0) v = f29_mul(v, ntt_scale_factor29<FrP>(post, i, logn));
-        store_fe(data + i * 8, f29_pack_canonical(f29_reduce_3p(v)));
+    if (lds_live) {
+        sync(prev_local && wl);
+        for (uint32_t j = 0; j * NTT_THREADS < tile_elems; j++) {
+            const uint32_t l = own_slot(j);
+            if (l < tile_elems) st(gidx(l), T.get(l));
+        }
     }
 }
 
@@ -456,10 +480,7 @@ inline std::vector<NttPass> ntt_plan(int logn) {
         if (ok && sum == logn && !ks.empty()) return make(ks);
     }
     if (logn <= K0MAX) return make({logn});
-#ifndef GA_NTT_KUP
-#define GA_NTT_KUP 7   // largest stage count of an upper pass in the default plan (8 = 128-byte rows)
-#endif
-    const int kup = GA_NTT_KUP;
+    const int kup = 7;   // largest stage count of an upper pass in the default plan (8 = 128-byte rows: measured +-0.1 ms, GA_NTT_PLAN)
     const int np = 1 + (logn - K0MAX + kup - 1) / kup;
     std::vector<int> best, cur(np, 0);
     int best_odd = 1 << 30, best_min = 0;
@@ -497,7 +518,7 @@ int ntt_run(Domain* d, uint32_t* d_data, bool inverse, bool dit, const NttScale&
     // d_src != nullptr: out-of-place transform (the first pass reads d_src, every pass writes d_data; d_src is left untouched)
     Ctx* ctx = d->ctx;
     const uint32_t* tw = coset_table ? coset_table : dit ? (inverse ? d->d_ts_inv : d->d_ts) : (inverse ? d->d_tb_inv : d->d_tb);
-    const int unit_ok = coset_table ? 0 : 1;
+    const int flags = (coset_table ? 0 : NTT_F_UNIT) | (ctx->tun.ntt_wave_local ? NTT_F_WAVE_LOCAL : 0) | (ctx->tun.ntt_direct ? NTT_F_DIRECT : 0);
     NttScale none;
     memset(&none, 0, sizeof(none));
     int np = (int)d->passes.size();
@@ -511,10 +532,10 @@ int ntt_run(Domain* d, uint32_t* d_data, bool inverse, bool dit, const NttScale&
         StageTimer st(ctx, dit ? "ntt_pass_dit" : "ntt_pass_dif");
         if (dit)
             hipLaunchKernelGGL((ntt_pass29r4_kernel<FrP, true>), dim3((unsigned)tiles), dim3(NTT_THREADS), 0, ctx->work_stream(),
-                               d_data, src, tw, d->logn, lg_tile, ps.s_lo, ps.K, ps.lc, pre, post, unit_ok);
+                               d_data, src, tw, d->logn, lg_tile, ps.s_lo, ps.K, ps.lc, pre, post, flags);
         else
             hipLaunchKernelGGL((ntt_pass29r4_kernel<FrP, false>), dim3((unsigned)tiles), dim3(NTT_THREADS), 0, ctx->work_stream(),
-                               d_data, src, tw, d->logn, lg_tile, ps.s_lo, ps.K, ps.lc, pre, post, unit_ok);
+                               d_data, src, tw, d->logn, lg_tile, ps.s_lo, ps.K, ps.lc, pre, post, flags);
         GA_KERNEL_CHECK();
     }
     return GA_OK;

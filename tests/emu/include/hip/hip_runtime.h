@@ -217,6 +217,11 @@ inline hipError_t hipGetDeviceCount(int* n) {
     *n = 1;
     return hipSuccess;
 }
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 0, hipDeviceAttributeWallClockRate = 1 };
+inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t a, int) {
+    *v = a == hipDeviceAttributeMultiprocessorCount ? 1 : 100000;
+    return hipSuccess;
+}
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     memset(p, 0, sizeof(*p));
     strcpy(p->name, "hipemu (CPU functional emulation)");

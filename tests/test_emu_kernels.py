@@ -72,6 +72,33 @@ def test_emu_fft_pass_shapes_vs_c_oracle(emu_ctx, c, logn):
         d.close()
 
 
+@pytest.mark.parametrize("knobs", [{}, {"GA_NTT_DIRECT": "0"}, {"GA_NTT_WAVE_LOCAL": "0"}, {"GA_NTT_WAVE_LOCAL": "0", "GA_NTT_DIRECT": "0"}],
+                         ids=["default", "no-direct", "no-wave-local", "round3"])
+@pytest.mark.parametrize("logn", [10, 12, 17, 18])
+def test_emu_fft_wave_local_rounds(emu_ctx, monkeypatch, logn, knobs):
+    """round 4's pass structure on full 1024-slot tiles: rounds below slot bit 8 exchange inside a wave (no workgroup barrier),
+    bits 8/9 form one radix-4 round behind the only __syncthreads, first / last rounds move quads straight between registers and
+    HBM -- every plan shape the 2^24 transforms use (10 stages alone, 10+2, 10+7, 10+8 / 9+9 with a single-stage round at slot
+    bit 7 or 8), each of the two A/B knobs off as well, against the C oracle's radix-2 transform in all eight modes."""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    c = BN254
+    n = 1 << logn
+    rng = np.random.default_rng(4100 + logn)
+    a = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    a[:, 3] &= (1 << 60) - 1   # below r as 256-bit integers (Montgomery images: any residue is a valid input)
+    d = fft.Domain(emu_ctx, c.name, n)
+    try:
+        for dec in (pyref.DIF, pyref.DIT):
+            for coset in (False, True):
+                for inv in (False, True):
+                    want = oracle.fft(c.cid, a, 1 if inv else 0, dec, coset, nthreads=4)
+                    got = (d.FFTInverse if inv else d.FFT)(a, dec, coset)
+                    assert np.array_equal(got, want), (logn, dec, coset, inv)
+    finally:
+        d.close()
+
+
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
 def test_emu_compute_h(emu_ctx, c):
     rng = pyref.Xoshiro(11)

@@ -27,6 +27,12 @@ def test_fft_multi_pass(gpu_ctx, c):
     cases.test_emu_fft_multi_pass(gpu_ctx, c)
 
 
+@pytest.mark.parametrize("knobs", [{}, {"GA_NTT_DIRECT": "0"}, {"GA_NTT_WAVE_LOCAL": "0", "GA_NTT_DIRECT": "0"}], ids=["default", "no-direct", "round3"])
+@pytest.mark.parametrize("logn", [10, 12, 17, 18])
+def test_fft_wave_local_rounds(gpu_ctx, monkeypatch, logn, knobs):
+    cases.test_emu_fft_wave_local_rounds(gpu_ctx, monkeypatch, logn, knobs)
+
+
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
 def test_compute_h_small(gpu_ctx, c):
     cases.test_emu_compute_h(gpu_ctx, c)

@@ -1,5 +1,6 @@
 #!/bin/bash
-# One parameterised driver for everything that runs on the GPU box (replaces the per-batch gpu_r2_* / gpu_r3_* scripts).
+# The one parameterised driver for everything that runs on the GPU box (the per-batch gpu_r2_* / gpu_r3_* / gpu_<topic> scripts of the
+# earlier rounds are gone; their outputs under profiles/ name the steps below).
 #   TAG=r04_a tools/gpu.sh <step> [<step> ...]        steps run in order; outputs go to gpurun_out/${TAG}_*
 # steps:
 #   tests[:<pytest -k expression>]   the -m gpu suite (or a selection)
@@ -13,6 +14,11 @@
 #                                    bench | bls (BLS12-381 G1+G2 table MSMs) | bn (BN254 ones) | ntt  -> ${TAG}_sq_<name>_{counters,summary}.txt
 #   ab:<name>:<parts>[:<curve>[:<variant>]]   tools/ab_kernels.py --parts <parts>, on gnark_amd/variants/libgnark_amd_<variant>.so when given
 #                                    (run-time knobs from the environment) -> ${TAG}_ab_<name>.json
+#   abenv:<name>:<parts>:<curve>:<K=V,K=V,...>   the same with run-time knobs set for that one run ("-" = none): same-box A/B of a knob
+#                                    (appends to ${TAG}_abenv.txt, one JSON line per run)
+#   plonk                            tools/bench_plonk_kernels.py (config 5 kernel work) -> ${TAG}_bench_plonk.json
+#   clock                            tools/clock_probe.py: shader clock / power held under each kernel family -> ${TAG}_clock_probe.json
+#   small:<log-n>                    tools/msm_small_trace.py: stage profile of a raw and a table MSM of 2^<log-n> points
 # Counter passes never combine --pmc with anything but --kernel-trace.
 TAG=${TAG:-r04}
 OUT=gpurun_out
@@ -100,6 +106,20 @@ for step in "$@"; do
       libenv=""; [ -n "$variant" ] && libenv="GA_LIB_PATH=$PWD/gnark_amd/variants/libgnark_amd_${variant}.so"
       env $libenv timeout 1200 python tools/ab_kernels.py --parts $parts --curve ${curve:-bn254} --tag $nm > $OUT/${TAG}_ab_${nm}.json 2> $OUT/${TAG}_ab_${nm}.err
       tail -2 $OUT/${TAG}_ab_${nm}.err; cut -c1-1500 $OUT/${TAG}_ab_${nm}.json ;;
+    abenv)
+      IFS=: read -r nm parts curve kv <<< "$arg"
+      envs=""; [ -n "$kv" ] && [ "$kv" != "-" ] && envs=${kv//,/ }
+      env $envs timeout 1200 python tools/ab_kernels.py --parts $parts --curve ${curve:-bn254} --tag "$nm" >> $OUT/${TAG}_abenv.txt 2>> $OUT/${TAG}_abenv.err
+      tail -1 $OUT/${TAG}_abenv.txt | cut -c1-900 ;;
+    plonk)
+      timeout 900 python tools/bench_plonk_kernels.py > $OUT/${TAG}_bench_plonk.json 2> $OUT/${TAG}_bench_plonk.err
+      cut -c1-1200 $OUT/${TAG}_bench_plonk.json ;;
+    clock)
+      timeout 600 python tools/clock_probe.py --seconds 2.5 > $OUT/${TAG}_clock_probe.json 2> $OUT/${TAG}_clock_probe.err
+      cut -c1-2500 $OUT/${TAG}_clock_probe.json ;;
+    small)
+      timeout 600 python tools/msm_small_trace.py --log-n ${arg:-20} --reps 20 > $OUT/${TAG}_msm_2p${arg:-20}_trace.json 2> $OUT/${TAG}_msm_small.err
+      cat $OUT/${TAG}_msm_2p${arg:-20}_trace.json ;;
     *) echo "unknown step $step" ;;
   esac
 done

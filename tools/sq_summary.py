@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-kernel issue accounting from the SQ counter passes collected by tools/gpu_r2_profiles.sh (text summaries of
+"""Per-kernel issue accounting from the SQ counter passes collected by tools/gpu.sh (step sq) (text summaries of
 tools/prof_summary.py --pmc).  SQ_ACTIVE_INST_ANY + SQ_WAIT_INST_ANY + SQ_WAIT_ANY ~= SQ_WAVE_CYCLES (disjoint, quad-cycles,
 /opt/skills/guides/MI355X_MICROARCH.md): a wave is issuing, stalled at the issue port, or parked on s_waitcnt / a barrier.
 With N waves per SIMD a saturated VALU gives every wave 1/N of the issue slots.
