@@ -14,7 +14,7 @@ DEFAULT_PATH = os.path.join(_HERE, "libgnark_amd.so")
 GA_OK = 0
 BN254, BLS12_381 = 0, 1
 G1, G2 = 0, 1
-BASES_ON_DEVICE, SCALARS_ON_DEVICE, SCALARS_MONTGOMERY = 0x1, 0x2, 0x4
+BASES_ON_DEVICE, SCALARS_ON_DEVICE, SCALARS_MONTGOMERY, TABLE_BATCHED = 0x1, 0x2, 0x4, 0x10
 FFT_FORWARD, FFT_INVERSE = 0, 1
 DIF, DIT = 0, 1
 

@@ -394,7 +394,7 @@ int ga_msm_table_create(ga_ctx* h, int curve, int group, const void* bases, size
     int rc = GA_OK;
     GA_DISPATCH_CURVE(curve, GA_DISPATCH_GROUP(group, {
                           typedef typename GroupField<C, G>::F F;
-                          rc = msm_plan_table<C>(n, &t->c, &t->nwin);
+                          rc = msm_plan_table<C>(n, &t->c, &t->nwin, (flags & GA_TABLE_BATCHED) != 0);
                           t->bytes = (uint64_t)t->nwin * n * msm_table_point_bytes<C, G>();
                           Staged sb{c};
                           if (rc == GA_OK) rc = sb.stage(bases, n * sizeof(Affine<F>), flags & GA_BASES_ON_DEVICE);

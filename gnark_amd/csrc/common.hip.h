@@ -307,7 +307,7 @@ template <class C>
 int msm_plan(int group, size_t n, int* c, int* nwin);
 // window width for the precomputed-table mode (one shared bucket set; table = nwin x n affine points)
 template <class C>
-int msm_plan_table(size_t n, int* c, int* nwin);
+int msm_plan_table(size_t n, int* c, int* nwin, bool batched = false);
 
 // Output of the group-independent half of an MSM (digits -> sort -> bucket offsets -> length-ordered task list).
 // The arrays live in the context's scratch; they stay valid until the next msm_prepare on the same context, so one

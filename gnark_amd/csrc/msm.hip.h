@@ -529,9 +529,6 @@ struct Table29 {
     // other three kernels, profiles/r04_a_prefetch_ab.txt.)
     static constexpr int THREADS = (4 * NW * 4 * 256 <= 72 * 1024) ? 256 : 128;
     static constexpr int MIN_WAVES = Lazy<F>::FP2 ? 2 : GA_ACC29_MINW;
-#ifdef GA_ACC_TOUCH
-    static constexpr bool TOUCH = GA_ACC_TOUCH >= 3 || (GA_ACC_TOUCH == 2 && (NW >= 14 || Lazy<F>::FP2)) || (GA_ACC_TOUCH == 1 && NW >= 28);
-#endif
 };
 
 // The lane's XYZZ accumulator lives in LDS, word-major (conflict-free): that is what keeps the G1 kernel at 128 VGPRs and four waves
@@ -663,16 +660,6 @@ __device__ __forceinline__ bool accumulate_task29(const LdsAcc29<F>& A, const ui
         T qx, qy;
         vn = p + 1 < end ? vals[p + 1] : v;
         load_point29<F>(table, v & ~MSM_SIGN, qx, qy);
-#ifdef GA_ACC_TOUCH
-        // A/B (round 4): one word of each cache line of the NEXT entry is requested behind this entry's loads and dropped at the end of
-        // the addition -- the gather of the next iteration then finds its lines (and the page's translation) in L2
-        uint32_t touch0 = 0, touch1 = 0;
-        if constexpr (Table29<F>::TOUCH) {
-            const uint32_t* nx = table + (uint64_t)(vn & ~MSM_SIGN) * Table29<F>::WORDS;
-            touch0 = *reinterpret_cast<const volatile uint32_t*>(nx);
-            if constexpr (sizeof(Affine<F>) > 128) touch1 = *reinterpret_cast<const volatile uint32_t*>(nx + Table29<F>::WORDS - 1);
-        }
-#endif
         if (!(f29_is_zero_limbs(qx) & f29_is_zero_limbs(qy))) {   // (0,0) = infinity: skip
             if (v & MSM_SIGN) qy = f29_sub<2>(Lazy<F>::from_mem(FieldTraits<F>::zero()), qy);   // 2p - y
             if (!have) {
@@ -687,12 +674,6 @@ __device__ __forceinline__ bool accumulate_task29(const LdsAcc29<F>& A, const ui
                 madd29<P>(A, qx, qy);
             }
         }
-#ifdef GA_ACC_TOUCH
-        if constexpr (Table29<F>::TOUCH) {
-            GA_KEEP_LIVE(touch0);
-            GA_KEEP_LIVE(touch1);
-        }
-#endif
         v = vn;
     }
     return have;

@@ -166,7 +166,7 @@ int msm_plan(int group, size_t n, int* c_out, int* nwin_out) {
 }
 
 template <class C>
-int msm_plan_table(size_t n, int* c_out, int* nwin_out) {
+int msm_plan_table(size_t n, int* c_out, int* nwin_out, bool batched) {
     const int bits = C::FrP::BITS;
     double best = 1e300;
     int bc = 4;
@@ -176,7 +176,10 @@ int msm_plan_table(size_t n, int* c_out, int* nwin_out) {
         if (table_c_override() && c != table_c_override()) continue;   // GA_TABLE_C (experiments; read with the other knobs)
         // one shared bucket set: its reduction costs ~6 mixed-add equivalents per bucket for mid-size inputs (latency-bound
         // kernels) and ~2.5 from 2^22 points up (measured: c = 17 best at 2^20, c = 22 best at 2^22 and 2^24)
-        const double per_bucket = n >= (1u << 22) ? 2.5 : 6.0;
+        // batched: the table serves runs over k scalar vectors at once (PLONK's grouped commitments): k bucket sets widen the sort
+        // keys and turn the reduction from latency- into issue-bound -- measured at 2^22 with batches of three: c = 20 beats c = 22
+        // by 3.2 ms per PLONK proof (profiles/r04_l_plonk_table_c.txt) while a single run loses 0.05 ms
+        const double per_bucket = (n >= (1u << 22) && !batched) ? 2.5 : 6.0;
         double cost = (double)nwin * (double)n + per_bucket * (double)(1u << (c - 1));
         // a top window of only 1-4 scalar bits puts its n additions into a handful of buckets, which the merge step then sums
         // almost serially (measured at c = 18 and 21: merge 0.2 -> 1.2-2.3 ms, profiles/r02_e_table_c_sweep.txt): avoid those widths

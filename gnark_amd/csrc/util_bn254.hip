@@ -8,5 +8,5 @@ template int util_fr_dot<Bn254>(Ctx*, const void*, const void*, size_t, void*);
 template int util_fr_vec_mul<Bn254>(Ctx*, const void*, const void*, size_t, void*);
 template int util_gather_fr<Bn254>(Ctx*, void*, const void*, const uint32_t*, size_t);
 template int msm_plan<Bn254>(int, size_t, int*, int*);
-template int msm_plan_table<Bn254>(size_t, int*, int*);
+template int msm_plan_table<Bn254>(size_t, int*, int*, bool);
 }  // namespace ga

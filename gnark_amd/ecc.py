@@ -54,7 +54,8 @@ class PrecomputedBases:
     """Bases pinned on the device together with [2^(c*w)]P for every Pippenger window w (ga_msm_table_*): the GPU analogue of
     keeping `pk.G1.A` etc. resident ("PinToGPU", provingkey.go:37-42) with ICICLE's PrecomputeFactor."""
 
-    def __init__(self, ctx: Context, curve, group: int, points, n: int | None = None):
+    def __init__(self, ctx: Context, curve, group: int, points, n: int | None = None, batched: bool = False):
+        """batched: the table will mostly serve MultiExpBatch (GA_TABLE_BATCHED: a narrower window is planned)"""
         cid = curve_id(curve)
         if not isinstance(points, (DeviceBuffer, int)):
             points = as_u64(points, affine_words(cid, group))
@@ -63,7 +64,7 @@ class PrecomputedBases:
             raise ValueError("n is required for device-resident points")
         bp, f1 = _arg(points, _lib.BASES_ON_DEVICE)
         h = C.c_void_p()
-        ctx.lib.check(ctx.lib.ga_msm_table_create(ctx.handle, cid, group, bp, n, f1, C.byref(h)))
+        ctx.lib.check(ctx.lib.ga_msm_table_create(ctx.handle, cid, group, bp, n, f1 | (_lib.TABLE_BATCHED if batched else 0), C.byref(h)))
         self.ctx, self.curve, self.group, self.n, self.handle = ctx, cid, group, n, h
 
     def info(self):

@@ -346,11 +346,16 @@ type Table struct {
 	N uint64
 }
 
-// NewTable pins n bases.
-func (c *Context) NewTable(curve Curve, group int, bases unsafe.Pointer, n uint64) (*Table, error) {
+// NewTable pins n bases.  batched: the table will mostly serve RunBatch (the KZG SRS of a PLONK key, whose commitments come in
+// groups of three): GA_TABLE_BATCHED plans a narrower window.
+func (c *Context) NewTable(curve Curve, group int, bases unsafe.Pointer, n uint64, batched bool) (*Table, error) {
 	t := &Table{N: n}
+	flags := C.uint(0)
+	if batched {
+		flags = C.GA_TABLE_BATCHED
+	}
 	err := call("ga_msm_table_create", func() C.int {
-		return C.ga_msm_table_create(c.h, C.int(curve), C.int(group), bases, C.size_t(n), 0, &t.h)
+		return C.ga_msm_table_create(c.h, C.int(curve), C.int(group), bases, C.size_t(n), flags, &t.h)
 	})
 	if err != nil {
 		return nil, err

@@ -50,10 +50,10 @@ func NewDevice(pk *plonk_bn254.ProvingKey, n uint64, deviceID int) (*Device, err
 		d.Free()
 		return nil, err
 	}
-	if d.srs, err = ctx.NewTable(ga.BN254, ga.G1, sliceData(pk.Kzg.G1), uint64(len(pk.Kzg.G1))); err != nil {
+	if d.srs, err = ctx.NewTable(ga.BN254, ga.G1, sliceData(pk.Kzg.G1), uint64(len(pk.Kzg.G1)), true); err != nil {
 		return fail(err)
 	}
-	if d.srsLagrange, err = ctx.NewTable(ga.BN254, ga.G1, sliceData(pk.KzgLagrange.G1), uint64(len(pk.KzgLagrange.G1))); err != nil {
+	if d.srsLagrange, err = ctx.NewTable(ga.BN254, ga.G1, sliceData(pk.KzgLagrange.G1), uint64(len(pk.KzgLagrange.G1)), true); err != nil {
 		return fail(err)
 	}
 	rho := uint64(4)

@@ -80,7 +80,7 @@ static ga_msm_table* pin_srs(uint64_t seed, size_t count) {
     CHECK(ga_copy_to_host(ctx, h, d, count * G1_AFF));
     CHECK(ga_free(ctx, d));
     ga_msm_table* t = NULL;
-    CHECK(ga_msm_table_create(ctx, PLONK_CURVE, GA_G1, h, count, 0, &t));
+    CHECK(ga_msm_table_create(ctx, PLONK_CURVE, GA_G1, h, count, GA_TABLE_BATCHED, &t)); /* hooks.go: NewTable(..., batched = true) */
     poison(h, count * G1_AFF);
     return t;
 }

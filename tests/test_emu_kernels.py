@@ -581,9 +581,9 @@ def _expect_from_dlogs(c, group, S_host, K_host):
 
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
 @pytest.mark.parametrize("group", [0, 1], ids=["G1", "G2"])
-def test_emu_msm_table_batch(emu_ctx, c, group, n=300, k=3):
+def test_emu_msm_table_batch(emu_ctx, c, group, n=300, k=3, batched=False):
     """ga_msm_table_run_batch: k scalar vectors over one table in one pass == k separate runs == [sum s_i k_i]G; host and device
-    scalars, edge vectors (all zero, all ones), argument validation"""
+    scalars, edge vectors (all zero, all ones), argument validation; batched = the GA_TABLE_BATCHED planning hint"""
     ctx = emu_ctx
     bases, dlogs, scal = _device_inputs(ctx, c, group, n, 0xBA7C + group)
     K = dlogs.to_host((n, 4))
@@ -596,7 +596,7 @@ def test_emu_msm_table_batch(emu_ctx, c, group, n=300, k=3):
         b.free()
     vecs.append(np.zeros((n, 4), dtype=np.uint64))
     vecs.append(np.tile(one, (n, 1)))
-    t = ecc.PrecomputedBases(ctx, c.name, group, bases, n=n)
+    t = ecc.PrecomputedBases(ctx, c.name, group, bases, n=n, batched=batched)
     devs = [ctx.to_device(v) for v in vecs]
     try:
         single = [t.MultiExp(v) for v in vecs]

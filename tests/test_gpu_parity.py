@@ -199,6 +199,23 @@ def test_msm_table_batch_2_18(gpu_ctx, c, group):
     cases.test_emu_msm_table_batch(gpu_ctx, c, group, n=1 << 18, k=3)
 
 
+def test_msm_table_batched_hint_2_22(gpu_ctx):
+    """GA_TABLE_BATCHED on a 2^22-point SRS (BASELINE config 5's size): a narrower window is planned (c = 20 instead of 22) and the
+    batched and single runs over it still equal [sum s_i k_i]G"""
+    c, n = BN254, 1 << 22
+    bases, dlogs, scal = _device_inputs(gpu_ctx, c, 0, n, 0xBA7D)
+    plain = ecc.PrecomputedBases(gpu_ctx, c.name, 0, bases, n=n)
+    hinted = ecc.PrecomputedBases(gpu_ctx, c.name, 0, bases, n=n, batched=True)
+    try:
+        assert plain.info()["window_bits"] == 22 and hinted.info()["window_bits"] == 20, (plain.info(), hinted.info())
+    finally:
+        plain.free()
+        hinted.free()
+        for b in (bases, dlogs, scal):
+            b.free()
+    cases.test_emu_msm_table_batch(gpu_ctx, c, 0, n=n, k=3, batched=True)
+
+
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
 @pytest.mark.parametrize("group", [0, 1], ids=["G1", "G2"])
 @pytest.mark.parametrize("table", [True, False], ids=["table", "raw"])

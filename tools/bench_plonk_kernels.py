@@ -20,7 +20,7 @@ def run(ctx, logn=22, reps=3, reference_count=True):
     lib = ctx.lib
     srs = ctx.malloc(n * 64)
     lib.check(lib.ga_gen_bases(ctx.handle, 0, 0, 0x5EED0007, n, srs.ptr, None))
-    srs_table = ecc.PrecomputedBases(ctx, "bn254", ecc.G1, srs, n=n)   # the KZG SRS is a pinned key
+    srs_table = ecc.PrecomputedBases(ctx, "bn254", ecc.G1, srs, n=n, batched=True)   # the KZG SRS is a pinned key
     polys = [ctx.malloc(n * 32) for _ in range(12)]
     for i, p in enumerate(polys):
         lib.check(lib.ga_gen_scalars(ctx.handle, 0, 100 + i, n, p.ptr))
