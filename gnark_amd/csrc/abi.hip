@@ -268,6 +268,8 @@ void ga_ctx_destroy(ga_ctx* h) {
         hipEventDestroy(s.b);
     }
     for (int l = 0; l < GA_NUM_LANES; l++) hipStreamDestroy(c->lane_stream[l]);
+    for (int l = 0; l < GA_NUM_LANES; l++)
+        if (c->host_pin[l]) hipHostFree(c->host_pin[l]);
     hipStreamDestroy(c->copy_stream);
     hipStreamDestroy(c->slot_stream[0]);
     hipStreamDestroy(c->slot_stream[1]);

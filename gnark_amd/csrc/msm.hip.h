@@ -1419,9 +1419,14 @@ int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, X
     // bucket accumulation: the fast lazy loop, then the tasks it flagged (an exceptional addition: equal or opposite points met)
     // once more with the complete lazy loop, then whatever is left with the exact kernel.  A table on which most tasks were flagged
     // (a DummySetup key: every base the same point) is remembered and gets the complete loop directly from then on.
-    uint32_t h_redo = 0;
-    // the count of flagged tasks is copied into this stack variable asynchronously: every return path, the early error returns
-    // included, must leave with that copy finished
+    uint32_t h_redo_stack = 0;
+    uint32_t* h_redo = ctx->pinned_words();
+    if (!h_redo) h_redo = &h_redo_stack;
+    *h_redo = 0;
+    // the count of flagged tasks travels back asynchronously -- into the lane's pinned words, so that the host keeps launching the merge
+    // and reduction kernels while the bucket kernel runs (a stack variable, pageable, made that copy a host-side wait for the bucket
+    // kernel and every launch after it start from an empty queue).  Every return path, the early error returns included, must leave
+    // with that copy finished
     struct PendingRead {
         hipStream_t st;
         bool pending = false;
@@ -1468,11 +1473,11 @@ int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, X
                            (const uint32_t*)P.task_start, (const uint32_t*)P.task_key_by_id, seg, (const uint32_t*)redo2_list,
                            (const uint32_t*)(redo_count + 1), (const uint32_t*)P.task_dest, bsum);
         GA_KERNEL_CHECK();
-        GA_HIP_CHECK(hipMemcpyAsync(&h_redo, redo_count, 4, hipMemcpyDeviceToHost, st));   // read after the stream's final sync below
+        GA_HIP_CHECK(hipMemcpyAsync(h_redo, redo_count, 4, hipMemcpyDeviceToHost, st));   // read after the stream's final sync below
         redo_read.pending = true;
     }
     auto note_degenerate = [&]() {
-        if (P.table && (uint64_t)h_redo * 4 > P.max_tasks) ctx->mark_degenerate(d_bases);
+        if (P.table && (uint64_t)*h_redo * 4 > P.max_tasks) ctx->mark_degenerate(d_bases);
     };
     {
         StageTimer tm(ctx, "msm_merge");

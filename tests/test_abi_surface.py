@@ -45,6 +45,30 @@ def test_shared_library_exports_every_declared_symbol(built_so):
     assert b"curve" in lib.ga_last_error()
 
 
+@pytest.mark.parametrize("curve", [0, 1], ids=["bn254", "bls12-381"])
+@pytest.mark.parametrize("group", [0, 1], ids=["G1", "G2"])
+def test_host_side_group_arithmetic_of_the_built_library(built_so, curve, group):
+    """the HOST arithmetic of the hipcc-built library (64-bit-limb Montgomery products, field.hip.h `mul_host64` -- the emulation
+    build keeps the device form, so this is the only CPU-side check of it): ga_msm_combine_windows, the Horner step of a raw MSM,
+    on window sums [k_j]G against [sum_j 2^(c j) k_j]G from the C oracle.  No device is touched."""
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle
+    import pyref
+    from gnark_amd import _lib
+    lib = _lib.Library(built_so)
+    r = (pyref.BN254, pyref.BLS12_381)[curve].r
+    rng = np.random.default_rng(77 + 2 * curve + group)
+    for nwin, c in ((1, 22), (4, 13), (13, 20), (16, 16)):
+        ks = [int(x) for x in rng.integers(1, 1 << 40, size=nwin)]
+        W = np.ascontiguousarray(np.stack([oracle.generator_mul(curve, group, k) for k in ks]))
+        out = np.zeros_like(W[0])
+        assert lib.ga_msm_combine_windows(curve, group, W.ctypes.data_as(ctypes.c_void_p), nwin, c, out.ctypes.data_as(ctypes.c_void_p)) == 0
+        want = oracle.generator_mul(curve, group, sum(k << (c * j) for j, k in enumerate(ks)) % r)
+        assert np.array_equal(oracle.jac_to_affine(curve, group, out), oracle.jac_to_affine(curve, group, want)), (nwin, c)
+
+
 def test_no_cpu_fallback_in_package():
     """The product package must not import the oracle or the emulation build."""
     for dirpath, _, files in os.walk(os.path.join(ROOT, "gnark_amd")):
