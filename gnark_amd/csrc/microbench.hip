@@ -115,6 +115,44 @@ __global__ void __launch_bounds__(256) mb_mad_mix(uint32_t* out, uint32_t seed) 
     if (r == 0x12345u) out[threadIdx.x] = r;
 }
 
+// Does the register BANK of a multiply-add's operands matter (four VGPR banks, index mod 4)?  The same 64 multiply-adds per trip with
+// hand-picked registers: SAME = 1 puts both multiplicands and the low word of the accumulator in one bank (v2, v6, v[10:11], v[14:15], ...),
+// SAME = 0 spreads them (v0, v1 against accumulators starting in banks 2 and 0).
+template <int SAME>
+__global__ void __launch_bounds__(256) mb_mad_banks(uint32_t* out, uint32_t seed) {
+    uint32_t r = 0;
+    if (SAME) {
+        asm volatile(
+            "v_mov_b32 v2, %1\n v_mov_b32 v6, %2\n"
+            "v_mov_b32 v10, %1\n v_mov_b32 v11, 0\n v_mov_b32 v14, %2\n v_mov_b32 v15, 0\n v_mov_b32 v18, %1\n v_mov_b32 v19, 0\n v_mov_b32 v22, %2\n v_mov_b32 v23, 0\n"
+            "s_movk_i32 s20, 0x200\n"
+            "1:\n"
+            ".rept 16\n"
+            "v_mad_u64_u32 v[10:11], vcc, v2, v6, v[10:11]\n v_mad_u64_u32 v[14:15], vcc, v2, v6, v[14:15]\n"
+            "v_mad_u64_u32 v[18:19], vcc, v2, v6, v[18:19]\n v_mad_u64_u32 v[22:23], vcc, v2, v6, v[22:23]\n"
+            ".endr\n"
+            "s_sub_u32 s20, s20, 1\n s_cmp_lg_u32 s20, 0\n s_cbranch_scc1 1b\n"
+            "v_add_u32 %0, v10, v14\n v_add_u32 %0, %0, v18\n v_add_u32 %0, %0, v22\n"
+            : "=v"(r) : "v"(seed | 1u), "v"((seed >> 3) | 1u)
+            : "v2", "v6", "v10", "v11", "v14", "v15", "v18", "v19", "v22", "v23", "s20", "vcc", "scc");
+    } else {
+        asm volatile(
+            "v_mov_b32 v0, %1\n v_mov_b32 v1, %2\n"
+            "v_mov_b32 v10, %1\n v_mov_b32 v11, 0\n v_mov_b32 v14, %2\n v_mov_b32 v15, 0\n v_mov_b32 v18, %1\n v_mov_b32 v19, 0\n v_mov_b32 v22, %2\n v_mov_b32 v23, 0\n"
+            "s_movk_i32 s20, 0x200\n"
+            "1:\n"
+            ".rept 16\n"
+            "v_mad_u64_u32 v[10:11], vcc, v0, v1, v[10:11]\n v_mad_u64_u32 v[14:15], vcc, v0, v1, v[14:15]\n"
+            "v_mad_u64_u32 v[18:19], vcc, v0, v1, v[18:19]\n v_mad_u64_u32 v[22:23], vcc, v0, v1, v[22:23]\n"
+            ".endr\n"
+            "s_sub_u32 s20, s20, 1\n s_cmp_lg_u32 s20, 0\n s_cbranch_scc1 1b\n"
+            "v_add_u32 %0, v10, v14\n v_add_u32 %0, %0, v18\n v_add_u32 %0, %0, v22\n"
+            : "=v"(r) : "v"(seed | 1u), "v"((seed >> 3) | 1u)
+            : "v0", "v1", "v10", "v11", "v14", "v15", "v18", "v19", "v22", "v23", "s20", "vcc", "scc");
+    }
+    if (r == 0x12345u) out[threadIdx.x] = r;
+}
+
 // K independent Montgomery products per lane and trip (K = 1: the dependent chain of mb_f29_mul): how much of a product's cost
 // is waiting for its own carries
 template <class P, int K>
@@ -285,6 +323,8 @@ int util_microbench(Ctx* ctx, char* buf, size_t cap) {
     GA_CHECK(run_one(ctx, "mad64_sgpr_operand_Gops", mb_mad_mix<2>, n64, out, d_out, 20));
     GA_CHECK(run_one(ctx, "mad64_with_carry_per8_Gmad", mb_mad_mix<3>, n64, out, d_out, 20));
     GA_CHECK(run_one(ctx, "mad64_reduction_row_Gmad", mb_mad_mix<4>, n64, out, d_out, 20));
+    GA_CHECK(run_one(ctx, "mad64_operands_spread_over_banks_Gops", mb_mad_banks<0>, 64.0 * 512, out, d_out, 20));
+    GA_CHECK(run_one(ctx, "mad64_operands_in_one_bank_Gops", mb_mad_banks<1>, 64.0 * 512, out, d_out, 20));
     GA_CHECK(run_one(ctx, "f29mul_bn254_ilp1_Gmul", (mb_f29_mul_ilp<BN254_Fp, 1>), 2.0 * (MB_ITERS / 8), out, d_out, 20));
     GA_CHECK(run_one(ctx, "f29mul_bn254_ilp2_Gmul", (mb_f29_mul_ilp<BN254_Fp, 2>), 4.0 * (MB_ITERS / 8), out, d_out, 20));
     GA_CHECK(run_one(ctx, "f29mul_bn254_ilp3_Gmul", (mb_f29_mul_ilp<BN254_Fp, 3>), 6.0 * (MB_ITERS / 8), out, d_out, 20));
