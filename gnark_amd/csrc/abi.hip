@@ -5,6 +5,7 @@
 #include <stdlib.h>
 
 #include <memory>
+#include <new>
 #include <vector>
 
 #include "hostops.hip.h"
@@ -20,6 +21,30 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 const char* get_error() { return g_err; }
+
+int abi_exception_code() noexcept {
+    try {
+        throw;   // (Lippincott function: re-raise the exception being handled to classify it)
+    } catch (const std::bad_alloc&) {
+        set_error("out of host memory (std::bad_alloc) under %s", current_entry());
+        return GA_ERR_NOMEM;
+    } catch (const std::exception& e) {
+        set_error("internal error under %s: %s", current_entry(), e.what());
+        return GA_ERR_STATE;
+    } catch (...) {
+        set_error("internal error under %s: unknown exception", current_entry());
+        return GA_ERR_STATE;
+    }
+}
+static thread_local const char* g_entry = "";
+EntryScope::EntryScope(const char* name) : prev(g_entry) { g_entry = name; }
+EntryScope::~EntryScope() { g_entry = prev; }
+const char* current_entry() { return g_entry; }
+static uint64_t fnv1a(const char* s) {
+    uint64_t h = 1469598103934665603ull;
+    for (; *s; s++) h = (h ^ (uint8_t)*s) * 1099511628211ull;
+    return h ? h : 1;
+}
 
 static std::atomic<int> g_table_c{0};
 int table_c_override() { return g_table_c.load(); }
@@ -65,6 +90,9 @@ hipError_t device_malloc_bytes(void** p, size_t bytes) {
 
 int Ctx::scratch_get(const char* base_key, size_t bytes, void** out) {
     // every lane has its own namespace: a lane-1 proof never shares a buffer with the lane-0 work running beside it
+    // GA_FAULT_THROW=<entry point> (tests of the ABI's exception barrier): a host allocation failing deep inside that entry point
+    if (const uint64_t f = tun.fault_throw.load(std::memory_order_relaxed))
+        if (f == fnv1a(current_entry())) throw std::bad_alloc();
     const int lane = current_lane();
     const std::string lane_key = lane ? std::string(base_key) + "@" + std::to_string(lane) : std::string(base_key);
     const char* key = lane_key.c_str();
@@ -119,7 +147,12 @@ void Tunables::read_env() {
     put(ntt_direct, (int)num("GA_NTT_DIRECT", 1));
     put(table_c, (int)num("GA_TABLE_C", 0));
     put(msm_exact_redo, (int)num("GA_MSM_EXACT_REDO", 0));
-    put64(msm_fuse_min, num("GA_MSM_FUSE_MIN", 1ull << 25));
+    put64(msm_fuse_min, num("GA_MSM_FUSE_MIN", 1ull << 21));
+    put(msm_xcd, (int)num("GA_MSM_XCD", 3));
+    {
+        const char* e = getenv("GA_FAULT_THROW");
+        put64(fault_throw, (e && *e) ? fnv1a(e) : 0);
+    }
     const int grp = (int)num("GA_MSM_GROUP", 0);
     put(msm_group, (grp >= 2 && grp <= 256 && (grp & (grp - 1)) == 0) ? grp : 0);
     const uint64_t seg = num("GA_MSM_MIN_SEG", 256);
@@ -172,6 +205,16 @@ static int msm_impl(Ctx* ctx, const void* bases, const void* scalars, size_t n, 
     size_t max_chunk = ((size_t)1 << 31) / (size_t)(win_hi - win_lo) - 1;
     if (ctx->tun.msm_max_chunk > 0 && ctx->tun.msm_max_chunk < max_chunk)   // GA_MSM_MAX_CHUNK, like ICICLE's chunk-cap override (icicle.go:577-584)
         max_chunk = (size_t)ctx->tun.msm_max_chunk;
+    if (!want_windows && n <= max_chunk) {   // the usual case: one launch sequence, the Horner step shares the window reduction's host chain
+        Staged sb{ctx}, ss{ctx};
+        GA_CHECK(sb.stage(bases, n * sizeof(Affine<F>), flags & GA_BASES_ON_DEVICE));
+        GA_CHECK(ss.stage(scalars, n * 32, flags & GA_SCALARS_ON_DEVICE));
+        XYZZ<F> sum;
+        GA_CHECK((msm_windows_device<C, G>(ctx, sb.dev, ss.dev, n, (flags & GA_SCALARS_MONTGOMERY) != 0, c, win_lo, win_hi, &sum, true)));
+        for (int k = 0; k < c * win_lo; k++) sum = dbl(sum);
+        host_store_jac<F>(out, sum);
+        return GA_OK;
+    }
     std::vector<XYZZ<F>> W(win_hi - win_lo, xyzz_inf<F>());
     for (size_t done = 0; done < n || n == 0; ) {
         const size_t cn = n - done < max_chunk ? n - done : max_chunk;
@@ -219,12 +262,14 @@ extern "C" {
 const char* ga_last_error(void) { return get_error(); }
 const char* ga_version(void) { return "gnark_amd 0.1 (gfx950; Groth16/PLONK prover kernels: MSM G1/G2, NTT; BN254, BLS12-381)"; }
 
-int ga_device_count(int* count) {
+int ga_device_count(int* count) try {
+    GA_ABI_ENTRY();
     GA_HIP_CHECK(hipGetDeviceCount(count));
     return GA_OK;
-}
+} GA_ABI_CATCH
 
-int ga_ctx_create(int device, ga_ctx** out) {
+int ga_ctx_create(int device, ga_ctx** out) try {
+    GA_ABI_ENTRY();
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0) {
@@ -236,6 +281,14 @@ int ga_ctx_create(int device, ga_ctx** out) {
         return GA_ERR_INVALID;
     }
     GA_HIP_CHECK(hipSetDevice(device));
+    {
+        hipDeviceProp_t prop;
+        GA_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+        if (prop.warpSize != 64) {   // (common.hip.h: every kernel is written for 64-lane wavefronts)
+            set_error("device %d runs %d-lane wavefronts; libgnark_amd's kernels need 64 (gfx950)", device, prop.warpSize);
+            return GA_ERR_INVALID;
+        }
+    }
     Ctx* c = new Ctx();
     c->device = device;
     hipStream_t* slots[3 + GA_NUM_LANES] = {&c->lane_stream[0], &c->lane_stream[1], &c->lane_stream[2], &c->lane_stream[3],
@@ -255,9 +308,10 @@ int ga_ctx_create(int device, ga_ctx** out) {
     c->tun.read_env();
     *out = reinterpret_cast<ga_ctx*>(c);
     return GA_OK;
-}
+} GA_ABI_CATCH
 
-void ga_ctx_destroy(ga_ctx* h) {
+void ga_ctx_destroy(ga_ctx* h) try {
+    GA_ABI_ENTRY();
     if (!h) return;
     Ctx* c = reinterpret_cast<Ctx*>(h);
     hipSetDevice(c->device);
@@ -274,9 +328,10 @@ void ga_ctx_destroy(ga_ctx* h) {
     hipStreamDestroy(c->slot_stream[0]);
     hipStreamDestroy(c->slot_stream[1]);
     delete c;
-}
+} GA_ABI_CATCH_VOID
 
-int ga_device_info(ga_ctx* h, char* name, size_t name_len, uint64_t* total_bytes, uint64_t* free_bytes) {
+int ga_device_info(ga_ctx* h, char* name, size_t name_len, uint64_t* total_bytes, uint64_t* free_bytes) try {
+    GA_ABI_ENTRY();
     Ctx* c = reinterpret_cast<Ctx*>(h);
     Lock l(c);
     hipDeviceProp_t p;
@@ -287,9 +342,10 @@ int ga_device_info(ga_ctx* h, char* name, size_t name_len, uint64_t* total_bytes
     if (total_bytes) *total_bytes = t;
     if (free_bytes) *free_bytes = f;
     return GA_OK;
-}
+} GA_ABI_CATCH
 
-int ga_malloc(ga_ctx* h, size_t bytes, void** dptr) {
+int ga_malloc(ga_ctx* h, size_t bytes, void** dptr) try {
+    GA_ABI_ENTRY();
     Ctx* c = reinterpret_cast<Ctx*>(h);
     Lock l(c);
     hipError_t e = device_malloc(dptr, bytes ? bytes : 16);
@@ -298,41 +354,46 @@ int ga_malloc(ga_ctx* h, size_t bytes, void** dptr) {
         return GA_ERR_NOMEM;
     }
     return GA_OK;
-}
+} GA_ABI_CATCH
 
-int ga_free(ga_ctx* h, void* dptr) {
+int ga_free(ga_ctx* h, void* dptr) try {
+    GA_ABI_ENTRY();
     Ctx* c = reinterpret_cast<Ctx*>(h);
     Lock l(c);
     GA_HIP_CHECK(hipStreamSynchronize(c->stream));
     GA_HIP_CHECK(hipFree(dptr));
     return GA_OK;
-}
+} GA_ABI_CATCH
 
-int ga_copy_to_device(ga_ctx* h, void* dst, const void* src, size_t bytes) {
+int ga_copy_to_device(ga_ctx* h, void* dst, const void* src, size_t bytes) try {
+    GA_ABI_ENTRY();
     Ctx* c = reinterpret_cast<Ctx*>(h);
     Lock l(c);
     GA_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     GA_HIP_CHECK(hipStreamSynchronize(c->stream));
     return GA_OK;
-}
+} GA_ABI_CATCH
 
-int ga_copy_to_host(ga_ctx* h, void* dst, const void* src, size_t bytes) {
+int ga_copy_to_host(ga_ctx* h, void* dst, const void* src, size_t bytes) try {
+    GA_ABI_ENTRY();
     Ctx* c = reinterpret_cast<Ctx*>(h);
     Lock l(c);
     GA_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     GA_HIP_CHECK(hipStreamSynchronize(c->stream));
     return GA_OK;
-}
+} GA_ABI_CATCH
 
-int ga_sync(ga_ctx* h) {   // (every entry point returns with its own work finished; this waits for both lanes' streams)
+int ga_sync(ga_ctx* h) try {   // (every entry point returns with its own work finished; this waits for both lanes' streams)
+    GA_ABI_ENTRY();
     Ctx* c = reinterpret_cast<Ctx*>(h);
     Lock l(c);
     for (int l = 0; l < GA_NUM_LANES; l++) GA_HIP_CHECK(hipStreamSynchronize(c->lane_stream[l]));
     return GA_OK;
-}
+} GA_ABI_CATCH
 
 // ---- MSM ------------------------------------------------------------------------------------------------
-int ga_msm(ga_ctx* h, int curve, int group, const void* bases, const void* scalars, size_t n, unsigned flags, void* out_jac) {
+int ga_msm(ga_ctx* h, int curve, int group, const void* bases, const void* scalars, size_t n, unsigned flags, void* out_jac) try {
+    GA_ABI_ENTRY();
     Ctx* c = reinterpret_cast<Ctx*>(h);
     if (!c || !out_jac || (n && (!bases || !scalars))) {
         set_error("ga_msm: null argument");
@@ -341,10 +402,11 @@ int ga_msm(ga_ctx* h, int curve, int group, const void* bases, const void* scala
     Lock l(c);
     GA_DISPATCH_CURVE(curve, GA_DISPATCH_GROUP(group, return (msm_impl<C, G>(c, bases, scalars, n, flags, 0, -1, out_jac, nullptr, nullptr, false))));
     return GA_OK;
-}
+} GA_ABI_CATCH
 
 int ga_msm_windows(ga_ctx* h, int curve, int group, const void* bases, const void* scalars, size_t n, unsigned flags, int win_lo,
-                   int win_hi, void* out_windows, int* window_bits, int* num_windows) {
+                   int win_hi, void* out_windows, int* window_bits, int* num_windows) try {
+    GA_ABI_ENTRY();
     Ctx* c = reinterpret_cast<Ctx*>(h);
     if (!c || !out_windows || (n && (!bases || !scalars))) {
         set_error("ga_msm_windows: null argument");
@@ -354,14 +416,16 @@ int ga_msm_windows(ga_ctx* h, int curve, int group, const void* bases, const voi
     GA_DISPATCH_CURVE(curve, GA_DISPATCH_GROUP(group, return (msm_impl<C, G>(c, bases, scalars, n, flags, win_lo, win_hi, out_windows,
                                                                             window_bits, num_windows, true))));
     return GA_OK;
-}
+} GA_ABI_CATCH
 
-int ga_msm_plan(int curve, int group, size_t n, int* window_bits, int* num_windows) {
+int ga_msm_plan(int curve, int group, size_t n, int* window_bits, int* num_windows) try {
+    GA_ABI_ENTRY();
     GA_DISPATCH_CURVE(curve, return msm_plan<C>(group, n, window_bits, num_windows));
     return GA_OK;
-}
+} GA_ABI_CATCH
 
-int ga_msm_combine_windows(int curve, int group, const void* windows, int num_windows, int window_bits, void* out_jac) {
+int ga_msm_combine_windows(int curve, int group, const void* windows, int num_windows, int window_bits, void* out_jac) try {
+    GA_ABI_ENTRY();
     if (!windows || !out_jac || num_windows <= 0 || window_bits <= 0) {
         set_error("ga_msm_combine_windows: bad argument");
         return GA_ERR_INVALID;
@@ -374,7 +438,7 @@ int ga_msm_combine_windows(int curve, int group, const void* windows, int num_wi
                           host_store_jac<F>(out_jac, host_horner(W.data(), num_windows, window_bits));
                       }));
     return GA_OK;
-}
+} GA_ABI_CATCH
 
 // ---- precomputed tables ------------------------------------------------------------------------------------
 struct MsmTable {
@@ -385,14 +449,24 @@ struct MsmTable {
     uint64_t bytes;
 };
 
-int ga_msm_table_create(ga_ctx* h, int curve, int group, const void* bases, size_t n, unsigned flags, ga_msm_table** out) {
+int ga_msm_table_create(ga_ctx* h, int curve, int group, const void* bases, size_t n, unsigned flags, ga_msm_table** out) try {
+    GA_ABI_ENTRY();
     Ctx* c = reinterpret_cast<Ctx*>(h);
     if (!c || !out || !bases || n == 0) {
         set_error("ga_msm_table_create: bad argument");
         return GA_ERR_INVALID;
     }
     Lock l(c);
-    MsmTable* t = new MsmTable{c, curve, group, 0, 0, n, nullptr, 0};
+    struct Owner {   // (the table object and its device memory are released on every way out but the successful one)
+        MsmTable* t;
+        ~Owner() {
+            if (t) {
+                hipFree(t->d_table);
+                delete t;
+            }
+        }
+    } own{new MsmTable{c, curve, group, 0, 0, n, nullptr, 0}};
+    MsmTable* t = own.t;
     int rc = GA_OK;
     GA_DISPATCH_CURVE(curve, GA_DISPATCH_GROUP(group, {
                           typedef typename GroupField<C, G>::F F;
@@ -410,16 +484,14 @@ int ga_msm_table_create(ga_ctx* h, int curve, int group, const void* bases, size
                               rc = GA_ERR_HIP;
                           }
                       }));
-    if (rc != GA_OK) {
-        hipFree(t->d_table);
-        delete t;
-        return rc;
-    }
+    if (rc != GA_OK) return rc;
+    own.t = nullptr;
     *out = reinterpret_cast<ga_msm_table*>(t);
     return GA_OK;
-}
+} GA_ABI_CATCH
 
-void ga_msm_table_destroy(ga_msm_table* th) {
+void ga_msm_table_destroy(ga_msm_table* th) try {
+    GA_ABI_ENTRY();
     MsmTable* t = reinterpret_cast<MsmTable*>(th);
     if (!t) return;
     Lock l(t->ctx);
@@ -427,18 +499,20 @@ void ga_msm_table_destroy(ga_msm_table* th) {
     t->ctx->forget_table(t->d_table);
     hipFree(t->d_table);
     delete t;
-}
+} GA_ABI_CATCH_VOID
 
-int ga_msm_table_info(ga_msm_table* th, int* window_bits, int* num_windows, uint64_t* table_bytes) {
+int ga_msm_table_info(ga_msm_table* th, int* window_bits, int* num_windows, uint64_t* table_bytes) try {
+    GA_ABI_ENTRY();
     MsmTable* t = reinterpret_cast<MsmTable*>(th);
     if (!t) return GA_ERR_INVALID;
     if (window_bits) *window_bits = t->c;
     if (num_windows) *num_windows = t->nwin;
     if (table_bytes) *table_bytes = t->bytes;
     return GA_OK;
-}
+} GA_ABI_CATCH
 
-int ga_msm_table_run(ga_msm_table* th, const void* scalars, unsigned flags, void* out_jac) {
+int ga_msm_table_run(ga_msm_table* th, const void* scalars, unsigned flags, void* out_jac) try {
+    GA_ABI_ENTRY();
     MsmTable* t = reinterpret_cast<MsmTable*>(th);
     if (!t || !scalars || !out_jac) {
         set_error("ga_msm_table_run: null argument");
@@ -455,9 +529,10 @@ int ga_msm_table_run(ga_msm_table* th, const void* scalars, unsigned flags, void
                           host_store_jac<F>(out_jac, sum);
                       }));
     return GA_OK;
-}
+} GA_ABI_CATCH
 
-int ga_msm_table_run_batch(ga_msm_table* th, const void* const* scalars, uint32_t k, unsigned flags, void* out_jacs) {
+int ga_msm_table_run_batch(ga_msm_table* th, const void* const* scalars, uint32_t k, unsigned flags, void* out_jacs) try {
+    GA_ABI_ENTRY();
     MsmTable* t = reinterpret_cast<MsmTable*>(th);
     if (!t || !scalars || !out_jacs || k == 0 || k > 16) {
         set_error("ga_msm_table_run_batch: null argument or batch size %u outside [1, 16]", k);
@@ -490,9 +565,10 @@ int ga_msm_table_run_batch(ga_msm_table* th, const void* const* scalars, uint32_
                           for (uint32_t j = 0; j < k; j++) host_store_jac<F>((char*)out_jacs + j * sizeof(Jac<F>), sums[j]);
                       }));
     return GA_OK;
-}
+} GA_ABI_CATCH
 
-int ga_msm_table_run_windows(ga_msm_table* th, const void* scalars, unsigned flags, int win_lo, int win_hi, void* out_jac) {
+int ga_msm_table_run_windows(ga_msm_table* th, const void* scalars, unsigned flags, int win_lo, int win_hi, void* out_jac) try {
+    GA_ABI_ENTRY();
     MsmTable* t = reinterpret_cast<MsmTable*>(th);
     if (!t || !scalars || !out_jac) {
         set_error("ga_msm_table_run_windows: null argument");
@@ -514,10 +590,11 @@ int ga_msm_table_run_windows(ga_msm_table* th, const void* scalars, unsigned fla
                           host_store_jac<F>(out_jac, sum);
                       }));
     return GA_OK;
-}
+} GA_ABI_CATCH
 
 int ga_fr_linear_combination(ga_ctx* h, int curve, uint64_t n, int k, const void* const* vecs, const void* scalars, void* out,
-                             int on_device) {
+                             int on_device) try {
+    GA_ABI_ENTRY();
     Ctx* c = reinterpret_cast<Ctx*>(h);
     if (!c || !vecs || !scalars || (!out && n)) {
         set_error("ga_fr_linear_combination: null argument");
@@ -531,10 +608,11 @@ int ga_fr_linear_combination(ga_ctx* h, int curve, uint64_t n, int k, const void
     Lock l(c);
     GA_DISPATCH_CURVE(curve, GA_CHECK(fr_vec_lincomb<C>(c, n, k, vecs, scalars, out, on_device != 0)));
     return GA_OK;
-}
+} GA_ABI_CATCH
 
 // p(point) for a polynomial in canonical form (iop.Polynomial.Evaluate / evaluateBlinded, prove.go:1186-1215)
-int ga_fr_poly_evaluate(ga_ctx* h, int curve, const void* poly, uint64_t n, const void* point, void* value_out, int on_device) {
+int ga_fr_poly_evaluate(ga_ctx* h, int curve, const void* poly, uint64_t n, const void* point, void* value_out, int on_device) try {
+    GA_ABI_ENTRY();
     Ctx* c = reinterpret_cast<Ctx*>(h);
     if (!c || (!poly && n) || !point || !value_out) {
         set_error("ga_fr_poly_evaluate: null argument");
@@ -551,10 +629,11 @@ int ga_fr_poly_evaluate(ga_ctx* h, int curve, const void* poly, uint64_t n, cons
     GA_CHECK(c->scratch_get("kzg_quotient", n * 32, &q));
     GA_DISPATCH_CURVE(curve, GA_CHECK(kzg_domain_divide<C>(c, sp.dev, n, point, q, value_out)));
     return GA_OK;
-}
+} GA_ABI_CATCH
 
 // kzg.Open(p, point, pk): claimed value p(point) and the commitment to (p(X) - p(point)) / (X - point) over the pinned SRS
-int ga_kzg_open(ga_msm_table* th, const void* poly, size_t n, unsigned flags, const void* point, void* claimed_value_out, void* h_out) {
+int ga_kzg_open(ga_msm_table* th, const void* poly, size_t n, unsigned flags, const void* point, void* claimed_value_out, void* h_out) try {
+    GA_ABI_ENTRY();
     MsmTable* t = reinterpret_cast<MsmTable*>(th);
     if (!t || !poly || !point || !claimed_value_out || !h_out || n == 0) {
         set_error("ga_kzg_open: null argument or empty polynomial");
@@ -580,26 +659,29 @@ int ga_kzg_open(ga_msm_table* th, const void* poly, size_t n, unsigned flags, co
         host_store_jac<F>(h_out, sum);
     });
     return GA_OK;
-}
+} GA_ABI_CATCH
 
 // ---- host group helpers ---------------------------------------------------------------------------------
-int ga_jac_add(int curve, int group, const void* a, const void* b, void* out) {
+int ga_jac_add(int curve, int group, const void* a, const void* b, void* out) try {
+    GA_ABI_ENTRY();
     GA_DISPATCH_CURVE(curve, GA_DISPATCH_GROUP(group, {
                           typedef typename GroupField<C, G>::F F;
                           host_store_jac<F>(out, add(host_load_jac<F>(a), host_load_jac<F>(b)));
                       }));
     return GA_OK;
-}
+} GA_ABI_CATCH
 
-int ga_jac_to_affine(int curve, int group, const void* a, void* out) {
+int ga_jac_to_affine(int curve, int group, const void* a, void* out) try {
+    GA_ABI_ENTRY();
     GA_DISPATCH_CURVE(curve, GA_DISPATCH_GROUP(group, {
                           typedef typename GroupField<C, G>::F F;
                           host_store_affine<F>(out, host_load_jac<F>(a));
                       }));
     return GA_OK;
-}
+} GA_ABI_CATCH
 
-int ga_jac_scalar_mul(int curve, int group, const void* a, const void* k, void* out) {
+int ga_jac_scalar_mul(int curve, int group, const void* a, const void* k, void* out) try {
+    GA_ABI_ENTRY();
     GA_DISPATCH_CURVE(curve, GA_DISPATCH_GROUP(group, {
                           typedef typename GroupField<C, G>::F F;
                           uint32_t kw[8];
@@ -607,10 +689,11 @@ int ga_jac_scalar_mul(int curve, int group, const void* a, const void* k, void* 
                           host_store_jac<F>(out, scalar_mul(host_load_jac<F>(a), kw, 8));
                       }));
     return GA_OK;
-}
+} GA_ABI_CATCH
 
 // ---- NTT ------------------------------------------------------------------------------------------------
-int ga_domain_create(ga_ctx* h, int curve, uint64_t cardinality, ga_domain** out) {
+int ga_domain_create(ga_ctx* h, int curve, uint64_t cardinality, ga_domain** out) try {
+    GA_ABI_ENTRY();
     Ctx* c = reinterpret_cast<Ctx*>(h);
     if (!c || !out || cardinality == 0) {
         set_error("ga_domain_create: bad argument");
@@ -621,17 +704,19 @@ int ga_domain_create(ga_ctx* h, int curve, uint64_t cardinality, ga_domain** out
     GA_DISPATCH_CURVE(curve, GA_CHECK(ntt_domain_new<C>(c, cardinality, &d)));
     *out = reinterpret_cast<ga_domain*>(d);
     return GA_OK;
-}
+} GA_ABI_CATCH
 
-void ga_domain_destroy(ga_domain* dh) {
+void ga_domain_destroy(ga_domain* dh) try {
+    GA_ABI_ENTRY();
     if (!dh) return;
     Domain* d = reinterpret_cast<Domain*>(dh);
     Lock l(ntt_domain_ctx(d));
     hipStreamSynchronize(ntt_domain_ctx(d)->stream);
     ntt_domain_delete(d);
-}
+} GA_ABI_CATCH_VOID
 
-int ga_fft(ga_domain* dh, void* data, int direction, int decimation, int on_coset, int on_device) {
+int ga_fft(ga_domain* dh, void* data, int direction, int decimation, int on_coset, int on_device) try {
+    GA_ABI_ENTRY();
     Domain* d = reinterpret_cast<Domain*>(dh);
     if (!d || !data || (direction != GA_FFT_FORWARD && direction != GA_FFT_INVERSE) || (decimation != GA_DIF && decimation != GA_DIT)) {
         set_error("ga_fft: bad argument");
@@ -649,9 +734,10 @@ int ga_fft(ga_domain* dh, void* data, int direction, int decimation, int on_cose
     if (!on_device) GA_HIP_CHECK(hipMemcpyAsync(data, dev, bytes, hipMemcpyDeviceToHost, c->stream));
     GA_HIP_CHECK(hipStreamSynchronize(c->stream));
     return GA_OK;
-}
+} GA_ABI_CATCH
 
-int ga_plonk_quotient(ga_domain* dh0, ga_domain* dh1, const ga_plonk_quotient_in* in, void* h_out) {
+int ga_plonk_quotient(ga_domain* dh0, ga_domain* dh1, const ga_plonk_quotient_in* in, void* h_out) try {
+    GA_ABI_ENTRY();
     Domain *d0 = reinterpret_cast<Domain*>(dh0), *d1 = reinterpret_cast<Domain*>(dh1);
     if (!d0 || !d1 || !in || !h_out || !in->l || !in->r || !in->o || !in->z || !in->ql || !in->qr || !in->qm || !in->qo || !in->qk ||
         !in->s1 || !in->s2 || !in->s3 || !in->bl || !in->br || !in->bo || !in->bz || !in->alpha || !in->beta || !in->gamma ||
@@ -684,7 +770,7 @@ int ga_plonk_quotient(ga_domain* dh0, ga_domain* dh1, const ga_plonk_quotient_in
     a.alpha = in->alpha; a.beta = in->beta; a.gamma = in->gamma;
     GA_DISPATCH_CURVE(ntt_domain_curve(d0), GA_CHECK(plonk_domain_quotient<C>(d0, d1, a, h_out)));
     return GA_OK;
-}
+} GA_ABI_CATCH
 
 static int plonk_args_from(const ga_plonk_quotient_in* in, bool need_fixed, bool need_var, PlonkQuotientArgs* a) {
     memset(a, 0, sizeof(*a));
@@ -721,7 +807,8 @@ static int plonk_args_from(const ga_plonk_quotient_in* in, bool need_fixed, bool
     return GA_OK;
 }
 
-int ga_plonk_pk_create(ga_domain* dh0, ga_domain* dh1, const ga_plonk_quotient_in* in, ga_plonk_pk** out) {
+int ga_plonk_pk_create(ga_domain* dh0, ga_domain* dh1, const ga_plonk_quotient_in* in, ga_plonk_pk** out) try {
+    GA_ABI_ENTRY();
     Domain *d0 = reinterpret_cast<Domain*>(dh0), *d1 = reinterpret_cast<Domain*>(dh1);
     if (!d0 || !d1 || !in || !out || ntt_domain_curve(d0) != ntt_domain_curve(d1) || ntt_domain_ctx(d0) != ntt_domain_ctx(d1)) {
         set_error("ga_plonk_pk_create: null argument, or the two domains differ in curve/context");
@@ -735,18 +822,20 @@ int ga_plonk_pk_create(ga_domain* dh0, ga_domain* dh1, const ga_plonk_quotient_i
     GA_DISPATCH_CURVE(ntt_domain_curve(d0), GA_CHECK(plonk_domain_fixed_create<C>(d0, d1, a, &fx)));
     *out = reinterpret_cast<ga_plonk_pk*>(fx);
     return GA_OK;
-}
+} GA_ABI_CATCH
 
-void ga_plonk_pk_destroy(ga_plonk_pk* p) {
+void ga_plonk_pk_destroy(ga_plonk_pk* p) try {
+    GA_ABI_ENTRY();
     PlonkFixed* fx = reinterpret_cast<PlonkFixed*>(p);
     if (!fx) return;
     Ctx* c = ntt_domain_ctx(plonk_fixed_domain0(fx));
     Lock l(c);
     hipStreamSynchronize(c->stream);
     plonk_fixed_delete(fx);
-}
+} GA_ABI_CATCH_VOID
 
-int ga_plonk_quotient_pinned(ga_plonk_pk* p, const ga_plonk_quotient_in* in, void* h_out) {
+int ga_plonk_quotient_pinned(ga_plonk_pk* p, const ga_plonk_quotient_in* in, void* h_out) try {
+    GA_ABI_ENTRY();
     PlonkFixed* fx = reinterpret_cast<PlonkFixed*>(p);
     if (!fx || !in || !h_out) {
         set_error("ga_plonk_quotient_pinned: null argument");
@@ -759,10 +848,11 @@ int ga_plonk_quotient_pinned(ga_plonk_pk* p, const ga_plonk_quotient_in* in, voi
     GA_CHECK(plonk_args_from(in, false, true, &a));
     GA_DISPATCH_CURVE(ntt_domain_curve(d0), GA_CHECK(plonk_domain_quotient_pinned<C>(fx, a, h_out)));
     return GA_OK;
-}
+} GA_ABI_CATCH
 
 int ga_plonk_build_z(ga_domain* dh0, const void* lv, const void* rv, const void* ov, const int64_t* permutation, const void* beta,
-                     const void* gamma, int on_device, void* z_out) {
+                     const void* gamma, int on_device, void* z_out) try {
+    GA_ABI_ENTRY();
     Domain* d0 = reinterpret_cast<Domain*>(dh0);
     if (!d0 || !lv || !rv || !ov || !permutation || !beta || !gamma || !z_out) {
         set_error("ga_plonk_build_z: null argument");
@@ -780,9 +870,10 @@ int ga_plonk_build_z(ga_domain* dh0, const void* lv, const void* rv, const void*
     }
     GA_DISPATCH_CURVE(ntt_domain_curve(d0), GA_CHECK(plonk_domain_build_z<C>(d0, lv, rv, ov, permutation, beta, gamma, on_device != 0, z_out)));
     return GA_OK;
-}
+} GA_ABI_CATCH
 
-int ga_fr_batch_invert(ga_ctx* h, int curve, void* v, uint64_t n, int on_device) {
+int ga_fr_batch_invert(ga_ctx* h, int curve, void* v, uint64_t n, int on_device) try {
+    GA_ABI_ENTRY();
     Ctx* c = reinterpret_cast<Ctx*>(h);
     if (!c || (!v && n)) {
         set_error("ga_fr_batch_invert: null argument");
@@ -791,9 +882,10 @@ int ga_fr_batch_invert(ga_ctx* h, int curve, void* v, uint64_t n, int on_device)
     Lock l(c);
     GA_DISPATCH_CURVE(curve, GA_CHECK(fr_vec_batch_inverse<C>(c, v, n, on_device != 0)));
     return GA_OK;
-}
+} GA_ABI_CATCH
 
-int ga_compute_h(ga_domain* dh, const void* a, const void* b, const void* cc, uint64_t n_constraints, void* h_out, int on_device) {
+int ga_compute_h(ga_domain* dh, const void* a, const void* b, const void* cc, uint64_t n_constraints, void* h_out, int on_device) try {
+    GA_ABI_ENTRY();
     Domain* d = reinterpret_cast<Domain*>(dh);
     if (!d || !a || !b || !cc || !h_out || n_constraints > ntt_domain_size(d)) {
         set_error("ga_compute_h: bad argument (n_constraints must be <= domain cardinality)");
@@ -817,17 +909,19 @@ int ga_compute_h(ga_domain* dh, const void* a, const void* b, const void* cc, ui
     GA_HIP_CHECK(hipMemcpyAsync(h_out, da, full, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
     GA_HIP_CHECK(hipStreamSynchronize(c->stream));
     return GA_OK;
-}
+} GA_ABI_CATCH
 
 // ---- profiling ------------------------------------------------------------------------------------------
-int ga_profile_enable(ga_ctx* h, int on) {
+int ga_profile_enable(ga_ctx* h, int on) try {
+    GA_ABI_ENTRY();
     Ctx* c = reinterpret_cast<Ctx*>(h);
     Lock l(c);
     c->profiling = on != 0;
     return GA_OK;
-}
+} GA_ABI_CATCH
 
-int ga_profile_reset(ga_ctx* h) {
+int ga_profile_reset(ga_ctx* h) try {
+    GA_ABI_ENTRY();
     Ctx* c = reinterpret_cast<Ctx*>(h);
     Lock l(c);
     hipStreamSynchronize(c->stream);
@@ -837,9 +931,10 @@ int ga_profile_reset(ga_ctx* h) {
     }
     c->stages.clear();
     return GA_OK;
-}
+} GA_ABI_CATCH
 
-int ga_profile_read(ga_ctx* h, char* buf, size_t cap) {
+int ga_profile_read(ga_ctx* h, char* buf, size_t cap) try {
+    GA_ABI_ENTRY();
     Ctx* c = reinterpret_cast<Ctx*>(h);
     Lock l(c);
     GA_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -854,41 +949,46 @@ int ga_profile_read(ga_ctx* h, char* buf, size_t cap) {
     if (!buf || cap == 0) return GA_ERR_INVALID;
     snprintf(buf, cap, "%s", out.c_str());
     return GA_OK;
-}
+} GA_ABI_CATCH
 
 // ---- test / bench support -------------------------------------------------------------------------------
-int ga_gen_bases(ga_ctx* h, int curve, int group, uint64_t seed, size_t n, void* bases_dev, void* dlogs_dev) {
+int ga_gen_bases(ga_ctx* h, int curve, int group, uint64_t seed, size_t n, void* bases_dev, void* dlogs_dev) try {
+    GA_ABI_ENTRY();
     Ctx* c = reinterpret_cast<Ctx*>(h);
     Lock l(c);
     GA_DISPATCH_CURVE(curve, GA_DISPATCH_GROUP(group, GA_CHECK((util_gen_bases<C, G>(c, seed, n, bases_dev, dlogs_dev)))));
     GA_HIP_CHECK(hipStreamSynchronize(c->stream));
     return GA_OK;
-}
+} GA_ABI_CATCH
 
-int ga_gen_bases_at(ga_ctx* h, int curve, int group, uint64_t seed, uint64_t first, size_t n, void* bases_dev, void* dlogs_dev) {
+int ga_gen_bases_at(ga_ctx* h, int curve, int group, uint64_t seed, uint64_t first, size_t n, void* bases_dev, void* dlogs_dev) try {
+    GA_ABI_ENTRY();
     Ctx* c = reinterpret_cast<Ctx*>(h);
     Lock l(c);
     GA_DISPATCH_CURVE(curve, GA_DISPATCH_GROUP(group, GA_CHECK((util_gen_bases<C, G>(c, seed, n, bases_dev, dlogs_dev, first)))));
     GA_HIP_CHECK(hipStreamSynchronize(c->stream));
     return GA_OK;
-}
+} GA_ABI_CATCH
 
-int ga_gen_scalars(ga_ctx* h, int curve, uint64_t seed, size_t n, void* scalars_dev) {
+int ga_gen_scalars(ga_ctx* h, int curve, uint64_t seed, size_t n, void* scalars_dev) try {
+    GA_ABI_ENTRY();
     Ctx* c = reinterpret_cast<Ctx*>(h);
     Lock l(c);
     GA_DISPATCH_CURVE(curve, GA_CHECK(util_gen_scalars<C>(c, seed, n, scalars_dev)));
     GA_HIP_CHECK(hipStreamSynchronize(c->stream));
     return GA_OK;
-}
+} GA_ABI_CATCH
 
-int ga_fr_dot(ga_ctx* h, int curve, const void* a_dev, const void* b_dev, size_t n, void* out_host) {
+int ga_fr_dot(ga_ctx* h, int curve, const void* a_dev, const void* b_dev, size_t n, void* out_host) try {
+    GA_ABI_ENTRY();
     Ctx* c = reinterpret_cast<Ctx*>(h);
     Lock l(c);
     GA_DISPATCH_CURVE(curve, GA_CHECK(util_fr_dot<C>(c, a_dev, b_dev, n, out_host)));
     return GA_OK;
-}
+} GA_ABI_CATCH
 
-int ga_fr_vec_mul(ga_ctx* h, int curve, const void* a, const void* b, size_t n, void* out, int on_device) {
+int ga_fr_vec_mul(ga_ctx* h, int curve, const void* a, const void* b, size_t n, void* out, int on_device) try {
+    GA_ABI_ENTRY();
     Ctx* c = reinterpret_cast<Ctx*>(h);
     if (!c || (n && (!a || !b || !out))) {
         set_error("ga_fr_vec_mul: null argument");
@@ -905,9 +1005,10 @@ int ga_fr_vec_mul(ga_ctx* h, int curve, const void* a, const void* b, size_t n, 
     if (!on_device) GA_HIP_CHECK(hipMemcpyAsync(out, d_out, n * 32, hipMemcpyDeviceToHost, c->stream));
     GA_HIP_CHECK(hipStreamSynchronize(c->stream));
     return GA_OK;
-}
+} GA_ABI_CATCH
 
-int ga_generator_mul(int curve, int group, const void* k, void* out_jac) {
+int ga_generator_mul(int curve, int group, const void* k, void* out_jac) try {
+    GA_ABI_ENTRY();
     GA_DISPATCH_CURVE(curve, GA_DISPATCH_GROUP(group, {
                           typedef typename GroupField<C, G>::F F;
                           uint32_t kw[8];
@@ -915,21 +1016,23 @@ int ga_generator_mul(int curve, int group, const void* k, void* out_jac) {
                           host_store_jac<F>(out_jac, scalar_mul(to_xyzz(Generator<C, G>::get()), kw, 8));
                       }));
     return GA_OK;
-}
+} GA_ABI_CATCH
 
-int ga_clock_probe(ga_ctx* h, uint32_t micros, double* mhz_out) {
+int ga_clock_probe(ga_ctx* h, uint32_t micros, double* mhz_out) try {
+    GA_ABI_ENTRY();
     Ctx* c = reinterpret_cast<Ctx*>(h);
     if (!c || !mhz_out || micros == 0) {
         set_error("ga_clock_probe: bad argument");
         return GA_ERR_INVALID;
     }
     return util_clock_probe(c, micros, mhz_out);   // (no context lock: it is meant to run BESIDE whatever holds it)
-}
+} GA_ABI_CATCH
 
-int ga_microbench(ga_ctx* h, char* buf, size_t cap) {
+int ga_microbench(ga_ctx* h, char* buf, size_t cap) try {
+    GA_ABI_ENTRY();
     Ctx* c = reinterpret_cast<Ctx*>(h);
     Lock l(c);
     return util_microbench(c, buf, cap);
-}
+} GA_ABI_CATCH
 
 }  // extern "C"

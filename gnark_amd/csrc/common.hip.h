@@ -19,11 +19,22 @@
 
 namespace ga {
 
+// Every kernel of the library assumes 64-lane wavefronts: lane = tid & 63 and wave = tid >> 6, wave-local LDS exchanges without an
+// s_barrier (wave_lds_sync, the NTT rounds below slot bit 8), a 16-wave scan of 1024 threads (msm_block_excl_scan_1024).  ROCm 7 defines
+// no compile-time wavefront-size macro any more; GFX9 / CDNA (gfx950 included) has no wave32 mode, so the device pass insists on that
+// family here, and ga_ctx_create refuses a device whose hipDeviceProp_t::warpSize is not 64.  GA_REQUIRE_WAVE64() marks the code
+// that would silently compute wrong results on 32-lane waves.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__GFX9__)
+#error "libgnark_amd: the kernels assume the 64-lane wavefronts of GFX9 / CDNA (gfx950); a wave32 target would compile and compute wrong transforms and sorts"
+#endif
+#define GA_REQUIRE_WAVE64() static_assert(true, "64-lane wavefronts: enforced for the whole device pass at the top of common.hip.h")
+
 // Rendezvous of the lanes of ONE wave around LDS traffic among themselves: a wave's LDS instructions are served in issue order, so
 // a ds_write by one lane is visible to a later ds_read of another lane of the same wave without an s_barrier; what is needed is
 // that the compiler keeps the two sides in program order (the fences emit no instruction).  The functional emulation runs lanes as
 // fibers and has them meet for real.
 __device__ __forceinline__ void wave_lds_sync() {
+    GA_REQUIRE_WAVE64();
 #if defined(__HIP_DEVICE_COMPILE__)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -36,6 +47,27 @@ __device__ __forceinline__ void wave_lds_sync() {
 // ---- errors --------------------------------------------------------------------------------------
 void set_error(const char* fmt, ...);
 const char* get_error();
+
+// ---- the exception barrier of the C ABI ------------------------------------------------------------------------------------------
+// No C++ exception may cross an extern "C" entry point (a std::bad_alloc / std::system_error unwinding into cgo aborts the Go
+// process; the reference turns device errors into Go errors, icicle.go:122-208).  EVERY entry point is a function-try-block
+//     int ga_x(...) try { GA_ABI_ENTRY(); ... } GA_ABI_CATCH
+// whose handler maps the exception to an error code + ga_last_error text (abi_exception_code); the RAII guards inside (locks, lanes,
+// slot leases, staged buffers, thread joiners) release on the way out, so the context stays usable.
+// GA_ABI_ENTRY also names the entry point for the fault knob GA_FAULT_THROW=<entry point> (tests only): Ctx::scratch_get then throws
+// std::bad_alloc when called under that entry point on the calling thread.
+int abi_exception_code() noexcept;   // call inside a catch (...) handler
+struct EntryScope {
+    const char* prev;
+    explicit EntryScope(const char* name);
+    ~EntryScope();
+};
+const char* current_entry();         // the innermost entry point of the calling thread ("" outside the library)
+#define GA_ABI_ENTRY() ::ga::EntryScope _ga_entry_scope(__func__)
+#define GA_ABI_CATCH \
+    catch (...) { return ::ga::abi_exception_code(); }
+#define GA_ABI_CATCH_VOID \
+    catch (...) { (void)::ga::abi_exception_code(); }
 
 #define GA_HIP_CHECK(expr)                                                                              \
     do {                                                                                                \
@@ -112,6 +144,9 @@ struct StageRec {
 //   GA_REDUCE_LAZY_MIN    bucket count from which the window reduction runs in the lazy representation
 //   GA_G16_SHARE_MIN_PCT  a Groth16 base vector shares the single witness sort when it covers at least this % of the wires
 //   GA_MSM_MIN_SEG        shortest task length the bucket lists are cut into (points per task)
+//   GA_MSM_FUSE_MIN       (point, window) pairs from which an MSM sorts with the fused two-level sort instead of the library's (2^21)
+//   GA_MSM_XCD            fused sort: bit 0 per-XCD slices in the first level (from 2^24 pairs; bit 2: at any size), bit 1 XCD swizzle in the second (3; A/B knob)
+//   GA_FAULT_THROW        tests: name of an entry point under which the next device-scratch request throws std::bad_alloc
 //   GA_MSM_EXACT_REDO     1: tasks flagged by the fast bucket loop go straight to the exact-arithmetic kernel (tests)
 //   GA_TABLE_C            force the window width of precomputed tables built from now on (experiments; 0 = planned)
 //   GA_G16_LANES          1: a second concurrent ga_g16_prove caller queues for the device instead of proving on its own lanes
@@ -133,8 +168,10 @@ struct Tunables {
     std::atomic<int> table_c{0};
     std::atomic<uint64_t> msm_min_seg{256};
     std::atomic<int> msm_exact_redo{0};
-    std::atomic<uint64_t> msm_fuse_min{1ull << 25};   // pairs from which the digits are fused with the first sort pass (msm.hip.h 1b)
+    std::atomic<uint64_t> msm_fuse_min{1ull << 21};   // pairs from which the digits are fused with the first sort pass (msm.hip.h 1b)
     std::atomic<int> msm_group{0};                   // buckets per running-sum group of the window reduction (0 = MSM_GROUP)
+    std::atomic<uint64_t> fault_throw{0};            // FNV-1a of GA_FAULT_THROW (0 = unset): the entry point under which scratch_get throws (tests)
+    std::atomic<int> msm_xcd{3};                     // fused sort placement: bit 0 per-XCD slices of the first level's groups, bit 1 XCD swizzle of the second level's segments
     void read_env();
 };
 
@@ -312,9 +349,10 @@ static inline int ilog2_u64(uint64_t x) {
 // ---- per-curve entry points; explicitly instantiated in msm_*.hip / ntt_*.hip / util_*.hip -------------
 // MSM: accumulates windows [win_lo, win_hi) of sum scalars[i]*bases[i]; writes (win_hi-win_lo) XYZZ window sums
 // (host memory, XYZZ<F> images).  d_bases / d_scalars are device pointers.
+// combine: h_window_sums receives ONE point, sum_w 2^(c (w - win_lo)) W_w (the Horner step folded into the window reduction's host tail).
 template <class C, int G>
 int msm_windows_device(Ctx* ctx, const void* d_bases, const void* d_scalars, size_t n, bool scalars_mont, int c,
-                       int win_lo, int win_hi, void* h_window_sums);
+                       int win_lo, int win_hi, void* h_window_sums, bool combine = false);
 template <class C>
 int msm_plan(int group, size_t n, int* c, int* nwin);
 // window width for the precomputed-table mode (one shared bucket set; table = nwin x n affine points)

@@ -1789,35 +1789,10 @@ static int prove_multi(G16Pk* const* pks, uint32_t n, const void* w, const void*
 
 using namespace ga;
 
-// no C++ exception may cross the C ABI: host allocations sized from key files / caller arguments are the ones that can throw
-#define GA_NOTHROW_BEGIN try {
-#define GA_NOTHROW_END                                                              \
-    }                                                                               \
-    catch (const std::bad_alloc&) {                                                 \
-        set_error("out of host memory");                                            \
-        return GA_ERR_NOMEM;                                                        \
-    }                                                                               \
-    catch (const std::exception& e) {                                               \
-        set_error("internal error: %s", e.what());                                  \
-        return GA_ERR_STATE;                                                        \
-    }
-
-// The proving entry points construct std::thread helpers and host vectors: a std::system_error / std::bad_alloc must not unwind
-// through the C ABI into cgo (the RAII guards inside release the locks, lanes and slot leases and join the helper on the way out).
-template <class F>
-static int g16_nothrow(F&& body) {
-    GA_NOTHROW_BEGIN
-    return body();
-    GA_NOTHROW_END
-    catch (...) {
-        set_error("internal error: unknown exception");
-        return GA_ERR_STATE;
-    }
-}
-
 extern "C" {
 
-int ga_g16_pk_create(ga_ctx* h, const ga_g16_key* key, ga_g16_pk** out) {
+int ga_g16_pk_create(ga_ctx* h, const ga_g16_key* key, ga_g16_pk** out) try {
+    GA_ABI_ENTRY();
     Ctx* ctx = reinterpret_cast<Ctx*>(h);
     if (!ctx || !key || !out) {
         set_error("ga_g16_pk_create: null argument");
@@ -1825,15 +1800,14 @@ int ga_g16_pk_create(ga_ctx* h, const ga_g16_key* key, ga_g16_pk** out) {
     }
     CtxLock g(ctx);
     G16Pk* pk = nullptr;
-    GA_NOTHROW_BEGIN
     GA_CHECK(pk_create_from_struct(ctx, key, &pk));
-    GA_NOTHROW_END
     *out = reinterpret_cast<ga_g16_pk*>(pk);
     return GA_OK;
-}
+} GA_ABI_CATCH
 
 int ga_g16_builder_create(ga_ctx* h, int curve, uint64_t domain_cardinality, uint64_t nb_wires, uint32_t shard_index,
-                          uint32_t shard_count, ga_g16_builder** out) {
+                          uint32_t shard_count, ga_g16_builder** out) try {
+    GA_ABI_ENTRY();
     Ctx* ctx = reinterpret_cast<Ctx*>(h);
     if (!ctx || !out || (curve != GA_BN254 && curve != GA_BLS12_381) || domain_cardinality == 0) {
         set_error("ga_g16_builder_create: bad argument");
@@ -1853,7 +1827,7 @@ int ga_g16_builder_create(ga_ctx* h, int curve, uint64_t domain_cardinality, uin
     st->shard_count = shard_count;
     *out = reinterpret_cast<ga_g16_builder*>(st);
     return GA_OK;
-}
+} GA_ABI_CATCH
 
 #define GA_STAGE(b)                                     \
     G16Stage* st = reinterpret_cast<G16Stage*>(b);      \
@@ -1863,12 +1837,14 @@ int ga_g16_builder_create(ga_ctx* h, int curve, uint64_t domain_cardinality, uin
     }                                                   \
     CtxLock g(st->ctx)
 
-int ga_g16_builder_reserve(ga_g16_builder* b, int which, uint64_t total_len) {
+int ga_g16_builder_reserve(ga_g16_builder* b, int which, uint64_t total_len) try {
+    GA_ABI_ENTRY();
     GA_STAGE(b);
     return stage_reserve(st, which, total_len);
-}
+} GA_ABI_CATCH
 
-int ga_g16_builder_append(ga_g16_builder* b, int which, const void* points, uint64_t count) {
+int ga_g16_builder_append(ga_g16_builder* b, int which, const void* points, uint64_t count) try {
+    GA_ABI_ENTRY();
     GA_STAGE(b);
     if (count && !points) {
         // skipping is allowed for points that are none of this shard's business
@@ -1887,32 +1863,34 @@ int ga_g16_builder_append(ga_g16_builder* b, int which, const void* points, uint
         return GA_OK;
     }
     return stage_append(st, which, points, count);
-}
+} GA_ABI_CATCH
 
-int ga_g16_builder_set_point(ga_g16_builder* b, int which, const void* affine) {
+int ga_g16_builder_set_point(ga_g16_builder* b, int which, const void* affine) try {
+    GA_ABI_ENTRY();
     GA_STAGE(b);
     return stage_set_point(st, which, affine);
-}
+} GA_ABI_CATCH
 
-int ga_g16_builder_set_infinity(ga_g16_builder* b, int which, const uint8_t* mask, uint64_t nb_wires) {
+int ga_g16_builder_set_infinity(ga_g16_builder* b, int which, const uint8_t* mask, uint64_t nb_wires) try {
+    GA_ABI_ENTRY();
     GA_STAGE(b);
     if ((which != 0 && which != 1) || !mask || nb_wires != st->nb_wires) {
         set_error("ga_g16_builder_set_infinity: which must be 0/1 and the mask must have nbWires = %llu entries", (unsigned long long)st->nb_wires);
         return GA_ERR_INVALID;
     }
-    GA_NOTHROW_BEGIN
     st->inf[which].assign(mask, mask + nb_wires);
-    GA_NOTHROW_END
     st->have_inf[which] = true;
     return GA_OK;
-}
+} GA_ABI_CATCH
 
-int ga_g16_builder_add_commitment_key(ga_g16_builder* b, const void* basis, const void* sigma, uint64_t len) {
+int ga_g16_builder_add_commitment_key(ga_g16_builder* b, const void* basis, const void* sigma, uint64_t len) try {
+    GA_ABI_ENTRY();
     GA_STAGE(b);
     return stage_add_commitment_key(st, basis, sigma, len);
-}
+} GA_ABI_CATCH
 
-int ga_g16_builder_set_k_remove(ga_g16_builder* b, const uint64_t* ids, uint64_t len) {
+int ga_g16_builder_set_k_remove(ga_g16_builder* b, const uint64_t* ids, uint64_t len) try {
+    GA_ABI_ENTRY();
     GA_STAGE(b);
     if (len && !ids) {
         set_error("ga_g16_builder_set_k_remove: null pointer");
@@ -1922,13 +1900,12 @@ int ga_g16_builder_set_k_remove(ga_g16_builder* b, const uint64_t* ids, uint64_t
         set_error("ga_g16_builder_set_k_remove: %llu removed wires for %llu wires", (unsigned long long)len, (unsigned long long)st->nb_wires);
         return GA_ERR_INVALID;
     }
-    GA_NOTHROW_BEGIN
     st->k_remove.assign(ids, ids + len);
-    GA_NOTHROW_END
     return GA_OK;
-}
+} GA_ABI_CATCH
 
-int ga_g16_builder_set_window_shard(ga_g16_builder* b, uint32_t index, uint32_t count) {
+int ga_g16_builder_set_window_shard(ga_g16_builder* b, uint32_t index, uint32_t count) try {
+    GA_ABI_ENTRY();
     GA_STAGE(b);
     if (count == 0 || index >= count) {
         set_error("ga_g16_builder_set_window_shard: index %u must be below count %u", index, count);
@@ -1937,9 +1914,10 @@ int ga_g16_builder_set_window_shard(ga_g16_builder* b, uint32_t index, uint32_t 
     st->win_index = index;
     st->win_count = count;
     return GA_OK;
-}
+} GA_ABI_CATCH
 
-int ga_g16_builder_finish(ga_g16_builder* b, int32_t precompute, ga_g16_pk** out) {
+int ga_g16_builder_finish(ga_g16_builder* b, int32_t precompute, ga_g16_pk** out) try {
+    GA_ABI_ENTRY();
     G16Stage* st = reinterpret_cast<G16Stage*>(b);
     if (!st || !out) {
         set_error("ga_g16_builder_finish: null argument");
@@ -1961,18 +1939,20 @@ int ga_g16_builder_finish(ga_g16_builder* b, int32_t precompute, ga_g16_pk** out
     }
     delete st;   // consumed either way: a failed finish leaves nothing half-built behind
     return rc;
-}
+} GA_ABI_CATCH
 
-void ga_g16_builder_destroy(ga_g16_builder* b) {
+void ga_g16_builder_destroy(ga_g16_builder* b) try {
+    GA_ABI_ENTRY();
     G16Stage* st = reinterpret_cast<G16Stage*>(b);
     if (!st) return;
     Ctx* ctx = st->ctx;
     CtxLock g(ctx);
     hipStreamSynchronize(ctx->stream);
     delete st;
-}
+} GA_ABI_CATCH_VOID
 
-void ga_g16_pk_destroy(ga_g16_pk* p) {
+void ga_g16_pk_destroy(ga_g16_pk* p) try {
+    GA_ABI_ENTRY();
     G16Pk* pk = reinterpret_cast<G16Pk*>(p);
     if (!pk) return;
     {   // wait for every entry point still working on this key (provers on other lanes, epilogues outside the device lock)
@@ -1983,7 +1963,7 @@ void ga_g16_pk_destroy(ga_g16_pk* p) {
     CtxLock g(pk->ctx);
     for (int l = 0; l < GA_NUM_LANES; l++) hipStreamSynchronize(pk->ctx->lane_stream[l]);
     pk_free(pk);
-}
+} GA_ABI_CATCH_VOID
 
 static int g16_prove_impl(ga_g16_pk* p, const void* w, const void* a, const void* b, const void* c, uint64_t n_constraints,
                  uint64_t nb_public, const void* r, const void* s, void* proof_out) {
@@ -2040,7 +2020,8 @@ static int g16_prove_impl(ga_g16_pk* p, const void* w, const void* a, const void
 // out[0..3] = ga_g16_prove calls of this context that ran on lanes 0/1, on lanes 2/3 beside another proof, that staged their
 // inputs and queued for the device, and proofs whose H side ran on a partner lane (any entry point); out[4..5] = device bytes
 // of scratch held by lanes 0/1 and by lanes 2/3
-int ga_g16_lane_stats(ga_ctx* h, uint64_t* out6) {
+int ga_g16_lane_stats(ga_ctx* h, uint64_t* out6) try {
+    GA_ABI_ENTRY();
     Ctx* ctx = reinterpret_cast<Ctx*>(h);
     if (!ctx || !out6) {
         set_error("ga_g16_lane_stats: null argument");
@@ -2058,7 +2039,7 @@ int ga_g16_lane_stats(ga_ctx* h, uint64_t* out6) {
         out6[lane < 2 ? 4 : 5] += kv.second.second;
     }
     return GA_OK;
-}
+} GA_ABI_CATCH
 
 static int g16_prove_partial_impl(ga_g16_pk* p, const void* w, const void* a, const void* b, const void* c, uint64_t n_constraints,
                          uint64_t nb_public, void* partials_out) {
@@ -2085,7 +2066,8 @@ static int g16_prove_partial_impl(ga_g16_pk* p, const void* w, const void* a, co
     return GA_OK;
 }
 
-int ga_g16_finish(ga_g16_pk* p, const void* partials_sum, const void* r, const void* s, void* proof_out) {
+int ga_g16_finish(ga_g16_pk* p, const void* partials_sum, const void* r, const void* s, void* proof_out) try {
+    GA_ABI_ENTRY();
     G16Pk* pk = reinterpret_cast<G16Pk*>(p);
     if (!pk || !partials_sum || !r || !s || !proof_out) {
         set_error("ga_g16_finish: null argument");
@@ -2100,10 +2082,11 @@ int ga_g16_finish(ga_g16_pk* p, const void* partials_sum, const void* r, const v
                          host_load_jac<F2>(i + 3 * sizeof(Jac<F1>)), r, s, proof_out);
     });
     return GA_OK;
-}
+} GA_ABI_CATCH
 
 // ---- pieces of a sharded proof (multi-GPU orchestration by the caller: gnark_amd/multigpu.py over RCCL, or ga_g16_prove_multi) ----
-int ga_g16_shard_layout(ga_g16_pk* p, uint64_t* out6) {
+int ga_g16_shard_layout(ga_g16_pk* p, uint64_t* out6) try {
+    GA_ABI_ENTRY();
     G16Pk* pk = reinterpret_cast<G16Pk*>(p);
     uint64_t* out8 = out6;
     if (!pk || !out6) {
@@ -2119,7 +2102,7 @@ int ga_g16_shard_layout(ga_g16_pk* p, uint64_t* out6) {
     out8[6] = pk->win_index;
     out8[7] = pk->win_count;
     return GA_OK;
-}
+} GA_ABI_CATCH
 
 static int g16_witness_partial_impl(ga_g16_pk* p, const void* w, uint64_t nb_public, void* partials_out) {
     G16Pk* pk = reinterpret_cast<G16Pk*>(p);
@@ -2149,7 +2132,8 @@ static int g16_witness_partial_impl(ga_g16_pk* p, const void* w, uint64_t nb_pub
     return GA_OK;
 }
 
-int ga_g16_h_chain(ga_g16_pk* p, const void* v, uint64_t n_constraints, void* out_dev) {
+int ga_g16_h_chain(ga_g16_pk* p, const void* v, uint64_t n_constraints, void* out_dev) try {
+    GA_ABI_ENTRY();
     G16Pk* pk = reinterpret_cast<G16Pk*>(p);
     if (!pk || !v || !out_dev) {
         set_error("ga_g16_h_chain: null argument");
@@ -2161,9 +2145,10 @@ int ga_g16_h_chain(ga_g16_pk* p, const void* v, uint64_t n_constraints, void* ou
     GA_DISPATCH_CURVE(pk->curve, GA_CHECK(ntt_domain_h_chain<C>(pk->dom, out_dev)));
     GA_HIP_CHECK(hipStreamSynchronize(pk->ctx->work_stream()));   // the buffer is handed to another stream / device next
     return GA_OK;
-}
+} GA_ABI_CATCH
 
-int ga_g16_h_chain_dev(ga_g16_pk* p, void* buf_dev, uint64_t n_constraints) {
+int ga_g16_h_chain_dev(ga_g16_pk* p, void* buf_dev, uint64_t n_constraints) try {
+    GA_ABI_ENTRY();
     G16Pk* pk = reinterpret_cast<G16Pk*>(p);
     if (!pk || !buf_dev) {
         set_error("ga_g16_h_chain_dev: null argument");
@@ -2182,9 +2167,10 @@ int ga_g16_h_chain_dev(ga_g16_pk* p, void* buf_dev, uint64_t n_constraints) {
     GA_DISPATCH_CURVE(pk->curve, GA_CHECK(ntt_domain_h_chain<C>(pk->dom, buf_dev)));
     GA_HIP_CHECK(hipStreamSynchronize(st));
     return GA_OK;
-}
+} GA_ABI_CATCH
 
-int ga_g16_h_combine(ga_g16_pk* p, void* a_dev, const void* b_dev, const void* c_dev) {
+int ga_g16_h_combine(ga_g16_pk* p, void* a_dev, const void* b_dev, const void* c_dev) try {
+    GA_ABI_ENTRY();
     G16Pk* pk = reinterpret_cast<G16Pk*>(p);
     if (!pk || !a_dev || !b_dev || !c_dev) {
         set_error("ga_g16_h_combine: null argument");
@@ -2195,9 +2181,10 @@ int ga_g16_h_combine(ga_g16_pk* p, void* a_dev, const void* b_dev, const void* c
     GA_DISPATCH_CURVE(pk->curve, GA_CHECK(ntt_domain_h_combine<C>(pk->dom, a_dev, b_dev, c_dev)));
     GA_HIP_CHECK(hipStreamSynchronize(pk->ctx->work_stream()));
     return GA_OK;
-}
+} GA_ABI_CATCH
 
-int ga_g16_z_partial(ga_g16_pk* p, const void* h_slice_dev, void* partial_out) {
+int ga_g16_z_partial(ga_g16_pk* p, const void* h_slice_dev, void* partial_out) try {
+    GA_ABI_ENTRY();
     G16Pk* pk = reinterpret_cast<G16Pk*>(p);
     if (!pk || (!h_slice_dev && pk->len_z) || !partial_out) {
         set_error("ga_g16_z_partial: null argument");
@@ -2212,7 +2199,7 @@ int ga_g16_z_partial(ga_g16_pk* p, const void* h_slice_dev, void* partial_out) {
         host_store_jac<F1>(partial_out, z);
     });
     return GA_OK;
-}
+} GA_ABI_CATCH
 
 static int g16_prove_multi_impl(ga_g16_pk* const* keys, uint32_t n, const void* w, const void* a, const void* b, const void* c,
                        uint64_t n_constraints, uint64_t nb_public, const void* r, const void* s, void* proof_out) {
@@ -2270,16 +2257,15 @@ static int pk_read_any(ga_ctx* h, int curve, ByteSource& src, int32_t precompute
     }
     CtxLock g(ctx);
     G16Pk* pk = nullptr;
-    GA_NOTHROW_BEGIN
     GA_DISPATCH_CURVE(curve, GA_CHECK(pk_read<C>(ctx, src, precompute, shard_index, shard_count, k_remove, len_k_remove, &pk)));
-    GA_NOTHROW_END
     *out = reinterpret_cast<ga_g16_pk*>(pk);
     if (bytes_read) *bytes_read = src.consumed;
     return GA_OK;
 }
 
 int ga_g16_pk_read_mem(ga_ctx* h, int curve, const uint8_t* data, size_t len, int32_t precompute, uint32_t shard_index, uint32_t shard_count,
-                       const uint64_t* k_remove, uint64_t len_k_remove, ga_g16_pk** out, uint64_t* bytes_read) {
+                       const uint64_t* k_remove, uint64_t len_k_remove, ga_g16_pk** out, uint64_t* bytes_read) try {
+    GA_ABI_ENTRY();
     if (!data) {
         set_error("ga_g16_pk_read_mem: null data");
         return GA_ERR_INVALID;
@@ -2288,10 +2274,11 @@ int ga_g16_pk_read_mem(ga_ctx* h, int curve, const uint8_t* data, size_t len, in
     src.mem = data;
     src.mem_len = len;
     return pk_read_any(h, curve, src, precompute, shard_index, shard_count, k_remove, len_k_remove, out, bytes_read);
-}
+} GA_ABI_CATCH
 
 int ga_g16_pk_read_fd(ga_ctx* h, int curve, int fd, int32_t precompute, uint32_t shard_index, uint32_t shard_count, const uint64_t* k_remove,
-                      uint64_t len_k_remove, ga_g16_pk** out, uint64_t* bytes_read) {
+                      uint64_t len_k_remove, ga_g16_pk** out, uint64_t* bytes_read) try {
+    GA_ABI_ENTRY();
     if (fd < 0) {
         set_error("ga_g16_pk_read_fd: bad file descriptor");
         return GA_ERR_INVALID;
@@ -2299,9 +2286,10 @@ int ga_g16_pk_read_fd(ga_ctx* h, int curve, int fd, int32_t precompute, uint32_t
     ByteSource src;
     src.fd = fd;
     return pk_read_any(h, curve, src, precompute, shard_index, shard_count, k_remove, len_k_remove, out, bytes_read);
-}
+} GA_ABI_CATCH
 
-int ga_g16_key_write_fd(ga_ctx* h, const ga_g16_key* key, int format, int fd, uint64_t* bytes_written) {
+int ga_g16_key_write_fd(ga_ctx* h, const ga_g16_key* key, int format, int fd, uint64_t* bytes_written) try {
+    GA_ABI_ENTRY();
     Ctx* ctx = reinterpret_cast<Ctx*>(h);
     if (!ctx || !key || fd < 0 || format < GA_KEY_FORMAT_COMPRESSED || format > GA_KEY_FORMAT_DUMP) {
         set_error("ga_g16_key_write_fd: bad argument");
@@ -2319,19 +2307,21 @@ int ga_g16_key_write_fd(ga_ctx* h, const ga_g16_key* key, int format, int fd, ui
     GA_DISPATCH_CURVE(key->curve, GA_CHECK(key_write<C>(ctx, key, format, dst)));
     if (bytes_written) *bytes_written = dst.written;
     return GA_OK;
-}
+} GA_ABI_CATCH
 
 int ga_g16_proof_unmarshal(int curve, const uint8_t* data, size_t len, void* proof_out, void* commitments_out, uint32_t max_commitments,
-                           uint32_t* n_commitments, void* pok_out, size_t* consumed) {
+                           uint32_t* n_commitments, void* pok_out, size_t* consumed) try {
+    GA_ABI_ENTRY();
     if (!data || !proof_out) {
         set_error("ga_g16_proof_unmarshal: null argument");
         return GA_ERR_INVALID;
     }
     GA_DISPATCH_CURVE(curve, return proof_unmarshal<C>(data, len, proof_out, commitments_out, max_commitments, n_commitments, pok_out, consumed));
     return GA_OK;
-}
+} GA_ABI_CATCH
 
-int ga_point_unmarshal(int curve, int group, const uint8_t* data, size_t len, void* affine_out, size_t* consumed) {
+int ga_point_unmarshal(int curve, int group, const uint8_t* data, size_t len, void* affine_out, size_t* consumed) try {
+    GA_ABI_ENTRY();
     if (!data || !affine_out) {
         set_error("ga_point_unmarshal: null argument");
         return GA_ERR_INVALID;
@@ -2351,38 +2341,42 @@ int ga_point_unmarshal(int curve, int group, const uint8_t* data, size_t len, vo
     memcpy(affine_out, img.data(), img.size());
     if (consumed) *consumed = src.mem_pos;
     return GA_OK;
-}
+} GA_ABI_CATCH
 
-int ga_g16_proof_marshal(int curve, const void* proof, uint8_t* out, size_t cap, size_t* len) {
+int ga_g16_proof_marshal(int curve, const void* proof, uint8_t* out, size_t cap, size_t* len) try {
+    GA_ABI_ENTRY();
     if (!proof || !out || !len) {
         set_error("ga_g16_proof_marshal: null argument");
         return GA_ERR_INVALID;
     }
     GA_DISPATCH_CURVE(curve, return marshal<C>(proof, nullptr, 0, nullptr, out, cap, len));
     return GA_OK;
-}
+} GA_ABI_CATCH
 
 int ga_g16_proof_marshal_bsb22(int curve, const void* proof, const void* commitments, uint32_t n, const void* pok, uint8_t* out,
-                               size_t cap, size_t* len) {
+                               size_t cap, size_t* len) try {
+    GA_ABI_ENTRY();
     if (!proof || !out || !len || (n && !commitments)) {
         set_error("ga_g16_proof_marshal_bsb22: null argument");
         return GA_ERR_INVALID;
     }
     GA_DISPATCH_CURVE(curve, return marshal<C>(proof, commitments, n, pok, out, cap, len));
     return GA_OK;
-}
+} GA_ABI_CATCH
 
 int ga_g16_proof_marshal_raw(int curve, const void* proof, const void* commitments, uint32_t n, const void* pok, uint8_t* out,
-                             size_t cap, size_t* len) {
+                             size_t cap, size_t* len) try {
+    GA_ABI_ENTRY();
     if (!proof || !out || !len || (n && !commitments)) {
         set_error("ga_g16_proof_marshal_raw: null argument");
         return GA_ERR_INVALID;
     }
     GA_DISPATCH_CURVE(curve, return marshal<C>(proof, commitments, n, pok, out, cap, len, true));
     return GA_OK;
-}
+} GA_ABI_CATCH
 
-int ga_g1_marshal_uncompressed(int curve, const void* affine, uint8_t* out, size_t cap, size_t* len) {
+int ga_g1_marshal_uncompressed(int curve, const void* affine, uint8_t* out, size_t cap, size_t* len) try {
+    GA_ABI_ENTRY();
     if (!affine || !out || !len) {
         set_error("ga_g1_marshal_uncompressed: null argument");
         return GA_ERR_INVALID;
@@ -2406,9 +2400,10 @@ int ga_g1_marshal_uncompressed(int curve, const void* affine, uint8_t* out, size
         *len = 2 * nb;
     });
     return GA_OK;
-}
+} GA_ABI_CATCH
 
-int ga_g16_commit(ga_g16_pk* p, uint32_t index, const void* values, uint64_t n_values, void* commitment_out, void* pok_out) {
+int ga_g16_commit(ga_g16_pk* p, uint32_t index, const void* values, uint64_t n_values, void* commitment_out, void* pok_out) try {
+    GA_ABI_ENTRY();
     G16Pk* pk = reinterpret_cast<G16Pk*>(p);
     if (!pk || (!values && n_values) || !commitment_out || !pok_out) {
         set_error("ga_g16_commit: null argument");
@@ -2418,31 +2413,36 @@ int ga_g16_commit(ga_g16_pk* p, uint32_t index, const void* values, uint64_t n_v
     CtxLock g(pk->ctx);
     GA_DISPATCH_CURVE(pk->curve, return commit<C>(pk, index, values, n_values, commitment_out, pok_out));
     return GA_OK;
-}
+} GA_ABI_CATCH
 
-int ga_g16_fold_pok(int curve, const void* poks, uint64_t n, const void* challenge, void* out) {
+int ga_g16_fold_pok(int curve, const void* poks, uint64_t n, const void* challenge, void* out) try {
+    GA_ABI_ENTRY();
     if ((!poks && n) || !challenge || !out) {
         set_error("ga_g16_fold_pok: null argument");
         return GA_ERR_INVALID;
     }
     GA_DISPATCH_CURVE(curve, return fold_pok<C>(poks, n, challenge, out));
     return GA_OK;
-}
+} GA_ABI_CATCH
 
 
 int ga_g16_prove(ga_g16_pk* p, const void* w, const void* a, const void* b, const void* c, uint64_t n_constraints,
-                 uint64_t nb_public, const void* r, const void* s, void* proof_out) {
-    return g16_nothrow([&]() { return g16_prove_impl(p, w, a, b, c, n_constraints, nb_public, r, s, proof_out); });
-}
+                 uint64_t nb_public, const void* r, const void* s, void* proof_out) try {
+    GA_ABI_ENTRY();
+    return g16_prove_impl(p, w, a, b, c, n_constraints, nb_public, r, s, proof_out);
+} GA_ABI_CATCH
 int ga_g16_prove_partial(ga_g16_pk* p, const void* w, const void* a, const void* b, const void* c, uint64_t n_constraints,
-                         uint64_t nb_public, void* partials_out) {
-    return g16_nothrow([&]() { return g16_prove_partial_impl(p, w, a, b, c, n_constraints, nb_public, partials_out); });
-}
-int ga_g16_witness_partial(ga_g16_pk* p, const void* w, uint64_t nb_public, void* partials_out) {
-    return g16_nothrow([&]() { return g16_witness_partial_impl(p, w, nb_public, partials_out); });
-}
+                         uint64_t nb_public, void* partials_out) try {
+    GA_ABI_ENTRY();
+    return g16_prove_partial_impl(p, w, a, b, c, n_constraints, nb_public, partials_out);
+} GA_ABI_CATCH
+int ga_g16_witness_partial(ga_g16_pk* p, const void* w, uint64_t nb_public, void* partials_out) try {
+    GA_ABI_ENTRY();
+    return g16_witness_partial_impl(p, w, nb_public, partials_out);
+} GA_ABI_CATCH
 int ga_g16_prove_multi(ga_g16_pk* const* keys, uint32_t n, const void* w, const void* a, const void* b, const void* c,
-                       uint64_t n_constraints, uint64_t nb_public, const void* r, const void* s, void* proof_out) {
-    return g16_nothrow([&]() { return g16_prove_multi_impl(keys, n, w, a, b, c, n_constraints, nb_public, r, s, proof_out); });
-}
+                       uint64_t n_constraints, uint64_t nb_public, const void* r, const void* s, void* proof_out) try {
+    GA_ABI_ENTRY();
+    return g16_prove_multi_impl(keys, n, w, a, b, c, n_constraints, nb_public, r, s, proof_out);
+} GA_ABI_CATCH
 }  // extern "C"

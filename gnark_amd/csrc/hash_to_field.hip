@@ -136,19 +136,21 @@ static int hash_to_field(const uint8_t* msg, size_t msg_len, const uint8_t* dst,
 
 using namespace ga;
 
-extern "C" int ga_hash_to_field(int curve, const uint8_t* msg, size_t msg_len, const uint8_t* dst, size_t dst_len, uint32_t count, void* out) {
+extern "C" int ga_hash_to_field(int curve, const uint8_t* msg, size_t msg_len, const uint8_t* dst, size_t dst_len, uint32_t count, void* out) try {
+    GA_ABI_ENTRY();
     if ((!msg && msg_len) || (!dst && dst_len) || !out) {
         set_error("ga_hash_to_field: null argument");
         return GA_ERR_INVALID;
     }
     GA_DISPATCH_CURVE(curve, return hash_to_field<C>(msg, msg_len, dst, dst_len, count, out));
     return GA_OK;
-}
+} GA_ABI_CATCH
 
 // exposed for the fixture test of the expand_test.go vectors
-extern "C" int ga_expand_message_xmd(const uint8_t* msg, size_t msg_len, const uint8_t* dst, size_t dst_len, size_t n, uint8_t* out) {
+extern "C" int ga_expand_message_xmd(const uint8_t* msg, size_t msg_len, const uint8_t* dst, size_t dst_len, size_t n, uint8_t* out) try {
+    GA_ABI_ENTRY();
     std::vector<uint8_t> v;
     GA_CHECK(expand_message_xmd(msg, msg_len, dst, dst_len, n, &v));
     memcpy(out, v.data(), n);
     return GA_OK;
-}
+} GA_ABI_CATCH

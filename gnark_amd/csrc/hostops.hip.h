@@ -68,6 +68,13 @@ int host_msm(Ctx* ctx, const void* d_bases, const void* d_scalars, size_t n, boo
     GA_CHECK(msm_plan<C>(G, n, &c, &nwin));
     int lo = 0, hi = nwin;
     window_share(nwin, win_index, win_count ? win_count : 1, &lo, &hi);
+    if (hi > lo && n > 0 && n <= ((size_t)1 << 31) / (size_t)(hi - lo) - 1) {   // one launch sequence: Horner folded into the reduction's host tail
+        XYZZ<F> sum;
+        GA_CHECK((msm_windows_device<C, G>(ctx, d_bases, d_scalars, n, mont, c, lo, hi, &sum, true)));
+        for (int k = 0; k < c * lo; k++) sum = dbl(sum);
+        *out = sum;
+        return GA_OK;
+    }
     std::vector<XYZZ<F>> W(nwin, xyzz_inf<F>());
     if (hi > lo && n > 0) {
         const size_t max_chunk = ((size_t)1 << 31) / (size_t)(hi - lo) - 1;

@@ -10,7 +10,7 @@
 //                          witness cost nothing downstream.
 //   2. radix sort          of the pairs by key (rocprim onesweep on the significant bits only, msm_sort_pairs) -- the utility
 //                          step; after it every bucket is a contiguous run of point indices.
-//   3. msm_offsets_kernel  bucket boundaries by binary search; msm_tasks_kernel splits buckets into tasks of at most
+//   3. msm_offsets_tasks_kernel  bucket boundaries by binary search; buckets are split into tasks of at most
 //                          SEG points so that a hot bucket (witness values 0/1 make bucket 1 of window 0 huge) is spread
 //                          over many lanes; exclusive scan gives the task table.
 //   4. msm_accumulate_kernel  one lane per task: gathers its affine bases (16 B/lane vector loads), XYZZ mixed adds.
@@ -127,39 +127,49 @@ __global__ void msm_digits_kernel(const uint32_t* __restrict__ scalars, uint64_t
     }
 }
 
-// ---- 1b. digits fused with the first pass of the radix sort (large shared bucket sets) ----------------------------------------
+// ---- 1b. digits fused with the first level of the sort (large bucket sets) ------------------------------------------------------
 // The plain sequence writes the (key, value) pairs in scalar order (1.6 GB at 12 x 2^24), reads the keys for the histograms and
-// reads / scatters the pairs twice (two 11-bit onesweep passes).  Here the FIRST LSD pass -- a partition by the low BITS (11 or 12) key
-// bits -- is made by the kernel that extracts the digits: a histogram of the low key bits straight from the scalars (digits are
-// cheap to recompute: nothing is written), then a tile of <= 1024 scalars x windows is partitioned in LDS and leaves the CU as one
-// run per (tile, bin); the second level (1c below) finishes the grouping without the library.
-// The order inside a bin is not the input order (ranks come from LDS atomics) -- irrelevant for a first pass.  Any key distribution
-// works: a bin's slice of the output is reserved with one global atomic per (tile, bin).
+// reads / scatters the pairs twice (two 11-bit onesweep passes).  Here the FIRST level -- a partition into at most 2^BITS groups of
+// consecutive keys -- is made by the kernel that extracts the digits: a histogram of the groups straight from the scalars (digits
+// are cheap to recompute: nothing is written), then a tile of <= 1024 scalars x windows is partitioned in LDS and leaves the CU as
+// one run per (tile, group); the second level (1c below) finishes the grouping without the library.
+// The order inside a group is not the input order (ranks come from LDS atomics) -- irrelevant for a first level.  Any key distribution
+// works: a group's slice of the output is reserved with one global atomic per (tile, group).
 // Measured at 12 x 2^24 pairs (tools/exp/partbench.hip, profiles/README.md round 3 batch ZZ2): digits 0.37 + sort 3.62 ms ->
-// histogram 0.19 + digits/first pass 1.38 + one library pass for the high bits 1.87 ms (1c replaces that pass: 1.41 ms).
+// histogram 0.19 + digits/first pass 1.38 + one library pass for the other bits 1.87 ms (1c replaces that pass).
 constexpr int MSM_P1_THREADS = 1024;
 constexpr int MSM_P1_MAXW = 16;                       // windows a thread keeps in registers
 constexpr uint32_t MSM_P1_ENTRIES = 1024 * 13;        // pairs staged per tile: 104 KB of LDS (+ 16 / 32 KB of bin tables)
 constexpr uint32_t MSM_P2_SEG = 16384;                // pairs per second-level segment
-constexpr uint32_t MSM_P2_HB = 4104;                  // capacity for the high key parts of the second level
-// Key width.  The first level splits off the low BITS key bits, the second level handles hb = (nb >> BITS) + 1 high parts in LDS.
-// BITS = 11 while those fit (key spaces below 2^23: a table's 2^21 shared buckets -> hb = 1025, PLONK's three bucket sets of a
-// batched commitment -> 3073, the 13 x 2^19 buckets of a raw 2^24 MSM -> 3329), BITS = 12 up to 2^24 keys (round 4; round 3
-// stopped at 22 key bits and one scalar vector, and those two callers fell back to the library sort).
-static inline int msm_p1_bits(uint64_t nb) { return (nb >> 11) + 1 <= MSM_P2_HB ? 11 : 12; }
+constexpr uint32_t MSM_P2_HB = 4104;                  // capacity for the key parts the second level counts in LDS
+constexpr uint32_t MSM_XCDS = 8;                      // XCDs of the device: block b is observed to run on XCD b % 8 (a speed assumption only)
+// How a key splits between the two levels: the first level groups by key >> low (at most 2^BITS groups), the second level counts the
+// 2^low <= 4096 low parts of a group's keys.  A group owns a CONTIGUOUS key range, hence a contiguous slice of the per-key counters,
+// of the cursors and of the sorted output: a segment's atomics are consecutive words and its runs land inside the group's own slice.
+// (Rounds 3 and 4 split the other way round -- first level on the low 11 / 12 key bits -- which spreads one segment's counters and
+// runs 2^BITS keys apart: one memory transaction per (segment, key) three times over.  Same box, 2^24 points,
+// profiles/r05_a_sort_ab_2p24.txt: second level 4.06 -> 1.38 ms on the 13 x 2^19 keys of un-pinned bases, 1.44 -> 1.08 ms on a
+// table's 2^21 keys; with the XCD placement below 1.15 / 0.98 ms and the first level 1.80 -> 1.44 / 1.73 -> 1.28 ms.)
+// BITS = 11 while 2^12 low parts suffice, else 12 (key spaces up to 2^24).
+static inline int msm_p1_bits(uint64_t nb) { return (nb >> 12) + 1 <= 2048 ? 11 : 12; }
 static inline bool msm_fused_fits(uint64_t nb) {
     const int b = msm_p1_bits(nb);
-    return nb >= (1ull << b) && (nb >> b) + 1 <= MSM_P2_HB;
+    return nb >= (1ull << b) && (nb >> 12) + 1 <= (1ull << b);
+}
+static inline int msm_key_low(uint64_t nb, int bits) {   // smallest low with (nb >> low) + 1 <= 2^bits groups
+    int low = 0;
+    while ((nb >> low) + 1 > (1ull << bits)) low++;
+    return low;
 }
 static inline uint32_t msm_p1_tile_scalars(int nwl) {
     const uint32_t t = MSM_P1_ENTRIES / (uint32_t)nwl;
     return t < (uint32_t)MSM_P1_THREADS ? t : (uint32_t)MSM_P1_THREADS;
 }
-
 // In-place exclusive prefix sums of a[0, count) in LDS by a block of exactly 1024 threads (count <= 5 * 1024); a[count] receives the
 // total, which is also returned.  wtot: 16 words of LDS.  The caller has synchronised the block on a[]; the block is synchronised on
 // return.  (Round 3 scanned with two ping-pong arrays: 3 x 4 bytes per bin instead of 1 -- what kept 12-bit levels out of 160 KB.)
 __device__ __forceinline__ uint32_t msm_block_excl_scan_1024(uint32_t* __restrict__ a, uint32_t count, uint32_t* __restrict__ wtot) {
+    GA_REQUIRE_WAVE64();   // 16 waves of 64 lanes: lane 63 publishes the wave total, __shfl_up runs to distance 32
     constexpr int PER = 5;
     const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
     uint32_t v[PER], s = 0;
@@ -196,44 +206,62 @@ __device__ __forceinline__ uint32_t msm_block_excl_scan_1024(uint32_t* __restric
     return total;
 }
 
+// Histogram of the first-level groups straight from the scalars (digits recomputed, nothing written).  A block walks whole TILES of
+// the first pass (tile t, t + grid, ...; the grid is a multiple of 8), so that with per-XCD slices (ncls = 8) the counts of class
+// t % 8 -- the XCD the first pass's block t is expected on -- are kept apart: ghist[bin * ncls + class].
 template <class FrP, int BITS>
 __global__ void __launch_bounds__(256)
 msm_digit_hist_kernel(const uint32_t* __restrict__ scalars, uint64_t n, int mont, int c, int nwin, int win_lo, int win_hi, int table,
-                      uint32_t key_base, uint32_t skip, uint32_t* __restrict__ ghist) {
+                      uint32_t key_base, uint32_t skip, uint32_t tile_scalars, int low, uint32_t ncls, uint32_t* __restrict__ ghist) {
     constexpr uint32_t BINS = 1u << BITS;
     __shared__ uint32_t h[BINS];
     for (uint32_t b = threadIdx.x; b < BINS; b += blockDim.x) h[b] = 0;
     __syncthreads();
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        DigitWalk<FrP> D;
-        D.load(scalars, i, mont);
-        for (int w = 0; w < win_hi; w++) {
-            uint32_t k, v;
-            D.next(c, w, win_lo, n, i, table, key_base, skip, k, v);
-            if (w >= win_lo) atomicAdd(&h[k & (BINS - 1)], 1u);
+    const uint64_t ntiles = (n + tile_scalars - 1) / tile_scalars;
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint64_t i0 = tile * tile_scalars;
+        const uint64_t i1 = i0 + tile_scalars < n ? i0 + tile_scalars : n;
+        for (uint64_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+            DigitWalk<FrP> D;
+            D.load(scalars, i, mont);
+            for (int w = 0; w < win_hi; w++) {
+                uint32_t k, v;
+                D.next(c, w, win_lo, n, i, table, key_base, skip, k, v);
+                if (w >= win_lo) atomicAdd(&h[(k >> low)], 1u);
+            }
         }
     }
     __syncthreads();
+    const uint32_t cls = ncls > 1 ? (blockIdx.x % ncls) : 0;
     for (uint32_t b = threadIdx.x; b < BINS; b += blockDim.x)
-        if (h[b]) atomicAdd(&ghist[b], h[b]);
+        if (h[b]) atomicAdd(&ghist[b * ncls + cls], h[b]);
 }
 
-// exclusive scans of the bin counts (one block): where each bin's slice of the partitioned arrays starts (cursor: consumed by the
-// first pass; bin_off: kept, BINS + 1 entries) and the number of MSM_P2_SEG-pair segments before each bin (seg_off)
+// exclusive scans of the group counts (one block): where each group's slice of the partitioned arrays starts (bin_off: kept, BINS + 1
+// entries), where each (group, class) sub-slice starts (cursor: consumed by the first pass) and the number of MSM_P2_SEG-pair
+// segments before each group (seg_off)
 template <int BITS>
-static __global__ void __launch_bounds__(1024) msm_p1_scan_kernel(const uint32_t* __restrict__ ghist, uint32_t* __restrict__ cursor,
+static __global__ void __launch_bounds__(1024) msm_p1_scan_kernel(const uint32_t* __restrict__ ghist, uint32_t ncls, uint32_t* __restrict__ cursor,
                                                                   uint32_t* __restrict__ bin_off, uint32_t* __restrict__ seg_off) {
     constexpr uint32_t BINS = 1u << BITS;
     __shared__ uint32_t a[BINS + 1], g[BINS + 1], wtot[16];
     for (uint32_t b = threadIdx.x; b < BINS; b += blockDim.x) {
-        a[b] = ghist[b];
-        g[b] = (ghist[b] + MSM_P2_SEG - 1) / MSM_P2_SEG;
+        uint32_t tot = 0;
+        for (uint32_t k = 0; k < ncls; k++) tot += ghist[b * ncls + k];
+        a[b] = tot;
+        g[b] = (tot + MSM_P2_SEG - 1) / MSM_P2_SEG;
     }
     __syncthreads();
     msm_block_excl_scan_1024(a, BINS, wtot);
     msm_block_excl_scan_1024(g, BINS, wtot);
     for (uint32_t b = threadIdx.x; b <= BINS; b += blockDim.x) {
-        if (b < BINS) cursor[b] = a[b];
+        if (b < BINS) {
+            uint32_t s = a[b];
+            for (uint32_t k = 0; k < ncls; k++) {
+                cursor[b * ncls + k] = s;
+                s += ghist[b * ncls + k];
+            }
+        }
         bin_off[b] = a[b];
         seg_off[b] = g[b];
     }
@@ -242,7 +270,7 @@ static __global__ void __launch_bounds__(1024) msm_p1_scan_kernel(const uint32_t
 template <class FrP, int BITS>
 __global__ void __launch_bounds__(MSM_P1_THREADS)
 msm_digits_pass1_kernel(const uint32_t* __restrict__ scalars, uint64_t n, int mont, int c, int nwin, int win_lo, int win_hi, int table,
-                        uint32_t key_base, uint32_t skip, uint32_t tile_scalars, uint32_t* __restrict__ cursor,
+                        uint32_t key_base, uint32_t skip, uint32_t tile_scalars, int low, uint32_t ncls, uint32_t* __restrict__ cursor,
                         uint32_t* __restrict__ out_keys, uint32_t* __restrict__ out_vals) {
     constexpr uint32_t BINS = 1u << BITS;
     __shared__ uint32_t stage_k[MSM_P1_ENTRIES], stage_v[MSM_P1_ENTRIES];
@@ -264,21 +292,24 @@ msm_digits_pass1_kernel(const uint32_t* __restrict__ scalars, uint64_t n, int mo
         for (int q = 0; q < MSM_P1_MAXW; q++)
             if (win_lo + q < win_hi) {
                 D.next(c, win_lo + q, win_lo, n, i, table, key_base, skip, key[q], val[q]);
-                rank[q] = atomicAdd(&start[key[q] & (BINS - 1)], 1u);
+                rank[q] = atomicAdd(&start[(key[q] >> low)], 1u);
             }
     }
     __syncthreads();
     const uint32_t total = msm_block_excl_scan_1024(start, BINS, wtot);
-    // a bin's slice of the output is reserved with one global atomic per (tile, bin); delta = where the run goes - where it is staged
+    // a bin's slice of the output is reserved with one global atomic per (tile, bin) -- with per-XCD slices (ncls = 8) inside the
+    // sub-slice of this block's class, so that the runs one XCD's L2 collects are neighbours; delta = where the run goes - where it
+    // is staged
+    const uint32_t cls = ncls > 1 ? (blockIdx.x % ncls) : 0;
     for (uint32_t b = t; b < BINS; b += blockDim.x) {
         const uint32_t cnt = start[b + 1] - start[b];
-        delta[b] = cnt ? atomicAdd(&cursor[b], cnt) - start[b] : 0;
+        delta[b] = cnt ? atomicAdd(&cursor[b * ncls + cls], cnt) - start[b] : 0;
     }
     if (live) {
 #pragma unroll
         for (int q = 0; q < MSM_P1_MAXW; q++)
             if (win_lo + q < win_hi) {
-                const uint32_t at = start[key[q] & (BINS - 1)] + rank[q];
+                const uint32_t at = start[(key[q] >> low)] + rank[q];
                 stage_k[at] = key[q];
                 stage_v[at] = val[q];
             }
@@ -286,26 +317,35 @@ msm_digits_pass1_kernel(const uint32_t* __restrict__ scalars, uint64_t n, int mo
     __syncthreads();
     for (uint32_t p = t; p < total; p += blockDim.x) {   // consecutive lanes write consecutive addresses inside a run
         const uint32_t k = stage_k[p];
-        const uint32_t dst = p + delta[k & (BINS - 1)];
+        const uint32_t dst = p + delta[(k >> low)];
         out_keys[dst] = k;
         out_vals[dst] = stage_v[p];
     }
 }
 
 // ---- 1c. the second level of the fused sort, in place of the library pass and the binary-search offsets ------------------------
-// After the first pass the pairs are grouped by their low BITS key bits; inside a group a pair's final place is
-// off[key] + (any rank among the pairs with the same key): no stability is needed, only the per-key counts.  Segments of at most
-// MSM_P2_SEG pairs of ONE group count the high key parts in LDS and add them to a global per-key histogram (gcount[key]: the low
-// part is the group); an exclusive scan of that histogram IS the bucket-offset array `off`; then the same segments reserve one run
-// per (segment, key) behind a global atomic and write the VALUES (the sorted keys are never materialised), LDS-staged so that a
-// run leaves the CU as consecutive addresses.  Any key distribution works (a group of any size is just more segments).
+// After the first pass the pairs are grouped; inside a group a pair's final place is off[key] + (any rank among the pairs with the
+// same key): no stability is needed, only the per-key counts.  Segments of at most MSM_P2_SEG pairs of ONE group count their key
+// parts in LDS and add them to a global per-key histogram (gcount[key]); an exclusive scan of that histogram IS the bucket-offset
+// array `off`; then the same segments reserve one run per (segment, key) behind a global atomic and write the VALUES (the sorted
+// keys are never materialised), LDS-staged so that a run leaves the CU as consecutive addresses.  Any key distribution works (a
+// group of any size is just more segments).
 // Measured at 12 x 2^24 pairs (tools/exp/partbench.hip variant C): 1.41 ms against the library pass + offsets kernel's 2.0 ms.
+// swz: consecutive segments -- the segments of one group, whose runs are neighbours in the output when the groups are key ranges --
+// go to ONE XCD (block b runs on XCD b % 8: it takes segment (b % 8) * ceil(S / 8) + b / 8 of the S the device counted), so that the
+// partial lines they write meet in one L2.  Placement is a speed assumption only.
 template <int BITS>
-__device__ __forceinline__ bool msm_p2_segment(const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ bin_off, uint32_t& bin,
+__device__ __forceinline__ bool msm_p2_segment(const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ bin_off, int swz, uint32_t& bin,
                                                uint32_t& lo, uint32_t& hi) {
     constexpr uint32_t BINS = 1u << BITS;
-    const uint32_t sidx = blockIdx.x;
-    if (sidx >= seg_off[BINS]) return false;
+    const uint32_t nseg = seg_off[BINS];
+    uint32_t sidx = blockIdx.x;
+    if (swz) {
+        const uint32_t per = (nseg + MSM_XCDS - 1) / MSM_XCDS, j = blockIdx.x / MSM_XCDS;
+        if (j >= per) return false;
+        sidx = (blockIdx.x % MSM_XCDS) * per + j;
+    }
+    if (sidx >= nseg) return false;
     uint32_t l = 0, r = BINS;   // the last bin with seg_off[bin] <= sidx
     while (r - l > 1) {
         const uint32_t mid = (l + r) >> 1;
@@ -321,10 +361,10 @@ __device__ __forceinline__ bool msm_p2_segment(const uint32_t* __restrict__ seg_
 template <int BITS>
 static __global__ void __launch_bounds__(1024)
 msm_p2_count_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ bin_off,
-                    uint32_t hb, uint32_t* __restrict__ gcount) {
+                    uint32_t hb, int low, int swz, uint32_t* __restrict__ gcount) {
     __shared__ uint32_t cnt[MSM_P2_HB];
     uint32_t bin, lo, hi;
-    if (!msm_p2_segment<BITS>(seg_off, bin_off, bin, lo, hi)) return;   // (uniform per block)
+    if (!msm_p2_segment<BITS>(seg_off, bin_off, swz, bin, lo, hi)) return;   // (uniform per block)
     for (uint32_t h = threadIdx.x; h < hb; h += blockDim.x) cnt[h] = 0;
     __syncthreads();
     constexpr int U = MSM_P2_SEG / 1024;
@@ -336,20 +376,21 @@ msm_p2_count_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restric
     }
 #pragma unroll
     for (int u = 0; u < U; u++)
-        if (kk[u] != 0xFFFFFFFFu) atomicAdd(&cnt[kk[u] >> BITS], 1u);
+        if (kk[u] != 0xFFFFFFFFu) atomicAdd(&cnt[(kk[u] & ((1u << low) - 1))], 1u);
     __syncthreads();
     for (uint32_t h = threadIdx.x; h < hb; h += blockDim.x)
-        if (cnt[h]) atomicAdd(&gcount[(h << BITS) | bin], cnt[h]);
+        if (cnt[h]) atomicAdd(&gcount[(bin << low) | h], cnt[h]);
 }
 template <int BITS>
 static __global__ void __launch_bounds__(1024)
 msm_p2_scatter_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ seg_off,
-                      const uint32_t* __restrict__ bin_off, uint32_t hb, uint32_t* __restrict__ cursor, uint32_t* __restrict__ out_vals) {
+                      const uint32_t* __restrict__ bin_off, uint32_t hb, int low, int swz, uint32_t* __restrict__ cursor,
+                      uint32_t* __restrict__ out_vals) {
     __shared__ uint32_t stage_v[MSM_P2_SEG];
     __shared__ uint16_t stage_h[MSM_P2_SEG];
     __shared__ uint32_t start[MSM_P2_HB + 1], delta[MSM_P2_HB], wtot[16];
     uint32_t bin, lo, hi;
-    if (!msm_p2_segment<BITS>(seg_off, bin_off, bin, lo, hi)) return;
+    if (!msm_p2_segment<BITS>(seg_off, bin_off, swz, bin, lo, hi)) return;
     const uint32_t t = threadIdx.x;
     for (uint32_t h = t; h < hb; h += blockDim.x) start[h] = 0;
     __syncthreads();
@@ -363,17 +404,17 @@ msm_p2_scatter_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restr
     }
 #pragma unroll
     for (int u = 0; u < U; u++)
-        if (kk[u] != 0xFFFFFFFFu) rk[u] = atomicAdd(&start[kk[u] >> BITS], 1u);
+        if (kk[u] != 0xFFFFFFFFu) rk[u] = atomicAdd(&start[(kk[u] & ((1u << low) - 1))], 1u);
     __syncthreads();
     msm_block_excl_scan_1024(start, hb, wtot);
     for (uint32_t h = t; h < hb; h += blockDim.x) {
         const uint32_t cnt = start[h + 1] - start[h];
-        delta[h] = cnt ? atomicAdd(&cursor[(h << BITS) | bin], cnt) - start[h] : 0;
+        delta[h] = cnt ? atomicAdd(&cursor[(bin << low) | h], cnt) - start[h] : 0;
     }
 #pragma unroll
     for (int u = 0; u < U; u++)
         if (kk[u] != 0xFFFFFFFFu) {
-            const uint32_t h = kk[u] >> BITS, at = start[h] + rk[u];
+            const uint32_t h = (kk[u] & ((1u << low) - 1)), at = start[h] + rk[u];
             stage_v[at] = vv[u];
             stage_h[at] = (uint16_t)h;
         }
@@ -387,42 +428,52 @@ msm_p2_scatter_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restr
 template <class FrP, int BITS>
 int msm_fused_sort(Ctx* ctx, const std::string& sfx, hipStream_t st, const void* d_scalars, size_t n, bool scalars_mont, int c, int nwin,
                    int win_lo, int win_hi, bool table, int batch, uint32_t half, uint32_t nb, uint64_t m, uint32_t* keys, uint32_t* vals,
-                   uint32_t* vals2, uint32_t* off) {
+                   uint32_t* vals2, uint32_t* off, int xcd) {
+    // xcd (GA_MSM_XCD, A/B knob): bit 0 per-XCD slices in the first level, bit 1 XCD swizzle of the second level's segments, bit 2
+    // the slices at any size (tests)
     constexpr uint32_t BINS = 1u << BITS;
     auto key = [&](const char* k) { return std::string(k) + sfx; };
     const int nwl = win_hi - win_lo;
+    const int low = msm_key_low(nb, BITS);
+    // (per-XCD slices make the histogram and cursor tables 8 x as long: below 2^24 pairs they cost what they save,
+    // profiles/r05_b_fuse_min_sweep.txt)
+    const uint32_t ncls = ((xcd & 1) && (m >= (1ull << 24) || (xcd & 4))) ? MSM_XCDS : 1;
+    const int swz = (xcd & 2) ? 1 : 0;
     uint32_t *ghist, *cursor, *bin_off, *seg_off, *gcount, *kcursor;
-    GA_CHECK(ctx->scratch_get(key("msm_p1_hist").c_str(), BINS * 4, (void**)&ghist));
-    GA_CHECK(ctx->scratch_get(key("msm_p1_cursor").c_str(), BINS * 4, (void**)&cursor));
+    GA_CHECK(ctx->scratch_get(key("msm_p1_hist").c_str(), BINS * MSM_XCDS * 4, (void**)&ghist));
+    GA_CHECK(ctx->scratch_get(key("msm_p1_cursor").c_str(), BINS * MSM_XCDS * 4, (void**)&cursor));
     GA_CHECK(ctx->scratch_get(key("msm_p1_bin_off").c_str(), (BINS + 1) * 4, (void**)&bin_off));
     GA_CHECK(ctx->scratch_get(key("msm_p2_seg_off").c_str(), (BINS + 1) * 4, (void**)&seg_off));
-    const uint64_t nkeys = (((uint64_t)nb >> BITS) + 1) << BITS;   // >= nb + 1: every (high part, group) pair a key 0..nb can form
+    // the key parts the second level counts, and every key a (group, part) pair can form (>= nb + 1)
+    const uint32_t hb = 1u << low;
+    const uint64_t nkeys = (((uint64_t)nb >> low) + 1) << low;
     GA_CHECK(ctx->scratch_get(key("msm_p2_count").c_str(), nkeys * 4, (void**)&gcount));
     GA_CHECK(ctx->scratch_get(key("msm_p2_cursor").c_str(), nkeys * 4, (void**)&kcursor));
     auto vec = [&](int b) { return batch == 1 ? (const uint32_t*)d_scalars : reinterpret_cast<const uint32_t* const*>(d_scalars)[b]; };
     {
         StageTimer tm(ctx, "msm_digits_pass1", st);
         const uint32_t tile = msm_p1_tile_scalars(nwl);
-        uint64_t hist_blocks = (n + 255) / 256;
+        const uint64_t ntiles = (n + tile - 1) / tile;
+        uint64_t hist_blocks = (ntiles + MSM_XCDS - 1) / MSM_XCDS * MSM_XCDS;   // a multiple of 8: tile t and the block that counts it agree on t % 8
         if (hist_blocks > 2048) hist_blocks = 2048;
-        GA_HIP_CHECK(hipMemsetAsync(ghist, 0, BINS * 4, st));
+        GA_HIP_CHECK(hipMemsetAsync(ghist, 0, BINS * ncls * 4, st));
         for (int b = 0; b < batch; b++)   // (a batch: the vectors' bucket sets are stacked in ONE key space, key_base = b * 2^(c-1))
             hipLaunchKernelGGL((msm_digit_hist_kernel<FrP, BITS>), dim3((unsigned)hist_blocks), dim3(256), 0, st, vec(b), (uint64_t)n,
-                               scalars_mont ? 1 : 0, c, nwin, win_lo, win_hi, table ? 1 : 0, (uint32_t)b * half, nb, ghist);
-        hipLaunchKernelGGL(msm_p1_scan_kernel<BITS>, dim3(1), dim3(1024), 0, st, (const uint32_t*)ghist, cursor, bin_off, seg_off);
+                               scalars_mont ? 1 : 0, c, nwin, win_lo, win_hi, table ? 1 : 0, (uint32_t)b * half, nb, tile, low, ncls, ghist);
+        hipLaunchKernelGGL(msm_p1_scan_kernel<BITS>, dim3(1), dim3(1024), 0, st, (const uint32_t*)ghist, ncls, cursor, bin_off, seg_off);
         for (int b = 0; b < batch; b++)
-            hipLaunchKernelGGL((msm_digits_pass1_kernel<FrP, BITS>), dim3((unsigned)((n + tile - 1) / tile)), dim3(MSM_P1_THREADS), 0, st, vec(b),
-                               (uint64_t)n, scalars_mont ? 1 : 0, c, nwin, win_lo, win_hi, table ? 1 : 0, (uint32_t)b * half, nb, tile, cursor, keys,
-                               vals);
+            hipLaunchKernelGGL((msm_digits_pass1_kernel<FrP, BITS>), dim3((unsigned)ntiles), dim3(MSM_P1_THREADS), 0, st, vec(b),
+                               (uint64_t)n, scalars_mont ? 1 : 0, c, nwin, win_lo, win_hi, table ? 1 : 0, (uint32_t)b * half, nb, tile, low, ncls, cursor,
+                               keys, vals);
         GA_KERNEL_CHECK();
     }
     {
         StageTimer tm(ctx, "msm_sort", st);
-        const unsigned max_seg = (unsigned)(m / MSM_P2_SEG + BINS);
-        const uint32_t hb = (nb >> BITS) + 1;   // high parts of the keys 0..nb
+        unsigned max_seg = (unsigned)(m / MSM_P2_SEG + BINS);
+        if (swz) max_seg = (max_seg + MSM_XCDS - 1) / MSM_XCDS * MSM_XCDS + MSM_XCDS;   // ceil(S / 8) blocks per XCD for any S <= max_seg
         GA_HIP_CHECK(hipMemsetAsync(gcount, 0, nkeys * 4, st));
         hipLaunchKernelGGL(msm_p2_count_kernel<BITS>, dim3(max_seg), dim3(1024), 0, st, (const uint32_t*)keys, (const uint32_t*)seg_off,
-                           (const uint32_t*)bin_off, hb, gcount);
+                           (const uint32_t*)bin_off, hb, low, swz, gcount);
         GA_KERNEL_CHECK();
         size_t sb = 0;
         void* stmp;
@@ -431,23 +482,34 @@ int msm_fused_sort(Ctx* ctx, const std::string& sfx, hipStream_t st, const void*
         GA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(stmp, sb, gcount, off, (int)(nb + 1), st));   // off[b], b = 0..nb (nb = SKIP)
         GA_HIP_CHECK(hipMemcpyAsync(kcursor, off, ((uint64_t)nb + 1) * 4, hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL(msm_p2_scatter_kernel<BITS>, dim3(max_seg), dim3(1024), 0, st, (const uint32_t*)keys, (const uint32_t*)vals,
-                           (const uint32_t*)seg_off, (const uint32_t*)bin_off, hb, kcursor, vals2);
+                           (const uint32_t*)seg_off, (const uint32_t*)bin_off, hb, low, swz, kcursor, vals2);
         GA_KERNEL_CHECK();
     }
     return GA_OK;
 }
 
 // ---- 3. bucket boundaries and tasks ---------------------------------------------------------------
-static __global__ void msm_offsets_kernel(const uint32_t* __restrict__ keys, uint64_t m, uint32_t nb, uint32_t* __restrict__ off) {
-    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b > nb) return;
-    uint64_t lo = 0, hi = m;   // first index with keys[idx] >= b
-    while (lo < hi) {
-        uint64_t mid = (lo + hi) >> 1;
-        if (keys[mid] < b) lo = mid + 1;
-        else hi = mid;
+// bucket boundaries by binary search + the number of tasks per bucket, one launch (library-sort path: small MSMs, where every launch is ~5 us of a ~2 ms call): a block shares its boundaries in LDS
+static __global__ void __launch_bounds__(256) msm_offsets_tasks_kernel(const uint32_t* __restrict__ keys, uint64_t m, uint32_t nb, uint32_t seg,
+                                                                       uint32_t* __restrict__ off, uint32_t* __restrict__ ntask) {
+    __shared__ uint32_t sh[257];
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    auto lower = [&](uint32_t key) {   // first index with keys[idx] >= key
+        uint64_t lo = 0, hi = m;
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (keys[mid] < key) lo = mid + 1;
+            else hi = mid;
+        }
+        return (uint32_t)lo;
+    };
+    if (b <= nb) {
+        sh[threadIdx.x] = lower(b);
+        off[b] = sh[threadIdx.x];
+        if (threadIdx.x == blockDim.x - 1 && b < nb) sh[blockDim.x] = lower(b + 1);
     }
-    off[b] = (uint32_t)lo;
+    __syncthreads();
+    if (b <= nb) ntask[b] = b < nb ? (sh[threadIdx.x + 1] - sh[threadIdx.x] + seg - 1) / seg : 0;
 }
 
 static __global__ void msm_tasks_kernel(const uint32_t* __restrict__ off, uint32_t nb, uint32_t seg, uint32_t* __restrict__ ntask) {
@@ -460,9 +522,15 @@ static __global__ void msm_tasks_kernel(const uint32_t* __restrict__ off, uint32
 // task t of bucket b covers sorted pairs [start, start+len); key = SEG - len so that an ascending radix sort puts the
 // longest tasks first and lanes of one wave get tasks of (nearly) equal length (bucket sizes are Poisson-distributed:
 // without this a wave waits for its longest bucket, ~25 % of the lanes' time at 2^24)
-static __global__ void msm_iota_kernel(uint32_t* __restrict__ out, uint32_t n) {
+// (one launch for what were two memsets and an iota: padding keys, the identity permutation the task sort starts from, the counter
+// of the long-bucket queue)
+static __global__ void msm_task_init_kernel(uint32_t* __restrict__ task_key, uint32_t* __restrict__ task_id, uint32_t n, uint32_t* __restrict__ long_count) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = i;
+    if (i < n) {
+        task_key[i] = 0xFFFFFFFFu;
+        task_id[i] = i;
+    }
+    if (i == 0) *long_count = 0;
 }
 
 // Buckets with more than MSM_LONG_TASKS tasks (a boolean-heavy witness puts millions of points into the digit-1 bucket of window 0)
@@ -1311,12 +1379,13 @@ int msm_prepare(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, in
     while ((1ull << end_bit) <= nb64) end_bit++;   // keys take values 0..nb (nb = SKIP)
     // digits fused with the first sort pass (1b / 1c): key spaces of 2^11 .. 2^24 keys, at most MSM_P1_MAXW windows per scalar, any
     // number of scalar vectors over one table, enough pairs for the saved traffic to matter (GA_MSM_FUSE_MIN)
+    const int xcd = ctx->tun.msm_xcd.load(std::memory_order_relaxed);
     const bool fused = msm_fused_fits(nb64) && nwl <= MSM_P1_MAXW && m >= ctx->tun.msm_fuse_min.load(std::memory_order_relaxed);
     if (fused) {
         if (msm_p1_bits(nb64) == 11)
-            GA_CHECK((msm_fused_sort<FrP, 11>(ctx, sfx, st, d_scalars, n, scalars_mont, c, nwin, win_lo, win_hi, table, batch, half, nb, m, keys, vals, vals2, off)));
+            GA_CHECK((msm_fused_sort<FrP, 11>(ctx, sfx, st, d_scalars, n, scalars_mont, c, nwin, win_lo, win_hi, table, batch, half, nb, m, keys, vals, vals2, off, xcd)));
         else
-            GA_CHECK((msm_fused_sort<FrP, 12>(ctx, sfx, st, d_scalars, n, scalars_mont, c, nwin, win_lo, win_hi, table, batch, half, nb, m, keys, vals, vals2, off)));
+            GA_CHECK((msm_fused_sort<FrP, 12>(ctx, sfx, st, d_scalars, n, scalars_mont, c, nwin, win_lo, win_hi, table, batch, half, nb, m, keys, vals, vals2, off, xcd)));
     } else {
         {
             StageTimer tm(ctx, "msm_digits", st);
@@ -1333,25 +1402,24 @@ int msm_prepare(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, in
     }
     {
         StageTimer tm(ctx, "msm_tasks", st);
+        uint32_t *long_list, *long_count;
+        GA_CHECK(ctx->scratch_get(key("msm_long").c_str(), (max_tasks / MSM_LONG_TASKS + 2) * 4, (void**)&long_list));
+        GA_CHECK(ctx->scratch_get(key("msm_long_count").c_str(), 256, (void**)&long_count));
+        // explicit task list, ordered by decreasing length (padding slots keep key = 0xFFFFFFFF >= seg)
+        hipLaunchKernelGGL(msm_task_init_kernel, dim3((unsigned)((max_tasks + 255) / 256)), dim3(256), 0, st, task_key, task_id, (uint32_t)max_tasks, long_count);
         if (!fused)   // (the fused sort produced `off` itself)
-            hipLaunchKernelGGL(msm_offsets_kernel, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, (const uint32_t*)keys2, m, nb, off);
-        hipLaunchKernelGGL(msm_tasks_kernel, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, (const uint32_t*)off, nb, seg, ntask);
+            hipLaunchKernelGGL(msm_offsets_tasks_kernel, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, (const uint32_t*)keys2, m, nb, seg, off, ntask);
+        else
+            hipLaunchKernelGGL(msm_tasks_kernel, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, (const uint32_t*)off, nb, seg, ntask);
         GA_KERNEL_CHECK();
         size_t tmp_bytes = 0;
         GA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, ntask, task_off, (int)(nb + 1), st));
         GA_CHECK(ctx->scratch_get(key("msm_scan_tmp").c_str(), tmp_bytes + 256, &tmp));
         GA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, ntask, task_off, (int)(nb + 1), st));
-        // explicit task list, ordered by decreasing length (padding slots keep key = 0xFFFFFFFF >= seg)
-        GA_HIP_CHECK(hipMemsetAsync(task_key, 0xFF, max_tasks * 4, st));
-        uint32_t *long_list, *long_count;
-        GA_CHECK(ctx->scratch_get(key("msm_long").c_str(), (max_tasks / MSM_LONG_TASKS + 2) * 4, (void**)&long_list));
-        GA_CHECK(ctx->scratch_get(key("msm_long_count").c_str(), 256, (void**)&long_count));
-        GA_HIP_CHECK(hipMemsetAsync(long_count, 0, 4, st));
         hipLaunchKernelGGL(msm_task_list_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, (const uint32_t*)off, (const uint32_t*)task_off,
                            nb, seg, task_start, task_key, task_dest, long_list, long_count);
         hipLaunchKernelGGL(msm_task_list_long_kernel, dim3(256), dim3(256), 0, st, (const uint32_t*)off, (const uint32_t*)task_off, nb, seg,
                            task_start, task_key, task_dest, (const uint32_t*)long_list, (const uint32_t*)long_count);
-        hipLaunchKernelGGL(msm_iota_kernel, dim3((unsigned)((max_tasks + 255) / 256)), dim3(256), 0, st, task_id, (uint32_t)max_tasks);
         GA_KERNEL_CHECK();
         int kbits = 1;
         while ((1u << kbits) <= seg) kbits++;
@@ -1386,8 +1454,11 @@ int msm_prepare(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, in
 // Group-dependent half: bucket accumulation over `d_bases` (the affine bases, or the precomputed table in table mode),
 // merge, per-set reduction.  Writes P.nsets XYZZ sums to host memory.
 
+// horner_c > 0 (raw bases, every window of the call): instead of the P.nsets window sums, out[0] receives their combination
+// sum_w 2^(horner_c * w) * set_w -- the window reduction's per-bit sums and the Horner step over the windows then share ONE chain of
+// doublings on the host (see the end of this function).
 template <class F>
-int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, XYZZ<F>* out) {
+int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, XYZZ<F>* out, int horner_c = 0) {
     const uint32_t nb = P.nb, half = P.half, seg = P.seg;
     const int nsets = P.nsets;
     // buckets per running-sum group: MSM_GROUP when there are plenty of buckets, smaller (down to 2) when a set has few so
@@ -1522,6 +1593,19 @@ int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, X
             hipLaunchKernelGGL((msm_segment_sum_kernel<F>), dim3(nsets), dim3(64), 0, st, (const XYZZ<F>*)gsum, groups_per_win, wsum);
         }
         GA_KERNEL_CHECK();
+        if (horner_c > 0) {
+            std::vector<XYZZ<F>> ws((size_t)nsets);
+            GA_HIP_CHECK(hipMemcpyAsync(ws.data(), wsum, (size_t)nsets * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
+            GA_HIP_CHECK(hipStreamSynchronize(st));
+            note_degenerate();
+            XYZZ<F> acc = xyzz_inf<F>();
+            for (int w = nsets - 1; w >= 0; w--) {
+                for (int k = 0; k < horner_c; k++) acc = dbl(acc);
+                acc = add(acc, ws[(size_t)w]);
+            }
+            out[0] = acc;
+            return GA_OK;
+        }
         GA_HIP_CHECK(hipMemcpyAsync(out, wsum, (size_t)nsets * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
         GA_HIP_CHECK(hipStreamSynchronize(st));
         note_degenerate();
@@ -1570,6 +1654,25 @@ int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, X
     if (P.table && !big_set) ctx->note_sparse_set(d_bases, (uint64_t)h_redo_groups * 4 > total_groups);
     int log_m = 0;
     while ((1u << log_m) < m_groups) log_m++;
+    if (horner_c > 0) {
+        // result = sum_w 2^(c w) [ L_w + 2^log_m * sum_b 2^b T_(w,b) ]: every term has a bit position (c w for L_w, c w + log_m + b for
+        // T_(w,b)), and ONE descent over the positions -- a doubling per position, an addition per term -- replaces the per-set chains
+        // (nbits + log_m doublings each) followed by the Horner step over the windows (c doublings each): 255 + 16 doublings instead
+        // of 15 x 16 + 255 for a 2^20-point MSM (c = 17), 0.1 ms of the 0.35 ms the host spent per call.
+        const int top = horner_c * (nsets - 1) + log_m + nbits - 1;
+        std::vector<std::vector<const XYZZ<F>*>> at((size_t)top + 1);
+        for (int w = 0; w < nsets; w++) {
+            at[(size_t)(horner_c * w)].push_back(&hb[(size_t)w * rows + nbits]);
+            for (int b = 0; b < nbits; b++) at[(size_t)(horner_c * w + log_m + b)].push_back(&hb[(size_t)w * rows + b]);
+        }
+        XYZZ<F> acc = xyzz_inf<F>();
+        for (int pos = top; pos >= 0; pos--) {
+            if (pos != top) acc = dbl(acc);
+            for (const XYZZ<F>* t : at[(size_t)pos]) acc = add(acc, *t);
+        }
+        out[0] = acc;
+        return GA_OK;
+    }
     for (int w = 0; w < nsets; w++) {   // host: ~nbits + log2(m) doublings and nbits additions per set
         XYZZ<F> acc = xyzz_inf<F>();
         for (int b = nbits - 1; b >= 0; b--) acc = add(dbl(acc), hb[(size_t)w * rows + b]);
@@ -1581,18 +1684,19 @@ int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, X
 
 template <class C, int G>
 int msm_windows_device(Ctx* ctx, const void* d_bases, const void* d_scalars, size_t n, bool scalars_mont, int c,
-                       int win_lo, int win_hi, void* h_window_sums) {
+                       int win_lo, int win_hi, void* h_window_sums, bool combine) {
     typedef typename GroupField<C, G>::F F;
     XYZZ<F>* out = reinterpret_cast<XYZZ<F>*>(h_window_sums);
     const int nwin = C::FrP::BITS / c + 1;
     if (win_hi < 0) win_hi = nwin;
     if (n == 0) {
-        for (int w = 0; w < win_hi - win_lo; w++) out[w] = xyzz_inf<F>();
+        for (int w = 0; w < (combine ? 1 : win_hi - win_lo); w++) out[w] = xyzz_inf<F>();
         return GA_OK;
     }
     MsmPrepared P;
     GA_CHECK(msm_prepare<typename C::FrP>(ctx, d_scalars, n, scalars_mont, c, win_lo, win_hi, false, &P));
-    return msm_accumulate_reduce<F>(ctx, d_bases, P, out);
+    // combine: out[0] = sum_w 2^(c (w - win_lo)) W_w; a window share that does not start at window 0 is shifted by the caller
+    return msm_accumulate_reduce<F>(ctx, d_bases, P, out, combine ? c : 0);
 }
 
 // MSM over a precomputed table: one XYZZ result (no Horner); windows [win_lo, win_hi) only (win_hi < 0 = all): the partial

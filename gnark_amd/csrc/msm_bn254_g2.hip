@@ -1,7 +1,7 @@
 // Explicit instantiation: Pippenger MSM, bn254 G2 (see msm.hip.h).
 #include "msm.hip.h"
 namespace ga {
-template int msm_windows_device<Bn254, GA_G2>(Ctx*, const void*, const void*, size_t, bool, int, int, int, void*);
+template int msm_windows_device<Bn254, GA_G2>(Ctx*, const void*, const void*, size_t, bool, int, int, int, void*, bool);
 template int msm_table_device<Bn254, GA_G2>(Ctx*, const void*, const void*, size_t, bool, int, void*, int, int);
 template int msm_table_device_reuse<Bn254, GA_G2>(Ctx*, const void*, const MsmPrepared&, void*);
 template int msm_table_device_batch<Bn254, GA_G2>(Ctx*, const void*, const void* const*, int, size_t, bool, int, void*);

@@ -174,6 +174,7 @@ ntt_pass29r4_kernel(uint32_t* data, const uint32_t* src, const uint32_t* __restr
     // NTT_F_UNIT clear: the table is a coset table (every entry carries its stage's power of the coset generator): no twiddle is 1
     static_assert(FrP::N == 8, "Fr is 4x64-bit limbs on both curves");
     static_assert(NTT_THREADS == 256 && NTT_LG_TILE == 10, "the wave-local slot mapping below is written for 4 waves x 256 slots");
+    GA_REQUIRE_WAVE64();   // a wave owns a 256-slot quarter of the tile between the barrier-free rounds
     typedef F29<FrP> E;
     __shared__ uint32_t lds[Radix<FrP>::NL << NTT_LG_TILE];
     LdsTile29<FrP> T{lds};

@@ -204,6 +204,7 @@ struct hipDeviceProp_t {
     char gcnArchName[256];
     size_t totalGlobalMem;
     int multiProcessorCount;
+    int warpSize;
 };
 
 inline const char* hipGetErrorString(hipError_t e) { return e == 0 ? "hipSuccess" : "hipemu error"; }
@@ -228,6 +229,7 @@ inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     strcpy(p->gcnArchName, "emu");
     p->totalGlobalMem = 8ull << 30;
     p->multiProcessorCount = 1;
+    p->warpSize = 64;
     return hipSuccess;
 }
 inline hipError_t hipMemGetInfo(size_t* f, size_t* t) {

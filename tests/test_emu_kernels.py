@@ -725,14 +725,16 @@ def test_emu_msm_very_hot_bucket(emu_ctx, c, group, table, n=36000):
             b.free()
 
 
+@pytest.mark.parametrize("xcd", [0, 7], ids=["no-xcd-placement", "xcd-slices-and-swizzle"])
 @pytest.mark.parametrize("c,group", [(BN254, 0), (BLS12_381, 1)], ids=["bn254-G1", "bls12-381-G2"])
-def test_emu_msm_fused_first_sort_pass(emu_ctx, c, group, monkeypatch, n=1300, table_c=16):
+def test_emu_msm_fused_first_sort_pass(emu_ctx, c, group, xcd, monkeypatch, n=1300, table_c=16):
     """msm.hip.h 1b -- the digit extraction fused with the first radix-sort pass (histogram of the low key bits from the scalars,
     LDS-partitioned tiles, one library pass for the high bits) -- forced on a small table MSM (GA_MSM_FUSE_MIN=0; GA_TABLE_C=16:
     16 windows, 2^15 buckets, partial tiles of 832 scalars) and compared with the same MSM through the plain digits + sort
     sequence and with [sum s_i k_i]G.  Scalars: uniform, 0, 1, r-1, a hot value, canonical and Montgomery inputs, window ranges."""
     ctx = emu_ctx
     monkeypatch.setenv("GA_TABLE_C", str(table_c))
+    monkeypatch.setenv("GA_MSM_XCD", str(xcd))   # per-XCD slices of the first level (bit 2: also below 2^24 pairs), XCD swizzle of the second: placement only
     bases, dlogs, scal = _device_inputs(ctx, c, group, n, 0xF05E + group)
     S = scal.to_host((n, 4))
     K = dlogs.to_host((n, 4))
@@ -791,8 +793,9 @@ def test_emu_msm_fused_first_sort_pass(emu_ctx, c, group, monkeypatch, n=1300, t
             b.free()
 
 
+@pytest.mark.parametrize("xcd", [0, 7], ids=["no-xcd-placement", "xcd-slices-and-swizzle"])
 @pytest.mark.parametrize("table_c,batch", [(22, 3), (23, 3)], ids=["23-bit-keys-11-bit-level", "24-bit-keys-12-bit-level"])
-def test_emu_msm_fused_sort_wide_keys(emu_ctx, monkeypatch, table_c, batch, c=BN254, group=0, n=257):
+def test_emu_msm_fused_sort_wide_keys(emu_ctx, monkeypatch, table_c, batch, xcd, c=BN254, group=0, n=257):
     """msm.hip.h 1b / 1c beyond 22 key bits and beyond one scalar vector (round 4): a batch of `batch` scalar vectors over one table
     stacks its bucket sets in ONE key space -- 3 x 2^21 keys (PLONK's batched commitments: 23 key bits, 11-bit first level with 3073
     high parts in the second) and 3 x 2^22 keys (24 key bits: the 12-bit first level).  Vectors: uniform; every scalar the same (all
@@ -801,6 +804,7 @@ def test_emu_msm_fused_sort_wide_keys(emu_ctx, monkeypatch, table_c, batch, c=BN
     in every vector here.  Fused == the library sort == [sum s_i k_i]G."""
     ctx = emu_ctx
     monkeypatch.setenv("GA_TABLE_C", str(table_c))
+    monkeypatch.setenv("GA_MSM_XCD", str(xcd))
     bases, dlogs, scal = _device_inputs(ctx, c, group, n, 0x57DE + table_c)
     K = dlogs.to_host((n, 4))
     mont = lambda v: np.array(pyref.to_mont_limbs(v, c.r, 4), dtype=np.uint64)

@@ -155,21 +155,23 @@ def test_msm_degenerate_bases_exact_kernel(gpu_ctx, monkeypatch):
     cases.test_emu_msm_degenerate_bases_exact_kernel(gpu_ctx, monkeypatch, n=1 << 14)
 
 
+@pytest.mark.parametrize("xcd", [0, 7], ids=["no-xcd-placement", "xcd-slices-and-swizzle"])
 @pytest.mark.parametrize("c,group,n,table_c", [(BN254, 0, 1 << 20, 22), (BLS12_381, 1, 1 << 18, 20), (BN254, 1, (1 << 16) + 77, 16)],
                          ids=["bn254-G1-2^20-c22", "bls12-381-G2-2^18-c20", "bn254-G2-ragged-c16"])
-def test_msm_fused_first_sort_pass(gpu_ctx, monkeypatch, c, group, n, table_c):
-    """the digit extraction fused with the first radix-sort pass (msm.hip.h 1b; the default from 2^25 pairs, forced here on smaller
-    inputs) == the plain digits + two-pass sort sequence == [sum s_i k_i]G: production shape (c = 22, 12 windows), 13 windows,
+def test_msm_fused_first_sort_pass(gpu_ctx, monkeypatch, c, group, n, table_c, xcd):
+    """the digit extraction fused with the first level of the sort (msm.hip.h 1b; the default from 2^21 pairs, forced here on smaller
+    inputs; with and without the XCD placement of round 5) == the plain digits + two-pass sort sequence == [sum s_i k_i]G: production shape (c = 22, 12 windows), 13 windows,
     16 windows with partial tiles and a ragged length; hot / zero / canonical scalars, window ranges; the same inputs as a raw-bases
     MSM in ranges of 16 windows (one bucket set per window)"""
-    cases.test_emu_msm_fused_first_sort_pass(gpu_ctx, c, group, monkeypatch, n=n, table_c=table_c)
+    cases.test_emu_msm_fused_first_sort_pass(gpu_ctx, c, group, xcd, monkeypatch, n=n, table_c=table_c)
 
 
+@pytest.mark.parametrize("xcd", [0, 7], ids=["no-xcd-placement", "xcd-slices-and-swizzle"])
 @pytest.mark.parametrize("table_c,batch,n", [(22, 3, 1 << 20), (23, 3, (1 << 18) + 5)], ids=["23-bit-keys-2^20", "24-bit-keys-ragged"])
-def test_msm_fused_sort_wide_keys(gpu_ctx, monkeypatch, table_c, batch, n):
+def test_msm_fused_sort_wide_keys(gpu_ctx, monkeypatch, table_c, batch, n, xcd):
     """the fused sort on 23- and 24-bit key spaces and batches of scalar vectors (PLONK's grouped commitments; the 12-bit first level):
     uniform / all-equal / zero-one vectors, fused == library sort == known discrete logs"""
-    cases.test_emu_msm_fused_sort_wide_keys(gpu_ctx, monkeypatch, table_c, batch, n=n)
+    cases.test_emu_msm_fused_sort_wide_keys(gpu_ctx, monkeypatch, table_c, batch, xcd, n=n)
 
 
 def test_raw_msm_2_24_takes_the_fused_sort(gpu_ctx):
