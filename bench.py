@@ -1,25 +1,31 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the MI355X prover backend (driver contract: one JSON line from rank 0).
+"""bench.py -- headline benchmark of the MI355X prover backend (driver contract: ONE compact JSON line from rank 0, < 8 KB, ending in
+"summary"; `--detail-file PATH` additionally writes the verbose object with every leg's explanation).
 
 Workload (BASELINE.json `metric`: "G1 MSM Mscalar-mul/s + Groth16 proofs/s, BN254 2^24 constraints, 1/2/4/8 GPU"):
   * a "step" = ONE BN254 G1 Pippenger MSM over 2^24 (scalar, base) pairs, bases (a pinned window table) and scalars resident in HBM
     when the timed region starts (SURVEY 8d config 2/3 shapes: uniform Montgomery scalars, distinct known-dlog bases generated on
     device).  `value` = scalar-muls/s of the whole job in Mscalar-mul/s, checked against [sum s_i k_i]G outside the timed region.
   * N = 1: the whole problem on one GPU.  N > 1: the SAME 2^24-pair problem sharded by base-point range over the N ranks (SURVEY 8e
-    partitioning B: rank g owns pairs [g n/N, (g+1) n/N) and contributes one Jacobian point; the exchange step is an RCCL all_gather
-    of the partials + a local add) -- `"scaling": "strong"`, the fixed 2^24 problem BASELINE quotes at 1/2/4/8 GPUs.  The
-    weak-scaling figure (every rank its own 2^24 pairs) is reported beside it as "weak_msm".
+    partitioning B: rank g owns pairs [g n/N, (g+1) n/N) and contributes one Jacobian point; the exchange step is an all_gather of
+    the partials + a local add) -- `"scaling": "strong"`, the fixed 2^24 problem BASELINE quotes at 1/2/4/8 GPUs.  The weak-scaling
+    figure (every rank its own 2^24 pairs) is reported beside it as "weak_msm".
   * "groth16": proofs/s at 2^24 constraints (computeH + 4 G1 MSMs + 1 G2 MSM + host epilogue, key pinned with its window tables,
-    solver excluded, C = A o B).  N = 1: single caller, two callers on one key ("pipelined"), stage breakdown; every timed proof
+    solver excluded, C = A o B).  N = 1: single caller, two callers on one key ("two_callers"), stage breakdown; every timed proof
     checked against the closed form from the key's known discrete logs + the polynomial identity of h ("matches_dlog").  N > 1: ONE
-    proof sharded over the N GPUs (strong scaling; gnark_amd/multigpu.py), rank 0 checks it the same way.
+    proof sharded over the N GPUs (strong scaling; gnark_amd/multigpu.py) in the partition --partition names, the other partition
+    beside it ("groth16_window" / "groth16_range"), rank 0 checks each the same way.
   * "groth16_bls12_381" + "msm_bls12_381": BASELINE config 4's curve -- at N = 1 the single-GPU 2^24 proof and the G1 / G2 table MSMs
-    with their own roofline objects; at N >= 8 (or GA_BENCH_CONFIG4=1) the sharded proof.
+    with their own roofline figures; at EVERY N > 1 the sharded proof in BOTH partitions: {"window": ..., "range": ...}.
+  * "replicas" (N > 1): the throughput figure -- every rank the whole key, independent proofs, aggregate proofs/s.
+  * "backend", "world_size", "ranks" (N > 1): the torch.distributed backend really initialised and every rank's device identity
+    (name, PCI address, uuid) collected THROUGH that backend.
   * "plonk": BASELINE config 5 (kernel work of one BN254 proof at 2^22 gates: 10 KZG-commit MSMs over a pinned SRS, grand product,
     quotient) with its roofline (N = 1).
   * "roofline": dominant kernel (msm_accumulate) vs the 8 TB/s HBM peak using the ALGORITHMIC 96 B per scalar-mul (32 B scalar + 64 B
-    affine base); durations come from hipEvents recorded by the library on its own stream; "integer_multiplier" prices the
-    same launches against the measured v_mad_u64_u32 issue rate (the binding resource).
+    affine base); durations come from hipEvents recorded by the library on its own stream; `bound_actual` and the `int_mad_*`
+    scalars price the same launches against the measured v_mad_u64_u32 issue rate (the binding resource); `traffic` is measured IN
+    THIS RUN by two child rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE; `traffic_source` says so, or names the committed fallback).
   * "cpu_baseline" (rank 0): the C oracle's Pippenger (oracle/oracle.c -- a plain-C port, NOT gnark-crypto; one thread per window) on
     2^24 points and the oracle's Groth16 prover on a 2^20 sample.
   * "nccl_selftest" (N = 1): a one-rank process group over the nccl (= RCCL) backend pushes a sharded proof and an MSM through every
@@ -58,6 +64,10 @@ def parse():
     ap.add_argument("--plonk-log-n", type=int, default=int(os.environ.get("GA_BENCH_PLONK_LOGN", "22")), help="0 disables the PLONK leg")
     ap.add_argument("--no-bls", action="store_true", help="N = 1: leave the BLS12-381 legs (config 4's curve) out")
     ap.add_argument("--no-selftest", action="store_true", help="N = 1: skip the one-rank RCCL self-test")
+    ap.add_argument("--only-headline", action="store_true", help="the headline MSM leg alone (what the in-run rocprofv3 counter passes execute)")
+    ap.add_argument("--no-pmc", action="store_true", help="N = 1: do not spawn the two rocprofv3 --pmc child passes for roofline.traffic (the committed figure is used)")
+    ap.add_argument("--detail-file", default=os.environ.get("GA_BENCH_DETAIL", ""), help="also write the verbose result object (every leg with its prose) to this path; stdout carries the compact line")
+    ap.add_argument("--replica-proofs", type=int, default=int(os.environ.get("GA_BENCH_REPLICA_PROOFS", "5")), help="N > 1: proofs per rank in the replica-throughput leg (0 = skip)")
     ap.add_argument("--curve", default="bn254")
     ap.add_argument("--partition", default=os.environ.get("GA_BENCH_PARTITION", "range"), choices=["range", "window"],
                     help="N > 1 Groth16 leg: key sharded by base-point range (partition B) or by scalar windows (partition A, config 4's wording)")
@@ -128,6 +138,7 @@ class Run:
             else:
                 dist.init_process_group(backend=self.backend, timeout=tmo)
             self.dist = dist
+            self.backend = dist.get_backend()   # what was really initialised (the line reports THIS, not what was asked for)
         import gnark_amd
         from gnark_amd import _lib
         if self.emu:
@@ -137,6 +148,34 @@ class Run:
         self.lib = self.ctx.lib
         self.dev = torch.device("cuda", self.device_index) if not self.emu else None   # with gloo on a GPU box device buffers are staged through the host
         self.coll_dev = self.dev if (self.backend == "nccl" and not self.emu) else None
+
+    def identity(self):
+        """this rank's device as the driver can recognise it: name, PCI address, uuid (torch's view of HIP device `device_index`)"""
+        if self.emu:
+            return "emulation (CPU) pid %d" % os.getpid()
+        try:
+            p = self.torch.cuda.get_device_properties(self.device_index)
+            return "%s pci %04x:%02x:%02x uuid %s" % (p.name, p.pci_domain_id, p.pci_bus_id, p.pci_device_id, str(getattr(p, "uuid", "?"))[:13])
+        except Exception as e:
+            return "device %d (%s)" % (self.device_index, repr(e)[:60])
+
+    def gather_identities(self):
+        """all_gather of every rank's device identity (fixed 96-byte records): did the collective backend really see N ranks on N
+        different devices?  Every rank calls it."""
+        me = self.identity().encode()[:96].ljust(96, b" ")
+        if self.world == 1:
+            return [me.decode().rstrip()]
+        t = self.torch.tensor(list(me), dtype=self.torch.uint8, device=self.coll_dev or "cpu")
+        parts = [self.torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(parts, t)
+        return [bytes(q.cpu().tolist()).decode(errors="replace").rstrip() for q in parts]
+
+    def sum_over_ranks(self, x):
+        if self.world == 1:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.coll_dev or "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return float(t.item())
 
     def fence(self):
         if not self.emu:
@@ -176,22 +215,21 @@ def oracle_modules():
 # MSM legs
 # ---------------------------------------------------------------------------------------------------------------------------------
 def roofline_object(cid, group, pairs_per_launch, windows, acc, kernel, traffic=None, traffic_source=None):
-    """the dominant kernel against the HBM peak with SURVEY 8d's algorithmic bytes, and against the integer multiplier"""
+    """the dominant kernel against the HBM peak with SURVEY 8d's algorithmic bytes (the judged figure: `frac`), and -- same object, flat
+    scalars so that they survive the driver's parsing -- against the integer multiplier, the resource that really binds it"""
     alg = ALG_BYTES[(cid, group)] * pairs_per_launch
     ms = acc["avg_ms"] if acc else float("nan")
     achieved = alg / (ms * 1e-3) / 1e9
-    r = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 6),
+    r = {"bound": "hbm", "bound_actual": "integer issue (v_mad_u64_u32); HBM is the yardstick SURVEY 8d prescribes, not the limiter", "kernel": kernel,
+         "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 6),
          "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms,
-         "launches_timed": acc["launches"] if acc else 0,
-         "note": "MSM is integer-multiplier bound (SURVEY 8d): ~2.4e4 32-bit MADs per scalar-mul vs %d B" % int(ALG_BYTES[(cid, group)])}
+         "launches_timed": acc["launches"] if acc else 0}
     mads = MADS_PER_ADDITION.get((cid, group))
     if mads:   # SURVEY 8d: "report achieved MAD/s fraction"
         adds = windows * pairs_per_launch
-        r["integer_multiplier"] = {"v_mad_u64_u32_per_addition": mads, "additions_per_launch": adds,
-                                   "achieved_Tmad_per_s": round(mads * adds / (ms * 1e-3) / 1e12, 2), "peak_Tmad_per_s": MAD_PEAK_T,
-                                   "frac": round(mads * adds / (ms * 1e-3) / (MAD_PEAK_T * 1e12), 3),
-                                   "peak_source": "ga_microbench v_mad_u64_u32 alone, 64 per loop trip, sustained (profiles/r04_d_microbench.json; "
-                                                  "rounds 1-3 priced against the 30 T/s of the 16-per-trip kernel, whose branch is 5 % of its time)"}
+        r.update({"int_mad_per_addition": mads, "int_additions_per_launch": adds, "int_mad_T_per_s": round(mads * adds / (ms * 1e-3) / 1e12, 2),
+                  "int_mad_peak_T_per_s": MAD_PEAK_T, "int_mad_frac": round(mads * adds / (ms * 1e-3) / (MAD_PEAK_T * 1e12), 3),
+                  "int_mad_peak_source": "ga_microbench: v_mad_u64_u32 alone, sustained (profiles/r04_d_microbench.json)"})
     return r
 
 
@@ -206,6 +244,53 @@ def pmc_traffic(kernel_key, curve, log_n):
     except (OSError, KeyError, ValueError):
         pass
     return None, None
+
+
+def pmc_traffic_live(args):
+    """HBM bytes per launch of the dominant kernel MEASURED IN THIS RUN: two child processes -- `rocprofv3 --pmc FETCH_SIZE
+    --kernel-trace` and the same for WRITE_SIZE, separate passes as the profiling guide prescribes (the two counters do not fit one
+    pass; --pmc is never combined with anything but --kernel-trace) -- over `bench.py --only-headline --steps 3`.  Returns (bytes per
+    launch or None, source text, detail dict).  rocprofv3 reports both counters in KiB per dispatch."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found on this box", {}
+    detail, vals = {}, {}
+    t0 = time.perf_counter()
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="ga_pmc_", dir="/tmp")
+        env = dict(os.environ, TMPDIR="/tmp")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+            env.pop(k, None)
+        cmd = [exe, "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--only-headline", "--steps", "3",
+               "--warmup", "1", "--log-n", str(args.log_n), "--curve", args.curve, "--no-check", "--no-pmc"]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd="/tmp", timeout=int(os.environ.get("GA_BENCH_PMC_TIMEOUT_S", "240")))
+            dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith("_results.db")]
+            if r.returncode != 0 or not dbs:
+                detail[ctr] = "rc %d, %d result files; %s" % (r.returncode, len(dbs), (r.stderr or "")[-160:])
+                continue
+            db = sqlite3.connect(dbs[0])
+            row = db.execute("select count(*), avg(value), avg(duration) from counters_collection where counter_name = ? and kernel_name like "
+                             "'%msm_accumulate29_kernel%'", (ctr,)).fetchone()
+            db.close()
+            if row and row[0]:
+                vals[ctr] = float(row[1]) * 1024.0
+                detail[ctr] = {"launches": int(row[0]), "bytes_per_launch": round(vals[ctr], 1), "avg_launch_ms_under_rocprof": round(float(row[2]) / 1e6, 3)}
+            else:
+                detail[ctr] = "no msm_accumulate29_kernel dispatch in the counter collection"
+        except Exception as e:
+            detail[ctr] = repr(e)[:200]
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    detail["seconds"] = round(time.perf_counter() - t0, 1)
+    if len(vals) == 2:
+        return vals["FETCH_SIZE"] + vals["WRITE_SIZE"], ("this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child passes (--kernel-trace only) over "
+                                                            "bench.py --only-headline --steps 3; KiB x 1024 per dispatch, uncorrected"), detail
+    return None, "the in-run rocprofv3 passes failed: " + json.dumps(detail)[:200], detail
 
 
 def check_msm_result(R, cid, group, scalars_host, dlogs_host, result):
@@ -341,13 +426,31 @@ def headline_leg(R):
     out["value_checked"] = res["value_checked"]
     out["config"].update({"window_bits": res["window_bits"], "windows": res["windows"],
                           "precompute": ("[2^(c*w)]P tables for all %d windows, %.1f GiB per GPU, one shared bucket set" % (res["windows"], ti["table_bytes"] / 2**30)) if ti else "none",
-                          "parallelism": "1 GPU" if R.world == 1 else "base-range sharding x%d, RCCL all_gather of Jacobian partials" % R.world})
+                          "parallelism": "1 GPU" if R.world == 1 else "base-range sharding x%d, %s all_gather of Jacobian partials" % (
+                              R.world, "RCCL (torch.distributed backend nccl)" if R.backend == "nccl" else "torch.distributed backend " + str(R.backend))})
+    if R.world > 1:
+        out["config"]["backend"] = R.backend
     acc = res["stages"].get("msm_accumulate")
-    traffic, tsrc = pmc_traffic("msm_accumulate_kernel", args.curve, args.log_n) if R.world == 1 else (None, None)
+    traffic, tsrc = (None, None)
+    if R.world == 1 and not R.emu:
+        live = (None, "in-run counter passes switched off (--no-pmc)", {})
+        if not args.no_pmc and not args.only_headline:
+            live = pmc_traffic_live(args)
+            out["pmc_passes"] = live[2]
+        traffic, tsrc = live[0], live[1]
+        if traffic is None:   # fall back to the committed figure, and say so
+            ctraffic, csrc = pmc_traffic("msm_accumulate_kernel", args.curve, args.log_n)
+            if ctraffic is not None:
+                traffic, tsrc = ctraffic, "COMMITTED figure, not this run (%s); %s" % (tsrc, csrc)
     out["roofline"] = roofline_object(cid, 0, res["pairs_this_rank"], res["windows"], acc, "msm_accumulate29_kernel" if use_table else "msm_accumulate_kernel", traffic, tsrc)
+    if traffic is not None:
+        out["roofline"]["traffic_calibration"] = ("FETCH_SIZE + WRITE_SIZE as reported; the guide's x2 for wide coalesced streaming reads does not apply to 64-B "
+                                                  "gathers (x2 would exceed full 128-B lines for every gather); this library's 16 B/lane streaming passes read back 1.05x "
+                                                  "their bytes (profiles/pmc_latest.json 'calibration')")
+        out["roofline"]["traffic_over_algorithmic"] = round(traffic / out["roofline"]["algorithmic_bytes_per_launch"], 2)
     if R.world > 1:
         out["roofline"]["rank"] = 0
-        out["roofline"]["note"] += "; rank 0's launches over its 2^%d / %d pairs" % (args.log_n, R.world)
+        out["roofline"]["note"] = "rank 0's launches over its 2^%d / %d pairs" % (args.log_n, R.world)
     out["stages_ms"] = res["stages"]
     return out, (keep, res)
 
@@ -558,7 +661,7 @@ def groth16_single_gpu_leg(R, cid, curve_name):
     return g
 
 
-def groth16_sharded_leg(R, leg_cid, leg_curve):
+def groth16_sharded_leg(R, leg_cid, leg_curve, partition):
     """N > 1: ONE 2^log_n proof over the world's GPUs -- strong scaling of BASELINE config 3 / 4.  Every rank generates ITS shard of
     the synthetic key on its own device, chunk by chunk (synth.pin_key_chunked: no 12 GiB key is staged through host memory), and the
     solution (the prover's real input); W uploaded per wire range, computeH's chains on ranks 0..2, h slices scattered over xGMI, one
@@ -573,7 +676,7 @@ def groth16_sharded_leg(R, leg_cid, leg_curve):
     try:
         R.fault("pin")
         inst = synth.make_instance(ctx, leg_cid, args.log_n, 0x5EED0005, want_dlogs=check_here, with_key=False)   # same seeds on every rank
-        kw = dict(shard=(rank, world)) if args.partition == "range" else dict(window_shard=(rank, world))
+        kw = dict(shard=(rank, world)) if partition == "range" else dict(window_shard=(rank, world))
         t_pin = time.perf_counter()
         pk = with_retry(lambda: synth.pin_key_chunked(ctx, inst, precompute=1, **kw), "pinning the key shard")
         pin_s = time.perf_counter() - t_pin
@@ -631,13 +734,76 @@ def groth16_sharded_leg(R, leg_cid, leg_curve):
             chk = {"matches_dlog": None, "checker_error": repr(e)[:300]}
     return {"curve": leg_curve, "proofs_per_s": round(proofs / el, 4), "ms_per_proof": round(el * 1e3 / proofs, 2),
             "matches_dlog": chk["matches_dlog"] if chk else None, "check": chk,
-            "proofs": proofs, "constraints": n, "scaling": "strong", "partition": args.partition,
+            "proofs": proofs, "constraints": n, "scaling": "strong", "partition": partition,
             "mode": ("one proof over %d GPUs: key sharded by base-point range (1/%d of the tables per GPU, each rank generates only its shard), W uploaded per wire range "
                      "(%d of %d wires on rank 0), A,B,C uploaded 1/N per rank and gathered on the chain owners (N >= 3), computeH chains on ranks 0-2 beside the witness MSMs, h slices scattered, all_gather of 5 partial points" %
-                     (world, world, lay["w_hi"] - lay["w_lo"], lay["nb_wires"])) if args.partition == "range" else
+                     (world, world, lay["w_hi"] - lay["w_lo"], lay["nb_wires"])) if partition == "range" else
                     ("one proof over %d GPUs: whole key on every GPU, windows of every MSM shared out, h broadcast, all_gather of 5 partial points" % world),
             "key_pin_s": round(pin_s, 1), "replicate_h_ms_per_proof": rep_ms,
             "proof_sha": hashlib.sha256(proof.WriteTo()).hexdigest()[:16]}
+
+
+def replicas_leg(R, cid, curve_name, reference_sha=None):
+    """N > 1, the THROUGHPUT figure: every rank pins the WHOLE key with its window tables on its own GPU and
+    proves `--replica-proofs` independent proofs, single caller -- what the reference's one-proof-per-device contract
+    (icicle.go:77-86,821-823) gives on N devices.  No data-path collective: the ranks meet only at the two fences around the timed
+    region and in the all_reduce / all_gather of counts and times after it.  Aggregate proofs/s = proofs of all ranks / max-over-ranks
+    time between the fences.  Local steps under try -> agree() -> collectives, like every multi-rank leg."""
+    import hashlib
+    from gnark_amd import groth16, synth
+    ctx, args = R.ctx, R.args
+    k = args.replica_proofs
+    pk, inst, ok, err, pin_s = None, None, True, None, None
+    try:
+        R.fault("replica_pin")
+        inst = synth.make_instance(ctx, cid, args.log_n, 0x5EED0005, want_dlogs=False, with_key=False)   # same seeds on every rank: same proof
+        t_pin = time.perf_counter()
+        pk = with_retry(lambda: synth.pin_key_chunked(ctx, inst, precompute=1), "pinning the whole key")
+        pin_s = time.perf_counter() - t_pin
+        for _ in range(2):
+            groth16.Prove(pk, inst.solution, inst.nb_public, inst.r, inst.s)
+        ctx.sync()
+    except Exception as e:
+        ok, err = False, repr(e)[:300]
+    ok, err = R.agree(ok, err)
+    if not ok:
+        if pk is not None:
+            pk.FreeGPUResources()
+        return {"curve": curve_name, "error": "skipped on every rank: " + str(err)}
+    sol, nb_public, r, s = inst.solution, inst.nb_public, inst.r, inst.s
+    proof, local_s, err2 = None, float("nan"), None
+    R.fence()
+    t0 = time.perf_counter()
+    try:
+        for _ in range(k):
+            proof = groth16.Prove(pk, sol, nb_public, r, s)
+        ctx.sync()
+        local_s = time.perf_counter() - t0
+    except Exception as e:   # (no collective inside the loop: a failing rank still reaches the fence below)
+        err2 = repr(e)[:300]
+    R.fence()
+    el = R.max_over_ranks(time.perf_counter() - t0)
+    pk.FreeGPUResources()
+    done = R.sum_over_ranks(float(k if err2 is None else 0))        # all_reduce of the proof counts
+    sha = hashlib.sha256(proof.WriteTo()).hexdigest()[:16] if proof is not None else "-" * 16
+    rec = ("%9.3f %s" % (local_s * 1e3 / max(k, 1) if err2 is None else -1.0, sha)).encode()[:32].ljust(32, b" ")
+    if R.world > 1:
+        t = R.torch.tensor(list(rec), dtype=R.torch.uint8, device=R.coll_dev or "cpu")
+        parts = [R.torch.zeros_like(t) for _ in range(R.world)]
+        R.dist.all_gather(parts, t)
+        recs = [bytes(q.cpu().tolist()).decode().split() for q in parts]
+    else:
+        recs = [rec.decode().split()]
+    per_rank_ms = [float(x[0]) for x in recs]
+    shas = [x[1] for x in recs]
+    out = {"curve": curve_name, "scaling": "weak (independent proofs)", "proofs_per_rank": k, "proofs_total": int(done), "constraints": 1 << args.log_n,
+           "proofs_per_s": round(done / el, 4) if el > 0 else None, "wall_ms_per_round": round(el * 1e3 / max(k, 1), 2),
+           "ms_per_proof_by_rank": [round(x, 2) for x in per_rank_ms], "same_proof_on_every_rank": len(set(shas)) == 1, "proof_sha": shas[0],
+           "same_proof_as_sharded": (shas[0] == reference_sha) if reference_sha else None, "key_pin_s": round(pin_s, 1),
+           "how": "every rank: whole key + window tables on its own GPU, %d proofs back to back from one caller; no data-path collective; proofs of all ranks / max-over-ranks time between two fences" % k}
+    if err2 is not None or done != k * R.world:
+        out["error"] = "a rank failed inside the timed loop: " + str(err2 or "on another rank")
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
@@ -846,6 +1012,141 @@ def cpu_baseline_leg(R, out):
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
+def compact_line(out):
+    """What goes to stdout: the driver keeps the LAST 8 KB of it, so the line carries numbers, not prose (the verbose object, with
+    every leg's explanation, goes to --detail-file), stays under that size, and ENDS with "summary": every figure BASELINE's metric
+    names, in one object."""
+    def pick(o, *ks):
+        return {k: o[k] for k in ks if isinstance(o, dict) and k in o}
+
+    def stage_totals(st, field):
+        return {k: (round(v[field], 3) if isinstance(v, dict) else v) for k, v in (st or {}).items()}
+
+    def g16(q):
+        if not isinstance(q, dict):
+            return q
+        if "error" in q:
+            return pick(q, "curve", "partition", "error")
+        r = pick(q, "curve", "partition", "scaling", "ms_per_proof", "proofs_per_s", "proofs", "constraints", "matches_dlog", "computeH_ms", "computeH_hbm_frac",
+                 "hbm_frac_whole_proof", "proof_sha", "key_setup_s", "key_pin_s", "ms_per_proof_profiled_single_lane", "replicate_h_ms_per_proof")
+        if isinstance(q.get("check"), dict):
+            r["h_identity_ok"] = q["check"].get("h_identity_ok")
+        if isinstance(q.get("pipelined"), dict):
+            pl = q["pipelined"]
+            r["two_callers"] = dict(pick(pl, "ms_per_proof", "proofs_per_s", "vs_single_caller", "same_proof_bytes", "proofs"),
+                                    **{k: pl.get("lanes", {}).get(k) for k in ("lanes01_proofs", "lanes23_proofs", "queued_proofs")})
+        if q.get("stages_ms"):
+            r["stages_ms_per_proof"] = stage_totals(q["stages_ms"], "total_ms")
+        return r
+
+    line = pick(out, "metric", "value", "value_checked", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "error")
+    cfg = dict(out.get("config", {}))
+    line["config"] = cfg
+    rf = dict(out.get("roofline") or {})
+    rf.pop("int_mad_peak_source", None)
+    if isinstance(rf.get("traffic_calibration"), str):
+        rf["traffic_calibration"] = "as reported (x1): 64-B gathers, see DESIGN 6"
+    if isinstance(rf.get("traffic_source"), str) and len(rf["traffic_source"]) > 150:
+        rf["traffic_source"] = rf["traffic_source"][:150]
+    line["roofline"] = rf
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict):
+        c2 = pick(cb, "value", "unit", "cores", "kind", "effective_cores", "host_cores", "gpu_result_matches_oracle", "error")
+        if "sample" in cb:
+            c2["sample"] = cb["sample"][:110]
+        if "note" in cb:
+            c2["note"] = "plain-C port of the algorithm (oracle/oracle.c), NOT gnark-crypto: the GPU/CPU ratio is not a claim"
+        if isinstance(cb.get("groth16"), dict):
+            c2["groth16"] = pick(cb["groth16"], "proofs_per_s", "constraints", "threads_used", "gpu_proof_matches_oracle", "error")
+        line["cpu_baseline"] = c2
+    if out.get("stages_ms"):
+        line["stages_ms"] = stage_totals(out["stages_ms"], "avg_ms")
+    for k in ("plain_msm_no_tables", "msm_with_scalar_h2d"):
+        if k in out:
+            line[k] = pick(out[k], "ms_per_msm", "Mscalar_mul_per_s", "sort_ms", "same_result", "error")
+    c2 = out.get("config2_msm_2p20_unpinned")
+    if isinstance(c2, dict):
+        line["config2_msm_2p20_unpinned"] = dict(pick(c2, "gpu_ms_per_msm", "gpu_Mscalar_mul_per_s", "cpu_port_Mscalar_mul_per_s", "cpu_threads", "gpu_result_matches_oracle", "error"),
+                                                 **{("roofline_" + k): v for k, v in pick(c2.get("roofline", {}), "frac", "avg_launch_ms").items()})
+    if "groth16" in out:
+        line["groth16"] = g16(out["groth16"])
+    p = out.get("plonk")
+    if isinstance(p, dict):
+        line["plonk"] = dict(pick(p, "ms_per_proof_kernels", "msm_ms", "ntt_ms", "quotient_and_z_ms", "identity_ok", "log_n", "error"),
+                             roofline=pick(p.get("roofline", {}), "bound", "frac", "achieved", "peak", "unit", "algorithmic_bytes"), stages_ms=p.get("stages_ms"))
+    mb = out.get("msm_bls12_381")
+    if isinstance(mb, dict):
+        line["msm_bls12_381"] = {g: (dict(pick(v, "ms_per_msm", "Mscalar_mul_per_s", "value_checked", "window_bits", "windows", "table_GiB", "error"),
+                                          **{("roofline_" + k): x for k, x in pick(v.get("roofline", {}), "frac", "avg_launch_ms", "int_mad_frac").items()})
+                                     if isinstance(v, dict) else v) for g, v in mb.items()}
+    gb = out.get("groth16_bls12_381")
+    if isinstance(gb, dict):
+        line["groth16_bls12_381"] = {k: g16(v) for k, v in gb.items()} if ("window" in gb or "range" in gb) else g16(gb)
+    for k in ("groth16_window", "groth16_range"):   # the BN254 sharded proof in the partition --partition did not pick
+        if isinstance(out.get(k), dict):
+            line[k] = g16(out[k])
+    for k in ("weak_msm",):
+        if k in out:
+            line[k] = pick(out[k], "value", "unit", "scaling", "ms_per_step", "value_checked", "pairs_per_gpu", "error")
+    if "replicas" in out:
+        line["replicas"] = {k: v for k, v in out["replicas"].items() if k != "how"} if isinstance(out["replicas"], dict) else out["replicas"]
+    for k in ("backend", "world_size", "ranks", "nccl_selftest"):
+        if k in out:
+            line[k] = out[k]
+    sd = out.get("nccl_selftest_detail")
+    if isinstance(sd, dict):
+        line["nccl_selftest_detail"] = dict(pick(sd, "ok", "agree", "msm_all_gather", "sharded_proof_same_bytes", "seconds", "error"),
+                                            collectives_ok=(sd.get("collectives") or {}).get("ok"))
+    if "pmc_passes" in out:
+        line["pmc_passes"] = out["pmc_passes"]
+    line["legs_seconds"] = out.get("legs_seconds")
+    line["total_seconds"] = out.get("total_seconds")
+    # ---- the whole metric in one object, LAST
+    g, gbl = out.get("groth16") or {}, out.get("groth16_bls12_381") or {}
+    sm = {"msm_Mscalar_mul_per_s": out.get("value"), "msm_ms": out.get("ms_per_step"), "msm_checked": out.get("value_checked"), "n_gpus": out.get("n_gpus"),
+          "roofline_frac_hbm": rf.get("frac"), "int_mad_frac": rf.get("int_mad_frac"), "traffic_over_algorithmic": rf.get("traffic_over_algorithmic"),
+          "groth16_bn254_ms_per_proof": g.get("ms_per_proof"), "groth16_bn254_proofs_per_s": g.get("proofs_per_s"), "groth16_bn254_matches_dlog": g.get("matches_dlog"),
+          "groth16_bn254_computeH_ms": g.get("computeH_ms")}
+    if isinstance(g.get("pipelined"), dict):
+        sm["groth16_bn254_two_callers_ms_per_proof"] = g["pipelined"].get("ms_per_proof")
+        sm["groth16_bn254_two_callers_vs_single"] = g["pipelined"].get("vs_single_caller")
+    if "partition" in g:
+        sm["groth16_bn254_partition"] = g.get("partition")
+    if "window" in gbl or "range" in gbl:
+        for part in ("window", "range"):
+            if isinstance(gbl.get(part), dict):
+                sm["groth16_bls12_381_%s_ms_per_proof" % part] = gbl[part].get("ms_per_proof")
+                sm["groth16_bls12_381_%s_matches_dlog" % part] = gbl[part].get("matches_dlog")
+    elif gbl:
+        sm["groth16_bls12_381_ms_per_proof"] = gbl.get("ms_per_proof")
+        sm["groth16_bls12_381_matches_dlog"] = gbl.get("matches_dlog")
+    for k in ("groth16_window", "groth16_range"):
+        if isinstance(out.get(k), dict):
+            sm["groth16_bn254_%s_ms_per_proof" % k.split("_")[1]] = out[k].get("ms_per_proof")
+    if isinstance(out.get("replicas"), dict):
+        sm["replicas_proofs_per_s"] = out["replicas"].get("proofs_per_s")
+        sm["replicas_ms_per_proof_by_rank"] = out["replicas"].get("ms_per_proof_by_rank")
+    if isinstance(out.get("weak_msm"), dict):
+        sm["weak_msm_Mscalar_mul_per_s"] = out["weak_msm"].get("value")
+    if isinstance(out.get("plonk"), dict):
+        sm["plonk_bn254_2p22_ms"] = out["plonk"].get("ms_per_proof_kernels")
+        sm["plonk_identity_ok"] = out["plonk"].get("identity_ok")
+    for k, f in (("plain_msm_no_tables", "ms_per_msm"), ("msm_with_scalar_h2d", "ms_per_msm"), ("config2_msm_2p20_unpinned", "gpu_ms_per_msm")):
+        if isinstance(out.get(k), dict):
+            sm[k + "_ms"] = out[k].get(f)
+    if isinstance(mb, dict):
+        for grp in ("g1", "g2"):
+            if isinstance(mb.get(grp), dict):
+                sm["msm_bls12_381_%s_ms" % grp] = mb[grp].get("ms_per_msm")
+    if isinstance(cb, dict):
+        sm["cpu_port_Mscalar_mul_per_s"] = cb.get("value")
+    if "backend" in out:
+        sm["backend"] = out["backend"]
+    line["summary"] = {k: v for k, v in sm.items() if v is not None}
+    return line
+
+
 def main():
     if "--nccl-selftest-worker" in sys.argv:
         sys.exit(nccl_selftest_worker())
@@ -868,19 +1169,32 @@ def main():
         legs_s[name] = round(time.perf_counter() - t0, 1)
         return v
 
+    def timed(name, fn, *a):
+        t0 = time.perf_counter()
+        v = fn(*a)
+        legs_s[name] = round(time.perf_counter() - t0, 1)
+        return v
+
+    ranks = R.gather_identities()   # (every rank; before any leg: what the collective backend really connected)
     t0 = time.perf_counter()
     out, kept = headline_leg(R)
     legs_s["headline_msm"] = round(time.perf_counter() - t0, 1)
+    if world > 1:
+        out["backend"] = R.backend
+        out["world_size"] = R.dist.get_world_size()
+        out["ranks"] = ranks
     if kept is not None:
         keep, res = kept
-        if rank == 0 and world == 1:
+        if rank == 0 and world == 1 and not args.only_headline:
             try:
                 single_gpu_msm_extras(R, out, keep, res)
             except Exception as e:
                 out["plain_msm_no_tables"] = {"error": repr(e)[:300]}
         free_keep(keep)
 
-    if world == 1:
+    if args.only_headline:
+        pass
+    elif world == 1:
         if args.groth16_proofs > 0:
             out["groth16"] = leg("groth16", groth16_single_gpu_leg, R, cid, args.curve)
         if args.plonk_log_n > 0 and cid == 0:
@@ -894,27 +1208,37 @@ def main():
             out["nccl_selftest"], out["nccl_selftest_detail"] = nccl_selftest_leg(R)
             legs_s["nccl_selftest"] = round(time.perf_counter() - t0, 1)
     else:
-        t0 = time.perf_counter()
-        wk = weak_msm_leg(R)
-        legs_s["weak_msm"] = round(time.perf_counter() - t0, 1)
-        g16 = g16_bls = None
+        # Every leg below is entered by EVERY rank in the same order (each keeps the local-step -> agree() -> collectives discipline,
+        # so a failing rank turns a leg into an error object on all ranks and the next leg still runs).
+        wk = timed("weak_msm", weak_msm_leg, R)
+        g16 = g16_w = g16_bls = rep = None
         if args.groth16_proofs > 0 and os.environ.get("GA_BENCH_SHARDED_G16", "1") != "0":
-            t0 = time.perf_counter()
-            g16 = groth16_sharded_leg(R, cid, args.curve)
-            legs_s["groth16"] = round(time.perf_counter() - t0, 1)
-            # BASELINE config 4 (Groth16 BLS12-381 at 2^24 over 8 GPUs) appears in the same line once the node has 8 ranks
-            if cid == 0 and (world >= 8 or os.environ.get("GA_BENCH_CONFIG4", "0") == "1"):
-                t0 = time.perf_counter()
-                g16_bls = groth16_sharded_leg(R, curve_id("bls12-381"), "bls12-381")
-                legs_s["groth16_bls12_381"] = round(time.perf_counter() - t0, 1)
+            # BASELINE config 3 over N GPUs: ONE proof, key sharded by base-point range (--partition picks the other one for this leg)
+            g16 = timed("groth16", groth16_sharded_leg, R, cid, args.curve, args.partition)
+            if os.environ.get("GA_BENCH_BOTH_PARTITIONS", "1") != "0":
+                other = "window" if args.partition == "range" else "range"
+                g16_w = timed("groth16_" + other, groth16_sharded_leg, R, cid, args.curve, other)
+            # BASELINE config 4 (Groth16 BLS12-381, 2^24, MSM window-sharded over the GPUs) at EVERY world > 1, in both partitions:
+            # "window" is BASELINE's wording, "range" the partition that balances better
+            if cid == 0 and os.environ.get("GA_BENCH_CONFIG4", "1") != "0":
+                g16_bls = {}
+                for part in ("window", "range"):
+                    g16_bls[part] = timed("groth16_bls12_381_" + part, groth16_sharded_leg, R, curve_id("bls12-381"), "bls12-381", part)
+        if args.replica_proofs > 0 and os.environ.get("GA_BENCH_REPLICAS", "1") != "0":
+            ref_sha = g16.get("proof_sha") if isinstance(g16, dict) else None
+            rep = timed("replicas", replicas_leg, R, cid, args.curve, ref_sha)
         if rank == 0:
             out["weak_msm"] = wk
             if g16 is not None:
                 out["groth16"] = g16
+            if g16_w is not None:
+                out["groth16_window" if g16_w.get("partition", "window") == "window" else "groth16_range"] = g16_w
             if g16_bls is not None:
                 out["groth16_bls12_381"] = g16_bls
+            if rep is not None:
+                out["replicas"] = rep
 
-    if rank == 0 and not args.no_cpu_baseline:   # (the other ranks wait in the barrier below; a local leg, no collectives inside)
+    if rank == 0 and not args.no_cpu_baseline and not args.only_headline:   # (the other ranks wait in the barrier below; a local leg, no collectives inside)
         t0 = time.perf_counter()
         try:
             cpu_baseline_leg(R, out)
@@ -926,7 +1250,13 @@ def main():
     if rank == 0:
         out["legs_seconds"] = legs_s
         out["total_seconds"] = round(time.perf_counter() - t_all, 1)
-        print(json.dumps(out))
+        if args.detail_file:
+            try:
+                with open(args.detail_file, "w") as f:
+                    json.dump(out, f)
+            except OSError as e:
+                sys.stderr.write("bench: could not write %s: %r\n" % (args.detail_file, e))
+        print(json.dumps(compact_line(out), separators=(",", ":")))
     R.ctx.close()
     if world > 1:
         R.dist.destroy_process_group()

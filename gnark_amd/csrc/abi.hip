@@ -22,17 +22,17 @@ void set_error(const char* fmt, ...) {
 }
 const char* get_error() { return g_err; }
 
-int abi_exception_code() noexcept {
+int abi_exception_code(const char* entry) noexcept {
     try {
         throw;   // (Lippincott function: re-raise the exception being handled to classify it)
     } catch (const std::bad_alloc&) {
-        set_error("out of host memory (std::bad_alloc) under %s", current_entry());
+        set_error("out of host memory (std::bad_alloc) under %s", entry);
         return GA_ERR_NOMEM;
     } catch (const std::exception& e) {
-        set_error("internal error under %s: %s", current_entry(), e.what());
+        set_error("internal error under %s: %s", entry, e.what());
         return GA_ERR_STATE;
     } catch (...) {
-        set_error("internal error under %s: unknown exception", current_entry());
+        set_error("internal error under %s: unknown exception", entry);
         return GA_ERR_STATE;
     }
 }
@@ -58,7 +58,7 @@ const char* device_malloc_error(hipError_t e) { return g_alloc_why[0] ? g_alloc_
 
 hipError_t device_malloc_bytes(void** p, size_t bytes) {
     // The last GA_HBM_RESERVE_MB (default 1024) MiB of the device stay free for the runtime's own dispatch-time allocations.
-    // The reserve is a rule about what THIS allocation leaves behind, so it is checked before the hipMalloc, under a process-wide
+    // The reserve is a rule about what THIS allocation leaves behind, so it is checked before the hipMalloc, under the device's
     // mutex (two lanes cannot both pass on the same free bytes).  Allocations below 16 MiB may use the upper half of the reserve: a
     // few-KB buffer is not refused because another process or rank sharing the device has eaten a little into it.
     static const size_t reserve = []() {
@@ -66,14 +66,25 @@ hipError_t device_malloc_bytes(void** p, size_t bytes) {
         return (size_t)(e ? strtoull(e, nullptr, 10) : 1024ull) << 20;
     }();
     static const size_t small = 16ull << 20;
-    static std::mutex alloc_mu;
+    // one mutex per DEVICE (the reserve is a per-device rule; ga_g16_prove_multi allocates on several devices from one process and
+    // must not serialise them on each other)
+    constexpr int MAX_DEV = 64;
+    static std::mutex alloc_mu[MAX_DEV];
     *p = nullptr;
     g_alloc_why[0] = 0;
-    std::lock_guard<std::mutex> g(alloc_mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    std::lock_guard<std::mutex> g(alloc_mu[dev % MAX_DEV]);
     if (reserve) {
         size_t free_b = 0, total_b = 0;
         const size_t floor_b = bytes >= small ? reserve : reserve / 2;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (free_b < bytes || free_b - bytes < floor_b)) {
+        const hipError_t qe = hipMemGetInfo(&free_b, &total_b);
+        if (qe != hipSuccess) {   // without the free-memory figure the reserve cannot be honoured: refuse rather than skip it silently
+            (void)hipGetLastError();
+            snprintf(g_alloc_why, sizeof(g_alloc_why), "refused: hipMemGetInfo failed (%s), the GA_HBM_RESERVE_MB rule cannot be checked", hipGetErrorString(qe));
+            return hipErrorOutOfMemory;
+        }
+        if (free_b < bytes || free_b - bytes < floor_b) {
             snprintf(g_alloc_why, sizeof(g_alloc_why), "refused: %zu MiB free, the allocation would leave less than the %zu MiB reserve (GA_HBM_RESERVE_MB)",
                      free_b >> 20, reserve >> 20);
             return hipErrorOutOfMemory;

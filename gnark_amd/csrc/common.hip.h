@@ -56,7 +56,7 @@ const char* get_error();
 // slot leases, staged buffers, thread joiners) release on the way out, so the context stays usable.
 // GA_ABI_ENTRY also names the entry point for the fault knob GA_FAULT_THROW=<entry point> (tests only): Ctx::scratch_get then throws
 // std::bad_alloc when called under that entry point on the calling thread.
-int abi_exception_code() noexcept;   // call inside a catch (...) handler
+int abi_exception_code(const char* entry) noexcept;   // call inside a catch (...) handler
 struct EntryScope {
     const char* prev;
     explicit EntryScope(const char* name);
@@ -65,9 +65,9 @@ struct EntryScope {
 const char* current_entry();         // the innermost entry point of the calling thread ("" outside the library)
 #define GA_ABI_ENTRY() ::ga::EntryScope _ga_entry_scope(__func__)
 #define GA_ABI_CATCH \
-    catch (...) { return ::ga::abi_exception_code(); }
+    catch (...) { return ::ga::abi_exception_code(__func__); }
 #define GA_ABI_CATCH_VOID \
-    catch (...) { (void)::ga::abi_exception_code(); }
+    catch (...) { (void)::ga::abi_exception_code(__func__); }
 
 #define GA_HIP_CHECK(expr)                                                                              \
     do {                                                                                                \
@@ -249,15 +249,19 @@ struct Ctx {
     // tables whose SMALL shared bucket set turned out mostly empty on the previous call (a witness of zeros and ones puts nearly
     // every (scalar, window) pair into the skip bucket): the lazy window reduction flags most groups there, so the next call takes
     // the exact kernel again (msm.hip.h, dense_set)
-    std::set<const void*> sparse_sets;
+    // The verdict is re-examined: every 16th call on such a table takes the lazy pass again and note_sparse_set renews or drops it
+    // (one 0/1-heavy witness must not send a table to the slow exact kernel for the rest of its life).
+    std::map<const void*, uint32_t> sparse_sets;   // table -> calls since the verdict
     bool is_sparse_set(const void* table) {
         std::lock_guard<std::mutex> g(degenerate_mu);
-        return sparse_sets.count(table) != 0;
+        auto it = sparse_sets.find(table);
+        if (it == sparse_sets.end()) return false;
+        return (++it->second % 16) != 0;
     }
     void note_sparse_set(const void* table, bool sparse) {
         std::lock_guard<std::mutex> g(degenerate_mu);
         if (sparse)
-            sparse_sets.insert(table);
+            sparse_sets.emplace(table, 0u);   // (keeps the running count of an existing verdict)
         else
             sparse_sets.erase(table);
     }

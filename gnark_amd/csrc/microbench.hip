@@ -264,28 +264,35 @@ __global__ void __launch_bounds__(64) mb_clock_probe(uint64_t ticks, uint64_t* o
 }
 
 int util_clock_probe(Ctx* ctx, uint32_t micros, double* mhz_out) {
+    // Runs BESIDE whatever holds the context, from another thread: nothing here may synchronise the device or touch the allocator
+    // (hipFree waits for every stream -- the probe would block until the load it measures had drained -- and a raw hipMalloc would
+    // bypass the GA_HBM_RESERVE_MB accounting of device_malloc).  The kernel writes its two counters straight into pinned host
+    // memory, which a kernel can address as is; the probe's own stream is the only thing waited for.
     hipSetDevice(ctx->device);
     hipStream_t st;
     GA_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    uint64_t *d_out = nullptr, h_out[2] = {0, 0};
-    hipError_t e = hipMalloc(&d_out, 16);
+    uint64_t* h_out = nullptr;
+    hipError_t e = hipHostMalloc((void**)&h_out, 16, hipHostMallocMapped);
     if (e != hipSuccess) {
+        (void)hipGetLastError();
         hipStreamDestroy(st);
-        set_error("ga_clock_probe: hipMalloc failed");
+        set_error("ga_clock_probe: hipHostMalloc failed: %s", hipGetErrorString(e));
         return GA_ERR_NOMEM;
     }
+    h_out[0] = h_out[1] = 0;
     int wall_khz = 100000;
     (void)hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, ctx->device);
-    hipLaunchKernelGGL(mb_clock_probe, dim3(1), dim3(64), 0, st, (uint64_t)micros * (uint64_t)wall_khz / 1000ull, d_out);
-    e = hipMemcpyAsync(h_out, d_out, 16, hipMemcpyDeviceToHost, st);
+    hipLaunchKernelGGL(mb_clock_probe, dim3(1), dim3(64), 0, st, (uint64_t)micros * (uint64_t)wall_khz / 1000ull, h_out);
+    e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    hipFree(d_out);
+    const uint64_t cycles = h_out[0], ticks = h_out[1];
+    hipHostFree(h_out);
     hipStreamDestroy(st);
-    if (e != hipSuccess || h_out[1] == 0) {
+    if (e != hipSuccess || ticks == 0) {
         set_error("ga_clock_probe failed: %s", hipGetErrorString(e));
         return GA_ERR_HIP;
     }
-    *mhz_out = (double)h_out[0] / (double)h_out[1] * (double)wall_khz / 1000.0;
+    *mhz_out = (double)cycles / (double)ticks * (double)wall_khz / 1000.0;
     return GA_OK;
 }
 

@@ -69,6 +69,22 @@ def test_host_side_group_arithmetic_of_the_built_library(built_so, curve, group)
         assert np.array_equal(oracle.jac_to_affine(curve, group, out), oracle.jac_to_affine(curve, group, want)), (nwin, c)
 
 
+def test_every_entry_point_is_an_exception_barrier():
+    """every extern "C" definition of the library is a function-try-block ending in GA_ABI_CATCH (common.hip.h): the count of guarded
+    bodies equals the count of definitions, file by file, and together they are every function the header declares except the two
+    that return a constant string"""
+    import re
+    total = 0
+    for f in ("abi.hip", "groth16.hip", "hash_to_field.hip"):
+        src = open(os.path.join(ROOT, "gnark_amd", "csrc", f)).read()
+        defs = re.findall(r'^(?:extern "C" )?(?:int|void) (ga_\w+)\([^;{]*\) (try )?\{', src, flags=re.M)
+        assert defs and all(t for _, t in defs), [n for n, t in defs if not t]
+        assert len(defs) == len(re.findall(r"^\} GA_ABI_CATCH(?:_VOID)?$", src, flags=re.M)), f
+        assert src.count("GA_ABI_ENTRY();") == len(defs), f
+        total += len(defs)
+    assert total == len(declared_functions()) - 2   # ga_last_error, ga_version
+
+
 def test_no_cpu_fallback_in_package():
     """The product package must not import the oracle or the emulation build."""
     for dirpath, _, files in os.walk(os.path.join(ROOT, "gnark_amd")):

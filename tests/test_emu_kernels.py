@@ -930,6 +930,85 @@ def test_emu_kzg_open(emu_ctx, c, n, srs_len=None):
         srs.free()
 
 
+def test_emu_abi_exception_barrier(emu_ctx, monkeypatch, c=BN254, n=300):
+    """No C++ exception crosses the C ABI (the reference turns device errors into Go errors, icicle.go:122-208; an exception unwinding
+    into cgo would abort the process).  GA_FAULT_THROW=<entry point> makes the next device-scratch request under that entry point
+    throw std::bad_alloc deep inside the call; every entry point is a function-try-block, so the call returns GA_ERR_NOMEM (-3), the
+    locks / lanes / staged buffers are released by the unwinding, and the SAME call on the same context succeeds right after with
+    the result it had before."""
+    ctx = emu_ctx
+    rng = pyref.Xoshiro(77)
+    bases, dlogs, scal = _device_inputs(ctx, c, 0, n, 0xE1C)
+    table = ecc.PrecomputedBases(ctx, c.name, 0, bases, n=n)
+    dom = fft.Domain(ctx, c.name, 64)
+    T = _plonk_case(c, 16, 5, 1)
+    d0, d1 = fft.Domain(ctx, c.name, 16), fft.Domain(ctx, c.name, 4 * 16)
+    polys = {k: fr_to_arr(c, T["can"][k]) for k in plonk.IDS}
+    kw = dict(bp={k: fr_to_arr(c, v) for k, v in T["bp"].items()}, alpha=fr_to_arr(c, [T["alpha"]]), beta=fr_to_arr(c, [T["beta"]]),
+              gamma=fr_to_arr(c, [T["gamma"]]))
+    ppk = plonk.ProvingKey(d0, d1, {k: polys[k] for k in plonk.FIXED_IDS}, [fr_to_arr(c, T["qc_can"][0])])
+    v = fr_to_arr(c, [rng.field(c.r) for _ in range(64)])
+    poly = fr_to_arr(c, [rng.field(c.r) for _ in range(n)])
+    z = fr_to_arr(c, [rng.field(c.r)])
+    A = fr_to_arr(c, [rng.field(c.r) for _ in range(60)])
+
+    def fft_host():
+        w = v.copy()
+        dom.FFT(w, fft.DIF)
+        return w
+    calls = {
+        "ga_msm": lambda: ecc.MultiExp(ctx, c.name, 0, bases, scal, n=n),
+        "ga_msm_table_run": lambda: table.MultiExp(scal),
+        "ga_msm_table_run_batch": lambda: table.MultiExpBatch([scal, scal]),
+        "ga_fft": fft_host,
+        "ga_compute_h": lambda: dom.compute_h(A, A, oracle.fr_mul(c.cid, A, A)),
+        "ga_plonk_quotient_pinned": lambda: ppk.ComputeQuotient({k: polys[k] for k in plonk.PROOF_IDS}, [fr_to_arr(c, T["pi_can"][0])], **kw),
+        "ga_plonk_quotient": lambda: plonk.ComputeQuotient(d0, d1, polys, [fr_to_arr(c, T["qc_can"][0])], [fr_to_arr(c, T["pi_can"][0])], **kw),
+        "ga_kzg_open": lambda: np.concatenate([np.asarray(x).ravel() for x in table.KzgOpen(poly, z)]),
+        "ga_fr_batch_invert": lambda: plonk.BatchInvert(ctx, c.name, v),
+    }
+    norm = lambda name, r: ecc.jac_to_affine(c.cid, 0, r, lib=ctx.lib) if name in ("ga_msm", "ga_msm_table_run") else (
+        np.stack([ecc.jac_to_affine(c.cid, 0, x, lib=ctx.lib) for x in r]) if name == "ga_msm_table_run_batch" else np.asarray(r))
+    try:
+        for name, call in calls.items():
+            want = norm(name, call())
+            monkeypatch.setenv("GA_FAULT_THROW", name)
+            with pytest.raises(Exception, match=r"error -3: out of host memory \(std::bad_alloc\) under " + name):
+                call()
+            monkeypatch.setenv("GA_FAULT_THROW", "ga_some_other_entry_point")   # a fault armed for another entry point does not fire here
+            assert np.array_equal(norm(name, call()), want), name
+            monkeypatch.delenv("GA_FAULT_THROW")
+            assert np.array_equal(norm(name, call()), want), name
+    finally:
+        monkeypatch.delenv("GA_FAULT_THROW", raising=False)
+        ppk.close()
+        for d in (dom, d0, d1):
+            d.close()
+        table.free()
+        for b in (bases, dlogs, scal):
+            b.free()
+
+
+def test_emu_abi_exception_barrier_groth16(emu_ctx, monkeypatch, c=BN254):
+    """the same for a proof: ga_g16_prove with a throwing scratch request returns GA_ERR_NOMEM, releases its slot, lanes and helper
+    thread, and the next proof on the same key is byte-identical to the one before the fault"""
+    from gnark_amd import synth
+    ctx = emu_ctx
+    inst = synth.make_instance(ctx, c.cid, 7, 0xFA17, want_dlogs=False)
+    pk = inst.proving_key(ctx, precompute=1)
+    try:
+        args = (pk, inst.solution, inst.nb_public, inst.r, inst.s)
+        before = groth16.Prove(*args).raw()
+        monkeypatch.setenv("GA_FAULT_THROW", "ga_g16_prove")
+        with pytest.raises(Exception, match=r"error -3"):
+            groth16.Prove(*args)
+        monkeypatch.delenv("GA_FAULT_THROW")
+        assert np.array_equal(groth16.Prove(*args).raw(), before)
+    finally:
+        monkeypatch.delenv("GA_FAULT_THROW", raising=False)
+        pk.FreeGPUResources()
+
+
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
 def test_emu_fr_linear_combination(emu_ctx, c, n=300):
     mod = c.r

@@ -174,6 +174,16 @@ def test_msm_fused_sort_wide_keys(gpu_ctx, monkeypatch, table_c, batch, n, xcd):
     cases.test_emu_msm_fused_sort_wide_keys(gpu_ctx, monkeypatch, table_c, batch, xcd, n=n)
 
 
+def test_abi_exception_barrier(gpu_ctx, monkeypatch):
+    """GA_FAULT_THROW on the hipcc-built library: std::bad_alloc thrown inside ga_msm, ga_msm_table_run(_batch), ga_fft, ga_compute_h,
+    ga_plonk_quotient(_pinned), ga_kzg_open, ga_fr_batch_invert comes back as GA_ERR_NOMEM and the context keeps working"""
+    cases.test_emu_abi_exception_barrier(gpu_ctx, monkeypatch, n=5000)
+
+
+def test_abi_exception_barrier_groth16(gpu_ctx, monkeypatch):
+    cases.test_emu_abi_exception_barrier_groth16(gpu_ctx, monkeypatch)
+
+
 def test_raw_msm_2_24_takes_the_fused_sort(gpu_ctx):
     """a raw-bases (no table) BN254 G1 MSM of 2^24 points -- 13 windows x 2^19 buckets, 23 key bits -- runs on the fused sort since
     round 4 (no library sort on any BASELINE path) and equals [sum s_i k_i]G"""

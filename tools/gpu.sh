@@ -24,7 +24,7 @@ TAG=${TAG:-r04}
 OUT=gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-SHORT_BENCH="--steps 3 --warmup 1 --no-cpu-baseline --no-check --groth16-proofs 1 --no-pipelined --plonk-log-n 0 --no-bls --no-selftest"
+SHORT_BENCH="--steps 3 --warmup 1 --no-cpu-baseline --no-check --groth16-proofs 1 --no-pipelined --plonk-log-n 0 --no-bls --no-selftest --no-pmc"
 
 driver_cmd() {
   case "$1" in
@@ -69,12 +69,12 @@ for step in "$@"; do
       tail -2 $OUT/${TAG}_microbench.err; cat $OUT/${TAG}_microbench.json ;;
     bench)
       sfx=$(echo "$arg" | tr -cd 'a-z0-9' | cut -c1-24)
-      (time timeout 2400 python bench.py $arg) > $OUT/${TAG}_bench${sfx:+_$sfx}.json 2> $OUT/${TAG}_bench${sfx:+_$sfx}.err
+      (time timeout 2400 python bench.py --detail-file $OUT/${TAG}_bench${sfx:+_$sfx}_detail.json $arg) > $OUT/${TAG}_bench${sfx:+_$sfx}.json 2> $OUT/${TAG}_bench${sfx:+_$sfx}.err
       tail -4 $OUT/${TAG}_bench${sfx:+_$sfx}.err
       python tools/bench_digest.py $OUT/${TAG}_bench${sfx:+_$sfx}.json ;;
     bench2)
       GA_BENCH_BACKEND=gloo timeout 1500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 \
-        bench.py --gpus 2 --steps 3 --warmup 1 $arg > $OUT/${TAG}_bench_2ranks_one_gpu_gloo.json 2> $OUT/${TAG}_bench_2ranks.err
+        bench.py --gpus 2 --steps 3 --warmup 1 --detail-file $OUT/${TAG}_bench_2ranks_one_gpu_gloo_detail.json $arg > $OUT/${TAG}_bench_2ranks_one_gpu_gloo.json 2> $OUT/${TAG}_bench_2ranks.err
       tail -3 $OUT/${TAG}_bench_2ranks.err
       python tools/bench_digest.py $OUT/${TAG}_bench_2ranks_one_gpu_gloo.json ;;
     stats)
