@@ -118,7 +118,10 @@ int Ctx::scratch_get(const char* base_key, size_t bytes, void** out) {
         scratch.erase(it);
     }
     void* p = nullptr;
-    size_t want = bytes + bytes / 8 + 256;
+    // growth slack so that slowly growing requests do not reallocate every time -- capped: 1/8 of a multi-GiB sort buffer is a
+    // gigabyte nobody uses (10 GiB of a 2^26 proof's 94 GiB of scratch)
+    const size_t slack = bytes / 8 < (64u << 20) ? bytes / 8 : (size_t)(64u << 20);
+    size_t want = bytes + slack + 256;
     hipError_t e = device_malloc(&p, want);
     if (e != hipSuccess) {
         set_error("device scratch '%s': device_malloc(%zu) failed: %s", key, want, device_malloc_error(e));
@@ -152,6 +155,7 @@ void Tunables::read_env() {
     put64(reduce_lazy_min, num("GA_REDUCE_LAZY_MIN", 1u << 14));
     put(g16_share_min_pct, (int)num("GA_G16_SHARE_MIN_PCT", 90));
     put(g16_lanes, (int)num("GA_G16_LANES", 2));
+    put64(g16_table_budget_pct, num("GA_G16_TABLE_BUDGET_PCT", 0));
     put(g16_split, (int)num("GA_G16_SPLIT", 1));
     put(ntt_coset_fold, (int)num("GA_NTT_COSET_FOLD", 1));
     put(ntt_wave_local, (int)num("GA_NTT_WAVE_LOCAL", 1));

@@ -143,6 +143,7 @@ struct StageRec {
 //   GA_MSM_MAX_CHUNK      split an MSM along the point axis into chunks of at most this many points (msmChunkedG1/G2 analogue)
 //   GA_REDUCE_LAZY_MIN    bucket count from which the window reduction runs in the lazy representation
 //   GA_G16_SHARE_MIN_PCT  a Groth16 base vector shares the single witness sort when it covers at least this % of the wires
+//   GA_G16_TABLE_BUDGET_PCT  % of the bytes of a key's five window tables that precompute = 0 may spend, instead of what the free HBM allows (tests: partial tables)
 //   GA_MSM_MIN_SEG        shortest task length the bucket lists are cut into (points per task)
 //   GA_MSM_FUSE_MIN       (point, window) pairs from which an MSM sorts with the fused two-level sort instead of the library's (2^21)
 //   GA_MSM_XCD            fused sort: bit 0 per-XCD slices in the first level (from 2^24 pairs; bit 2: at any size), bit 1 XCD swizzle in the second (3; A/B knob)
@@ -160,6 +161,7 @@ struct Tunables {
     std::atomic<uint64_t> msm_max_chunk{0};          // 0 = only the 2^31 pair-space limit
     std::atomic<uint64_t> reduce_lazy_min{1u << 14};
     std::atomic<int> g16_share_min_pct{90};
+    std::atomic<uint64_t> g16_table_budget_pct{0};    // 0 = from the free HBM; else the % of the five tables' bytes precompute = 0 may spend (tests)
     std::atomic<int> g16_lanes{2};
     std::atomic<int> g16_split{1};
     std::atomic<int> ntt_coset_fold{1};
@@ -373,8 +375,8 @@ struct MsmPrepared {
     bool table = false;
     uint32_t half = 0, nb = 0, seg = 0;
     uint64_t m = 0, max_tasks = 0;
-    uint32_t *vals = nullptr, *task_off = nullptr, *task_start = nullptr, *task_key = nullptr, *task_perm = nullptr;
-    uint32_t* task_key_by_id = nullptr;   // unsorted: seg - len of task id
+    uint32_t *vals = nullptr, *task_off = nullptr, *task_start = nullptr, *task_key = nullptr, *task_perm = nullptr;   // task_key: the SORTED quantised keys (0xFFFFFFFF = padding)
+    uint32_t* task_key_by_id = nullptr;   // unsorted, exact: seg - len of task id
     uint32_t* task_dest = nullptr;        // slot of the task's sum in [bucket sums | partial sums]
 };
 

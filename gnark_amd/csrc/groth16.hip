@@ -39,13 +39,18 @@ struct G16Pk {
     uint64_t len_k_remove = 0;
     std::vector<void*> d_ck_basis, d_ck_sigma;   // pinned pedersen keys (setup.go:260-287, icicle.go:231-261)
     std::vector<uint64_t> ck_len;
-    // precomputed window-multiple tables (msm.hip.h): d_a.. then point to windows x len points and c_* is the window width
-    bool tables = false;
+    // precomputed window-multiple tables (msm.hip.h): a vector with its tab_* flag set points to windows x len points and c_* is the
+    // window width.  Per VECTOR since round 5: when the five tables do not fit the free HBM together (2^26 constraints: 288 GiB), the
+    // ones that pay most per byte are built -- A, B (G1), K (they share one witness sort), then Z, then the twice as large G2.B --
+    // and the rest stay plain affine arrays that run as un-pinned MSMs.
+    bool tables = false;   // any of the five
+    bool tab_a = false, tab_b = false, tab_z = false, tab_k = false, tab_b2 = false;
     int c_a = 0, c_b = 0, c_z = 0, c_k = 0;
     // Wire-indexed tables: when a base vector covers (almost) every wire, its table is laid out by WIRE id with (0,0) at the
     // wires it lacks (infinity entries are skipped by the bucket kernel), so that the digit extraction + radix sort of the whole
     // witness is done ONCE and shared by the A, B (G1 and G2) and K MSMs instead of once per filtered copy of the witness.
-    bool share_a = false, share_b = false, share_k = false;
+    bool share_a = false, share_b = false, share_k = false;   // (each implies its tab_* flag)
+    bool share_b2 = false;                                    // G2.B wire-indexed too: it reuses the shared sort (share_b and tab_b2)
     int c_w = 0;
     // multi-GPU partition B: this key holds slice [off, off+len) of every base vector (ga_g16_key.shard_index/count)
     uint32_t shard_index = 0, shard_count = 1;
@@ -364,9 +369,50 @@ static int stage_finish(G16Stage* st, int precompute, G16Pk** out) {
         if (!plan_ok && precompute > 0) rc = GA_ERR_INVALID;   // vectors beyond the table index space: the caller asked for tables explicitly
         size_t free_b = 0, total_b = 0;
         hipMemGetInfo(&free_b, &total_b);
-        // leave room for the per-proof scratch (~0.6 KB per constraint measured) and some slack
-        const bool fits = plan_ok && (double)need + (double)pk->n * 1024.0 < 0.85 * (double)free_b;
-        if (rc == GA_OK && (precompute > 0 || fits)) {
+        // Which vectors get a table.  precompute > 0: all five (the caller insists; a table that does not fit fails the call).
+        // precompute == 0: as many as fit the free HBM next to the per-proof scratch, in the order of what a table buys per byte: A, B1, K (48 GiB each at 2^26 BN254; with all three the witness is
+        // sorted once instead of three times), Z, and last G2.B (twice the bytes for the smallest relative gain).
+        const uint64_t bytes_a = pk->share_a ? wide * t1 : (uint64_t)(C::FrP::BITS / pk->c_a + 1) * pk->len_a * t1;
+        const uint64_t bytes_b = pk->share_b ? wide * t1 : (uint64_t)(C::FrP::BITS / pk->c_b + 1) * pk->len_b * t1;
+        const uint64_t bytes_b2 = pk->share_b ? wide * t2 : (uint64_t)(C::FrP::BITS / pk->c_b + 1) * pk->len_b * t2;
+        const uint64_t bytes_z = (uint64_t)(C::FrP::BITS / pk->c_z + 1) * pk->len_z * t1;
+        const uint64_t bytes_k = pk->share_k ? wide * t1 : (uint64_t)(C::FrP::BITS / pk->c_k + 1) * pk->len_k * t1;
+        (void)need;
+        if (rc == GA_OK && plan_ok) {
+            if (precompute > 0) {
+                pk->tab_a = pk->tab_b = pk->tab_k = pk->tab_z = pk->tab_b2 = true;
+            } else {
+                // What the tables may take = free HBM - what a single caller's proof will allocate on this context (measured: 1.15 KB per
+                // constraint at 2^26 with three tables -- sort pairs, task lists, hat-domain copies of the plain vectors, input slots, NTT
+                // tables --, 1.25 KB allowed, + 10 %) - 4 GiB.  At 2^26 BN254 on an empty device: 244 - 88 - 4 = 152 GiB -> A, B, K (144).
+                // Scratch this context already holds (an earlier proof of this size) is credited against the allowance: it is not free
+                // any more, but it is exactly what the allowance was for.
+                uint64_t held = 0;
+                {
+                    std::lock_guard<std::mutex> g(ctx->scratch_mu);
+                    for (const auto& kv : ctx->scratch) held += kv.second.second;
+                }
+                const double per_proof = (double)pk->n * 1280.0;
+                const double allowance = per_proof > (double)held ? per_proof - (double)held : 0.0;
+                double budget = (double)free_b - 1.1 * allowance - 4.0 * 1073741824.0;
+                if (const uint64_t mb = ctx->tun.g16_table_budget_pct) budget = (double)mb / 100.0 * (double)(bytes_a + bytes_b + bytes_k + bytes_z + bytes_b2);   // GA_G16_TABLE_BUDGET_PCT (tests: partial tables on small keys)
+                struct Cand { bool* flag; uint64_t bytes; } order[5] = {{&pk->tab_a, bytes_a}, {&pk->tab_b, bytes_b}, {&pk->tab_k, bytes_k},
+                                                                       {&pk->tab_z, bytes_z}, {&pk->tab_b2, bytes_b2}};
+                for (auto& cnd : order) {
+                    // (the plain array it replaces is freed once the table stands; while it is built both are resident)
+                    if ((double)cnd.bytes <= budget) {
+                        *cnd.flag = true;
+                        budget -= (double)cnd.bytes;
+                    }
+                }
+            }
+        }
+        pk->share_a = pk->share_a && pk->tab_a;
+        pk->share_b = pk->share_b && pk->tab_b;
+        pk->share_k = pk->share_k && pk->tab_k;
+        pk->share_b2 = pk->share_b && pk->tab_b2;
+        pk->tables = pk->tab_a || pk->tab_b || pk->tab_k || pk->tab_z || pk->tab_b2;
+        if (rc == GA_OK && pk->tables) {
             auto make = [&](void** slot, uint64_t len, int c, size_t psz, auto build) -> int {
                 if (len == 0) return GA_OK;
                 const int nwin = C::FrP::BITS / c + 1;
@@ -418,20 +464,22 @@ static int stage_finish(G16Stage* st, int precompute, G16Pk** out) {
             }
             if (rc == GA_OK && pk->share_a) rc = widen(&pk->d_a, pk->len_a, pk->d_idx_a, s1);
             if (rc == GA_OK && pk->share_b) rc = widen(&pk->d_b, pk->len_b, pk->d_idx_b, s1);
-            if (rc == GA_OK && pk->share_b) rc = widen(&pk->d_b2, pk->len_b2, pk->d_idx_b, s2);
+            if (rc == GA_OK && pk->share_b2) rc = widen(&pk->d_b2, pk->len_b2, pk->d_idx_b, s2);
             if (rc == GA_OK && pk->share_k) rc = widen(&pk->d_k, pk->len_k, d_ik, s1);
             if (d_ik && d_ik != pk->d_idx_k) hipFree(d_ik);
             const uint64_t nwr = pk->nb_wires;
-            if (rc == GA_OK) rc = pk->share_a ? make(&pk->d_a, nwr, pk->c_w, t1, b1) : make(&pk->d_a, pk->len_a, pk->c_a, t1, b1);
-            if (rc == GA_OK) rc = pk->share_b ? make(&pk->d_b, nwr, pk->c_w, t1, b1) : make(&pk->d_b, pk->len_b, pk->c_b, t1, b1);
-            if (rc == GA_OK) rc = make(&pk->d_z, pk->len_z, pk->c_z, t1, b1);
-            if (rc == GA_OK) rc = pk->share_k ? make(&pk->d_k, nwr, pk->c_w, t1, b1) : make(&pk->d_k, pk->len_k, pk->c_k, t1, b1);
-            if (rc == GA_OK) rc = pk->share_b ? make(&pk->d_b2, nwr, pk->c_w, t2, b2) : make(&pk->d_b2, pk->len_b2, pk->c_b, t2, b2);
-            pk->tables = rc == GA_OK;
-            if (!pk->tables) pk->share_a = pk->share_b = pk->share_k = false;
+            if (rc == GA_OK && pk->tab_a) rc = pk->share_a ? make(&pk->d_a, nwr, pk->c_w, t1, b1) : make(&pk->d_a, pk->len_a, pk->c_a, t1, b1);
+            if (rc == GA_OK && pk->tab_b) rc = pk->share_b ? make(&pk->d_b, nwr, pk->c_w, t1, b1) : make(&pk->d_b, pk->len_b, pk->c_b, t1, b1);
+            if (rc == GA_OK && pk->tab_z) rc = make(&pk->d_z, pk->len_z, pk->c_z, t1, b1);
+            if (rc == GA_OK && pk->tab_k) rc = pk->share_k ? make(&pk->d_k, nwr, pk->c_w, t1, b1) : make(&pk->d_k, pk->len_k, pk->c_k, t1, b1);
+            if (rc == GA_OK && pk->tab_b2) rc = pk->share_b2 ? make(&pk->d_b2, nwr, pk->c_w, t2, b2) : make(&pk->d_b2, pk->len_b2, pk->c_b, t2, b2);
+            if (rc != GA_OK) pk->tables = false;
         }
     }
-    if (!pk->tables) pk->share_a = pk->share_b = pk->share_k = false;
+    if (!pk->tables) {
+        pk->share_a = pk->share_b = pk->share_k = pk->share_b2 = false;
+        pk->tab_a = pk->tab_b = pk->tab_k = pk->tab_z = pk->tab_b2 = false;
+    }
     if (rc != GA_OK) {
         pk_free(pk);
         return rc;
@@ -1057,7 +1105,7 @@ template <class C>
 static int k_msm(G16Pk* pk, uint64_t nb_public, WitnessShared& sh, XYZZ<Fe<typename C::FpP>>* out) {
     typedef Fe<typename C::FpP> F1;
     Ctx* ctx = pk->ctx;
-    if (pk->tables && pk->share_k) {
+    if (pk->share_k) {
         if (!sh.w_live) {
             *out = xyzz_inf<F1>();
             return GA_OK;
@@ -1072,7 +1120,7 @@ static int k_msm(G16Pk* pk, uint64_t nb_public, WitnessShared& sh, XYZZ<Fe<typen
         GA_CHECK(util_gather_fr<C>(ctx, g, d_w, pk->d_idx_k, pk->len_k));
         d_wk = g;
     }
-    if (pk->tables) {
+    if (pk->tab_k) {
         MsmPrepared prep;
         bool live;
         return g16_table_msm_g1<C>(pk, pk->d_k, d_wk, pk->len_k, pk->c_k, &prep, &live, out);
@@ -1107,7 +1155,7 @@ static int witness_msms(G16Pk* pk, const SlotLease& slot, uint64_t nb_public, Wi
     GA_CHECK(ctx->scratch_get("g16_wa", pk->len_a * 32 + 32, &d_wa));
     GA_CHECK(ctx->scratch_get("g16_wb", pk->len_b * 32 + 32, &d_wb));
     // digits + sort of the WHOLE witness once (scratch slot 1), reused by every wire-indexed table
-    if (pk->tables && (pk->share_a || pk->share_b || pk->share_k)) {
+    if (pk->share_a || pk->share_b || pk->share_k) {
         int lo, hi;
         g16_window_share<C>(pk, pk->c_w, &lo, &hi);
         if (hi > lo) {
@@ -1121,11 +1169,12 @@ static int witness_msms(G16Pk* pk, const SlotLease& slot, uint64_t nb_public, Wi
     sh.post(true);
     // ---- wire filtering (prove.go:147-168) ------------------------------------------------------------
     if (!pk->share_a) GA_CHECK(util_gather_fr<C>(ctx, d_wa, d_w, pk->d_idx_a, pk->len_a));
-    if (!pk->share_b) GA_CHECK(util_gather_fr<C>(ctx, d_wb, d_w, pk->d_idx_b, pk->len_b));
+    if (!pk->share_b || !pk->share_b2) GA_CHECK(util_gather_fr<C>(ctx, d_wb, d_w, pk->d_idx_b, pk->len_b));   // (G2.B may be plain beside a wire-indexed G1.B)
     // ---- the witness MSMs (prove.go:194,207,237,283) ---------------------------------------------------
     XYZZ<F1> ar, bs1;
     XYZZ<F2> bs2;
-    if (pk->tables) {
+    {   // every vector on its own kind of path: wire-indexed table over the shared sort, compact table with its own digits + sort, or
+        // plain bases (no table: un-pinned MSM, one bucket set per window + Horner)
         MsmPrepared prep;
         bool prep_live = false;   // `prep` holds the digits of wB for G2.B
         auto shared_g1 = [&](const void* table, XYZZ<F1>* out) -> int {
@@ -1136,20 +1185,27 @@ static int witness_msms(G16Pk* pk, const SlotLease& slot, uint64_t nb_public, Wi
             return msm_table_device_reuse<C, GA_G1>(ctx, table, sh.prep_w, out);
         };
         if (pk->share_a) GA_CHECK(shared_g1(pk->d_a, &ar));
-        else GA_CHECK(g16_table_msm_g1<C>(pk, pk->d_a, d_wa, pk->len_a, pk->c_a, &prep, &prep_live, &ar));
-        if (pk->share_b) {
-            GA_CHECK(shared_g1(pk->d_b, &bs1));
+        else if (pk->tab_a) GA_CHECK(g16_table_msm_g1<C>(pk, pk->d_a, d_wa, pk->len_a, pk->c_a, &prep, &prep_live, &ar));
+        else GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_a, d_wa, pk->len_a, true, &ar, pk->win_index, pk->win_count)));
+        prep_live = false;   // (whatever A left in `prep` is not wB's)
+        if (pk->share_b) GA_CHECK(shared_g1(pk->d_b, &bs1));
+        else if (pk->tab_b) GA_CHECK(g16_table_msm_g1<C>(pk, pk->d_b, d_wb, pk->len_b, pk->c_b, &prep, &prep_live, &bs1));
+        else GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_b, d_wb, pk->len_b, true, &bs1, pk->win_index, pk->win_count)));
+        if (pk->share_b2) {   // G2.B wire-indexed: the shared witness sort again
             if (sh.w_live) GA_CHECK((msm_table_device_reuse<C, GA_G2>(ctx, pk->d_b2, sh.prep_w, &bs2)));
             else bs2 = xyzz_inf<F2>();
+        } else if (pk->tab_b2) {   // compact G2.B table (window width c_b): the digits / sort of wB that G1.B's compact table has just made, or its own
+            int lo, hi;
+            g16_window_share<C>(pk, pk->c_b, &lo, &hi);
+            if (pk->len_b2 == 0 || hi <= lo) {
+                bs2 = xyzz_inf<F2>();
+            } else {
+                if (!prep_live) GA_CHECK(msm_prepare_table_scalars<C>(ctx, d_wb, pk->len_b2, true, pk->c_b, &prep, 0, lo, hi));
+                GA_CHECK((msm_table_device_reuse<C, GA_G2>(ctx, pk->d_b2, prep, &bs2)));
+            }
         } else {
-            GA_CHECK(g16_table_msm_g1<C>(pk, pk->d_b, d_wb, pk->len_b, pk->c_b, &prep, &prep_live, &bs1));
-            if (pk->len_b2 && prep_live) GA_CHECK((msm_table_device_reuse<C, GA_G2>(ctx, pk->d_b2, prep, &bs2)));   // same scalars wB: digits/sort shared
-            else bs2 = xyzz_inf<F2>();
+            GA_CHECK((host_msm<C, GA_G2>(ctx, pk->d_b2, d_wb, pk->len_b2, true, &bs2, pk->win_index, pk->win_count)));
         }
-    } else {
-        GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_a, d_wa, pk->len_a, true, &ar, pk->win_index, pk->win_count)));
-        GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_b, d_wb, pk->len_b, true, &bs1, pk->win_index, pk->win_count)));
-        GA_CHECK((host_msm<C, GA_G2>(ctx, pk->d_b2, d_wb, pk->len_b2, true, &bs2, pk->win_index, pk->win_count)));
     }
     *o_ar = ar;
     *o_bs1 = bs1;
@@ -1182,7 +1238,7 @@ static int z_msm(G16Pk* pk, const void* d_h_slice, XYZZ<Fe<typename C::FpP>>* ou
         *out = xyzz_inf<F1>();
         return GA_OK;
     }
-    if (pk->tables) {
+    if (pk->tab_z) {
         int lo, hi;
         window_share(C::FrP::BITS / pk->c_z + 1, pk->win_index, pk->win_count, &lo, &hi);
         if (hi <= lo) {
@@ -2100,7 +2156,11 @@ int ga_g16_shard_layout(ga_g16_pk* p, uint64_t* out6) try {
     out6[4] = pk->n;
     out6[5] = pk->nb_wires;
     out8[6] = pk->win_index;
-    out8[7] = pk->win_count;
+    // bits 32..: which vectors carry a window table (bit 32 A, 33 B, 34 Z, 35 K, 36 G2.B) and which of those are wire-indexed over the
+    // shared witness sort (bit 40 A, 41 B, 43 K, 44 G2.B)
+    const uint64_t tabs = (uint64_t)pk->tab_a | (uint64_t)pk->tab_b << 1 | (uint64_t)pk->tab_z << 2 | (uint64_t)pk->tab_k << 3 | (uint64_t)pk->tab_b2 << 4 |
+                          (uint64_t)pk->share_a << 8 | (uint64_t)pk->share_b << 9 | (uint64_t)pk->share_k << 11 | (uint64_t)pk->share_b2 << 12;
+    out8[7] = (uint64_t)pk->win_count | tabs << 32;
     return GA_OK;
 } GA_ABI_CATCH
 

@@ -46,6 +46,10 @@ typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_con
                                    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 21>, rocprim::kernel_config<1024, 21>, 11,
                                                                        rocprim::block_radix_rank_algorithm::match>>
     MsmSortWide;
+// The task list is sorted on 8 key bits (msm_prepare): ONE onesweep pass.  The library's default switches to a merge sort below 2^20
+// items -- 20 launches, 0.14 ms, for the 1.04 M tasks of a 2^20-point MSM (profiles/r05_h_msm_2p20_raw_kernels_seg256.txt) -- so the
+// limit is lowered to where a merge sort is really cheaper.
+typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 32768> MsmTaskSort;
 
 // Sort (key, value) pairs on the low end_bit key bits, ping-ponging between the two buffer pairs (no third copy of the data); on
 // return keys2/vals2 point at the sorted arrays and keys/vals at the other pair.  The library sort: small MSMs, and whatever the
@@ -521,13 +525,15 @@ static __global__ void msm_tasks_kernel(const uint32_t* __restrict__ off, uint32
 
 // task t of bucket b covers sorted pairs [start, start+len); key = SEG - len so that an ascending radix sort puts the
 // longest tasks first and lanes of one wave get tasks of (nearly) equal length (bucket sizes are Poisson-distributed:
-// without this a wave waits for its longest bucket, ~25 % of the lanes' time at 2^24)
+// without this a wave waits for its longest bucket, ~25 % of the lanes' time at 2^24).  The SORT key is the length quantised to
+// 7 bits (qkey = key >> qshift; lanes of a wave then differ by < 2^qshift points): with the padding bit that is ONE 8-bit radix pass
+// over the task list instead of two (2^20 raw MSM: task stage 0.18 -> 0.08 ms, profiles/r05_e); the exact key stays in task_key.
 // (one launch for what were two memsets and an iota: padding keys, the identity permutation the task sort starts from, the counter
 // of the long-bucket queue)
-static __global__ void msm_task_init_kernel(uint32_t* __restrict__ task_key, uint32_t* __restrict__ task_id, uint32_t n, uint32_t* __restrict__ long_count) {
+static __global__ void msm_task_init_kernel(uint32_t* __restrict__ task_qkey, uint32_t* __restrict__ task_id, uint32_t n, uint32_t* __restrict__ long_count) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
-        task_key[i] = 0xFFFFFFFFu;
+        task_qkey[i] = 0xFFFFFFFFu;
         task_id[i] = i;
     }
     if (i == 0) *long_count = 0;
@@ -537,8 +543,9 @@ static __global__ void msm_task_init_kernel(uint32_t* __restrict__ task_key, uin
 // are not written by their one lane: they are queued and written by msm_task_list_long_kernel, a block per bucket.
 constexpr uint32_t MSM_LONG_TASKS = 64;
 static __global__ void msm_task_list_kernel(const uint32_t* __restrict__ off, const uint32_t* __restrict__ task_off, uint32_t nb,
-                                            uint32_t seg, uint32_t* __restrict__ task_start, uint32_t* __restrict__ task_key,
-                                            uint32_t* __restrict__ task_dest, uint32_t* __restrict__ long_list, uint32_t* __restrict__ long_count) {
+                                            uint32_t seg, int qshift, uint32_t* __restrict__ task_start, uint32_t* __restrict__ task_key,
+                                            uint32_t* __restrict__ task_qkey, uint32_t* __restrict__ task_dest, uint32_t* __restrict__ long_list,
+                                            uint32_t* __restrict__ long_count) {
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
     uint32_t t0 = task_off[b], t1 = task_off[b + 1];
@@ -554,12 +561,14 @@ static __global__ void msm_task_list_kernel(const uint32_t* __restrict__ off, co
         // sum itself (the merge pass then has nothing to do for that bucket)
         task_dest[t] = (t1 - t0 == 1) ? b : nb + t;
         task_key[t] = seg - len;
+        task_qkey[t] = (seg - len) >> qshift;
         start += len;
     }
 }
 
 static __global__ void msm_task_list_long_kernel(const uint32_t* __restrict__ off, const uint32_t* __restrict__ task_off, uint32_t nb, uint32_t seg,
-                                                 uint32_t* __restrict__ task_start, uint32_t* __restrict__ task_key, uint32_t* __restrict__ task_dest,
+                                                 int qshift, uint32_t* __restrict__ task_start, uint32_t* __restrict__ task_key,
+                                                 uint32_t* __restrict__ task_qkey, uint32_t* __restrict__ task_dest,
                                                  const uint32_t* __restrict__ long_list, const uint32_t* __restrict__ long_count) {
     const uint32_t nl = *long_count;
     for (uint32_t h = blockIdx.x; h < nl; h += gridDim.x) {
@@ -572,6 +581,7 @@ static __global__ void msm_task_list_long_kernel(const uint32_t* __restrict__ of
             task_start[t] = s0;
             task_dest[t] = nb + t;
             task_key[t] = seg - len;
+            task_qkey[t] = (seg - len) >> qshift;
         }
     }
 }
@@ -768,8 +778,8 @@ __device__ __forceinline__ bool store_task29(const LdsAcc29<F>& A, bool have, XY
 template <class F, bool COMPLETE>
 __global__ void __launch_bounds__(Table29<F>::THREADS, Table29<F>::MIN_WAVES)
 msm_accumulate29_kernel(const uint32_t* __restrict__ table, const uint32_t* __restrict__ vals,
-                        const uint32_t* __restrict__ task_start, const uint32_t* __restrict__ task_key_sorted,
-                        const uint32_t* __restrict__ task_perm, uint32_t max_tasks, uint32_t seg,
+                        const uint32_t* __restrict__ task_start, const uint32_t* __restrict__ task_qkey_sorted,
+                        const uint32_t* __restrict__ task_key_by_tid, const uint32_t* __restrict__ task_perm, uint32_t max_tasks, uint32_t seg,
                         const uint32_t* __restrict__ task_dest, XYZZ<F>* __restrict__ sums, uint32_t* __restrict__ redo_list,
                         uint32_t* __restrict__ redo_count) {
     constexpr int NW = Lazy<F>::NW;
@@ -781,9 +791,9 @@ msm_accumulate29_kernel(const uint32_t* __restrict__ table, const uint32_t* __re
     // profiles/r04_e_resident_bucket_grid_ab.txt.)
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= max_tasks) return;
-    const uint32_t key = task_key_sorted[t];
-    if (key >= seg) return;
+    if (task_qkey_sorted[t] == 0xFFFFFFFFu) return;   // padding slot of the task list
     const uint32_t tid = task_perm[t];
+    const uint32_t key = task_key_by_tid[tid];
     const uint32_t start = task_start[tid];
     LdsAcc29<F> A(lds + threadIdx.x);
     const bool have = accumulate_task29<F, COMPLETE>(A, table, vals, start, start + (seg - key));
@@ -1360,9 +1370,6 @@ int msm_prepare(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, in
 
     uint32_t *keys, *vals, *keys2, *vals2, *off, *ntask, *task_off, *task_start, *task_key, *task_key2, *task_id, *task_perm;
     void* tmp;
-    GA_CHECK(ctx->scratch_get(key("msm_keys").c_str(), m * 4, (void**)&keys));
-    GA_CHECK(ctx->scratch_get(key("msm_vals").c_str(), m * 4, (void**)&vals));
-    GA_CHECK(ctx->scratch_get(key("msm_keys2").c_str(), m * 4, (void**)&keys2));
     GA_CHECK(ctx->scratch_get(key("msm_vals2").c_str(), m * 4, (void**)&vals2));
     GA_CHECK(ctx->scratch_get(key("msm_off").c_str(), ((uint64_t)nb + 2) * 4, (void**)&off));
     GA_CHECK(ctx->scratch_get(key("msm_ntask").c_str(), ((uint64_t)nb + 2) * 4, (void**)&ntask));
@@ -1370,6 +1377,8 @@ int msm_prepare(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, in
     GA_CHECK(ctx->scratch_get(key("msm_task_start").c_str(), max_tasks * 4, (void**)&task_start));
     GA_CHECK(ctx->scratch_get(key("msm_task_key").c_str(), max_tasks * 4, (void**)&task_key));
     GA_CHECK(ctx->scratch_get(key("msm_task_key2").c_str(), max_tasks * 4, (void**)&task_key2));
+    uint32_t* task_qkey;
+    GA_CHECK(ctx->scratch_get(key("msm_task_qkey").c_str(), max_tasks * 4, (void**)&task_qkey));
     GA_CHECK(ctx->scratch_get(key("msm_task_id").c_str(), max_tasks * 4, (void**)&task_id));
     GA_CHECK(ctx->scratch_get(key("msm_task_perm").c_str(), max_tasks * 4, (void**)&task_perm));
     uint32_t* task_dest;
@@ -1381,6 +1390,18 @@ int msm_prepare(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, in
     // number of scalar vectors over one table, enough pairs for the saved traffic to matter (GA_MSM_FUSE_MIN)
     const int xcd = ctx->tun.msm_xcd.load(std::memory_order_relaxed);
     const bool fused = msm_fused_fits(nb64) && nwl <= MSM_P1_MAXW && m >= ctx->tun.msm_fuse_min.load(std::memory_order_relaxed);
+    // Scratch of the sort.  Fused: keys / vals are the first level's output, dead once the second level has run, and the sorted keys
+    // are never materialised -- so the two sort slots of a lane SHARE them (stream order separates their uses) and there is no keys2:
+    // 12 bytes per pair less per extra slot, 10 GiB of a 2^26 proof.  Library sort: ping-pong pairs, the result may live in either.
+    keys2 = nullptr;
+    if (fused) {
+        GA_CHECK(ctx->scratch_get("msm_keys_level1", m * 4, (void**)&keys));
+        GA_CHECK(ctx->scratch_get("msm_vals_level1", m * 4, (void**)&vals));
+    } else {
+        GA_CHECK(ctx->scratch_get(key("msm_keys").c_str(), m * 4, (void**)&keys));
+        GA_CHECK(ctx->scratch_get(key("msm_vals").c_str(), m * 4, (void**)&vals));
+        GA_CHECK(ctx->scratch_get(key("msm_keys2").c_str(), m * 4, (void**)&keys2));
+    }
     if (fused) {
         if (msm_p1_bits(nb64) == 11)
             GA_CHECK((msm_fused_sort<FrP, 11>(ctx, sfx, st, d_scalars, n, scalars_mont, c, nwin, win_lo, win_hi, table, batch, half, nb, m, keys, vals, vals2, off, xcd)));
@@ -1406,7 +1427,10 @@ int msm_prepare(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, in
         GA_CHECK(ctx->scratch_get(key("msm_long").c_str(), (max_tasks / MSM_LONG_TASKS + 2) * 4, (void**)&long_list));
         GA_CHECK(ctx->scratch_get(key("msm_long_count").c_str(), 256, (void**)&long_count));
         // explicit task list, ordered by decreasing length (padding slots keep key = 0xFFFFFFFF >= seg)
-        hipLaunchKernelGGL(msm_task_init_kernel, dim3((unsigned)((max_tasks + 255) / 256)), dim3(256), 0, st, task_key, task_id, (uint32_t)max_tasks, long_count);
+        int kbits = 1;
+        while ((1u << kbits) <= seg) kbits++;
+        const int qbits = kbits < 7 ? kbits : 7, qshift = kbits - qbits;
+        hipLaunchKernelGGL(msm_task_init_kernel, dim3((unsigned)((max_tasks + 255) / 256)), dim3(256), 0, st, task_qkey, task_id, (uint32_t)max_tasks, long_count);
         if (!fused)   // (the fused sort produced `off` itself)
             hipLaunchKernelGGL(msm_offsets_tasks_kernel, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, (const uint32_t*)keys2, m, nb, seg, off, ntask);
         else
@@ -1417,17 +1441,15 @@ int msm_prepare(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, in
         GA_CHECK(ctx->scratch_get(key("msm_scan_tmp").c_str(), tmp_bytes + 256, &tmp));
         GA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, ntask, task_off, (int)(nb + 1), st));
         hipLaunchKernelGGL(msm_task_list_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, (const uint32_t*)off, (const uint32_t*)task_off,
-                           nb, seg, task_start, task_key, task_dest, long_list, long_count);
+                           nb, seg, qshift, task_start, task_key, task_qkey, task_dest, long_list, long_count);
         hipLaunchKernelGGL(msm_task_list_long_kernel, dim3(256), dim3(256), 0, st, (const uint32_t*)off, (const uint32_t*)task_off, nb, seg,
-                           task_start, task_key, task_dest, (const uint32_t*)long_list, (const uint32_t*)long_count);
+                           qshift, task_start, task_key, task_qkey, task_dest, (const uint32_t*)long_list, (const uint32_t*)long_count);
         GA_KERNEL_CHECK();
-        int kbits = 1;
-        while ((1u << kbits) <= seg) kbits++;
-        // padding keys are all-ones: sort on kbits+1 bits so that they stay behind every real key (real keys < seg)
+        // padding keys are all-ones: sort on qbits+1 bits so that they stay behind every real key (real keys < 2^qbits)
         size_t tb = 0;
-        GA_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, task_key, task_key2, task_id, task_perm, (unsigned)max_tasks, 0, kbits + 1, st));
+        GA_HIP_CHECK((rocprim::radix_sort_pairs<MsmTaskSort>(nullptr, tb, task_qkey, task_key2, task_id, task_perm, (size_t)max_tasks, 0u, (unsigned)(qbits + 1), st)));
         GA_CHECK(ctx->scratch_get(key("msm_tasksort_tmp").c_str(), tb + 256, &tmp));
-        GA_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp, tb, task_key, task_key2, task_id, task_perm, (unsigned)max_tasks, 0, kbits + 1, st));
+        GA_HIP_CHECK((rocprim::radix_sort_pairs<MsmTaskSort>(tmp, tb, task_qkey, task_key2, task_id, task_perm, (size_t)max_tasks, 0u, (unsigned)(qbits + 1), st)));
     }
     P->n = n;
     P->c = c;
@@ -1526,11 +1548,11 @@ int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, X
         const dim3 grid((unsigned)((P.max_tasks + AT - 1) / AT));
         if (P.table && !ctx->tun.msm_exact_redo && ctx->is_degenerate(d_bases))
             hipLaunchKernelGGL((msm_accumulate29_kernel<F, true>), grid, dim3(AT), 0, st, acc_table, (const uint32_t*)P.vals,
-                               (const uint32_t*)P.task_start, (const uint32_t*)P.task_key, (const uint32_t*)P.task_perm, (uint32_t)P.max_tasks, seg,
+                               (const uint32_t*)P.task_start, (const uint32_t*)P.task_key, (const uint32_t*)P.task_key_by_id, (const uint32_t*)P.task_perm, (uint32_t)P.max_tasks, seg,
                                (const uint32_t*)P.task_dest, bsum, redo2_list, redo_count + 1);
         else
             hipLaunchKernelGGL((msm_accumulate29_kernel<F, false>), grid, dim3(AT), 0, st, acc_table, (const uint32_t*)P.vals,
-                               (const uint32_t*)P.task_start, (const uint32_t*)P.task_key, (const uint32_t*)P.task_perm, (uint32_t)P.max_tasks, seg,
+                               (const uint32_t*)P.task_start, (const uint32_t*)P.task_key, (const uint32_t*)P.task_key_by_id, (const uint32_t*)P.task_perm, (uint32_t)P.max_tasks, seg,
                                (const uint32_t*)P.task_dest, bsum, redo_list, redo_count);
         if (!ctx->tun.msm_exact_redo)   // (GA_MSM_EXACT_REDO=1: tests send the flagged tasks straight to the exact kernel below)
             hipLaunchKernelGGL((msm_accumulate29_retry_kernel<F>), dim3(2048), dim3(AT), 0, st, acc_table, (const uint32_t*)P.vals,

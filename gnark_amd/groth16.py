@@ -310,7 +310,12 @@ def ShardLayout(pk: ProvingKey) -> dict:
     """where this key's shard sits: slice [off_z, off_z+len_z) of h / pk.G1.Z, wire range [w_lo, w_hi) of W (ga_g16_shard_layout)"""
     out = (C.c_uint64 * 8)()
     pk.ctx.lib.check(pk.ctx.lib.ga_g16_shard_layout(pk.handle, out))
-    return dict(zip(("off_z", "len_z", "w_lo", "w_hi", "n", "nb_wires", "win_index", "win_count"), (int(v) for v in out)))
+    d = dict(zip(("off_z", "len_z", "w_lo", "w_hi", "n", "nb_wires", "win_index", "win_count"), (int(v) for v in out)))
+    tabs = d["win_count"] >> 32
+    d["win_count"] &= 0xFFFFFFFF
+    d["tables"] = {k: bool(tabs >> b & 1) for k, b in (("A", 0), ("B", 1), ("Z", 2), ("K", 3), ("B2", 4))}          # vectors with a window table
+    d["wire_indexed"] = {k: bool(tabs >> b & 1) for k, b in (("A", 8), ("B", 9), ("K", 11), ("B2", 12))}            # ... sharing the one witness sort
+    return d
 
 
 def WitnessPartial(pk: ProvingKey, W, nb_public: int) -> np.ndarray:

@@ -521,7 +521,7 @@ def test_emu_plonk_build_z_and_batch_invert(emu_ctx, c, n):
 
 
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
-def test_emu_groth16_synthetic_vs_c_oracle(emu_ctx, c, logn=7):
+def test_emu_groth16_synthetic_vs_c_oracle(emu_ctx, c, monkeypatch, logn=7):
     """Synthetic instance (SURVEY 8d config 3 shape, scaled down; 2^7 under the emulation, 2^10 on the GPU): bases [k_i]G
     generated on the device, proof points identical to the C oracle's prover, with and without window tables."""
     ctx = emu_ctx
@@ -562,6 +562,27 @@ def test_emu_groth16_synthetic_vs_c_oracle(emu_ctx, c, logn=7):
         finally:
             pk.FreeGPUResources()
         assert np.array_equal(proof.Ar, want[0]) and np.array_equal(proof.Bs, want[1]) and np.array_equal(proof.Krs, want[2]), precompute
+    # precompute = 0 with a budget that does not hold all five tables (a 2^26-constraint key on one GPU; GA_G16_TABLE_BUDGET_PCT scales the
+    # situation down): the library builds tables for a PREFIX of A, B, K, Z, G2.B and proves with the rest as plain vectors -- wire-indexed
+    # tables over the shared sort, compact tables and un-pinned MSMs side by side in one proof, same proof points
+    order = ("A", "B", "K", "Z", "B2")
+    sizes = []
+    for pct in (0, 5, 30, 55, 80):   # (0 = no limit; a G1 table is ~1/6 of the five tables' bytes, G2.B 2/6)
+        if pct:
+            monkeypatch.setenv("GA_G16_TABLE_BUDGET_PCT", str(pct))
+        pk = groth16.ProvingKey(ctx, c.name, domain_cardinality=n, precompute=0, **{k: v for k, v in key.items() if k != "n"})
+        try:
+            lay = groth16.ShardLayout(pk)
+            proof = groth16.Prove(pk, groth16.Solution(W, A, B, Cc), nb_public, rs[0], rs[1])
+        finally:
+            pk.FreeGPUResources()
+        have = [k for k in order if lay["tables"][k]]
+        assert have == list(order[:len(have)]), lay["tables"]                      # a prefix of the preference order
+        assert all(lay["tables"][k] for k, v in lay["wire_indexed"].items() if v)  # wire-indexed implies a table
+        sizes.append(len(have))
+        assert np.array_equal(proof.Ar, want[0]) and np.array_equal(proof.Bs, want[1]) and np.array_equal(proof.Krs, want[2]), (pct, lay["tables"])
+    monkeypatch.delenv("GA_G16_TABLE_BUDGET_PCT", raising=False)
+    assert sizes == [5, 0, 1, 3, 4], sizes   # none / A / A, B, K / A, B, K, Z: partial table sets, growing with the budget
     assert len(proof.WriteTo()) == (164 if c.cid == 0 else 244)
 
 

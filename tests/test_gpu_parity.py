@@ -330,8 +330,10 @@ def test_fft_2_22_roundtrip_and_oracle_2_20(gpu_ctx):
 
 
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
-def test_groth16_synthetic_2_10_vs_oracle(gpu_ctx, c):
-    cases.test_emu_groth16_synthetic_vs_c_oracle(gpu_ctx, c, logn=10)
+def test_groth16_synthetic_2_10_vs_oracle(gpu_ctx, c, monkeypatch):
+    """2^10 synthetic instance vs the C oracle's prover: all tables, no tables, and (round 5) the partial table sets of precompute = 0
+    under a budget -- wire-indexed tables, compact tables and plain vectors in one proof"""
+    cases.test_emu_groth16_synthetic_vs_c_oracle(gpu_ctx, c, monkeypatch, logn=10)
 
 
 @pytest.mark.parametrize("precompute", [1, -1, "shared-sort"], ids=["tables", "no-tables", "tables-shared-sort"])
@@ -878,10 +880,12 @@ def test_groth16_2_24_known_dlogs(gpu_ctx, c):
 
 
 def test_groth16_2_26_known_dlogs_beyond_the_table_budget(gpu_ctx):
-    """four times the headline size: 2^26 constraints, BN254.  The window tables no longer fit HBM (precompute = 0 decides that by
-    itself), so the proof runs on the plain base vectors (per-window bucket sets, c = 22 plans over 2^26 points, 2^26-point
-    transforms: 4-pass plans) and must still equal the closed form from the key's discrete logs; h satisfies the identity.
-    (`tools/size_sweep.py` ran the same check at 2^27 -- 230 GiB of HBM -- profiles/README.md, round 3 batch M.)"""
+    """four times the headline size: 2^26 constraints, BN254.  The five window tables (288 GiB) no longer fit HBM together;
+    precompute = 0 builds the ones that fit beside the proof's scratch -- on an empty device A, B and K, which share one witness sort;
+    in the middle of this suite, with the scratch of the earlier tests resident, fewer -- and the rest (Z, G2.B, ...) run as un-pinned
+    MSMs (per-window bucket sets over 2^26 points); 2^26-point transforms (4-pass plans).  The proof must equal the closed form from
+    the key's discrete logs whichever mix of paths it took; h satisfies the identity.  (`tools/size_sweep.py` ran the same check at
+    2^27 -- 230 GiB of HBM -- profiles/README.md, round 3 batch M.)"""
     cases.check_groth16_known_dlogs(gpu_ctx, BN254, 26, nthreads=_NT, proofs=1, precompute=0)
 
 

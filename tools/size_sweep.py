@@ -31,8 +31,8 @@ def main():
     args = ap.parse_args()
     from gnark_amd import groth16, synth
     from gnark_amd.device import Context
-    ctx = Context(0)
     for logn in [int(x) for x in args.logs.split(",")]:
+        ctx = Context(0)   # a context per size: the scratch a smaller size left behind must not eat into a larger key's table budget
         info0 = ctx.info()
         t0 = time.perf_counter()
         checked = None
@@ -41,12 +41,15 @@ def main():
             import numpy as np
             rng = np.random.default_rng(1234)
             kw["inf_b"] = np.flatnonzero(rng.random(1 << logn) >= args.b_density)
-        if logn <= args.check_max:
+        if logn <= args.check_max:   # (in a context of its own: the check's proof must not leave scratch behind that the timed key's table budget sees)
             import checkers
             import pyref
             t0 = time.perf_counter()
-            checkers.check_groth16_known_dlogs(ctx, pyref.CURVES[args.curve], logn, nthreads=min(64, os.cpu_count() or 1), proofs=1, precompute=args.precompute, inst_kw=kw)
+            cctx = Context(0)
+            checkers.check_groth16_known_dlogs(cctx, pyref.CURVES[args.curve], logn, nthreads=min(64, os.cpu_count() or 1), proofs=1, precompute=args.precompute, inst_kw=kw)
+            cctx.close()
             checked = round(time.perf_counter() - t0, 1)
+            info0 = ctx.info()
         inst = synth.make_instance(ctx, args.curve, logn, 0x5EED0005, want_dlogs=False, **kw)
         t1 = time.perf_counter()
         pk = inst.proving_key(ctx, precompute=args.precompute)
@@ -62,6 +65,8 @@ def main():
         ctx.sync()
         ms = (time.perf_counter() - t3) * 1e3 / args.proofs
         info1 = ctx.info()
+        lanes = ctx.lane_stats()
+        lay = groth16.ShardLayout(pk)
         pk.FreeGPUResources()
         one_shot = None
         if args.one_shot:   # the Go package's default (PinToGPU = false): upload the plain key, prove, free -- every proof
@@ -75,10 +80,12 @@ def main():
         print(json.dumps({"curve": args.curve, "log_n": logn, "ms_per_proof": round(ms, 3), "proofs_per_s": round(1e3 / ms, 3),
                           "constraints_per_s": round((1 << logn) / ms * 1e3), "key_pin_s": round(t2 - t1, 2),
                           "hbm_used_gib": round((info0["free_bytes"] - info1["free_bytes"]) / 2**30, 2),
+                          "scratch_gib": round((lanes["lanes01_scratch_bytes"] + lanes["lanes23_scratch_bytes"]) / 2**30, 2),
+                          "tables": "".join(k + ("*" if lay["wire_indexed"].get(k) else "") + " " for k, v in lay["tables"].items() if v).strip() or "none",
                           "checked_known_dlogs_s": checked, "b_density": args.b_density,
                           "one_shot_pin_prove_free_ms": one_shot}), flush=True)
         del inst, sol
-    ctx.close()
+        ctx.close()
 
 
 if __name__ == "__main__":
