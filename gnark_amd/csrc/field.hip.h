@@ -176,7 +176,7 @@ GA_HD Fe<P> neg(const Fe<P>& a) {
 // Montgomery product a*b*R^-1 mod p, R = 2^(32N) (gnark's R), computed carry-free in a smaller radix.
 //
 // gfx950 has no multiply with carry-in: v_mad_u64_u32 is 32x32+64 -> 64 at ~half rate, and a 64-bit add or an add-with-
-// carry costs the same issue slot as the multiply (profiles/r01_microbench.txt: all ~30-35 Gop/s/lane-group), so a
+// carry costs the same issue slot as the multiply (profiles/r01_e_microbench.json: all ~30-35 Gop/s/lane-group), so a
 // 32-bit-limb CIOS spends more time on carry plumbing (v_lshl_add_u64, v_mov to build {x,0} pairs) than on products.
 // Instead the operands are unpacked to L-bit limbs (L = 29 for the 254/255-bit fields, 28 for the 381-bit one) so that
 // a whole column  sum_i a_i*b_j + sum_i m_i*p_j  (2*NL products < 2^(2L)) fits a 64-bit accumulator: every product is ONE

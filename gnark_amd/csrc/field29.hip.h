@@ -3,7 +3,7 @@
 //
 //     hat(x) = x * 2^(NL*L) mod p        (memory format is x * 2^(32N); hat = memory value * 2^S, S = NL*L - 32N)
 //
-// Why: on gfx950 every carry costs an issue slot as expensive as the multiply (profiles/r01_b_microbench.json).  In this
+// Why: on gfx950 every carry costs an issue slot as expensive as the multiply (profiles/r01_e_microbench.json).  In this
 // representation a Montgomery product is 2*NL^2 v_mad_u64_u32 + one shift/mask per column -- no operand unpacking, no
 // repacking, no final conditional subtraction -- and additions/subtractions are limb-wise with one carry sweep and NO
 // modular correction: values are only kept below 2^(NL*L - 2), far above p (7 spare bits for BN254, 11 for BLS12-381),
