@@ -29,7 +29,11 @@ struct PlonkConsts {
     uint32_t lone[8];      // (coset^n - 1) / n
     uint32_t omega[8];     // generator of the small domain
     uint32_t zh_inv[8];    // 1 / (coset^n - 1): divideByZH's factor for this coset (prove.go:1327-1350)
+    // 32 * c mod r of the constants that the lazy constraint kernel multiplies by (plonk_constraints29_kernel): a product of limb
+    // vectors divides by 2^261 where the memory format wants 2^256, so one factor carries the 2^5
+    uint32_t sh[11][8];
 };
+enum { PSH_OMEGA = 0, PSH_BL1, PSH_BR1, PSH_BO1, PSH_BZ2, PSH_BETA, PSH_CS, PSH_CSS, PSH_LONE, PSH_ALPHA, PSH_ZHINV };
 
 template <class FrP>
 __device__ __forceinline__ Fe<FrP> plonk_c(const uint32_t* w) {
@@ -127,6 +131,73 @@ plonk_constraints_kernel(PlonkPtrs P, PlonkConsts K, const uint32_t* __restrict_
     F res = add(mul(add(mul(loc, alpha), ord), alpha), gate);
     res = mul(res, plonk_c<FrP>(K.zh_inv));
     store_fe(out_block + bitrev64(j, logn) * 8, res);
+}
+
+// The same expression in the lazy representation (field29.hip.h) for scalar fields with >= 7 spare bits in nine 29-bit limbs
+// (BN254's Fr; BASELINE config 5): values are memory images x * 2^256 held as unreduced limbs -- additions are limb-wise with one carry
+// sweep and no modular correction, a product is f29_mul (162 multiply-adds + a shift / mask per column, ~250 instructions inline
+// against ~360 + a call for the packed product).  f29_mul divides by 2^261, the memory format by 2^256: a product takes one factor
+// times 32 -- a constant as its precomputed image 32 c mod r (PlonkConsts::sh: canonical, so the other factor may be anything below
+// 2^261), a variable by a 5-bit limb shift (it must then be below 2^256 = 5.29 r).  Every intermediate's bound: tools/lazy_bounds.py
+// check_plonk_constraints (largest value 27 r of the 169 r that fit); one exact reduction at the store.
+template <class FrP>
+__device__ __forceinline__ F29<FrP> plonk_shl5(const F29<FrP>& a) {   // 32 a for a normalized a < 2^256
+    constexpr int L = Radix<FrP>::L, NL = Radix<FrP>::NL;
+    constexpr uint32_t MASK = (1u << L) - 1;
+    F29<FrP> r;
+    r.l[0] = (a.l[0] << 5) & MASK;
+#pragma unroll
+    for (int i = 1; i < NL - 1; i++) r.l[i] = ((a.l[i] << 5) & MASK) | (a.l[i - 1] >> (L - 5));
+    r.l[NL - 1] = (a.l[NL - 1] << 5) | (a.l[NL - 2] >> (L - 5));
+    return r;
+}
+template <class FrP>
+__global__ void __launch_bounds__(128)
+plonk_constraints29_kernel(PlonkPtrs P, PlonkConsts K, const uint32_t* __restrict__ x_lo, const uint32_t* __restrict__ x_hi, int lo_bits,
+                           const uint32_t* __restrict__ inv_xm1, uint32_t* __restrict__ out_block, uint64_t n, int logn) {
+    static_assert(Radix<FrP>::NL * Radix<FrP>::L - 32 * FrP::N == 5 && Radix<FrP>::NL * Radix<FrP>::L - FrP::BITS >= 7,
+                  "the shift-by-5 products and the bounds of tools/lazy_bounds.py need nine 29-bit limbs over a <= 254-bit modulus");
+    typedef F29<FrP> E;
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    auto at = [&](int id, uint64_t idx) { return f29_unpack(load_fe<FrP>(P.p[id] + idx * 8)); };   // canonical
+    auto cst = [&](const uint32_t* w) { return f29_unpack(plonk_c<FrP>(w)); };                       // canonical
+    auto mulc = [&](int sh_id, const E& v) { return f29_mul(cst(K.sh[sh_id]), v); };                 // constant x anything below 2^261
+    auto mulv = [&](const E& small, const E& v) { return f29_mul(plonk_shl5<FrP>(small), v); };      // `small` below 2^256
+    E x = f29_unpack(load_fe<FrP>(x_lo + (j & ((1ull << lo_bits) - 1)) * 8));
+    if (const uint64_t h = j >> lo_bits) x = mulv(x, f29_unpack(load_fe<FrP>(x_hi + h * 8)));
+    const E xw = mulc(PSH_OMEGA, x);   // next point of the coset: ZS is Z shifted by one (prove.go:602,972)
+    const E gamma = cst(K.gamma);
+    // blinded wires (prove.go:957-973)
+    const E l = f29_add(at(PX_L, j), f29_add(cst(K.bl[0]), mulc(PSH_BL1, x)));
+    const E r = f29_add(at(PX_R, j), f29_add(cst(K.br[0]), mulc(PSH_BR1, x)));
+    const E o = f29_add(at(PX_O, j), f29_add(cst(K.bo[0]), mulc(PSH_BO1, x)));
+    auto bz = [&](const E& pt) { return f29_add(cst(K.bz[0]), mulv(pt, f29_add(cst(K.bz[1]), mulc(PSH_BZ2, pt)))); };
+    const E z = f29_add(at(PX_Z, j), bz(x));
+    const E zs = f29_add(at(PX_Z, j + 1 == n ? 0 : j + 1), bz(xw));
+    // gate (prove.go:868-885): the circuit-constant factor is canonical, so it is the one that takes the shift
+    E gate = f29_add(mulv(at(PX_QL, j), l), mulv(at(PX_QR, j), r));
+    gate = f29_add(gate, mulv(mulv(at(PX_QM, j), l), r));
+    gate = f29_add(gate, mulv(at(PX_QO, j), o));
+    gate = f29_add(gate, at(PX_QK, j));
+    for (int t = 0; t < P.nb_bsb; t++) gate = f29_add(gate, mulv(at(PLONK_NB_FIXED + 2 * t, j), at(PLONK_NB_FIXED + 2 * t + 1, j)));
+    // ordering (prove.go:898-923): each three-term factor stays below 2^256, the running product is always the un-shifted operand
+    const E id = mulc(PSH_BETA, x);
+    E a = f29_add(f29_add(gamma, l), id);
+    E b = f29_add(f29_add(mulc(PSH_CS, id), r), gamma);
+    E c = f29_add(f29_add(mulc(PSH_CSS, id), o), gamma);
+    const E rr = mulv(z, mulv(c, mulv(a, b)));
+    a = f29_add(f29_add(mulc(PSH_BETA, at(PX_S1, j)), l), gamma);
+    b = f29_add(f29_add(mulc(PSH_BETA, at(PX_S2, j)), r), gamma);
+    c = f29_add(f29_add(mulc(PSH_BETA, at(PX_S3, j)), o), gamma);
+    const E ll = mulv(zs, mulv(c, mulv(a, b)));
+    const E ord = f29_sub<8>(ll, rr);
+    // local (prove.go:926-934, 380-385)
+    const E lone = mulc(PSH_LONE, f29_unpack(load_fe<FrP>(inv_xm1 + j * 8)));
+    const E loc = mulv(lone, f29_sub<2>(z, f29_unpack(fe_one<FrP>())));
+    E res = f29_add(mulc(PSH_ALPHA, f29_add(mulc(PSH_ALPHA, loc), ord)), gate);
+    res = mulc(PSH_ZHINV, res);
+    store_fe(out_block + bitrev64(j, logn) * 8, f29_pack_canonical(f29_reduce_3p(res)));
 }
 
 // out[bitrev(i)] = in[i]
@@ -379,6 +450,15 @@ int plonk_quotient(Domain* d0, Domain* d1, const PlonkQuotientArgs& A, void* h_o
             for (int k = 0; k < 3; k++) put(K.bz[k], mul(ld(A.bz, k), cexp));
         put(K.lone, mul(cexp, ninv));
         put(K.zh_inv, inv(cexp));
+        {   // 32 c mod r of the constants the lazy constraint kernel multiplies by (five modular doublings each, host)
+            auto sh5 = [&](const uint32_t* c) {
+                F v = ld(c);
+                for (int k = 0; k < 5; k++) v = add(v, v);
+                return v;
+            };
+            const uint32_t* src[11] = {K.omega, K.bl[1], K.br[1], K.bo[1], K.bz[2], K.beta, K.cs, K.css, K.lone, K.alpha, K.zh_inv};
+            for (int q = 0; q < 11; q++) put(K.sh[q], sh5(src[q]));   // (index = PSH_*)
+        }
         // evaluations on coset*H: forward DIT with the coset powers fused into the first pass (prove.go:1033-1058)
         // (round 3: the coset lives in the twiddle table -- ntt_coset_table, built once per domain and coset and kept -- instead of
         // a scaling of the input by coset^i: two products per element and transform less)
@@ -407,8 +487,12 @@ int plonk_quotient(Domain* d0, Domain* d1, const PlonkQuotientArgs& A, void* h_o
             StageTimer tm(ctx, "plonk_constraints");
             uint64_t block = 0;   // bitrev_N(rho*j + i) = bitrev_rho(i)*n + bitrev_n(j)
             for (int b = 0; b < logrho; b++) block |= ((i >> b) & 1) << (logrho - 1 - b);
-            hipLaunchKernelGGL((plonk_constraints_kernel<FrP>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, P, K, x_lo, x_hi,
-                               NTT_POW_LO_BITS, inv_i, cres + block * n * 8, n, logn);
+            if constexpr (Radix<FrP>::NL * Radix<FrP>::L - FrP::BITS >= 7)   // (BN254: lazy representation; BLS12-381's 255-bit Fr leaves 6 spare bits: packed)
+                hipLaunchKernelGGL((plonk_constraints29_kernel<FrP>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, P, K, x_lo, x_hi,
+                                   NTT_POW_LO_BITS, inv_i, cres + block * n * 8, n, logn);
+            else
+                hipLaunchKernelGGL((plonk_constraints_kernel<FrP>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, P, K, x_lo, x_hi,
+                                   NTT_POW_LO_BITS, inv_i, cres + block * n * 8, n, logn);
             GA_KERNEL_CHECK();
         }
     }

@@ -82,3 +82,17 @@ def test_doubling_constants_match_the_kernel():
     src = open(os.path.join(ROOT, "gnark_amd", "csrc", "msm.hip.h")).read()
     d = src[src.index("__device__ __forceinline__ void dbl29("):src.index("// A lane carries TableBatch<F>::K points")]
     assert [int(x) for x in re.findall(r"f29_sub<(\d+)>", d)] == [4, 8] and "KMS = Lazy<F>::FP2 ? P::FP2Z_K : 8" in d
+
+
+def test_plonk_constraint_kernel_bounds():
+    """plonk.hip.h::plonk_constraints29_kernel: every intermediate of the PLONK constraint expression on unreduced limbs stays below
+    2^261 and every shifted factor below 2^256 for BN254's Fr with the maximum of 16 BSB22 gates; the subtraction constants are the
+    kernel's; the 255-bit Fr of BLS12-381 does NOT satisfy the bounds (which is why that curve keeps the packed kernel)"""
+    out = lazy_bounds.check_plonk_constraints()
+    assert out["res"] < 40 and out["limit"] > 160                       # 27 r of the 169 r that fit
+    with pytest.raises(AssertionError):
+        lazy_bounds.check_plonk_constraints(r=lazy_bounds.BLS12_381_R)
+    src = open(os.path.join(ROOT, "gnark_amd", "csrc", "plonk.hip.h")).read()
+    body = src[src.index("plonk_constraints29_kernel(PlonkPtrs P"):src.index("// out[bitrev(i)] = in[i]")]
+    assert [int(x) for x in re.findall(r"f29_sub<(\d+)>", body)] == [lazy_bounds.PLONK_SUB["ord"], lazy_bounds.PLONK_SUB["zm1"]]
+    assert "Radix<FrP>::NL * Radix<FrP>::L - FrP::BITS >= 7" in src       # the dispatch that keeps the 255-bit field on the packed kernel

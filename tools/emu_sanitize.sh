@@ -30,4 +30,8 @@ if [ "$KIND" = "asan" ]; then
 fi
 export UBSAN_OPTIONS=print_stacktrace=1
 cd $ROOT
-python -m pytest tests/test_emu_kernels.py -q -n 8 -p no:cacheprovider ${2:+-k "$2"}
+# (asan: the exception-barrier tests throw C++ exceptions inside a library that a Python process loaded next to an LD_PRELOADed
+# libasan -- its __cxa_throw interceptor has no real function to forward to there and aborts; they run under ubsan and in the plain build)
+SEL="$2"
+if [ "$KIND" = "asan" ]; then SEL="${SEL:+($SEL) and }not exception_barrier"; fi
+python -m pytest tests/test_emu_kernels.py -q -n 8 -p no:cacheprovider ${SEL:+-k "$SEL"}

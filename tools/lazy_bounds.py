@@ -368,3 +368,56 @@ if __name__ == "__main__":
     for c in CURVES:
         for fp2 in (False, True):
             check(c, fp2, verbose=True)
+
+
+# ---- plonk.hip.h::plonk_constraints29_kernel (round 5): the PLONK constraint expression on unreduced limbs, BN254's Fr -------------
+BN254_R = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+BLS12_381_R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+PLONK_SUB = dict(ord=8, zm1=2)   # f29_sub<8>(ll, rr), f29_sub<2>(z, 1)
+
+
+def check_plonk_constraints(r=BN254_R, nb_bsb=16, L=29, NL=9):
+    """Upper bound of every value of plonk_constraints29_kernel, statement by statement.  mulc(c, v) = f29_mul(32c mod r, v): the
+    constant factor is canonical, v only has to be a normalized limb vector (< 2^261).  mulv(s, v) = f29_mul(32 s, v): s < 2^256.
+    Either way the result is < factor * v / 2^261 + r.  Returns the bounds in units of r."""
+    R = 1 << (L * NL)
+    unit = 1 << (L * (NL - 1))
+
+    def lim(v):
+        assert v < R, ("value exceeds 2^261", v / r)
+        return v
+
+    def mulc(v):
+        return (r * lim(v)) // R + r
+
+    def mulv(s, v):
+        assert s < (1 << 256), ("shifted factor reaches 2^256", s / r)
+        return (32 * s * lim(v)) // R + r
+
+    def sub(K, a, b, what):
+        assert K * r - b > unit, (what, K, b / r)
+        return lim(a + K * r)
+    x = mulv(r, r)                     # lo * hi of the point tables
+    xw = mulc(x)
+    lro = r + r + mulc(x)              # L + bl0 + bl1 * x
+    bz = lambda pt: r + mulv(pt, r + mulc(pt))
+    z, zs = r + bz(x), r + bz(xw)
+    gate = 3 * mulv(r, lro) + mulv(mulv(r, lro), lro) + r + nb_bsb * mulv(r, r)
+    idv = mulc(x)
+    a = r + lro + idv
+    b = mulc(idv) + lro + r
+    rr = mulv(z, mulv(b, mulv(a, b)))
+    a2 = mulc(r) + lro + r
+    ll = mulv(zs, mulv(a2, mulv(a2, a2)))
+    ordv = sub(PLONK_SUB["ord"], ll, rr, "ord")
+    lone = mulc(r)
+    loc = mulv(lone, sub(PLONK_SUB["zm1"], z, r, "z - 1"))
+    res = mulc(mulc(loc) + ordv) + gate
+    lim(res)
+    out = mulc(res)
+    assert out < R                      # f29_reduce_3p takes any normalized value below 2^261
+    return {k: v / r for k, v in dict(x=x, l=lro, z=z, gate=gate, a=a, rr=rr, ll=ll, ord=ordv, loc=loc, res=res, out=out, limit=R).items()}
+
+
+if __name__ == "__main__" and False:
+    print(check_plonk_constraints())
