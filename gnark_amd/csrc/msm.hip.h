@@ -304,10 +304,17 @@ msm_digits_pass1_kernel(const uint32_t* __restrict__ scalars, uint64_t n, int mo
     // a bin's slice of the output is reserved with one global atomic per (tile, bin) -- with per-XCD slices (ncls = 8) inside the
     // sub-slice of this block's class, so that the runs one XCD's L2 collects are neighbours; delta = where the run goes - where it
     // is staged
+    // (the reservations are issued here and their results used only after the staging below, so that the atomics' round trips run
+    // under the LDS writes; measured: first level 1.26 -> 1.23 ms at 12 x 2^24 pairs, profiles/r05_n_sort_atomics_ab.txt -- the 52 %
+    // of wave cycles this kernel spends parked, r05_z_sq_bn_summary.txt, are the tile's loads and stores themselves)
     const uint32_t cls = ncls > 1 ? (blockIdx.x % ncls) : 0;
-    for (uint32_t b = t; b < BINS; b += blockDim.x) {
+    constexpr int PER_T = (int)(BINS / MSM_P1_THREADS);
+    uint32_t got[PER_T];
+#pragma unroll
+    for (int u = 0; u < PER_T; u++) {
+        const uint32_t b = t + (uint32_t)u * MSM_P1_THREADS;
         const uint32_t cnt = start[b + 1] - start[b];
-        delta[b] = cnt ? atomicAdd(&cursor[b * ncls + cls], cnt) - start[b] : 0;
+        got[u] = cnt ? atomicAdd(&cursor[b * ncls + cls], cnt) : 0u;
     }
     if (live) {
 #pragma unroll
@@ -317,6 +324,11 @@ msm_digits_pass1_kernel(const uint32_t* __restrict__ scalars, uint64_t n, int mo
                 stage_k[at] = key[q];
                 stage_v[at] = val[q];
             }
+    }
+#pragma unroll
+    for (int u = 0; u < PER_T; u++) {
+        const uint32_t b = t + (uint32_t)u * MSM_P1_THREADS;
+        delta[b] = got[u] - start[b];   // (bins without pairs: never looked up)
     }
     __syncthreads();
     for (uint32_t p = t; p < total; p += blockDim.x) {   // consecutive lanes write consecutive addresses inside a run
@@ -411,9 +423,18 @@ msm_p2_scatter_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restr
         if (kk[u] != 0xFFFFFFFFu) rk[u] = atomicAdd(&start[(kk[u] & ((1u << low) - 1))], 1u);
     __syncthreads();
     msm_block_excl_scan_1024(start, hb, wtot);
-    for (uint32_t h = t; h < hb; h += blockDim.x) {
-        const uint32_t cnt = start[h + 1] - start[h];
-        delta[h] = cnt ? atomicAdd(&cursor[(bin << low) | h], cnt) - start[h] : 0;
+    // (as in the first level: all of a thread's run reservations are issued before any result is used; no measurable change here,
+    // 0.94-0.97 -> 0.94-0.95 ms)
+    constexpr int PER_T = 4;   // hb <= 4096 key parts, 1024 threads
+    uint32_t got[PER_T];
+#pragma unroll
+    for (int u = 0; u < PER_T; u++) {
+        const uint32_t h = t + (uint32_t)u * 1024u;
+        got[u] = 0;
+        if (h < hb) {
+            const uint32_t cnt = start[h + 1] - start[h];
+            if (cnt) got[u] = atomicAdd(&cursor[(bin << low) | h], cnt);
+        }
     }
 #pragma unroll
     for (int u = 0; u < U; u++)
@@ -422,6 +443,11 @@ msm_p2_scatter_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restr
             stage_v[at] = vv[u];
             stage_h[at] = (uint16_t)h;
         }
+#pragma unroll
+    for (int u = 0; u < PER_T; u++) {
+        const uint32_t h = t + (uint32_t)u * 1024u;
+        if (h < hb) delta[h] = got[u] - start[h];
+    }
     __syncthreads();
     const uint32_t total = hi - lo;
     for (uint32_t p = t; p < total; p += blockDim.x) out_vals[p + delta[stage_h[p]]] = stage_v[p];
@@ -449,7 +475,7 @@ int msm_fused_sort(Ctx* ctx, const std::string& sfx, hipStream_t st, const void*
     GA_CHECK(ctx->scratch_get(key("msm_p1_bin_off").c_str(), (BINS + 1) * 4, (void**)&bin_off));
     GA_CHECK(ctx->scratch_get(key("msm_p2_seg_off").c_str(), (BINS + 1) * 4, (void**)&seg_off));
     // the key parts the second level counts, and every key a (group, part) pair can form (>= nb + 1)
-    const uint32_t hb = 1u << low;
+    const uint32_t hb = 1u << low;   // <= 4096 (msm_fused_fits): msm_p2_scatter_kernel reserves four runs per thread
     const uint64_t nkeys = (((uint64_t)nb >> low) + 1) << low;
     GA_CHECK(ctx->scratch_get(key("msm_p2_count").c_str(), nkeys * 4, (void**)&gcount));
     GA_CHECK(ctx->scratch_get(key("msm_p2_cursor").c_str(), nkeys * 4, (void**)&kcursor));

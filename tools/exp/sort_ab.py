@@ -5,7 +5,8 @@
   batch  ga_msm_table_run_batch, 3 vectors of 2^(log_n - 2) over a GA_TABLE_BATCHED table  (PLONK's grouped commitments)
 One JSON line per (shape, setting): wall ms per MSM and the library's stage profile; results are compared as affine points.
 
-  python tools/exp/sort_ab.py [--log-n 24] [--modes 0,1,2,3,4,5,6,7] [--shapes raw,table,batch]
+  python tools/exp/sort_ab.py [--log-n 24] [--modes 0,3] [--shapes raw,table,batch]        (GA_LIB_PATH selects another build)
+(profiles/r05_a_sort_ab_2p24.txt was made with the one-batch run-time modes of `GA_MSM_SORT_MODE`, which no longer exist.)
 """
 import argparse
 import hashlib
@@ -23,7 +24,7 @@ import numpy as np  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--log-n", type=int, default=24)
-    ap.add_argument("--modes", default="0,1,2,3,4,5,6,7")
+    ap.add_argument("--modes", default="3", help="values of GA_MSM_XCD to time (bit 0 per-XCD slices in the first level, bit 1 XCD swizzle in the second)")
     ap.add_argument("--shapes", default="raw,table,batch")
     ap.add_argument("--reps", type=int, default=4)
     ap.add_argument("--library", type=int, default=1, help="also time the library sort (GA_MSM_FUSE_MIN above every size)")
@@ -68,7 +69,7 @@ def main():
         ctx.profile(False)
         return wall, {k: round(v, 3) for k, v in agg.items()}, r
 
-    settings = [("mode%d" % int(m), {"GA_MSM_SORT_MODE": m, "GA_MSM_FUSE_MIN": "0"}) for m in args.modes.split(",")]
+    settings = [("xcd%d" % int(m), {"GA_MSM_XCD": m, "GA_MSM_FUSE_MIN": "0"}) for m in args.modes.split(",")]
     if args.library:
         settings.append(("library", {"GA_MSM_FUSE_MIN": str(1 << 40)}))
     shapes = args.shapes.split(",")
@@ -94,7 +95,7 @@ def main():
             h = sha(np.concatenate(pts))
             ref = ref or h
             front = sum(v for k, v in st.items() if k in ("msm_digits", "msm_digits_pass1", "msm_sort", "msm_tasks"))
-            print(json.dumps({"shape": shape, "log_n": args.log_n, "setting": tag, "ms_per_call": round(wall, 3), "front_end_ms": round(front, 3),
+            print(json.dumps({"lib": os.path.basename(lib.path), "shape": shape, "log_n": args.log_n, "setting": tag, "ms_per_call": round(wall, 3), "front_end_ms": round(front, 3),
                               "stages_ms": st, "same_points": h == ref}), flush=True)
             for k in env:
                 os.environ.pop(k, None)
