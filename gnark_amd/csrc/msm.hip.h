@@ -1130,6 +1130,27 @@ msm_table29_kernel(const Affine<F>* __restrict__ bases, uint64_t n, int c, int n
     }
 }
 
+// Un-pinned bases -> the packed hat format the bucket kernel gathers (a one-window "table"): S modular doublings per coordinate,
+// one point per lane.  (Round 1-4 ran msm_table29_kernel with a single window for this -- a kernel shaped for chains of doublings,
+// one wave per block: 83 us for 2^20 points, 1.3 ms for 2^24, of an HBM-bound conversion.)
+template <class F>
+__global__ void __launch_bounds__(256)
+msm_hat_bases_kernel(const Affine<F>* __restrict__ bases, uint64_t n, uint32_t* __restrict__ hat) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine<F> a = load_pod<Affine<F>>(&bases[i]);
+    if (!is_inf(a)) {   // (0,0) = infinity stays (0,0): the bucket kernel skips it
+        if constexpr (BaseFieldOf<F>::IS_FP) {
+            a.x = f29_hat_packed(a.x);
+            a.y = f29_hat_packed(a.y);
+        } else {
+            a.x = {f29_hat_packed(a.x.c0), f29_hat_packed(a.x.c1)};
+            a.y = {f29_hat_packed(a.y.c0), f29_hat_packed(a.y.c1)};
+        }
+    }
+    store_pod(hat + i * Table29<F>::WORDS, a);
+}
+
 // ---- block-wide sums of XYZZ points in the lazy representation ---------------------------------------------------------------
 // The tree sums after the group pass (per-bit sums, segment sums) are LATENCY-bound: one wave per block adds a handful of points
 // serially and then walks a 6-level tree, every step an addition in the exact packed arithmetic (~20 us G1, ~60 us G2 per dependent
@@ -1566,8 +1587,8 @@ int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, X
             // same lazy bucket kernel as the table path (an exact packed-arithmetic kernel cost ~1.5x more per addition: dropped)
             uint32_t* hat;
             GA_CHECK(ctx->scratch_get("msm_hat_bases", (uint64_t)P.n * sizeof(Affine<F>) + 256, (void**)&hat));
-            hipLaunchKernelGGL((msm_table29_kernel<F>), dim3((unsigned)(((P.n + TableBatch<F>::K - 1) / TableBatch<F>::K + 63) / 64)), dim3(64), 0,
-                               st, (const Affine<F>*)d_bases, (uint64_t)P.n, P.c, 1, hat);
+            hipLaunchKernelGGL((msm_hat_bases_kernel<F>), dim3((unsigned)((P.n + 255) / 256)), dim3(256), 0, st, (const Affine<F>*)d_bases,
+                               (uint64_t)P.n, hat);
             acc_table = hat;
         }
         constexpr unsigned AT = Table29<F>::THREADS;
