@@ -275,7 +275,7 @@ template <class FrP, int BITS>
 __global__ void __launch_bounds__(MSM_P1_THREADS)
 msm_digits_pass1_kernel(const uint32_t* __restrict__ scalars, uint64_t n, int mont, int c, int nwin, int win_lo, int win_hi, int table,
                         uint32_t key_base, uint32_t skip, uint32_t tile_scalars, int low, uint32_t ncls, uint32_t* __restrict__ cursor,
-                        uint32_t* __restrict__ out_keys, uint32_t* __restrict__ out_vals) {
+                        uint16_t* __restrict__ out_keys, uint32_t* __restrict__ out_vals) {
     constexpr uint32_t BINS = 1u << BITS;
     __shared__ uint32_t stage_k[MSM_P1_ENTRIES], stage_v[MSM_P1_ENTRIES];
     __shared__ uint32_t start[BINS + 1], delta[BINS], wtot[16];   // start: counts, then (scanned in place) where a bin's run starts in the staging arrays
@@ -334,7 +334,7 @@ msm_digits_pass1_kernel(const uint32_t* __restrict__ scalars, uint64_t n, int mo
     for (uint32_t p = t; p < total; p += blockDim.x) {   // consecutive lanes write consecutive addresses inside a run
         const uint32_t k = stage_k[p];
         const uint32_t dst = p + delta[(k >> low)];
-        out_keys[dst] = k;
+        out_keys[dst] = (uint16_t)(k & ((1u << low) - 1));   // the second level knows the group from its segment: only the part it counts travels
         out_vals[dst] = stage_v[p];
     }
 }
@@ -376,7 +376,7 @@ __device__ __forceinline__ bool msm_p2_segment(const uint32_t* __restrict__ seg_
 }
 template <int BITS>
 static __global__ void __launch_bounds__(1024)
-msm_p2_count_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ bin_off,
+msm_p2_count_kernel(const uint16_t* __restrict__ keys, const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ bin_off,
                     uint32_t hb, int low, int swz, uint32_t* __restrict__ gcount) {
     __shared__ uint32_t cnt[MSM_P2_HB];
     uint32_t bin, lo, hi;
@@ -388,18 +388,18 @@ msm_p2_count_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restric
 #pragma unroll
     for (int u = 0; u < U; u++) {
         const uint32_t p = lo + u * 1024 + threadIdx.x;
-        kk[u] = p < hi ? keys[p] : 0xFFFFFFFFu;
+        kk[u] = p < hi ? (uint32_t)keys[p] : 0xFFFFFFFFu;
     }
 #pragma unroll
     for (int u = 0; u < U; u++)
-        if (kk[u] != 0xFFFFFFFFu) atomicAdd(&cnt[(kk[u] & ((1u << low) - 1))], 1u);
+        if (kk[u] != 0xFFFFFFFFu) atomicAdd(&cnt[kk[u]], 1u);
     __syncthreads();
     for (uint32_t h = threadIdx.x; h < hb; h += blockDim.x)
         if (cnt[h]) atomicAdd(&gcount[(bin << low) | h], cnt[h]);
 }
 template <int BITS>
 static __global__ void __launch_bounds__(1024)
-msm_p2_scatter_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ seg_off,
+msm_p2_scatter_kernel(const uint16_t* __restrict__ keys, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ seg_off,
                       const uint32_t* __restrict__ bin_off, uint32_t hb, int low, int swz, uint32_t* __restrict__ cursor,
                       uint32_t* __restrict__ out_vals) {
     __shared__ uint32_t stage_v[MSM_P2_SEG];
@@ -415,12 +415,12 @@ msm_p2_scatter_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restr
 #pragma unroll
     for (int u = 0; u < U; u++) {
         const uint32_t p = lo + u * 1024 + t;
-        kk[u] = p < hi ? keys[p] : 0xFFFFFFFFu;
+        kk[u] = p < hi ? (uint32_t)keys[p] : 0xFFFFFFFFu;
         vv[u] = p < hi ? vals[p] : 0;
     }
 #pragma unroll
     for (int u = 0; u < U; u++)
-        if (kk[u] != 0xFFFFFFFFu) rk[u] = atomicAdd(&start[(kk[u] & ((1u << low) - 1))], 1u);
+        if (kk[u] != 0xFFFFFFFFu) rk[u] = atomicAdd(&start[kk[u]], 1u);
     __syncthreads();
     msm_block_excl_scan_1024(start, hb, wtot);
     // (as in the first level: all of a thread's run reservations are issued before any result is used; no measurable change here,
@@ -439,7 +439,7 @@ msm_p2_scatter_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restr
 #pragma unroll
     for (int u = 0; u < U; u++)
         if (kk[u] != 0xFFFFFFFFu) {
-            const uint32_t h = (kk[u] & ((1u << low) - 1)), at = start[h] + rk[u];
+            const uint32_t h = kk[u], at = start[h] + rk[u];
             stage_v[at] = vv[u];
             stage_h[at] = (uint16_t)h;
         }
@@ -457,7 +457,7 @@ msm_p2_scatter_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restr
 // the values grouped by key.  keys / vals: the first level's output (scratch).
 template <class FrP, int BITS>
 int msm_fused_sort(Ctx* ctx, const std::string& sfx, hipStream_t st, const void* d_scalars, size_t n, bool scalars_mont, int c, int nwin,
-                   int win_lo, int win_hi, bool table, int batch, uint32_t half, uint32_t nb, uint64_t m, uint32_t* keys, uint32_t* vals,
+                   int win_lo, int win_hi, bool table, int batch, uint32_t half, uint32_t nb, uint64_t m, uint16_t* keys, uint32_t* vals,
                    uint32_t* vals2, uint32_t* off, int xcd) {
     // xcd (GA_MSM_XCD, A/B knob): bit 0 per-XCD slices in the first level, bit 1 XCD swizzle of the second level's segments, bit 2
     // the slices at any size (tests)
@@ -502,7 +502,7 @@ int msm_fused_sort(Ctx* ctx, const std::string& sfx, hipStream_t st, const void*
         unsigned max_seg = (unsigned)(m / MSM_P2_SEG + BINS);
         if (swz) max_seg = (max_seg + MSM_XCDS - 1) / MSM_XCDS * MSM_XCDS + MSM_XCDS;   // ceil(S / 8) blocks per XCD for any S <= max_seg
         GA_HIP_CHECK(hipMemsetAsync(gcount, 0, nkeys * 4, st));
-        hipLaunchKernelGGL(msm_p2_count_kernel<BITS>, dim3(max_seg), dim3(1024), 0, st, (const uint32_t*)keys, (const uint32_t*)seg_off,
+        hipLaunchKernelGGL(msm_p2_count_kernel<BITS>, dim3(max_seg), dim3(1024), 0, st, (const uint16_t*)keys, (const uint32_t*)seg_off,
                            (const uint32_t*)bin_off, hb, low, swz, gcount);
         GA_KERNEL_CHECK();
         size_t sb = 0;
@@ -511,7 +511,7 @@ int msm_fused_sort(Ctx* ctx, const std::string& sfx, hipStream_t st, const void*
         GA_CHECK(ctx->scratch_get(key("msm_p2_scan_tmp").c_str(), sb + 256, &stmp));
         GA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(stmp, sb, gcount, off, (int)(nb + 1), st));   // off[b], b = 0..nb (nb = SKIP)
         GA_HIP_CHECK(hipMemcpyAsync(kcursor, off, ((uint64_t)nb + 1) * 4, hipMemcpyDeviceToDevice, st));
-        hipLaunchKernelGGL(msm_p2_scatter_kernel<BITS>, dim3(max_seg), dim3(1024), 0, st, (const uint32_t*)keys, (const uint32_t*)vals,
+        hipLaunchKernelGGL(msm_p2_scatter_kernel<BITS>, dim3(max_seg), dim3(1024), 0, st, (const uint16_t*)keys, (const uint32_t*)vals,
                            (const uint32_t*)seg_off, (const uint32_t*)bin_off, hb, low, swz, kcursor, vals2);
         GA_KERNEL_CHECK();
     }
@@ -1437,12 +1437,13 @@ int msm_prepare(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, in
     // number of scalar vectors over one table, enough pairs for the saved traffic to matter (GA_MSM_FUSE_MIN)
     const int xcd = ctx->tun.msm_xcd.load(std::memory_order_relaxed);
     const bool fused = msm_fused_fits(nb64) && nwl <= MSM_P1_MAXW && m >= ctx->tun.msm_fuse_min.load(std::memory_order_relaxed);
-    // Scratch of the sort.  Fused: keys / vals are the first level's output, dead once the second level has run, and the sorted keys
-    // are never materialised -- so the two sort slots of a lane SHARE them (stream order separates their uses) and there is no keys2:
-    // 12 bytes per pair less per extra slot, 10 GiB of a 2^26 proof.  Library sort: ping-pong pairs, the result may live in either.
-    keys2 = nullptr;
+    // Scratch of the sort.  Fused: key parts (16 bits) / vals are the first level's output, dead once the second level has run, and
+    // the sorted keys are never materialised -- so the two sort slots of a lane SHARE them (stream order separates their uses) and
+    // there is no keys2: 14 bytes per pair less per extra slot.  Library sort: ping-pong pairs, the result may live in either.
+    keys = keys2 = nullptr;
+    uint16_t* key_parts = nullptr;   // fused: what the first level hands to the second per pair besides the value -- the <= 12 low key bits
     if (fused) {
-        GA_CHECK(ctx->scratch_get("msm_keys_level1", m * 4, (void**)&keys));
+        GA_CHECK(ctx->scratch_get("msm_keys_level1", m * 2, (void**)&key_parts));
         GA_CHECK(ctx->scratch_get("msm_vals_level1", m * 4, (void**)&vals));
     } else {
         GA_CHECK(ctx->scratch_get(key("msm_keys").c_str(), m * 4, (void**)&keys));
@@ -1451,9 +1452,9 @@ int msm_prepare(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, in
     }
     if (fused) {
         if (msm_p1_bits(nb64) == 11)
-            GA_CHECK((msm_fused_sort<FrP, 11>(ctx, sfx, st, d_scalars, n, scalars_mont, c, nwin, win_lo, win_hi, table, batch, half, nb, m, keys, vals, vals2, off, xcd)));
+            GA_CHECK((msm_fused_sort<FrP, 11>(ctx, sfx, st, d_scalars, n, scalars_mont, c, nwin, win_lo, win_hi, table, batch, half, nb, m, key_parts, vals, vals2, off, xcd)));
         else
-            GA_CHECK((msm_fused_sort<FrP, 12>(ctx, sfx, st, d_scalars, n, scalars_mont, c, nwin, win_lo, win_hi, table, batch, half, nb, m, keys, vals, vals2, off, xcd)));
+            GA_CHECK((msm_fused_sort<FrP, 12>(ctx, sfx, st, d_scalars, n, scalars_mont, c, nwin, win_lo, win_hi, table, batch, half, nb, m, key_parts, vals, vals2, off, xcd)));
     } else {
         {
             StageTimer tm(ctx, "msm_digits", st);
