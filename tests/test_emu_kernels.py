@@ -1283,7 +1283,7 @@ def test_emu_groth16_split_schedule_and_late_free(emu_ctx, c, precompute, monkey
     pk.FreeGPUResources()
     t.join()
     # either the proof was already in flight (the destroy waited and the proof is right) or it started after the key died (refused)
-    assert (out and np.array_equal(out[0], split)) or (refused and "destroyed" in refused[0]), (len(out), refused)
+    assert (out and np.array_equal(out[0], split)) or (refused and ("destroyed" in refused[0] or "freed" in refused[0])), (len(out), refused)
 
 
 # ---- one proof over several devices from one process (ga_g16_prove_multi) ------------------------------------------------------
