@@ -165,6 +165,10 @@ void Tunables::read_env() {
     put64(msm_fuse_min, num("GA_MSM_FUSE_MIN", 1ull << 21));
     put(msm_xcd, (int)num("GA_MSM_XCD", 3));
     {
+        const uint64_t g = num("GA_MSM_P1_GRID", 512);
+        put64(msm_p1_grid, g ? g : 1);
+    }
+    {
         const char* e = getenv("GA_FAULT_THROW");
         put64(fault_throw, (e && *e) ? fnv1a(e) : 0);
     }

@@ -148,6 +148,7 @@ struct StageRec {
 //   GA_MSM_FUSE_MIN       (point, window) pairs from which an MSM sorts with the fused two-level sort instead of the library's (2^21)
 //   GA_MSM_XCD            fused sort: bit 0 per-XCD slices in the first level (from 2^24 pairs; bit 2: at any size), bit 1 XCD swizzle in the second (3; A/B knob)
 //   GA_FAULT_THROW        tests: name of an entry point under which the next device-scratch request throws std::bad_alloc
+//   GA_MSM_P1_GRID        workgroups of the fused sort's first level (each walks tiles b, b + grid, ...; 512; tests: 1 .. 9)
 //   GA_MSM_EXACT_REDO     1: tasks flagged by the fast bucket loop go straight to the exact-arithmetic kernel (tests)
 //   GA_TABLE_C            force the window width of precomputed tables built from now on (experiments; 0 = planned)
 //   GA_G16_LANES          1: a second concurrent ga_g16_prove caller queues for the device instead of proving on its own lanes
@@ -173,6 +174,7 @@ struct Tunables {
     std::atomic<uint64_t> msm_fuse_min{1ull << 21};   // pairs from which the digits are fused with the first sort pass (msm.hip.h 1b)
     std::atomic<int> msm_group{0};                   // buckets per running-sum group of the window reduction (0 = MSM_GROUP)
     std::atomic<uint64_t> fault_throw{0};            // FNV-1a of GA_FAULT_THROW (0 = unset): the entry point under which scratch_get throws (tests)
+    std::atomic<uint64_t> msm_p1_grid{512};         // blocks of the first sort level (a block walks several tiles)
     std::atomic<int> msm_xcd{3};                     // fused sort placement: bit 0 per-XCD slices of the first level's groups, bit 1 XCD swizzle of the second level's segments
     void read_env();
 };

@@ -80,8 +80,9 @@ template <class FrP>
 struct DigitWalk {
     Fe<FrP> s;
     uint32_t carry = 0;
-    __device__ __forceinline__ void load(const uint32_t* __restrict__ scalars, uint64_t i, int mont) {
-        s = load_fe<FrP>(scalars + i * 8);
+    __device__ __forceinline__ void load(const uint32_t* __restrict__ scalars, uint64_t i, int mont) { set(load_fe<FrP>(scalars + i * 8), mont); }
+    __device__ __forceinline__ void set(const Fe<FrP>& raw, int mont) {   // (the words may have been loaded ahead of time)
+        s = raw;
         if (mont) s = from_mont(s);
         else {
             // canonical input may be any 256-bit integer (a caller's big.Int bytes): bring it below r, at most 2^256 / r < 6 steps,
@@ -271,71 +272,82 @@ static __global__ void __launch_bounds__(1024) msm_p1_scan_kernel(const uint32_t
     }
 }
 
+// A block walks tiles blockIdx.x, blockIdx.x + grid, ... (the grid is a multiple of 8 whenever a block gets more than one tile, so a
+// block's tiles share its XCD class) and loads the NEXT tile's scalars before it writes the current one out: the CU holds one
+// workgroup (123 KB of LDS), so nothing else could hide that load.  Same box, 12 x 2^24 pairs (profiles/r05_s_sort_pipelined_ab.txt):
+// histogram + first level 1.19 -> 1.13 ms with 256 / 512 / 1024 blocks (one tile per block in this loop form: 1.26).
 template <class FrP, int BITS>
 __global__ void __launch_bounds__(MSM_P1_THREADS)
 msm_digits_pass1_kernel(const uint32_t* __restrict__ scalars, uint64_t n, int mont, int c, int nwin, int win_lo, int win_hi, int table,
-                        uint32_t key_base, uint32_t skip, uint32_t tile_scalars, int low, uint32_t ncls, uint32_t* __restrict__ cursor,
-                        uint16_t* __restrict__ out_keys, uint32_t* __restrict__ out_vals) {
+                        uint32_t key_base, uint32_t skip, uint32_t tile_scalars, uint64_t ntiles, int low, uint32_t ncls,
+                        uint32_t* __restrict__ cursor, uint16_t* __restrict__ out_keys, uint32_t* __restrict__ out_vals) {
     constexpr uint32_t BINS = 1u << BITS;
     __shared__ uint32_t stage_k[MSM_P1_ENTRIES], stage_v[MSM_P1_ENTRIES];
     __shared__ uint32_t start[BINS + 1], delta[BINS], wtot[16];   // start: counts, then (scanned in place) where a bin's run starts in the staging arrays
     const uint32_t t = threadIdx.x;
-    for (uint32_t b = t; b < BINS; b += blockDim.x) start[b] = 0;
-    __syncthreads();
-    const uint64_t i = (uint64_t)blockIdx.x * tile_scalars + t;
-    const bool live = t < tile_scalars && i < n;
-    uint32_t key[MSM_P1_MAXW], val[MSM_P1_MAXW], rank[MSM_P1_MAXW];
-    if (live) {
-        DigitWalk<FrP> D;
-        D.load(scalars, i, mont);
-        for (int w = 0; w < win_lo; w++) {   // (windows below this device's share: only their carries matter)
-            uint32_t k, v;
-            D.next(c, w, win_lo, n, i, table, key_base, skip, k, v);
-        }
-#pragma unroll
-        for (int q = 0; q < MSM_P1_MAXW; q++)
-            if (win_lo + q < win_hi) {
-                D.next(c, win_lo + q, win_lo, n, i, table, key_base, skip, key[q], val[q]);
-                rank[q] = atomicAdd(&start[(key[q] >> low)], 1u);
-            }
-    }
-    __syncthreads();
-    const uint32_t total = msm_block_excl_scan_1024(start, BINS, wtot);
-    // a bin's slice of the output is reserved with one global atomic per (tile, bin) -- with per-XCD slices (ncls = 8) inside the
-    // sub-slice of this block's class, so that the runs one XCD's L2 collects are neighbours; delta = where the run goes - where it
-    // is staged
-    // (the reservations are issued here and their results used only after the staging below, so that the atomics' round trips run
-    // under the LDS writes; measured: first level 1.26 -> 1.23 ms at 12 x 2^24 pairs, profiles/r05_n_sort_atomics_ab.txt -- the 52 %
-    // of wave cycles this kernel spends parked, r05_z_sq_bn_summary.txt, are the tile's loads and stores themselves)
     const uint32_t cls = ncls > 1 ? (blockIdx.x % ncls) : 0;
-    constexpr int PER_T = (int)(BINS / MSM_P1_THREADS);
-    uint32_t got[PER_T];
-#pragma unroll
-    for (int u = 0; u < PER_T; u++) {
-        const uint32_t b = t + (uint32_t)u * MSM_P1_THREADS;
-        const uint32_t cnt = start[b + 1] - start[b];
-        got[u] = cnt ? atomicAdd(&cursor[b * ncls + cls], cnt) : 0u;
-    }
-    if (live) {
-#pragma unroll
-        for (int q = 0; q < MSM_P1_MAXW; q++)
-            if (win_lo + q < win_hi) {
-                const uint32_t at = start[(key[q] >> low)] + rank[q];
-                stage_k[at] = key[q];
-                stage_v[at] = val[q];
+    uint64_t i = (uint64_t)blockIdx.x * tile_scalars + t;
+    bool live = t < tile_scalars && i < n;
+    Fe<FrP> raw;
+    if (live) raw = load_fe<FrP>(scalars + i * 8);
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        for (uint32_t b = t; b < BINS; b += blockDim.x) start[b] = 0;
+        __syncthreads();
+        uint32_t key[MSM_P1_MAXW], val[MSM_P1_MAXW], rank[MSM_P1_MAXW];
+        if (live) {
+            DigitWalk<FrP> D;
+            D.set(raw, mont);
+            for (int w = 0; w < win_lo; w++) {   // (windows below this device's share: only their carries matter)
+                uint32_t k, v;
+                D.next(c, w, win_lo, n, i, table, key_base, skip, k, v);
             }
-    }
 #pragma unroll
-    for (int u = 0; u < PER_T; u++) {
-        const uint32_t b = t + (uint32_t)u * MSM_P1_THREADS;
-        delta[b] = got[u] - start[b];   // (bins without pairs: never looked up)
-    }
-    __syncthreads();
-    for (uint32_t p = t; p < total; p += blockDim.x) {   // consecutive lanes write consecutive addresses inside a run
-        const uint32_t k = stage_k[p];
-        const uint32_t dst = p + delta[(k >> low)];
-        out_keys[dst] = (uint16_t)(k & ((1u << low) - 1));   // the second level knows the group from its segment: only the part it counts travels
-        out_vals[dst] = stage_v[p];
+            for (int q = 0; q < MSM_P1_MAXW; q++)
+                if (win_lo + q < win_hi) {
+                    D.next(c, win_lo + q, win_lo, n, i, table, key_base, skip, key[q], val[q]);
+                    rank[q] = atomicAdd(&start[(key[q] >> low)], 1u);
+                }
+        }
+        __syncthreads();
+        const uint32_t total = msm_block_excl_scan_1024(start, BINS, wtot);
+        // a bin's slice of the output is reserved with one global atomic per (tile, bin) -- with per-XCD slices (ncls = 8) inside the
+        // sub-slice of this block's class, so that the runs one XCD's L2 collects are neighbours; delta = where the run goes - where
+        // it is staged.  (The reservations are issued here and their results used only after the staging below, so that the atomics'
+        // round trips run under the LDS writes: 1.26 -> 1.23 ms at 12 x 2^24 pairs, profiles/r05_n_sort_atomics_ab.txt.)
+        constexpr int PER_T = (int)(BINS / MSM_P1_THREADS);
+        uint32_t got[PER_T];
+#pragma unroll
+        for (int u = 0; u < PER_T; u++) {
+            const uint32_t b = t + (uint32_t)u * MSM_P1_THREADS;
+            const uint32_t cnt = start[b + 1] - start[b];
+            got[u] = cnt ? atomicAdd(&cursor[b * ncls + cls], cnt) : 0u;
+        }
+        if (live) {
+#pragma unroll
+            for (int q = 0; q < MSM_P1_MAXW; q++)
+                if (win_lo + q < win_hi) {
+                    const uint32_t at = start[(key[q] >> low)] + rank[q];
+                    stage_k[at] = key[q];
+                    stage_v[at] = val[q];
+                }
+        }
+        // the next tile's scalars: requested now, needed after the write phase
+        i += (uint64_t)gridDim.x * tile_scalars;
+        live = tile + gridDim.x < ntiles && t < tile_scalars && i < n;
+        if (live) raw = load_fe<FrP>(scalars + i * 8);
+#pragma unroll
+        for (int u = 0; u < PER_T; u++) {
+            const uint32_t b = t + (uint32_t)u * MSM_P1_THREADS;
+            delta[b] = got[u] - start[b];   // (bins without pairs: never looked up)
+        }
+        __syncthreads();
+        for (uint32_t p = t; p < total; p += blockDim.x) {   // consecutive lanes write consecutive addresses inside a run
+            const uint32_t k = stage_k[p];
+            const uint32_t dst = p + delta[(k >> low)];
+            out_keys[dst] = (uint16_t)(k & ((1u << low) - 1));   // the second level knows the group from its segment: only the part it counts travels
+            out_vals[dst] = stage_v[p];
+        }
+        __syncthreads();   // (the staging arrays and the bin tables are rewritten by the next tile)
     }
 }
 
@@ -486,15 +498,18 @@ int msm_fused_sort(Ctx* ctx, const std::string& sfx, hipStream_t st, const void*
         const uint64_t ntiles = (n + tile - 1) / tile;
         uint64_t hist_blocks = (ntiles + MSM_XCDS - 1) / MSM_XCDS * MSM_XCDS;   // a multiple of 8: tile t and the block that counts it agree on t % 8
         if (hist_blocks > 2048) hist_blocks = 2048;
+        const uint64_t p1_grid = ctx->tun.msm_p1_grid.load(std::memory_order_relaxed);   // GA_MSM_P1_GRID (A/B knob; tests)
+        uint64_t p1_blocks = ntiles <= p1_grid ? ntiles : p1_grid;
+        if (ncls > 1 && p1_blocks < ntiles) p1_blocks = (p1_blocks + MSM_XCDS - 1) / MSM_XCDS * MSM_XCDS;   // a block's tiles must share t % 8 (the histogram's classes)
         GA_HIP_CHECK(hipMemsetAsync(ghist, 0, BINS * ncls * 4, st));
         for (int b = 0; b < batch; b++)   // (a batch: the vectors' bucket sets are stacked in ONE key space, key_base = b * 2^(c-1))
             hipLaunchKernelGGL((msm_digit_hist_kernel<FrP, BITS>), dim3((unsigned)hist_blocks), dim3(256), 0, st, vec(b), (uint64_t)n,
                                scalars_mont ? 1 : 0, c, nwin, win_lo, win_hi, table ? 1 : 0, (uint32_t)b * half, nb, tile, low, ncls, ghist);
         hipLaunchKernelGGL(msm_p1_scan_kernel<BITS>, dim3(1), dim3(1024), 0, st, (const uint32_t*)ghist, ncls, cursor, bin_off, seg_off);
         for (int b = 0; b < batch; b++)
-            hipLaunchKernelGGL((msm_digits_pass1_kernel<FrP, BITS>), dim3((unsigned)ntiles), dim3(MSM_P1_THREADS), 0, st, vec(b),
-                               (uint64_t)n, scalars_mont ? 1 : 0, c, nwin, win_lo, win_hi, table ? 1 : 0, (uint32_t)b * half, nb, tile, low, ncls, cursor,
-                               keys, vals);
+            hipLaunchKernelGGL((msm_digits_pass1_kernel<FrP, BITS>), dim3((unsigned)p1_blocks), dim3(MSM_P1_THREADS), 0, st, vec(b),
+                               (uint64_t)n, scalars_mont ? 1 : 0, c, nwin, win_lo, win_hi, table ? 1 : 0, (uint32_t)b * half, nb, tile, (uint64_t)ntiles, low,
+                               ncls, cursor, keys, vals);
         GA_KERNEL_CHECK();
     }
     {
