@@ -26,7 +26,7 @@ Workload (BASELINE.json `metric`: "G1 MSM Mscalar-mul/s + Groth16 proofs/s, BN25
     affine base); durations come from hipEvents recorded by the library on its own stream; `bound_actual` and the `int_mad_*`
     scalars price the same launches against the measured v_mad_u64_u32 issue rate (the binding resource); `traffic` is measured IN
     THIS RUN by two child rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE; `traffic_source` says so, or names the committed fallback).
-  * "cpu_baseline" (rank 0): the C oracle's Pippenger (oracle/oracle.c -- a plain-C port, NOT gnark-crypto; one thread per window) on
+  * "cpu_baseline" (rank 0, N = 1 only): the C oracle's Pippenger (oracle/oracle.c -- a plain-C port, NOT gnark-crypto; one thread per window) on
     2^24 points and the oracle's Groth16 prover on a 2^20 sample.
   * "nccl_selftest" (N = 1): a one-rank process group over the nccl (= RCCL) backend pushes a sharded proof and an MSM through every
     collective gnark_amd/multigpu.py uses, on device tensors (a 1-GPU box cannot run N > 1, but it can run the RCCL code path).
@@ -1055,7 +1055,7 @@ def compact_line(out):
     line["roofline"] = rf
     cb = out.get("cpu_baseline")
     if isinstance(cb, dict):
-        c2 = pick(cb, "value", "unit", "cores", "kind", "effective_cores", "host_cores", "gpu_result_matches_oracle", "error")
+        c2 = pick(cb, "value", "unit", "cores", "kind", "effective_cores", "host_cores", "gpu_result_matches_oracle", "skipped", "error")
         if "sample" in cb:
             c2["sample"] = cb["sample"][:110]
         if "note" in cb:
@@ -1241,7 +1241,11 @@ def main():
             if rep is not None:
                 out["replicas"] = rep
 
-    if rank == 0 and not args.no_cpu_baseline and not args.only_headline:   # (the other ranks wait in the barrier below; a local leg, no collectives inside)
+    # the CPU port is timed at N = 1 only (rank 0 would keep N - 1 GPUs waiting in the barrier below for the same figure at every N)
+    cpu_at_any_n = os.environ.get("GA_BENCH_CPU_BASELINE_ANY_N", "0") != "0"
+    if rank == 0 and world > 1 and not cpu_at_any_n and not args.no_cpu_baseline and not args.only_headline:
+        out["cpu_baseline"] = {"value": None, "unit": "Mscalar-mul/s", "kind": "port", "skipped": "timed at N = 1 only (the --gpus 1 line of the same commit)"}
+    elif rank == 0 and not args.no_cpu_baseline and not args.only_headline:   # (a local leg, no collectives inside)
         t0 = time.perf_counter()
         try:
             cpu_baseline_leg(R, out)

@@ -76,6 +76,7 @@ for step in "$@"; do
       GA_BENCH_BACKEND=gloo timeout 1500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 \
         bench.py --gpus 2 --steps 3 --warmup 1 --detail-file $OUT/${TAG}_bench_2ranks_one_gpu_gloo_detail.json $arg > $OUT/${TAG}_bench_2ranks_one_gpu_gloo.json 2> $OUT/${TAG}_bench_2ranks.err
       tail -3 $OUT/${TAG}_bench_2ranks.err
+      sed -i '/^{/!d' $OUT/${TAG}_bench_2ranks_one_gpu_gloo.json     # (gloo prints its connection banner on stdout)
       python tools/bench_digest.py $OUT/${TAG}_bench_2ranks_one_gpu_gloo.json ;;
     stats)
       d=$OUT/stats_tmp_$$
