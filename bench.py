@@ -433,7 +433,7 @@ def headline_leg(R):
     acc = res["stages"].get("msm_accumulate")
     traffic, tsrc = (None, None)
     if R.world == 1 and not R.emu:
-        live = (None, "in-run counter passes switched off (--no-pmc)", {})
+        live = (None, "in-run counter passes switched off (%s)" % ("--only-headline" if args.only_headline else "--no-pmc"), {})
         if not args.no_pmc and not args.only_headline:
             live = pmc_traffic_live(args)
             out["pmc_passes"] = live[2]
