@@ -2,8 +2,9 @@
 //
 // Mirrors backend/groth16/bn254/prove.go:130-315 (CPU) and backend/accelerated/icicle/groth16/bn254/icicle.go:784-1360
 // (GPU):  computeH -> filter wire values -> 4 G1 MSMs + 1 G2 MSM -> host epilogue with the caller-supplied randomness
-// (r, s); BSB22 commitments are the two extra MSMs per commitment of ga_g16_commit (prove.go:84,114) plus the K filter.  The host side is C++ because the reference's host side is compiled Go and no Go
-// toolchain exists in the build image (INTEGRATION.md shows the cgo binding that calls this file's two entry points).
+// (r, s); BSB22 commitments are the two extra MSMs per commitment of ga_g16_commit (prove.go:84,114) plus the K filter.  The host
+// side is C++ because the reference's host side is compiled Go and no Go toolchain exists in the build image (INTEGRATION.md shows
+// the cgo binding that calls this file's entry points).
 #include <algorithm>
 #include <condition_variable>
 #include <memory>
@@ -359,25 +360,21 @@ static int stage_finish(G16Stage* st, int precompute, G16Pk** out) {
         bool plan_ok = msm_plan_table<C>(pk->nb_wires, &pk->c_w, &nw) == GA_OK;
         const uint64_t wide = (uint64_t)nw * pk->nb_wires;
         plan_ok = msm_plan_table<C>(pk->len_a, &pk->c_a, &nw) == GA_OK && plan_ok;
-        uint64_t need = pk->share_a ? wide * t1 : (uint64_t)nw * pk->len_a * t1;
         plan_ok = msm_plan_table<C>(pk->len_b, &pk->c_b, &nw) == GA_OK && plan_ok;
-        need += pk->share_b ? wide * (t1 + t2) : (uint64_t)nw * pk->len_b * (t1 + t2);
         plan_ok = msm_plan_table<C>(pk->len_z, &pk->c_z, &nw) == GA_OK && plan_ok;
-        need += (uint64_t)nw * pk->len_z * t1;
         plan_ok = msm_plan_table<C>(pk->len_k, &pk->c_k, &nw) == GA_OK && plan_ok;
-        need += pk->share_k ? wide * t1 : (uint64_t)nw * pk->len_k * t1;
         if (!plan_ok && precompute > 0) rc = GA_ERR_INVALID;   // vectors beyond the table index space: the caller asked for tables explicitly
         size_t free_b = 0, total_b = 0;
         hipMemGetInfo(&free_b, &total_b);
         // Which vectors get a table.  precompute > 0: all five (the caller insists; a table that does not fit fails the call).
-        // precompute == 0: as many as fit the free HBM next to the per-proof scratch, in the order of what a table buys per byte: A, B1, K (48 GiB each at 2^26 BN254; with all three the witness is
-        // sorted once instead of three times), Z, and last G2.B (twice the bytes for the smallest relative gain).
+        // precompute == 0: as many as fit the free HBM next to the per-proof scratch, in the order of what a table buys per byte:
+        // A, B1, K (48 GiB each at 2^26 BN254; with all three the witness is sorted once instead of three times), Z, and last G2.B
+        // (twice the bytes for the smallest relative gain).
         const uint64_t bytes_a = pk->share_a ? wide * t1 : (uint64_t)(C::FrP::BITS / pk->c_a + 1) * pk->len_a * t1;
         const uint64_t bytes_b = pk->share_b ? wide * t1 : (uint64_t)(C::FrP::BITS / pk->c_b + 1) * pk->len_b * t1;
         const uint64_t bytes_b2 = pk->share_b ? wide * t2 : (uint64_t)(C::FrP::BITS / pk->c_b + 1) * pk->len_b * t2;
         const uint64_t bytes_z = (uint64_t)(C::FrP::BITS / pk->c_z + 1) * pk->len_z * t1;
         const uint64_t bytes_k = pk->share_k ? wide * t1 : (uint64_t)(C::FrP::BITS / pk->c_k + 1) * pk->len_k * t1;
-        (void)need;
         if (rc == GA_OK && plan_ok) {
             if (precompute > 0) {
                 pk->tab_a = pk->tab_b = pk->tab_k = pk->tab_z = pk->tab_b2 = true;
@@ -395,7 +392,8 @@ static int stage_finish(G16Stage* st, int precompute, G16Pk** out) {
                 const double per_proof = (double)pk->n * 1280.0;
                 const double allowance = per_proof > (double)held ? per_proof - (double)held : 0.0;
                 double budget = (double)free_b - 1.1 * allowance - 4.0 * 1073741824.0;
-                if (const uint64_t mb = ctx->tun.g16_table_budget_pct) budget = (double)mb / 100.0 * (double)(bytes_a + bytes_b + bytes_k + bytes_z + bytes_b2);   // GA_G16_TABLE_BUDGET_PCT (tests: partial tables on small keys)
+                if (const uint64_t pct = ctx->tun.g16_table_budget_pct)   // GA_G16_TABLE_BUDGET_PCT (tests: partial tables on small keys)
+                    budget = (double)pct / 100.0 * (double)(bytes_a + bytes_b + bytes_k + bytes_z + bytes_b2);
                 struct Cand { bool* flag; uint64_t bytes; } order[5] = {{&pk->tab_a, bytes_a}, {&pk->tab_b, bytes_b}, {&pk->tab_k, bytes_k},
                                                                        {&pk->tab_z, bytes_z}, {&pk->tab_b2, bytes_b2}};
                 for (auto& cnd : order) {

@@ -3,22 +3,27 @@
 // Replaces G1Jac.MultiExp / G2Jac.MultiExp (backend/groth16/bn254/prove.go:194,207,227,237,283) and the ICICLE
 // msm.Msm / g2.G2Msm calls (backend/accelerated/icicle/groth16/bn254/icicle.go:362-467).
 //
-// Pipeline (all on the context's stream, no host synchronisation until the window sums are copied back):
+// Pipeline (all on the context's stream, no host synchronisation until a few hundred bytes of sums are copied back):
 //   1. msm_digits_kernel   scalar -> signed c-bit digits (Montgomery reduction fused in); one (key, value) pair per
 //                          (point, window): key = window*2^(c-1) + |digit|-1, value = point index | sign<<31.
 //                          Zero digits get key = SKIP (sorts last), so zero scalars and the constant-0 wires of a
 //                          witness cost nothing downstream.
-//   2. radix sort          of the pairs by key (rocprim onesweep on the significant bits only, msm_sort_pairs) -- the utility
-//                          step; after it every bucket is a contiguous run of point indices.
-//   3. msm_offsets_tasks_kernel  bucket boundaries by binary search; buckets are split into tasks of at most
-//                          SEG points so that a hot bucket (witness values 0/1 make bucket 1 of window 0 huge) is spread
-//                          over many lanes; exclusive scan gives the task table.
-//   4. msm_accumulate_kernel  one lane per task: gathers its affine bases (16 B/lane vector loads), XYZZ mixed adds.
+//   2. radix sort          of the pairs by key (rocprim onesweep on the significant bits only, msm_sort_pairs); after it every
+//                          bucket is a contiguous run of point indices.
+//      From GA_MSM_FUSE_MIN (2^21) pairs up, 1 and 2 are ONE two-level sort of our own, fused with the digit extraction
+//      (1b / 1c below): the pairs are written once and read once, the sorted keys are never materialised.
+//   3. msm_offsets_tasks_kernel / msm_tasks_kernel  bucket boundaries (by binary search, or the fused sort's own per-key scan);
+//                          buckets are split into tasks of at most SEG points so that a hot bucket (witness values 0/1 make
+//                          bucket 1 of window 0 huge) is spread over many lanes; the task list is ordered by decreasing length
+//                          (one 8-bit radix pass on the quantised length) so that the lanes of a wave finish together.
+//   4. msm_accumulate29_kernel  one lane per task: gathers its bases from the window table (or the hat-domain copy of un-pinned
+//                          bases), XYZZ mixed additions in the lazy 29 / 28-bit limb representation, accumulator in LDS.
 //   5. msm_merge_kernel / msm_hot_kernel  partial sums -> one XYZZ sum per bucket (wave-level LDS tree for hot buckets).
-//   6. msm_reduce_groups_kernel + msm_window_sum_kernel  sum_k k*B_k per window via per-group running sums and a
-//                          wave tree; window sums go back to the host, which does the c doublings per window (Horner)
-//                          -- ~256 sequential doublings are latency-bound on a GPU lane and free on a host core, and the
-//                          multi-GPU window-sharded mode needs the window sums on the host anyway.
+//   6. msm_reduce_groups29_kernel + per-bit / segment sums  sum_k k*B_k per bucket set via per-group running sums and a wave
+//                          tree; the last ~c doublings of that sum -- and, for un-pinned bases, the Horner step over the windows,
+//                          merged into the same chain -- run on the host: a chain of sequential doublings is latency-bound on a
+//                          GPU lane and free on a host core, and the multi-GPU window-sharded mode needs the window sums on the
+//                          host anyway.
 #pragma once
 #include <cstring>
 #include <hipcub/hipcub.hpp>
@@ -534,7 +539,8 @@ int msm_fused_sort(Ctx* ctx, const std::string& sfx, hipStream_t st, const void*
 }
 
 // ---- 3. bucket boundaries and tasks ---------------------------------------------------------------
-// bucket boundaries by binary search + the number of tasks per bucket, one launch (library-sort path: small MSMs, where every launch is ~5 us of a ~2 ms call): a block shares its boundaries in LDS
+// bucket boundaries by binary search + the number of tasks per bucket, one launch (library-sort path: small MSMs, where every launch
+// is ~5 us of a ~2 ms call): a block shares its boundaries in LDS
 static __global__ void __launch_bounds__(256) msm_offsets_tasks_kernel(const uint32_t* __restrict__ keys, uint64_t m, uint32_t nb, uint32_t seg,
                                                                        uint32_t* __restrict__ off, uint32_t* __restrict__ ntask) {
     __shared__ uint32_t sh[257];
