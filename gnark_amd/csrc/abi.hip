@@ -163,6 +163,7 @@ void Tunables::read_env() {
     put(table_c, (int)num("GA_TABLE_C", 0));
     put(msm_exact_redo, (int)num("GA_MSM_EXACT_REDO", 0));
     put64(msm_fuse_min, num("GA_MSM_FUSE_MIN", 1ull << 21));
+    put64(msm_task_exact_min, num("GA_MSM_TASK_EXACT_MIN", 1ull << 25));
     put(msm_xcd, (int)num("GA_MSM_XCD", 3));
     {
         const uint64_t g = num("GA_MSM_P1_GRID", 512);

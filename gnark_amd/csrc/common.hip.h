@@ -175,6 +175,7 @@ struct Tunables {
     std::atomic<int> msm_group{0};                   // buckets per running-sum group of the window reduction (0 = MSM_GROUP)
     std::atomic<uint64_t> fault_throw{0};            // FNV-1a of GA_FAULT_THROW (0 = unset): the entry point under which scratch_get throws (tests)
     std::atomic<uint64_t> msm_p1_grid{512};         // blocks of the first sort level (a block walks several tiles)
+    std::atomic<uint64_t> msm_task_exact_min{1ull << 25};   // pairs from which the task list is sorted on exact lengths (msm.hip.h 3)
     std::atomic<int> msm_xcd{3};                     // fused sort placement: bit 0 per-XCD slices of the first level's groups, bit 1 XCD swizzle of the second level's segments
     void read_env();
 };

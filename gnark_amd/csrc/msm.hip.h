@@ -572,9 +572,12 @@ static __global__ void msm_tasks_kernel(const uint32_t* __restrict__ off, uint32
 
 // task t of bucket b covers sorted pairs [start, start+len); key = SEG - len so that an ascending radix sort puts the
 // longest tasks first and lanes of one wave get tasks of (nearly) equal length (bucket sizes are Poisson-distributed:
-// without this a wave waits for its longest bucket, ~25 % of the lanes' time at 2^24).  The SORT key is the length quantised to
-// 7 bits (qkey = key >> qshift; lanes of a wave then differ by < 2^qshift points): with the padding bit that is ONE 8-bit radix pass
-// over the task list instead of two (2^20 raw MSM: task stage 0.18 -> 0.08 ms, profiles/r05_e); the exact key stays in task_key.
+// without this a wave waits for its longest bucket, ~25 % of the lanes' time at 2^24).  Below 2^25 pairs the SORT key is the length
+// quantised to 7 bits (qkey = key >> qshift; lanes of a wave then differ by < 2^qshift points): with the padding bit that is ONE
+// 8-bit radix pass over the task list instead of two (2^20 raw MSM: task stage 0.18 -> 0.08 ms, profiles/r05_e); the exact key
+// stays in task_key.  From 2^25 pairs up the sort key IS the exact key: the second pass costs ~0.02 ms, lanes that wait for a
+// neighbour 1-3 points longer cost the bucket kernel 1.4 % (15.40 -> 15.62 ms at 12 x 2^24 pairs, same box against round 4's
+// exact sort, profiles/r05_w_round4_vs_round5_same_box.txt).
 // (one launch for what were two memsets and an iota: padding keys, the identity permutation the task sort starts from, the counter
 // of the long-bucket queue)
 static __global__ void msm_task_init_kernel(uint32_t* __restrict__ task_qkey, uint32_t* __restrict__ task_id, uint32_t n, uint32_t* __restrict__ long_count) {
@@ -1498,7 +1501,9 @@ int msm_prepare(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, in
         // explicit task list, ordered by decreasing length (padding slots keep key = 0xFFFFFFFF >= seg)
         int kbits = 1;
         while ((1u << kbits) <= seg) kbits++;
-        const int qbits = kbits < 7 ? kbits : 7, qshift = kbits - qbits;
+        // (long lists: the exact length, two radix passes -- GA_MSM_TASK_EXACT_MIN, see msm_task_init_kernel)
+        const bool exact = m >= ctx->tun.msm_task_exact_min.load(std::memory_order_relaxed);
+        const int qbits = exact || kbits < 7 ? kbits : 7, qshift = kbits - qbits;
         hipLaunchKernelGGL(msm_task_init_kernel, dim3((unsigned)((max_tasks + 255) / 256)), dim3(256), 0, st, task_qkey, task_id, (uint32_t)max_tasks, long_count);
         if (!fused)   // (the fused sort produced `off` itself)
             hipLaunchKernelGGL(msm_offsets_tasks_kernel, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, (const uint32_t*)keys2, m, nb, seg, off, ntask);

@@ -757,6 +757,8 @@ def test_emu_msm_fused_first_sort_pass(emu_ctx, c, group, xcd, monkeypatch, n=13
     monkeypatch.setenv("GA_TABLE_C", str(table_c))
     monkeypatch.setenv("GA_MSM_XCD", str(xcd))   # per-XCD slices of the first level (bit 2: also below 2^24 pairs), XCD swizzle of the second: placement only
     monkeypatch.setenv("GA_MSM_P1_GRID", "1" if xcd == 0 else "9")   # one block walks every tile / nine (-> 16) blocks with XCD classes: the tile loop
+    if xcd == 0:
+        monkeypatch.setenv("GA_MSM_TASK_EXACT_MIN", "0")   # the task list ordered by exact length (what MSMs of 2^25 pairs and more do); the other case: quantised
     bases, dlogs, scal = _device_inputs(ctx, c, group, n, 0xF05E + group)
     S = scal.to_host((n, 4))
     K = dlogs.to_host((n, 4))
