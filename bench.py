@@ -255,6 +255,10 @@ def pmc_traffic_live(args):
     import sqlite3
     import subprocess
     import tempfile
+    # (a bench.py that is itself being profiled does not start profilers of its own: the tool library of the outer rocprofv3 is
+    # inherited by every child, and counter collection must never meet another tracing mode)
+    if any(k.startswith("ROCPROF_") or k == "ROCP_TOOL_LIBRARIES" for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this process runs under a profiler: in-run counter passes skipped", {}
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if exe is None:
         return None, "rocprofv3 not found on this box", {}

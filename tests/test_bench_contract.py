@@ -167,3 +167,17 @@ def test_a_failing_rank_in_the_replica_leg(env):
     d = _line(r.stdout)
     assert d["value_checked"] is True and d["groth16"]["matches_dlog"] is True
     assert "skipped on every rank" in d["replicas"]["error"] and "injected fault" in d["replicas"]["error"]
+
+
+def test_counter_passes_are_not_nested_under_a_profiler(monkeypatch):
+    """bench.py measures `roofline.traffic` with child rocprofv3 passes -- but not when it is itself being profiled (the outer tool's
+    library is inherited by children; --pmc must never meet another tracing mode): it says so and the committed figure is used"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for var, val in (("ROCPROF_OUTPUT_PATH", "/tmp/x"), ("ROCP_TOOL_LIBRARIES", "librocprofiler-sdk-tool.so"), ("LD_PRELOAD", "/opt/rocm/lib/librocprofiler-sdk-tool.so")):
+        monkeypatch.setenv(var, val)
+        traffic, source, detail = bench.pmc_traffic_live(None)
+        assert traffic is None and "under a profiler" in source and detail == {}
+        monkeypatch.delenv(var)
