@@ -26,8 +26,10 @@ Workload (BASELINE.json `metric`: "G1 MSM Mscalar-mul/s + Groth16 proofs/s, BN25
     affine base); durations come from hipEvents recorded by the library on its own stream; `bound_actual` and the `int_mad_*`
     scalars price the same launches against the measured v_mad_u64_u32 issue rate (the binding resource); `traffic` is measured IN
     THIS RUN by two child rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE; `traffic_source` says so, or names the committed fallback).
-  * "cpu_baseline" (rank 0, N = 1 only): the C oracle's Pippenger (oracle/oracle.c -- a plain-C port, NOT gnark-crypto; one thread per window) on
-    2^24 points and the oracle's Groth16 prover on a 2^20 sample.
+  * "cpu_baseline" (rank 0): oracle/msm_fast.c on 2^24 points -- a plain-C restatement of the algorithm gnark-crypto's CPU MultiExp
+    publishes (signed digits, batch-affine buckets, tasks on every usable core), NOT gnark-crypto itself; kind "port-batch-affine";
+    `value_simple` is oracle/oracle.c's Pippenger (Jacobian buckets, one thread per window) on the same input.  N = 1 adds the
+    oracle's Groth16 prover on a 2^20-constraint sample ("groth16_2p20_sample") and config 2; N > 1 carries the MSM figure alone.
   * "nccl_selftest" (N = 1): a one-rank process group over the nccl (= RCCL) backend pushes a sharded proof and an MSM through every
     collective gnark_amd/multigpu.py uses, on device tensors (a 1-GPU box cannot run N > 1, but it can run the RCCL code path).
 
@@ -931,8 +933,9 @@ def nccl_selftest_leg(R):
         return "failed", {"error": "timeout"}
 
 
-def cpu_baseline_leg(R, out):
-    """the oracle's Pippenger on a bounded sample (rank 0): a plain-C port, NOT gnark-crypto"""
+def cpu_baseline_leg(R, out, msm_only=False):
+    """the oracle's Pippenger on a bounded sample (rank 0): a plain-C port, NOT gnark-crypto.  `msm_only` (N > 1: the other ranks
+    wait in the closing barrier meanwhile) leaves out the config-2 and Groth16 samples the N = 1 line carries."""
     from gnark_amd import _lib, ecc
     from gnark_amd.device import affine_words, curve_id
     ctx, lib, args = R.ctx, R.lib, R.args
@@ -943,8 +946,9 @@ def cpu_baseline_leg(R, out):
     sample_log = min(args.log_n, 24)
     sn = 1 << sample_log
 
-    def cpu_vs_gpu(logn):
-        """the oracle's Pippenger and the library's plain (un-pinned bases: no table) MSM on the same 2^logn inputs"""
+    def cpu_vs_gpu(logn, simple=True):
+        """the oracle's two CPU MSMs (msm_fast.c: batch-affine, all cores; oracle.c: the simple one, a thread per window) and the
+        library's plain (un-pinned bases: no table) MSM on the same 2^logn inputs"""
         m = 1 << logn
         sb = ctx.malloc(m * words_aff * 8)
         lib.check(lib.ga_gen_bases(ctx.handle, cid, _lib.G1, 0x5EED0002, m, sb.ptr, None))
@@ -953,8 +957,14 @@ def cpu_baseline_leg(R, out):
         lib.check(lib.ga_gen_scalars(ctx.handle, cid, 0x5EED0001, m, ss.ptr))
         S = ss.to_host((m, 4))
         t0 = time.perf_counter()
-        ref = oracle.msm(cid, 0, P, S, nthreads=eff_cores)
+        ref = oracle.msm_fast(cid, P, S, nthreads=eff_cores)
         cpu = time.perf_counter() - t0
+        cpu_simple, simple_same = None, None
+        if simple:
+            t0 = time.perf_counter()
+            ref_simple = oracle.msm(cid, 0, P, S, nthreads=eff_cores)
+            cpu_simple = time.perf_counter() - t0
+            simple_same = bool(np.array_equal(oracle.jac_to_affine(cid, 0, ref), oracle.jac_to_affine(cid, 0, ref_simple)))
         gpu_res = ecc.MultiExp(ctx, cid, _lib.G1, sb, ss, n=m)   # (also the warm-up of the timed repetitions below)
         reps = 5 if logn >= 24 else 20
         ctx.sync()
@@ -970,26 +980,33 @@ def cpu_baseline_leg(R, out):
         ctx.sync()
         st = stage_stats(ctx.profile_read())
         ctx.profile(False)
-        same = bool(np.array_equal(oracle.jac_to_affine(cid, 0, ref), ecc.jac_to_affine(cid, _lib.G1, gpu_res)))
+        same = bool(np.array_equal(oracle.jac_to_affine(cid, 0, ref), ecc.jac_to_affine(cid, _lib.G1, gpu_res))) and simple_same is not False
         sb.free()
         ss.free()
-        return cpu, gpu, same, st
-    cpu_s, _, same, _ = cpu_vs_gpu(sample_log)
-    threads_used = min(eff_cores, oracle.msm_windows(cid, sn))   # the port runs one thread per Pippenger window
+        return cpu, gpu, same, st, cpu_simple
+    cpu_s, _, same, _, cpu_simple_s = cpu_vs_gpu(sample_log, simple=not msm_only)
+    cbits, nwin_f, splits = oracle.msm_fast_plan(cid, sn, eff_cores)
+    threads_used = min(eff_cores, nwin_f * splits)          # (window x point-range) tasks on a thread pool: every usable core works
+    threads_simple = min(eff_cores, oracle.msm_windows(cid, sn))   # the simple port runs one thread per Pippenger window
     out["cpu_baseline"] = {"value": round(sn / cpu_s / 1e6, 4), "unit": "Mscalar-mul/s", "cores": threads_used, "threads_used": threads_used,
-                           "effective_cores": eff_cores, "logical_cpus": logical_cpus, "cgroup_cpu_quota": quota, "host_cores": logical_cpus, "kind": "port",
-                           "sample": "%s G1 MSM of 2^%d points, oracle/oracle.c Pippenger (one thread per window: %d windows, %d usable CPUs), %.1f s" % (args.curve.upper(), sample_log, oracle.msm_windows(cid, sn), eff_cores, cpu_s),
+                           "effective_cores": eff_cores, "logical_cpus": logical_cpus, "cgroup_cpu_quota": quota, "host_cores": logical_cpus, "kind": "port-batch-affine",
+                           "value_simple": round(sn / cpu_simple_s / 1e6, 4) if cpu_simple_s else None, "cores_simple": threads_simple,
+                           "speedup_over_simple": round(cpu_simple_s / cpu_s, 2) if cpu_simple_s else None,
+                           "sample": "%s G1 MSM of 2^%d points, oracle/msm_fast.c: signed %d-bit digits, batch-affine buckets, %d windows x %d point ranges on %d threads, %.1f s%s" % (
+                               args.curve.upper(), sample_log, cbits, nwin_f, splits, threads_used, cpu_s,
+                               "; value_simple: oracle/oracle.c Pippenger, Jacobian buckets, one thread per window (%d), %.1f s" % (threads_simple, cpu_simple_s) if cpu_simple_s else ""),
                            "gpu_result_matches_oracle": same,
-                           "note": "a plain-C restatement (64-bit CIOS, no assembly, no batch-affine buckets), NOT gnark-crypto -- gnark-crypto on the same cores would be several times faster, so the GPU/CPU ratio of this line is not a claim; gnark cannot be built here (no Go toolchain); the box shows %d logical CPUs but its cgroup grants %s of them" % (logical_cpus, "all" if quota is None else "%.0f" % quota)}
+                           "note": "a plain-C restatement of the algorithm gnark-crypto's CPU MultiExp publishes (signed digits, batch-affine buckets behind one inversion per batch, conflict queue, tasks beyond the window count; 64-bit CIOS, no assembly), NOT gnark-crypto itself -- gnark cannot be built here (no Go toolchain), so the GPU/CPU ratio of this line is not a claim; the box shows %d logical CPUs but its cgroup grants %s of them" % (logical_cpus, "all" if quota is None else "%.0f" % quota)}
     # BASELINE config 2: G1 MSM over 2^20 random, UN-PINNED bases (ga_msm: bases converted per call, no table), GPU beside the CPU port
-    if args.log_n >= 20:
+    if args.log_n >= 20 and not msm_only:
         try:
-            c2_cpu, c2_gpu, c2_same, c2_st = cpu_vs_gpu(20)
+            c2_cpu, c2_gpu, c2_same, c2_st, c2_cpu_simple = cpu_vs_gpu(20)
             acc2 = c2_st.get("msm_accumulate", {}).get("avg_ms")
             alg2 = ALG_BYTES[(cid, 0)] * (1 << 20)
             out["config2_msm_2p20_unpinned"] = {
                 "gpu_ms_per_msm": round(c2_gpu * 1e3, 3), "gpu_Mscalar_mul_per_s": round((1 << 20) / c2_gpu / 1e6, 2),
-                "cpu_port_Mscalar_mul_per_s": round((1 << 20) / c2_cpu / 1e6, 4), "cpu_threads": min(eff_cores, oracle.msm_windows(cid, 1 << 20)),
+                "cpu_port_Mscalar_mul_per_s": round((1 << 20) / c2_cpu / 1e6, 4), "cpu_threads": eff_cores,
+                "cpu_port_simple_Mscalar_mul_per_s": round((1 << 20) / c2_cpu_simple / 1e6, 4),
                 "gpu_result_matches_oracle": c2_same,
                 "roofline": {"bound": "hbm", "kernel": "msm_accumulate29_kernel (raw bases: one bucket set per window)", "avg_launch_ms": acc2,
                              "algorithmic_bytes_per_launch": alg2, "achieved": round(alg2 / (acc2 * 1e-3) / 1e9, 3) if acc2 else None, "peak": 8000.0, "unit": "GB/s",
@@ -998,7 +1015,7 @@ def cpu_baseline_leg(R, out):
         except Exception as e:
             out["config2_msm_2p20_unpinned"] = {"error": repr(e)[:300]}
     # proofs/s for the same port: the oracle's Groth16 prover (7 FFTs + 4 G1 + 1 G2 MSM) on a bounded 2^20-constraint sample
-    if args.groth16_proofs > 0:
+    if args.groth16_proofs > 0 and not msm_only:
         try:
             glog = min(args.log_n, int(os.environ.get("GA_BENCH_CPU_G16_LOGN", "20")))
             from gnark_amd import groth16, synth
@@ -1011,11 +1028,11 @@ def cpu_baseline_leg(R, out):
             gp = groth16.Prove(gpk, gs, ginst.nb_public, ginst.r, ginst.s)
             gpk.FreeGPUResources()
             g_same = bool(np.array_equal(gp.Ar, want[0]) and np.array_equal(gp.Bs, want[1]) and np.array_equal(gp.Krs, want[2]))
-            out["cpu_baseline"]["groth16"] = {"proofs_per_s": round(1.0 / g_s, 4), "constraints": 1 << glog, "kind": "port", "threads_used": eff_cores,
-                                              "sample": "oracle/oracle.c Groth16 prover, 2^%d constraints, %d threads, %.1f s" % (glog, eff_cores, g_s),
+            out["cpu_baseline"]["groth16_2p%d_sample" % glog] = {"proofs_per_s": round(1.0 / g_s, 4), "constraints": 1 << glog, "kind": "port", "threads_used": eff_cores,
+                                              "sample": "oracle/oracle.c Groth16 prover (its simple MSM), 2^%d constraints -- NOT the 2^%d of the GPU proofs beside it --, %d threads, %.1f s" % (glog, args.log_n, eff_cores, g_s),
                                               "gpu_proof_matches_oracle": g_same}
         except Exception as e:
-            out["cpu_baseline"]["groth16"] = {"error": repr(e)[:300]}
+            out["cpu_baseline"]["groth16_sample"] = {"error": repr(e)[:300]}
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
@@ -1059,13 +1076,14 @@ def compact_line(out):
     line["roofline"] = rf
     cb = out.get("cpu_baseline")
     if isinstance(cb, dict):
-        c2 = pick(cb, "value", "unit", "cores", "kind", "effective_cores", "host_cores", "gpu_result_matches_oracle", "skipped", "error")
+        c2 = pick(cb, "value", "unit", "cores", "kind", "value_simple", "cores_simple", "speedup_over_simple", "effective_cores", "host_cores", "gpu_result_matches_oracle", "source", "error")
         if "sample" in cb:
-            c2["sample"] = cb["sample"][:110]
+            c2["sample"] = cb["sample"][:150]
         if "note" in cb:
-            c2["note"] = "plain-C port of the algorithm (oracle/oracle.c), NOT gnark-crypto: the GPU/CPU ratio is not a claim"
-        if isinstance(cb.get("groth16"), dict):
-            c2["groth16"] = pick(cb["groth16"], "proofs_per_s", "constraints", "threads_used", "gpu_proof_matches_oracle", "error")
+            c2["note"] = "plain-C port of gnark-crypto's published algorithm (oracle/msm_fast.c), NOT gnark-crypto: the GPU/CPU ratio is not a claim"
+        for k, v in cb.items():
+            if k.startswith("groth16_") and isinstance(v, dict):
+                c2[k] = pick(v, "proofs_per_s", "constraints", "threads_used", "gpu_proof_matches_oracle", "error")
         line["cpu_baseline"] = c2
     if out.get("stages_ms"):
         line["stages_ms"] = stage_totals(out["stages_ms"], "avg_ms")
@@ -1148,16 +1166,78 @@ def compact_line(out):
                 sm["msm_bls12_381_%s_ms" % grp] = mb[grp].get("ms_per_msm")
     if isinstance(cb, dict):
         sm["cpu_port_Mscalar_mul_per_s"] = cb.get("value")
+        sm["cpu_port_simple_Mscalar_mul_per_s"] = cb.get("value_simple")
     if "backend" in out:
         sm["backend"] = out["backend"]
     line["summary"] = {k: v for k, v in sm.items() if v is not None}
     return line
 
 
+def error_line(args, text):
+    """the one-line JSON a run that must not be mistaken for a measurement prints (rank 0 / the launcher only) before it exits non-zero"""
+    return json.dumps({"metric": "G1 MSM throughput, %s, 2^%d scalar-muls" % (args.curve.upper(), args.log_n), "value": None, "unit": "Mscalar-mul/s",
+                       "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "error": text}, separators=(",", ":"))
+
+
+def world_check(args):
+    """`--gpus N` is the number of ranks this line is ABOUT: a launcher's WORLD_SIZE that disagrees with it, or (backend nccl = RCCL,
+    one rank per GPU) fewer visible GPUs than ranks, is an error -- never a silent one-GPU measurement.  Returns the error text or None."""
+    ws = os.environ.get("WORLD_SIZE")
+    if ws is not None and int(ws) != args.gpus:
+        return "--gpus %d but the launcher set WORLD_SIZE=%s: refusing to measure a world other than the one asked for" % (args.gpus, ws)
+    emu = os.environ.get("GA_BENCH_EMU", "0") == "1"
+    backend = os.environ.get("GA_BENCH_BACKEND", "gloo" if emu else "nccl")
+    if args.gpus > 1 and backend == "nccl" and not emu:
+        import torch
+        ndev = torch.cuda.device_count()
+        if args.gpus > ndev:
+            return ("--gpus %d with backend nccl (RCCL: one rank per GPU) but this node shows %d GPU(s); GA_BENCH_BACKEND=gloo runs the "
+                    "N > 1 code path with ranks sharing a GPU (a functional run, not a scaling figure)" % (args.gpus, ndev))
+    return None
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` (N > 1) WITHOUT a launcher: start the N ranks ourselves -- `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>` over this same script and arguments -- and pass rank 0's JSON
+    line through as the only thing on stdout (everything else a child prints there, e.g. gloo's connection banner, goes to stderr)."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("bench: --gpus %d without a launcher: %s\n" % (args.gpus, " ".join(cmd[1:10])))
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=os.getcwd())
+    lines = 0
+    for ln in p.stdout:
+        if ln.startswith("{"):
+            sys.stdout.write(ln)
+            sys.stdout.flush()
+            lines += 1
+        else:
+            sys.stderr.write(ln)
+    rc = p.wait()
+    if lines == 0:
+        print(error_line(args, "the %d ranks launched for --gpus %d exited with code %d without printing a line" % (args.gpus, args.gpus, rc)))
+        return rc or 1
+    return rc
+
+
 def main():
     if "--nccl-selftest-worker" in sys.argv:
         sys.exit(nccl_selftest_worker())
     args = parse()
+    bad = world_check(args)
+    if bad is not None:
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(error_line(args, bad))
+        sys.stderr.write("bench: " + bad + "\n")
+        sys.exit(2)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     R = Run(args)
     from gnark_amd.device import curve_id
     cid = curve_id(args.curve)
@@ -1245,14 +1325,17 @@ def main():
             if rep is not None:
                 out["replicas"] = rep
 
-    # the CPU port is timed at N = 1 only (rank 0 would keep N - 1 GPUs waiting in the barrier below for the same figure at every N)
-    cpu_at_any_n = os.environ.get("GA_BENCH_CPU_BASELINE_ANY_N", "0") != "0"
-    if rank == 0 and world > 1 and not cpu_at_any_n and not args.no_cpu_baseline and not args.only_headline:
-        out["cpu_baseline"] = {"value": None, "unit": "Mscalar-mul/s", "kind": "port", "skipped": "timed at N = 1 only (the --gpus 1 line of the same commit)"}
-    elif rank == 0 and not args.no_cpu_baseline and not args.only_headline:   # (a local leg, no collectives inside)
+    # the CPU port: rank 0, a local leg (no collectives inside).  N > 1 times the MSM sample alone -- the same figure the N = 1 line
+    # carries, so that every line of a scaling record holds its own CPU number -- while the other ranks wait in the barrier below
+    # (outside every timed region); GA_BENCH_CPU_BASELINE_JSON hands in a figure measured elsewhere on this box instead.
+    if rank == 0 and not args.no_cpu_baseline and not args.only_headline:
         t0 = time.perf_counter()
+        given = os.environ.get("GA_BENCH_CPU_BASELINE_JSON", "")
         try:
-            cpu_baseline_leg(R, out)
+            if given:
+                out["cpu_baseline"] = dict(json.loads(open(given).read() if os.path.exists(given) else given), source="GA_BENCH_CPU_BASELINE_JSON")
+            else:
+                cpu_baseline_leg(R, out, msm_only=world > 1)
         except Exception as e:
             out["cpu_baseline"] = {"error": repr(e)[:300]}
         legs_s["cpu_baseline"] = round(time.perf_counter() - t0, 1)

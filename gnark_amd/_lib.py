@@ -115,6 +115,7 @@ _PROTOS = {
     "ga_g16_finish": (C.c_int, [_P, _P, _P, _P, _P]),
     "ga_g16_shard_layout": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "ga_g16_lane_stats": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "ga_g16_table_layout": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "ga_g16_witness_partial": (C.c_int, [_P, _P, C.c_uint64, _P]),
     "ga_g16_h_chain": (C.c_int, [_P, _P, C.c_uint64, _P]),
     "ga_g16_h_chain_dev": (C.c_int, [_P, _P, C.c_uint64]),

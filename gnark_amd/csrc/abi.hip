@@ -105,6 +105,10 @@ int Ctx::scratch_get(const char* base_key, size_t bytes, void** out) {
     if (const uint64_t f = tun.fault_throw.load(std::memory_order_relaxed))
         if (f == fnv1a(current_entry())) throw std::bad_alloc();
     const int lane = current_lane();
+    if (lane >= 2 && tun.fault_lane2_nomem.load(std::memory_order_relaxed)) {
+        set_error("device scratch '%s@%d': GA_FAULT_LANE2_NOMEM is set (test knob: lanes 2/3 cannot allocate)", base_key, lane);
+        return GA_ERR_NOMEM;
+    }
     const std::string lane_key = lane ? std::string(base_key) + "@" + std::to_string(lane) : std::string(base_key);
     const char* key = lane_key.c_str();
     std::lock_guard<std::mutex> g(scratch_mu);
@@ -136,6 +140,19 @@ void Ctx::scratch_free_all() {
     std::lock_guard<std::mutex> g(scratch_mu);
     for (auto& kv : scratch) hipFree(kv.second.first);
     scratch.clear();
+}
+
+void Ctx::scratch_free_lanes(int first_lane) {
+    std::lock_guard<std::mutex> g(scratch_mu);
+    for (auto it = scratch.begin(); it != scratch.end();) {
+        const size_t at = it->first.rfind('@');
+        const int lane = at == std::string::npos ? 0 : atoi(it->first.c_str() + at + 1);
+        if (lane >= first_lane) {
+            hipFree(it->second.first);
+            it = scratch.erase(it);
+        } else
+            ++it;
+    }
 }
 
 void Tunables::read_env() {
@@ -173,6 +190,7 @@ void Tunables::read_env() {
         const char* e = getenv("GA_FAULT_THROW");
         put64(fault_throw, (e && *e) ? fnv1a(e) : 0);
     }
+    put(fault_lane2_nomem, (int)num("GA_FAULT_LANE2_NOMEM", 0));
     const int grp = (int)num("GA_MSM_GROUP", 0);
     put(msm_group, (grp >= 2 && grp <= 256 && (grp & (grp - 1)) == 0) ? grp : 0);
     const uint64_t seg = num("GA_MSM_MIN_SEG", 256);

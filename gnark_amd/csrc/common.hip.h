@@ -27,6 +27,8 @@ namespace ga {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__GFX9__)
 #error "libgnark_amd: the kernels assume the 64-lane wavefronts of GFX9 / CDNA (gfx950); a wave32 target would compile and compute wrong transforms and sorts"
 #endif
+// (GA_REQUIRE_WAVE64 is DOCUMENTATION: it expands to a tautology and checks nothing by itself; the checks are the #error above
+// and the warpSize test in ga_ctx_create)
 #define GA_REQUIRE_WAVE64() static_assert(true, "64-lane wavefronts: enforced for the whole device pass at the top of common.hip.h")
 
 // Rendezvous of the lanes of ONE wave around LDS traffic among themselves: a wave's LDS instructions are served in issue order, so
@@ -174,6 +176,7 @@ struct Tunables {
     std::atomic<uint64_t> msm_fuse_min{1ull << 21};   // pairs from which the digits are fused with the first sort pass (msm.hip.h 1b)
     std::atomic<int> msm_group{0};                   // buckets per running-sum group of the window reduction (0 = MSM_GROUP)
     std::atomic<uint64_t> fault_throw{0};            // FNV-1a of GA_FAULT_THROW (0 = unset): the entry point under which scratch_get throws (tests)
+    std::atomic<int> fault_lane2_nomem{0};           // GA_FAULT_LANE2_NOMEM (tests): scratch requests of lanes 2/3 fail as if HBM were exhausted
     std::atomic<uint64_t> msm_p1_grid{512};         // blocks of the first sort level (a block walks several tiles)
     std::atomic<uint64_t> msm_task_exact_min{1ull << 25};   // pairs from which the task list is sorted on exact lengths (msm.hip.h 3)
     std::atomic<int> msm_xcd{3};                     // fused sort placement: bit 0 per-XCD slices of the first level's groups, bit 1 XCD swizzle of the second level's segments
@@ -273,6 +276,7 @@ struct Ctx {
 
     int scratch_get(const char* key, size_t bytes, void** out);
     void scratch_free_all();
+    void scratch_free_lanes(int first_lane);   // give back the scratch of lanes >= first_lane (their streams must be idle)
 };
 
 // every ABI entry point: take the context's mutex (one proof at a time per device, icicle.go:821-823), select its device (HIP's

@@ -346,7 +346,7 @@ static int stage_finish(G16Stage* st, int precompute, G16Pk** out) {
     }
     // ---- optional precomputation: [2^(c*w)]P for every window (one shared bucket set per MSM afterwards) ----------
     if (rc == GA_OK && precompute >= 0) {
-        int nw;
+        int nw = 0;
         const size_t t1 = msm_table_point_bytes<C, GA_G1>(), t2 = msm_table_point_bytes<C, GA_G2>();
         // share the witness sort between the vectors that cover at least GA_G16_SHARE_MIN_PCT % of the wires (default 90: a
         // sparse vector would make the lanes of the bucket kernel idle on its missing wires, and waste table memory)
@@ -370,11 +370,13 @@ static int stage_finish(G16Stage* st, int precompute, G16Pk** out) {
         // precompute == 0: as many as fit the free HBM next to the per-proof scratch, in the order of what a table buys per byte:
         // A, B1, K (48 GiB each at 2^26 BN254; with all three the witness is sorted once instead of three times), Z, and last G2.B
         // (twice the bytes for the smallest relative gain).
-        const uint64_t bytes_a = pk->share_a ? wide * t1 : (uint64_t)(C::FrP::BITS / pk->c_a + 1) * pk->len_a * t1;
-        const uint64_t bytes_b = pk->share_b ? wide * t1 : (uint64_t)(C::FrP::BITS / pk->c_b + 1) * pk->len_b * t1;
-        const uint64_t bytes_b2 = pk->share_b ? wide * t2 : (uint64_t)(C::FrP::BITS / pk->c_b + 1) * pk->len_b * t2;
-        const uint64_t bytes_z = (uint64_t)(C::FrP::BITS / pk->c_z + 1) * pk->len_z * t1;
-        const uint64_t bytes_k = pk->share_k ? wide * t1 : (uint64_t)(C::FrP::BITS / pk->c_k + 1) * pk->len_k * t1;
+        // (a vector the planner refused -- beyond the 2^31 pair space, or a forced GA_TABLE_C too narrow -- has c_* = 0: no table, no size)
+        auto nwin_of = [](int cbits) -> uint64_t { return cbits > 0 ? (uint64_t)(C::FrP::BITS / cbits + 1) : 0; };
+        const uint64_t bytes_a = !plan_ok ? 0 : pk->share_a ? wide * t1 : nwin_of(pk->c_a) * pk->len_a * t1;
+        const uint64_t bytes_b = !plan_ok ? 0 : pk->share_b ? wide * t1 : nwin_of(pk->c_b) * pk->len_b * t1;
+        const uint64_t bytes_b2 = !plan_ok ? 0 : pk->share_b ? wide * t2 : nwin_of(pk->c_b) * pk->len_b * t2;
+        const uint64_t bytes_z = !plan_ok ? 0 : nwin_of(pk->c_z) * pk->len_z * t1;
+        const uint64_t bytes_k = !plan_ok ? 0 : pk->share_k ? wide * t1 : nwin_of(pk->c_k) * pk->len_k * t1;
         if (rc == GA_OK && plan_ok) {
             if (precompute > 0) {
                 pk->tab_a = pk->tab_b = pk->tab_k = pk->tab_z = pk->tab_b2 = true;
@@ -2038,37 +2040,51 @@ static int g16_prove_impl(ga_g16_pk* p, const void* w, const void* a, const void
     // and the kernels interleave.  When lane 2 is taken as well, or while the profiler records stages, or with GA_G16_LANES=1,
     // the caller stages its solution in its input slot and queues for the device.  The host epilogue always runs outside the
     // device lock.  ga_g16_lane_stats reports how the calls of a context were scheduled.
+    // A lane-2 proof that cannot get its scratch (precompute = 0 fills HBM with tables beside ONE caller's scratch: at 2^26 a second
+    // caller's 77 GiB are not there) gives back what lanes 2/3 hold and queues for the device like a third caller would -- a proof
+    // is slower then, never failed.
     Ctx* ctx = pk->ctx;
     SlotLease slot(ctx);
-    bool preloaded = false;
-    int lane = 0;
     std::unique_lock<std::mutex> dev(ctx->mu, std::try_to_lock);
     std::unique_lock<std::mutex> lane2(ctx->lane_mu[2], std::defer_lock);
     hipSetDevice(ctx->device);
-    if (!dev.owns_lock()) {
-        if (!ctx->profiling && ctx->tun.g16_lanes > 1 && lane2.try_lock()) {
-            lane = 2;
-            ctx->stat_lane2++;
-        } else {
-            GA_CHECK(preload_solution(pk, slot, w, a, b, c, n_constraints, nb_public));
-            preloaded = true;
-            dev.lock();
-            ctx->stat_queued++;
+    for (int attempt = 0;; attempt++) {
+        bool preloaded = false;
+        int lane = 0;
+        if (!dev.owns_lock()) {
+            if (attempt == 0 && !ctx->profiling && ctx->tun.g16_lanes > 1 && lane2.try_lock()) {
+                lane = 2;
+                ctx->stat_lane2++;
+            } else {
+                GA_CHECK(preload_solution(pk, slot, w, a, b, c, n_constraints, nb_public));
+                preloaded = true;
+                dev.lock();
+                ctx->stat_queued++;
+            }
         }
+        if (lane == 0 && !preloaded) ctx->stat_lane0++;
+        int partial_rc = GA_OK;
+        {
+            LaneScope on_lane(lane);
+            if (lane == 0) ctx->tun.read_env();
+            GA_DISPATCH_CURVE(pk->curve, {
+                XYZZ<Fe<typename C::FpP>> ar, bs1, krs;
+                XYZZ<Fe2<typename C::FpP>> bs2;
+                partial_rc = prove_partial<C>(pk, slot, preloaded, w, a, b, c, n_constraints, nb_public, &ar, &bs1, &krs, &bs2);
+                if (partial_rc == GA_OK) {
+                    const bool profiling = ctx->profiling;
+                    if (lane == 0 && !profiling) dev.unlock();   // the stage list of the profiler is guarded by the device lock
+                    if (lane == 2) lane2.unlock();
+                    return finish<C>(pk, ar, bs1, krs, bs2, r, s, proof_out);
+                }
+            });
+        }
+        if (partial_rc != GA_ERR_NOMEM || lane != 2) return partial_rc;
+        // (everything prove_partial started on lanes 2/3 has joined; hipFree synchronises with what their streams still hold)
+        ctx->scratch_free_lanes(2);
+        ctx->stat_lane2--;
+        lane2.unlock();
     }
-    if (lane == 0 && !preloaded) ctx->stat_lane0++;
-    LaneScope on_lane(lane);
-    if (lane == 0) ctx->tun.read_env();
-    GA_DISPATCH_CURVE(pk->curve, {
-        XYZZ<Fe<typename C::FpP>> ar, bs1, krs;
-        XYZZ<Fe2<typename C::FpP>> bs2;
-        GA_CHECK(prove_partial<C>(pk, slot, preloaded, w, a, b, c, n_constraints, nb_public, &ar, &bs1, &krs, &bs2));
-        const bool profiling = ctx->profiling;
-        if (lane == 0 && !profiling) dev.unlock();   // the stage list of the profiler is guarded by the device lock
-        if (lane == 2) lane2.unlock();
-        return finish<C>(pk, ar, bs1, krs, bs2, r, s, proof_out);
-    });
-    return GA_OK;
 }
 
 // out[0..3] = ga_g16_prove calls of this context that ran on lanes 0/1, on lanes 2/3 beside another proof, that staged their
@@ -2154,11 +2170,21 @@ int ga_g16_shard_layout(ga_g16_pk* p, uint64_t* out6) try {
     out6[4] = pk->n;
     out6[5] = pk->nb_wires;
     out8[6] = pk->win_index;
-    // bits 32..: which vectors carry a window table (bit 32 A, 33 B, 34 Z, 35 K, 36 G2.B) and which of those are wire-indexed over the
-    // shared witness sort (bit 40 A, 41 B, 43 K, 44 G2.B)
-    const uint64_t tabs = (uint64_t)pk->tab_a | (uint64_t)pk->tab_b << 1 | (uint64_t)pk->tab_z << 2 | (uint64_t)pk->tab_k << 3 | (uint64_t)pk->tab_b2 << 4 |
-                          (uint64_t)pk->share_a << 8 | (uint64_t)pk->share_b << 9 | (uint64_t)pk->share_k << 11 | (uint64_t)pk->share_b2 << 12;
-    out8[7] = (uint64_t)pk->win_count | tabs << 32;
+    out8[7] = pk->win_count;   // (the plain count: which vectors carry tables is ga_g16_table_layout's answer)
+    return GA_OK;
+} GA_ABI_CATCH
+
+// out2[0]: which vectors carry a window table (bit 0 G1.A, 1 G1.B, 2 G1.Z, 3 G1.K, 4 G2.B); out2[1]: which of those are laid out by
+// wire id over the shared witness sort (bit 0 A, 1 B, 3 K, 4 G2.B)
+int ga_g16_table_layout(ga_g16_pk* p, uint64_t* out2) try {
+    GA_ABI_ENTRY();
+    G16Pk* pk = reinterpret_cast<G16Pk*>(p);
+    if (!pk || !out2) {
+        set_error("ga_g16_table_layout: null argument");
+        return GA_ERR_INVALID;
+    }
+    out2[0] = (uint64_t)pk->tab_a | (uint64_t)pk->tab_b << 1 | (uint64_t)pk->tab_z << 2 | (uint64_t)pk->tab_k << 3 | (uint64_t)pk->tab_b2 << 4;
+    out2[1] = (uint64_t)pk->share_a | (uint64_t)pk->share_b << 1 | (uint64_t)pk->share_k << 3 | (uint64_t)pk->share_b2 << 4;
     return GA_OK;
 } GA_ABI_CATCH
 

@@ -1464,6 +1464,10 @@ int msm_prepare(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, in
     // Scratch of the sort.  Fused: key parts (16 bits) / vals are the first level's output, dead once the second level has run, and
     // the sorted keys are never materialised -- so the two sort slots of a lane SHARE them (stream order separates their uses) and
     // there is no keys2: 14 bytes per pair less per extra slot.  Library sort: ping-pong pairs, the result may live in either.
+    // INVARIANT behind the sharing: scratch names are per LANE (Ctx::scratch_get appends "@lane") and a lane has exactly one work
+    // stream, so both slots issue on the same stream; a buffer that has to grow is released with hipFree, which waits for the device.
+    // A slot prepared on any other stream, or an asynchronous free (hipFreeAsync, a pool), would let one slot's first level overwrite
+    // pairs the other slot's second level has not read yet: key these two buffers by stream before doing either.
     keys = keys2 = nullptr;
     uint16_t* key_parts = nullptr;   // fused: what the first level hands to the second per pair besides the value -- the <= 12 low key bits
     if (fused) {

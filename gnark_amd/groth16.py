@@ -311,10 +311,10 @@ def ShardLayout(pk: ProvingKey) -> dict:
     out = (C.c_uint64 * 8)()
     pk.ctx.lib.check(pk.ctx.lib.ga_g16_shard_layout(pk.handle, out))
     d = dict(zip(("off_z", "len_z", "w_lo", "w_hi", "n", "nb_wires", "win_index", "win_count"), (int(v) for v in out)))
-    tabs = d["win_count"] >> 32
-    d["win_count"] &= 0xFFFFFFFF
-    d["tables"] = {k: bool(tabs >> b & 1) for k, b in (("A", 0), ("B", 1), ("Z", 2), ("K", 3), ("B2", 4))}          # vectors with a window table
-    d["wire_indexed"] = {k: bool(tabs >> b & 1) for k, b in (("A", 8), ("B", 9), ("K", 11), ("B2", 12))}            # ... sharing the one witness sort
+    t = (C.c_uint64 * 2)()
+    pk.ctx.lib.check(pk.ctx.lib.ga_g16_table_layout(pk.handle, t))
+    d["tables"] = {k: bool(t[0] >> b & 1) for k, b in (("A", 0), ("B", 1), ("Z", 2), ("K", 3), ("B2", 4))}          # vectors with a window table
+    d["wire_indexed"] = {k: bool(t[1] >> b & 1) for k, b in (("A", 0), ("B", 1), ("K", 3), ("B2", 4))}            # ... sharing the one witness sort
     return d
 
 

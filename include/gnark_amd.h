@@ -245,7 +245,7 @@ typedef struct ga_g16_key {
     uint64_t nb_wires;
     uint64_t nb_infinity_a;
     uint64_t nb_infinity_b;
-    int32_t precompute;              /* 0: precompute window tables for A,B,K,Z,G2.B -- those that fit comfortably in free HBM, see ga_g16_shard_layout
+    int32_t precompute;              /* 0: precompute window tables for A,B,K,Z,G2.B -- those that fit comfortably in free HBM, see ga_g16_table_layout
                                         (default), 1: always, -1: never */
     uint32_t shard_index;            /* multi-GPU partition B: pin only slice shard_index of shard_count of every */
     uint32_t shard_count;            /* base vector (contiguous ranges); 0 or 1 = the whole key */
@@ -333,11 +333,13 @@ int ga_g16_finish(ga_g16_pk* pk, const void* partials_sum, const void* r, const 
  * of ga_g16_h_combine of the SAME library build, never as the coset evaluations themselves), the combination
  * h = iFFT_coset((a*b - c)/(g^n - 1)) in a_dev from three such chains
  * (bit-reversed), and the MSM of this shard's slice of pk.G1.Z with the matching slice of h (h_slice_dev points at element off_z).
- * ga_g16_shard_layout: out8 = {off_z, len_z, w_lo, w_hi, domain cardinality, nb_wires, window_shard_index, window_shard_count | tables << 32}
- * (a window-sharded key covers all of h and W: off_z = 0, len_z = n - 1).  tables: bit 0 G1.A, 1 G1.B, 2 G1.Z, 3 G1.K, 4 G2.B carry a
- * window table (with precompute = 0 the library builds as many as fit the free HBM, in that order of preference A, B, K, Z, G2.B);
- * bits 8, 9, 11, 12: that table (A, B, K, G2.B) is laid out by wire id and shares the single witness sort. */
+ * ga_g16_shard_layout: out8 = {off_z, len_z, w_lo, w_hi, domain cardinality, nb_wires, window_shard_index, window_shard_count}
+ * (a window-sharded key covers all of h and W: off_z = 0, len_z = n - 1).
+ * ga_g16_table_layout: out2[0] = which vectors carry a window table -- bit 0 G1.A, 1 G1.B, 2 G1.Z, 3 G1.K, 4 G2.B (with precompute = 0
+ * the library builds as many as fit the free HBM, in the order of preference A, B, K, Z, G2.B); out2[1] = which of those tables are
+ * laid out by wire id and share the single witness sort (bit 0 A, 1 B, 3 K, 4 G2.B). */
 int ga_g16_shard_layout(ga_g16_pk* pk, uint64_t* out8);
+int ga_g16_table_layout(ga_g16_pk* pk, uint64_t* out2);
 int ga_g16_witness_partial(ga_g16_pk* pk, const void* w, uint64_t nb_public, void* partials_out);
 int ga_g16_h_chain(ga_g16_pk* pk, const void* v, uint64_t n_constraints, void* out_dev);
 /* the same chain on a vector that already sits on the device (buf_dev: n fr elements of room, the first n_constraints hold the

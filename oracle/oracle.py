@@ -22,8 +22,8 @@ class OraclePk(C.Structure):
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("oracle.c", "msm_fast.c", "msm_fast_body.inc", "oracle_constants.h")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call([os.path.join(_HERE, "build.sh")], stdout=subprocess.DEVNULL)
     return _SO
 
@@ -63,6 +63,27 @@ def msm(curve, group, points, scalars, mont=True, nthreads=1, naive=False):
     else:
         dll().oracle_msm(curve, group, _p(points), _p(scalars), C.c_size_t(n), int(mont), _p(out), nthreads)
     return out
+
+
+def msm_fast(curve, points, scalars, mont=True, nthreads=1, force_c=0, force_splits=0):
+    """msm_fast.c: G1 MSM with signed digits, batch-affine buckets and (window x point-range) tasks on `nthreads` threads -- the
+    CPU baseline bench.py quotes (kind "port-batch-affine"); same result contract as msm(curve, 0, ...)"""
+    points, scalars = _u64(points), _u64(scalars)
+    n = scalars.reshape(-1, 4).shape[0]
+    out = np.zeros(jac_words(curve, 0), dtype=np.uint64)
+    d = dll()
+    d.oracle_msm_fast.restype = C.c_int
+    rc = d.oracle_msm_fast(curve, _p(points), _p(scalars), C.c_size_t(n), int(mont), _p(out), int(nthreads), int(force_c), int(force_splits))
+    if rc != 0:
+        raise ValueError("oracle_msm_fast: rc %d" % rc)
+    return out
+
+
+def msm_fast_plan(curve, n, nthreads):
+    """(window bits, windows, range splits) msm_fast uses for n points on nthreads threads"""
+    o = (C.c_int * 3)()
+    dll().oracle_msm_fast_plan(curve, C.c_size_t(n), int(nthreads), o)
+    return tuple(o)
 
 
 def msm_windows(curve, n) -> int:

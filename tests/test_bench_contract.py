@@ -52,8 +52,10 @@ def test_single_rank_line(env, tmp_path):
     assert "integer issue" in rf["bound_actual"] and rf["int_mad_per_addition"] == 1467 and rf["int_mad_frac"] >= 0 and rf["int_mad_peak_T_per_s"] > 30
     assert "traffic" in rf and "traffic_source" in rf
     cb = line["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["gpu_result_matches_oracle"] is True and cb["host_cores"] >= cb["cores"] >= 1
-    assert "NOT gnark-crypto" in cb["note"] and cb["groth16"]["gpu_proof_matches_oracle"] is True
+    # the CPU figure is the batch-affine port on every usable core; the simple one-thread-per-window port stays beside it
+    assert cb["kind"] == "port-batch-affine" and cb["gpu_result_matches_oracle"] is True and cb["host_cores"] >= cb["cores"] >= 1
+    assert cb["value"] > 0 and cb["value_simple"] > 0 and cb["speedup_over_simple"] > 0
+    assert "NOT gnark-crypto" in cb["note"] and cb["groth16_2p8_sample"]["gpu_proof_matches_oracle"] is True and cb["groth16_2p8_sample"]["constraints"] == 256
     g = line["groth16"]
     assert g["matches_dlog"] is True and g["h_identity_ok"] is True and g["proofs"] == 2 and g["two_callers"]["same_proof_bytes"] is True
     assert line["plonk"]["identity_ok"] is True and line["plonk"]["roofline"]["bound"] == "hbm"
@@ -124,10 +126,53 @@ def test_two_ranks_line(env):
     assert "error" not in rp, rp
     assert rp["proofs_total"] == 2 * rp["proofs_per_rank"] and rp["proofs_per_s"] > 0 and len(rp["ms_per_proof_by_rank"]) == 2
     assert rp["same_proof_on_every_rank"] is True and rp["same_proof_as_sharded"] is True
-    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] is None and "N = 1 only" in d["cpu_baseline"]["skipped"]   # the CPU port is timed at N = 1 only
+    # every line of a scaling record carries its own CPU figure (rank 0 times the MSM sample while the others wait in the last barrier)
+    assert d["cpu_baseline"]["kind"] == "port-batch-affine" and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["gpu_result_matches_oracle"] is True
+    assert sm["cpu_port_Mscalar_mul_per_s"] == d["cpu_baseline"]["value"]
     for k in ("groth16_bn254_ms_per_proof", "groth16_bn254_window_ms_per_proof", "groth16_bls12_381_window_ms_per_proof", "groth16_bls12_381_range_ms_per_proof",
               "replicas_proofs_per_s", "weak_msm_Mscalar_mul_per_s", "backend"):
         assert k in sm, k
+
+
+def test_plain_gpus_2_launches_two_ranks(env):
+    """the driver's BENCH command shape -- `python bench.py --gpus 2 ...`, no launcher, no WORLD_SIZE -- starts the two ranks itself
+    (round 5: --gpus was parsed and never read, so this command measured ONE rank and said n_gpus 1)"""
+    e = {k: v for k, v in env.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(GA_BENCH_BOTH_PARTITIONS="0", GA_BENCH_CONFIG4="0", GA_BENCH_REPLICAS="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log-n", "9", "--steps", "1", "--warmup", "1", "--groth16-proofs", "1"],
+                       capture_output=True, text=True, env=e, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert [l for l in r.stdout.splitlines() if l.strip()] == [l for l in r.stdout.splitlines() if l.startswith("{")]   # rank 0's line is ALL of stdout
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 2 and d["world_size"] == 2 and len(d["ranks"]) == 2 and d["ranks"][0] != d["ranks"][1]
+    assert d["value"] > 0 and d["value_checked"] is True and "sharded" in d["config"]["workload"]
+    assert d["groth16"]["matches_dlog"] is True and d["cpu_baseline"]["value"] > 0
+    assert "torch.distributed.run" in r.stderr
+
+
+def test_world_size_mismatch_is_an_error(env):
+    """--gpus is the world the line is ABOUT: a launcher world that disagrees is refused, loudly, with a one-line JSON error and a
+    non-zero exit code -- never a silent measurement of another world"""
+    for gpus, ws in (("2", "1"), ("1", "2"), ("4", "2")):
+        e = dict(env, WORLD_SIZE=ws, RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", gpus, "--log-n", "8"], capture_output=True, text=True, env=e, cwd=ROOT, timeout=120)
+        assert r.returncode != 0
+        d = _line(r.stdout)
+        assert d["value"] is None and "WORLD_SIZE=" + ws in d["error"] and d["n_gpus"] == int(gpus)
+    # a rank other than 0 exits the same way without printing a line
+    e = dict(env, WORLD_SIZE="2", RANK="1", LOCAL_RANK="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True, env=e, cwd=ROOT, timeout=120)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+
+
+def test_more_ranks_than_gpus_over_rccl_is_an_error():
+    """backend nccl (= RCCL) is one rank per GPU: --gpus 2 on a node with fewer GPUs (this container has none) must not fall back
+    to ranks sharing a device and call it a 2-GPU figure; GA_BENCH_BACKEND=gloo is the explicit functional mode"""
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "GA_BENCH_EMU", "GA_BENCH_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=e, cwd=ROOT, timeout=300)
+    assert r.returncode != 0
+    d = _line(r.stdout)
+    assert d["value"] is None and d["n_gpus"] == 2 and "GPU(s)" in d["error"] and "GA_BENCH_BACKEND=gloo" in d["error"]
 
 
 @pytest.mark.parametrize("fault,where", [

@@ -1250,6 +1250,53 @@ def test_emu_groth16_two_callers_distinct_solutions(emu_ctx, c, precompute, logn
         pk.FreeGPUResources()
 
 
+def test_emu_groth16_second_caller_without_memory_queues_instead_of_failing(emu_ctx, monkeypatch, logn=7, rounds=3):
+    """precompute = 0 fills the HBM with tables beside ONE caller's scratch; a second concurrent ga_g16_prove caller is sent
+    to lanes 2/3, whose scratch may then not fit.  GA_FAULT_LANE2_NOMEM makes every scratch request of lanes 2/3 fail as if HBM were
+    exhausted: such a caller must give back what lanes 2/3 hold and queue for the device -- its proof is the right one, never an
+    error -- and be counted as queued, not as a lane-2 proof."""
+    import threading
+    from gnark_amd import synth
+    c = BN254
+    inst = synth.make_instance(emu_ctx, c.name, logn, 0x4E4F, nb_constraints=(1 << logn) - 3)
+    other = synth.make_instance(emu_ctx, c.name, logn, 0x4E50, nb_constraints=(1 << logn) - 3, want_dlogs=False)
+    sols, rs = [inst.solution, other.solution], [(inst.r, inst.s), (other.r, other.s)]
+    pk = inst.proving_key(emu_ctx, precompute=1)
+    try:
+        want = [groth16.Prove(pk, sol, inst.nb_public, r, s_).raw() for sol, (r, s_) in zip(sols, rs)]
+        monkeypatch.setenv("GA_FAULT_LANE2_NOMEM", "1")
+        groth16.Prove(pk, sols[0], inst.nb_public, *rs[0])             # (a lane-0 call reads the knobs)
+        bad, errs = [], []
+
+        def prover(tid):
+            try:
+                for k in range(rounds):
+                    j = (tid + k) % 2
+                    if not np.array_equal(groth16.Prove(pk, sols[j], inst.nb_public, rs[j][0], rs[j][1]).raw(), want[j]):
+                        bad.append((tid, k, j))
+            except Exception as e:   # noqa: BLE001 -- the point of the test: no caller may see GA_ERR_NOMEM
+                errs.append(repr(e))
+
+        before = emu_ctx.lane_stats()
+        th = [threading.Thread(target=prover, args=(t,)) for t in range(3)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        after = emu_ctx.lane_stats()
+        assert not errs, errs
+        assert not bad, bad
+        assert after["lanes23_proofs"] == before["lanes23_proofs"]          # nobody proved on lanes 2/3 ...
+        assert after["lanes23_scratch_bytes"] == 0                           # ... and what they held was given back
+        ran = sum(after[k] - before[k] for k in ("lanes01_proofs", "lanes23_proofs", "queued_proofs"))
+        assert ran == 3 * rounds, (before, after)                            # every call counted exactly once
+        monkeypatch.delenv("GA_FAULT_LANE2_NOMEM")
+        groth16.Prove(pk, sols[0], inst.nb_public, *rs[0])
+    finally:
+        monkeypatch.delenv("GA_FAULT_LANE2_NOMEM", raising=False)
+        pk.FreeGPUResources()
+
+
 @pytest.mark.parametrize("c,precompute", [(BN254, 1), (BLS12_381, -1)], ids=["bn254-tables", "bls12-381-no-tables"])
 def test_emu_groth16_split_schedule_and_late_free(emu_ctx, c, precompute, monkeypatch, logn=7):
     """A proof's H side (computeH, Z MSM, possibly K) runs on the partner lane from a helper thread (prove_partial): the proof must

@@ -42,6 +42,61 @@ def test_msm_pippenger_vs_naive_vs_python(c, group):
 
 
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_msm_fast_batch_affine_vs_python_and_simple(c):
+    """msm_fast.c (bench.py's CPU baseline: signed digits, batch-affine buckets, window x range tasks) against the big-integer
+    MSM, the simple Pippenger and the closed form [sum s_i k_i]G -- with every exceptional case of the AFFINE addition inside one
+    bucket list: equal points (tangent), P and -P (nothing left), infinity among the bases, zero and maximal scalars, and lists
+    that become empty in the middle of a chunk's tree."""
+    import numpy as np
+    rng = pyref.Xoshiro(91)
+    G, g = group_of(c, 0), gen_of(c, 0)
+    n = 40
+    pts = [G.mul(g, rng.next() & 0xFFFFF) for _ in range(n)]
+    sc = [rng.field(c.r) for _ in range(n)]
+    sc[0], sc[1], sc[2] = 0, 1, c.r - 1
+    pts[3] = None
+    pts[5] = pts[4]
+    sc[5] = sc[4]                       # the same point twice in the same bucket of every window: tangent
+    pts[7] = G.neg(pts[6])
+    sc[7] = sc[6]                       # P and -P in the same bucket of every window: they cancel
+    pts[9] = pts[8]
+    sc[9] = c.r - sc[8]                 # [s]P + [r - s]P = infinity through opposite digits
+    for k in range(10, 18):
+        pts[k], sc[k] = pts[10], 5      # eight copies in one bucket: three tangent rounds in a row
+    P, S = pts_to_arr(c, 0, pts), fr_to_arr(c, sc)
+    want = G.msm(pts, sc)
+    assert jac_to_affine_py(c, 0, oracle.msm(c.cid, 0, P, S)) == want
+    for force_c, force_splits, threads in ((0, 0, 1), (0, 0, 8), (3, 4, 8), (7, 1, 2), (16, 3, 3), (5, 40, 4)):
+        got = oracle.msm_fast(c.cid, P, S, nthreads=threads, force_c=force_c, force_splits=force_splits)
+        assert jac_to_affine_py(c, 0, got) == want, (force_c, force_splits, threads)
+    # everything cancels / nothing to add
+    assert jac_to_affine_py(c, 0, oracle.msm_fast(c.cid, P[6:8], S[6:8])) is None
+    assert jac_to_affine_py(c, 0, oracle.msm_fast(c.cid, P[:0], S[:0])) is None
+    # a few thousand points with known discrete logs: the closed form, canonical (non-Montgomery) scalars, ragged splits
+    m = 3001
+    ks = np.array([rng.next() >> 1 for _ in range(m)], dtype=np.uint64)
+    Pb = oracle.gen_bases(c.cid, 0, ks)
+    sc2 = [rng.field(c.r) for _ in range(m)]
+    e = sum(int(k) * s for k, s in zip(ks, sc2)) % c.r
+    want2 = G.mul(g, e)
+    S2 = fr_to_arr(c, sc2)
+    for threads, fs in ((1, 0), (5, 0), (8, 7)):
+        assert jac_to_affine_py(c, 0, oracle.msm_fast(c.cid, Pb, S2, nthreads=threads, force_splits=fs)) == want2
+    Sc = np.array([[(s >> (64 * i)) & (2**64 - 1) for i in range(4)] for s in sc2], dtype=np.uint64)
+    assert jac_to_affine_py(c, 0, oracle.msm_fast(c.cid, Pb, Sc, mont=False, nthreads=4)) == want2
+    # a boolean-like witness: 6000 operations on two buckets -- the conflict queue (4096) overflows into the Jacobian side sums
+    m3 = 6000
+    ks3 = np.array([rng.next() >> 1 for _ in range(m3)], dtype=np.uint64)
+    Pb3 = oracle.gen_bases(c.cid, 0, ks3)
+    sc3 = [1 + (i % 2) for i in range(m3)]
+    want3 = G.mul(g, sum(int(k) * s for k, s in zip(ks3, sc3)) % c.r)
+    for threads, fc in ((1, 0), (4, 16), (3, 5)):
+        assert jac_to_affine_py(c, 0, oracle.msm_fast(c.cid, Pb3, fr_to_arr(c, sc3), nthreads=threads, force_c=fc)) == want3
+    cbits, nwin, splits = oracle.msm_fast_plan(c.cid, 1 << 24, 64)
+    assert 12 <= cbits <= 16 and nwin * splits >= 64      # more cores than windows: the point range is split so that all work
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
 def test_fft_conventions(c):
     rng = pyref.Xoshiro(3)
     for logn in (0, 1, 4, 7):
