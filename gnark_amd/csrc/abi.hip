@@ -174,6 +174,7 @@ void Tunables::read_env() {
     put(g16_lanes, (int)num("GA_G16_LANES", 2));
     put64(g16_table_budget_pct, num("GA_G16_TABLE_BUDGET_PCT", 0));
     put(g16_split, (int)num("GA_G16_SPLIT", 1));
+    put(g16_batch_tables, (int)num("GA_G16_BATCH_TABLES", 1));
     put(ntt_coset_fold, (int)num("GA_NTT_COSET_FOLD", 1));
     put(ntt_wave_local, (int)num("GA_NTT_WAVE_LOCAL", 1));
     put(ntt_direct, (int)num("GA_NTT_DIRECT", 1));

@@ -167,6 +167,7 @@ struct Tunables {
     std::atomic<uint64_t> g16_table_budget_pct{0};    // 0 = from the free HBM; else the % of the five tables' bytes precompute = 0 may spend (tests)
     std::atomic<int> g16_lanes{2};
     std::atomic<int> g16_split{1};
+    std::atomic<int> g16_batch_tables{1};            // 1: the wire-indexed G1 tables of a proof (A, B1, K) in one pass of every MSM kernel
     std::atomic<int> ntt_coset_fold{1};
     std::atomic<int> ntt_wave_local{1};
     std::atomic<int> ntt_direct{1};
@@ -404,6 +405,9 @@ int msm_prepare_table_scalars(Ctx* ctx, const void* d_scalars, size_t n, bool sc
                               int win_lo = 0, int win_hi = -1);
 template <class C, int G>
 int msm_table_device_reuse(Ctx* ctx, const void* d_table, const MsmPrepared& P, void* h_sum);
+// the same over 2..4 tables of one shape in ONE pass of every kernel (msm.hip.h): h_sums[i] = the XYZZ sum over tables[i]
+template <class C, int G>
+int msm_table_device_reuse_multi(Ctx* ctx, const void* const* tables, int ntab, const MsmPrepared& P, void* h_sums);
 
 struct Domain;   // ntt.hip.h
 template <class C> int ntt_domain_new(Ctx* ctx, uint64_t n, Domain** out);

@@ -1184,11 +1184,47 @@ static int witness_msms(G16Pk* pk, const SlotLease& slot, uint64_t nb_public, Wi
             }
             return msm_table_device_reuse<C, GA_G1>(ctx, table, sh.prep_w, out);
         };
-        if (pk->share_a) GA_CHECK(shared_g1(pk->d_a, &ar));
+        // The wire-indexed G1 tables (A, B1 and -- when this lane gets it -- K) in ONE pass of the bucket kernel, the merge and the window
+        // reduction over the shared witness sort (msm_table_device_reuse_multi): one kernel tail, one reduction with k x the waves and
+        // one host synchronisation instead of k of each (prove.go:194,207,237: three MultiExp over the same wireValues).  A table the
+        // bucket kernel has found degenerate (a DummySetup key) keeps its own pass with the complete loop; GA_G16_BATCH_TABLES=0: round 5.
+        bool multi_a = false, multi_b = false;
+        if (sh.w_live && ctx->tun.g16_batch_tables.load(std::memory_order_relaxed)) {
+            const void* tabs[3];
+            XYZZ<F1>* dst[3];
+            int nt = 0;
+            auto want = [&](bool shared, const void* table, XYZZ<F1>* out) {
+                if (!shared || ctx->is_degenerate(table)) return false;
+                tabs[nt] = table;
+                dst[nt++] = out;
+                return true;
+            };
+            multi_a = want(pk->share_a, pk->d_a, &ar);
+            multi_b = want(pk->share_b, pk->d_b, &bs1);
+            const bool k_fits = pk->share_k && !ctx->is_degenerate(pk->d_k);
+            if (nt + (k_fits ? 1 : 0) >= 2) {
+                if (k_fits && sh.claim_k(current_lane())) {
+                    want(true, pk->d_k, o_k);
+                    *did_k = true;
+                }
+                if (nt >= 2) {
+                    XYZZ<F1> sums[3];
+                    GA_CHECK((msm_table_device_reuse_multi<C, GA_G1>(ctx, tabs, nt, sh.prep_w, sums)));
+                    for (int i = 0; i < nt; i++) *dst[i] = sums[i];
+                } else {   // (K went to the partner lane after all: one table left)
+                    GA_CHECK(shared_g1(tabs[0], dst[0]));
+                }
+            } else {
+                multi_a = multi_b = false;
+            }
+        }
+        if (multi_a) {
+        } else if (pk->share_a) GA_CHECK(shared_g1(pk->d_a, &ar));
         else if (pk->tab_a) GA_CHECK(g16_table_msm_g1<C>(pk, pk->d_a, d_wa, pk->len_a, pk->c_a, &prep, &prep_live, &ar));
         else GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_a, d_wa, pk->len_a, true, &ar, pk->win_index, pk->win_count)));
         prep_live = false;   // (whatever A left in `prep` is not wB's)
-        if (pk->share_b) GA_CHECK(shared_g1(pk->d_b, &bs1));
+        if (multi_b) {
+        } else if (pk->share_b) GA_CHECK(shared_g1(pk->d_b, &bs1));
         else if (pk->tab_b) GA_CHECK(g16_table_msm_g1<C>(pk, pk->d_b, d_wb, pk->len_b, pk->c_b, &prep, &prep_live, &bs1));
         else GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_b, d_wb, pk->len_b, true, &bs1, pk->win_index, pk->win_count)));
         if (pk->share_b2) {   // G2.B wire-indexed: the shared witness sort again
@@ -1210,7 +1246,7 @@ static int witness_msms(G16Pk* pk, const SlotLease& slot, uint64_t nb_public, Wi
     *o_ar = ar;
     *o_bs1 = bs1;
     *o_bs2 = bs2;
-    if (sh.claim_k(current_lane())) {
+    if (!*did_k && sh.claim_k(current_lane())) {
         GA_CHECK(k_msm<C>(pk, nb_public, sh, o_k));
         *did_k = true;
     }

@@ -825,9 +825,20 @@ __device__ __forceinline__ bool store_task29(const LdsAcc29<F>& A, bool have, XY
 
 // COMPLETE = false: the fast loop (exceptional additions make ZZ == 0 and flag the task); true: the same loop with the exceptional
 // cases handled in place -- used directly on tables that turned out degenerate (a DummySetup key: every base the same point).
+// Multi-table pass (the Groth16 witness MSMs A, B1, K: ONE scalar vector, k wire-indexed tables of the same shape): blockIdx.y is
+// the table; its sums live in the table's own slice of [k x nb bucket sums | k x max_tasks partial sums] and its flagged tasks in its
+// own redo lists.  A single-table launch is the case k = 1, y = 0 of the same arithmetic.
+struct MsmTables {
+    const uint32_t* t[4];
+    uint32_t k, nb, max_tasks;
+};
+__device__ __forceinline__ uint32_t msm_multi_dest(const MsmTables& mt, uint32_t dest) {
+    return dest < mt.nb ? dest + blockIdx.y * mt.nb : dest + (mt.k - 1) * mt.nb + blockIdx.y * mt.max_tasks;
+}
+
 template <class F, bool COMPLETE>
 __global__ void __launch_bounds__(Table29<F>::THREADS, Table29<F>::MIN_WAVES)
-msm_accumulate29_kernel(const uint32_t* __restrict__ table, const uint32_t* __restrict__ vals,
+msm_accumulate29_kernel(const MsmTables mt, const uint32_t* __restrict__ vals,
                         const uint32_t* __restrict__ task_start, const uint32_t* __restrict__ task_qkey_sorted,
                         const uint32_t* __restrict__ task_key_by_tid, const uint32_t* __restrict__ task_perm, uint32_t max_tasks, uint32_t seg,
                         const uint32_t* __restrict__ task_dest, XYZZ<F>* __restrict__ sums, uint32_t* __restrict__ redo_list,
@@ -846,40 +857,46 @@ msm_accumulate29_kernel(const uint32_t* __restrict__ table, const uint32_t* __re
     const uint32_t key = task_key_by_tid[tid];
     const uint32_t start = task_start[tid];
     LdsAcc29<F> A(lds + threadIdx.x);
-    const bool have = accumulate_task29<F, COMPLETE>(A, table, vals, start, start + (seg - key));
-    if (!store_task29<F>(A, have, &sums[task_dest[tid]])) redo_list[atomicAdd(redo_count, 1u)] = tid;   // redo it
+    const bool have = accumulate_task29<F, COMPLETE>(A, mt.t[blockIdx.y], vals, start, start + (seg - key));
+    if (!store_task29<F>(A, have, &sums[msm_multi_dest(mt, task_dest[tid])]))   // redo it
+        redo_list[(uint64_t)blockIdx.y * (mt.max_tasks + 2) + atomicAdd(redo_count + 2 * blockIdx.y, 1u)] = tid;
 }
 
 // second chance for the tasks the fast loop flagged: the complete lazy loop over the redo list (grid-stride); what even that
 // cannot finish (a base of order 2, never on these curves) goes to the exact kernel below through a second list
 template <class F>
 __global__ void __launch_bounds__(Table29<F>::THREADS, Table29<F>::MIN_WAVES)
-msm_accumulate29_retry_kernel(const uint32_t* __restrict__ table, const uint32_t* __restrict__ vals,
+msm_accumulate29_retry_kernel(const MsmTables mt, const uint32_t* __restrict__ vals,
                               const uint32_t* __restrict__ task_start, const uint32_t* __restrict__ task_key_by_tid, uint32_t seg,
                               const uint32_t* __restrict__ redo_list, const uint32_t* __restrict__ redo_count,
                               const uint32_t* __restrict__ task_dest, XYZZ<F>* __restrict__ sums, uint32_t* __restrict__ redo2_list,
                               uint32_t* __restrict__ redo2_count) {
     constexpr int NW = Lazy<F>::NW;
     __shared__ uint32_t lds[4 * NW * Table29<F>::THREADS];
-    const uint32_t nredo = *redo_count;
+    // (the lists and counters of table y: see msm_accumulate29_kernel)
+    redo_list += (uint64_t)blockIdx.y * (mt.max_tasks + 2);
+    redo2_list += (uint64_t)blockIdx.y * (mt.max_tasks + 2);
+    const uint32_t nredo = redo_count[2 * blockIdx.y];
     LdsAcc29<F> A(lds + threadIdx.x);
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nredo; r += gridDim.x * blockDim.x) {
         const uint32_t tid = redo_list[r];
         const uint32_t start = task_start[tid];
-        const bool have = accumulate_task29<F, true>(A, table, vals, start, start + (seg - task_key_by_tid[tid]));
-        if (!store_task29<F>(A, have, &sums[task_dest[tid]])) redo2_list[atomicAdd(redo2_count, 1u)] = tid;
+        const bool have = accumulate_task29<F, true>(A, mt.t[blockIdx.y], vals, start, start + (seg - task_key_by_tid[tid]));
+        if (!store_task29<F>(A, have, &sums[msm_multi_dest(mt, task_dest[tid])])) redo2_list[atomicAdd(redo2_count + 2 * blockIdx.y, 1u)] = tid;
     }
 }
 
 // exact re-run of the tasks the lazy kernel flagged (complete formulas; table points converted back to gnark's form)
 template <class F>
 __global__ void __launch_bounds__(64)
-msm_accumulate29_redo_kernel(const uint32_t* __restrict__ table, const uint32_t* __restrict__ vals,
+msm_accumulate29_redo_kernel(const MsmTables mt, const uint32_t* __restrict__ vals,
                              const uint32_t* __restrict__ task_start, const uint32_t* __restrict__ task_key_by_tid,
                              uint32_t seg, const uint32_t* __restrict__ redo_list, const uint32_t* __restrict__ redo_count,
                              const uint32_t* __restrict__ task_dest, XYZZ<F>* __restrict__ sums) {
     typedef typename Lazy<F>::T T;
-    const uint32_t nredo = *redo_count;
+    redo_list += (uint64_t)blockIdx.y * (mt.max_tasks + 2);
+    const uint32_t nredo = redo_count[2 * blockIdx.y];
+    const uint32_t* __restrict__ table = mt.t[blockIdx.y];
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nredo; r += gridDim.x * blockDim.x) {
         const uint32_t tid = redo_list[r];
         const uint32_t start = task_start[tid];
@@ -893,7 +910,7 @@ msm_accumulate29_redo_kernel(const uint32_t* __restrict__ table, const uint32_t*
             if (v & MSM_SIGN) q.y = neg(q.y);
             acc = madd(acc, q);
         }
-        store_pod(&sums[task_dest[tid]], acc);
+        store_pod(&sums[msm_multi_dest(mt, task_dest[tid])], acc);
     }
 }
 
@@ -1243,10 +1260,13 @@ __device__ __forceinline__ void block_sum29(uint32_t count, Src src, XYZZ<F>* ds
 template <class F>
 __global__ void __launch_bounds__(64)
 msm_hot_kernel(const XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__ task_off,
-               const uint32_t* __restrict__ hot_list, const uint32_t* __restrict__ hot_count, XYZZ<F>* __restrict__ bsum) {
+               const uint32_t* __restrict__ hot_list, const uint32_t* __restrict__ hot_count, XYZZ<F>* __restrict__ bsum,
+               uint32_t bsum_stride, uint32_t part_stride) {
     __shared__ LazyPt<F> sh[64];
     __shared__ XYZZ<F> shx[64];
     __shared__ uint32_t bad;
+    partial += (uint64_t)blockIdx.y * part_stride;   // (multi-table pass: table y's slices; the lists are the same for every table)
+    bsum += (uint64_t)blockIdx.y * bsum_stride;
     const uint32_t nh = *hot_count;
     for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
         const uint32_t b = hot_list[h];
@@ -1262,10 +1282,12 @@ msm_hot_kernel(const XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__
 template <class F>
 __global__ void __launch_bounds__(64)
 msm_vhot_stage1_kernel(const XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__ task_off, const uint32_t* __restrict__ vhot_list,
-                       const uint32_t* __restrict__ vhot_count, XYZZ<F>* __restrict__ vtmp) {
+                       const uint32_t* __restrict__ vhot_count, XYZZ<F>* __restrict__ vtmp, uint32_t part_stride, uint32_t vtmp_stride) {
     __shared__ LazyPt<F> sh[64];
     __shared__ XYZZ<F> shx[64];
     __shared__ uint32_t bad;
+    partial += (uint64_t)blockIdx.y * part_stride;
+    vtmp += (uint64_t)blockIdx.y * vtmp_stride;
     const uint32_t items = *vhot_count * MSM_VHOT_SPLIT;
     for (uint32_t id = blockIdx.x; id < items; id += gridDim.x) {
         const uint32_t h = id / MSM_VHOT_SPLIT, part = id % MSM_VHOT_SPLIT;
@@ -1280,11 +1302,13 @@ msm_vhot_stage1_kernel(const XYZZ<F>* __restrict__ partial, const uint32_t* __re
 template <class F>
 __global__ void __launch_bounds__(64)
 msm_vhot_stage2_kernel(const XYZZ<F>* __restrict__ vtmp, const uint32_t* __restrict__ vhot_list, const uint32_t* __restrict__ vhot_count,
-                       XYZZ<F>* __restrict__ bsum) {
+                       XYZZ<F>* __restrict__ bsum, uint32_t bsum_stride, uint32_t vtmp_stride) {
     static_assert(MSM_VHOT_SPLIT == 64, "one partial result per lane");
     __shared__ LazyPt<F> sh[64];
     __shared__ XYZZ<F> shx[64];
     __shared__ uint32_t bad;
+    vtmp += (uint64_t)blockIdx.y * vtmp_stride;
+    bsum += (uint64_t)blockIdx.y * bsum_stride;
     const uint32_t nv = *vhot_count;
     for (uint32_t h = blockIdx.x; h < nv; h += gridDim.x)
         block_sum29<F>(MSM_VHOT_SPLIT, [&](uint32_t i) { return &vtmp[h * MSM_VHOT_SPLIT + i]; }, &bsum[vhot_list[h]], sh, shx, &bad);
@@ -1296,18 +1320,21 @@ msm_vhot_stage2_kernel(const XYZZ<F>* __restrict__ vtmp, const uint32_t* __restr
 template <class F>
 __global__ void msm_merge_kernel(const XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__ task_off, uint32_t nb,
                                  XYZZ<F>* __restrict__ bsum, uint32_t* __restrict__ hot_list, uint32_t* __restrict__ hot_count,
-                                 uint32_t* __restrict__ vhot_list, uint32_t* __restrict__ vhot_count) {
+                                 uint32_t* __restrict__ vhot_list, uint32_t* __restrict__ vhot_count, uint32_t part_stride) {
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
+    // multi-table pass: table y's slices; which buckets are hot depends on the task list alone, so table 0's blocks write the lists
+    partial += (uint64_t)blockIdx.y * part_stride;
+    bsum += (uint64_t)blockIdx.y * nb;
     uint32_t t0 = task_off[b], t1 = task_off[b + 1];
     uint32_t nt = t1 - t0;
     if (nt == 1) return;   // its only task wrote bsum[b] directly (task_dest)
     if (nt > MSM_VHOT_TASKS) {
-        vhot_list[atomicAdd(vhot_count, 1u)] = b;
+        if (blockIdx.y == 0) vhot_list[atomicAdd(vhot_count, 1u)] = b;
         return;
     }
     if (nt > MSM_HOT_TASKS) {
-        hot_list[atomicAdd(hot_count, 1u)] = b;
+        if (blockIdx.y == 0) hot_list[atomicAdd(hot_count, 1u)] = b;
         return;
     }
     XYZZ<F> out = xyzz_inf<F>();
@@ -1557,10 +1584,20 @@ int msm_prepare(Ctx* ctx, const void* d_scalars, size_t n, bool scalars_mont, in
 // horner_c > 0 (raw bases, every window of the call): instead of the P.nsets window sums, out[0] receives their combination
 // sum_w 2^(horner_c * w) * set_w -- the window reduction's per-bit sums and the Horner step over the windows then share ONE chain of
 // doublings on the host (see the end of this function).
+//
+// ntab > 1 (table mode, ONE scalar vector, `tables` = ntab tables of the same shape as d_bases -- the wire-indexed A, B1, K of a Groth16
+// key): every kernel of the pipeline runs ONCE over all the tables -- the bucket kernel with the table as the grid's y dimension, the
+// merge the same way, the window reduction over ntab bucket sets as it does for a batch of scalar vectors -- and out[i] receives
+// table i's sum: one tail per kernel, one host synchronisation, ntab x the waves in the latency-bound reduction kernels.
 template <class F>
-int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, XYZZ<F>* out, int horner_c = 0) {
+int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, XYZZ<F>* out, int horner_c = 0, const void* const* tables = nullptr,
+                          int ntab = 1) {
     const uint32_t nb = P.nb, half = P.half, seg = P.seg;
-    const int nsets = P.nsets;
+    if (ntab < 1 || ntab > 4 || (ntab > 1 && (!tables || !P.table || P.nsets != 1 || horner_c != 0))) {
+        set_error("msm: a multi-table pass takes 2..4 precomputed tables over one prepared scalar vector (ntab=%d, table=%d, sets=%d)", ntab, (int)P.table, P.nsets);
+        return GA_ERR_INVALID;
+    }
+    const int nsets = ntab > 1 ? ntab : P.nsets;
     // buckets per running-sum group: MSM_GROUP when there are plenty of buckets, smaller (down to 2) when a set has few so
     // that the reduction still spreads over >= 2^15 lanes (small n, or table mode's single bucket set)
     const int tuned_group = ctx->tun.msm_group.load(std::memory_order_relaxed);
@@ -1578,10 +1615,12 @@ int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, X
     XYZZ<F>* vtmp;
     const uint64_t vhot_cap = P.max_tasks / MSM_VHOT_TASKS + 2;
     GA_CHECK(ctx->scratch_get("msm_vhot", vhot_cap * 4, (void**)&vhot_list));
-    GA_CHECK(ctx->scratch_get("msm_vhot_tmp", vhot_cap * MSM_VHOT_SPLIT * sizeof(XYZZ<F>), (void**)&vtmp));
-    // one array [nb bucket sums | max_tasks partial sums]: tasks write at task_dest (see msm_task_list_kernel)
-    GA_CHECK(ctx->scratch_get("msm_bsum_partial", ((uint64_t)nb + P.max_tasks) * sizeof(XYZZ<F>), (void**)&bsum));
-    partial = bsum + nb;
+    GA_CHECK(ctx->scratch_get("msm_vhot_tmp", (uint64_t)ntab * vhot_cap * MSM_VHOT_SPLIT * sizeof(XYZZ<F>), (void**)&vtmp));
+    // one array [nb bucket sums | max_tasks partial sums]: tasks write at task_dest (see msm_task_list_kernel); a multi-table pass:
+    // [ntab x nb | ntab x max_tasks], so that the bucket sums of the tables are the consecutive sets the reduction expects
+    GA_CHECK(ctx->scratch_get("msm_bsum_partial", (uint64_t)ntab * ((uint64_t)nb + P.max_tasks) * sizeof(XYZZ<F>), (void**)&bsum));
+    partial = bsum + (uint64_t)ntab * nb;
+    const uint32_t part_stride = (uint32_t)P.max_tasks, vtmp_stride = (uint32_t)(vhot_cap * MSM_VHOT_SPLIT);
     GA_CHECK(ctx->scratch_get("msm_gsum", (uint64_t)total_groups * sizeof(XYZZ<F>), (void**)&gsum));
     GA_CHECK(ctx->scratch_get("msm_gsum2", ((uint64_t)total_groups / 1024 + 64) * sizeof(XYZZ<F>), (void**)&gsum2));
     GA_CHECK(ctx->scratch_get("msm_wsum", (uint64_t)nsets * sizeof(XYZZ<F>), (void**)&wsum));
@@ -1608,10 +1647,10 @@ int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, X
     const uint32_t* acc_table = (const uint32_t*)d_bases;
     {
         uint32_t *redo_list, *redo_count, *redo2_list;
-        GA_CHECK(ctx->scratch_get("msm_redo", (P.max_tasks + 2) * 4, (void**)&redo_list));
-        GA_CHECK(ctx->scratch_get("msm_redo2", (P.max_tasks + 2) * 4, (void**)&redo2_list));
-        GA_CHECK(ctx->scratch_get("msm_redo_count", 256, (void**)&redo_count));   // [0] flagged by the first loop, [1] by the retry
-        GA_HIP_CHECK(hipMemsetAsync(redo_count, 0, 8, st));
+        GA_CHECK(ctx->scratch_get("msm_redo", (uint64_t)ntab * (P.max_tasks + 2) * 4, (void**)&redo_list));
+        GA_CHECK(ctx->scratch_get("msm_redo2", (uint64_t)ntab * (P.max_tasks + 2) * 4, (void**)&redo2_list));
+        GA_CHECK(ctx->scratch_get("msm_redo_count", 256, (void**)&redo_count));   // per table: [0] flagged by the first loop, [1] by the retry
+        GA_HIP_CHECK(hipMemsetAsync(redo_count, 0, 8 * ntab, st));
         StageTimer tm(ctx, "msm_accumulate");
         if (!P.table) {
             // raw (not precomputed) bases: one conversion pass to the packed hat-domain format (a one-window "table"), then the
@@ -1623,43 +1662,57 @@ int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, X
             acc_table = hat;
         }
         constexpr unsigned AT = Table29<F>::THREADS;
-        const dim3 grid((unsigned)((P.max_tasks + AT - 1) / AT));
-        if (P.table && !ctx->tun.msm_exact_redo && ctx->is_degenerate(d_bases))
-            hipLaunchKernelGGL((msm_accumulate29_kernel<F, true>), grid, dim3(AT), 0, st, acc_table, (const uint32_t*)P.vals,
+        const dim3 grid((unsigned)((P.max_tasks + AT - 1) / AT), (unsigned)ntab);
+        MsmTables mt;
+        mt.k = (uint32_t)ntab;
+        mt.nb = nb;
+        mt.max_tasks = (uint32_t)P.max_tasks;
+        for (int i = 0; i < 4; i++) mt.t[i] = ntab > 1 ? (const uint32_t*)tables[i < ntab ? i : 0] : acc_table;
+        // (a multi-table pass is only started on tables none of which is known as degenerate: groth16.hip witness_msms)
+        if (ntab == 1 && P.table && !ctx->tun.msm_exact_redo && ctx->is_degenerate(d_bases))
+            hipLaunchKernelGGL((msm_accumulate29_kernel<F, true>), grid, dim3(AT), 0, st, mt, (const uint32_t*)P.vals,
                                (const uint32_t*)P.task_start, (const uint32_t*)P.task_key, (const uint32_t*)P.task_key_by_id, (const uint32_t*)P.task_perm, (uint32_t)P.max_tasks, seg,
                                (const uint32_t*)P.task_dest, bsum, redo2_list, redo_count + 1);
         else
-            hipLaunchKernelGGL((msm_accumulate29_kernel<F, false>), grid, dim3(AT), 0, st, acc_table, (const uint32_t*)P.vals,
+            hipLaunchKernelGGL((msm_accumulate29_kernel<F, false>), grid, dim3(AT), 0, st, mt, (const uint32_t*)P.vals,
                                (const uint32_t*)P.task_start, (const uint32_t*)P.task_key, (const uint32_t*)P.task_key_by_id, (const uint32_t*)P.task_perm, (uint32_t)P.max_tasks, seg,
                                (const uint32_t*)P.task_dest, bsum, redo_list, redo_count);
         if (!ctx->tun.msm_exact_redo)   // (GA_MSM_EXACT_REDO=1: tests send the flagged tasks straight to the exact kernel below)
-            hipLaunchKernelGGL((msm_accumulate29_retry_kernel<F>), dim3(2048), dim3(AT), 0, st, acc_table, (const uint32_t*)P.vals,
+            hipLaunchKernelGGL((msm_accumulate29_retry_kernel<F>), dim3(2048, (unsigned)ntab), dim3(AT), 0, st, mt, (const uint32_t*)P.vals,
                                (const uint32_t*)P.task_start, (const uint32_t*)P.task_key_by_id, seg, (const uint32_t*)redo_list,
                                (const uint32_t*)redo_count, (const uint32_t*)P.task_dest, bsum, redo2_list, redo_count + 1);
         else
-            hipLaunchKernelGGL((msm_accumulate29_redo_kernel<F>), dim3(1024), dim3(64), 0, st, acc_table, (const uint32_t*)P.vals,
+            hipLaunchKernelGGL((msm_accumulate29_redo_kernel<F>), dim3(1024, (unsigned)ntab), dim3(64), 0, st, mt, (const uint32_t*)P.vals,
                                (const uint32_t*)P.task_start, (const uint32_t*)P.task_key_by_id, seg, (const uint32_t*)redo_list,
                                (const uint32_t*)redo_count, (const uint32_t*)P.task_dest, bsum);
-        hipLaunchKernelGGL((msm_accumulate29_redo_kernel<F>), dim3(1024), dim3(64), 0, st, acc_table, (const uint32_t*)P.vals,
+        hipLaunchKernelGGL((msm_accumulate29_redo_kernel<F>), dim3(1024, (unsigned)ntab), dim3(64), 0, st, mt, (const uint32_t*)P.vals,
                            (const uint32_t*)P.task_start, (const uint32_t*)P.task_key_by_id, seg, (const uint32_t*)redo2_list,
                            (const uint32_t*)(redo_count + 1), (const uint32_t*)P.task_dest, bsum);
         GA_KERNEL_CHECK();
-        GA_HIP_CHECK(hipMemcpyAsync(h_redo, redo_count, 4, hipMemcpyDeviceToHost, st));   // read after the stream's final sync below
+        // read after the stream's final sync below (per table: [2 i] = tasks the fast loop flagged; a stack fallback holds table 0's only)
+        GA_HIP_CHECK(hipMemcpyAsync(h_redo, redo_count, h_redo == &h_redo_stack ? 4 : 8 * (size_t)ntab, hipMemcpyDeviceToHost, st));
         redo_read.pending = true;
     }
     auto note_degenerate = [&]() {
-        if (P.table && (uint64_t)*h_redo * 4 > P.max_tasks) ctx->mark_degenerate(d_bases);
+        if (!P.table) return;
+        if (ntab == 1) {
+            if ((uint64_t)*h_redo * 4 > P.max_tasks) ctx->mark_degenerate(d_bases);
+        } else if (h_redo != &h_redo_stack) {
+            for (int i = 0; i < ntab; i++)
+                if ((uint64_t)h_redo[2 * i] * 4 > P.max_tasks) ctx->mark_degenerate(tables[i]);
+        }
     };
     {
         StageTimer tm(ctx, "msm_merge");
-        hipLaunchKernelGGL((msm_merge_kernel<F>), dim3((nb + 255) / 256), dim3(256), 0, st, (const XYZZ<F>*)partial,
-                           (const uint32_t*)P.task_off, nb, bsum, hot_list, hot_count, vhot_list, hot_count + 1);
-        hipLaunchKernelGGL((msm_hot_kernel<F>), dim3(512), dim3(64), 0, st, (const XYZZ<F>*)partial, (const uint32_t*)P.task_off,
-                           (const uint32_t*)hot_list, (const uint32_t*)hot_count, bsum);
-        hipLaunchKernelGGL((msm_vhot_stage1_kernel<F>), dim3(2048), dim3(64), 0, st, (const XYZZ<F>*)partial, (const uint32_t*)P.task_off,
-                           (const uint32_t*)vhot_list, (const uint32_t*)(hot_count + 1), vtmp);
-        hipLaunchKernelGGL((msm_vhot_stage2_kernel<F>), dim3(256), dim3(64), 0, st, (const XYZZ<F>*)vtmp, (const uint32_t*)vhot_list,
-                           (const uint32_t*)(hot_count + 1), bsum);
+        const unsigned ny = (unsigned)ntab;
+        hipLaunchKernelGGL((msm_merge_kernel<F>), dim3((nb + 255) / 256, ny), dim3(256), 0, st, (const XYZZ<F>*)partial,
+                           (const uint32_t*)P.task_off, nb, bsum, hot_list, hot_count, vhot_list, hot_count + 1, part_stride);
+        hipLaunchKernelGGL((msm_hot_kernel<F>), dim3(512, ny), dim3(64), 0, st, (const XYZZ<F>*)partial, (const uint32_t*)P.task_off,
+                           (const uint32_t*)hot_list, (const uint32_t*)hot_count, bsum, nb, part_stride);
+        hipLaunchKernelGGL((msm_vhot_stage1_kernel<F>), dim3(2048, ny), dim3(64), 0, st, (const XYZZ<F>*)partial, (const uint32_t*)P.task_off,
+                           (const uint32_t*)vhot_list, (const uint32_t*)(hot_count + 1), vtmp, part_stride, vtmp_stride);
+        hipLaunchKernelGGL((msm_vhot_stage2_kernel<F>), dim3(256, ny), dim3(64), 0, st, (const XYZZ<F>*)vtmp, (const uint32_t*)vhot_list,
+                           (const uint32_t*)(hot_count + 1), bsum, nb, vtmp_stride);
         GA_KERNEL_CHECK();
     }
     // Window reduction.  Large bucket sets: lazy per-group pass without the per-lane scalar multiplication,
@@ -1676,7 +1729,8 @@ int msm_accumulate_reduce(Ctx* ctx, const void* d_bases, const MsmPrepared& P, X
     // device at this point, so the verdict comes from the previous call on the same table: when the lazy pass flagged more than a
     // quarter of the groups, the set is remembered as sparse and small sets take the exact kernel again.
     const bool big_set = (uint64_t)half * nsets >= ctx->tun.reduce_lazy_min;
-    const bool dense_set = P.m >= 16ull * (uint64_t)half * (uint64_t)nsets && !(P.table && ctx->is_sparse_set(d_bases));
+    // (P.m and half describe ONE table's pairs and buckets; the tables of a multi-table pass share the scalar vector, hence the verdict)
+    const bool dense_set = P.m >= 16ull * (uint64_t)half * (uint64_t)P.nsets && !(P.table && ctx->is_sparse_set(d_bases));
     const bool lazy_reduce = big_set || dense_set;
     if (!lazy_reduce) {
         StageTimer tm(ctx, "msm_reduce");
@@ -1836,6 +1890,14 @@ template <class C, int G>
 int msm_table_device_reuse(Ctx* ctx, const void* d_table, const MsmPrepared& P, void* h_sum) {
     typedef typename GroupField<C, G>::F F;
     return msm_accumulate_reduce<F>(ctx, d_table, P, reinterpret_cast<XYZZ<F>*>(h_sum));
+}
+
+// ... and for SEVERAL tables of that shape in one pass (the wire-indexed G1.A, G1.B, G1.K of a Groth16 key over the one witness sort,
+// prove.go:194,207,237): h_sums[i] = the MSM over tables[i].  2 <= ntab <= 4.
+template <class C, int G>
+int msm_table_device_reuse_multi(Ctx* ctx, const void* const* tables, int ntab, const MsmPrepared& P, void* h_sums) {
+    typedef typename GroupField<C, G>::F F;
+    return msm_accumulate_reduce<F>(ctx, tables[0], P, reinterpret_cast<XYZZ<F>*>(h_sums), 0, tables, ntab);
 }
 
 // group-independent preparation callable from translation units that do not include this header (groth16.hip)

@@ -1250,6 +1250,73 @@ def test_emu_groth16_two_callers_distinct_solutions(emu_ctx, c, precompute, logn
         pk.FreeGPUResources()
 
 
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_emu_groth16_batched_witness_tables(emu_ctx, c, monkeypatch, logn=7):
+    """The wire-indexed G1 tables A, B1, K go through ONE pass of the bucket kernel / merge / window reduction over the shared
+    witness sort (msm_table_device_reuse_multi; prove.go:194,207,237 are three MultiExp over the same wireValues): proof points equal
+    to the C oracle's prover and to the one-pass-per-table schedule (GA_G16_BATCH_TABLES=0) -- on a key with REPEATED and OPPOSITE
+    bases inside A, B and K, so that each table flags its own tasks in the pass (per-table redo lists) --, with a 0/1-heavy witness
+    (one very hot bucket: the merge's hot lists are shared by the tables), and on a DummySetup-like key (every base of a table the
+    same point): the first proof marks the tables degenerate inside the batched pass, the second one takes them out of it."""
+    ctx, lib = emu_ctx, emu_ctx.lib
+    n = 1 << logn
+    nw, nb_public = n, 3
+
+    def gen(group, count, seed):
+        buf = ctx.malloc(count * affine_words(c.cid, group) * 8)
+        lib.check(lib.ga_gen_bases(ctx.handle, c.cid, group, seed, count, buf.ptr, None))
+        h = buf.to_host((count, affine_words(c.cid, group)))
+        buf.free()
+        return h
+
+    def scal(count, seed):
+        buf = ctx.malloc(count * 32)
+        lib.check(lib.ga_gen_scalars(ctx.handle, c.cid, seed, count, buf.ptr))
+        h = buf.to_host((count, 4))
+        buf.free()
+        return h
+
+    def neg_y(pt):   # -P of a G1 affine image (Montgomery limbs): y -> p - y
+        fp = c.fp_limbs
+        y = sum(int(v) << (64 * i) for i, v in enumerate(pt[fp:]))
+        q = pt.copy()
+        q[fp:] = [((c.p - y) >> (64 * i)) & (2**64 - 1) for i in range(fp)]
+        return q
+    infA, infB = np.zeros(nw, np.uint8), np.zeros(nw, np.uint8)
+    infA[[2, nw - 1]] = 1
+    infB[[4]] = 1
+    m1, m2 = gen(0, 3, 21), gen(1, 2, 22)
+    A, B, K = gen(0, nw - 2, 23), gen(0, nw - 1, 24), gen(0, nw - nb_public, 25)
+    for V in (A, B, K):   # runs of equal points and a P, -P pair: wires with equal scalars below make them meet in one bucket
+        V[10:20] = V[10]
+        V[31] = neg_y(V[30])
+    key = dict(n=n, alpha1=m1[0:1], beta1=m1[1:2], delta1=m1[2:3], A=A, B=B, Z=gen(0, n - 1, 26), K=K, beta2=m2[0:1], delta2=m2[1:2],
+               B2=gen(1, nw - 1, 27), infinityA=infA, infinityB=infB)
+    m = n - 5
+    W, Av, Bv = scal(nw, 30), scal(m, 31), scal(m, 32)
+    W[8:40] = W[8]                       # equal scalars over the equal / opposite bases
+    Cc = oracle.fr_mul(c.cid, Av, Bv)
+    rs = scal(2, 33)
+    one = fr_to_arr(c, [1])[0]
+    W01 = W.copy()
+    W01[nw // 4:] = one                  # a boolean-heavy witness: the digit-1 bucket of window 0 holds most of the wires
+    W01[nw // 2:] = 0
+    dummy = dict(key, A=np.repeat(A[:1], nw - 2, axis=0), B=np.repeat(B[:1], nw - 1, axis=0), K=np.repeat(K[:1], nw - nb_public, axis=0))
+    for name, kd, wit, rounds in (("exceptional", key, W, 1), ("boolean", key, W01, 1), ("dummy", dummy, W, 3)):
+        want = oracle.groth16_prove(c.cid, kd, wit, Av, Bv, Cc, nb_public, rs[0], rs[1], nthreads=8)
+        pk = groth16.ProvingKey(ctx, c.name, domain_cardinality=n, precompute=1, **{k: v for k, v in kd.items() if k != "n"})
+        try:
+            lay = groth16.ShardLayout(pk)
+            assert lay["wire_indexed"]["A"] and lay["wire_indexed"]["B"] and lay["wire_indexed"]["K"], lay
+            for batched in ["1"] * rounds + ["0"]:
+                monkeypatch.setenv("GA_G16_BATCH_TABLES", batched)
+                proof = groth16.Prove(pk, groth16.Solution(wit, Av, Bv, Cc), nb_public, rs[0], rs[1])
+                assert np.array_equal(proof.Ar, want[0]) and np.array_equal(proof.Bs, want[1]) and np.array_equal(proof.Krs, want[2]), (name, batched)
+        finally:
+            monkeypatch.delenv("GA_G16_BATCH_TABLES", raising=False)
+            pk.FreeGPUResources()
+
+
 def test_emu_groth16_second_caller_without_memory_queues_instead_of_failing(emu_ctx, monkeypatch, logn=7, rounds=3):
     """precompute = 0 fills the HBM with tables beside ONE caller's scratch; a second concurrent ga_g16_prove caller is sent
     to lanes 2/3, whose scratch may then not fit.  GA_FAULT_LANE2_NOMEM makes every scratch request of lanes 2/3 fail as if HBM were

@@ -60,6 +60,19 @@ def test_msm_empty_and_single(gpu_ctx):
     cases.test_emu_msm_empty_and_single(gpu_ctx)
 
 
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_groth16_batched_witness_tables_2_12(gpu_ctx, c, monkeypatch):
+    """round 6: A, B1, K in ONE pass of the bucket kernel / merge / reduction (msm_table_device_reuse_multi) vs the C oracle's prover
+    and vs one pass per table -- exceptional additions inside every table, a boolean-heavy witness, a DummySetup-like key"""
+    cases.test_emu_groth16_batched_witness_tables(gpu_ctx, c, monkeypatch, logn=12)
+
+
+def test_groth16_second_caller_without_memory_queues(gpu_ctx, monkeypatch):
+    """a second concurrent ga_g16_prove caller whose lanes 2/3 cannot allocate (GA_FAULT_LANE2_NOMEM) gives their scratch back and
+    queues for the device: right proofs, no error"""
+    cases.test_emu_groth16_second_caller_without_memory_queues_instead_of_failing(gpu_ctx, monkeypatch, logn=14, rounds=4)
+
+
 @pytest.mark.parametrize("precompute", [1, -1, "shared-sort"], ids=["tables", "no-tables", "tables-shared-sort"])
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
 def test_groth16_cubic_bytes(gpu_ctx, c, precompute):

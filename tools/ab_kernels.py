@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--tag", default="")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--proofs", type=int, default=5)
+    ap.add_argument("--knob", default="", help="g16ab: NAME=v1,v2[,v3]: a run-time knob of the library toggled IN this process, the settings interleaved round by round")
+    ap.add_argument("--rounds", type=int, default=3)
     args = ap.parse_args()
     import gnark_amd
     from gnark_amd import _lib, ecc, fft
@@ -170,6 +172,62 @@ def main():
         os.environ.pop("GA_G16_SPLIT", None)
         pk.FreeGPUResources()
         out["g16"] = res
+    if "g16ab" in parts:
+        # one pinned key, one process, one box: the settings of a run-time knob interleaved (A B A B ...), so that drift and box spread
+        # cancel; per setting the one-caller and two-caller proof times of every round, the proof hash, and the stage table of a
+        # profiled (single-lane) proof
+        from gnark_amd import groth16, synth
+        name, vals = args.knob.split("=")
+        vals = vals.split(",")
+        inst = synth.make_instance(ctx, cid, args.log_n, 0x5EED0005, want_dlogs=False)
+        pk = inst.proving_key(ctx, precompute=1)
+        sol, nbp, r, s = inst.solution, inst.nb_public, inst.r, inst.s
+        res = {v: {"one_caller_ms": [], "two_callers_ms": []} for v in vals}
+
+        def run_pair(count):
+            def prover():
+                for _ in range(count):
+                    groth16.Prove(pk, sol, nbp, r, s)
+            th = [threading.Thread(target=prover) for _ in range(2)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            ctx.sync()
+        for v in vals:   # warm both lane pairs under every setting (scratch sizes differ)
+            os.environ[name] = v
+            for _ in range(2):
+                groth16.Prove(pk, sol, nbp, r, s)
+            run_pair(2)
+        for rnd in range(args.rounds):
+            for v in vals:
+                os.environ[name] = v
+                groth16.Prove(pk, sol, nbp, r, s)   # (a lane-0 call reads the knobs)
+                ctx.sync()
+                t0 = time.perf_counter()
+                for _ in range(args.proofs):
+                    proof = groth16.Prove(pk, sol, nbp, r, s)
+                ctx.sync()
+                res[v]["one_caller_ms"].append(round((time.perf_counter() - t0) * 1e3 / args.proofs, 2))
+                res[v]["sha"] = sha(proof.raw())
+                t0 = time.perf_counter()
+                run_pair(args.proofs)
+                res[v]["two_callers_ms"].append(round((time.perf_counter() - t0) * 1e3 / (2 * args.proofs), 2))
+        for v in vals:
+            os.environ[name] = v
+            groth16.Prove(pk, sol, nbp, r, s)
+            ctx.profile(True)
+            ctx.profile_reset()
+            for _ in range(2):
+                groth16.Prove(pk, sol, nbp, r, s)
+            ctx.sync()
+            res[v]["stages_ms_per_proof"] = {k: round(x["total_ms"] / 2, 3) for k, x in stage_avg(ctx.profile_read()).items()}
+            ctx.profile(False)
+            res[v]["one_caller_best_ms"] = min(res[v]["one_caller_ms"])
+            res[v]["two_callers_best_ms"] = min(res[v]["two_callers_ms"])
+        os.environ.pop(name, None)
+        pk.FreeGPUResources()
+        out["g16ab"] = {"knob": name, "settings": res}
     print(json.dumps(out))
     ctx.close()
 

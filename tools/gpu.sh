@@ -16,6 +16,8 @@
 #                                    (run-time knobs from the environment) -> ${TAG}_ab_<name>.json
 #   abenv:<name>:<parts>:<curve>:<K=V,K=V,...>   the same with run-time knobs set for that one run ("-" = none): same-box A/B of a knob
 #                                    (appends to ${TAG}_abenv.txt, one JSON line per run)
+#   g16ab:<name>:<KNOB=v1,v2>[:<curve>[:<log-n>]]   same-box, same-process A/B of a run-time knob on one pinned Groth16 key (settings
+#                                    interleaved; one- and two-caller proof times per round + the profiled stage table) -> ${TAG}_g16ab_<name>.json
 #   plonk                            tools/bench_plonk_kernels.py (config 5 kernel work) -> ${TAG}_bench_plonk.json
 #   clock                            tools/clock_probe.py: shader clock / power held under each kernel family -> ${TAG}_clock_probe.json
 #   small:<log-n>                    tools/msm_small_trace.py: stage profile of a raw and a table MSM of 2^<log-n> points
@@ -112,6 +114,10 @@ for step in "$@"; do
       envs=""; [ -n "$kv" ] && [ "$kv" != "-" ] && envs=${kv//,/ }
       env $envs timeout 1200 python tools/ab_kernels.py --parts $parts --curve ${curve:-bn254} --tag "$nm" >> $OUT/${TAG}_abenv.txt 2>> $OUT/${TAG}_abenv.err
       tail -1 $OUT/${TAG}_abenv.txt | cut -c1-900 ;;
+    g16ab)   # g16ab:<name>:<KNOB=v1,v2>[:<curve>[:<log-n>]]  one key, one process: the knob's settings interleaved round by round
+      IFS=: read -r nm knob curve logn <<< "$arg"
+      timeout 1500 python tools/ab_kernels.py --parts g16ab --knob "$knob" --curve ${curve:-bn254} --log-n ${logn:-24} --tag "$nm" > $OUT/${TAG}_g16ab_${nm}.json 2> $OUT/${TAG}_g16ab_${nm}.err
+      tail -2 $OUT/${TAG}_g16ab_${nm}.err; cut -c1-2500 $OUT/${TAG}_g16ab_${nm}.json ;;
     plonk)
       timeout 900 python tools/bench_plonk_kernels.py > $OUT/${TAG}_bench_plonk.json 2> $OUT/${TAG}_bench_plonk.err
       cut -c1-1200 $OUT/${TAG}_bench_plonk.json ;;
