@@ -586,13 +586,17 @@ def groth16_single_gpu_leg(R, cid, curve_name):
     pk = with_retry(lambda: inst.proving_key(ctx, precompute=pre), "pinning the proving key")
     sol, nb_public, r, s = inst.solution, inst.nb_public, inst.r, inst.s
     setup_s = time.perf_counter() - t_setup
-    for _ in range(2):   # warm-up: scratch of both lanes of the pair (witness MSMs on lane 0, H side on lane 1)
+    warm = int(os.environ.get("GA_BENCH_G16_WARMUP", "2"))
+    for _ in range(warm):   # warm-up: scratch of both lanes of the pair (witness MSMs on lane 0, H side on lane 1)
         groth16.Prove(pk, sol, nb_public, r, s)
     ctx.sync()
     lanes0 = ctx.lane_stats()
     t0 = time.perf_counter()
+    each = []
     for _ in range(proofs):
+        q0 = time.perf_counter()
         proof = groth16.Prove(pk, sol, nb_public, r, s)
+        each.append(round((time.perf_counter() - q0) * 1e3, 2))
     ctx.sync()
     el = time.perf_counter() - t0
     lanes1 = ctx.lane_stats()
@@ -664,7 +668,7 @@ def groth16_single_gpu_leg(R, cid, curve_name):
     ntt_ms = sum(v["total_ms"] for k, v in gst.items() if k.startswith("ntt_") or k == "h_pointwise") / prof_proofs
     bytes_per_constraint = 992 if cid == 0 else 1184   # 4 G1 + 1 G2 MSM + 7 NTTs
     g = {"curve": curve_name, "proofs_per_s": round(proofs / el, 4), "ms_per_proof": round(el * 1e3 / proofs, 2),
-         "proofs": proofs, "constraints": n, "key_setup_s": round(setup_s, 1),
+         "proofs": proofs, "constraints": n, "key_setup_s": round(setup_s, 1), "ms_each": each,
          "schedule": {"split_proofs": lanes1["split_proofs"] - lanes0["split_proofs"],
                       "how": "one caller: witness MSMs (A, B1, B2) on lane 0, uploads of A,B,C + computeH + Z MSM on lane 1 from a helper thread, K MSM on whichever lane is free first (GA_G16_SPLIT=0: everything on lane 0)"},
          "ms_per_proof_profiled_single_lane": round(el_prof * 1e3 / prof_proofs, 2),
@@ -1264,6 +1268,13 @@ def main():
         sys.exit(2)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
+    # This SCRIPT's cyclic garbage collector stays out of the timed regions: with the 15 GB of numpy arrays a 2^24 instance and its
+    # discrete logs hold, one generation-2 collection landed inside a timed proof and cost it 35 ms (130 -> 165 ms, one proof in
+    # five: profiles/r06_d_gc_hiccup.txt).  Reference counting still frees everything the legs drop; GA_BENCH_GC=1 leaves it on.
+    if os.environ.get("GA_BENCH_GC", "0") == "0":
+        import gc
+        gc.collect()
+        gc.disable()
     R = Run(args)
     from gnark_amd.device import curve_id
     cid = curve_id(args.curve)
