@@ -11,6 +11,7 @@
 #include <new>
 #include <stdexcept>
 #include <string>
+#include <chrono>
 #include <thread>
 
 #include "hostops.hip.h"
@@ -99,6 +100,16 @@ struct PkUse {
         return GA_ERR_STATE;                                                     \
     }
 
+// GA_TRACE_PIN=1: milestones of a key's way to the device on stderr (ms since the first mark of the calling thread) -- tools/exp
+struct PinTrace {
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    PinTrace() : on(getenv("GA_TRACE_PIN") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    void mark(const char* what) const {
+        if (on) fprintf(stderr, "[pin] %8.2f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what);
+    }
+};
+
 static int upload(Ctx* ctx, const void* src, size_t bytes, void** dst) {
     *dst = nullptr;
     hipError_t e = device_malloc(dst, bytes ? bytes : 16);
@@ -146,11 +157,48 @@ struct G16Stage {
     } v[GA_KEY_NB_VECTORS];
     std::vector<uint8_t> inf[2];                 // InfinityA, InfinityB (Go []bool images)
     bool have_inf[2] = {false, false};
+    // the wire ids each mask keeps, ascending (the gather lists of prove.go:147-168): built by a helper thread as soon as a mask is
+    // set -- beside the uploads of the vectors, which keep the calling thread busy for 19 ms per GiB -- and joined by stage_finish
+    struct WireList {
+        std::unique_ptr<uint32_t[]> ids;
+        uint64_t size = 0;
+        std::thread job;
+    } lists[2];
+    void start_list(int which) {
+        WireList& L = lists[which];
+        if (L.job.joinable()) L.job.join();
+        L.ids.reset(new uint32_t[inf[which].size() + 8]);   // (uninitialised on purpose: 64 MiB at 2^24 wires)
+        L.size = 0;
+        const uint8_t* m = inf[which].data();
+        const uint64_t nw = inf[which].size();
+        uint32_t* out = L.ids.get();
+        uint64_t* size = &L.size;
+        L.job = std::thread([m, nw, out, size]() {
+            uint32_t* p = out;
+            uint64_t i = 0;
+            for (; i + 8 <= nw; i += 8) {   // masks are zero almost everywhere: eight wires per test
+                uint64_t w;
+                memcpy(&w, m + i, 8);
+                if (w == 0) {
+                    for (int k = 0; k < 8; k++) p[k] = (uint32_t)(i + k);
+                    p += 8;
+                } else {
+                    for (int k = 0; k < 8; k++)
+                        if (!m[i + k]) *p++ = (uint32_t)(i + k);
+                }
+            }
+            for (; i < nw; i++)
+                if (!m[i]) *p++ = (uint32_t)i;
+            *size = (uint64_t)(p - out);
+        });
+    }
     std::vector<uint8_t> pts[GA_KEY_NB_POINTS];  // alpha1, beta1, delta1, beta2, delta2
     std::vector<void*> d_ck_basis, d_ck_sigma;
     std::vector<uint64_t> ck_len;
     std::vector<uint64_t> k_remove;
     ~G16Stage() {
+        for (auto& L : lists)
+            if (L.job.joinable()) L.job.join();
         for (auto& x : v) hipFree(x.d);
         for (void* p : d_ck_basis) hipFree(p);
         for (void* p : d_ck_sigma) hipFree(p);
@@ -258,14 +306,13 @@ static int stage_finish(G16Stage* st, int precompute, G16Pk** out) {
                   st->win_index, st->win_count);
         return GA_ERR_INVALID;
     }
-    std::vector<uint32_t> ia, ib;
-    ia.reserve(len_a);
-    ib.reserve(len_b);
-    for (uint64_t i = 0; i < st->nb_wires; i++) {
-        if (!st->inf[0][i]) ia.push_back((uint32_t)i);
-        if (!st->inf[1][i]) ib.push_back((uint32_t)i);
+    PinTrace tr;
+    for (int k = 0; k < 2; k++) {
+        if (!st->lists[k].job.joinable()) st->start_list(k);   // (a caller that set the mask through a path without the early start)
+        st->lists[k].job.join();
     }
-    if (ia.size() != len_a || ib.size() != len_b || len_b2 != len_b) {
+    const uint32_t *ia = st->lists[0].ids.get(), *ib = st->lists[1].ids.get();
+    if (st->lists[0].size != len_a || st->lists[1].size != len_b || len_b2 != len_b) {
         set_error("proving key: InfinityA/B masks disagree with len(A)/len(B), or len(G2.B) != len(G1.B)");
         return GA_ERR_INVALID;
     }
@@ -294,7 +341,7 @@ static int stage_finish(G16Stage* st, int precompute, G16Pk** out) {
     pk->full_len_k = len_k;
     {   // wire range of this shard: the sorted gather lists are sliced contiguously, so min/max are the slice ends
         uint64_t lo = st->nb_wires, hi = 0;
-        auto span = [&](const std::vector<uint32_t>& v, uint64_t off, uint64_t cnt) {
+        auto span = [&](const uint32_t* v, uint64_t off, uint64_t cnt) {
             if (cnt == 0) return;
             lo = lo < v[off] ? lo : v[off];
             hi = hi > (uint64_t)v[off + cnt - 1] + 1 ? hi : (uint64_t)v[off + cnt - 1] + 1;
@@ -304,9 +351,11 @@ static int stage_finish(G16Stage* st, int precompute, G16Pk** out) {
         pk->w_lo = st->shard_count == 1 ? 0 : lo;
         pk->w_hi = st->shard_count == 1 ? st->nb_wires : hi;
     }
+    tr.mark("finish: gather lists built on the host");
     int rc = ntt_domain_new<C>(ctx, pk->n, &pk->dom);
-    if (rc == GA_OK) rc = upload(ctx, ia.data() + lo_a, pk->len_a * 4, (void**)&pk->d_idx_a);
-    if (rc == GA_OK) rc = upload(ctx, ib.data() + lo_b, pk->len_b * 4, (void**)&pk->d_idx_b);
+    tr.mark("finish: ntt_domain_new returned");
+    if (rc == GA_OK) rc = upload(ctx, ia + lo_a, pk->len_a * 4, (void**)&pk->d_idx_a);
+    if (rc == GA_OK) rc = upload(ctx, ib + lo_b, pk->len_b * 4, (void**)&pk->d_idx_b);
     // K filter with commitments: wireValues[nbPublic:] minus the private committed and commitment wires (prove.go:231-235)
     std::vector<uint32_t> ik;
     pk->len_k_remove = st->k_remove.size();
@@ -344,6 +393,7 @@ static int stage_finish(G16Stage* st, int precompute, G16Pk** out) {
         set_error("proving key upload: stream synchronize failed");
         rc = GA_ERR_HIP;
     }
+    tr.mark("finish: gather lists uploaded, stream drained");
     // ---- optional precomputation: [2^(c*w)]P for every window (one shared bucket set per MSM afterwards) ----------
     if (rc == GA_OK && precompute >= 0) {
         int nw = 0;
@@ -546,6 +596,7 @@ static int pk_create_from_struct(Ctx* ctx, const ga_g16_key* key, G16Pk** out) {
         set_error("proving key: k_remove missing");
         return GA_ERR_INVALID;
     }
+    PinTrace tr;
     G16Stage st;
     st.ctx = ctx;
     st.curve = key->curve;
@@ -559,22 +610,29 @@ static int pk_create_from_struct(Ctx* ctx, const ga_g16_key* key, G16Pk** out) {
     }
     st.win_count = key->window_shard_count ? key->window_shard_count : 1;
     st.win_index = key->window_shard_index;
+    // the masks first: their gather lists are built by helper threads while this thread is busy with the 6-9 GiB of uploads below
+    st.inf[0].assign(key->infinity_a, key->infinity_a + key->nb_wires);
+    st.inf[1].assign(key->infinity_b, key->infinity_b + key->nb_wires);
+    st.have_inf[0] = st.have_inf[1] = true;
+    st.start_list(0);
+    st.start_list(1);
     const void* vec[GA_KEY_NB_VECTORS] = {key->g1_a, key->g1_b, key->g1_z, key->g1_k, key->g2_b};
     const uint64_t len[GA_KEY_NB_VECTORS] = {key->len_a, key->len_b, key->len_z, key->len_k, key->len_b2};
     for (int w = 0; w < GA_KEY_NB_VECTORS; w++) {
         GA_CHECK(stage_reserve(&st, w, len[w]));
         GA_CHECK(stage_append(&st, w, vec[w], len[w], /*pinned=*/true));   // one drain below instead of five
+        tr.mark("vector reserved + appended");
     }
     GA_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    tr.mark("uploads drained");
     const void* pt[GA_KEY_NB_POINTS] = {key->g1_alpha, key->g1_beta, key->g1_delta, key->g2_beta, key->g2_delta};
     for (int q = 0; q < GA_KEY_NB_POINTS; q++) GA_CHECK(stage_set_point(&st, q, pt[q]));
-    st.inf[0].assign(key->infinity_a, key->infinity_a + key->nb_wires);
-    st.inf[1].assign(key->infinity_b, key->infinity_b + key->nb_wires);
-    st.have_inf[0] = st.have_inf[1] = true;
     for (uint32_t i = 0; i < key->nb_commitments; i++) GA_CHECK(stage_add_commitment_key(&st, key->ck_basis[i], key->ck_basis_exp_sigma[i], key->ck_len[i]));
     if (key->len_k_remove) st.k_remove.assign(key->k_remove, key->k_remove + key->len_k_remove);
+    tr.mark("points, infinity masks, commitment keys staged");
     G16Pk* pk = nullptr;
     GA_DISPATCH_CURVE(key->curve, GA_CHECK(stage_finish<C>(&st, key->precompute, &pk)));
+    tr.mark("stage_finish");
     *out = pk;
     return GA_OK;
 }
@@ -1970,8 +2028,10 @@ int ga_g16_builder_set_infinity(ga_g16_builder* b, int which, const uint8_t* mas
         set_error("ga_g16_builder_set_infinity: which must be 0/1 and the mask must have nbWires = %llu entries", (unsigned long long)st->nb_wires);
         return GA_ERR_INVALID;
     }
+    if (st->lists[which].job.joinable()) st->lists[which].job.join();   // (a mask set twice: the list of the old one must not outlive it)
     st->inf[which].assign(mask, mask + nb_wires);
     st->have_inf[which] = true;
+    st->start_list(which);   // (beside whatever the caller appends next)
     return GA_OK;
 } GA_ABI_CATCH
 

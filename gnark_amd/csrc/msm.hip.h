@@ -37,6 +37,9 @@
 namespace ga {
 
 constexpr int GA_ACC29_MINW = 4;      // waves per SIMD requested for the G1 bucket kernel (2 for Fp2 points: 72 KiB of LDS per workgroup)
+#ifndef GA_ACC29_FP2_MINW             // (compile-time experiments only: tools/exp/r06_bls_g2_two_waves.sh)
+#define GA_ACC29_FP2_MINW 2
+#endif
 constexpr uint32_t MSM_SIGN = 0x80000000u;
 constexpr int MSM_HOT_TASKS = 16;     // buckets with more partials than this go to the wave-parallel merge
 constexpr uint32_t MSM_VHOT_TASKS = 512;   // ... and with more than this, to the two-stage merge over MSM_VHOT_SPLIT blocks per bucket
@@ -656,7 +659,7 @@ struct Table29 {
     // the next table entry requested one addition ahead and parked in registers: G2 97.1 -> 95.9 ms on BLS12-381, nothing on the
     // other three kernels, profiles/r04_a_prefetch_ab.txt.)
     static constexpr int THREADS = (4 * NW * 4 * 256 <= 72 * 1024) ? 256 : 128;
-    static constexpr int MIN_WAVES = Lazy<F>::FP2 ? 2 : GA_ACC29_MINW;
+    static constexpr int MIN_WAVES = Lazy<F>::FP2 ? GA_ACC29_FP2_MINW : GA_ACC29_MINW;
 };
 
 // The lane's XYZZ accumulator lives in LDS, word-major (conflict-free): that is what keeps the G1 kernel at 128 VGPRs and four waves
@@ -836,8 +839,13 @@ __device__ __forceinline__ uint32_t msm_multi_dest(const MsmTables& mt, uint32_t
     return dest < mt.nb ? dest + blockIdx.y * mt.nb : dest + (mt.k - 1) * mt.nb + blockIdx.y * mt.max_tasks;
 }
 
+#ifdef GA_ACC29_NUM_VGPR   // (compile-time experiment: FORCE that many waves per SIMD on the bucket kernel -- the allocator must spill to get there; tools/exp/r06_bls_g2_two_waves.sh)
+#define GA_ACC29_VGPR_ATTR __attribute__((amdgpu_waves_per_eu(GA_ACC29_NUM_VGPR, GA_ACC29_NUM_VGPR)))
+#else
+#define GA_ACC29_VGPR_ATTR
+#endif
 template <class F, bool COMPLETE>
-__global__ void __launch_bounds__(Table29<F>::THREADS, Table29<F>::MIN_WAVES)
+__global__ void __launch_bounds__(Table29<F>::THREADS, Table29<F>::MIN_WAVES) GA_ACC29_VGPR_ATTR
 msm_accumulate29_kernel(const MsmTables mt, const uint32_t* __restrict__ vals,
                         const uint32_t* __restrict__ task_start, const uint32_t* __restrict__ task_qkey_sorted,
                         const uint32_t* __restrict__ task_key_by_tid, const uint32_t* __restrict__ task_perm, uint32_t max_tasks, uint32_t seg,

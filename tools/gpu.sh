@@ -7,7 +7,7 @@
 #   smoke                            __graft_entry__.smoke()
 #   micro                            ga_microbench: instruction issue rates (burst and sustained), dependency distance x occupancy
 #   bench[:<extra bench.py args>]    python bench.py -> ${TAG}_bench.json  (":--curve bls12-381" etc.; spaces as '+')
-#   bench2                           the --gpus 2 code path: two ranks share this box's GPU, collectives over gloo
+#   bench2                           `python bench.py --gpus 2` as the driver would type it (bench.py launches its ranks): two ranks share this box's GPU, collectives over gloo
 #   stats[:<bench args>]             rocprofv3 --kernel-trace --stats of a short bench -> ${TAG}_kernel_stats.txt
 #   hbm[:<bench args>]               FETCH_SIZE / WRITE_SIZE passes (separate, kernel-trace only) -> ${TAG}_pmc_{FETCH,WRITE}_SIZE.txt
 #   sq:<name>:<driver>               the SQ issue accounting + the wait split (LDS / VMEM / instruction cache) of <driver>:
@@ -75,10 +75,9 @@ for step in "$@"; do
       tail -4 $OUT/${TAG}_bench${sfx:+_$sfx}.err
       python tools/bench_digest.py $OUT/${TAG}_bench${sfx:+_$sfx}.json ;;
     bench2)
-      GA_BENCH_BACKEND=gloo timeout 1500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 \
-        bench.py --gpus 2 --steps 3 --warmup 1 --detail-file $OUT/${TAG}_bench_2ranks_one_gpu_gloo_detail.json $arg > $OUT/${TAG}_bench_2ranks_one_gpu_gloo.json 2> $OUT/${TAG}_bench_2ranks.err
+      # the PLAIN form -- the shape of the driver's BENCH command: no launcher, bench.py starts its two ranks itself (round 6)
+      GA_BENCH_BACKEND=gloo timeout 1500 python bench.py --gpus 2 --steps 3 --warmup 1 --detail-file $OUT/${TAG}_bench_2ranks_one_gpu_gloo_detail.json $arg > $OUT/${TAG}_bench_2ranks_one_gpu_gloo.json 2> $OUT/${TAG}_bench_2ranks.err
       tail -3 $OUT/${TAG}_bench_2ranks.err
-      sed -i '/^{/!d' $OUT/${TAG}_bench_2ranks_one_gpu_gloo.json     # (gloo prints its connection banner on stdout)
       python tools/bench_digest.py $OUT/${TAG}_bench_2ranks_one_gpu_gloo.json ;;
     stats)
       d=$OUT/stats_tmp_$$
