@@ -356,6 +356,8 @@ void ga_ctx_destroy(ga_ctx* h) try {
     hipSetDevice(c->device);
     for (int l = 0; l < GA_NUM_LANES; l++) hipStreamSynchronize(c->lane_stream[l]);
     c->scratch_free_all();
+    if (c->spare_domain) ntt_domain_delete(c->spare_domain);
+    c->spare_domain = nullptr;
     for (auto& s : c->stages) {
         hipEventDestroy(s.a);
         hipEventDestroy(s.b);

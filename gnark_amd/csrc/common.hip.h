@@ -46,6 +46,8 @@ __device__ __forceinline__ void wave_lds_sync() {
 #endif
 }
 
+struct Domain;   // ntt.hip.h
+
 // ---- errors --------------------------------------------------------------------------------------
 void set_error(const char* fmt, ...);
 const char* get_error();
@@ -234,6 +236,8 @@ struct Ctx {
     bool slot_busy[2] = {false, false};
     hipStream_t slot_stream[2] = {nullptr, nullptr};
     std::mutex scratch_mu;   // the scratch map is touched by the staging thread outside `mu`
+    std::mutex spare_mu;
+    Domain* spare_domain = nullptr;   // ntt_domain_give_spare / ntt_domain_take_spare
     std::atomic<bool> profiling{false};
     std::vector<StageRec> stages;
     // reusable device scratch, grown on demand (keyed by purpose)
@@ -416,6 +420,11 @@ template <class C> int ntt_domain_compute_h(Domain* d, void* d_a, void* d_b, voi
 template <class C> int ntt_domain_h_chain(Domain* d, void* d_v);                                        // v <- FFT_coset(iFFT(v))
 template <class C> int ntt_domain_h_combine(Domain* d, void* d_a, const void* d_b, const void* d_c);    // a <- h (bit-reversed)
 void ntt_domain_delete(Domain* d);
+// The NTT domain of the last proving key freed on a context stays with the context (like its scratch): a caller that re-pins its key
+// for every proof -- the Go package's default, PinToGPU = false -- gets it back instead of rebuilding 3 GiB of twiddle tables (11 ms
+// of a 160 ms pin at 2^24).  One domain at most; GA_DOMAIN_SPARE=0 frees it at once.
+Domain* ntt_domain_take_spare(Ctx* ctx, int curve, uint64_t n);   // null when the spare does not match
+void ntt_domain_give_spare(Ctx* ctx, Domain* d);                  // the previous spare is deleted
 int ntt_domain_curve(const Domain* d);
 uint64_t ntt_domain_size(const Domain* d);
 Ctx* ntt_domain_ctx(const Domain* d);

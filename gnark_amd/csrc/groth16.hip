@@ -135,7 +135,7 @@ static void pk_free(G16Pk* pk) {
     hipFree(pk->d_idx_k);
     for (void* p : pk->d_ck_basis) hipFree(p);
     for (void* p : pk->d_ck_sigma) hipFree(p);
-    if (pk->dom) ntt_domain_delete(pk->dom);
+    if (pk->dom) ntt_domain_give_spare(pk->ctx, pk->dom);   // (kept for the next key of this size: common.hip.h)
     delete pk;
 }
 
@@ -352,7 +352,9 @@ static int stage_finish(G16Stage* st, int precompute, G16Pk** out) {
         pk->w_hi = st->shard_count == 1 ? st->nb_wires : hi;
     }
     tr.mark("finish: gather lists built on the host");
-    int rc = ntt_domain_new<C>(ctx, pk->n, &pk->dom);
+    int rc = GA_OK;
+    pk->dom = ntt_domain_take_spare(ctx, C::ID, pk->n);   // the domain of the key this context freed last, when it has this size
+    if (!pk->dom) rc = ntt_domain_new<C>(ctx, pk->n, &pk->dom);
     tr.mark("finish: ntt_domain_new returned");
     if (rc == GA_OK) rc = upload(ctx, ia + lo_a, pk->len_a * 4, (void**)&pk->d_idx_a);
     if (rc == GA_OK) rc = upload(ctx, ib + lo_b, pk->len_b * 4, (void**)&pk->d_idx_b);
