@@ -167,8 +167,11 @@ __device__ __forceinline__ F29<FrP> ntt_twiddle29(const uint32_t* __restrict__ t
 // last store (GA_NTT_WAVE_LOCAL / GA_NTT_DIRECT, A/B knobs of round 4).
 constexpr int NTT_F_UNIT = 1, NTT_F_WAVE_LOCAL = 2, NTT_F_DIRECT = 4;
 
+#ifndef GA_NTT_MIN_WAVES   // (waves per SIMD the register allocation is sized for; 3 measured in round 6: tools/exp/r06_g.sh)
+#define GA_NTT_MIN_WAVES 4
+#endif
 template <class FrP, bool DIT_>
-__global__ void __launch_bounds__(NTT_THREADS, 4)
+__global__ void __launch_bounds__(NTT_THREADS, GA_NTT_MIN_WAVES)
 ntt_pass29r4_kernel(uint32_t* data, const uint32_t* src, const uint32_t* __restrict__ tw, int logn, int lg_tile, int s_lo, int K,
                     int lc, NttScale pre, NttScale post, int flags) {
     // NTT_F_UNIT clear: the table is a coset table (every entry carries its stage's power of the coset generator): no twiddle is 1
