@@ -111,6 +111,7 @@ _PROTOS = {
     "ga_g16_builder_finish": (C.c_int, [_P, C.c_int32, C.POINTER(_P)]),
     "ga_g16_builder_destroy": (None, [_P]),
     "ga_g16_prove": (C.c_int, [_P, _P, _P, _P, _P, C.c_uint64, C.c_uint64, _P, _P, _P]),
+    "ga_g16_prove_oneshot": (C.c_int, [_P, C.POINTER(G16Key), _P, _P, _P, _P, C.c_uint64, C.c_uint64, _P, _P, _P]),
     "ga_g16_prove_partial": (C.c_int, [_P, _P, _P, _P, _P, C.c_uint64, C.c_uint64, _P]),
     "ga_g16_finish": (C.c_int, [_P, _P, _P, _P, _P]),
     "ga_g16_shard_layout": (C.c_int, [_P, C.POINTER(C.c_uint64)]),

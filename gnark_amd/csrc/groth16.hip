@@ -73,7 +73,32 @@ struct G16Pk {
     std::condition_variable use_cv;
     int users = 0;
     bool dying = false;
+    // A key whose base vectors are still ON THEIR WAY (ga_g16_prove_oneshot: the key goes up as plain vectors, is used for ONE proof
+    // and dropped -- the Go package's default, PinToGPU = false): an uploader thread copies them in the order the proof consumes
+    // them (A, B, G2.B, K, Z) while the proof already runs; an MSM waits for ITS vector (await_vector), not for the key.
+    struct Pending {
+        std::mutex mu;
+        std::condition_variable cv;
+        bool done[GA_KEY_NB_VECTORS] = {false, false, false, false, false};
+        int rc = GA_OK;
+        std::string err;
+        std::thread uploader;
+    };
+    std::unique_ptr<Pending> pending;
 };
+
+// the vector `which` of a key is on the device (always true for a key made by ga_g16_pk_create / the builder / a key file)
+static int await_vector(G16Pk* pk, int which) {
+    G16Pk::Pending* pd = pk->pending.get();
+    if (!pd) return GA_OK;
+    std::unique_lock<std::mutex> g(pd->mu);
+    pd->cv.wait(g, [&] { return pd->done[which] || pd->rc != GA_OK; });
+    if (pd->rc != GA_OK) {
+        set_error("%s", pd->err.c_str());
+        return pd->rc;
+    }
+    return GA_OK;
+}
 
 struct PkUse {
     G16Pk* pk;
@@ -123,6 +148,7 @@ static int upload(Ctx* ctx, const void* src, size_t bytes, void** dst) {
 
 static void pk_free(G16Pk* pk) {
     if (!pk) return;
+    if (pk->pending && pk->pending->uploader.joinable()) pk->pending->uploader.join();   // (it writes into the buffers freed below)
     if (pk->ctx)
         for (const void* t : {pk->d_a, pk->d_b, pk->d_z, pk->d_k, pk->d_b2}) pk->ctx->forget_table(t);
     hipFree(pk->d_a);
@@ -579,7 +605,10 @@ static int stage_add_commitment_key(G16Stage* st, const void* basis, const void*
 }
 
 // ga_g16_pk_create: the struct-of-pointers form of the same thing (C and ctypes callers; from Go only with runtime.Pinner)
-static int pk_create_from_struct(Ctx* ctx, const ga_g16_key* key, G16Pk** out) {
+// defer_uploads (ga_g16_prove_oneshot): the five base vectors get their device buffers here but are copied by an uploader thread
+// that this function starts before it returns -- plain vectors only (no tables), the whole key on one device; the caller must keep
+// the host vectors alive until the thread has been joined (pk_free does).
+static int pk_create_from_struct(Ctx* ctx, const ga_g16_key* key, G16Pk** out, bool defer_uploads = false) {
     if (!key->g1_alpha || !key->g1_beta || !key->g1_delta || !key->g2_beta || !key->g2_delta || !key->infinity_a || !key->infinity_b ||
         (key->len_a && !key->g1_a) || (key->len_b && !key->g1_b) || (key->len_z && !key->g1_z) || (key->len_k && !key->g1_k) ||
         (key->len_b2 && !key->g2_b)) {
@@ -620,9 +649,14 @@ static int pk_create_from_struct(Ctx* ctx, const ga_g16_key* key, G16Pk** out) {
     st.start_list(1);
     const void* vec[GA_KEY_NB_VECTORS] = {key->g1_a, key->g1_b, key->g1_z, key->g1_k, key->g2_b};
     const uint64_t len[GA_KEY_NB_VECTORS] = {key->len_a, key->len_b, key->len_z, key->len_k, key->len_b2};
+    if (defer_uploads && (st.shard_count != 1 || st.win_count != 1)) {
+        set_error("ga_g16_prove_oneshot: the key must be whole (no base-range or window sharding)");
+        return GA_ERR_INVALID;
+    }
     for (int w = 0; w < GA_KEY_NB_VECTORS; w++) {
         GA_CHECK(stage_reserve(&st, w, len[w]));
-        GA_CHECK(stage_append(&st, w, vec[w], len[w], /*pinned=*/true));   // one drain below instead of five
+        if (defer_uploads) st.v[w].seen = st.v[w].total;   // (the uploader below fills the buffer)
+        else GA_CHECK(stage_append(&st, w, vec[w], len[w], /*pinned=*/true));   // one drain below instead of five
         tr.mark("vector reserved + appended");
     }
     GA_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -633,8 +667,53 @@ static int pk_create_from_struct(Ctx* ctx, const ga_g16_key* key, G16Pk** out) {
     if (key->len_k_remove) st.k_remove.assign(key->k_remove, key->k_remove + key->len_k_remove);
     tr.mark("points, infinity masks, commitment keys staged");
     G16Pk* pk = nullptr;
-    GA_DISPATCH_CURVE(key->curve, GA_CHECK(stage_finish<C>(&st, key->precompute, &pk)));
+    GA_DISPATCH_CURVE(key->curve, GA_CHECK(stage_finish<C>(&st, defer_uploads ? -1 : key->precompute, &pk)));
     tr.mark("stage_finish");
+    if (defer_uploads) {
+        pk->pending.reset(new G16Pk::Pending());
+        G16Pk::Pending* pd = pk->pending.get();
+        // in the order the proof consumes them: A, B (G1), B (G2), K on the witness lane, Z last (it waits for h anyway)
+        struct Job { int which; void* dst; const void* src; size_t bytes; };
+        std::vector<Job> jobs;
+        void* const dst[GA_KEY_NB_VECTORS] = {pk->d_a, pk->d_b, pk->d_z, pk->d_k, pk->d_b2};
+        for (int w : {GA_KEY_G1_A, GA_KEY_G1_B, GA_KEY_G2_B, GA_KEY_G1_K, GA_KEY_G1_Z})
+            jobs.push_back(Job{w, dst[w], vec[w], (size_t)len[w] * stage_point_bytes(key->curve, w)});
+        const int device = ctx->device;
+        pd->uploader = std::thread([pd, jobs, device]() {
+            int rc = GA_OK;
+            std::string err;
+            hipStream_t up = nullptr;
+            try {
+                if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&up, hipStreamNonBlocking) != hipSuccess) {
+                    rc = GA_ERR_HIP;
+                    err = "one-shot key upload: no stream";
+                }
+                for (const Job& j : jobs) {
+                    if (rc != GA_OK) break;
+                    hipError_t e = j.bytes ? hipMemcpyAsync(j.dst, j.src, j.bytes, hipMemcpyHostToDevice, up) : hipSuccess;
+                    if (e == hipSuccess) e = hipStreamSynchronize(up);
+                    std::lock_guard<std::mutex> g(pd->mu);
+                    if (e != hipSuccess) {
+                        rc = GA_ERR_HIP;
+                        err = std::string("one-shot key upload: ") + hipGetErrorString(e);
+                    } else {
+                        pd->done[j.which] = true;
+                        pd->cv.notify_all();
+                    }
+                }
+            } catch (...) {   // (an exception leaving a thread function terminates the process)
+                rc = GA_ERR_STATE;
+                err = "one-shot key upload: exception in the uploader thread";
+            }
+            if (up) hipStreamDestroy(up);
+            if (rc != GA_OK) {
+                std::lock_guard<std::mutex> g(pd->mu);
+                pd->rc = rc;
+                pd->err = err;
+                pd->cv.notify_all();
+            }
+        });
+    }
     *out = pk;
     return GA_OK;
 }
@@ -1185,6 +1264,7 @@ static int k_msm(G16Pk* pk, uint64_t nb_public, WitnessShared& sh, XYZZ<Fe<typen
         bool live;
         return g16_table_msm_g1<C>(pk, pk->d_k, d_wk, pk->len_k, pk->c_k, &prep, &live, out);
     }
+    GA_CHECK(await_vector(pk, GA_KEY_G1_K));
     return host_msm<C, GA_G1>(ctx, pk->d_k, d_wk, pk->len_k, true, out, pk->win_index, pk->win_count);
 }
 
@@ -1281,12 +1361,18 @@ static int witness_msms(G16Pk* pk, const SlotLease& slot, uint64_t nb_public, Wi
         if (multi_a) {
         } else if (pk->share_a) GA_CHECK(shared_g1(pk->d_a, &ar));
         else if (pk->tab_a) GA_CHECK(g16_table_msm_g1<C>(pk, pk->d_a, d_wa, pk->len_a, pk->c_a, &prep, &prep_live, &ar));
-        else GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_a, d_wa, pk->len_a, true, &ar, pk->win_index, pk->win_count)));
+        else {
+            GA_CHECK(await_vector(pk, GA_KEY_G1_A));
+            GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_a, d_wa, pk->len_a, true, &ar, pk->win_index, pk->win_count)));
+        }
         prep_live = false;   // (whatever A left in `prep` is not wB's)
         if (multi_b) {
         } else if (pk->share_b) GA_CHECK(shared_g1(pk->d_b, &bs1));
         else if (pk->tab_b) GA_CHECK(g16_table_msm_g1<C>(pk, pk->d_b, d_wb, pk->len_b, pk->c_b, &prep, &prep_live, &bs1));
-        else GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_b, d_wb, pk->len_b, true, &bs1, pk->win_index, pk->win_count)));
+        else {
+            GA_CHECK(await_vector(pk, GA_KEY_G1_B));
+            GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_b, d_wb, pk->len_b, true, &bs1, pk->win_index, pk->win_count)));
+        }
         if (pk->share_b2) {   // G2.B wire-indexed: the shared witness sort again
             if (sh.w_live) GA_CHECK((msm_table_device_reuse<C, GA_G2>(ctx, pk->d_b2, sh.prep_w, &bs2)));
             else bs2 = xyzz_inf<F2>();
@@ -1300,6 +1386,7 @@ static int witness_msms(G16Pk* pk, const SlotLease& slot, uint64_t nb_public, Wi
                 GA_CHECK((msm_table_device_reuse<C, GA_G2>(ctx, pk->d_b2, prep, &bs2)));
             }
         } else {
+            GA_CHECK(await_vector(pk, GA_KEY_G2_B));
             GA_CHECK((host_msm<C, GA_G2>(ctx, pk->d_b2, d_wb, pk->len_b2, true, &bs2, pk->win_index, pk->win_count)));
         }
     }
@@ -1345,6 +1432,7 @@ static int z_msm(G16Pk* pk, const void* d_h_slice, XYZZ<Fe<typename C::FpP>>* ou
         GA_CHECK(msm_prepare_table_scalars<C>(ctx, d_h_slice, pk->len_z, true, pk->c_z, &prep, 0, lo, hi));
         return msm_table_device_reuse<C, GA_G1>(ctx, pk->d_z, prep, out);
     }
+    GA_CHECK(await_vector(pk, GA_KEY_G1_Z));
     return host_msm<C, GA_G1>(ctx, pk->d_z, d_h_slice, pk->len_z, true, out, pk->win_index, pk->win_count);
 }
 
@@ -2105,9 +2193,7 @@ void ga_g16_builder_destroy(ga_g16_builder* b) try {
     delete st;
 } GA_ABI_CATCH_VOID
 
-void ga_g16_pk_destroy(ga_g16_pk* p) try {
-    GA_ABI_ENTRY();
-    G16Pk* pk = reinterpret_cast<G16Pk*>(p);
+static void pk_destroy_impl(G16Pk* pk) {
     if (!pk) return;
     {   // wait for every entry point still working on this key (provers on other lanes, epilogues outside the device lock)
         std::unique_lock<std::mutex> u(pk->use_mu);
@@ -2117,6 +2203,11 @@ void ga_g16_pk_destroy(ga_g16_pk* p) try {
     CtxLock g(pk->ctx);
     for (int l = 0; l < GA_NUM_LANES; l++) hipStreamSynchronize(pk->ctx->lane_stream[l]);
     pk_free(pk);
+}
+
+void ga_g16_pk_destroy(ga_g16_pk* p) try {
+    GA_ABI_ENTRY();
+    pk_destroy_impl(reinterpret_cast<G16Pk*>(p));
 } GA_ABI_CATCH_VOID
 
 static int g16_prove_impl(ga_g16_pk* p, const void* w, const void* a, const void* b, const void* c, uint64_t n_constraints,
@@ -2612,6 +2703,30 @@ int ga_g16_prove(ga_g16_pk* p, const void* w, const void* a, const void* b, cons
                  uint64_t nb_public, const void* r, const void* s, void* proof_out) try {
     GA_ABI_ENTRY();
     return g16_prove_impl(p, w, a, b, c, n_constraints, nb_public, r, s, proof_out);
+} GA_ABI_CATCH
+// One proof on a key that is NOT kept on the device (the Go package's default, PinToGPU = false, as icicle.go:797-805): the key
+// goes up as plain vectors WHILE the proof runs -- the uploader thread of pk_create_from_struct copies A, B, G2.B, K, Z in the order
+// the MSMs consume them, every MSM waits for its own vector only -- and is dropped afterwards.  Same proof bytes as
+// ga_g16_pk_create(precompute = -1) + ga_g16_prove + ga_g16_pk_destroy, in about the time of the longer of the two (PCIe, device)
+// instead of their sum.  No host pointer is used after the call returns (the uploader is joined before the key is freed).
+int ga_g16_prove_oneshot(ga_ctx* h, const ga_g16_key* key, const void* w, const void* a, const void* b, const void* c, uint64_t n_constraints,
+                         uint64_t nb_public, const void* r, const void* s, void* proof_out) try {
+    GA_ABI_ENTRY();
+    Ctx* ctx = reinterpret_cast<Ctx*>(h);
+    if (!ctx || !key || !w || !a || !b || !c || !r || !s || !proof_out) {
+        set_error("ga_g16_prove_oneshot: null argument");
+        return GA_ERR_INVALID;
+    }
+    G16Pk* pk = nullptr;
+    {
+        CtxLock g(ctx);
+        GA_CHECK(pk_create_from_struct(ctx, key, &pk, /*defer_uploads=*/true));
+    }
+    struct Drop {   // whatever happens below, the uploader is joined and the key freed before the host vectors go out of scope
+        G16Pk* pk;
+        ~Drop() { pk_destroy_impl(pk); }
+    } drop{pk};
+    return g16_prove_impl(reinterpret_cast<ga_g16_pk*>(pk), w, a, b, c, n_constraints, nb_public, r, s, proof_out);
 } GA_ABI_CATCH
 int ga_g16_prove_partial(ga_g16_pk* p, const void* w, const void* a, const void* b, const void* c, uint64_t n_constraints,
                          uint64_t nb_public, void* partials_out) try {

@@ -291,6 +291,51 @@ def Prove(pk: ProvingKey, solution: Solution, nb_public: int, r: np.ndarray, s: 
     return Proof(pk.curve, out[: 2 * fp].copy(), out[2 * fp: 6 * fp].copy(), out[6 * fp:].copy(), lib)
 
 
+def ProveOneShot(ctx: Context, curve, solution: Solution, nb_public: int, r, s, *, domain_cardinality, alpha1, beta1, delta1, A, B, Z, K,
+                 beta2, delta2, B2, infinityA, infinityB, k_remove=()) -> Proof:
+    """groth16.Prove with the key NOT kept on the device (the reference's and the Go package's default, PinToGPU = false,
+    icicle.go:797-805): ga_g16_prove_oneshot uploads the key as plain vectors WHILE the proof runs and frees it afterwards.  Same
+    proof bytes as ProvingKey(precompute=-1) + Prove + FreeGPUResources."""
+    cid = curve_id(curve)
+    fp = FP_LIMBS[cid]
+    g1 = lambda v: as_u64(np.asarray(v).reshape(-1, 2 * fp), 2 * fp)
+    g2 = lambda v: as_u64(np.asarray(v).reshape(-1, 4 * fp), 4 * fp)
+    A, B, Z, K, B2 = g1(A), g1(B), g1(Z), g1(K), g2(B2)
+    alpha1, beta1, delta1, beta2, delta2 = g1(alpha1), g1(beta1), g1(delta1), g2(beta2), g2(delta2)
+    ia = np.ascontiguousarray(infinityA, dtype=np.uint8)
+    ib = np.ascontiguousarray(infinityB, dtype=np.uint8)
+    if ia.shape != ib.shape:
+        raise ValueError("InfinityA and InfinityB must have nbWires entries each")
+    key = _lib.G16Key()
+    key.curve, key.domain_cardinality = cid, int(domain_cardinality)
+    key.g1_alpha, key.g1_beta, key.g1_delta = alpha1.ctypes.data, beta1.ctypes.data, delta1.ctypes.data
+    key.g1_a, key.len_a = A.ctypes.data, A.shape[0]
+    key.g1_b, key.len_b = B.ctypes.data, B.shape[0]
+    key.g1_z, key.len_z = Z.ctypes.data, Z.shape[0]
+    key.g1_k, key.len_k = K.ctypes.data, K.shape[0]
+    key.g2_beta, key.g2_delta = beta2.ctypes.data, delta2.ctypes.data
+    key.g2_b, key.len_b2 = B2.ctypes.data, B2.shape[0]
+    key.infinity_a, key.infinity_b = ia.ctypes.data, ib.ctypes.data
+    key.nb_wires = ia.shape[0]
+    key.nb_infinity_a, key.nb_infinity_b = int(np.count_nonzero(ia)), int(np.count_nonzero(ib))
+    key.precompute = -1
+    key.shard_index, key.shard_count = 0, 1
+    rem = np.ascontiguousarray(k_remove, dtype=np.uint64)
+    if rem.size:
+        key.k_remove, key.len_k_remove = rem.ctypes.data_as(C.POINTER(C.c_uint64)), rem.size
+    W, Av, Bv, Cc = (as_u64(x, 4) for x in (solution.W, solution.A, solution.B, solution.C))
+    if W.shape[0] != ia.shape[0]:
+        raise ValueError(f"len(W)={W.shape[0]} != nbWires={ia.shape[0]}")
+    if not (Av.shape == Bv.shape == Cc.shape):
+        raise ValueError("A, B, C must have the same length")
+    r, s = as_u64(np.asarray(r).reshape(1, 4), 4), as_u64(np.asarray(s).reshape(1, 4), 4)
+    out = np.zeros(8 * fp, dtype=np.uint64)
+    lib = ctx.lib
+    lib.check(lib.ga_g16_prove_oneshot(ctx.handle, C.byref(key), _ptr(W), _ptr(Av), _ptr(Bv), _ptr(Cc), Av.shape[0], nb_public, _ptr(r), _ptr(s),
+                                       _ptr(out)))
+    return Proof(cid, out[: 2 * fp].copy(), out[2 * fp: 6 * fp].copy(), out[6 * fp:].copy(), lib)
+
+
 def ProvePartial(pk: ProvingKey, solution: Solution, nb_public: int) -> np.ndarray:
     """Device part of a proof on this key's shard (ga_g16_prove_partial): Jacobian sums A | B1 | K+Z | B2 before
     randomisation, as one uint64 vector (3 G1Jac + 1 G2Jac) ready for an all_gather."""

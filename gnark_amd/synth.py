@@ -56,6 +56,11 @@ class Instance:
     def proving_key(self, ctx: Context, **kw) -> groth16.ProvingKey:
         return groth16.ProvingKey(ctx, self.curve, domain_cardinality=self.n, **self.key, **kw)
 
+    def prove_oneshot(self, ctx: Context, solution=None, r=None, s=None) -> groth16.Proof:
+        """the key uploaded while the proof runs, then dropped (ga_g16_prove_oneshot)"""
+        return groth16.ProveOneShot(ctx, self.curve, solution or self.solution, self.nb_public, self.r if r is None else r,
+                                    self.s if s is None else s, domain_cardinality=self.n, **self.key)
+
 
 def _gen_bases(ctx: Context, cid: int, group: int, count: int, seed: int, want_dlogs: bool):
     words = affine_words(cid, group)

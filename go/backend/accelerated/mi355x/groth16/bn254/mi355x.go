@@ -247,6 +247,61 @@ func (pk *ProvingKey) FreeGPUResources() {
 	pk.freeLocked()
 }
 
+// oneShot reports whether this proof takes the upload-while-proving path: nothing pinned or asked to be, the whole key on one
+// device, plain vectors, no commitments, and no device copy already there (a second prover on a key that IS on the device uses it).
+func (pk *ProvingKey) oneShot(cfg *mi355x.Config, info constraint.Groth16Commitments) bool {
+	pk.setupMu.Lock()
+	defer pk.setupMu.Unlock()
+	return !pk.PinToGPU && !cfg.PinToGPU && pk.deviceInfo == nil && len(cfg.DeviceIDs()) == 1 && len(info) == 0 && len(pk.InfinityA) > 0 &&
+		effectivePrecompute(cfg, false) == int32(mi355x.PrecomputeNever)
+}
+
+// proveOneShot is Prove for a key that stays on the host: solver on the CPU, then ga.ProveOneShot.
+func proveOneShot(r1cs *cs.R1CS, pk *ProvingKey, fullWitness witness.Witness, cfg *mi355x.Config, opt backend.ProverConfig) (*groth16_bn254.Proof, error) {
+	log := logger.Logger().With().Str("curve", r1cs.CurveID().String()).Str("acceleration", "mi355x").Int("nbConstraints", r1cs.GetNbConstraints()).Str("backend", "groth16").Logger()
+	ctx, err := ga.ContextFor(cfg.DeviceIDs()[0])
+	if err != nil {
+		return nil, err
+	}
+	_solution, err := r1cs.Solve(fullWitness, opt.SolverOpts...)
+	if err != nil {
+		return nil, err
+	}
+	solution := _solution.(*cs.R1CSSolution)
+	wireValues := []fr.Element(solution.W)
+	start := time.Now()
+	var r, s fr.Element // the prover's randomness (prove.go:171-177)
+	if _, err := r.SetRandom(); err != nil {
+		return nil, err
+	}
+	if _, err := s.SetRandom(); err != nil {
+		return nil, err
+	}
+	var out struct {
+		Ar  curve.G1Affine
+		Bs  curve.G2Affine
+		Krs curve.G1Affine
+	}
+	key := &ga.OneShotKey{
+		Curve: curveID, DomainCardinality: pk.Domain.Cardinality,
+		A: sliceData(pk.G1.A), LenA: uint64(len(pk.G1.A)), B: sliceData(pk.G1.B), LenB: uint64(len(pk.G1.B)),
+		Z: sliceData(pk.G1.Z), LenZ: uint64(len(pk.G1.Z)), K: sliceData(pk.G1.K), LenK: uint64(len(pk.G1.K)),
+		B2: sliceData(pk.G2.B), LenB2: uint64(len(pk.G2.B)),
+		Alpha1: unsafe.Pointer(&pk.G1.Alpha), Beta1: unsafe.Pointer(&pk.G1.Beta), Delta1: unsafe.Pointer(&pk.G1.Delta),
+		Beta2: unsafe.Pointer(&pk.G2.Beta), Delta2: unsafe.Pointer(&pk.G2.Delta),
+		InfinityA: pk.InfinityA, InfinityB: pk.InfinityB, NbInfinityA: pk.NbInfinityA, NbInfinityB: pk.NbInfinityB,
+	}
+	err = ctx.ProveOneShot(key, sliceData(wireValues), sliceData([]fr.Element(solution.A)), sliceData([]fr.Element(solution.B)),
+		sliceData([]fr.Element(solution.C)), uint64(len(solution.A)), uint64(r1cs.GetNbPublicVariables()), unsafe.Pointer(&r), unsafe.Pointer(&s),
+		unsafe.Pointer(&out))
+	if err != nil {
+		return nil, err
+	}
+	proof := &groth16_bn254.Proof{Ar: out.Ar, Bs: out.Bs, Krs: out.Krs}
+	log.Debug().Dur("took", time.Since(start)).Msg("prover done (one shot: key uploaded while proving)")
+	return proof, nil
+}
+
 // Prove generates the proof of knowledge of a r1cs with full witness (secret + public part).
 //
 // The solver, the BSB22 hashing and the Fiat-Shamir fold stay on the CPU exactly as in
@@ -263,6 +318,12 @@ func Prove(r1cs *cs.R1CS, pk *ProvingKey, fullWitness witness.Witness, cfg *mi35
 	log := logger.Logger().With().Str("curve", r1cs.CurveID().String()).Str("acceleration", "mi355x").Int("nbConstraints", r1cs.GetNbConstraints()).Str("backend", "groth16").Logger()
 
 	commitmentInfo := r1cs.CommitmentInfo.(constraint.Groth16Commitments)
+	// The default -- a key that is not kept on the device, one device, no window tables asked for, no BSB22 commitment (whose MSMs
+	// run inside the solver, before the proof) -- goes through ONE call that uploads the key while the proof already runs and
+	// drops it afterwards (ga_g16_prove_oneshot): about the longer of "6 GiB over PCIe" and "the proof" instead of their sum.
+	if pk.oneShot(cfg, commitmentInfo) {
+		return proveOneShot(r1cs, pk, fullWitness, cfg, opt)
+	}
 	// pin (if needed) and hold the device copy for the whole proof; an un-pinned key is freed by the last prover's release
 	di, err := pk.acquire(cfg, commitmentInfo)
 	if err != nil {

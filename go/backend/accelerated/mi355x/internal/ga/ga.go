@@ -291,6 +291,62 @@ func (pk *ProvingKey) Prove(w, a, b, c unsafe.Pointer, nbConstraints, nbPublic u
 	})
 }
 
+// OneShotKey names the host images of a proving key for ProveOneShot: pointers to the first elements of pk.G1.A, B, Z, K,
+// pk.G2.B ([]G1Affine / []G2Affine), to the five single points, and the infinity masks and K filter of the key.
+type OneShotKey struct {
+	Curve                       Curve
+	DomainCardinality           uint64
+	A, B, Z, K, B2              unsafe.Pointer
+	LenA, LenB, LenZ, LenK, LenB2 uint64
+	Alpha1, Beta1, Delta1       unsafe.Pointer
+	Beta2, Delta2               unsafe.Pointer
+	InfinityA, InfinityB        []bool
+	NbInfinityA, NbInfinityB    uint64
+	KRemove                     []uint64
+}
+
+// ProveOneShot is one proof on a key that is NOT kept on the device (PinToGPU false, the default here as in
+// icicle.go:797-805): ga_g16_prove_oneshot uploads the key as plain vectors while the proof already runs -- every MSM waits
+// for its own vector only -- and frees it before it returns.  The ga_g16_key lives in C memory; the Go slices it points to
+// are pinned for the duration of the call (runtime.Pinner), nothing is retained afterwards.
+func (c *Context) ProveOneShot(key *OneShotKey, w, a, b, cc unsafe.Pointer, nbConstraints, nbPublic uint64, r, s, out unsafe.Pointer) error {
+	if len(key.InfinityA) == 0 || len(key.InfinityA) != len(key.InfinityB) {
+		return errors.New("gnark_amd: infinity masks must have nbWires entries each")
+	}
+	var p runtime.Pinner
+	defer p.Unpin()
+	pin := func(x unsafe.Pointer) unsafe.Pointer {
+		if x != nil {
+			p.Pin(x)
+		}
+		return x
+	}
+	k := (*C.ga_g16_key)(C.calloc(1, C.size_t(unsafe.Sizeof(C.ga_g16_key{}))))
+	defer C.free(unsafe.Pointer(k))
+	k.curve = C.int(key.Curve)
+	k.domain_cardinality = C.uint64_t(key.DomainCardinality)
+	k.g1_alpha, k.g1_beta, k.g1_delta = pin(key.Alpha1), pin(key.Beta1), pin(key.Delta1)
+	k.g2_beta, k.g2_delta = pin(key.Beta2), pin(key.Delta2)
+	k.g1_a, k.len_a = pin(key.A), C.uint64_t(key.LenA)
+	k.g1_b, k.len_b = pin(key.B), C.uint64_t(key.LenB)
+	k.g1_z, k.len_z = pin(key.Z), C.uint64_t(key.LenZ)
+	k.g1_k, k.len_k = pin(key.K), C.uint64_t(key.LenK)
+	k.g2_b, k.len_b2 = pin(key.B2), C.uint64_t(key.LenB2)
+	k.infinity_a = (*C.uint8_t)(pin(unsafe.Pointer(unsafe.SliceData(key.InfinityA))))
+	k.infinity_b = (*C.uint8_t)(pin(unsafe.Pointer(unsafe.SliceData(key.InfinityB))))
+	k.nb_wires = C.uint64_t(len(key.InfinityA))
+	k.nb_infinity_a, k.nb_infinity_b = C.uint64_t(key.NbInfinityA), C.uint64_t(key.NbInfinityB)
+	k.precompute = -1
+	k.shard_count = 1
+	if len(key.KRemove) > 0 {
+		k.k_remove = (*C.uint64_t)(pin(unsafe.Pointer(unsafe.SliceData(key.KRemove))))
+		k.len_k_remove = C.uint64_t(len(key.KRemove))
+	}
+	return call("ga_g16_prove_oneshot", func() C.int {
+		return C.ga_g16_prove_oneshot(c.h, k, w, a, b, cc, C.uint64_t(nbConstraints), C.uint64_t(nbPublic), r, s, out)
+	})
+}
+
 // ProveMulti proves ONE statement over several devices: keys[i] is shard i of len(keys) of the same proving key, each on
 // its own device (ga_g16_prove_multi: one host thread per device inside the library, partial sums added on the host).
 func ProveMulti(keys []*ProvingKey, w, a, b, c unsafe.Pointer, nbConstraints, nbPublic uint64, r, s, out unsafe.Pointer) error {

@@ -265,6 +265,13 @@ typedef struct ga_g16_key {
 } ga_g16_key;
 
 int ga_g16_pk_create(ga_ctx* ctx, const ga_g16_key* key, ga_g16_pk** out);
+/* One proof on a key that is not kept on the device -- the default of the reference's GPU backend (PinToGPU false: the key is uploaded
+ * for every proof, icicle.go:797-805) and of the Go package here.  The key (key->precompute is ignored: plain vectors, no tables; whole
+ * key, no commitments needed before the proof) is uploaded by a helper thread WHILE the proof runs, each MSM waiting for its own vector
+ * only, and freed before the call returns; proof bytes identical to ga_g16_pk_create + ga_g16_prove + ga_g16_pk_destroy.  Arguments
+ * after `key` as ga_g16_prove.  No pointer is retained after the call. */
+int ga_g16_prove_oneshot(ga_ctx* ctx, const ga_g16_key* key, const void* w, const void* a, const void* b, const void* c,
+                         uint64_t n_constraints, uint64_t nb_public, const void* r, const void* s, void* proof_out);
 void ga_g16_pk_destroy(ga_g16_pk* pk);   /* FreeGPUResources, icicle.go:1493-1549; waits for entry points still using the key */
 /* How the ga_g16_prove calls of a context were scheduled since it was created: out6[0] on lanes 0/1 (device free), [1] on lanes
  * 2/3 beside another proof, [2] staged + queued for the device, [3] proofs whose H side ran on a partner lane; [4], [5] = bytes of

@@ -60,6 +60,7 @@ def test_single_rank_line(env, tmp_path):
     assert g["matches_dlog"] is True and g["h_identity_ok"] is True and g["proofs"] == 2 and g["two_callers"]["same_proof_bytes"] is True
     # the drop-in default (key uploaded as plain vectors, one proof, freed) beside the pinned headline
     assert g["one_shot_unpinned_ms"] > 0 and g["one_shot_unpinned"]["same_proof_bytes"] is True and sm["groth16_bn254_one_shot_unpinned_ms"] == g["one_shot_unpinned_ms"]
+    assert g["one_shot_unpinned"]["fused_same_proof_bytes"] is True and g["one_shot_unpinned"]["sequential_ms"] > 0
     assert line["plonk"]["identity_ok"] is True and line["plonk"]["roofline"]["bound"] == "hbm"
     assert line["msm_with_scalar_h2d"]["same_result"] is True and line["msm_with_scalar_h2d"]["ms_per_msm"] > 0
     gb = line["groth16_bls12_381"]

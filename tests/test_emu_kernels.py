@@ -1317,6 +1317,64 @@ def test_emu_groth16_batched_witness_tables(emu_ctx, c, monkeypatch, logn=7):
             pk.FreeGPUResources()
 
 
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_emu_groth16_prove_oneshot(emu_ctx, c, logn=7):
+    """ga_g16_prove_oneshot -- the key uploaded by a helper thread WHILE the proof runs, every MSM waiting for its own vector, the
+    key dropped afterwards (the reference's default PinToGPU = false, icicle.go:797-805): proof bytes identical to pinning the
+    plain vectors, proving and freeing, and to the pinned-with-tables proof; two callers at once on one context; bad keys are
+    errors that leave the context usable; the examples/cubic bytes of the oracle."""
+    import threading
+    from gnark_amd import synth
+    inst = synth.make_instance(emu_ctx, c.name, logn, 0x4F53, nb_constraints=(1 << logn) - 3)
+    other = synth.make_instance(emu_ctx, c.name, logn, 0x4F54, nb_constraints=(1 << logn) - 3, want_dlogs=False)
+    pk = inst.proving_key(emu_ctx, precompute=-1)
+    pkt = inst.proving_key(emu_ctx, precompute=1)
+    try:
+        want = groth16.Prove(pk, inst.solution, inst.nb_public, inst.r, inst.s).raw()
+        assert np.array_equal(groth16.Prove(pkt, inst.solution, inst.nb_public, inst.r, inst.s).raw(), want)
+        want_other = groth16.Prove(pk, other.solution, inst.nb_public, other.r, other.s).raw()
+    finally:
+        pk.FreeGPUResources()
+        pkt.FreeGPUResources()
+    for _ in range(2):   # (the second call gets the first one's NTT domain back from the context)
+        assert np.array_equal(inst.prove_oneshot(emu_ctx).raw(), want)
+    assert np.array_equal(inst.prove_oneshot(emu_ctx, other.solution, other.r, other.s).raw(), want_other)
+    bad = []
+
+    def caller(k):
+        for j in range(2):
+            sol, r, s_, w = ((inst.solution, inst.r, inst.s, want), (other.solution, other.r, other.s, want_other))[(k + j) % 2]
+            if not np.array_equal(inst.prove_oneshot(emu_ctx, sol, r, s_).raw(), w):
+                bad.append((k, j))
+    th = [threading.Thread(target=caller, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not bad, bad
+    # a key whose masks disagree with its vectors: an error (after the buffers were reserved), nothing left behind, context usable
+    broken = dict(inst.key, infinityA=np.zeros_like(inst.key["infinityA"]))
+    with pytest.raises(Exception, match="Infinity|len"):
+        groth16.ProveOneShot(emu_ctx, c.name, inst.solution, inst.nb_public, inst.r, inst.s, domain_cardinality=inst.n, **broken)
+    with pytest.raises(Exception, match="nbWires|len\\(W\\)"):
+        groth16.ProveOneShot(emu_ctx, c.name, groth16.Solution(inst.solution.W[:-1], inst.solution.A, inst.solution.B, inst.solution.C),
+                             inst.nb_public, inst.r, inst.s, domain_cardinality=inst.n, **inst.key)
+    assert np.array_equal(inst.prove_oneshot(emu_ctx).raw(), want)
+    # examples/cubic (BASELINE config 1): the bytes of the oracle's prover
+    rng = pyref.Xoshiro(5)
+    cs, w = pyref.cubic_r1cs(), pyref.cubic_witness(3)
+    opk, _, _ = pyref.groth16_setup(c, cs, [rng.field(c.r) for _ in range(5)])
+    r, s_ = rng.field(c.r), rng.field(c.r)
+    a_, b_, c_ = pyref.r1cs_solve(c, cs, w)
+    proof = groth16.ProveOneShot(
+        emu_ctx, c.name, groth16.Solution(fr_to_arr(c, w), fr_to_arr(c, a_), fr_to_arr(c, b_), fr_to_arr(c, c_)), cs.nb_public,
+        fr_to_arr(c, [r]), fr_to_arr(c, [s_]), domain_cardinality=opk.n, alpha1=pts_to_arr(c, 0, [opk.alpha1]),
+        beta1=pts_to_arr(c, 0, [opk.beta1]), delta1=pts_to_arr(c, 0, [opk.delta1]), A=pts_to_arr(c, 0, opk.A), B=pts_to_arr(c, 0, opk.B),
+        Z=pts_to_arr(c, 0, opk.Z), K=pts_to_arr(c, 0, opk.K), beta2=pts_to_arr(c, 1, [opk.beta2]), delta2=pts_to_arr(c, 1, [opk.delta2]),
+        B2=pts_to_arr(c, 1, opk.B2), infinityA=opk.infinityA, infinityB=opk.infinityB)
+    assert proof.WriteTo() == pyref.proof_bytes(c, *pyref.groth16_prove(opk, cs, w, r, s_))
+
+
 def test_emu_groth16_second_caller_without_memory_queues_instead_of_failing(emu_ctx, monkeypatch, logn=7, rounds=3):
     """precompute = 0 fills the HBM with tables beside ONE caller's scratch; a second concurrent ga_g16_prove caller is sent
     to lanes 2/3, whose scratch may then not fit.  GA_FAULT_LANE2_NOMEM makes every scratch request of lanes 2/3 fail as if HBM were

@@ -67,6 +67,13 @@ def test_groth16_batched_witness_tables_2_12(gpu_ctx, c, monkeypatch):
     cases.test_emu_groth16_batched_witness_tables(gpu_ctx, c, monkeypatch, logn=12)
 
 
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_groth16_prove_oneshot_2_14(gpu_ctx, c):
+    """round 6: ga_g16_prove_oneshot (the key uploaded while the proof runs, then dropped -- the reference's default, PinToGPU false):
+    same bytes as pin + prove + free and as the pinned-with-tables proof, two callers at once, bad keys as errors, examples/cubic"""
+    cases.test_emu_groth16_prove_oneshot(gpu_ctx, c, logn=14)
+
+
 def test_groth16_second_caller_without_memory_queues(gpu_ctx, monkeypatch):
     """a second concurrent ga_g16_prove caller whose lanes 2/3 cannot allocate (GA_FAULT_LANE2_NOMEM) gives their scratch back and
     queues for the device: right proofs, no error"""
