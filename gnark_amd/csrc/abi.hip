@@ -358,6 +358,11 @@ void ga_ctx_destroy(ga_ctx* h) try {
     c->scratch_free_all();
     if (c->spare_domain) ntt_domain_delete(c->spare_domain);
     c->spare_domain = nullptr;
+    for (void*& q : c->spare_vectors.p) {
+        hipFree(q);
+        q = nullptr;
+    }
+    c->spare_vectors.have = false;
     for (auto& s : c->stages) {
         hipEventDestroy(s.a);
         hipEventDestroy(s.b);

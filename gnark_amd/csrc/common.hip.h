@@ -236,8 +236,48 @@ struct Ctx {
     bool slot_busy[2] = {false, false};
     hipStream_t slot_stream[2] = {nullptr, nullptr};
     std::mutex scratch_mu;   // the scratch map is touched by the staging thread outside `mu`
+    // While a one-shot proof is in flight (ga_g16_prove_oneshot: 6-9 GiB of key on their way beside W and the solver's A, B, C) the
+    // pageable host-to-device copies of this context take turns, 128 MiB at a time, in the order they asked (a ticket lock): two
+    // such copies at once share the link at 24 + 24 GB/s where one alone gets 56 (profiles/r06_j_h2d_concurrency.json).  Otherwise
+    // they run as they come: two pinned-key proofs in flight LOSE with the turns (122 -> 131 ms per proof, r06_k).
+    std::atomic<int> oneshot_inflight{0};
+    struct TicketLock {
+        std::mutex mu;
+        std::condition_variable cv;
+        uint64_t next = 0, serving = 0;
+        void lock() {
+            std::unique_lock<std::mutex> g(mu);
+            const uint64_t my = next++;
+            cv.wait(g, [&] { return serving == my; });
+        }
+        void unlock() {
+            {
+                std::lock_guard<std::mutex> g(mu);
+                serving++;
+            }
+            cv.notify_all();
+        }
+    } h2d_turn;
+    hipError_t h2d_pageable(void* dst, const void* src, size_t bytes, hipStream_t st) {
+        if (oneshot_inflight.load(std::memory_order_relaxed) == 0) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+        const size_t chunk = (size_t)128 << 20;
+        for (size_t off = 0; off < bytes; off += chunk) {
+            const size_t nb = bytes - off < chunk ? bytes - off : chunk;
+            std::lock_guard<TicketLock> g(h2d_turn);
+            const hipError_t e = hipMemcpyAsync((char*)dst + off, (const char*)src + off, nb, hipMemcpyHostToDevice, st);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
     std::mutex spare_mu;
     Domain* spare_domain = nullptr;   // ntt_domain_give_spare / ntt_domain_take_spare
+    // ... and so do the five vector buffers of the last ONE-SHOT key (groth16.hip): a caller that uploads its key for every proof gets
+    // them back instead of 6-9 GiB of hipMalloc / hipFree per proof (5-200 ms, r06_k)
+    struct SpareVectors {
+        void* p[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        size_t bytes[5] = {0, 0, 0, 0, 0};
+        bool have = false;
+    } spare_vectors;
     std::atomic<bool> profiling{false};
     std::vector<StageRec> stages;
     // reusable device scratch, grown on demand (keyed by purpose)

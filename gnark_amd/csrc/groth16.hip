@@ -80,6 +80,7 @@ struct G16Pk {
         std::mutex mu;
         std::condition_variable cv;
         bool done[GA_KEY_NB_VECTORS] = {false, false, false, false, false};
+        size_t bytes[GA_KEY_NB_VECTORS] = {0, 0, 0, 0, 0};   // allocation sizes (the buffers go back to the context's spare set)
         int rc = GA_OK;
         std::string err;
         std::thread uploader;
@@ -87,12 +88,15 @@ struct G16Pk {
     std::unique_ptr<Pending> pending;
 };
 
+static void trace_event(const char* what, int arg, double extra_ms);
 // the vector `which` of a key is on the device (always true for a key made by ga_g16_pk_create / the builder / a key file)
 static int await_vector(G16Pk* pk, int which) {
     G16Pk::Pending* pd = pk->pending.get();
     if (!pd) return GA_OK;
+    const auto t0 = std::chrono::steady_clock::now();
     std::unique_lock<std::mutex> g(pd->mu);
     pd->cv.wait(g, [&] { return pd->done[which] || pd->rc != GA_OK; });
+    trace_event("MSM waited for vector", which, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     if (pd->rc != GA_OK) {
         set_error("%s", pd->err.c_str());
         return pd->rc;
@@ -125,6 +129,16 @@ struct PkUse {
         return GA_ERR_STATE;                                                     \
     }
 
+// GA_TRACE_PIN=1, process-wide clock: one line per event of a one-shot proof (uploader, waits) on stderr
+static void trace_event(const char* what, int arg, double extra_ms = -1.0) {
+    static const bool on = getenv("GA_TRACE_PIN") != nullptr;
+    static const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    if (!on) return;
+    const double t = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (extra_ms >= 0) fprintf(stderr, "[one-shot] %10.2f ms  %s %d (%.2f ms)\n", t, what, arg, extra_ms);
+    else fprintf(stderr, "[one-shot] %10.2f ms  %s %d\n", t, what, arg);
+}
+
 // GA_TRACE_PIN=1: milestones of a key's way to the device on stderr (ms since the first mark of the calling thread) -- tools/exp
 struct PinTrace {
     bool on;
@@ -149,6 +163,20 @@ static int upload(Ctx* ctx, const void* src, size_t bytes, void** dst) {
 static void pk_free(G16Pk* pk) {
     if (!pk) return;
     if (pk->pending && pk->pending->uploader.joinable()) pk->pending->uploader.join();   // (it writes into the buffers freed below)
+    if (pk->pending && pk->ctx && !pk->tables) {   // a one-shot key: its plain vector buffers stay with the context for the next one
+        const char* e = getenv("GA_DOMAIN_SPARE");
+        Ctx* c = pk->ctx;
+        std::lock_guard<std::mutex> g(c->spare_mu);
+        if (!(e && atoi(e) == 0) && !c->spare_vectors.have) {
+            void** slot[GA_KEY_NB_VECTORS] = {&pk->d_a, &pk->d_b, &pk->d_z, &pk->d_k, &pk->d_b2};
+            for (int w = 0; w < GA_KEY_NB_VECTORS; w++) {
+                c->spare_vectors.p[w] = *slot[w];
+                c->spare_vectors.bytes[w] = pk->pending->bytes[w];
+                *slot[w] = nullptr;
+            }
+            c->spare_vectors.have = true;
+        }
+    }
     if (pk->ctx)
         for (const void* t : {pk->d_a, pk->d_b, pk->d_z, pk->d_k, pk->d_b2}) pk->ctx->forget_table(t);
     hipFree(pk->d_a);
@@ -653,8 +681,31 @@ static int pk_create_from_struct(Ctx* ctx, const ga_g16_key* key, G16Pk** out, b
         set_error("ga_g16_prove_oneshot: the key must be whole (no base-range or window sharding)");
         return GA_ERR_INVALID;
     }
+    size_t alloc_bytes[GA_KEY_NB_VECTORS];
+    for (int w = 0; w < GA_KEY_NB_VECTORS; w++) alloc_bytes[w] = len[w] ? (size_t)len[w] * stage_point_bytes(key->curve, w) : 16;
+    if (defer_uploads) {   // the buffers of the previous one-shot key, when they have the sizes this one needs
+        std::lock_guard<std::mutex> g(ctx->spare_mu);
+        Ctx::SpareVectors& sp = ctx->spare_vectors;
+        if (sp.have) {
+            bool fits = true;
+            for (int w = 0; w < GA_KEY_NB_VECTORS; w++) fits = fits && sp.bytes[w] == alloc_bytes[w];
+            for (int w = 0; w < GA_KEY_NB_VECTORS; w++) {
+                if (fits) {
+                    G16Stage::Vec& x = st.v[w];
+                    x.d = sp.p[w];
+                    x.total = x.cnt = len[w];
+                    x.lo = 0;
+                    x.reserved = true;
+                } else {
+                    hipFree(sp.p[w]);
+                }
+                sp.p[w] = nullptr;
+            }
+            sp.have = false;
+        }
+    }
     for (int w = 0; w < GA_KEY_NB_VECTORS; w++) {
-        GA_CHECK(stage_reserve(&st, w, len[w]));
+        if (!st.v[w].reserved) GA_CHECK(stage_reserve(&st, w, len[w]));
         if (defer_uploads) st.v[w].seen = st.v[w].total;   // (the uploader below fills the buffer)
         else GA_CHECK(stage_append(&st, w, vec[w], len[w], /*pinned=*/true));   // one drain below instead of five
         tr.mark("vector reserved + appended");
@@ -672,6 +723,7 @@ static int pk_create_from_struct(Ctx* ctx, const ga_g16_key* key, G16Pk** out, b
     if (defer_uploads) {
         pk->pending.reset(new G16Pk::Pending());
         G16Pk::Pending* pd = pk->pending.get();
+        for (int w = 0; w < GA_KEY_NB_VECTORS; w++) pd->bytes[w] = alloc_bytes[w];
         // in the order the proof consumes them: A, B (G1), B (G2), K on the witness lane, Z last (it waits for h anyway)
         struct Job { int which; void* dst; const void* src; size_t bytes; };
         std::vector<Job> jobs;
@@ -679,7 +731,7 @@ static int pk_create_from_struct(Ctx* ctx, const ga_g16_key* key, G16Pk** out, b
         for (int w : {GA_KEY_G1_A, GA_KEY_G1_B, GA_KEY_G2_B, GA_KEY_G1_K, GA_KEY_G1_Z})
             jobs.push_back(Job{w, dst[w], vec[w], (size_t)len[w] * stage_point_bytes(key->curve, w)});
         const int device = ctx->device;
-        pd->uploader = std::thread([pd, jobs, device]() {
+        pd->uploader = std::thread([pd, jobs, device, ctx]() {
             int rc = GA_OK;
             std::string err;
             hipStream_t up = nullptr;
@@ -690,7 +742,7 @@ static int pk_create_from_struct(Ctx* ctx, const ga_g16_key* key, G16Pk** out, b
                 }
                 for (const Job& j : jobs) {
                     if (rc != GA_OK) break;
-                    hipError_t e = j.bytes ? hipMemcpyAsync(j.dst, j.src, j.bytes, hipMemcpyHostToDevice, up) : hipSuccess;
+                    hipError_t e = j.bytes ? ctx->h2d_pageable(j.dst, j.src, j.bytes, up) : hipSuccess;
                     if (e == hipSuccess) e = hipStreamSynchronize(up);
                     std::lock_guard<std::mutex> g(pd->mu);
                     if (e != hipSuccess) {
@@ -699,6 +751,7 @@ static int pk_create_from_struct(Ctx* ctx, const ga_g16_key* key, G16Pk** out, b
                     } else {
                         pd->done[j.which] = true;
                         pd->cv.notify_all();
+                        trace_event("uploaded vector", j.which);
                     }
                 }
             } catch (...) {   // (an exception leaving a thread function terminates the process)
@@ -1178,7 +1231,7 @@ static int witness_upload(G16Pk* pk, const SlotLease& slot, const void* w, uint6
     if (lo > hi) lo = hi;
     // (timed only on the main stream: a staging thread runs outside the device lock that guards the profiler's stage list)
     StageTimer tm(up_stream == ctx->work_stream() ? ctx : nullptr, "g16_h2d_w", up_stream);
-    if (hi > lo) GA_HIP_CHECK(hipMemcpyAsync((char*)d_w + lo * 32, (const char*)w + lo * 32, (hi - lo) * 32, hipMemcpyHostToDevice, up_stream));
+    if (hi > lo) GA_HIP_CHECK(ctx->h2d_pageable((char*)d_w + lo * 32, (const char*)w + lo * 32, (hi - lo) * 32, up_stream));
     return GA_OK;
 }
 
@@ -1407,7 +1460,7 @@ static int h_upload(G16Pk* pk, const void* v, uint64_t n_constraints, void* d_v,
         set_error("prove: %llu constraints exceed the domain cardinality %llu", (unsigned long long)n_constraints, (unsigned long long)n);
         return GA_ERR_INVALID;
     }
-    GA_HIP_CHECK(hipMemcpyAsync(d_v, v, n_constraints * 32, hipMemcpyHostToDevice, up_stream));
+    GA_HIP_CHECK(pk->ctx->h2d_pageable(d_v, v, n_constraints * 32, up_stream));
     if (n > n_constraints)   // computeH pads to the domain size (prove.go:356-359)
         GA_HIP_CHECK(hipMemsetAsync((char*)d_v + n_constraints * 32, 0, (n - n_constraints) * 32, up_stream));
     return GA_OK;
@@ -2717,6 +2770,12 @@ int ga_g16_prove_oneshot(ga_ctx* h, const ga_g16_key* key, const void* w, const 
         set_error("ga_g16_prove_oneshot: null argument");
         return GA_ERR_INVALID;
     }
+    trace_event("ga_g16_prove_oneshot", 0);
+    struct InFlight {   // pageable uploads of this context take turns while the key is on its way (common.hip.h)
+        Ctx* c;
+        explicit InFlight(Ctx* x) : c(x) { c->oneshot_inflight++; }
+        ~InFlight() { c->oneshot_inflight--; }
+    } inflight(ctx);
     G16Pk* pk = nullptr;
     {
         CtxLock g(ctx);
@@ -2724,9 +2783,15 @@ int ga_g16_prove_oneshot(ga_ctx* h, const ga_g16_key* key, const void* w, const 
     }
     struct Drop {   // whatever happens below, the uploader is joined and the key freed before the host vectors go out of scope
         G16Pk* pk;
-        ~Drop() { pk_destroy_impl(pk); }
+        ~Drop() {
+            pk_destroy_impl(pk);
+            trace_event("key dropped", 0);
+        }
     } drop{pk};
-    return g16_prove_impl(reinterpret_cast<ga_g16_pk*>(pk), w, a, b, c, n_constraints, nb_public, r, s, proof_out);
+    trace_event("key reserved, uploader started", 0);
+    const int rc = g16_prove_impl(reinterpret_cast<ga_g16_pk*>(pk), w, a, b, c, n_constraints, nb_public, r, s, proof_out);
+    trace_event("proof done", rc);
+    return rc;
 } GA_ABI_CATCH
 int ga_g16_prove_partial(ga_g16_pk* p, const void* w, const void* a, const void* b, const void* c, uint64_t n_constraints,
                          uint64_t nb_public, void* partials_out) try {
