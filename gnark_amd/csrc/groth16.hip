@@ -250,6 +250,7 @@ struct G16Stage {
     std::vector<void*> d_ck_basis, d_ck_sigma;
     std::vector<uint64_t> ck_len;
     std::vector<uint64_t> k_remove;
+    std::thread* early_uploader = nullptr;       // one-shot keys: the thread already filling the vectors' buffers (pk_create_from_struct)
     ~G16Stage() {
         for (auto& L : lists)
             if (L.job.joinable()) L.job.join();
@@ -587,6 +588,7 @@ static int stage_finish(G16Stage* st, int precompute, G16Pk** out) {
         pk->tab_a = pk->tab_b = pk->tab_k = pk->tab_z = pk->tab_b2 = false;
     }
     if (rc != GA_OK) {
+        if (st->early_uploader && st->early_uploader->joinable()) st->early_uploader->join();   // (it writes into the buffers pk_free frees)
         pk_free(pk);
         return rc;
     }
@@ -712,22 +714,25 @@ static int pk_create_from_struct(Ctx* ctx, const ga_g16_key* key, G16Pk** out, b
     }
     GA_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     tr.mark("uploads drained");
-    const void* pt[GA_KEY_NB_POINTS] = {key->g1_alpha, key->g1_beta, key->g1_delta, key->g2_beta, key->g2_delta};
-    for (int q = 0; q < GA_KEY_NB_POINTS; q++) GA_CHECK(stage_set_point(&st, q, pt[q]));
-    for (uint32_t i = 0; i < key->nb_commitments; i++) GA_CHECK(stage_add_commitment_key(&st, key->ck_basis[i], key->ck_basis_exp_sigma[i], key->ck_len[i]));
-    if (key->len_k_remove) st.k_remove.assign(key->k_remove, key->k_remove + key->len_k_remove);
-    tr.mark("points, infinity masks, commitment keys staged");
-    G16Pk* pk = nullptr;
-    GA_DISPATCH_CURVE(key->curve, GA_CHECK(stage_finish<C>(&st, defer_uploads ? -1 : key->precompute, &pk)));
-    tr.mark("stage_finish");
+    // one-shot: the uploader starts NOW, on the buffers just reserved -- the masks, gather lists and domain below (30-40 ms at 2^24)
+    // are built while the first vector is already on its way
+    std::unique_ptr<G16Pk::Pending> pending;
+    struct JoinOnError {   // an error return below must not free the buffers (G16Stage's destructor) under a running uploader
+        G16Pk::Pending* pd = nullptr;
+        ~JoinOnError() {
+            if (pd && pd->uploader.joinable()) pd->uploader.join();
+        }
+    } join_on_error;
     if (defer_uploads) {
-        pk->pending.reset(new G16Pk::Pending());
-        G16Pk::Pending* pd = pk->pending.get();
+        pending.reset(new G16Pk::Pending());
+        G16Pk::Pending* pd = pending.get();
+        join_on_error.pd = pd;
+        st.early_uploader = &pd->uploader;
         for (int w = 0; w < GA_KEY_NB_VECTORS; w++) pd->bytes[w] = alloc_bytes[w];
         // in the order the proof consumes them: A, B (G1), B (G2), K on the witness lane, Z last (it waits for h anyway)
         struct Job { int which; void* dst; const void* src; size_t bytes; };
         std::vector<Job> jobs;
-        void* const dst[GA_KEY_NB_VECTORS] = {pk->d_a, pk->d_b, pk->d_z, pk->d_k, pk->d_b2};
+        void* const dst[GA_KEY_NB_VECTORS] = {st.v[GA_KEY_G1_A].d, st.v[GA_KEY_G1_B].d, st.v[GA_KEY_G1_Z].d, st.v[GA_KEY_G1_K].d, st.v[GA_KEY_G2_B].d};
         for (int w : {GA_KEY_G1_A, GA_KEY_G1_B, GA_KEY_G2_B, GA_KEY_G1_K, GA_KEY_G1_Z})
             jobs.push_back(Job{w, dst[w], vec[w], (size_t)len[w] * stage_point_bytes(key->curve, w)});
         const int device = ctx->device;
@@ -766,6 +771,19 @@ static int pk_create_from_struct(Ctx* ctx, const ga_g16_key* key, G16Pk** out, b
                 pd->cv.notify_all();
             }
         });
+    }
+
+    const void* pt[GA_KEY_NB_POINTS] = {key->g1_alpha, key->g1_beta, key->g1_delta, key->g2_beta, key->g2_delta};
+    for (int q = 0; q < GA_KEY_NB_POINTS; q++) GA_CHECK(stage_set_point(&st, q, pt[q]));
+    for (uint32_t i = 0; i < key->nb_commitments; i++) GA_CHECK(stage_add_commitment_key(&st, key->ck_basis[i], key->ck_basis_exp_sigma[i], key->ck_len[i]));
+    if (key->len_k_remove) st.k_remove.assign(key->k_remove, key->k_remove + key->len_k_remove);
+    tr.mark("points, infinity masks, commitment keys staged");
+    G16Pk* pk = nullptr;
+    GA_DISPATCH_CURVE(key->curve, GA_CHECK(stage_finish<C>(&st, defer_uploads ? -1 : key->precompute, &pk)));
+    tr.mark("stage_finish");
+    if (defer_uploads) {
+        pk->pending = std::move(pending);   // (the key now owns the uploader: pk_free joins it)
+        join_on_error.pd = nullptr;
     }
     *out = pk;
     return GA_OK;
