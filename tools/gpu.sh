@@ -8,8 +8,9 @@
 #   micro                            ga_microbench: instruction issue rates (burst and sustained), dependency distance x occupancy
 #   bench[:<extra bench.py args>]    python bench.py -> ${TAG}_bench.json  (":--curve bls12-381" etc.; spaces as '+')
 #   bench2                           `python bench.py --gpus 2` as the driver would type it (bench.py launches its ranks): two ranks share this box's GPU, collectives over gloo
-#   stats[:<bench args>]             rocprofv3 --kernel-trace --stats of a short bench -> ${TAG}_kernel_stats.txt
-#   hbm[:<bench args>]               FETCH_SIZE / WRITE_SIZE passes (separate, kernel-trace only) -> ${TAG}_pmc_{FETCH,WRITE}_SIZE.txt
+#   stats[:<bench args>]             rocprofv3 --kernel-trace --stats of the headline leg (bench.py --only-headline) -> ${TAG}_kernel_stats.txt
+#   stats_proof                      the same over a short bench WITH a Groth16 proof (multi-table launches included) -> ${TAG}_kernel_stats_proof.txt
+#   hbm[:<bench args>]               FETCH_SIZE / WRITE_SIZE passes of the headline leg (separate, kernel-trace only) -> ${TAG}_pmc_{FETCH,WRITE}_SIZE.txt
 #   sq:<name>:<driver>               the SQ issue accounting + the wait split (LDS / VMEM / instruction cache) of <driver>:
 #                                    bench | bls (BLS12-381 G1+G2 table MSMs) | bn (BN254 ones) | ntt  -> ${TAG}_sq_<name>_{counters,summary}.txt
 #   ab:<name>:<parts>[:<curve>[:<variant>]]   tools/ab_kernels.py --parts <parts>, on gnark_amd/variants/libgnark_amd_<variant>.so when given
@@ -81,14 +82,22 @@ for step in "$@"; do
       python tools/bench_digest.py $OUT/${TAG}_bench_2ranks_one_gpu_gloo.json ;;
     stats)
       d=$OUT/stats_tmp_$$
-      timeout 900 rocprofv3 --kernel-trace --stats -d $d -o k -- python bench.py $SHORT_BENCH $arg > $OUT/${TAG}_stats.log 2>&1
+      # the HEADLINE leg alone (20 MSM steps): since round 6 a proof launches the bucket kernel once for THREE tables (A, B1, K), so a
+      # profile of the whole short bench would average single- and triple-table launches under one kernel name
+      timeout 900 rocprofv3 --kernel-trace --stats -d $d -o k -- python bench.py --only-headline --steps 20 --warmup 2 ${arg:-} > $OUT/${TAG}_stats.log 2>&1
       python tools/prof_summary.py $d/k_results.db > $OUT/${TAG}_kernel_stats.txt 2>/dev/null
       rm -rf $d
       head -12 $OUT/${TAG}_kernel_stats.txt | cut -c1-200 ;;
+    stats_proof)
+      d=$OUT/stats_tmp_$$
+      timeout 900 rocprofv3 --kernel-trace --stats -d $d -o k -- python bench.py $SHORT_BENCH $arg > $OUT/${TAG}_stats_proof.log 2>&1
+      python tools/prof_summary.py $d/k_results.db > $OUT/${TAG}_kernel_stats_proof.txt 2>/dev/null
+      rm -rf $d
+      head -10 $OUT/${TAG}_kernel_stats_proof.txt | cut -c1-200 ;;
     hbm)
       for ctr in FETCH_SIZE WRITE_SIZE; do
         rm -f $OUT/${TAG}_pmc_${ctr}.txt
-        pmc_pass $OUT/${TAG}_pmc_${ctr}.txt $ctr -- python bench.py $SHORT_BENCH $arg
+        pmc_pass $OUT/${TAG}_pmc_${ctr}.txt $ctr -- python bench.py --only-headline --steps 10 --warmup 2 ${arg:-}
         head -5 $OUT/${TAG}_pmc_${ctr}.txt | cut -c1-170
       done ;;
     sq)
