@@ -649,7 +649,7 @@ def groth16_single_gpu_leg(R, cid, curve_name):
     if os.environ.get("GA_BENCH_ONE_SHOT", "1") != "0":
         try:
             rounds = []
-            for _ in range(3):
+            for _ in range(1 if R.emu else 3):
                 ctx.sync()
                 q0 = time.perf_counter()
                 pk1 = inst.proving_key(ctx, precompute=-1)
@@ -662,7 +662,7 @@ def groth16_single_gpu_leg(R, cid, curve_name):
                 rounds.append(((q3 - q0) * 1e3, (q1 - q0) * 1e3, (q2 - q1) * 1e3, (q3 - q2) * 1e3))
             # ... and the same through ga_g16_prove_oneshot: the key uploaded by a helper thread WHILE the proof runs
             fused = []
-            for _ in range(3):
+            for _ in range(1 if R.emu else 3):
                 ctx.sync()
                 q0 = time.perf_counter()
                 p2 = inst.prove_oneshot(ctx)

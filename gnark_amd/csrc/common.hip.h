@@ -241,30 +241,38 @@ struct Ctx {
     // such copies at once share the link at 24 + 24 GB/s where one alone gets 56 (profiles/r06_j_h2d_concurrency.json).  Otherwise
     // they run as they come: two pinned-key proofs in flight LOSE with the turns (122 -> 131 ms per proof, r06_k).
     std::atomic<int> oneshot_inflight{0};
-    struct TicketLock {
+    // (turns are taken by PRIORITY = the order in which the proof needs the data: W, key A, key B, the solver's A, B, C, key G2.B,
+    // K, Z; equal priorities in arrival order; a copy gives way at 128 MiB boundaries)
+    struct TurnLock {
         std::mutex mu;
         std::condition_variable cv;
-        uint64_t next = 0, serving = 0;
-        void lock() {
+        bool busy = false;
+        uint64_t seq = 0;
+        std::set<std::pair<int, uint64_t>> waiting;
+        void lock(int prio) {
             std::unique_lock<std::mutex> g(mu);
-            const uint64_t my = next++;
-            cv.wait(g, [&] { return serving == my; });
+            const std::pair<int, uint64_t> me(prio, seq++);
+            waiting.insert(me);
+            cv.wait(g, [&] { return !busy && *waiting.begin() == me; });
+            waiting.erase(waiting.begin());
+            busy = true;
         }
         void unlock() {
             {
                 std::lock_guard<std::mutex> g(mu);
-                serving++;
+                busy = false;
             }
             cv.notify_all();
         }
     } h2d_turn;
-    hipError_t h2d_pageable(void* dst, const void* src, size_t bytes, hipStream_t st) {
+    hipError_t h2d_pageable(void* dst, const void* src, size_t bytes, hipStream_t st, int prio = 3) {
         if (oneshot_inflight.load(std::memory_order_relaxed) == 0) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
         const size_t chunk = (size_t)128 << 20;
         for (size_t off = 0; off < bytes; off += chunk) {
             const size_t nb = bytes - off < chunk ? bytes - off : chunk;
-            std::lock_guard<TicketLock> g(h2d_turn);
+            h2d_turn.lock(prio);
             const hipError_t e = hipMemcpyAsync((char*)dst + off, (const char*)src + off, nb, hipMemcpyHostToDevice, st);
+            h2d_turn.unlock();
             if (e != hipSuccess) return e;
         }
         return hipSuccess;

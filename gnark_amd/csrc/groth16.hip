@@ -730,11 +730,15 @@ static int pk_create_from_struct(Ctx* ctx, const ga_g16_key* key, G16Pk** out, b
         st.early_uploader = &pd->uploader;
         for (int w = 0; w < GA_KEY_NB_VECTORS; w++) pd->bytes[w] = alloc_bytes[w];
         // in the order the proof consumes them: A, B (G1), B (G2), K on the witness lane, Z last (it waits for h anyway)
-        struct Job { int which; void* dst; const void* src; size_t bytes; };
+        struct Job { int which; void* dst; const void* src; size_t bytes; int prio; };
         std::vector<Job> jobs;
         void* const dst[GA_KEY_NB_VECTORS] = {st.v[GA_KEY_G1_A].d, st.v[GA_KEY_G1_B].d, st.v[GA_KEY_G1_Z].d, st.v[GA_KEY_G1_K].d, st.v[GA_KEY_G2_B].d};
-        for (int w : {GA_KEY_G1_A, GA_KEY_G1_B, GA_KEY_G2_B, GA_KEY_G1_K, GA_KEY_G1_Z})
-            jobs.push_back(Job{w, dst[w], vec[w], (size_t)len[w] * stage_point_bytes(key->curve, w)});
+        int order = 0;
+        for (int w : {GA_KEY_G1_A, GA_KEY_G1_B, GA_KEY_G2_B, GA_KEY_G1_K, GA_KEY_G1_Z}) {
+            // turn priorities (common.hip.h): W 0 | A 1, B 2 | the solver's A, B, C 3 | G2.B 4, K 5, Z 6
+            static const int prio[5] = {1, 2, 4, 5, 6};
+            jobs.push_back(Job{w, dst[w], vec[w], (size_t)len[w] * stage_point_bytes(key->curve, w), prio[order++]});
+        }
         const int device = ctx->device;
         pd->uploader = std::thread([pd, jobs, device, ctx]() {
             int rc = GA_OK;
@@ -747,7 +751,7 @@ static int pk_create_from_struct(Ctx* ctx, const ga_g16_key* key, G16Pk** out, b
                 }
                 for (const Job& j : jobs) {
                     if (rc != GA_OK) break;
-                    hipError_t e = j.bytes ? ctx->h2d_pageable(j.dst, j.src, j.bytes, up) : hipSuccess;
+                    hipError_t e = j.bytes ? ctx->h2d_pageable(j.dst, j.src, j.bytes, up, j.prio) : hipSuccess;
                     if (e == hipSuccess) e = hipStreamSynchronize(up);
                     std::lock_guard<std::mutex> g(pd->mu);
                     if (e != hipSuccess) {
@@ -1249,7 +1253,7 @@ static int witness_upload(G16Pk* pk, const SlotLease& slot, const void* w, uint6
     if (lo > hi) lo = hi;
     // (timed only on the main stream: a staging thread runs outside the device lock that guards the profiler's stage list)
     StageTimer tm(up_stream == ctx->work_stream() ? ctx : nullptr, "g16_h2d_w", up_stream);
-    if (hi > lo) GA_HIP_CHECK(ctx->h2d_pageable((char*)d_w + lo * 32, (const char*)w + lo * 32, (hi - lo) * 32, up_stream));
+    if (hi > lo) GA_HIP_CHECK(ctx->h2d_pageable((char*)d_w + lo * 32, (const char*)w + lo * 32, (hi - lo) * 32, up_stream, /*prio=*/0));
     return GA_OK;
 }
 

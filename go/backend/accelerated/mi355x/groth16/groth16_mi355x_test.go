@@ -87,7 +87,8 @@ func TestProveVerifiesWithNativeVerifier(t *testing.T) {
 			pw, err := w.Public()
 			assert.NoError(err)
 			for _, opts := range [][]mi355x.Option{
-				nil,
+				nil, // the default: the key is NOT kept on the device -- one call uploads it while the proof runs (ga_g16_prove_oneshot)
+				nil, // ... twice: the second call gets the context's spare buffers and NTT domain back
 				{mi355x.WithPinKeysToGPU(true)},
 				{mi355x.WithPinKeysToGPU(true), mi355x.WithPrecompute(mi355x.PrecomputeNever)},
 			} {
