@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <atomic>
 #include <map>
@@ -270,9 +271,16 @@ struct Ctx {
         const size_t chunk = (size_t)128 << 20;
         for (size_t off = 0; off < bytes; off += chunk) {
             const size_t nb = bytes - off < chunk ? bytes - off : chunk;
+            static const bool trace = getenv("GA_TRACE_H2D") != nullptr;
+            const auto t0 = std::chrono::steady_clock::now();
             h2d_turn.lock(prio);
+            const auto t1 = std::chrono::steady_clock::now();
             const hipError_t e = hipMemcpyAsync((char*)dst + off, (const char*)src + off, nb, hipMemcpyHostToDevice, st);
             h2d_turn.unlock();
+            if (trace)
+                fprintf(stderr, "[h2d] prio %d chunk %zu: waited %.2f ms, copy call %.2f ms\n", prio, off / chunk,
+                        std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
             if (e != hipSuccess) return e;
         }
         return hipSuccess;

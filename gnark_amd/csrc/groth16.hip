@@ -75,12 +75,20 @@ struct G16Pk {
     bool dying = false;
     // A key whose base vectors are still ON THEIR WAY (ga_g16_prove_oneshot: the key goes up as plain vectors, is used for ONE proof
     // and dropped -- the Go package's default, PinToGPU = false): an uploader thread copies them in the order the proof consumes
-    // them (A, B, G2.B, K, Z) while the proof already runs; an MSM waits for ITS vector (await_vector), not for the key.
+    // them (A, B, K, G2.B, Z) while the proof already runs; an MSM waits for ITS vector (await_vector), not for the key.
     struct Pending {
         std::mutex mu;
         std::condition_variable cv;
         bool done[GA_KEY_NB_VECTORS] = {false, false, false, false, false};
         size_t bytes[GA_KEY_NB_VECTORS] = {0, 0, 0, 0, 0};   // allocation sizes (the buffers go back to the context's spare set)
+        // recorded on the uploader's stream behind a vector's copies: the consumer's STREAM waits for it (hipStreamWaitEvent), no host
+        // thread does -- a hipStreamSynchronize of the upload stream was seen to return only when another thread's wait for a 54 ms
+        // bucket kernel did (profiles/r06_h_oneshot_timeline.txt)
+        hipEvent_t ev[GA_KEY_NB_VECTORS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        ~Pending() {
+            for (hipEvent_t e : ev)
+                if (e) hipEventDestroy(e);
+        }
         int rc = GA_OK;
         std::string err;
         std::thread uploader;
@@ -101,6 +109,8 @@ static int await_vector(G16Pk* pk, int which) {
         set_error("%s", pd->err.c_str());
         return pd->rc;
     }
+    g.unlock();
+    GA_HIP_CHECK(hipStreamWaitEvent(pk->ctx->work_stream(), pd->ev[which], 0));   // the MSM about to be launched on this lane starts behind the copies
     return GA_OK;
 }
 
@@ -728,14 +738,19 @@ static int pk_create_from_struct(Ctx* ctx, const ga_g16_key* key, G16Pk** out, b
         G16Pk::Pending* pd = pending.get();
         join_on_error.pd = pd;
         st.early_uploader = &pd->uploader;
-        for (int w = 0; w < GA_KEY_NB_VECTORS; w++) pd->bytes[w] = alloc_bytes[w];
-        // in the order the proof consumes them: A, B (G1), B (G2), K on the witness lane, Z last (it waits for h anyway)
+        for (int w = 0; w < GA_KEY_NB_VECTORS; w++) {
+            pd->bytes[w] = alloc_bytes[w];
+            GA_HIP_CHECK(hipEventCreateWithFlags(&pd->ev[w], hipEventDisableTiming));
+        }
+        // in the order the proof consumes them: A, B, K (G1), B (G2) on the witness lane, Z last (it waits for h anyway)
         struct Job { int which; void* dst; const void* src; size_t bytes; int prio; };
         std::vector<Job> jobs;
         void* const dst[GA_KEY_NB_VECTORS] = {st.v[GA_KEY_G1_A].d, st.v[GA_KEY_G1_B].d, st.v[GA_KEY_G1_Z].d, st.v[GA_KEY_G1_K].d, st.v[GA_KEY_G2_B].d};
         int order = 0;
-        for (int w : {GA_KEY_G1_A, GA_KEY_G1_B, GA_KEY_G2_B, GA_KEY_G1_K, GA_KEY_G1_Z}) {
-            // turn priorities (common.hip.h): W 0 | A 1, B 2 | the solver's A, B, C 3 | G2.B 4, K 5, Z 6
+        for (int w : {GA_KEY_G1_A, GA_KEY_G1_B, GA_KEY_G1_K, GA_KEY_G2_B, GA_KEY_G1_Z}) {
+            // turn priorities (common.hip.h): W 0 | A 1, B 2 | the solver's A, B, C 3 | K 4, G2.B 5, Z 6.  (K before G2.B, and its MSM
+            // before G2.B's in witness_msms: copies make little progress while the G2 bucket kernel runs -- 2 GiB in 72 ms where
+            // they take 38 -- so as much as possible is on the device before that kernel starts)
             static const int prio[5] = {1, 2, 4, 5, 6};
             jobs.push_back(Job{w, dst[w], vec[w], (size_t)len[w] * stage_point_bytes(key->curve, w), prio[order++]});
         }
@@ -752,7 +767,7 @@ static int pk_create_from_struct(Ctx* ctx, const ga_g16_key* key, G16Pk** out, b
                 for (const Job& j : jobs) {
                     if (rc != GA_OK) break;
                     hipError_t e = j.bytes ? ctx->h2d_pageable(j.dst, j.src, j.bytes, up, j.prio) : hipSuccess;
-                    if (e == hipSuccess) e = hipStreamSynchronize(up);
+                    if (e == hipSuccess) e = hipEventRecord(pd->ev[j.which], up);
                     std::lock_guard<std::mutex> g(pd->mu);
                     if (e != hipSuccess) {
                         rc = GA_ERR_HIP;
@@ -767,7 +782,13 @@ static int pk_create_from_struct(Ctx* ctx, const ga_g16_key* key, G16Pk** out, b
                 rc = GA_ERR_STATE;
                 err = "one-shot key upload: exception in the uploader thread";
             }
-            if (up) hipStreamDestroy(up);
+            if (up) {   // the host vectors may be released once this thread has been joined: every copy must have left them
+                if (hipStreamSynchronize(up) != hipSuccess && rc == GA_OK) {
+                    rc = GA_ERR_HIP;
+                    err = "one-shot key upload: stream synchronize failed";
+                }
+                hipStreamDestroy(up);
+            }
             if (rc != GA_OK) {
                 std::lock_guard<std::mutex> g(pd->mu);
                 pd->rc = rc;
@@ -1447,6 +1468,10 @@ static int witness_msms(G16Pk* pk, const SlotLease& slot, uint64_t nb_public, Wi
         else {
             GA_CHECK(await_vector(pk, GA_KEY_G1_B));
             GA_CHECK((host_msm<C, GA_G1>(ctx, pk->d_b, d_wb, pk->len_b, true, &bs1, pk->win_index, pk->win_count)));
+        }
+        if (pk->pending && !*did_k && sh.claim_k(current_lane())) {   // a key still on its way: K's MSM before G2.B's (upload order)
+            GA_CHECK(k_msm<C>(pk, nb_public, sh, o_k));
+            *did_k = true;
         }
         if (pk->share_b2) {   // G2.B wire-indexed: the shared witness sort again
             if (sh.w_live) GA_CHECK((msm_table_device_reuse<C, GA_G2>(ctx, pk->d_b2, sh.prep_w, &bs2)));
@@ -2780,7 +2805,7 @@ int ga_g16_prove(ga_g16_pk* p, const void* w, const void* a, const void* b, cons
     return g16_prove_impl(p, w, a, b, c, n_constraints, nb_public, r, s, proof_out);
 } GA_ABI_CATCH
 // One proof on a key that is NOT kept on the device (the Go package's default, PinToGPU = false, as icicle.go:797-805): the key
-// goes up as plain vectors WHILE the proof runs -- the uploader thread of pk_create_from_struct copies A, B, G2.B, K, Z in the order
+// goes up as plain vectors WHILE the proof runs -- the uploader thread of pk_create_from_struct copies A, B, K, G2.B, Z in the order
 // the MSMs consume them, every MSM waits for its own vector only -- and is dropped afterwards.  Same proof bytes as
 // ga_g16_pk_create(precompute = -1) + ga_g16_prove + ga_g16_pk_destroy, in about the time of the longer of the two (PCIe, device)
 // instead of their sum.  No host pointer is used after the call returns (the uploader is joined before the key is freed).
