@@ -463,6 +463,14 @@ static int stage_finish(G16Stage* st, int precompute, G16Pk** out) {
     tr.mark("finish: gather lists uploaded, stream drained");
     // ---- optional precomputation: [2^(c*w)]P for every window (one shared bucket set per MSM afterwards) ----------
     if (rc == GA_OK && precompute >= 0) {
+        {   // a key that is here to stay: the buffers kept for one-shot keys (6-9 GiB) go back to the device before the tables are sized
+            std::lock_guard<std::mutex> g(ctx->spare_mu);
+            for (void*& q : ctx->spare_vectors.p) {
+                hipFree(q);
+                q = nullptr;
+            }
+            ctx->spare_vectors.have = false;
+        }
         int nw = 0;
         const size_t t1 = msm_table_point_bytes<C, GA_G1>(), t2 = msm_table_point_bytes<C, GA_G2>();
         // share the witness sort between the vectors that cover at least GA_G16_SHARE_MIN_PCT % of the wires (default 90: a
