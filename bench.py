@@ -91,6 +91,12 @@ def effective_cores():
     return eff, n, quota
 
 
+def rate(x):
+    """a throughput for the JSON line: three decimals, more for the tiny figures of an emulation dry run (2^9 pairs in a second must
+    not round to 0)"""
+    return round(x, 3) if x >= 1 else float("%.3g" % x)
+
+
 def stage_stats(records):
     agg = {}
     for name, ms in records:
@@ -427,7 +433,7 @@ def headline_leg(R):
         out["error"] = "headline MSM skipped on every rank: " + res["error"]
         return out, None
     ti = res["table_info"]
-    out["value"] = round(n * args.steps / res["elapsed_s"] / 1e6, 3)
+    out["value"] = rate(n * args.steps / res["elapsed_s"] / 1e6)
     out["ms_per_step"] = round(res["ms_per_step"], 4)
     out["value_checked"] = res["value_checked"]
     out["config"].update({"window_bits": res["window_bits"], "windows": res["windows"],
@@ -507,7 +513,7 @@ def weak_msm_leg(R):
     free_keep(keep)
     if "error" in res:
         return {"error": "skipped on every rank: " + res["error"]}
-    return {"value": round(R.world * n * args.steps / res["elapsed_s"] / 1e6, 3), "unit": "Mscalar-mul/s", "scaling": "weak",
+    return {"value": rate(R.world * n * args.steps / res["elapsed_s"] / 1e6), "unit": "Mscalar-mul/s", "scaling": "weak",
             "ms_per_step": round(res["ms_per_step"], 4), "value_checked": res["value_checked"], "pairs_per_gpu": n,
             "how": "every rank its own 2^%d pairs (base-range partition of a %d x 2^%d problem), one all_gather of a Jacobian point per step" % (args.log_n, R.world, args.log_n)}
 
@@ -1026,9 +1032,9 @@ def cpu_baseline_leg(R, out, msm_only=False):
     cbits, nwin_f, splits = oracle.msm_fast_plan(cid, sn, eff_cores)
     threads_used = min(eff_cores, nwin_f * splits)          # (window x point-range) tasks on a thread pool: every usable core works
     threads_simple = min(eff_cores, oracle.msm_windows(cid, sn))   # the simple port runs one thread per Pippenger window
-    out["cpu_baseline"] = {"value": round(sn / cpu_s / 1e6, 4), "unit": "Mscalar-mul/s", "cores": threads_used, "threads_used": threads_used,
+    out["cpu_baseline"] = {"value": rate(sn / cpu_s / 1e6) if sn / cpu_s < 1e6 else round(sn / cpu_s / 1e6, 4), "unit": "Mscalar-mul/s", "cores": threads_used, "threads_used": threads_used,
                            "effective_cores": eff_cores, "logical_cpus": logical_cpus, "cgroup_cpu_quota": quota, "host_cores": logical_cpus, "kind": "port-batch-affine",
-                           "value_simple": round(sn / cpu_simple_s / 1e6, 4) if cpu_simple_s else None, "cores_simple": threads_simple,
+                           "value_simple": rate(sn / cpu_simple_s / 1e6) if cpu_simple_s else None, "cores_simple": threads_simple,
                            "speedup_over_simple": round(cpu_simple_s / cpu_s, 2) if cpu_simple_s else None,
                            "sample": "%s G1 MSM of 2^%d points, oracle/msm_fast.c: signed %d-bit digits, batch-affine buckets, %d windows x %d point ranges on %d threads, %.1f s%s" % (
                                args.curve.upper(), sample_log, cbits, nwin_f, splits, threads_used, cpu_s,
