@@ -292,6 +292,64 @@ int main(void) {
         printf("un-pinned key: %llu bytes of plain vectors, HBM delta on pin %lld, after destroy %lld\n", (unsigned long long)plain,
                (long long)(free0 - free1), (long long)(free0 - free2));
     }
+    /* ---- ... and the same default as ONE call (round 6, what mi355x.go proveOneShot does): ga_g16_prove_oneshot with the ga_g16_key in C
+     * heap, every array it points to and the whole solution private copies that are poisoned the moment the call returns -- the key
+     * goes up while the proof runs, so a pointer used after the return would read 0xA5 garbage -- twice (the second call takes the
+     * context's spare buffers and NTT domain), same bytes as the pinned proof. */
+    for (int round = 0; round < 2; round++) {
+        ga_g16_key* key = calloc(1, sizeof *key);
+        const size_t bytes[5] = {k.len_a * 64, k.len_b * 64, k.len_z * 64, k.len_k * 64, k.len_b * 128};
+        const void* src[5] = {k.A, k.B, k.Z, k.K, k.B2};
+        void* cp[5];
+        for (int w = 0; w < 5; w++) {
+            cp[w] = malloc(bytes[w]);
+            memcpy(cp[w], src[w], bytes[w]);
+        }
+        uint8_t *ia = malloc(k.nw), *ib = malloc(k.nw);
+        memcpy(ia, k.inf_a, k.nw);
+        memcpy(ib, k.inf_b, k.nw);
+        key->curve = GA_BN254;
+        key->domain_cardinality = k.n;
+        key->g1_alpha = k.misc1;
+        key->g1_beta = (const char*)k.misc1 + 64;
+        key->g1_delta = (const char*)k.misc1 + 128;
+        key->g1_a = cp[0]; key->len_a = k.len_a;
+        key->g1_b = cp[1]; key->len_b = k.len_b;
+        key->g1_z = cp[2]; key->len_z = k.len_z;
+        key->g1_k = cp[3]; key->len_k = k.len_k;
+        key->g2_beta = k.misc2;
+        key->g2_delta = (const char*)k.misc2 + 128;
+        key->g2_b = cp[4]; key->len_b2 = k.len_b;
+        key->infinity_a = ia;
+        key->infinity_b = ib;
+        key->nb_wires = k.nw;
+        key->nb_infinity_a = 2;
+        key->nb_infinity_b = 2;
+        key->precompute = 1;   /* ignored: a one-shot key is plain vectors */
+        const size_t bw = s.nw * 32, bc = s.n * 32;
+        void *w = malloc(bw), *a = malloc(bc), *b = malloc(bc), *c = malloc(bc);
+        memcpy(w, s.W, bw);
+        memcpy(a, s.A, bc);
+        memcpy(b, s.B, bc);
+        memcpy(c, s.C, bc);
+        uint64_t p6[32];
+        CHECK(ga_g16_prove_oneshot(ctx, key, w, a, b, c, s.n, s.nb_public, s.rs, (const char*)s.rs + 32, p6));
+        for (int v = 0; v < 5; v++) {
+            memset(cp[v], 0xA5, bytes[v]);
+            free(cp[v]);
+        }
+        memset(ia, 0xA5, k.nw); memset(ib, 0xA5, k.nw);
+        free(ia); free(ib);
+        memset(w, 0xA5, bw); memset(a, 0xA5, bc); memset(b, 0xA5, bc); memset(c, 0xA5, bc);
+        free(w); free(a); free(b); free(c);
+        memset(key, 0xA5, sizeof *key);
+        free(key);
+        if (memcmp(p6, p1, sizeof p1)) {
+            fprintf(stderr, "ga_g16_prove_oneshot (round %d) proves to different bytes\n", round);
+            return 1;
+        }
+    }
+    printf("ga_g16_prove_oneshot: same proof bytes, twice\n");
     /* ---- FreeGPUResources from one thread while another is still proving on the key (a Go `defer pk.FreeGPUResources()` beside a
      * second goroutine's Prove): ga_g16_pk_destroy waits for the proof in flight; a call that arrives after the key started dying is
      * refused with GA_ERR_STATE instead of touching freed memory ---- */
