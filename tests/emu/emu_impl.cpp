@@ -8,6 +8,49 @@ namespace hipemu {
 
 static constexpr size_t STACK_BYTES = 512 * 1024;
 
+#ifdef HIPEMU_ASM_SWITCH
+// void hipemu_switch(void** save_sp, void* load_sp): the System V callee-saved registers go on the current stack, its pointer is
+// stored, the other stack's registers are popped and `ret` continues where that stack last called hipemu_switch (or, for a fresh
+// fiber, at the trampoline whose address fiber_init put there).
+extern "C" void hipemu_switch(void** save_sp, void* load_sp);
+asm(R"(
+    .text
+    .globl hipemu_switch
+    .type hipemu_switch,@function
+hipemu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size hipemu_switch,.-hipemu_switch
+)");
+static void trampoline();
+static void* fiber_init(char* stack) {
+    uintptr_t top = ((uintptr_t)stack + STACK_BYTES) & ~(uintptr_t)15;
+    uint64_t* p = (uint64_t*)top;
+    *--p = 0;                        // where a return address would be: the trampoline never returns (rsp = 8 mod 16 at its entry)
+    *--p = (uint64_t)&trampoline;    // popped by hipemu_switch's ret
+    for (int i = 0; i < 6; i++) *--p = 0;   // rbp, rbx, r12..r15
+    return p;
+}
+#define HIPEMU_TO_SCHED(f, b) hipemu_switch(&(f).sp, (b)->sched_sp)
+#define HIPEMU_TO_FIBER(b, f) hipemu_switch(&(b)->sched_sp, (f).sp)
+#else
+#define HIPEMU_TO_SCHED(f, b) swapcontext(&(f).ctx, &(b)->sched)
+#define HIPEMU_TO_FIBER(b, f) swapcontext(&(b)->sched, &(f).ctx)
+#endif
+
 static void release_block(Block* b) {
     for (auto& f : b->fibers)
         if (f.state == 1) f.state = 0;
@@ -27,7 +70,7 @@ void block_barrier() {
         return;
     }
     f.state = 1;
-    swapcontext(&f.ctx, &b->sched);
+    HIPEMU_TO_SCHED(f, b);
 }
 
 void wave_barrier() {
@@ -39,7 +82,7 @@ void wave_barrier() {
         return;
     }
     f.state = 2;
-    swapcontext(&f.ctx, &b->sched);
+    HIPEMU_TO_SCHED(f, b);
 }
 
 static void trampoline() {
@@ -52,7 +95,7 @@ static void trampoline() {
     b->waves[w].live--;
     if (b->live > 0 && b->arrived == b->live) release_block(b);
     if (b->waves[w].live > 0 && b->waves[w].arrived == b->waves[w].live) release_wave(b, w);
-    swapcontext(&b->fibers[t].ctx, &b->sched);   // never resumed
+    HIPEMU_TO_SCHED(b->fibers[t], b);   // never resumed
 }
 
 void run_block(unsigned nthreads, size_t shmem, dim3 block_dim, dim3 grid_dim, Idx block_idx, const std::function<void()>& body) {
@@ -84,11 +127,15 @@ void run_block(unsigned nthreads, size_t shmem, dim3 block_dim, dim3 grid_dim, I
                 abort();
             }
         }
+#ifdef HIPEMU_ASM_SWITCH
+        f.sp = fiber_init(f.stack);
+#else
         getcontext(&f.ctx);
         f.ctx.uc_stack.ss_sp = f.stack;
         f.ctx.uc_stack.ss_size = STACK_BYTES;
         f.ctx.uc_link = nullptr;
         makecontext(&f.ctx, trampoline, 0);
+#endif
         f.state = 0;
     }
     unsigned done = 0;
@@ -99,7 +146,7 @@ void run_block(unsigned nthreads, size_t shmem, dim3 block_dim, dim3 grid_dim, I
             if (f.state != 0) continue;
             b->cur = t;
             set_tid(t);
-            swapcontext(&b->sched, &f.ctx);
+            HIPEMU_TO_FIBER(b, f);
             progress = true;
             if (f.state == 3) done++;
         }

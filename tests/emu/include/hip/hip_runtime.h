@@ -58,8 +58,15 @@ struct Wave {
     uint64_t scratch[64];
     unsigned live = 0, arrived = 0;
 };
+// Switching fibers: glibc's swapcontext saves and restores the signal mask -- two system calls per switch, a third of the CPU suite's
+// time in the kernel -- so, outside AddressSanitizer builds (whose stack bookkeeping follows ucontext), a fiber is a saved stack
+// pointer and a switch is hipemu_switch (emu_impl.cpp): push the callee-saved registers, swap rsp, pop, ret.
+#if defined(__x86_64__) && !defined(__SANITIZE_ADDRESS__) && !defined(HIPEMU_UCONTEXT)
+#define HIPEMU_ASM_SWITCH 1
+#endif
 struct Fiber {
     ucontext_t ctx;
+    void* sp = nullptr;   // HIPEMU_ASM_SWITCH: the fiber's saved stack pointer
     int state = 3;   // 0 runnable, 1 parked at the block barrier, 2 parked at its wave barrier, 3 finished
     char* stack = nullptr;
 };
@@ -70,6 +77,7 @@ struct Idx {
 struct Block {
     std::vector<Fiber> fibers;
     ucontext_t sched;
+    void* sched_sp = nullptr;   // HIPEMU_ASM_SWITCH: the scheduler's saved stack pointer
     unsigned cur = 0, nthreads = 0, live = 0, arrived = 0;
     std::vector<Wave> waves;
     std::vector<char> smem;
